@@ -1,0 +1,198 @@
+/*
+ * pps.h -- C-ABI of the MI355X-native plane-SLAM backend (libpps.so).
+ *
+ * One opaque handle `pps_graph` replaces, wholesale, the three seams the
+ * reference exposes for this path (paths relative to
+ * /root/reference/pop_planar_slam):
+ *   - isam::Slam public API            Thirdparty/isam/include/isam/Slam.h:82-215
+ *   - isam::OptimizationInterface      Thirdparty/isam/include/isam/OptimizationInterface.h:224-245
+ *   - isam::Cholesky (solver plugin)   Thirdparty/isam/include/isam/Cholesky.h:148-178
+ * plus the popup_plane statics the mapper calls
+ *   - update_plane_equation_from_seg   /root/reference/pop_up_wall/include/pop_up_wall/popup_plane.h:137-139
+ *   - generate_cloud / get_depth_map_good  popup_plane.h:142-143,155-157
+ *
+ * Everything is plain pointers and sizes; no C++/torch types.  All functions
+ * return a status (PPS_OK == 0) and never exit()/abort() (the reference's
+ * require() does: Thirdparty/isam/include/isam/util.h:174-184).
+ *
+ * Conventions
+ *   quaternion  (x,y,z,w)                      -- Eigen coeffs() order
+ *   pose        (tx,ty,tz,qx,qy,qz,qw)         -- isam::Pose3d (Pose3d.h:70-274)
+ *   plane       unit 4-vector (a,b,c,d)        -- isam::Plane3d (src/isam_plane3d.h:27-193)
+ *   meas6       (x,y,z,yaw,pitch,roll)         -- Pose3d::vector() (Pose3d.h:138-145)
+ *   sqrtinf_ut  packed upper triangle, row-major (Factor.h:169-190): 21 (6x6) / 6 (3x3)
+ *   ids         handle-local integers starting at 0 (the reference uses
+ *               process-global counters, Slam.cpp:47-48)
+ *
+ * Threading: one handle = one device + one HIP stream; distinct handles may be
+ * driven from distinct host threads.  No global mutable state.
+ */
+#ifndef PPS_H
+#define PPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPS_VERSION 100
+
+typedef struct pps_graph pps_graph;
+
+enum pps_status {
+  PPS_OK = 0,
+  PPS_EINVAL = 1,     /* bad argument / unknown id                                   */
+  PPS_ENOTPD = 2,     /* normal equations not positive definite (silent in CHOLMOD)  */
+  PPS_EHIP = 3,       /* HIP runtime error (no device, OOM, launch failure)          */
+  PPS_ENOMEM = 4,
+  PPS_ESTATE = 5      /* operation not valid in the current state                    */
+};
+
+/* Jacobian evaluation mode of the per-edge sweep */
+enum pps_jacobian_mode {
+  PPS_JAC_NUMERIC = 0,   /* central differences, eps = 1e-4, through exmap: numericalDiff.cpp:32-87 (reference behaviour) */
+  PPS_JAC_ANALYTIC = 1   /* closed-form derivative of the same residuals */
+};
+
+/* Mirrors isam::Properties (Properties.h:37-110); defaults = the app's values (Mapping.cpp:32-43). */
+typedef struct pps_props {
+  double epsilon2;          /* 1e-3 : stop when ||delta|| <= epsilon2                  */
+  double epsilon_abs;       /* 1e-4 : stop when chi2 <= epsilon_abs                    */
+  double epsilon_rel;       /* 1e-6 : stop when improvement < epsilon_rel * chi2       */
+  int    max_iterations;    /* 500                                                      */
+  double lm_lambda0;        /* 1e-6                                                     */
+  double lm_lambda_factor;  /* 10                                                       */
+  int    jacobian_mode;     /* enum pps_jacobian_mode, default PPS_JAC_NUMERIC          */
+  int    device;            /* HIP device ordinal, default 0                            */
+  int    verbose;           /* 0 = quiet (prop.quiet = true, Mapping.cpp:35)            */
+} pps_props;
+
+void pps_default_props(pps_props* p);
+int  pps_version(void);
+const char* pps_last_error(const pps_graph* g);      /* thread-compatible, handle-local */
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+int pps_graph_create(const pps_props* props, pps_graph** out);   /* isam::Slam::Slam, Slam.cpp:69-78 */
+int pps_graph_destroy(pps_graph* g);
+int pps_get_props(const pps_graph* g, pps_props* out);           /* Slam::properties()     */
+int pps_set_props(pps_graph* g, const pps_props* p);             /* Slam::set_properties() */
+
+/* ---- nodes: Slam::add_node (Slam.cpp:91-94) + NodeT::init (Node.h:121-124) ------------ */
+int pps_add_pose(pps_graph* g, const double tq[7], int* id);
+int pps_add_plane(pps_graph* g, const double abcd[4], int* id);  /* normalised like Plane3d(Vector4d), isam_plane3d.h:59-66 */
+
+/* ---- factors: Slam::add_factor (Slam.cpp:96-105) -------------------------------------- */
+/* Pose3d_Factor            slam3d.h:58-89   */
+int pps_add_pose_prior(pps_graph* g, int pose, const double meas6[6], const double sqrtinf_ut[21], int* fid);
+/* Pose3d_Pose3d_Factor     slam3d.h:91-193  */
+int pps_add_odometry(pps_graph* g, int pose1, int pose2, const double meas6[6], const double sqrtinf_ut[21], int* fid);
+/* Pose3d_Plane3d_Factor    src/isam_plane3d.h:221-308 (relative = false, Mapping.cpp:21,513) */
+int pps_add_plane_obs(pps_graph* g, int pose, int plane, const double meas4[4], const double sqrtinf_ut[6], int* fid);
+/* Plane3d_Factor           src/isam_plane3d.h:428-474 */
+int pps_add_plane_prior(pps_graph* g, int plane, const double meas4[4], const double sqrtinf_ut[6], int* fid);
+
+/* FactorT::set_measurement (Factor.h:206) for plane factors; batched form for
+ * Mapper_mono::update_plane_measurement (Mapping.cpp:590-607) */
+int pps_set_measurement(pps_graph* g, int fid, const double meas4[4]);
+int pps_set_measurements(pps_graph* g, int n, const int* fids, const double* meas4 /* n x 4 */);
+
+/* Slam::remove_factor / remove_node (Slam.cpp:107-126); removing a node removes its factors */
+int pps_remove_factor(pps_graph* g, int fid);
+int pps_remove_node(pps_graph* g, int nid);
+
+/* ---- solve ---------------------------------------------------------------------------- */
+/* Slam::update with mod_batch = 1 (Slam.cpp:157-175 -> Optimizer::relinearize, Optimizer.cpp:114-185):
+ * relinearise at the estimate, one Gauss-Newton step (lambda = 0). */
+int pps_update(pps_graph* g);
+/* Slam::batch_optimization (Slam.cpp:198-210) -> Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) */
+int pps_batch_optimize(pps_graph* g, int* iterations);
+/* Slam::chi2(ESTIMATE) (Slam.cpp:266-268) */
+int pps_chi2(pps_graph* g, double* chi2);
+
+/* ---- state access (NodeT::value(), Node.h:130) ---------------------------------------- */
+int pps_num_nodes(const pps_graph* g, int* n);
+int pps_num_factors(const pps_graph* g, int* n);
+int pps_get_pose(pps_graph* g, int id, double tq[7]);
+int pps_get_plane(pps_graph* g, int id, double abcd[4]);
+int pps_set_pose(pps_graph* g, int id, const double tq[7]);     /* NodeT::init on an existing node */
+int pps_set_plane(pps_graph* g, int id, const double abcd[4]);
+/* bulk: ids may be NULL (= all poses / all planes in insertion order); out is n x 7 / n x 4 */
+int pps_get_poses(pps_graph* g, int n, const int* ids, double* out);
+int pps_get_planes(pps_graph* g, int n, const int* ids, double* out);
+
+/* ---- introspection (tests, bench, INTEGRATION) ---------------------------------------- */
+typedef struct pps_stats {
+  int    n_poses, n_planes, n_factors;
+  int    dim_nodes, dim_measure;           /* Slam::_dim_nodes / _dim_measure               */
+  int    n_fronts, n_levels, max_front;    /* multifrontal elimination tree of the last analysis */
+  int64_t nnz_L;                           /* scalars stored in the factor panels           */
+  int    lm_iterations;                    /* of the last batch_optimize                    */
+  int    lm_trials_accepted, lm_trials_rejected;
+  double chi2_initial, chi2_final, lambda_final;
+  double last_delta_norm;
+  /* wall-clock seconds of the last solve call, host side */
+  double t_total, t_analysis, t_upload;
+  /* device time (HIP events) of the last solve call, seconds, summed over launches */
+  double t_linearize, t_assemble, t_factor, t_backsolve, t_retract_chi2;
+  int    n_linearize, n_factorize;         /* launches of the sweep / factorizations        */
+} pps_stats;
+int pps_get_stats(const pps_graph* g, pps_stats* out);
+/* LM trace of the last batch_optimize: per trial (lambda, chi2_new, accepted); returns count via n */
+int pps_get_trace(const pps_graph* g, int cap, double* lambda, double* chi2, int* accepted, int* n);
+/* enable per-phase HIP-event timing (adds stream syncs; off by default) */
+int pps_set_profiling(pps_graph* g, int on);
+
+/* Per-factor residual / Jacobian of the device sweep, for parity tests.
+ * sel: 0 = linearisation point, 1 = estimate.  J is (dim x cols) row-major, r is the whitened residual. */
+int pps_factor_shape(const pps_graph* g, int fid, int* dim, int* cols);
+int pps_eval_factor(pps_graph* g, int fid, int mode /* enum pps_jacobian_mode */, double* J, double* r);
+
+/* Host-side symbolic analysis only (no device needed): runs ordering + front construction. */
+int pps_analyze(pps_graph* g);
+/* Flat dump of the analysis for host-logic tests.  Call with out == NULL to get the needed length. */
+int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed);
+
+/* ---- K1 micro-benchmark entry: the Jacobian sweep over a batch of replicated graphs --- */
+/* Replicates the handle's plane-observation and odometry edges `replicas` times in device
+ * memory (state shared), runs `iters` sweeps and returns the mean kernel time (HIP events, seconds)
+ * and the number of plane / odometry edges per sweep.  Used for the HBM roofline figure. */
+int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec_per_sweep,
+                    int64_t* n_plane_edges, int64_t* n_odo_edges);
+
+/* ---- pop-up (fp32), /root/reference/pop_up_wall --------------------------------------- */
+/* popup_plane::update_plane_equation_from_seg (libs/popup_plane.cpp:654-705).
+ * seg2d n x 4 (u1,v1,u2,v2); invK 3x3, T_wc 4x4 row-major; planes_out (n+1) x 4, row 0 = ground.
+ * Host pointers; runs on `device`. */
+int pps_popup_planes(int device, const float* seg2d, int n, const float invK[9], const float T_wc[16],
+                     float* planes_out);
+
+typedef struct pps_popup pps_popup;   /* per-camera pop-up context: device buffers for one image size */
+int pps_popup_create(int device, int width, int height, const float invK[9], pps_popup** out);
+int pps_popup_destroy(pps_popup* p);
+/* Fused frame kernel: segments -> plane equations (K5) and pixels -> 3-D (K6) in one launch.
+ *   polys      : closed 2-D polygons of the good planes, packed (x,y) vertices, poly_off[nplanes+1]
+ *                (popup_plane::all_closed_2d_bound_polygons, popup_plane.h:70-76); plane 0 = ground
+ *   seg2d      : n x 4 ground segments; plane i (i>=1) comes from segment i-1
+ *   bgr        : width*height*3 u8 or NULL
+ * Outputs (host, may be NULL): planes_out (n+1)x4 sensor-frame planes; xyz (w*h*3 fp32, world);
+ * rgb (w*h*3 u8); valid (w*h u8); depth (w*h fp32, get_depth_map_good semantics, ceiling substituted
+ * above ceiling_thre).  Filters follow matrixToCloud (popup_plane.cpp:948-960): z_s<0, z_s>depth_thre,
+ * z_w<-0.2 dropped; z_w clamped to ceiling_thre. */
+int pps_popup_frame(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
+                    const float* polys, const int* poly_off, int nplanes,
+                    const unsigned char* bgr, float depth_thre, float ceiling_thre,
+                    float* planes_out, float* xyz, unsigned char* rgb, unsigned char* valid, float* depth,
+                    int* n_valid);
+/* Same kernel, but every stage stays on the device: measurements of the listed plane-observation
+ * factors of graph g are overwritten in place from the new plane equations
+ * (Mapper_mono::update_plane_measurement, Mapping.cpp:590-607).  fids[i] < 0 = skip plane i. */
+int pps_popup_refresh_measurements(pps_graph* g, int n_frames, const int* pose_ids,
+                                   const int* seg_off /* n_frames+1 */, const float* seg2d,
+                                   const float invK[9], const int* fids /* per (frame,plane) incl. ground, seg_off[f]+f.. */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPS_H */

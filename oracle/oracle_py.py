@@ -1,0 +1,263 @@
+"""ctypes binding of the CPU oracle (oracle/libpps_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, bench.py's cpu_baseline leg
+and __graft_entry__.smoke().  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OraProps(C.Structure):
+    _fields_ = [
+        ("epsilon2", C.c_double), ("epsilon_abs", C.c_double), ("epsilon_rel", C.c_double),
+        ("max_iterations", C.c_int), ("lm_lambda0", C.c_double), ("lm_lambda_factor", C.c_double),
+        ("analytic", C.c_int), ("cache_ordering", C.c_int),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libpps_oracle.so")
+    src = os.path.join(_HERE, "pps_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = build()
+        L = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int)
+        L.ora_create.restype = C.c_void_p
+        L.ora_create.argtypes = [C.POINTER(OraProps)]
+        L.ora_destroy.argtypes = [C.c_void_p]
+        L.ora_default_props.argtypes = [C.POINTER(OraProps)]
+        for name, args, res in [
+            ("ora_add_pose", [C.c_void_p, dp], C.c_int),
+            ("ora_add_plane", [C.c_void_p, dp], C.c_int),
+            ("ora_add_pose_prior", [C.c_void_p, C.c_int, dp, dp], C.c_int),
+            ("ora_add_odometry", [C.c_void_p, C.c_int, C.c_int, dp, dp], C.c_int),
+            ("ora_add_plane_obs", [C.c_void_p, C.c_int, C.c_int, dp, dp], C.c_int),
+            ("ora_add_plane_prior", [C.c_void_p, C.c_int, dp, dp], C.c_int),
+            ("ora_set_measurement", [C.c_void_p, C.c_int, dp], None),
+            ("ora_remove_factor", [C.c_void_p, C.c_int], None),
+            ("ora_remove_node", [C.c_void_p, C.c_int], None),
+            ("ora_batch_optimize", [C.c_void_p], C.c_int),
+            ("ora_update", [C.c_void_p], None),
+            ("ora_chi2", [C.c_void_p], C.c_double),
+            ("ora_num_nodes", [C.c_void_p], C.c_int),
+            ("ora_num_factors", [C.c_void_p], C.c_int),
+            ("ora_node_dim", [C.c_void_p, C.c_int], C.c_int),
+            ("ora_get_pose", [C.c_void_p, C.c_int, dp], None),
+            ("ora_get_plane", [C.c_void_p, C.c_int, dp], None),
+            ("ora_set_pose", [C.c_void_p, C.c_int, dp], None),
+            ("ora_set_plane", [C.c_void_p, C.c_int, dp], None),
+            ("ora_factor_dim", [C.c_void_p, C.c_int], C.c_int),
+            ("ora_factor_cols", [C.c_void_p, C.c_int], C.c_int),
+            ("ora_factor_error", [C.c_void_p, C.c_int, C.c_int, dp], None),
+            ("ora_factor_jacobian", [C.c_void_p, C.c_int, C.c_int, dp, dp], None),
+            ("ora_trace_len", [C.c_void_p], C.c_int),
+            ("ora_trace_get", [C.c_void_p, C.c_int, dp, dp, ip], None),
+            ("ora_initial_chi2", [C.c_void_p], C.c_double),
+            ("ora_timers", [C.c_void_p, dp], None),
+            ("ora_last_nnzL", [C.c_void_p], C.c_long),
+            ("ora_plane_transform_to", [dp, dp, dp], None),
+            ("ora_plane_transform_from", [dp, dp, dp], None),
+            ("ora_plane_exmap", [dp, dp, dp], None),
+            ("ora_pose_exmap", [dp, dp, dp], None),
+            ("ora_pose_vector", [dp, dp], None),
+            ("ora_pose_from_vector", [dp, dp], None),
+            ("ora_pose_oplus", [dp, dp, dp], None),
+            ("ora_pose_ominus", [dp, dp, dp], None),
+            ("ora_popup_planes", [fp, C.c_int, fp, fp, fp], None),
+            ("ora_popup_cloud", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_float, C.c_float, fp,
+                                 C.POINTER(C.c_ubyte)], None),
+            ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
+        ]:
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_props(**kw):
+    p = OraProps()
+    lib().ora_default_props(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class OracleGraph:
+    """Same add-node / add-factor surface as pop_up_slam_amd.Graph (the product)."""
+
+    def __init__(self, **props):
+        self.L = lib()
+        self.props = default_props(**props)
+        self.h = C.c_void_p(self.L.ora_create(C.byref(self.props)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ora_destroy(self.h)
+            self.h = None
+
+    def add_pose(self, tq):
+        a, p = _d(tq); return self.L.ora_add_pose(self.h, p)
+
+    def add_plane(self, abcd):
+        a, p = _d(abcd); return self.L.ora_add_plane(self.h, p)
+
+    def add_pose_prior(self, pose, meas6, ut21):
+        a, p = _d(meas6); b, q = _d(ut21); return self.L.ora_add_pose_prior(self.h, pose, p, q)
+
+    def add_odometry(self, p1, p2, meas6, ut21):
+        a, p = _d(meas6); b, q = _d(ut21); return self.L.ora_add_odometry(self.h, p1, p2, p, q)
+
+    def add_plane_obs(self, pose, plane, meas4, ut6):
+        a, p = _d(meas4); b, q = _d(ut6); return self.L.ora_add_plane_obs(self.h, pose, plane, p, q)
+
+    def add_plane_prior(self, plane, meas4, ut6):
+        a, p = _d(meas4); b, q = _d(ut6); return self.L.ora_add_plane_prior(self.h, plane, p, q)
+
+    def set_measurement(self, fid, meas4):
+        a, p = _d(meas4); self.L.ora_set_measurement(self.h, fid, p)
+
+    def remove_factor(self, fid):
+        self.L.ora_remove_factor(self.h, fid)
+
+    def remove_node(self, nid):
+        self.L.ora_remove_node(self.h, nid)
+
+    def batch_optimize(self):
+        return self.L.ora_batch_optimize(self.h)
+
+    def update(self):
+        self.L.ora_update(self.h)
+
+    def chi2(self):
+        return self.L.ora_chi2(self.h)
+
+    def get_pose(self, nid):
+        out = np.zeros(7); self.L.ora_get_pose(self.h, nid, out.ctypes.data_as(C.POINTER(C.c_double))); return out
+
+    def get_plane(self, nid):
+        out = np.zeros(4); self.L.ora_get_plane(self.h, nid, out.ctypes.data_as(C.POINTER(C.c_double))); return out
+
+    def set_pose(self, nid, tq):
+        a, p = _d(tq); self.L.ora_set_pose(self.h, nid, p)
+
+    def set_plane(self, nid, abcd):
+        a, p = _d(abcd); self.L.ora_set_plane(self.h, nid, p)
+
+    def node_dim(self, nid):
+        return self.L.ora_node_dim(self.h, nid)
+
+    def num_nodes(self):
+        return self.L.ora_num_nodes(self.h)
+
+    def num_factors(self):
+        return self.L.ora_num_factors(self.h)
+
+    def factor_error(self, fid, sel=1):
+        m = self.L.ora_factor_dim(self.h, fid)
+        out = np.zeros(m); self.L.ora_factor_error(self.h, fid, sel, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def factor_jacobian(self, fid, analytic=0):
+        m = self.L.ora_factor_dim(self.h, fid); n = self.L.ora_factor_cols(self.h, fid)
+        H = np.zeros((m, n)); r = np.zeros(m)
+        self.L.ora_factor_jacobian(self.h, fid, analytic, H.ctypes.data_as(C.POINTER(C.c_double)),
+                                   r.ctypes.data_as(C.POINTER(C.c_double)))
+        return H, r
+
+    def trace(self):
+        n = self.L.ora_trace_len(self.h)
+        out = []
+        for i in range(n):
+            lam, chi = C.c_double(), C.c_double(); acc = C.c_int()
+            self.L.ora_trace_get(self.h, i, C.byref(lam), C.byref(chi), C.byref(acc))
+            out.append((lam.value, chi.value, bool(acc.value)))
+        return out
+
+    def initial_chi2(self):
+        return self.L.ora_initial_chi2(self.h)
+
+    def timers(self):
+        t = np.zeros(4); self.L.ora_timers(self.h, t.ctypes.data_as(C.POINTER(C.c_double))); return t
+
+    def nnzL(self):
+        return self.L.ora_last_nnzL(self.h)
+
+
+# free-standing helpers ------------------------------------------------------
+def _call3(fn, a, b, n):
+    a_, pa = _d(a); b_, pb = _d(b); out = np.zeros(n)
+    fn(pa, pb, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def plane_transform_to(abcd, tq): return _call3(lib().ora_plane_transform_to, abcd, tq, 4)
+def plane_transform_from(abcd, tq): return _call3(lib().ora_plane_transform_from, abcd, tq, 4)
+def plane_exmap(abcd, d): return _call3(lib().ora_plane_exmap, abcd, d, 4)
+def pose_exmap(tq, d): return _call3(lib().ora_pose_exmap, tq, d, 7)
+def pose_oplus(a, d): return _call3(lib().ora_pose_oplus, a, d, 7)
+def pose_ominus(a, b): return _call3(lib().ora_pose_ominus, a, b, 7)
+
+
+def pose_vector(tq):
+    a, p = _d(tq); out = np.zeros(6)
+    lib().ora_pose_vector(p, out.ctypes.data_as(C.POINTER(C.c_double))); return out
+
+
+def pose_from_vector(v6):
+    a, p = _d(v6); out = np.zeros(7)
+    lib().ora_pose_from_vector(p, out.ctypes.data_as(C.POINTER(C.c_double))); return out
+
+
+def popup_planes(seg2d, invK, T_wc):
+    seg, ps = _f(seg2d); n = seg.reshape(-1, 4).shape[0]
+    k, pk = _f(invK); t, pt = _f(T_wc)
+    out = np.zeros((n + 1, 4), dtype=np.float32)
+    lib().ora_popup_planes(ps, n, pk, pt, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def popup_cloud(plane_id, invK, T_wc, planes_sensor, depth_thre=10.0, ceiling_thre=2.5):
+    pid = np.ascontiguousarray(plane_id, dtype=np.int32); h, w = pid.shape
+    k, pk = _f(invK); t, pt = _f(T_wc); pl, pp = _f(planes_sensor)
+    xyz = np.zeros((h, w, 3), dtype=np.float32); valid = np.zeros((h, w), dtype=np.uint8)
+    lib().ora_popup_cloud(pid.ctypes.data_as(C.POINTER(C.c_int)), w, h, pk, pt, pp, pl.reshape(-1, 4).shape[0],
+                          depth_thre, ceiling_thre, xyz.ctypes.data_as(C.POINTER(C.c_float)),
+                          valid.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return xyz, valid
+
+
+def popup_depth(plane_id, invK, T_wc, planes_sensor, ceiling_plane_sensor, ceiling_thre=2.5):
+    pid = np.ascontiguousarray(plane_id, dtype=np.int32); h, w = pid.shape
+    k, pk = _f(invK); t, pt = _f(T_wc); pl, pp = _f(planes_sensor); c, pc = _f(ceiling_plane_sensor)
+    depth = np.zeros((h, w), dtype=np.float32)
+    lib().ora_popup_depth(pid.ctypes.data_as(C.POINTER(C.c_int)), w, h, pk, pt, pp, pl.reshape(-1, 4).shape[0],
+                          pc, ceiling_thre, depth.ctypes.data_as(C.POINTER(C.c_float)))
+    return depth

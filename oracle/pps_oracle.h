@@ -1,0 +1,119 @@
+/*
+ * pps_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C, fp64, single-threaded restatement of the reference's plane-SLAM
+ * graph solve (pop_planar_slam + its vendored iSAM).  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load this library; the
+ * product (libpps.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors for this path
+ * and cannot be compiled here (Eigen, Boost, SuiteSparse, ROS absent), so this
+ * restatement is pinned only by (a) an independent numpy evaluation
+ * (oracle/numpy_ref.py -> tests/golden/) and (b) analytic invariants.
+ *
+ * Conventions: quaternions are stored (x,y,z,w) everywhere (Eigen coeffs()
+ * order); a plane (a,b,c,d) is the quaternion x=a,y=b,z=c,w=d
+ * (pop_planar_slam/src/isam_plane3d.h:74-76).  A pose is 7 doubles
+ * (tx,ty,tz,qx,qy,qz,qw).  Pose measurements are 6 doubles
+ * (x,y,z,yaw,pitch,roll) = Pose3d::vector() (Pose3d.h:138-145).
+ * sqrt-information matrices are packed upper-triangular, row-major
+ * (noise_to_string order, Factor.h:169-190): 21 doubles for 6x6, 6 for 3x3.
+ */
+#ifndef PPS_ORACLE_H
+#define PPS_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ora_graph ora_graph;
+
+/* Properties.h:37-110 with the app overrides of Mapping.cpp:32-43 as defaults */
+typedef struct ora_props {
+  double epsilon2;        /* 1e-3  stop on ||delta||               */
+  double epsilon_abs;     /* 1e-4  stop on chi2                    */
+  double epsilon_rel;     /* 1e-6  stop on relative improvement    */
+  int    max_iterations;  /* 500                                   */
+  double lm_lambda0;      /* 1e-6                                  */
+  double lm_lambda_factor;/* 10                                    */
+  int    analytic;        /* 0 = reference-faithful central differences (numericalDiff.cpp) */
+  int    cache_ordering;  /* 0 = re-order every factorisation like Cholesky.cpp:98 */
+} ora_props;
+
+void ora_default_props(ora_props* p);
+
+ora_graph* ora_create(const ora_props* p);
+void ora_destroy(ora_graph* g);
+
+/* nodes (Slam::add_node, Slam.cpp:91-94); return node id */
+int ora_add_pose(ora_graph* g, const double tq[7]);
+int ora_add_plane(ora_graph* g, const double abcd[4]);  /* normalised like Plane3d(Vector4d) */
+
+/* factors (Slam::add_factor, Slam.cpp:96-105); return factor id */
+int ora_add_pose_prior(ora_graph* g, int pose, const double meas6[6], const double sqrtinf_ut[21]);
+int ora_add_odometry(ora_graph* g, int p1, int p2, const double meas6[6], const double sqrtinf_ut[21]);
+int ora_add_plane_obs(ora_graph* g, int pose, int plane, const double meas4[4], const double sqrtinf_ut[6]);
+int ora_add_plane_prior(ora_graph* g, int plane, const double meas4[4], const double sqrtinf_ut[6]);
+void ora_set_measurement(ora_graph* g, int fid, const double meas4[4]);  /* Factor.h:206 */
+void ora_remove_factor(ora_graph* g, int fid);
+void ora_remove_node(ora_graph* g, int nid);
+
+/* solve */
+int    ora_batch_optimize(ora_graph* g);   /* Slam::batch_optimization -> LM; returns iterations */
+void   ora_update(ora_graph* g);           /* Slam::update with mod_batch=1: one GN step     */
+double ora_chi2(ora_graph* g);             /* Slam::chi2(ESTIMATE), Slam.cpp:266-268        */
+
+/* state access */
+int  ora_num_nodes(const ora_graph* g);
+int  ora_num_factors(const ora_graph* g);
+int  ora_node_dim(const ora_graph* g, int nid);
+void ora_get_pose(const ora_graph* g, int nid, double tq[7]);
+void ora_get_plane(const ora_graph* g, int nid, double abcd[4]);
+void ora_set_pose(ora_graph* g, int nid, const double tq[7]);
+void ora_set_plane(ora_graph* g, int nid, const double abcd[4]);
+
+/* per-factor evaluation for fixture tests.  sel: 0 = LINPOINT, 1 = ESTIMATE */
+int  ora_factor_dim(const ora_graph* g, int fid);
+int  ora_factor_cols(const ora_graph* g, int fid);
+void ora_factor_error(ora_graph* g, int fid, int sel, double* r_out);
+/* H is (dim x cols) row-major; analytic=0 -> numericalDiff restatement */
+void ora_factor_jacobian(ora_graph* g, int fid, int analytic, double* H_out, double* r_out);
+
+/* LM trace of the last batch_optimize: per trial (lambda, chi2_new, accepted) */
+int  ora_trace_len(const ora_graph* g);
+void ora_trace_get(const ora_graph* g, int i, double* lambda, double* chi2_new, int* accepted);
+double ora_initial_chi2(const ora_graph* g);
+
+/* timers of the last solve, seconds: [0] linearise, [1] factor+solve, [2] retract+chi2, [3] ordering (subset of 1) */
+void ora_timers(const ora_graph* g, double t[4]);
+/* nnz(L) of the last factorisation */
+long ora_last_nnzL(const ora_graph* g);
+
+/* free-standing geometry helpers exposed for unit tests */
+void ora_plane_transform_to(const double abcd[4], const double tq[7], double out[4]);   /* isam_plane3d.h:180-182 */
+void ora_plane_transform_from(const double abcd[4], const double tq[7], double out[4]); /* isam_plane3d.h:186-188 */
+void ora_plane_exmap(const double abcd[4], const double d[3], double out[4]);            /* isam_plane3d.h:101-127 */
+void ora_pose_exmap(const double tq[7], const double d[6], double out[7]);               /* Pose3d.h:131-136 */
+void ora_pose_vector(const double tq[7], double v6[6]);                                  /* Pose3d.h:138-145 */
+void ora_pose_from_vector(const double v6[6], double tq[7]);                             /* Pose3d.h:152-155 */
+void ora_pose_oplus(const double a[7], const double d[7], double out[7]);                /* Pose3d.h:222-224 */
+void ora_pose_ominus(const double a[7], const double b[7], double out[7]);               /* Pose3d.h:233-235 */
+
+/* pop-up (fp32) restatement: pop_up_wall/libs/popup_plane.cpp:654-705.
+ * seg2d: n x 4 (u1 v1 u2 v2) row-major, invK 3x3 row-major, T_wc 4x4 row-major.
+ * planes_out: (n+1) x 4, row 0 = ground plane in the sensor frame. */
+void ora_popup_planes(const float* seg2d, int n, const float invK[9], const float T_wc[16], float* planes_out);
+/* per-pixel pop-up: generate_cloud + matrixToCloud (popup_plane.cpp:807-863,925-985) given a
+ * per-pixel plane-id mask (-1 = none).  xyz_out: 3 floats per pixel (world), valid_out: 1 = kept. */
+void ora_popup_cloud(const int* plane_id, int width, int height, const float invK[9], const float T_wc[16],
+                     const float* planes_sensor, int nplanes, float depth_thre, float ceiling_thre,
+                     float* xyz_out, unsigned char* valid_out);
+/* get_depth_map_good (popup_plane.cpp:866-921) without the half-res resize */
+void ora_popup_depth(const int* plane_id, int width, int height, const float invK[9], const float T_wc[16],
+                     const float* planes_sensor, int nplanes, const float ceiling_plane_sensor[4],
+                     float ceiling_thre, float* depth_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

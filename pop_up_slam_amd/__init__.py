@@ -1,0 +1,309 @@
+"""pop_up_slam_amd -- MI355X-native plane-SLAM backend (graph solve + pop-up).
+
+The product is the C-ABI shared library ``libpps.so`` (HIP kernels for gfx950,
+``include/pps.h``).  This module is only the thin Python binding used by the
+tests and ``bench.py``; a C++ host reaches the same entry points through
+``include/pps_isam.hpp``.  There is no CPU fallback: if the library is
+missing, importing :class:`Graph` users fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpps.so")
+
+PPS_OK, PPS_EINVAL, PPS_ENOTPD, PPS_EHIP, PPS_ENOMEM, PPS_ESTATE = range(6)
+JAC_NUMERIC, JAC_ANALYTIC = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+class PpsProps(C.Structure):
+    _fields_ = [
+        ("epsilon2", C.c_double), ("epsilon_abs", C.c_double), ("epsilon_rel", C.c_double),
+        ("max_iterations", C.c_int), ("lm_lambda0", C.c_double), ("lm_lambda_factor", C.c_double),
+        ("jacobian_mode", C.c_int), ("device", C.c_int), ("verbose", C.c_int),
+    ]
+
+
+class PpsStats(C.Structure):
+    _fields_ = [
+        ("n_poses", C.c_int), ("n_planes", C.c_int), ("n_factors", C.c_int),
+        ("dim_nodes", C.c_int), ("dim_measure", C.c_int),
+        ("n_fronts", C.c_int), ("n_levels", C.c_int), ("max_front", C.c_int),
+        ("nnz_L", C.c_int64),
+        ("lm_iterations", C.c_int), ("lm_trials_accepted", C.c_int), ("lm_trials_rejected", C.c_int),
+        ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+        ("last_delta_norm", C.c_double),
+        ("t_total", C.c_double), ("t_analysis", C.c_double), ("t_upload", C.c_double),
+        ("t_linearize", C.c_double), ("t_assemble", C.c_double), ("t_factor", C.c_double),
+        ("t_backsolve", C.c_double), ("t_retract_chi2", C.c_double),
+        ("n_linearize", C.c_int), ("n_factorize", C.c_int),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PpsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pps error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+# every symbol include/pps.h declares (checked by tests/test_cabi.py)
+SYMBOLS = [
+    "pps_default_props", "pps_version", "pps_last_error", "pps_graph_create", "pps_graph_destroy",
+    "pps_get_props", "pps_set_props", "pps_add_pose", "pps_add_plane", "pps_add_pose_prior",
+    "pps_add_odometry", "pps_add_plane_obs", "pps_add_plane_prior", "pps_set_measurement",
+    "pps_set_measurements", "pps_remove_factor", "pps_remove_node", "pps_update", "pps_batch_optimize",
+    "pps_chi2", "pps_num_nodes", "pps_num_factors", "pps_get_pose", "pps_get_plane", "pps_set_pose",
+    "pps_set_plane", "pps_get_poses", "pps_get_planes", "pps_get_stats", "pps_get_trace",
+    "pps_set_profiling", "pps_factor_shape", "pps_eval_factor", "pps_analyze", "pps_analysis_dump",
+    "pps_bench_sweep",
+]
+
+
+def lib():
+    """Load libpps.so (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C pop_up_slam_amd/csrc).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.pps_last_error.restype = C.c_char_p
+        L.pps_last_error.argtypes = [C.c_void_p]
+        L.pps_default_props.argtypes = [C.POINTER(PpsProps)]
+        L.pps_default_props.restype = None
+        L.pps_graph_create.argtypes = [C.POINTER(PpsProps), C.POINTER(C.c_void_p)]
+        L.pps_graph_destroy.argtypes = [C.c_void_p]
+        L.pps_get_props.argtypes = [C.c_void_p, C.POINTER(PpsProps)]
+        L.pps_set_props.argtypes = [C.c_void_p, C.POINTER(PpsProps)]
+        L.pps_add_pose.argtypes = [C.c_void_p, _dp, _ip]
+        L.pps_add_plane.argtypes = [C.c_void_p, _dp, _ip]
+        L.pps_add_pose_prior.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
+        L.pps_add_odometry.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip]
+        L.pps_add_plane_obs.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip]
+        L.pps_add_plane_prior.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
+        L.pps_set_measurement.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.pps_set_measurements.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+        L.pps_remove_factor.argtypes = [C.c_void_p, C.c_int]
+        L.pps_remove_node.argtypes = [C.c_void_p, C.c_int]
+        L.pps_update.argtypes = [C.c_void_p]
+        L.pps_batch_optimize.argtypes = [C.c_void_p, _ip]
+        L.pps_chi2.argtypes = [C.c_void_p, _dp]
+        L.pps_num_nodes.argtypes = [C.c_void_p, _ip]
+        L.pps_num_factors.argtypes = [C.c_void_p, _ip]
+        L.pps_get_pose.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.pps_get_plane.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.pps_set_pose.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.pps_set_plane.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.pps_get_poses.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+        L.pps_get_planes.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+        L.pps_get_stats.argtypes = [C.c_void_p, C.POINTER(PpsStats)]
+        L.pps_get_trace.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _ip]
+        L.pps_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.pps_factor_shape.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
+        L.pps_eval_factor.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp]
+        L.pps_analyze.argtypes = [C.c_void_p]
+        L.pps_analysis_dump.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        L.pps_bench_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64)]
+        _LIB = L
+    return _LIB
+
+
+def _d(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} doubles, got {a.size}")
+    return a, a.ctypes.data_as(_dp)
+
+
+def default_props(**kw):
+    p = PpsProps()
+    lib().pps_default_props(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Graph:
+    """Python mirror of the ``isam::Slam`` surface the mapper uses (Slam.h:82-215 of the
+    reference): add_node / add_factor / update / batch_optimization / chi2, ids instead of pointers."""
+
+    def __init__(self, **props):
+        self.L = lib()
+        self.props = default_props(**props)
+        h = C.c_void_p()
+        rc = self.L.pps_graph_create(C.byref(self.props), C.byref(h))
+        if rc != PPS_OK:
+            raise PpsError(rc, "pps_graph_create failed")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pps_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != PPS_OK:
+            raise PpsError(rc, self.L.pps_last_error(self.h).decode())
+
+    def set_props(self, **kw):
+        for k, v in kw.items():
+            setattr(self.props, k, v)
+        self._ck(self.L.pps_set_props(self.h, C.byref(self.props)))
+
+    # ---- nodes / factors ----
+    def add_pose(self, tq):
+        a, p = _d(tq, 7); i = C.c_int(); self._ck(self.L.pps_add_pose(self.h, p, C.byref(i))); return i.value
+
+    def add_plane(self, abcd):
+        a, p = _d(abcd, 4); i = C.c_int(); self._ck(self.L.pps_add_plane(self.h, p, C.byref(i))); return i.value
+
+    def add_pose_prior(self, pose, meas6, ut21):
+        a, p = _d(meas6, 6); b, q = _d(ut21, 21); i = C.c_int()
+        self._ck(self.L.pps_add_pose_prior(self.h, pose, p, q, C.byref(i))); return i.value
+
+    def add_odometry(self, p1, p2, meas6, ut21):
+        a, p = _d(meas6, 6); b, q = _d(ut21, 21); i = C.c_int()
+        self._ck(self.L.pps_add_odometry(self.h, p1, p2, p, q, C.byref(i))); return i.value
+
+    def add_plane_obs(self, pose, plane, meas4, ut6):
+        a, p = _d(meas4, 4); b, q = _d(ut6, 6); i = C.c_int()
+        self._ck(self.L.pps_add_plane_obs(self.h, pose, plane, p, q, C.byref(i))); return i.value
+
+    def add_plane_prior(self, plane, meas4, ut6):
+        a, p = _d(meas4, 4); b, q = _d(ut6, 6); i = C.c_int()
+        self._ck(self.L.pps_add_plane_prior(self.h, plane, p, q, C.byref(i))); return i.value
+
+    def set_measurement(self, fid, meas4):
+        a, p = _d(meas4, 4); self._ck(self.L.pps_set_measurement(self.h, fid, p))
+
+    def set_measurements(self, fids, meas):
+        f = np.ascontiguousarray(fids, dtype=np.int32); a, p = _d(meas, 4 * len(f))
+        self._ck(self.L.pps_set_measurements(self.h, len(f), f.ctypes.data_as(_ip), p))
+
+    def remove_factor(self, fid):
+        self._ck(self.L.pps_remove_factor(self.h, fid))
+
+    def remove_node(self, nid):
+        self._ck(self.L.pps_remove_node(self.h, nid))
+
+    # ---- solve ----
+    def update(self):
+        self._ck(self.L.pps_update(self.h))
+
+    def batch_optimize(self):
+        it = C.c_int(); self._ck(self.L.pps_batch_optimize(self.h, C.byref(it))); return it.value
+
+    def chi2(self):
+        v = C.c_double(); self._ck(self.L.pps_chi2(self.h, C.byref(v))); return v.value
+
+    # ---- state ----
+    def num_nodes(self):
+        n = C.c_int(); self._ck(self.L.pps_num_nodes(self.h, C.byref(n))); return n.value
+
+    def num_factors(self):
+        n = C.c_int(); self._ck(self.L.pps_num_factors(self.h, C.byref(n))); return n.value
+
+    def get_pose(self, nid):
+        out = np.zeros(7); self._ck(self.L.pps_get_pose(self.h, nid, out.ctypes.data_as(_dp))); return out
+
+    def get_plane(self, nid):
+        out = np.zeros(4); self._ck(self.L.pps_get_plane(self.h, nid, out.ctypes.data_as(_dp))); return out
+
+    def set_pose(self, nid, tq):
+        a, p = _d(tq, 7); self._ck(self.L.pps_set_pose(self.h, nid, p))
+
+    def set_plane(self, nid, abcd):
+        a, p = _d(abcd, 4); self._ck(self.L.pps_set_plane(self.h, nid, p))
+
+    def get_poses(self, ids=None, n=None):
+        if ids is not None:
+            i = np.ascontiguousarray(ids, dtype=np.int32); n = len(i); ptr = i.ctypes.data_as(_ip)
+        else:
+            ptr = None
+            if n is None:
+                n = self.stats()["n_poses"]
+        out = np.zeros((n, 7)); self._ck(self.L.pps_get_poses(self.h, n, ptr, out.ctypes.data_as(_dp))); return out
+
+    def get_planes(self, ids=None, n=None):
+        if ids is not None:
+            i = np.ascontiguousarray(ids, dtype=np.int32); n = len(i); ptr = i.ctypes.data_as(_ip)
+        else:
+            ptr = None
+            if n is None:
+                n = self.stats()["n_planes"]
+        out = np.zeros((n, 4)); self._ck(self.L.pps_get_planes(self.h, n, ptr, out.ctypes.data_as(_dp))); return out
+
+    # ---- introspection ----
+    def stats(self):
+        s = PpsStats(); self._ck(self.L.pps_get_stats(self.h, C.byref(s))); return s.asdict()
+
+    def trace(self):
+        n = C.c_int(); self._ck(self.L.pps_get_trace(self.h, 0, None, None, None, C.byref(n)))
+        lam = np.zeros(n.value); chi = np.zeros(n.value); acc = np.zeros(n.value, dtype=np.int32)
+        self._ck(self.L.pps_get_trace(self.h, n.value, lam.ctypes.data_as(_dp), chi.ctypes.data_as(_dp),
+                                      acc.ctypes.data_as(_ip), C.byref(n)))
+        return [(float(l), float(c), bool(a)) for l, c, a in zip(lam, chi, acc)]
+
+    def set_profiling(self, on=True):
+        self._ck(self.L.pps_set_profiling(self.h, int(on)))
+
+    def eval_factor(self, fid, mode=JAC_NUMERIC):
+        m, c = C.c_int(), C.c_int(); self._ck(self.L.pps_factor_shape(self.h, fid, C.byref(m), C.byref(c)))
+        J = np.zeros((m.value, c.value)); r = np.zeros(m.value)
+        self._ck(self.L.pps_eval_factor(self.h, fid, mode, J.ctypes.data_as(_dp), r.ctypes.data_as(_dp)))
+        return J, r
+
+    def analyze(self):
+        self._ck(self.L.pps_analyze(self.h))
+
+    def analysis_dump(self):
+        need = C.c_int64(); self._ck(self.L.pps_analysis_dump(self.h, 0, None, C.byref(need)))
+        buf = np.zeros(need.value, dtype=np.int32)
+        self._ck(self.L.pps_analysis_dump(self.h, need.value, buf.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(need)))
+        return parse_analysis_dump(buf)
+
+    def bench_sweep(self, mode=JAC_NUMERIC, replicas=1, iters=10):
+        sec = C.c_double(); npl = C.c_int64(); nod = C.c_int64()
+        self._ck(self.L.pps_bench_sweep(self.h, mode, replicas, iters, C.byref(sec), C.byref(npl), C.byref(nod)))
+        return sec.value, npl.value, nod.value
+
+
+_DUMP_SCALARS = ["n_nodes", "n_scalars", "n_fronts", "n_levels", "max_front", "n_blocks", "n_segs", "L_size",
+                 "U_size", "H_size", "J_size"]
+_DUMP_VECTORS = ["node_pos", "node_voff", "order", "f_p", "f_b", "f_poff", "f_parent", "f_level", "f_Loff", "f_Uoff",
+                 "f_bidx_off", "bidx", "f_child_off", "child", "f_cmap_off", "cmap", "level_off", "level_fronts",
+                 "f_asm_off", "asm_blk", "asm_lrow", "asm_lcol", "blk_rows", "blk_cols", "blk_size", "blk_nseg",
+                 "blk_hoff", "seg_blk", "seg_c0", "seg_cnt", "seg_hoff", "contrib", "node_compact", "factor_joff"]
+
+
+def parse_analysis_dump(buf):
+    out = {}
+    k = 0
+    for name in _DUMP_SCALARS:
+        out[name] = int(buf[k]); k += 1
+    for name in _DUMP_VECTORS:
+        n = int(buf[k]); k += 1
+        out[name] = np.array(buf[k:k + n], dtype=np.int64); k += n
+    assert k == len(buf), (k, len(buf))
+    return out

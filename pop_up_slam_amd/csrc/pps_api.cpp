@@ -1,0 +1,854 @@
+// pps_api.cpp -- C-ABI implementation: graph container, upload, LM / GN drivers.
+//
+// Host control flow follows the reference line by line where it matters for parity:
+//   pps_batch_optimize  == Optimizer::levenberg_marquardt  (Thirdparty/isam/isamlib/Optimizer.cpp:371-467)
+//   pps_update          == Optimizer::relinearize          (Optimizer.cpp:114-185) via Slam::update, mod_batch = 1
+// Everything numeric runs on the device; per LM trial one 32-byte result record (chi2, |delta|^2,
+// not-PD flag) returns to the host for the accept / reject decision.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pps.h"
+#include "pps_device.h"
+#include "pps_geom.h"
+#include "pps_symbolic.h"
+
+using namespace pps;
+
+namespace {
+
+struct HostNode {
+  int type;
+  double v[7];
+  bool deleted;
+  int compact;   // index among live nodes (SymNode id)
+  int slot;      // index in the pose / plane device array
+};
+struct HostFactor {
+  int type;
+  int a, b;
+  double meas[6];
+  double w[21];
+  bool deleted;
+  int slot;      // index in its type's device arrays
+};
+
+double now_s() {
+  using namespace std::chrono;
+  return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct pps_graph {
+  pps_props props;
+  std::string err;
+  std::vector<HostNode> nodes;
+  std::vector<HostFactor> factors;
+  int n_live_nodes = 0, n_live_factors = 0, dim_nodes = 0, dim_measure = 0;
+  bool topo_dirty = true;       // structure changed since the last analysis/upload
+  bool host_values_newer = true;   // host node values must be pushed before the next solve
+  bool dev_values_newer = false;   // device estimate is newer than the host copy
+  bool meas_dirty = false;
+  bool analyzed = false;
+  Analysis an;
+  AnalysisParams aprm;
+  std::vector<int> pose_ids, plane_ids;   // slot -> node id
+  std::vector<int> fslot_ids[4];          // per type: slot -> factor id
+  std::vector<int> level_max_front;
+  // device
+  bool dev_ready = false;
+  hipStream_t stream = nullptr;
+  DevGraph dev;
+  std::vector<void*> allocs;
+  double* host_result = nullptr;   // pinned, 4 doubles
+  bool profiling = false;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  // stats / trace
+  pps_stats stats{};
+  std::vector<double> tr_lambda, tr_chi2;
+  std::vector<int> tr_acc;
+};
+
+namespace {
+
+int fail(pps_graph* g, int code, const std::string& msg) {
+  if (g) g->err = msg;
+  return code;
+}
+int hip_fail(pps_graph* g, hipError_t e, const char* what) {
+  return fail(g, PPS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(g, expr)                                   \
+  do {                                                     \
+    hipError_t _e = (expr);                                \
+    if (_e != hipSuccess) return hip_fail(g, _e, #expr);   \
+  } while (0)
+
+void free_device(pps_graph* g) {
+  for (void* p : g->allocs) (void)hipFree(p);
+  g->allocs.clear();
+  g->dev = DevGraph();
+}
+
+template <class T>
+int dev_alloc(pps_graph* g, T** out, size_t count) {
+  *out = nullptr;
+  if (count == 0) count = 1;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, count * sizeof(T));
+  if (e != hipSuccess) return hip_fail(g, e, "hipMalloc");
+  g->allocs.push_back(p);
+  *out = static_cast<T*>(p);
+  return PPS_OK;
+}
+template <class T>
+int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
+  int rc = dev_alloc(g, out, v.size());
+  if (rc != PPS_OK) return rc;
+  if (!v.empty()) HIP_TRY(g, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PPS_OK;
+}
+
+int ensure_device(pps_graph* g) {
+  if (g->dev_ready) return PPS_OK;
+  HIP_TRY(g, hipSetDevice(g->props.device));
+  HIP_TRY(g, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->host_result), 8 * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(g, hipEventCreate(&g->ev[0]));
+  HIP_TRY(g, hipEventCreate(&g->ev[1]));
+  g->dev_ready = true;
+  return PPS_OK;
+}
+
+// ---- compaction + symbolic analysis (host only) -------------------------------------------
+int run_analysis(pps_graph* g) {
+  const double t0 = now_s();
+  g->pose_ids.clear(); g->plane_ids.clear();
+  for (int t = 0; t < 4; t++) g->fslot_ids[t].clear();
+  std::vector<SymNode> sn;
+  for (size_t i = 0; i < g->nodes.size(); i++) {
+    HostNode& n = g->nodes[i];
+    if (n.deleted) { n.compact = n.slot = -1; continue; }
+    n.compact = (int)sn.size();
+    if (n.type == NODE_POSE) { n.slot = (int)g->pose_ids.size(); g->pose_ids.push_back((int)i); sn.push_back({NODE_POSE, 6, n.slot}); }
+    else { n.slot = (int)g->plane_ids.size(); g->plane_ids.push_back((int)i); sn.push_back({NODE_PLANE, 3, -1}); }
+  }
+  for (size_t i = 0; i < g->factors.size(); i++) {
+    HostFactor& f = g->factors[i];
+    if (f.deleted) { f.slot = -1; continue; }
+    f.slot = (int)g->fslot_ids[f.type].size();
+    g->fslot_ids[f.type].push_back((int)i);
+  }
+  const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(),
+                n_obs = g->fslot_ids[F_PLANE_OBS].size();
+  const int64_t joff_obs = 0, joff_odo = n_obs * 30, joff_pp = joff_odo + n_odo * 78, joff_lp = joff_pp + n_pp * 42;
+  const int64_t base[4] = {joff_pp, joff_odo, joff_obs, joff_lp};
+  if (joff_lp + (int64_t)g->fslot_ids[F_PLANE_PRIOR].size() * 12 > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
+  std::vector<SymFactor> sf;
+  sf.reserve(g->factors.size());
+  for (size_t i = 0; i < g->factors.size(); i++) {
+    const HostFactor& f = g->factors[i];
+    if (f.deleted) continue;
+    SymFactor s;
+    s.type = f.type;
+    s.a = g->nodes[f.a].compact;
+    s.b = f.b >= 0 ? g->nodes[f.b].compact : -1;
+    s.joff = (int)(base[f.type] + (int64_t)f.slot * kJSize[f.type]);
+    sf.push_back(s);
+  }
+  if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
+  if (const char* e = getenv("PPS_MAX_PIVOTS")) g->aprm.max_pivots = atoi(e);
+  const char* msg = "";
+  if (!analyze(sn, sf, g->aprm, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+  g->level_max_front.assign(g->an.n_levels, 0);
+  for (int s = 0; s < g->an.n_fronts; s++) {
+    int& m = g->level_max_front[g->an.f_level[s]];
+    m = std::max(m, g->an.f_p[s] + g->an.f_b[s]);
+  }
+  g->analyzed = true;
+  g->stats.n_fronts = g->an.n_fronts; g->stats.n_levels = g->an.n_levels; g->stats.max_front = g->an.max_front;
+  g->stats.nnz_L = g->an.L_size;
+  g->stats.t_analysis = now_s() - t0;
+  return PPS_OK;
+}
+
+// pull the device estimate back into the host node table
+int download_state(pps_graph* g) {
+  if (!g->dev_values_newer) return PPS_OK;
+  const DevGraph& d = g->dev;
+  std::vector<double> bp((size_t)7 * d.pose_ld), bl((size_t)4 * d.plane_ld);
+  if (d.n_pose) HIP_TRY(g, hipMemcpyAsync(bp.data(), d.pose_est, bp.size() * 8, hipMemcpyDeviceToHost, g->stream));
+  if (d.n_plane) HIP_TRY(g, hipMemcpyAsync(bl.data(), d.plane_est, bl.size() * 8, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) g->nodes[g->pose_ids[s]].v[k] = bp[(size_t)k * d.pose_ld + s];
+  for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) g->nodes[g->plane_ids[s]].v[k] = bl[(size_t)k * d.plane_ld + s];
+  g->dev_values_newer = false;
+  return PPS_OK;
+}
+
+int upload_state(pps_graph* g) {
+  DevGraph& d = g->dev;
+  std::vector<double> bp((size_t)7 * d.pose_ld, 0.0), bl((size_t)4 * d.plane_ld, 0.0);
+  for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) bp[(size_t)k * d.pose_ld + s] = g->nodes[g->pose_ids[s]].v[k];
+  for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) bl[(size_t)k * d.plane_ld + s] = g->nodes[g->plane_ids[s]].v[k];
+  if (d.n_pose) {
+    HIP_TRY(g, hipMemcpyAsync(d.pose_est, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(d.pose_lin, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, g->stream));
+  }
+  if (d.n_plane) {
+    HIP_TRY(g, hipMemcpyAsync(d.plane_est, bl.data(), bl.size() * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(d.plane_lin, bl.data(), bl.size() * 8, hipMemcpyHostToDevice, g->stream));
+  }
+  HIP_TRY(g, hipStreamSynchronize(g->stream));   // staging vectors die at scope exit
+  g->host_values_newer = false;
+  return PPS_OK;
+}
+
+template <int K>
+void pack_soa(const pps_graph* g, int type, const double HostFactor::*dummy, bool weights, std::vector<double>& out) {
+  (void)dummy;
+  const std::vector<int>& ids = g->fslot_ids[type];
+  const size_t n = ids.size();
+  out.assign((size_t)K * n, 0.0);
+  for (size_t s = 0; s < n; s++) {
+    const HostFactor& f = g->factors[ids[s]];
+    const double* src = weights ? f.w : f.meas;
+    for (int k = 0; k < K; k++) out[(size_t)k * n + s] = src[k];
+  }
+}
+
+int upload_measurements(pps_graph* g) {
+  DevGraph& d = g->dev;
+  std::vector<double> m;
+  pack_soa<4>(g, F_PLANE_OBS, nullptr, false, m);
+  if (!m.empty()) HIP_TRY(g, hipMemcpyAsync(d.obs_meas, m.data(), m.size() * 8, hipMemcpyHostToDevice, g->stream));
+  std::vector<double> m2;
+  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, m2);
+  if (!m2.empty()) HIP_TRY(g, hipMemcpyAsync(d.lp_meas, m2.data(), m2.size() * 8, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  g->meas_dirty = false;
+  return PPS_OK;
+}
+
+int upload_all(pps_graph* g) {
+  const double t0 = now_s();
+  int rc = ensure_device(g);
+  if (rc != PPS_OK) return rc;
+  if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  free_device(g);
+  if (!g->analyzed || g->topo_dirty) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
+  const Analysis& A = g->an;
+  DevGraph& d = g->dev;
+  d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
+  d.pose_ld = std::max(1, (d.n_pose + 63) / 64 * 64); d.plane_ld = std::max(1, (d.n_plane + 63) / 64 * 64);
+#define TRY(x) do { rc = (x); if (rc != PPS_OK) return rc; } while (0)
+  TRY(dev_alloc(g, &d.pose_est, (size_t)7 * d.pose_ld)); TRY(dev_alloc(g, &d.pose_lin, (size_t)7 * d.pose_ld));
+  TRY(dev_alloc(g, &d.plane_est, (size_t)4 * d.plane_ld)); TRY(dev_alloc(g, &d.plane_lin, (size_t)4 * d.plane_ld));
+  std::vector<int> pv(d.n_pose), lv(d.n_plane);
+  for (int s = 0; s < d.n_pose; s++) pv[s] = A.node_voff[g->nodes[g->pose_ids[s]].compact];
+  for (int s = 0; s < d.n_plane; s++) lv[s] = A.node_voff[g->nodes[g->plane_ids[s]].compact];
+  TRY(dev_upload(g, &d.pose_voff, pv)); TRY(dev_upload(g, &d.plane_voff, lv));
+  // factors
+  d.n_obs = (int)g->fslot_ids[F_PLANE_OBS].size(); d.n_odo = (int)g->fslot_ids[F_ODOMETRY].size();
+  d.n_pp = (int)g->fslot_ids[F_POSE_PRIOR].size(); d.n_lp = (int)g->fslot_ids[F_PLANE_PRIOR].size();
+  d.joff_obs = 0; d.joff_odo = (int64_t)d.n_obs * 30; d.joff_pp = d.joff_odo + (int64_t)d.n_odo * 78;
+  d.joff_lp = d.joff_pp + (int64_t)d.n_pp * 42;
+  auto idx_of = [&](int type, bool second) {
+    std::vector<int> v(g->fslot_ids[type].size());
+    for (size_t s = 0; s < v.size(); s++) {
+      const HostFactor& f = g->factors[g->fslot_ids[type][s]];
+      v[s] = g->nodes[second ? f.b : f.a].slot;
+    }
+    return v;
+  };
+  std::vector<double> tmp;
+  TRY(dev_upload(g, &d.obs_pose, idx_of(F_PLANE_OBS, false))); TRY(dev_upload(g, &d.obs_plane, idx_of(F_PLANE_OBS, true)));
+  pack_soa<4>(g, F_PLANE_OBS, nullptr, false, tmp); TRY(dev_upload(g, &d.obs_meas, tmp));
+  pack_soa<6>(g, F_PLANE_OBS, nullptr, true, tmp); TRY(dev_upload(g, &d.obs_w, tmp));
+  TRY(dev_upload(g, &d.odo_a, idx_of(F_ODOMETRY, false))); TRY(dev_upload(g, &d.odo_b, idx_of(F_ODOMETRY, true)));
+  pack_soa<6>(g, F_ODOMETRY, nullptr, false, tmp); TRY(dev_upload(g, &d.odo_meas, tmp));
+  pack_soa<21>(g, F_ODOMETRY, nullptr, true, tmp); TRY(dev_upload(g, &d.odo_w, tmp));
+  TRY(dev_upload(g, &d.pp_pose, idx_of(F_POSE_PRIOR, false)));
+  pack_soa<6>(g, F_POSE_PRIOR, nullptr, false, tmp); TRY(dev_upload(g, &d.pp_meas, tmp));
+  pack_soa<21>(g, F_POSE_PRIOR, nullptr, true, tmp); TRY(dev_upload(g, &d.pp_w, tmp));
+  TRY(dev_upload(g, &d.lp_plane, idx_of(F_PLANE_PRIOR, false)));
+  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, tmp); TRY(dev_upload(g, &d.lp_meas, tmp));
+  pack_soa<6>(g, F_PLANE_PRIOR, nullptr, true, tmp); TRY(dev_upload(g, &d.lp_w, tmp));
+  // linear system storage
+  TRY(dev_alloc(g, &d.J, (size_t)A.J_size)); TRY(dev_alloc(g, &d.H, (size_t)A.H_size));
+  TRY(dev_alloc(g, &d.L, (size_t)A.L_size)); TRY(dev_alloc(g, &d.U, (size_t)A.U_size));
+  TRY(dev_alloc(g, &d.delta, (size_t)A.n_scalars));
+  HIP_TRY(g, hipMemsetAsync(d.delta, 0, (size_t)std::max(1, A.n_scalars) * 8, g->stream));
+  d.n_scalars = A.n_scalars;
+  d.n_fronts = A.n_fronts; d.n_levels = A.n_levels; d.max_front = A.max_front; d.n_segs = A.n_segs; d.n_blocks = A.n_blocks;
+  TRY(dev_upload(g, &d.f_p, A.f_p)); TRY(dev_upload(g, &d.f_b, A.f_b)); TRY(dev_upload(g, &d.f_poff, A.f_poff));
+  TRY(dev_upload(g, &d.f_Loff, A.f_Loff)); TRY(dev_upload(g, &d.f_Uoff, A.f_Uoff));
+  TRY(dev_upload(g, &d.f_bidx_off, A.f_bidx_off)); TRY(dev_upload(g, &d.bidx, A.bidx));
+  TRY(dev_upload(g, &d.f_child_off, A.f_child_off)); TRY(dev_upload(g, &d.child, A.child));
+  TRY(dev_upload(g, &d.f_cmap_off, A.f_cmap_off)); TRY(dev_upload(g, &d.cmap, A.cmap));
+  TRY(dev_upload(g, &d.level_fronts, A.level_fronts));
+  TRY(dev_upload(g, &d.f_asm_off, A.f_asm_off)); TRY(dev_upload(g, &d.asm_blk, A.asm_blk));
+  TRY(dev_upload(g, &d.asm_lrow, A.asm_lrow)); TRY(dev_upload(g, &d.asm_lcol, A.asm_lcol));
+  TRY(dev_upload(g, &d.blk_rows, A.blk_rows)); TRY(dev_upload(g, &d.blk_cols, A.blk_cols));
+  TRY(dev_upload(g, &d.blk_size, A.blk_size)); TRY(dev_upload(g, &d.blk_nseg, A.blk_nseg));
+  TRY(dev_upload(g, &d.blk_hoff, A.blk_hoff));
+  TRY(dev_upload(g, &d.seg_blk, A.seg_blk)); TRY(dev_upload(g, &d.seg_c0, A.seg_c0)); TRY(dev_upload(g, &d.seg_cnt, A.seg_cnt));
+  TRY(dev_upload(g, &d.seg_hoff, A.seg_hoff));
+  TRY(dev_upload(g, &d.contrib, A.contrib));
+  d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
+  TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
+  TRY(dev_alloc(g, &d.result_dev, 4));
+  // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
+  if (A.max_front > lds_front_limit()) {
+    const int fa = A.max_front + 1;
+    d.gwork_stride = (int64_t)fa * (fa | 1);
+    int widest = 0;
+    for (int l = 0; l < A.n_levels; l++)
+      if (g->level_max_front[l] > lds_front_limit()) widest = std::max(widest, A.level_off[l + 1] - A.level_off[l]);
+    TRY(dev_alloc(g, &d.gwork, (size_t)d.gwork_stride * std::max(1, widest)));
+  }
+#undef TRY
+  HIP_TRY(g, hipStreamSynchronize(g->stream));   // host staging vectors go out of scope
+  g->topo_dirty = false;
+  g->meas_dirty = false;
+  rc = upload_state(g);
+  g->stats.t_upload = now_s() - t0 - g->stats.t_analysis;
+  return rc;
+}
+
+int prepare_solve(pps_graph* g) {
+  int rc;
+  if (g->n_live_nodes == 0) return fail(g, PPS_ESTATE, "empty graph");
+  if (g->topo_dirty || !g->dev_ready || g->dev.n_scalars == 0) { rc = upload_all(g); if (rc != PPS_OK) return rc; }
+  if (g->host_values_newer) { rc = upload_state(g); if (rc != PPS_OK) return rc; }
+  if (g->meas_dirty) { rc = upload_measurements(g); if (rc != PPS_OK) return rc; }
+  return PPS_OK;
+}
+
+struct PhaseTimer {
+  pps_graph* g; double* acc; bool on;
+  PhaseTimer(pps_graph* g_, double* a) : g(g_), acc(a), on(g_->profiling) { if (on) (void)hipEventRecord(g->ev[0], g->stream); }
+  ~PhaseTimer() {
+    if (!on) return;
+    (void)hipEventRecord(g->ev[1], g->stream);
+    (void)hipEventSynchronize(g->ev[1]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, g->ev[0], g->ev[1]);
+    *acc += 1e-3 * ms;
+  }
+};
+
+// linearise at `lin` (K1) and reduce the H blocks (K2)
+int do_linearize(pps_graph* g) {
+  { PhaseTimer t(g, &g->stats.t_linearize); HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream)); }
+  { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream)); }
+  g->stats.n_linearize++;
+  return PPS_OK;
+}
+
+// delta = (J'J + lambda diag(J'J))^-1 J'b  (Optimizer::compute_gauss_newton_step, Optimizer.cpp:49-67)
+int do_solve(pps_graph* g, double lambda) {
+  const Analysis& A = g->an;
+  {
+    PhaseTimer t(g, &g->stats.t_factor);
+    for (int l = 0; l < A.n_levels; l++)
+      HIP_TRY(g, launch_factor_level(g->dev, A.level_off[l], A.level_off[l + 1] - A.level_off[l], g->level_max_front[l], lambda,
+                                     g->stream));
+  }
+  {
+    PhaseTimer t(g, &g->stats.t_backsolve);
+    for (int l = A.n_levels - 1; l >= 0; l--)
+      HIP_TRY(g, launch_backsolve_level(g->dev, A.level_off[l], A.level_off[l + 1] - A.level_off[l], g->stream));
+  }
+  g->stats.n_factorize++;
+  return PPS_OK;
+}
+
+int copy_state(pps_graph* g, bool est_to_lin) {
+  const DevGraph& d = g->dev;
+  double *ps = est_to_lin ? d.pose_est : d.pose_lin, *pd = est_to_lin ? d.pose_lin : d.pose_est;
+  double *ls = est_to_lin ? d.plane_est : d.plane_lin, *ld = est_to_lin ? d.plane_lin : d.plane_est;
+  if (d.n_pose) HIP_TRY(g, hipMemcpyAsync(pd, ps, (size_t)7 * d.pose_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  if (d.n_plane) HIP_TRY(g, hipMemcpyAsync(ld, ls, (size_t)4 * d.plane_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  return PPS_OK;
+}
+
+// chi2 (and |delta|^2, not-PD flag) -> host
+int read_result(pps_graph* g, bool at_estimate, double* chi2, double* dnorm, bool* notpd) {
+  {
+    PhaseTimer t(g, &g->stats.t_retract_chi2);
+    HIP_TRY(g, launch_chi2(g->dev, at_estimate, g->host_result, g->stream));
+  }
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  *chi2 = g->host_result[0];
+  if (dnorm) *dnorm = std::sqrt(g->host_result[1]);
+  if (notpd) *notpd = g->host_result[2] != 0.0;
+  return PPS_OK;
+}
+
+void reset_solve_stats(pps_graph* g) {
+  pps_stats& s = g->stats;
+  s.t_linearize = s.t_assemble = s.t_factor = s.t_backsolve = s.t_retract_chi2 = 0;
+  s.n_linearize = s.n_factorize = 0;
+  s.lm_iterations = s.lm_trials_accepted = s.lm_trials_rejected = 0;
+  s.t_analysis = s.t_upload = 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+void pps_default_props(pps_props* p) {
+  if (!p) return;
+  p->epsilon2 = 1e-2 * 0.1;      // Properties.h:94 x Mapping.cpp:37
+  p->epsilon_abs = 1e-3 * 0.1;   // Properties.h:98 x Mapping.cpp:38
+  p->epsilon_rel = 1e-5 * 0.1;   // Properties.h:99 x Mapping.cpp:39
+  p->max_iterations = 500;
+  p->lm_lambda0 = 1e-6;
+  p->lm_lambda_factor = 10.;
+  p->jacobian_mode = PPS_JAC_NUMERIC;
+  p->device = 0;
+  p->verbose = 0;
+}
+
+int pps_version(void) { return PPS_VERSION; }
+
+const char* pps_last_error(const pps_graph* g) { return g ? g->err.c_str() : "null handle"; }
+
+int pps_graph_create(const pps_props* props, pps_graph** out) {
+  if (!out) return PPS_EINVAL;
+  pps_graph* g = new (std::nothrow) pps_graph();
+  if (!g) return PPS_ENOMEM;
+  if (props) g->props = *props; else pps_default_props(&g->props);
+  *out = g;
+  return PPS_OK;
+}
+
+int pps_graph_destroy(pps_graph* g) {
+  if (!g) return PPS_EINVAL;
+  if (g->dev_ready) {
+    (void)hipSetDevice(g->props.device);
+    (void)hipStreamSynchronize(g->stream);
+    free_device(g);
+    if (g->host_result) (void)hipHostFree(g->host_result);
+    if (g->ev[0]) (void)hipEventDestroy(g->ev[0]);
+    if (g->ev[1]) (void)hipEventDestroy(g->ev[1]);
+    (void)hipStreamDestroy(g->stream);
+  }
+  delete g;
+  return PPS_OK;
+}
+
+int pps_get_props(const pps_graph* g, pps_props* out) {
+  if (!g || !out) return PPS_EINVAL;
+  *out = g->props;
+  return PPS_OK;
+}
+int pps_set_props(pps_graph* g, const pps_props* p) {
+  if (!g || !p) return PPS_EINVAL;
+  if (g->dev_ready && p->device != g->props.device) return fail(g, PPS_ESTATE, "device cannot change after the first solve");
+  g->props = *p;
+  return PPS_OK;
+}
+
+static int add_node(pps_graph* g, int type, const double* v, int nv, int* id) {
+  if (!g || !v) return PPS_EINVAL;
+  for (int k = 0; k < nv; k++) if (!std::isfinite(v[k])) return fail(g, PPS_EINVAL, "non-finite node value");
+  if (g->dev_values_newer) { int rc = download_state(g); if (rc != PPS_OK) return rc; }
+  HostNode n{};
+  n.type = type;
+  for (int k = 0; k < nv; k++) n.v[k] = v[k];
+  if (type == NODE_PLANE) normalize4(n.v);
+  n.deleted = false; n.compact = n.slot = -1;
+  g->nodes.push_back(n);
+  g->n_live_nodes++;
+  g->dim_nodes += type == NODE_POSE ? 6 : 3;
+  g->topo_dirty = true; g->host_values_newer = true;
+  if (id) *id = (int)g->nodes.size() - 1;
+  return PPS_OK;
+}
+
+int pps_add_pose(pps_graph* g, const double tq[7], int* id) { return add_node(g, NODE_POSE, tq, 7, id); }
+int pps_add_plane(pps_graph* g, const double abcd[4], int* id) { return add_node(g, NODE_PLANE, abcd, 4, id); }
+
+static bool live_node(const pps_graph* g, int id, int type) {
+  return id >= 0 && id < (int)g->nodes.size() && !g->nodes[id].deleted && g->nodes[id].type == type;
+}
+
+static int add_factor(pps_graph* g, int type, int a, int b, const double* meas, int nm, const double* ut, int nw, int* fid) {
+  if (!g || !meas || !ut) return PPS_EINVAL;
+  for (int k = 0; k < nm; k++) if (!std::isfinite(meas[k])) return fail(g, PPS_EINVAL, "non-finite measurement");
+  for (int k = 0; k < nw; k++) if (!std::isfinite(ut[k])) return fail(g, PPS_EINVAL, "non-finite sqrtinf");
+  HostFactor f{};
+  f.type = type; f.a = a; f.b = b; f.deleted = false; f.slot = -1;
+  for (int k = 0; k < nm; k++) f.meas[k] = meas[k];
+  if (nm == 4) normalize4(f.meas);
+  for (int k = 0; k < nw; k++) f.w[k] = ut[k];
+  g->factors.push_back(f);
+  g->n_live_factors++;
+  g->dim_measure += kFDim[type];
+  g->topo_dirty = true;
+  if (fid) *fid = (int)g->factors.size() - 1;
+  return PPS_OK;
+}
+
+int pps_add_pose_prior(pps_graph* g, int pose, const double meas6[6], const double ut[21], int* fid) {
+  if (!g) return PPS_EINVAL;
+  if (!live_node(g, pose, NODE_POSE)) return fail(g, PPS_EINVAL, "pose prior: unknown pose id");
+  return add_factor(g, F_POSE_PRIOR, pose, -1, meas6, 6, ut, 21, fid);
+}
+int pps_add_odometry(pps_graph* g, int p1, int p2, const double meas6[6], const double ut[21], int* fid) {
+  if (!g) return PPS_EINVAL;
+  if (!live_node(g, p1, NODE_POSE) || !live_node(g, p2, NODE_POSE) || p1 == p2) return fail(g, PPS_EINVAL, "odometry: bad pose ids");
+  return add_factor(g, F_ODOMETRY, p1, p2, meas6, 6, ut, 21, fid);
+}
+int pps_add_plane_obs(pps_graph* g, int pose, int plane, const double meas4[4], const double ut[6], int* fid) {
+  if (!g) return PPS_EINVAL;
+  if (!live_node(g, pose, NODE_POSE) || !live_node(g, plane, NODE_PLANE)) return fail(g, PPS_EINVAL, "plane obs: bad node ids");
+  return add_factor(g, F_PLANE_OBS, pose, plane, meas4, 4, ut, 6, fid);
+}
+int pps_add_plane_prior(pps_graph* g, int plane, const double meas4[4], const double ut[6], int* fid) {
+  if (!g) return PPS_EINVAL;
+  if (!live_node(g, plane, NODE_PLANE)) return fail(g, PPS_EINVAL, "plane prior: unknown plane id");
+  return add_factor(g, F_PLANE_PRIOR, plane, -1, meas4, 4, ut, 6, fid);
+}
+
+int pps_set_measurement(pps_graph* g, int fid, const double meas4[4]) { return pps_set_measurements(g, 1, &fid, meas4); }
+
+int pps_set_measurements(pps_graph* g, int n, const int* fids, const double* meas4) {
+  if (!g || !fids || !meas4 || n < 0) return PPS_EINVAL;
+  for (int i = 0; i < n; i++) {
+    const int fid = fids[i];
+    if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "set_measurement: unknown factor id");
+    HostFactor& f = g->factors[fid];
+    if (f.type != F_PLANE_OBS && f.type != F_PLANE_PRIOR) return fail(g, PPS_EINVAL, "set_measurement: not a plane factor");
+    for (int k = 0; k < 4; k++) {
+      if (!std::isfinite(meas4[4 * i + k])) return fail(g, PPS_EINVAL, "non-finite measurement");
+      f.meas[k] = meas4[4 * i + k];
+    }
+    normalize4(f.meas);
+  }
+  g->meas_dirty = true;
+  return PPS_OK;
+}
+
+int pps_remove_factor(pps_graph* g, int fid) {
+  if (!g) return PPS_EINVAL;
+  if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "remove_factor: unknown id");
+  g->factors[fid].deleted = true;
+  g->n_live_factors--;
+  g->dim_measure -= kFDim[g->factors[fid].type];
+  g->topo_dirty = true;
+  return PPS_OK;
+}
+
+int pps_remove_node(pps_graph* g, int nid) {
+  if (!g) return PPS_EINVAL;
+  if (nid < 0 || nid >= (int)g->nodes.size() || g->nodes[nid].deleted) return fail(g, PPS_EINVAL, "remove_node: unknown id");
+  if (g->dev_values_newer) { int rc = download_state(g); if (rc != PPS_OK) return rc; }
+  for (size_t i = 0; i < g->factors.size(); i++) {
+    HostFactor& f = g->factors[i];
+    if (!f.deleted && (f.a == nid || f.b == nid)) pps_remove_factor(g, (int)i);
+  }
+  g->nodes[nid].deleted = true;
+  g->n_live_nodes--;
+  g->dim_nodes -= g->nodes[nid].type == NODE_POSE ? 6 : 3;
+  g->topo_dirty = true; g->host_values_newer = true;
+  return PPS_OK;
+}
+
+int pps_update(pps_graph* g) {
+  if (!g) return PPS_EINVAL;
+  const double t0 = now_s();
+  reset_solve_stats(g);
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+  rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:116)
+  rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:119)
+  rc = do_solve(g, 0.0); if (rc != PPS_OK) return rc;             // compute_gauss_newton_step, lambda = 0 (:122)
+  { PhaseTimer t(g, &g->stats.t_retract_chi2); HIP_TRY(g, launch_retract_apply(g->dev, g->stream)); }   // apply_exmap (:183)
+  double chi2, dn; bool notpd;
+  rc = read_result(g, true, &chi2, &dn, &notpd); if (rc != PPS_OK) return rc;
+  g->dev_values_newer = true;
+  g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
+  g->stats.t_total = now_s() - t0;
+  if (notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite");
+  return PPS_OK;
+}
+
+int pps_batch_optimize(pps_graph* g, int* iterations) {
+  if (!g) return PPS_EINVAL;
+  const double t0 = now_s();
+  reset_solve_stats(g);
+  g->tr_lambda.clear(); g->tr_chi2.clear(); g->tr_acc.clear();
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  const pps_props& prop = g->props;
+  HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+  int num_iter = 0;
+  double lambda = prop.lm_lambda0;
+  double* slot0 = g->host_result;       // chi2 at the linearisation point
+  double* slot1 = g->host_result + 4;   // speculative trial: |delta|^2 of the step and chi2 after it
+  // One stream, one host sync per LM trial.  After every solve the trial step is applied
+  // speculatively (est <- lin, lin <- lin (+) delta) and its chi2 is reduced, so a single result
+  // record carries everything the loop condition and the accept test need; if the loop ends on
+  // |delta| <= eps2 the speculative step is undone (lin <- est).
+  auto enqueue_trial = [&](double lam) -> int {
+    int r = do_solve(g, lam); if (r != PPS_OK) return r;                       // compute_gauss_newton_step (:395,458)
+    { PhaseTimer t(g, &g->stats.t_retract_chi2);
+      HIP_TRY(g, launch_retract_trial(g->dev, g->stream));                     // linpoint_to_estimate + self_exmap (:414-416)
+      HIP_TRY(g, launch_chi2(g->dev, false, slot1, g->stream)); }              // weighted_errors(LINPOINT) (:417)
+    return PPS_OK;
+  };
+  rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:376)
+  rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:379)
+  HIP_TRY(g, launch_chi2(g->dev, false, slot0, g->stream));       // r = weighted_errors(LINPOINT); error = |r|^2 (:382-385)
+  rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  double error = slot0[0];
+  g->stats.chi2_initial = error;
+  double dnorm = std::sqrt(slot1[1]);
+  bool any_notpd = slot1[2] != 0.0;
+  bool trial_pending = true;
+  while ((prop.max_iterations <= 0 || num_iter < prop.max_iterations) && dnorm > prop.epsilon2 && error > prop.epsilon_abs) {
+    num_iter++;
+    const double error_new = slot1[0];
+    const double error_diff = error - error_new;
+    const bool accepted = error_diff > 0.;
+    g->tr_lambda.push_back(lambda); g->tr_chi2.push_back(error_new); g->tr_acc.push_back(accepted ? 1 : 0);
+    if (prop.verbose) fprintf(stderr, "LM Iteration %d: (lambda=%g) %s %.12g\n", num_iter, lambda, accepted ? "residual:" : "rejected", error_new);
+    if (accepted) {
+      g->stats.lm_trials_accepted++;
+      if (error_diff < prop.epsilon_rel * error) { error = error_new; trial_pending = false; break; }   // (:431-434)
+      lambda /= prop.lm_lambda_factor;
+      error = error_new;
+      rc = do_linearize(g); if (rc != PPS_OK) return rc;          // relinearise around the accepted point (:444)
+    } else {
+      g->stats.lm_trials_rejected++;
+      lambda *= prop.lm_lambda_factor;
+      rc = copy_state(g, true); if (rc != PPS_OK) return rc;      // estimate_to_linpoint: restore (:454)
+    }
+    rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    dnorm = std::sqrt(slot1[1]);
+    any_notpd = any_notpd || slot1[2] != 0.0;
+  }
+  if (trial_pending) { rc = copy_state(g, true); if (rc != PPS_OK) return rc; }   // undo the speculative step
+  rc = copy_state(g, false); if (rc != PPS_OK) return rc;         // linpoint_to_estimate (:466)
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  g->dev_values_newer = true;
+  g->stats.lm_iterations = num_iter;
+  g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
+  g->stats.t_total = now_s() - t0;
+  if (iterations) *iterations = num_iter;
+  if (any_notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite");
+  return PPS_OK;
+}
+
+int pps_chi2(pps_graph* g, double* chi2) {
+  if (!g || !chi2) return PPS_EINVAL;
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  double dn; bool np;
+  return read_result(g, true, chi2, &dn, &np);
+}
+
+int pps_num_nodes(const pps_graph* g, int* n) { if (!g || !n) return PPS_EINVAL; *n = g->n_live_nodes; return PPS_OK; }
+int pps_num_factors(const pps_graph* g, int* n) { if (!g || !n) return PPS_EINVAL; *n = g->n_live_factors; return PPS_OK; }
+
+int pps_get_pose(pps_graph* g, int id, double tq[7]) {
+  if (!g || !tq) return PPS_EINVAL;
+  if (!live_node(g, id, NODE_POSE)) return fail(g, PPS_EINVAL, "get_pose: unknown id");
+  int rc = download_state(g); if (rc != PPS_OK) return rc;
+  memcpy(tq, g->nodes[id].v, 7 * sizeof(double));
+  return PPS_OK;
+}
+int pps_get_plane(pps_graph* g, int id, double abcd[4]) {
+  if (!g || !abcd) return PPS_EINVAL;
+  if (!live_node(g, id, NODE_PLANE)) return fail(g, PPS_EINVAL, "get_plane: unknown id");
+  int rc = download_state(g); if (rc != PPS_OK) return rc;
+  memcpy(abcd, g->nodes[id].v, 4 * sizeof(double));
+  return PPS_OK;
+}
+int pps_set_pose(pps_graph* g, int id, const double tq[7]) {
+  if (!g || !tq) return PPS_EINVAL;
+  if (!live_node(g, id, NODE_POSE)) return fail(g, PPS_EINVAL, "set_pose: unknown id");
+  int rc = download_state(g); if (rc != PPS_OK) return rc;
+  memcpy(g->nodes[id].v, tq, 7 * sizeof(double));
+  g->host_values_newer = true;
+  return PPS_OK;
+}
+int pps_set_plane(pps_graph* g, int id, const double abcd[4]) {
+  if (!g || !abcd) return PPS_EINVAL;
+  if (!live_node(g, id, NODE_PLANE)) return fail(g, PPS_EINVAL, "set_plane: unknown id");
+  int rc = download_state(g); if (rc != PPS_OK) return rc;
+  memcpy(g->nodes[id].v, abcd, 4 * sizeof(double));
+  normalize4(g->nodes[id].v);
+  g->host_values_newer = true;
+  return PPS_OK;
+}
+
+static int get_bulk(pps_graph* g, int type, int n, const int* ids, double* out, int w) {
+  if (!g || !out || n < 0) return PPS_EINVAL;
+  int rc = download_state(g); if (rc != PPS_OK) return rc;
+  if (ids) {
+    for (int i = 0; i < n; i++) {
+      if (!live_node(g, ids[i], type)) return fail(g, PPS_EINVAL, "bulk get: unknown id");
+      memcpy(out + (size_t)w * i, g->nodes[ids[i]].v, w * sizeof(double));
+    }
+  } else {
+    int k = 0;
+    for (size_t i = 0; i < g->nodes.size() && k < n; i++)
+      if (!g->nodes[i].deleted && g->nodes[i].type == type) { memcpy(out + (size_t)w * k, g->nodes[i].v, w * sizeof(double)); k++; }
+    if (k != n) return fail(g, PPS_EINVAL, "bulk get: count mismatch");
+  }
+  return PPS_OK;
+}
+int pps_get_poses(pps_graph* g, int n, const int* ids, double* out) { return get_bulk(g, NODE_POSE, n, ids, out, 7); }
+int pps_get_planes(pps_graph* g, int n, const int* ids, double* out) { return get_bulk(g, NODE_PLANE, n, ids, out, 4); }
+
+int pps_get_stats(const pps_graph* g, pps_stats* out) {
+  if (!g || !out) return PPS_EINVAL;
+  *out = g->stats;
+  out->n_poses = out->n_planes = 0;
+  for (const auto& n : g->nodes) if (!n.deleted) (n.type == NODE_POSE ? out->n_poses : out->n_planes)++;
+  out->n_factors = g->n_live_factors;
+  out->dim_nodes = g->dim_nodes; out->dim_measure = g->dim_measure;
+  return PPS_OK;
+}
+
+int pps_get_trace(const pps_graph* g, int cap, double* lambda, double* chi2, int* accepted, int* n) {
+  if (!g || !n) return PPS_EINVAL;
+  *n = (int)g->tr_lambda.size();
+  for (int i = 0; i < *n && i < cap; i++) {
+    if (lambda) lambda[i] = g->tr_lambda[i];
+    if (chi2) chi2[i] = g->tr_chi2[i];
+    if (accepted) accepted[i] = g->tr_acc[i];
+  }
+  return PPS_OK;
+}
+
+int pps_set_profiling(pps_graph* g, int on) { if (!g) return PPS_EINVAL; g->profiling = on != 0; return PPS_OK; }
+
+int pps_factor_shape(const pps_graph* g, int fid, int* dim, int* cols) {
+  if (!g) return PPS_EINVAL;
+  if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return PPS_EINVAL;
+  const HostFactor& f = g->factors[fid];
+  if (dim) *dim = kFDim[f.type];
+  if (cols) *cols = (g->nodes[f.a].type == NODE_POSE ? 6 : 3) + (f.b >= 0 ? (g->nodes[f.b].type == NODE_POSE ? 6 : 3) : 0);
+  return PPS_OK;
+}
+
+int pps_eval_factor(pps_graph* g, int fid, int mode, double* J, double* r) {
+  if (!g || !J || !r) return PPS_EINVAL;
+  if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "eval_factor: unknown id");
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  HIP_TRY(g, launch_linearize(g->dev, mode, true, g->stream));
+  const HostFactor& f = g->factors[fid];
+  const int m = kFDim[f.type];
+  const int da = g->nodes[f.a].type == NODE_POSE ? 6 : 3;
+  const int db = f.b >= 0 ? (g->nodes[f.b].type == NODE_POSE ? 6 : 3) : 0;
+  const int64_t base[4] = {g->dev.joff_pp, g->dev.joff_odo, g->dev.joff_obs, g->dev.joff_lp};
+  std::vector<double> buf(kJSize[f.type]);
+  HIP_TRY(g, hipMemcpyAsync(buf.data(), g->dev.J + base[f.type] + (int64_t)f.slot * kJSize[f.type], buf.size() * 8,
+                            hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  const int cols = da + db;
+  for (int i = 0; i < m; i++) {
+    for (int j = 0; j < da; j++) J[i * cols + j] = buf[i * da + j];
+    for (int j = 0; j < db; j++) J[i * cols + da + j] = buf[m * da + i * db + j];
+    r[i] = buf[m * (da + db) + i];
+  }
+  return PPS_OK;
+}
+
+int pps_analyze(pps_graph* g) {
+  if (!g) return PPS_EINVAL;
+  if (g->n_live_nodes == 0) return fail(g, PPS_ESTATE, "empty graph");
+  return run_analysis(g);
+}
+
+int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed) {
+  if (!g || !needed) return PPS_EINVAL;
+  if (!g->analyzed || g->topo_dirty) { int rc = pps_analyze(g); if (rc != PPS_OK) return rc; }
+  std::vector<int32_t> v;
+  dump_analysis(g->an, v);
+  // append the compact-id tables the tests need: node id -> compact id, factor id -> joff
+  v.push_back((int32_t)g->nodes.size());
+  for (const auto& n : g->nodes) v.push_back(n.deleted ? -1 : n.compact);
+  const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(), n_obs = g->fslot_ids[F_PLANE_OBS].size();
+  const int64_t base[4] = {n_obs * 30 + n_odo * 78, n_obs * 30, 0, n_obs * 30 + n_odo * 78 + n_pp * 42};
+  v.push_back((int32_t)g->factors.size());
+  for (const auto& f : g->factors) v.push_back(f.deleted ? -1 : (int32_t)(base[f.type] + (int64_t)f.slot * kJSize[f.type]));
+  *needed = (int64_t)v.size();
+  if (out && cap >= (int64_t)v.size()) memcpy(out, v.data(), v.size() * sizeof(int32_t));
+  return PPS_OK;
+}
+
+int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec_per_sweep, int64_t* n_plane_edges,
+                    int64_t* n_odo_edges) {
+  if (!g || replicas < 1 || iters < 1 || !sec_per_sweep) return PPS_EINVAL;
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  DevGraph d = g->dev;   // shallow copy with replicated edge arrays
+  std::vector<void*> tmp;
+  auto rep = [&](auto** ptr, size_t count_per) -> int {
+    using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>;
+    if (count_per == 0) return PPS_OK;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, count_per * sizeof(T) * (size_t)replicas);
+    if (e != hipSuccess) return hip_fail(g, e, "hipMalloc(bench)");
+    tmp.push_back(p);
+    for (int r = 0; r < replicas; r++) {
+      e = hipMemcpyAsync(static_cast<char*>(p) + (size_t)r * count_per * sizeof(T), *ptr, count_per * sizeof(T),
+                         hipMemcpyDeviceToDevice, g->stream);
+      if (e != hipSuccess) return hip_fail(g, e, "hipMemcpyAsync(bench)");
+    }
+    *ptr = static_cast<T*>(p);
+    return PPS_OK;
+  };
+  auto cleanup = [&]() { (void)hipStreamSynchronize(g->stream); for (void* p : tmp) (void)hipFree(p); };
+#define BT(x) do { rc = (x); if (rc != PPS_OK) { cleanup(); return rc; } } while (0)
+  BT(rep(&d.obs_pose, (size_t)d.n_obs)); BT(rep(&d.obs_plane, (size_t)d.n_obs));
+  BT(rep(&d.obs_meas, (size_t)4 * d.n_obs)); BT(rep(&d.obs_w, (size_t)6 * d.n_obs));
+  BT(rep(&d.odo_a, (size_t)d.n_odo)); BT(rep(&d.odo_b, (size_t)d.n_odo));
+  BT(rep(&d.odo_meas, (size_t)6 * d.n_odo)); BT(rep(&d.odo_w, (size_t)21 * d.n_odo));
+#undef BT
+  const size_t slab = (size_t)d.n_obs * 30 + (size_t)d.n_odo * 78;
+  double* Jbig = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&Jbig), slab * sizeof(double) * (size_t)replicas);
+  if (e != hipSuccess) { cleanup(); return hip_fail(g, e, "hipMalloc(Jbig)"); }
+  tmp.push_back(Jbig);
+  e = launch_sweep_bench(d, mode, replicas, Jbig, g->stream);   // warm-up
+  if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+  float total_ms = 0;
+  for (int it = 0; it < iters && e == hipSuccess; it++) {
+    (void)hipEventRecord(g->ev[0], g->stream);
+    e = launch_sweep_bench(d, mode, replicas, Jbig, g->stream);
+    (void)hipEventRecord(g->ev[1], g->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(g->ev[1]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, g->ev[0], g->ev[1]);
+    total_ms += ms;
+  }
+  cleanup();
+  if (e != hipSuccess) return hip_fail(g, e, "sweep bench");
+  *sec_per_sweep = 1e-3 * total_ms / iters;
+  if (n_plane_edges) *n_plane_edges = (int64_t)d.n_obs * replicas;
+  if (n_odo_edges) *n_odo_edges = (int64_t)d.n_odo * replicas;
+  return PPS_OK;
+}
+
+}  // extern "C"

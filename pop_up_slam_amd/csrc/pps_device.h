@@ -1,0 +1,81 @@
+// pps_device.h -- device-side data layout and kernel launchers of the graph solve.
+//
+// HBM layout (all fp64 unless noted; everything for one graph stays resident):
+//   state        pose SoA [7][pose_ld] (tx,ty,tz,qx,qy,qz,qw), plane SoA [4][plane_ld]; two copies:
+//                `est` (estimate, NodeT::_value) and `lin` (linearisation point, NodeT::_value0).
+//   factors      SoA per type: int32 node indices, measurements, packed upper-triangular sqrtinf.
+//   J            AoS per factor [J_a | J_b | r]: plane edge 30, odometry 78, pose prior 42, plane prior 12 doubles.
+//   H            block-sparse J'J (lower triangle in elimination order) as per-segment partial blocks.
+//   L / U        multifrontal factor panels and update matrices, offsets from the symbolic analysis.
+//   delta, g     elimination-ordered vectors (front pivots are contiguous ranges).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pps {
+
+struct DevGraph {
+  // ---- state ----
+  int n_pose = 0, n_plane = 0, pose_ld = 0, plane_ld = 0;
+  double *pose_est = nullptr, *pose_lin = nullptr;
+  double *plane_est = nullptr, *plane_lin = nullptr;
+  int *pose_voff = nullptr, *plane_voff = nullptr;   // scalar offset of each node in delta
+  // ---- factors (SoA, leading dimension = count) ----
+  int n_obs = 0, n_odo = 0, n_pp = 0, n_lp = 0;
+  int *obs_pose = nullptr, *obs_plane = nullptr; double *obs_meas = nullptr, *obs_w = nullptr;
+  int *odo_a = nullptr, *odo_b = nullptr;         double *odo_meas = nullptr, *odo_w = nullptr;
+  int *pp_pose = nullptr;                          double *pp_meas = nullptr, *pp_w = nullptr;
+  int *lp_plane = nullptr;                         double *lp_meas = nullptr, *lp_w = nullptr;
+  // ---- linear system ----
+  double* J = nullptr;
+  int64_t joff_obs = 0, joff_odo = 0, joff_pp = 0, joff_lp = 0;
+  double* H = nullptr;       // segment slots
+  double* L = nullptr;
+  double* U = nullptr;
+  double* delta = nullptr;   // n_scalars
+  int n_scalars = 0;
+  // symbolic arrays (device copies of pps::Analysis)
+  int n_fronts = 0, n_levels = 0, max_front = 0, n_segs = 0, n_blocks = 0;
+  int *f_p = nullptr, *f_b = nullptr, *f_poff = nullptr;
+  int64_t *f_Loff = nullptr, *f_Uoff = nullptr;
+  int *f_bidx_off = nullptr, *bidx = nullptr;
+  int *f_child_off = nullptr, *child = nullptr;
+  int *f_cmap_off = nullptr, *cmap = nullptr;
+  int *level_fronts = nullptr;
+  int *f_asm_off = nullptr, *asm_blk = nullptr, *asm_lrow = nullptr, *asm_lcol = nullptr;
+  int *blk_rows = nullptr, *blk_cols = nullptr, *blk_size = nullptr, *blk_nseg = nullptr;
+  int64_t* blk_hoff = nullptr;
+  int *seg_blk = nullptr, *seg_c0 = nullptr, *seg_cnt = nullptr;
+  int64_t* seg_hoff = nullptr;
+  int* contrib = nullptr;
+  // ---- reductions / status ----
+  double* chi2_partials = nullptr;   // one per block of the residual sweep
+  int chi2_blocks = 0;
+  double* result_dev = nullptr;      // [0] chi2, [1] |delta|^2, [2] not-PD flag (as double), [3] reserved
+  double* gwork = nullptr;           // global-memory front workspace for fronts that exceed LDS
+  int64_t gwork_stride = 0;
+};
+
+// All launchers enqueue on `st` and return the HIP error of the launch.
+hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st);
+hipError_t launch_hblocks(const DevGraph& d, hipStream_t st);
+hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
+                               hipStream_t st);
+hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);
+// est <- lin ; lin <- lin (+) delta          (LM trial: Optimizer.cpp:414-416)
+hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st);
+// est <- lin (+) delta                        (GN step: Optimizer.cpp:183)
+hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st);
+// chi2 at lin (at_estimate=false) or est; result_dev[0] = chi2, [1] = |delta|^2; then copied to host_result
+hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, hipStream_t st);
+hipError_t launch_clear_status(const DevGraph& d, hipStream_t st);
+
+// Largest front (scalars incl. rhs row) the LDS path of the factor kernel accepts.
+int lds_front_limit();
+
+// K1 micro-benchmark over replicated edge arrays (pps_bench_sweep)
+hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, hipStream_t st);
+
+}  // namespace pps

@@ -1,0 +1,434 @@
+// pps_symbolic.cpp -- see pps_symbolic.h.
+#include "pps_symbolic.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <numeric>
+
+namespace pps {
+namespace {
+
+struct TNode {
+  std::vector<int> piv;   // node ids
+  std::vector<int> kids;  // tnode ids
+};
+
+struct Builder {
+  const std::vector<SymNode>& nodes;
+  const std::vector<SymFactor>& factors;
+  const AnalysisParams& prm;
+  int N;
+  std::vector<int> adj_off, adj;   // CSR, unique neighbours
+  std::vector<TNode> tree;
+  std::vector<int> lidx;           // scratch: node -> local pose index in the current call
+  std::vector<char> dense;
+
+  Builder(const std::vector<SymNode>& n, const std::vector<SymFactor>& f, const AnalysisParams& p)
+      : nodes(n), factors(f), prm(p), N((int)n.size()) {}
+
+  void build_adjacency() {
+    std::vector<std::pair<int, int>> e;
+    e.reserve(factors.size() * 2);
+    for (const auto& f : factors)
+      if (f.b >= 0 && f.a != f.b) { e.emplace_back(f.a, f.b); e.emplace_back(f.b, f.a); }
+    std::sort(e.begin(), e.end());
+    e.erase(std::unique(e.begin(), e.end()), e.end());
+    adj_off.assign(N + 1, 0);
+    for (auto& p : e) adj_off[p.first + 1]++;
+    for (int i = 0; i < N; i++) adj_off[i + 1] += adj_off[i];
+    adj.resize(e.size());
+    for (size_t i = 0; i < e.size(); i++) adj[i] = e[i].second;   // already grouped & sorted by first
+  }
+  int degree(int u) const { return adj_off[u + 1] - adj_off[u]; }
+
+  int new_tnode() { tree.emplace_back(); return (int)tree.size() - 1; }
+
+  // poses: node ids sorted by rank; planes: node ids.  Returns tnode id.
+  int dissect(std::vector<int> poses, std::vector<int> planes) {
+    const int n = (int)poses.size();
+    const int t = new_tnode();
+    if (n <= prm.leaf_poses) {
+      for (int pl : planes) tree[t].piv.push_back(pl);
+      for (int po : poses) tree[t].piv.push_back(po);
+      return t;
+    }
+    for (int i = 0; i < n; i++) lidx[poses[i]] = i;
+    // observer span of every plane inside this sub-chain
+    std::vector<int> pmin(planes.size(), n), pmax(planes.size(), -1);
+    std::vector<int> diff(n + 1, 0);
+    for (size_t k = 0; k < planes.size(); k++) {
+      const int pl = planes[k];
+      for (int q = adj_off[pl]; q < adj_off[pl + 1]; q++) {
+        const int li = lidx[adj[q]];
+        if (li < 0) continue;
+        pmin[k] = std::min(pmin[k], li);
+        pmax[k] = std::max(pmax[k], li);
+      }
+      if (pmax[k] - pmin[k] >= 2) { diff[pmin[k] + 1] += 3; diff[pmax[k]] -= 3; }  // spans m for pmin < m < pmax
+    }
+    // pose-pose edges that are not between chain neighbours
+    std::vector<std::pair<int, int>> cross;
+    for (int i = 0; i < n; i++) {
+      const int u = poses[i];
+      for (int q = adj_off[u]; q < adj_off[u + 1]; q++) {
+        const int v = adj[q];
+        if (nodes[v].type != NODE_POSE) continue;
+        const int lj = lidx[v];
+        if (lj > i + 1) { cross.emplace_back(i, lj); diff[i + 1] += 6; diff[lj] -= 6; }
+      }
+    }
+    int lo = std::max(1, n / 3), hi = std::min(n - 2, (2 * n) / 3);
+    if (hi < lo) { lo = hi = n / 2; }
+    int best = -1, best_cost = 1 << 30, run = 0;
+    std::vector<int> cost(n, 0);
+    for (int m = 0; m < n; m++) { run += diff[m]; cost[m] = run; }
+    for (int m = lo; m <= hi; m++) {
+      const int c = cost[m];
+      if (c < best_cost || (c == best_cost && std::abs(m - n / 2) < std::abs(best - n / 2))) { best_cost = c; best = m; }
+    }
+    const int m = best;
+    std::vector<char> in_sep(n, 0);
+    in_sep[m] = 1;
+    for (auto& e : cross)
+      if (e.first < m && e.second > m) in_sep[e.second] = 1;
+    std::vector<int> lposes, rposes, lplanes, rplanes, sep_planes, sep_poses;
+    for (int i = 0; i < n; i++) {
+      if (in_sep[i]) sep_poses.push_back(poses[i]);
+      else if (i < m) lposes.push_back(poses[i]);
+      else rposes.push_back(poses[i]);
+    }
+    for (size_t k = 0; k < planes.size(); k++) {
+      const int pl = planes[k];
+      // which sides still hold an observer once the separator poses are gone?
+      bool has_l = false, has_r = false;
+      for (int q = adj_off[pl]; q < adj_off[pl + 1]; q++) {
+        const int li = lidx[adj[q]];
+        if (li < 0 || in_sep[li]) continue;
+        if (li < m) has_l = true; else has_r = true;
+      }
+      if (has_l && has_r) sep_planes.push_back(pl);
+      else if (has_l) lplanes.push_back(pl);
+      else if (has_r) rplanes.push_back(pl);
+      else sep_planes.push_back(pl);   // attached to separator poses (or ancestors) only
+    }
+    for (int i = 0; i < n; i++) lidx[poses[i]] = -1;
+    for (int pl : sep_planes) tree[t].piv.push_back(pl);
+    for (int po : sep_poses) tree[t].piv.push_back(po);
+    if (!lposes.empty()) { const int c = dissect(std::move(lposes), std::move(lplanes)); tree[t].kids.push_back(c); }
+    if (!rposes.empty()) { const int c = dissect(std::move(rposes), std::move(rplanes)); tree[t].kids.push_back(c); }
+    return t;
+  }
+};
+
+}  // namespace
+
+bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
+             Analysis& A, const char** msg) {
+  static const char* kOk = "";
+  *msg = kOk;
+  A = Analysis();
+  const int N = (int)nodes.size();
+  A.n_nodes = N;
+  if (N == 0) { *msg = "empty graph"; return false; }
+  Builder B(nodes, factors, prm);
+  B.build_adjacency();
+  B.lidx.assign(N, -1);
+  B.dense.assign(N, 0);
+
+  // ---- 1. dense nodes -> root border ----
+  const double thr = std::max((double)prm.dense_min, prm.dense_mult * std::sqrt((double)N));
+  std::vector<int> dense_nodes, poses, planes;
+  for (int u = 0; u < N; u++) {
+    if (B.degree(u) > thr) { B.dense[u] = 1; dense_nodes.push_back(u); }
+    else if (nodes[u].type == NODE_POSE) poses.push_back(u);
+    else planes.push_back(u);
+  }
+  std::sort(poses.begin(), poses.end(), [&](int a, int b) { return nodes[a].rank < nodes[b].rank; });
+  // strip dense nodes from the adjacency the dissection sees
+  {
+    std::vector<int> off(N + 1, 0), a2;
+    a2.reserve(B.adj.size());
+    for (int u = 0; u < N; u++) {
+      for (int q = B.adj_off[u]; q < B.adj_off[u + 1]; q++)
+        if (!B.dense[B.adj[q]] && !B.dense[u]) a2.push_back(B.adj[q]);
+      off[u + 1] = (int)a2.size();
+    }
+    std::vector<int> full_off = B.adj_off, full_adj = B.adj;
+    B.adj_off.swap(off);
+    B.adj.swap(a2);
+    int top = -1;
+    if (!poses.empty() || !planes.empty()) top = B.dissect(poses, planes);
+    B.adj_off.swap(full_off);
+    B.adj.swap(full_adj);
+    int root = top;
+    if (!dense_nodes.empty()) {
+      root = B.new_tnode();
+      // planes first, poses last
+      for (int u : dense_nodes) if (nodes[u].type == NODE_PLANE) B.tree[root].piv.push_back(u);
+      for (int u : dense_nodes) if (nodes[u].type == NODE_POSE) B.tree[root].piv.push_back(u);
+      if (top >= 0) B.tree[root].kids.push_back(top);
+    }
+    // ---- 2./3. post-order over the separator tree; oversized supernodes are emitted as a chain of
+    // fronts (first chunk child-most: it receives the tnode's children) ----
+    std::vector<int> post;
+    post.reserve(B.tree.size());
+    {
+      std::vector<std::pair<int, size_t>> st;
+      st.emplace_back(root, 0);
+      while (!st.empty()) {
+        auto& top2 = st.back();
+        const int t = top2.first;
+        if (top2.second < B.tree[t].kids.size()) { const int c = B.tree[t].kids[top2.second++]; st.emplace_back(c, 0); }
+        else { post.push_back(t); st.pop_back(); }
+      }
+    }
+    A.node_pos.assign(N, -1);
+    A.node_voff.assign(N, -1);
+    A.order.clear();
+    std::vector<int> f_pos0, f_npiv;
+    std::vector<int> tn_last(B.tree.size(), -1);
+    int pos = 0, voff = 0;
+    for (int t : post) {
+      const TNode& tn = B.tree[t];
+      std::vector<std::vector<int>> chunks(1);
+      int acc = 0;
+      for (int u : tn.piv) {
+        if (acc + nodes[u].dim > prm.max_pivots && acc > 0) { chunks.emplace_back(); acc = 0; }
+        chunks.back().push_back(u);
+        acc += nodes[u].dim;
+      }
+      for (size_t k = 0; k < chunks.size(); k++) {
+        const int s = (int)A.f_p.size();
+        f_pos0.push_back(pos);
+        A.f_poff.push_back(voff);
+        for (int u : chunks[k]) {
+          if (A.node_pos[u] != -1) { *msg = "internal: node placed twice"; return false; }
+          A.node_pos[u] = pos++;
+          A.node_voff[u] = voff;
+          voff += nodes[u].dim;
+          A.order.push_back(u);
+        }
+        f_npiv.push_back(pos - f_pos0[s]);
+        A.f_p.push_back(voff - A.f_poff[s]);
+        A.f_parent.push_back(-1);
+        if (k == 0) { for (int c : tn.kids) A.f_parent[tn_last[c]] = s; }
+        else A.f_parent[s - 1] = s;
+      }
+      tn_last[t] = (int)A.f_p.size() - 1;
+    }
+    const int F = (int)A.f_p.size();
+    A.n_fronts = F;
+    A.f_b.assign(F, 0); A.f_level.assign(F, 0);
+    if (pos != N) { *msg = "internal: ordering does not cover all nodes"; return false; }
+    A.n_scalars = voff;
+
+    // ---- 4. boundaries ----
+    std::vector<std::vector<int>> bnd(F);
+    std::vector<std::vector<int>> kids(F);
+    for (int s = 0; s < F; s++) if (A.f_parent[s] >= 0) kids[A.f_parent[s]].push_back(s);
+    auto compute_boundaries = [&]() {
+      std::vector<int> stamp(N, -1);
+      for (int s = 0; s < F; s++) {
+        const int end = f_pos0[s] + f_npiv[s];
+        std::vector<int>& b = bnd[s];
+        b.clear();
+        for (int k = f_pos0[s]; k < end; k++) {
+          const int u = A.order[k];
+          for (int q = B.adj_off[u]; q < B.adj_off[u + 1]; q++) {
+            const int v = B.adj[q];
+            if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
+          }
+        }
+        for (int c : kids[s])
+          for (int v : bnd[c])
+            if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
+        std::sort(b.begin(), b.end(), [&](int x, int y) { return A.node_pos[x] < A.node_pos[y]; });
+      }
+    };
+    compute_boundaries();
+    // verify the separator property: every boundary node of s is a pivot of an ancestor of s,
+    // and every boundary node of a child is inside the parent's front.
+    std::vector<int> node_front(N);
+    for (int s = 0; s < F; s++)
+      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) node_front[A.order[k]] = s;
+    bool valid = true;
+    {
+      std::vector<int> anc_stamp(F, -1);
+      for (int s = 0; s < F && valid; s++) {
+        for (int x = A.f_parent[s]; x >= 0; x = A.f_parent[x]) anc_stamp[x] = s;
+        for (int v : bnd[s]) if (anc_stamp[node_front[v]] != s) { valid = false; break; }
+      }
+    }
+    if (!valid) {
+      // fall back to a chain: every later front is an ancestor, which is always a valid assembly tree
+      for (int s = 0; s < F; s++) { A.f_parent[s] = (s + 1 < F) ? s + 1 : -1; kids[s].clear(); }
+      for (int s = 0; s + 1 < F; s++) kids[s + 1].push_back(s);
+      compute_boundaries();
+    }
+    // levels
+    A.n_levels = 0;
+    for (int s = 0; s < F; s++) {
+      int lv = 0;
+      for (int c : kids[s]) lv = std::max(lv, A.f_level[c] + 1);
+      A.f_level[s] = lv;
+      A.n_levels = std::max(A.n_levels, lv + 1);
+    }
+    A.level_off.assign(A.n_levels + 1, 0);
+    for (int s = 0; s < F; s++) A.level_off[A.f_level[s] + 1]++;
+    for (int l = 0; l < A.n_levels; l++) A.level_off[l + 1] += A.level_off[l];
+    A.level_fronts.resize(F);
+    {
+      std::vector<int> w(A.level_off.begin(), A.level_off.end() - 1);
+      for (int s = 0; s < F; s++) A.level_fronts[w[A.f_level[s]]++] = s;
+    }
+    // children CSR
+    A.f_child_off.assign(F + 1, 0);
+    for (int s = 0; s < F; s++) A.f_child_off[s + 1] = A.f_child_off[s] + (int)kids[s].size();
+    A.child.clear();
+    for (int s = 0; s < F; s++) for (int c : kids[s]) A.child.push_back(c);
+    // boundary scalar indices, sizes, storage
+    A.f_bidx_off.assign(F + 1, 0);
+    A.bidx.clear();
+    A.max_front = 0;
+    A.f_Loff.assign(F, 0); A.f_Uoff.assign(F, 0);
+    A.L_size = 0; A.U_size = 0;
+    for (int s = 0; s < F; s++) {
+      int b = 0;
+      for (int v : bnd[s]) { for (int d = 0; d < nodes[v].dim; d++) A.bidx.push_back(A.node_voff[v] + d); b += nodes[v].dim; }
+      A.f_b[s] = b;
+      A.f_bidx_off[s + 1] = (int)A.bidx.size();
+      const int f = A.f_p[s] + b;
+      A.max_front = std::max(A.max_front, f);
+      A.f_Loff[s] = A.L_size; A.L_size += (int64_t)(f + 1) * A.f_p[s];
+      A.f_Uoff[s] = A.U_size; A.U_size += (int64_t)(b + 1) * (b + 1);
+    }
+    // child -> parent scatter maps
+    A.f_cmap_off.assign(F + 1, 0);
+    A.cmap.clear();
+    std::vector<int> loc(N, -1);
+    // process per parent so that loc[] is filled once per front
+    std::vector<std::vector<int>> cm(F);
+    for (int s = 0; s < F; s++) {
+      int off = 0;
+      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
+      for (int v : bnd[s]) { loc[v] = off; off += nodes[v].dim; }
+      const int rhs_row = off;   // == f
+      for (int c : kids[s]) {
+        for (int v : bnd[c]) {
+          if (loc[v] < 0) { *msg = "internal: child boundary not inside parent front"; return false; }
+          for (int d = 0; d < nodes[v].dim; d++) cm[c].push_back(loc[v] + d);
+        }
+        cm[c].push_back(rhs_row);
+      }
+      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
+      for (int v : bnd[s]) loc[v] = -1;
+    }
+    for (int s = 0; s < F; s++) {
+      A.f_cmap_off[s] = (int)A.cmap.size();
+      A.cmap.insert(A.cmap.end(), cm[s].begin(), cm[s].end());
+    }
+    A.f_cmap_off[F] = (int)A.cmap.size();
+
+    // ---- 5. block-sparse H and contribution lists ----
+    struct Ctr { int64_t key; int jv, ju, roff, m; };
+    std::vector<Ctr> ctr;
+    ctr.reserve(factors.size() * 3);
+    A.J_size = 0;
+    for (const auto& f : factors) {
+      const int m = kFDim[f.type];
+      const int da = nodes[f.a].dim;
+      const int db = f.b >= 0 ? nodes[f.b].dim : 0;
+      const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
+      A.J_size = std::max<int64_t>(A.J_size, (int64_t)roff + m);
+      const int64_t pa = A.node_pos[f.a];
+      ctr.push_back({pa * N + pa, ja, ja, roff, m});
+      if (f.b >= 0) {
+        const int64_t pb = A.node_pos[f.b];
+        ctr.push_back({pb * N + pb, jb, jb, roff, m});
+        if (pa > pb) ctr.push_back({pa * N + pb, ja, jb, roff, m});   // rows = later node
+        else         ctr.push_back({pb * N + pa, jb, ja, roff, m});
+      }
+    }
+    // every node needs a diagonal block even when it has no factor (it will then fail as not PD)
+    std::vector<char> has_diag(N, 0);
+    for (auto& c : ctr) if (c.key / N == c.key % N) has_diag[c.key / N] = 1;
+    for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({(int64_t)p * N + p, 0, 0, 0, 0});
+    std::stable_sort(ctr.begin(), ctr.end(), [](const Ctr& x, const Ctr& y) { return x.key < y.key; });
+    A.contrib.clear();
+    A.contrib.reserve(ctr.size() * 4);
+    std::vector<std::vector<int>> asm_of(F);   // block ids per front
+    A.H_size = 0;
+    for (size_t i = 0; i < ctr.size();) {
+      size_t j = i;
+      while (j < ctr.size() && ctr[j].key == ctr[i].key) j++;
+      const int pv = (int)(ctr[i].key / N), pu = (int)(ctr[i].key % N);
+      const int v = A.order[pv], u = A.order[pu];
+      const int rows = nodes[v].dim, cols = nodes[u].dim;
+      const int size = rows * cols + (v == u ? rows : 0);
+      const int cnt = (int)(j - i);
+      const int nseg = std::max(1, (cnt + prm.seg_len - 1) / prm.seg_len);
+      const int blk = A.n_blocks++;
+      A.blk_rows.push_back(rows); A.blk_cols.push_back(cols); A.blk_size.push_back(size); A.blk_nseg.push_back(nseg);
+      A.blk_hoff.push_back(A.H_size);
+      for (int sgi = 0; sgi < nseg; sgi++) {
+        const int c0 = sgi * prm.seg_len;
+        A.seg_blk.push_back(blk);
+        A.seg_c0.push_back((int)(A.contrib.size() / 4));
+        int k = 0;
+        for (; k < prm.seg_len && c0 + k < cnt; k++) {
+          const Ctr& c = ctr[i + c0 + k];
+          if (c.m == 0) continue;   // placeholder for a factor-less node
+          A.contrib.push_back(c.jv); A.contrib.push_back(c.ju); A.contrib.push_back(c.roff); A.contrib.push_back(c.m);
+        }
+        A.seg_cnt.push_back((int)(A.contrib.size() / 4) - A.seg_c0.back());
+        A.seg_hoff.push_back(A.H_size);
+        A.H_size += size;
+        A.n_segs++;
+      }
+      asm_of[node_front[u]].push_back(blk);
+      // remember (v,u) for the local offsets below
+      A.asm_lrow.push_back(v); A.asm_lcol.push_back(u);   // temporarily indexed by block id
+      i = j;
+    }
+    // per-front assembly lists with local offsets
+    std::vector<int> blk_v(A.asm_lrow), blk_u(A.asm_lcol);
+    A.asm_blk.clear(); A.asm_lrow.clear(); A.asm_lcol.clear();
+    A.f_asm_off.assign(F + 1, 0);
+    for (int s = 0; s < F; s++) {
+      int off = 0;
+      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
+      for (int v : bnd[s]) { loc[v] = off; off += nodes[v].dim; }
+      for (int blk : asm_of[s]) {
+        const int v = blk_v[blk], u = blk_u[blk];
+        if (loc[v] < 0 || loc[u] < 0) { *msg = "internal: H block outside its front"; return false; }
+        A.asm_blk.push_back(blk); A.asm_lrow.push_back(loc[v]); A.asm_lcol.push_back(loc[u]);
+      }
+      A.f_asm_off[s + 1] = (int)A.asm_blk.size();
+      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
+      for (int v : bnd[s]) loc[v] = -1;
+    }
+  }
+  return true;
+}
+
+void dump_analysis(const Analysis& a, std::vector<int32_t>& out) {
+  out.clear();
+  auto put = [&](int64_t v) { out.push_back((int32_t)v); };
+  auto putv = [&](const std::vector<int>& v) { put((int64_t)v.size()); for (int x : v) out.push_back(x); };
+  auto putv64 = [&](const std::vector<int64_t>& v) { put((int64_t)v.size()); for (int64_t x : v) out.push_back((int32_t)x); };
+  put(a.n_nodes); put(a.n_scalars); put(a.n_fronts); put(a.n_levels); put(a.max_front);
+  put(a.n_blocks); put(a.n_segs); put(a.L_size); put(a.U_size); put(a.H_size); put(a.J_size);
+  putv(a.node_pos); putv(a.node_voff); putv(a.order);
+  putv(a.f_p); putv(a.f_b); putv(a.f_poff); putv(a.f_parent); putv(a.f_level);
+  putv64(a.f_Loff); putv64(a.f_Uoff);
+  putv(a.f_bidx_off); putv(a.bidx); putv(a.f_child_off); putv(a.child); putv(a.f_cmap_off); putv(a.cmap);
+  putv(a.level_off); putv(a.level_fronts);
+  putv(a.f_asm_off); putv(a.asm_blk); putv(a.asm_lrow); putv(a.asm_lcol);
+  putv(a.blk_rows); putv(a.blk_cols); putv(a.blk_size); putv(a.blk_nseg); putv64(a.blk_hoff);
+  putv(a.seg_blk); putv(a.seg_c0); putv(a.seg_cnt); putv64(a.seg_hoff);
+  putv(a.contrib);
+}
+
+}  // namespace pps

@@ -1,0 +1,84 @@
+// pps_symbolic.h -- host-side symbolic analysis of the plane-SLAM normal equations.
+//
+// Replaces cholmod_analyze (reference: Thirdparty/isam/isamlib/Cholesky.cpp:98,105), which the
+// reference re-runs on every factorisation.  Here it runs once per graph topology and is cached:
+//   1. nested-dissection ordering of the node graph along the pose chain (planes that are seen
+//      from both sides of a cut, and the cut pose, form the separator; very-high-degree nodes
+//      such as the ground plane are pulled out first and become the root "border" block --
+//      SURVEY.md section 7, hard part 2),
+//   2. separator tree -> supernodes ("fronts") with bounded pivot counts,
+//   3. boundary (update) index sets, child->parent scatter maps, level schedule,
+//   4. block-sparse layout of H = J'J and the per-block contribution lists the device reduces.
+// All index arrays are flat int32 so they upload to the GPU as-is.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace pps {
+
+enum { NODE_POSE = 0, NODE_PLANE = 1 };
+enum { F_POSE_PRIOR = 0, F_ODOMETRY = 1, F_PLANE_OBS = 2, F_PLANE_PRIOR = 3 };
+
+// doubles of Jacobian storage per factor type: [J_a | J_b | r]
+constexpr int kJSize[4] = {36 + 6, 36 + 36 + 6, 18 + 9 + 3, 9 + 3};
+constexpr int kFDim[4] = {6, 6, 3, 3};
+
+struct SymNode { int type; int dim; int rank; };        // rank: insertion index among poses (time order), -1 for planes
+struct SymFactor { int type; int a, b; int joff; };       // compact node ids (b = -1 when unary); joff: offset in the J buffer
+
+struct AnalysisParams {
+  int leaf_poses = 4;      // a sub-chain with <= leaf_poses poses becomes one leaf front
+  int max_pivots = 48;     // split supernodes with more pivot scalars into a chain
+  int seg_len = 32;        // contributions reduced per wave in the H-block kernel
+  int dense_min = 64;      // a node is "dense" if degree > max(dense_min, dense_mult*sqrt(N))
+  double dense_mult = 8.0;
+};
+
+struct Analysis {
+  int n_nodes = 0, n_scalars = 0;
+  std::vector<int> node_pos;    // [n_nodes] elimination position
+  std::vector<int> node_voff;   // [n_nodes] scalar offset in the elimination-ordered delta / g vectors
+  std::vector<int> order;       // [n_nodes] order[pos] = node
+
+  // ---- fronts (post-order: children before parents) ----
+  int n_fronts = 0, n_levels = 0, max_front = 0;
+  std::vector<int> f_p, f_b;        // pivot / boundary scalar counts
+  std::vector<int> f_poff;          // scalar offset of the first pivot (pivots are contiguous)
+  std::vector<int> f_parent, f_level;
+  std::vector<int64_t> f_Loff;      // offset of the (f+1) x p factor panel (row-major, ld = p)
+  std::vector<int64_t> f_Uoff;      // offset of the (b+1) x (b+1) update matrix (row-major, ld = b+1)
+  std::vector<int> f_bidx_off;      // [n_fronts+1] -> bidx
+  std::vector<int> bidx;            // boundary scalar -> global scalar index
+  std::vector<int> f_child_off;     // [n_fronts+1] -> child
+  std::vector<int> child;
+  std::vector<int> f_cmap_off;      // [n_fronts+1] -> cmap ; front c's boundary (+rhs) -> local index in parent
+  std::vector<int> cmap;
+  std::vector<int> level_off;       // [n_levels+1] -> level_fronts
+  std::vector<int> level_fronts;
+  std::vector<int> f_asm_off;       // [n_fronts+1] -> asm_* (original entries gathered by the front)
+  std::vector<int> asm_blk, asm_lrow, asm_lcol;
+  int64_t L_size = 0, U_size = 0;
+
+  // ---- block-sparse H = J'J (lower triangle in elimination order) ----
+  int n_blocks = 0;
+  std::vector<int> blk_rows, blk_cols;   // dims (rows = later node, cols = earlier node); diagonal blocks carry g appended
+  std::vector<int> blk_size;             // doubles per segment slot
+  std::vector<int> blk_nseg;
+  std::vector<int64_t> blk_hoff;         // offset of the block's first segment slot in the H buffer
+  int n_segs = 0;
+  std::vector<int> seg_blk, seg_c0, seg_cnt;
+  std::vector<int64_t> seg_hoff;
+  std::vector<int> contrib;              // 4 ints per contribution: jv, ju, roff, m
+  int64_t H_size = 0;
+  int64_t J_size = 0;
+};
+
+// nodes/factors are the compacted live sets.  Returns false (with msg) on structural problems.
+bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
+             Analysis& out, const char** msg);
+
+// Serialise the analysis into one int32 vector for host-logic tests (pps_analysis_dump).
+void dump_analysis(const Analysis& a, std::vector<int32_t>& out);
+
+}  // namespace pps
