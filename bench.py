@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the plane-SLAM graph solve on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full `pps_batch_optimize` (Levenberg-Marquardt to convergence, the reference's
+Slam::batch_optimization) of the BASELINE.json config-2 graph -- synthetic corridor, 1 000 SE3 poses,
+200 plane landmarks, 5 000 plane edges + 999 odometry edges + priors -- restarted from its initial
+(dead-reckoned) estimate, which is restored from a device-resident snapshot.  Graph, measurements
+and state are resident in HBM before the timed region starts.  value = LM iterations / second over
+all ranks (one independent graph per GPU, no collective: SURVEY.md section 8(e)).
+
+Extra objects on the JSON line:
+  roofline      K1 (Jacobian sweep) inside the timed solves: algorithmic bytes per launch (392 B per
+                plane edge, 840 B per odometry edge) / mean launch duration from HIP
+                event pairs recorded on the solver's stream.  The single C2 graph (2.8 MB) lives in
+                cache, so `roofline_batched` repeats the sweep over replicated edges (> 256 MB).
+  cpu_baseline  the CPU oracle (oracle/pps_oracle.c, a "port": the reference itself cannot be built
+                here) solving the same graph on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+B_PLANE_EDGE = 392   # 152 B read + 240 B written per pose-plane edge linearisation
+B_ODO_EDGE = 840     # 216 B read + 624 B written per odometry edge
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(spec, budget_s=12.0):
+    """Reference-faithful CPU path (numeric Jacobians, re-ordering every factorisation, 1 thread)."""
+    from oracle import oracle_py as O
+    iters, secs, runs, chi2 = 0, 0.0, 0, None
+    phases = np.zeros(4)
+    while secs < budget_s and runs < 8:
+        o = O.OracleGraph()
+        spec.replay(o)
+        t0 = time.perf_counter()
+        it = o.batch_optimize()
+        secs += time.perf_counter() - t0
+        iters += it
+        runs += 1
+        chi2 = o.chi2()
+        phases += o.timers()
+    return {
+        "value": iters / secs, "unit": "LM iters/s", "cores": 1, "kind": "port",
+        "sample": f"{runs} full LM solves of the same C2 graph ({iters} iterations, {secs:.1f} s), oracle/pps_oracle.c -O3, "
+                  f"numeric Jacobians + per-call re-ordering as the reference",
+        "final_chi2": chi2, "host_cores_total": os.cpu_count(),
+        "phase_split_s": {"linearise": phases[0] / runs, "factor_solve": phases[1] / runs,
+                          "retract_chi2": phases[2] / runs, "ordering": phases[3] / runs},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["numeric", "analytic"], default="numeric",
+                    help="Jacobian mode of the sweep (numeric = reference behaviour)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched-replicas", type=int, default=0, help="0 = auto (> 256 MB per sweep)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+
+    import pop_up_slam_amd as P
+    from pop_up_slam_amd import synth
+
+    # C4: independently seeded C2-size graphs, one per GPU (seed 42 on rank 0 == BASELINE config 2)
+    seed = 42 if rank == 0 else 100 + rank
+    spec = synth.corridor(seed=seed)
+    mode = P.JAC_NUMERIC if args.mode == "numeric" else P.JAC_ANALYTIC
+    g = P.Graph(device=local_rank, jacobian_mode=mode)
+    spec.replay(g)
+    g.save_state()
+    g.set_profiling(1)      # event pairs around K1 only; no extra host syncs
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        g.restore_state()
+        g.batch_optimize()
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    k1_time, k1_launches = 0.0, 0
+    for _ in range(args.steps):
+        g.restore_state()
+        iters += g.batch_optimize()
+        st = g.stats()
+        k1_time += st["t_linearize"]
+        k1_launches += st["n_linearize"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    chi2 = g.chi2()
+    st = g.stats()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        it_t = torch.tensor([iters], dtype=torch.float64, device="cuda")
+        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
+        total_iters = float(it_t.item())
+    else:
+        total_iters = float(iters)
+
+    if rank == 0:
+        counts = spec.counts()
+        n_obs, n_odo = counts[synth.F_PLANE_OBS], counts[synth.F_ODOMETRY]
+        bytes_per_launch = n_obs * B_PLANE_EDGE + n_odo * B_ODO_EDGE
+        k1_avg = k1_time / max(1, k1_launches)
+        achieved = bytes_per_launch / k1_avg / 1e9 if k1_avg > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "k_linearize", "launches": k1_launches, "avg_launch_us": k1_avg * 1e6,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "note": "single C2 graph: 2.8 MB per sweep, cache-resident and launch-latency bound"}
+        # batched variant: replicate the edge arrays until one sweep moves > 256 MB
+        reps = args.batched_replicas or int(np.ceil(300e6 / bytes_per_launch))
+        sec, npl, nod = g.bench_sweep(mode, reps, 10)
+        bb = npl * B_PLANE_EDGE + nod * B_ODO_EDGE
+        roofline_batched = {"bound": "hbm", "achieved": bb / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": bb / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_sweep_bench",
+                            "replicas": reps, "plane_edges": npl, "odometry_edges": nod,
+                            "algorithmic_bytes_per_launch": bb, "avg_launch_us": sec * 1e6}
+        out = {
+            "metric": "graph-solve iters/sec + final chi2, 1k-pose/5k-edge plane graph",
+            "value": total_iters / elapsed, "unit": "LM iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2 synthetic corridor: 1000 SE3 poses, 200 planes, 5000 plane edges, 999 odometry edges "
+                                   "(BASELINE.json configs[1]); one independent graph per GPU, no collective",
+                       "jacobian_mode": args.mode, "lm_iterations_per_solve": iters / args.steps,
+                       "graphs_per_sec": world * args.steps / elapsed},
+            "final_chi2": chi2, "chi2_initial": st["chi2_initial"],
+            "fronts": st["n_fronts"], "levels": st["n_levels"], "max_front": st["max_front"],
+            "roofline": roofline, "roofline_batched": roofline_batched,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb = cpu_baseline(spec)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            out["chi2_rel_err_vs_cpu"] = abs(chi2 - cb["final_chi2"]) / abs(cb["final_chi2"])
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

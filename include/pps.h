@@ -121,6 +121,10 @@ int pps_set_plane(pps_graph* g, int id, const double abcd[4]);
 /* bulk: ids may be NULL (= all poses / all planes in insertion order); out is n x 7 / n x 4 */
 int pps_get_poses(pps_graph* g, int n, const int* ids, double* out);
 int pps_get_planes(pps_graph* g, int n, const int* ids, double* out);
+/* Device-resident snapshot of the current estimate and its restore (bench / what-if solves):
+ * the analogue of copying every NodeT::_value aside and back (Node.h:104-146). */
+int pps_save_state(pps_graph* g);
+int pps_restore_state(pps_graph* g);
 
 /* ---- introspection (tests, bench, INTEGRATION) ---------------------------------------- */
 typedef struct pps_stats {
@@ -141,8 +145,9 @@ typedef struct pps_stats {
 int pps_get_stats(const pps_graph* g, pps_stats* out);
 /* LM trace of the last batch_optimize: per trial (lambda, chi2_new, accepted); returns count via n */
 int pps_get_trace(const pps_graph* g, int cap, double* lambda, double* chi2, int* accepted, int* n);
-/* enable per-phase HIP-event timing (adds stream syncs; off by default) */
-int pps_set_profiling(pps_graph* g, int on);
+/* HIP-event timing: 0 = off (default); 1 = event pairs around the Jacobian sweep only, no host syncs
+ * (t_linearize / n_linearize = mean launch duration); 2 = every phase, adds stream syncs. */
+int pps_set_profiling(pps_graph* g, int level);
 
 /* Per-factor residual / Jacobian of the device sweep, for parity tests.
  * sel: 0 = linearisation point, 1 = estimate.  J is (dim x cols) row-major, r is the whitened residual. */

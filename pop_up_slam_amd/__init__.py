@@ -68,7 +68,7 @@ SYMBOLS = [
     "pps_chi2", "pps_num_nodes", "pps_num_factors", "pps_get_pose", "pps_get_plane", "pps_set_pose",
     "pps_set_plane", "pps_get_poses", "pps_get_planes", "pps_get_stats", "pps_get_trace",
     "pps_set_profiling", "pps_factor_shape", "pps_eval_factor", "pps_analyze", "pps_analysis_dump",
-    "pps_bench_sweep",
+    "pps_bench_sweep", "pps_save_state", "pps_restore_state",
 ]
 
 
@@ -110,6 +110,8 @@ def lib():
         L.pps_set_plane.argtypes = [C.c_void_p, C.c_int, _dp]
         L.pps_get_poses.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
         L.pps_get_planes.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+        L.pps_save_state.argtypes = [C.c_void_p]
+        L.pps_restore_state.argtypes = [C.c_void_p]
         L.pps_get_stats.argtypes = [C.c_void_p, C.POINTER(PpsStats)]
         L.pps_get_trace.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _ip]
         L.pps_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -254,6 +256,12 @@ class Graph:
                 n = self.stats()["n_planes"]
         out = np.zeros((n, 4)); self._ck(self.L.pps_get_planes(self.h, n, ptr, out.ctypes.data_as(_dp))); return out
 
+    def save_state(self):
+        self._ck(self.L.pps_save_state(self.h))
+
+    def restore_state(self):
+        self._ck(self.L.pps_restore_state(self.h))
+
     # ---- introspection ----
     def stats(self):
         s = PpsStats(); self._ck(self.L.pps_get_stats(self.h, C.byref(s))); return s.asdict()
@@ -265,8 +273,8 @@ class Graph:
                                       acc.ctypes.data_as(_ip), C.byref(n)))
         return [(float(l), float(c), bool(a)) for l, c, a in zip(lam, chi, acc)]
 
-    def set_profiling(self, on=True):
-        self._ck(self.L.pps_set_profiling(self.h, int(on)))
+    def set_profiling(self, level=2):
+        self._ck(self.L.pps_set_profiling(self.h, int(level)))
 
     def eval_factor(self, fid, mode=JAC_NUMERIC):
         m, c = C.c_int(), C.c_int(); self._ck(self.L.pps_factor_shape(self.h, fid, C.byref(m), C.byref(c)))

@@ -68,9 +68,13 @@ struct pps_graph {
   hipStream_t stream = nullptr;
   DevGraph dev;
   std::vector<void*> allocs;
-  double* host_result = nullptr;   // pinned, 4 doubles
-  bool profiling = false;
+  double* host_result = nullptr;   // pinned, 8 doubles
+  double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
+  int snap_version = -1, upload_version = 0;
+  int profiling = 0;               // 0 off, 1 = K1 event pairs without host syncs, 2 = every phase (adds syncs)
   hipEvent_t ev[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> k1_events;   // pairs (start, stop) recorded around the sweep
+  int k1_used = 0;
   // stats / trace
   pps_stats stats{};
   std::vector<double> tr_lambda, tr_chi2;
@@ -245,6 +249,7 @@ int upload_all(pps_graph* g) {
   if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   free_device(g);
+  g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
   if (!g->analyzed || g->topo_dirty) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
@@ -336,7 +341,7 @@ int prepare_solve(pps_graph* g) {
 
 struct PhaseTimer {
   pps_graph* g; double* acc; bool on;
-  PhaseTimer(pps_graph* g_, double* a) : g(g_), acc(a), on(g_->profiling) { if (on) (void)hipEventRecord(g->ev[0], g->stream); }
+  PhaseTimer(pps_graph* g_, double* a) : g(g_), acc(a), on(g_->profiling >= 2) { if (on) (void)hipEventRecord(g->ev[0], g->stream); }
   ~PhaseTimer() {
     if (!on) return;
     (void)hipEventRecord(g->ev[1], g->stream);
@@ -349,6 +354,15 @@ struct PhaseTimer {
 
 // linearise at `lin` (K1) and reduce the H blocks (K2)
 int do_linearize(pps_graph* g) {
+  if (g->profiling == 1) {
+    if (g->k1_used + 2 > (int)g->k1_events.size()) {
+      for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->k1_events.push_back(e); }
+    }
+    HIP_TRY(g, hipEventRecord(g->k1_events[g->k1_used], g->stream));
+    HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream));
+    HIP_TRY(g, hipEventRecord(g->k1_events[g->k1_used + 1], g->stream));
+    g->k1_used += 2;
+  } else
   { PhaseTimer t(g, &g->stats.t_linearize); HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream)); }
   { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream)); }
   g->stats.n_linearize++;
@@ -393,6 +407,15 @@ int read_result(pps_graph* g, bool at_estimate, double* chi2, double* dnorm, boo
   if (dnorm) *dnorm = std::sqrt(g->host_result[1]);
   if (notpd) *notpd = g->host_result[2] != 0.0;
   return PPS_OK;
+}
+
+// after the final stream sync of a solve: fold the K1 event pairs into stats.t_linearize
+void resolve_k1_events(pps_graph* g) {
+  for (int k = 0; k + 1 < g->k1_used; k += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g->k1_events[k], g->k1_events[k + 1]) == hipSuccess) g->stats.t_linearize += 1e-3 * ms;
+  }
+  g->k1_used = 0;
 }
 
 void reset_solve_stats(pps_graph* g) {
@@ -443,6 +466,7 @@ int pps_graph_destroy(pps_graph* g) {
     if (g->host_result) (void)hipHostFree(g->host_result);
     if (g->ev[0]) (void)hipEventDestroy(g->ev[0]);
     if (g->ev[1]) (void)hipEventDestroy(g->ev[1]);
+    for (hipEvent_t e : g->k1_events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(g->stream);
   }
   delete g;
@@ -581,6 +605,7 @@ int pps_update(pps_graph* g) {
   double chi2, dn; bool notpd;
   rc = read_result(g, true, &chi2, &dn, &notpd); if (rc != PPS_OK) return rc;
   g->dev_values_newer = true;
+  resolve_k1_events(g);
   g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
   g->stats.t_total = now_s() - t0;
   if (notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite");
@@ -648,6 +673,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   rc = copy_state(g, false); if (rc != PPS_OK) return rc;         // linpoint_to_estimate (:466)
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->dev_values_newer = true;
+  resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
   g->stats.t_total = now_s() - t0;
@@ -718,6 +744,33 @@ static int get_bulk(pps_graph* g, int type, int n, const int* ids, double* out, 
 int pps_get_poses(pps_graph* g, int n, const int* ids, double* out) { return get_bulk(g, NODE_POSE, n, ids, out, 7); }
 int pps_get_planes(pps_graph* g, int n, const int* ids, double* out) { return get_bulk(g, NODE_PLANE, n, ids, out, 4); }
 
+int pps_save_state(pps_graph* g) {
+  if (!g) return PPS_EINVAL;
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  const DevGraph& d = g->dev;
+  if (!g->snap_pose || g->snap_version != g->upload_version) {
+    // (re)allocate with the current leading dimensions; owned by the allocation list of this upload
+    rc = dev_alloc(g, &g->snap_pose, (size_t)7 * d.pose_ld); if (rc != PPS_OK) return rc;
+    rc = dev_alloc(g, &g->snap_plane, (size_t)4 * d.plane_ld); if (rc != PPS_OK) return rc;
+    g->snap_version = g->upload_version;
+  }
+  HIP_TRY(g, hipMemcpyAsync(g->snap_pose, d.pose_est, (size_t)7 * d.pose_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  HIP_TRY(g, hipMemcpyAsync(g->snap_plane, d.plane_est, (size_t)4 * d.plane_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  return PPS_OK;
+}
+
+int pps_restore_state(pps_graph* g) {
+  if (!g) return PPS_EINVAL;
+  if (!g->snap_pose || g->snap_version != g->upload_version || g->topo_dirty) return fail(g, PPS_ESTATE, "no snapshot for the current topology");
+  if (g->host_values_newer) return fail(g, PPS_ESTATE, "host values were modified after the snapshot");
+  const DevGraph& d = g->dev;
+  HIP_TRY(g, hipMemcpyAsync(d.pose_est, g->snap_pose, (size_t)7 * d.pose_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  HIP_TRY(g, hipMemcpyAsync(d.plane_est, g->snap_plane, (size_t)4 * d.plane_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  g->dev_values_newer = true;
+  return PPS_OK;
+}
+
 int pps_get_stats(const pps_graph* g, pps_stats* out) {
   if (!g || !out) return PPS_EINVAL;
   *out = g->stats;
@@ -739,7 +792,7 @@ int pps_get_trace(const pps_graph* g, int cap, double* lambda, double* chi2, int
   return PPS_OK;
 }
 
-int pps_set_profiling(pps_graph* g, int on) { if (!g) return PPS_EINVAL; g->profiling = on != 0; return PPS_OK; }
+int pps_set_profiling(pps_graph* g, int level) { if (!g) return PPS_EINVAL; g->profiling = level < 0 ? 0 : level; return PPS_OK; }
 
 int pps_factor_shape(const pps_graph* g, int fid, int* dim, int* cols) {
   if (!g) return PPS_EINVAL;

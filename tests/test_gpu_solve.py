@@ -1,0 +1,84 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded graphs."""
+import numpy as np
+import pytest
+
+import pop_up_slam_amd as P
+from pop_up_slam_amd import synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [lambda: synth.small_world(5, 3, seed=1), lambda: synth.small_world(20, 6, seed=2),
+         lambda: synth.small_world(50, 10, seed=3), lambda: synth.corridor(120, 26, seed=5)]
+
+
+def _pair(spec, **props):
+    g = P.Graph(**props)
+    nid, fid = spec.replay(g)
+    o = O.OracleGraph(analytic=props.get("jacobian_mode", 0))
+    onid, ofid = spec.replay(o)
+    return g, o, nid, fid, onid, ofid
+
+
+@pytest.mark.parametrize("mk", SMALL)
+@pytest.mark.parametrize("mode", [P.JAC_NUMERIC, P.JAC_ANALYTIC])
+def test_factor_jacobians_match_oracle(built, mk, mode):
+    spec = mk()
+    g, o, nid, fid, onid, ofid = _pair(spec)
+    for k in range(len(fid)):
+        J, r = g.eval_factor(int(fid[k]), mode)
+        Jo, ro = o.factor_jacobian(int(ofid[k]), analytic=mode)
+        np.testing.assert_allclose(r, ro, rtol=0, atol=1e-12)
+        # central differences divide the 1e-16 residual noise by 2e-4
+        np.testing.assert_allclose(J, Jo, rtol=0, atol=(5e-11 if mode == P.JAC_NUMERIC else 1e-12))
+
+
+@pytest.mark.parametrize("mk", SMALL)
+def test_chi2_matches_oracle(built, mk):
+    spec = mk()
+    g, o, *_ = _pair(spec)
+    c, co = g.chi2(), o.chi2()
+    assert abs(c - co) <= 1e-12 * max(1.0, abs(co))
+
+
+@pytest.mark.parametrize("mk", SMALL)
+def test_gauss_newton_update_matches_oracle(built, mk):
+    spec = mk()
+    g, o, nid, fid, onid, ofid = _pair(spec)
+    g.update()
+    o.update()
+    c, co = g.chi2(), o.chi2()
+    assert abs(c - co) <= 1e-8 * abs(co), (c, co)
+    for a, b in zip(nid, onid):
+        if spec.node_type[list(nid).index(a)] == synth.NODE_POSE:
+            np.testing.assert_allclose(g.get_pose(int(a)), o.get_pose(int(b)), atol=1e-8)
+        else:
+            np.testing.assert_allclose(g.get_plane(int(a)), o.get_plane(int(b)), atol=1e-8)
+
+
+@pytest.mark.parametrize("mk", SMALL)
+@pytest.mark.parametrize("mode", [P.JAC_NUMERIC, P.JAC_ANALYTIC])
+def test_lm_matches_oracle(built, mk, mode):
+    spec = mk()
+    g, o, *_ = _pair(spec, jacobian_mode=mode)
+    it = g.batch_optimize()
+    ito = o.batch_optimize()
+    c, co = g.chi2(), o.chi2()
+    assert abs(c - co) <= 1e-5 * abs(co), (c, co)      # north_star tolerance: rel 1e-5 on final chi2
+    assert abs(c - co) <= 1e-7 * abs(co), (c, co)      # and much tighter in practice
+    assert it == ito
+    tr, tro = g.trace(), o.trace()
+    assert [a for _, _, a in tr] == [a for _, _, a in tro]
+    np.testing.assert_allclose([x for _, x, _ in tr], [x for _, x, _ in tro], rtol=1e-6)
+
+
+def test_c2_corridor_final_chi2(built):
+    """BASELINE config 2: 1000 poses / 200 planes / 5000 plane edges, reference-faithful mode."""
+    spec = synth.corridor()
+    g, o, *_ = _pair(spec)
+    it = g.batch_optimize()
+    ito = o.batch_optimize()
+    c, co = g.chi2(), o.chi2()
+    st = g.stats()
+    print("C2: gpu chi2 %.12g (%d it, %.3f s) oracle %.12g (%d it)" % (c, it, st["t_total"], co, ito))
+    assert abs(c - co) <= 1e-5 * abs(co), (c, co)
