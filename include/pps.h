@@ -173,29 +173,44 @@ int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec
 int pps_popup_planes(int device, const float* seg2d, int n, const float invK[9], const float T_wc[16],
                      float* planes_out);
 
-typedef struct pps_popup pps_popup;   /* per-camera pop-up context: device buffers for one image size */
+/* One pop-up point: world xyz + packed colour, 16 bytes (pcl::PointXYZRGB carries the same payload in
+ * 32 B: popup_plane.cpp:943-983).  rgba = valid<<24 | r<<16 | g<<8 | b. */
+typedef struct pps_point { float x, y, z; uint32_t rgba; } pps_point;
+
+typedef struct pps_popup pps_popup;   /* per-camera context: device buffers for one image size */
 int pps_popup_create(int device, int width, int height, const float invK[9], pps_popup** out);
 int pps_popup_destroy(pps_popup* p);
-/* Fused frame kernel: segments -> plane equations (K5) and pixels -> 3-D (K6) in one launch.
- *   polys      : closed 2-D polygons of the good planes, packed (x,y) vertices, poly_off[nplanes+1]
- *                (popup_plane::all_closed_2d_bound_polygons, popup_plane.h:70-76); plane 0 = ground
- *   seg2d      : n x 4 ground segments; plane i (i>=1) comes from segment i-1
- *   bgr        : width*height*3 u8 or NULL
- * Outputs (host, may be NULL): planes_out (n+1)x4 sensor-frame planes; xyz (w*h*3 fp32, world);
- * rgb (w*h*3 u8); valid (w*h u8); depth (w*h fp32, get_depth_map_good semantics, ceiling substituted
- * above ceiling_thre).  Filters follow matrixToCloud (popup_plane.cpp:948-960): z_s<0, z_s>depth_thre,
- * z_w<-0.2 dropped; z_w clamped to ceiling_thre. */
-int pps_popup_frame(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
-                    const float* polys, const int* poly_off, int nplanes,
-                    const unsigned char* bgr, float depth_thre, float ceiling_thre,
-                    float* planes_out, float* xyz, unsigned char* rgb, unsigned char* valid, float* depth,
-                    int* n_valid);
-/* Same kernel, but every stage stays on the device: measurements of the listed plane-observation
- * factors of graph g are overwritten in place from the new plane equations
- * (Mapper_mono::update_plane_measurement, Mapping.cpp:590-607).  fids[i] < 0 = skip plane i. */
-int pps_popup_refresh_measurements(pps_graph* g, int n_frames, const int* pose_ids,
-                                   const int* seg_off /* n_frames+1 */, const float* seg2d,
-                                   const float invK[9], const int* fids /* per (frame,plane) incl. ground, seg_off[f]+f.. */);
+const char* pps_popup_last_error(const pps_popup* p);
+/* upload a BGR image (u8, width*height*3); stays resident for the following runs.  NULL = no colour. */
+int pps_popup_set_image(pps_popup* p, const unsigned char* bgr);
+/* Fused frame kernel, one launch: K5 segments -> plane equations (get_plane_equation,
+ * popup_plane.cpp:551-603) and K6 pixels -> 3-D (generate_cloud + matrixToCloud :807-863,925-985;
+ * get_depth_map_good :866-921).  Results stay on the device until pps_popup_download.
+ *   seg2d    n x 4 ground segments; plane i >= 1 comes from segment i-1, plane 0 = ground
+ *   polys    closed 2-D polygons (x,y) of the planes to pop up (all_closed_2d_bound_polygons,
+ *            popup_plane.h:70-76), poly_off[nplanes+1] vertex offsets; an empty polygon skips the plane.
+ *            A pixel belongs to the LAST convex polygon that contains it (edges inclusive).
+ *   step     1 = every pixel, 2 = every second pixel in x and y (downsample_poly, popup_plane.cpp:86-108)
+ * Filters (matrixToCloud :948-960): z_s < 0, z_s > depth_thre, z_w < -0.2 dropped; z_w clamped to
+ * ceiling_thre.  Depth: z_s, with the ceiling plane substituted above ceiling_thre (:903-916). */
+int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys,
+                  const int* poly_off, int nplanes, int step, float depth_thre, float ceiling_thre, int* n_valid);
+/* any output may be NULL: planes (n+1)x4 sensor-frame, cloud width*height pps_point, depth width*height,
+ * plane_id width*height (-1 = none) */
+int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* depth, int32_t* plane_id);
+/* device time of the last pps_popup_run kernel (HIP events), seconds */
+int pps_popup_last_kernel_time(const pps_popup* p, double* sec);
+
+/* ---- pop-up feeding the graph: Mapper_mono::update_plane_measurement (Mapping.cpp:590-607) ------
+ * Frames register their 2-D ground segments once; pps_refresh_measurements then re-derives every
+ * registered edge's measurement from the CURRENT pose estimate, on the device, and writes it straight
+ * into the edge array the Jacobian sweep reads (fp32 pop-up math, cast to fp64 and normalised like
+ * Plane3d(Vector4d)).  fids has n_seg+1 entries (plane 0 = ground); -1 skips a plane. */
+int pps_frames_set_calibration(pps_graph* g, const float invK[9]);
+int pps_frames_add(pps_graph* g, int pose_id, int n_seg, const float* seg2d, const int* fids, int* frame_id);
+int pps_refresh_measurements(pps_graph* g);
+/* read back a plane factor's current measurement (FactorT::measurement(), Factor.h:203) */
+int pps_get_measurement(pps_graph* g, int fid, double meas4[4]);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,9 @@ SYMBOLS = [
     "pps_set_plane", "pps_get_poses", "pps_get_planes", "pps_get_stats", "pps_get_trace",
     "pps_set_profiling", "pps_factor_shape", "pps_eval_factor", "pps_analyze", "pps_analysis_dump",
     "pps_bench_sweep", "pps_save_state", "pps_restore_state",
+    "pps_popup_planes", "pps_popup_create", "pps_popup_destroy", "pps_popup_last_error", "pps_popup_set_image",
+    "pps_popup_run", "pps_popup_download", "pps_popup_last_kernel_time",
+    "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
 ]
 
 
@@ -121,6 +124,20 @@ def lib():
         L.pps_analysis_dump.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         L.pps_bench_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64)]
+        _u8 = C.POINTER(C.c_ubyte)
+        L.pps_popup_planes.argtypes = [C.c_int, _fp, C.c_int, _fp, _fp, _fp]
+        L.pps_popup_create.argtypes = [C.c_int, C.c_int, C.c_int, _fp, C.POINTER(C.c_void_p)]
+        L.pps_popup_destroy.argtypes = [C.c_void_p]
+        L.pps_popup_last_error.argtypes = [C.c_void_p]
+        L.pps_popup_last_error.restype = C.c_char_p
+        L.pps_popup_set_image.argtypes = [C.c_void_p, _u8]
+        L.pps_popup_run.argtypes = [C.c_void_p, _fp, C.c_int, _fp, _fp, _ip, C.c_int, C.c_int, C.c_float, C.c_float, _ip]
+        L.pps_popup_download.argtypes = [C.c_void_p, _fp, C.c_void_p, _fp, C.POINTER(C.c_int32)]
+        L.pps_popup_last_kernel_time.argtypes = [C.c_void_p, _dp]
+        L.pps_frames_set_calibration.argtypes = [C.c_void_p, _fp]
+        L.pps_frames_add.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _ip, _ip]
+        L.pps_refresh_measurements.argtypes = [C.c_void_p]
+        L.pps_get_measurement.argtypes = [C.c_void_p, C.c_int, _dp]
         _LIB = L
     return _LIB
 
@@ -256,6 +273,25 @@ class Graph:
                 n = self.stats()["n_planes"]
         out = np.zeros((n, 4)); self._ck(self.L.pps_get_planes(self.h, n, ptr, out.ctypes.data_as(_dp))); return out
 
+    # ---- pop-up feeding the graph (Mapper_mono::update_plane_measurement) ----
+    def frames_set_calibration(self, invK):
+        k = np.ascontiguousarray(invK, dtype=np.float32).reshape(9)
+        self._ck(self.L.pps_frames_set_calibration(self.h, k.ctypes.data_as(_fp)))
+
+    def frames_add(self, pose_id, seg2d, fids):
+        seg = np.ascontiguousarray(seg2d, dtype=np.float32).reshape(-1, 4)
+        f = np.ascontiguousarray(fids, dtype=np.int32)
+        assert len(f) == len(seg) + 1
+        out = C.c_int()
+        self._ck(self.L.pps_frames_add(self.h, pose_id, len(seg), seg.ctypes.data_as(_fp), f.ctypes.data_as(_ip), C.byref(out)))
+        return out.value
+
+    def refresh_measurements(self):
+        self._ck(self.L.pps_refresh_measurements(self.h))
+
+    def get_measurement(self, fid):
+        out = np.zeros(4); self._ck(self.L.pps_get_measurement(self.h, fid, out.ctypes.data_as(_dp))); return out
+
     def save_state(self):
         self._ck(self.L.pps_save_state(self.h))
 
@@ -315,3 +351,87 @@ def parse_analysis_dump(buf):
         out[name] = np.array(buf[k:k + n], dtype=np.int64); k += n
     assert k == len(buf), (k, len(buf))
     return out
+
+
+POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
+
+
+def popup_planes(seg2d, invK, T_wc, device=0):
+    """popup_plane::update_plane_equation_from_seg on the device; returns (n+1) x 4 fp32."""
+    seg = np.ascontiguousarray(seg2d, dtype=np.float32).reshape(-1, 4)
+    k = np.ascontiguousarray(invK, dtype=np.float32).reshape(9)
+    t = np.ascontiguousarray(T_wc, dtype=np.float32).reshape(16)
+    out = np.zeros((len(seg) + 1, 4), dtype=np.float32)
+    rc = lib().pps_popup_planes(device, seg.ctypes.data_as(_fp), len(seg), k.ctypes.data_as(_fp), t.ctypes.data_as(_fp),
+                                out.ctypes.data_as(_fp))
+    if rc != PPS_OK:
+        raise PpsError(rc, "pps_popup_planes failed")
+    return out
+
+
+class Popup:
+    """Per-camera pop-up context (popup_plane object of the reference, image-size bound)."""
+
+    def __init__(self, width, height, invK, device=0):
+        self.L = lib()
+        self.w, self.h_ = width, height
+        k = np.ascontiguousarray(invK, dtype=np.float32).reshape(9)
+        h = C.c_void_p()
+        rc = self.L.pps_popup_create(device, width, height, k.ctypes.data_as(_fp), C.byref(h))
+        if rc != PPS_OK:
+            raise PpsError(rc, "pps_popup_create failed")
+        self.h = h
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pps_popup_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != PPS_OK:
+            raise PpsError(rc, self.L.pps_popup_last_error(self.h).decode())
+
+    def set_image(self, bgr):
+        if bgr is None:
+            self._ck(self.L.pps_popup_set_image(self.h, None))
+            return
+        a = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert a.size == self.w * self.h_ * 3
+        self._ck(self.L.pps_popup_set_image(self.h, a.ctypes.data_as(C.POINTER(C.c_ubyte))))
+
+    def run(self, seg2d, T_wc, polys, step=1, depth_thre=10.0, ceiling_thre=2.5):
+        """polys: list of (k_i x 2) vertex arrays, one per plane (plane 0 = ground); may be empty arrays."""
+        seg = np.ascontiguousarray(seg2d, dtype=np.float32).reshape(-1, 4)
+        t = np.ascontiguousarray(T_wc, dtype=np.float32).reshape(16)
+        off = np.zeros(len(polys) + 1, dtype=np.int32)
+        for i, p in enumerate(polys):
+            off[i + 1] = off[i] + len(p)
+        flat = np.zeros((max(1, off[-1]), 2), dtype=np.float32)
+        for i, p in enumerate(polys):
+            if len(p):
+                flat[off[i]:off[i + 1]] = np.asarray(p, dtype=np.float32).reshape(-1, 2)
+        nv = C.c_int()
+        self._ck(self.L.pps_popup_run(self.h, seg.ctypes.data_as(_fp), len(seg), t.ctypes.data_as(_fp),
+                                      flat.ctypes.data_as(_fp), off.ctypes.data_as(_ip), len(polys), step,
+                                      depth_thre, ceiling_thre, C.byref(nv)))
+        self.n = len(seg)
+        return nv.value
+
+    def download(self):
+        planes = np.zeros((self.n + 1, 4), dtype=np.float32)
+        cloud = np.zeros(self.w * self.h_, dtype=POINT_DTYPE)
+        depth = np.zeros((self.h_, self.w), dtype=np.float32)
+        pid = np.zeros((self.h_, self.w), dtype=np.int32)
+        self._ck(self.L.pps_popup_download(self.h, planes.ctypes.data_as(_fp), cloud.ctypes.data_as(C.c_void_p),
+                                           depth.ctypes.data_as(_fp), pid.ctypes.data_as(C.POINTER(C.c_int32))))
+        return planes, cloud.reshape(self.h_, self.w), depth, pid
+
+    def last_kernel_time(self):
+        s = C.c_double(); self._ck(self.L.pps_popup_last_kernel_time(self.h, C.byref(s))); return s.value

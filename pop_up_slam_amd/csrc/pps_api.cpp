@@ -18,6 +18,7 @@
 #include "../../include/pps.h"
 #include "pps_device.h"
 #include "pps_geom.h"
+#include "pps_popup_dev.h"
 #include "pps_symbolic.h"
 
 using namespace pps;
@@ -75,6 +76,17 @@ struct pps_graph {
   hipEvent_t ev[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> k1_events;   // pairs (start, stop) recorded around the sweep
   int k1_used = 0;
+  // registered frames (pps_frames_add): 2-D ground segments that re-derive edge measurements on the device
+  float frames_invK[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  std::vector<int> fr_pose;          // frame -> pose node id
+  std::vector<int> fr_seg_off{0};    // frame -> first segment
+  std::vector<float> fr_seg;         // 4 floats per segment
+  std::vector<int> fr_item_frame, fr_item_plane, fr_item_fid;
+  bool frames_dirty = true;          // device tables must be rebuilt
+  int frames_version = -1;
+  int *d_item_frame = nullptr, *d_item_plane = nullptr, *d_item_slot = nullptr, *d_frame_pose_slot = nullptr, *d_frame_seg_off = nullptr;
+  float* d_fr_seg = nullptr;
+  bool dev_meas_newer = false;       // device edge measurements are newer than the host copies
   // stats / trace
   pps_stats stats{};
   std::vector<double> tr_lambda, tr_chi2;
@@ -229,6 +241,22 @@ void pack_soa(const pps_graph* g, int type, const double HostFactor::*dummy, boo
   }
 }
 
+// pull device-refreshed plane-observation measurements back into the host factor table
+int download_measurements(pps_graph* g) {
+  if (!g->dev_meas_newer) return PPS_OK;
+  const DevGraph& d = g->dev;
+  const size_t n = g->fslot_ids[F_PLANE_OBS].size();
+  std::vector<double> m((size_t)4 * n);
+  if (n) HIP_TRY(g, hipMemcpyAsync(m.data(), d.obs_meas, m.size() * 8, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  for (size_t s2 = 0; s2 < n; s2++) {
+    HostFactor& f = g->factors[g->fslot_ids[F_PLANE_OBS][s2]];
+    for (int k = 0; k < 4; k++) f.meas[k] = m[(size_t)k * n + s2];
+  }
+  g->dev_meas_newer = false;
+  return PPS_OK;
+}
+
 int upload_measurements(pps_graph* g) {
   DevGraph& d = g->dev;
   std::vector<double> m;
@@ -247,8 +275,11 @@ int upload_all(pps_graph* g) {
   int rc = ensure_device(g);
   if (rc != PPS_OK) return rc;
   if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
+  if (g->dev_meas_newer) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   free_device(g);
+  g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
+  g->frames_dirty = true;
   g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
   if (!g->analyzed || g->topo_dirty) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
   const Analysis& A = g->an;
@@ -551,6 +582,7 @@ int pps_set_measurement(pps_graph* g, int fid, const double meas4[4]) { return p
 
 int pps_set_measurements(pps_graph* g, int n, const int* fids, const double* meas4) {
   if (!g || !fids || !meas4 || n < 0) return PPS_EINVAL;
+  if (g->dev_meas_newer) { int rc = download_measurements(g); if (rc != PPS_OK) return rc; }
   for (int i = 0; i < n; i++) {
     const int fid = fids[i];
     if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "set_measurement: unknown factor id");
@@ -901,6 +933,75 @@ int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec
   *sec_per_sweep = 1e-3 * total_ms / iters;
   if (n_plane_edges) *n_plane_edges = (int64_t)d.n_obs * replicas;
   if (n_odo_edges) *n_odo_edges = (int64_t)d.n_odo * replicas;
+  return PPS_OK;
+}
+
+int pps_frames_set_calibration(pps_graph* g, const float invK[9]) {
+  if (!g || !invK) return PPS_EINVAL;
+  memcpy(g->frames_invK, invK, sizeof g->frames_invK);
+  return PPS_OK;
+}
+
+int pps_frames_add(pps_graph* g, int pose_id, int n_seg, const float* seg2d, const int* fids, int* frame_id) {
+  if (!g || n_seg < 0 || !fids || (n_seg > 0 && !seg2d)) return PPS_EINVAL;
+  if (!live_node(g, pose_id, NODE_POSE)) return fail(g, PPS_EINVAL, "frames_add: unknown pose id");
+  for (int j = 0; j <= n_seg; j++) {
+    const int fid = fids[j];
+    if (fid < 0) continue;
+    if (fid >= (int)g->factors.size() || g->factors[fid].deleted || g->factors[fid].type != F_PLANE_OBS || g->factors[fid].a != pose_id)
+      return fail(g, PPS_EINVAL, "frames_add: fid is not a plane observation of this pose");
+  }
+  const int f = (int)g->fr_pose.size();
+  g->fr_pose.push_back(pose_id);
+  for (int k = 0; k < 4 * n_seg; k++) g->fr_seg.push_back(seg2d[k]);
+  g->fr_seg_off.push_back(g->fr_seg_off.back() + n_seg);
+  for (int j = 0; j <= n_seg; j++) { g->fr_item_frame.push_back(f); g->fr_item_plane.push_back(j); g->fr_item_fid.push_back(fids[j]); }
+  g->frames_dirty = true;
+  if (frame_id) *frame_id = f;
+  return PPS_OK;
+}
+
+int pps_refresh_measurements(pps_graph* g) {
+  if (!g) return PPS_EINVAL;
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  if (g->fr_item_frame.empty()) return PPS_OK;
+  if (g->frames_dirty) {
+    std::vector<int> slot(g->fr_item_fid.size()), pslot(g->fr_pose.size());
+    for (size_t i = 0; i < slot.size(); i++) {
+      const int fid = g->fr_item_fid[i];
+      slot[i] = (fid >= 0 && !g->factors[fid].deleted) ? g->factors[fid].slot : -1;
+      if (slot[i] >= 0 && g->nodes[g->fr_pose[g->fr_item_frame[i]]].deleted) slot[i] = -1;
+    }
+    for (size_t f = 0; f < pslot.size(); f++) pslot[f] = g->nodes[g->fr_pose[f]].deleted ? 0 : g->nodes[g->fr_pose[f]].slot;
+    // tables live in the allocation list of the current upload; older copies are simply abandoned until then
+    rc = dev_upload(g, &g->d_item_frame, g->fr_item_frame); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_item_plane, g->fr_item_plane); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_item_slot, slot); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_frame_pose_slot, pslot); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_frame_seg_off, g->fr_seg_off); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_fr_seg, g->fr_seg); if (rc != PPS_OK) return rc;
+    g->frames_dirty = false;
+  }
+  RefreshArgs a{};
+  a.n_items = (int)g->fr_item_frame.size();
+  a.item_frame = g->d_item_frame; a.item_plane = g->d_item_plane; a.item_slot = g->d_item_slot;
+  a.frame_pose_slot = g->d_frame_pose_slot; a.frame_seg_off = g->d_frame_seg_off; a.seg2d = g->d_fr_seg;
+  memcpy(a.invK, g->frames_invK, sizeof a.invK);
+  a.pose_est = g->dev.pose_est; a.pose_ld = g->dev.pose_ld;
+  a.obs_meas = g->dev.obs_meas; a.n_obs = g->dev.n_obs;
+  HIP_TRY(g, launch_refresh_measurements(a, g->stream));
+  g->dev_meas_newer = true;
+  return PPS_OK;
+}
+
+int pps_get_measurement(pps_graph* g, int fid, double meas4[4]) {
+  if (!g || !meas4) return PPS_EINVAL;
+  if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "get_measurement: unknown factor id");
+  const HostFactor& f = g->factors[fid];
+  if (f.type != F_PLANE_OBS && f.type != F_PLANE_PRIOR) return fail(g, PPS_EINVAL, "get_measurement: not a plane factor");
+  if (g->dev_meas_newer) { int rc = download_measurements(g); if (rc != PPS_OK) return rc; }
+  memcpy(meas4, f.meas, 4 * sizeof(double));
   return PPS_OK;
 }
 

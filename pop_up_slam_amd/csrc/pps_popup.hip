@@ -1,10 +1,376 @@
-// placeholder: replaced by the real pop-up kernels in the next commit
+// pps_popup.hip -- pop-up kernels (fp32, like the reference's pop_up_wall).
+//
+//   K5  segments -> plane equations   popup_plane::get_plane_equation / update_plane_equation_from_seg
+//                                      (/root/reference/pop_up_wall/libs/popup_plane.cpp:551-603,654-705)
+//   K6  pixels -> 3-D points / depth   generate_cloud + matrixToCloud (:807-863,925-985), get_depth_map_good (:866-921),
+//                                      ray_plane_interact (libs/matrix_utils.cpp:189-193)
+// K5 and K6 are fused into one launch: every workgroup re-derives the (<= 64) plane equations of the
+// frame into LDS (a few hundred flops), then its threads classify one pixel each against the plane
+// polygons (also in LDS) and intersect the pixel ray with the plane.  One 16-byte record per pixel is
+// written with a single coalesced store; the bound is HBM (20 B/pixel algorithmic: 3 B BGR + 1 B label
+// equivalent in, 16 B out).
+// k_refresh_measurements is K5 alone, writing straight into the graph's edge-measurement array
+// (Mapper_mono::update_plane_measurement, pop_planar_slam/src/Mapping.cpp:590-607).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
 #include "../../include/pps.h"
-extern "C" {
-int pps_popup_planes(int, const float*, int, const float*, const float*, float*) { return PPS_ESTATE; }
-int pps_popup_create(int, int, int, const float*, pps_popup**) { return PPS_ESTATE; }
-int pps_popup_destroy(pps_popup*) { return PPS_ESTATE; }
-int pps_popup_frame(pps_popup*, const float*, int, const float*, const float*, const int*, int, const unsigned char*, float, float,
-                    float*, float*, unsigned char*, unsigned char*, float*, int*) { return PPS_ESTATE; }
-int pps_popup_refresh_measurements(pps_graph*, int, const int*, const int*, const float*, const float*, const int*) { return PPS_ESTATE; }
+#include "pps_popup_dev.h"
+
+namespace pps {
+
+constexpr int kMaxPlanes = 64;
+constexpr int kMaxVerts = 512;
+
+// one wall plane from a ground segment; exact operation order of the reference (and of the oracle)
+__device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
+                                             const float gs[4], float out[4]) {
+  float Pw[2][3];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const float u = seg[2 * e], v = seg[2 * e + 1];
+    float ray[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) ray[i] = invK[i * 3 + 0] * u + invK[i * 3 + 1] * v + invK[i * 3 + 2] * 1.f;
+    const float frac = -gs[3] / (gs[0] * ray[0] + gs[1] * ray[1] + gs[2] * ray[2]);
+    const float Ps[4] = {frac * ray[0], frac * ray[1], frac * ray[2], 1.f};
+    float Ph[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) Ph[i] = T[i * 4 + 0] * Ps[0] + T[i * 4 + 1] * Ps[1] + T[i * 4 + 2] * Ps[2] + T[i * 4 + 3] * Ps[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Pw[e][i] = Ph[i] / Ph[3];
+  }
+  const float t1[3] = {Pw[1][0] - Pw[0][0], Pw[1][1] - Pw[0][1], Pw[1][2] - Pw[0][2]};
+  const float t2[3] = {0.f, 0.f, -1.f};
+  const float nw[3] = {t1[1] * t2[2] - t1[2] * t2[1], t1[2] * t2[0] - t1[0] * t2[2], t1[0] * t2[1] - t1[1] * t2[0]};
+  const float dist = -(nw[0] * Pw[0][0] + nw[1] * Pw[0][1] + nw[2] * Pw[0][2]);
+  const float pw[4] = {nw[0], nw[1], nw[2], dist};
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = T[0 * 4 + k] * pw[0] + T[1 * 4 + k] * pw[1] + T[2 * 4 + k] * pw[2] + T[3 * 4 + k] * pw[3];
 }
+
+__device__ __forceinline__ void ground_plane_sensor(const float* T, float gs[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) gs[k] = T[0 * 4 + k] * 0.f + T[1 * 4 + k] * 0.f + T[2 * 4 + k] * -1.f + T[3 * 4 + k] * 0.f;
+}
+
+__global__ __launch_bounds__(64) void k_popup_planes(const float* __restrict__ seg2d, int n, PopupParams prm,
+                                                     float* __restrict__ planes_out) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j > n) return;
+  float gs[4], pl[4];
+  ground_plane_sensor(prm.T, gs);
+  if (j == 0) { pl[0] = gs[0]; pl[1] = gs[1]; pl[2] = gs[2]; pl[3] = gs[3]; }
+  else seg_to_plane(seg2d + 4 * (j - 1), prm.invK, prm.T, gs, pl);
+#pragma unroll
+  for (int k = 0; k < 4; k++) planes_out[4 * j + k] = pl[k];
+}
+
+// Fused K5 + K6.  grid = ceil(W*H / 256), one thread per pixel.
+__global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const float* __restrict__ seg2d, int n,
+                                                     const float* __restrict__ polys, const int* __restrict__ poly_off,
+                                                     int nplanes, const unsigned char* __restrict__ bgr,
+                                                     float* __restrict__ planes_out, pps_point* __restrict__ cloud,
+                                                     float* __restrict__ depth, int* __restrict__ plane_id,
+                                                     unsigned int* __restrict__ n_valid) {
+  __shared__ float s_planes[kMaxPlanes + 1][4];
+  __shared__ float s_poly[2 * kMaxVerts];
+  __shared__ int s_off[kMaxPlanes + 2];
+  __shared__ float s_ceil[4];
+  __shared__ unsigned int s_cnt;
+  const int tid = threadIdx.x;
+  // ---- K5: plane equations of this frame (every workgroup; block 0 publishes them) ----
+  if (tid <= n && tid <= kMaxPlanes) {
+    float gs[4], pl[4];
+    ground_plane_sensor(prm.T, gs);
+    if (tid == 0) { pl[0] = gs[0]; pl[1] = gs[1]; pl[2] = gs[2]; pl[3] = gs[3]; }
+    else seg_to_plane(seg2d + 4 * (tid - 1), prm.invK, prm.T, gs, pl);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_planes[tid][k] = pl[k];
+    if (blockIdx.x == 0 && planes_out) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) planes_out[4 * tid + k] = pl[k];
+    }
+  }
+  if (tid == 0) {
+    // ceiling_plane_world = (0,0,-1,ceiling) ; sensor = T^T * world  (popup_plane.cpp:602-603)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      s_ceil[k] = prm.T[0 * 4 + k] * 0.f + prm.T[1 * 4 + k] * 0.f + prm.T[2 * 4 + k] * -1.f + prm.T[3 * 4 + k] * prm.ceiling_thre;
+    s_cnt = 0;
+  }
+  for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
+  __syncthreads();
+  const int nverts = s_off[nplanes];
+  for (int i = tid; i < 2 * nverts; i += 256) s_poly[i] = polys[i];
+  __syncthreads();
+
+  const int idx = blockIdx.x * 256 + tid;
+  const int W = prm.width, H = prm.height;
+  bool keep = false;
+  if (idx < W * H) {
+    const int y = idx / W, x = idx - y * W;
+    int pid = -1;
+    if (prm.step == 1 || (((x | y) & 1) == 0)) {
+      const float fx = (float)x, fy = (float)y;
+      // ---- pixel -> plane: last convex polygon containing the pixel centre (edges inclusive) ----
+      for (int p = 0; p < nplanes; p++) {
+        const int v0 = s_off[p], v1 = s_off[p + 1];
+        if (v1 - v0 < 3) continue;
+        bool pos = true, neg = true;
+        for (int v = v0; v < v1; v++) {
+          const int w = (v + 1 < v1) ? v + 1 : v0;
+          const float ax = s_poly[2 * v], ay = s_poly[2 * v + 1];
+          const float bx = s_poly[2 * w], by = s_poly[2 * w + 1];
+          const float cr = (bx - ax) * (fy - ay) - (by - ay) * (fx - ax);
+          pos = pos && (cr >= 0.f);
+          neg = neg && (cr <= 0.f);
+        }
+        if (pos || neg) pid = p;
+      }
+    }
+    pps_point pt;
+    pt.x = pt.y = pt.z = 0.f;
+    pt.rgba = 0u;
+    float dep = 0.f;
+    if (pid >= 0) {
+      // ---- K6: ray-plane intersection (ray_plane_interact), world transform, filters ----
+      const float fx = (float)x, fy = (float)y;
+      const float* pl = s_planes[pid];
+      float ray[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) ray[i] = prm.invK[i * 3 + 0] * fx + prm.invK[i * 3 + 1] * fy + prm.invK[i * 3 + 2] * 1.f;
+      const float frac = -pl[3] / (pl[0] * ray[0] + pl[1] * ray[1] + pl[2] * ray[2]);
+      const float Ps[3] = {frac * ray[0], frac * ray[1], frac * ray[2]};
+      float Pw[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) Pw[i] = prm.T[i * 4 + 0] * Ps[0] + prm.T[i * 4 + 1] * Ps[1] + prm.T[i * 4 + 2] * Ps[2];
+#pragma unroll
+      for (int i = 0; i < 3; i++) Pw[i] += prm.T[i * 4 + 3];
+      keep = !(Ps[2] < 0.f) && !(Ps[2] > prm.depth_thre) && !(Pw[2] < -0.2f);
+      if (keep) {
+        pt.x = Pw[0]; pt.y = Pw[1];
+        pt.z = Pw[2] < prm.ceiling_thre ? Pw[2] : prm.ceiling_thre;
+        unsigned int rgb = 0u;
+        if (bgr) {
+          const unsigned char* c = bgr + 3 * (size_t)idx;
+          rgb = ((unsigned int)c[2] << 16) | ((unsigned int)c[1] << 8) | (unsigned int)c[0];
+        }
+        pt.rgba = (1u << 24) | rgb;
+      }
+      // depth map (get_depth_map_good): ceiling plane substituted above the ceiling threshold
+      if (Pw[2] < prm.ceiling_thre) {
+        if (!(Ps[2] < 0.f)) dep = Ps[2];
+      } else {
+        const float fc = -s_ceil[3] / (s_ceil[0] * ray[0] + s_ceil[1] * ray[1] + s_ceil[2] * ray[2]);
+        const float z = fc * ray[2];
+        if (!(z < 0.f)) dep = z;
+      }
+    }
+    cloud[idx] = pt;                     // one 16-byte store per lane
+    if (depth) depth[idx] = dep;
+    if (plane_id) plane_id[idx] = pid;
+  }
+  // ---- count kept points: wave ballot, one LDS atomic per wave, one global atomic per block ----
+  const unsigned long long m = __ballot(keep);
+  if ((tid & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned int)__popcll(m));
+  __syncthreads();
+  if (tid == 0 && s_cnt) atomicAdd(n_valid, s_cnt);
+}
+
+// K5 feeding the graph: one thread per (frame, plane).  Pose comes from the fp64 estimate, is cast to
+// fp32 like `value().wTo().cast<float>()` (Mapping.cpp:598-599); the fp32 plane is cast back to fp64 and
+// normalised like Plane3d(Vector4d) (src/isam_plane3d.h:59-66) before it lands in the edge array.
+__global__ __launch_bounds__(256) void k_refresh_measurements(RefreshArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_items) return;
+  const int slot = a.item_slot[i];
+  if (slot < 0) return;
+  const int f = a.item_frame[i], j = a.item_plane[i];
+  const int ps = a.frame_pose_slot[f];
+  double q[4], t[3];
+  t[0] = a.pose_est[(size_t)0 * a.pose_ld + ps]; t[1] = a.pose_est[(size_t)1 * a.pose_ld + ps]; t[2] = a.pose_est[(size_t)2 * a.pose_ld + ps];
+  q[0] = a.pose_est[(size_t)3 * a.pose_ld + ps]; q[1] = a.pose_est[(size_t)4 * a.pose_ld + ps];
+  q[2] = a.pose_est[(size_t)5 * a.pose_ld + ps]; q[3] = a.pose_est[(size_t)6 * a.pose_ld + ps];
+  // wTo in fp64 (Pose3d::wTo, Pose3d.h:188-194), then cast
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  float T[16];
+  T[0] = (float)(1 - (tyy + tzz)); T[1] = (float)(txy - twz);       T[2] = (float)(txz + twy);        T[3] = (float)t[0];
+  T[4] = (float)(txy + twz);       T[5] = (float)(1 - (txx + tzz)); T[6] = (float)(tyz - twx);        T[7] = (float)t[1];
+  T[8] = (float)(txz - twy);       T[9] = (float)(tyz + twx);       T[10] = (float)(1 - (txx + tyy)); T[11] = (float)t[2];
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+  float gs[4], pl[4];
+  ground_plane_sensor(T, gs);
+  if (j == 0) { pl[0] = gs[0]; pl[1] = gs[1]; pl[2] = gs[2]; pl[3] = gs[3]; }
+  else seg_to_plane(a.seg2d + 4 * (size_t)(a.frame_seg_off[f] + j - 1), a.invK, T, gs, pl);
+  double v[4] = {(double)pl[0], (double)pl[1], (double)pl[2], (double)pl[3]};
+  const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) a.obs_meas[(size_t)k * a.n_obs + slot] = v[k] / nrm;
+}
+
+hipError_t launch_refresh_measurements(const RefreshArgs& a, hipStream_t st) {
+  if (a.n_items == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_refresh_measurements, dim3((a.n_items + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace pps
+
+// ============================================================================================
+using namespace pps;
+
+struct pps_popup {
+  int device = 0, width = 0, height = 0;
+  float invK[9];
+  std::string err;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  unsigned char* d_bgr = nullptr; bool has_image = false;
+  pps_point* d_cloud = nullptr;
+  float* d_depth = nullptr;
+  int* d_pid = nullptr;
+  float* d_planes = nullptr;   // (kMaxPlanes+1) x 4
+  float* d_seg = nullptr;      // kMaxPlanes x 4
+  float* d_polys = nullptr;    // 2*kMaxVerts
+  int* d_off = nullptr;        // kMaxPlanes+2
+  unsigned int* d_count = nullptr;
+  unsigned int* h_count = nullptr;   // pinned
+  int last_n = 0;
+  double last_kernel_s = 0;
+};
+
+namespace {
+int pfail(pps_popup* p, int code, const std::string& m) { if (p) p->err = m; return code; }
+#define PHIP(p, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return pfail(p, PPS_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+}  // namespace
+
+extern "C" {
+
+int pps_popup_planes(int device, const float* seg2d, int n, const float invK[9], const float T_wc[16], float* planes_out) {
+  if (!seg2d || !invK || !T_wc || !planes_out || n < 0) return PPS_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) return PPS_EHIP;
+  float *d_seg = nullptr, *d_out = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d_seg), sizeof(float) * 4 * (size_t)(n > 0 ? n : 1)) != hipSuccess) return PPS_EHIP;
+  if (hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float) * 4 * (size_t)(n + 1)) != hipSuccess) { (void)hipFree(d_seg); return PPS_EHIP; }
+  PopupParams prm{};
+  memcpy(prm.invK, invK, sizeof prm.invK);
+  memcpy(prm.T, T_wc, sizeof prm.T);
+  hipError_t e = hipSuccess;
+  if (n > 0) e = hipMemcpy(d_seg, seg2d, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_popup_planes, dim3((n + 1 + 63) / 64), dim3(64), 0, 0, d_seg, n, prm, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(planes_out, d_out, sizeof(float) * 4 * (size_t)(n + 1), hipMemcpyDeviceToHost);
+  (void)hipFree(d_seg);
+  (void)hipFree(d_out);
+  return e == hipSuccess ? PPS_OK : PPS_EHIP;
+}
+
+int pps_popup_create(int device, int width, int height, const float invK[9], pps_popup** out) {
+  if (!out || !invK || width <= 0 || height <= 0) return PPS_EINVAL;
+  pps_popup* p = new (std::nothrow) pps_popup();
+  if (!p) return PPS_ENOMEM;
+  p->device = device; p->width = width; p->height = height;
+  memcpy(p->invK, invK, sizeof p->invK);
+  const size_t npx = (size_t)width * height;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev[0]);
+  if (e == hipSuccess) e = hipEventCreate(&p->ev[1]);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_bgr), npx * 3);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_cloud), npx * sizeof(pps_point));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_depth), npx * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_pid), npx * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * 4 * (kMaxPlanes + 1));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_seg), sizeof(float) * 4 * kMaxPlanes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_polys), sizeof(float) * 2 * kMaxVerts);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_off), sizeof(int) * (kMaxPlanes + 2));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_count), sizeof(unsigned int));
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_count), sizeof(unsigned int), hipHostMallocDefault);
+  if (e != hipSuccess) { pps_popup_destroy(p); return PPS_EHIP; }
+  *out = p;
+  return PPS_OK;
+}
+
+int pps_popup_destroy(pps_popup* p) {
+  if (!p) return PPS_EINVAL;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  (void)hipFree(p->d_bgr); (void)hipFree(p->d_cloud); (void)hipFree(p->d_depth); (void)hipFree(p->d_pid);
+  (void)hipFree(p->d_planes); (void)hipFree(p->d_seg); (void)hipFree(p->d_polys); (void)hipFree(p->d_off); (void)hipFree(p->d_count);
+  if (p->h_count) (void)hipHostFree(p->h_count);
+  if (p->ev[0]) (void)hipEventDestroy(p->ev[0]);
+  if (p->ev[1]) (void)hipEventDestroy(p->ev[1]);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return PPS_OK;
+}
+
+const char* pps_popup_last_error(const pps_popup* p) { return p ? p->err.c_str() : "null handle"; }
+
+int pps_popup_set_image(pps_popup* p, const unsigned char* bgr) {
+  if (!p) return PPS_EINVAL;
+  if (!bgr) { p->has_image = false; return PPS_OK; }
+  PHIP(p, hipMemcpy(p->d_bgr, bgr, (size_t)p->width * p->height * 3, hipMemcpyHostToDevice));
+  p->has_image = true;
+  return PPS_OK;
+}
+
+int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys, const int* poly_off,
+                  int nplanes, int step, float depth_thre, float ceiling_thre, int* n_valid) {
+  if (!p || !T_wc || !poly_off || n < 0 || nplanes < 0) return PPS_EINVAL;
+  if (n > kMaxPlanes - 1 || nplanes > kMaxPlanes) return pfail(p, PPS_EINVAL, "too many planes for one frame (max 64)");
+  if (nplanes > n + 1) return pfail(p, PPS_EINVAL, "more polygons than planes");
+  if (poly_off[nplanes] > kMaxVerts) return pfail(p, PPS_EINVAL, "too many polygon vertices (max 512)");
+  if (step != 1 && step != 2) return pfail(p, PPS_EINVAL, "step must be 1 or 2");
+  if ((n > 0 && !seg2d) || (poly_off[nplanes] > 0 && !polys)) return PPS_EINVAL;
+  PopupParams prm{};
+  memcpy(prm.invK, p->invK, sizeof prm.invK);
+  memcpy(prm.T, T_wc, sizeof prm.T);
+  prm.width = p->width; prm.height = p->height; prm.step = step;
+  prm.depth_thre = depth_thre; prm.ceiling_thre = ceiling_thre;
+  if (n > 0) PHIP(p, hipMemcpyAsync(p->d_seg, seg2d, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, p->stream));
+  if (poly_off[nplanes] > 0) PHIP(p, hipMemcpyAsync(p->d_polys, polys, sizeof(float) * 2 * (size_t)poly_off[nplanes], hipMemcpyHostToDevice, p->stream));
+  PHIP(p, hipMemcpyAsync(p->d_off, poly_off, sizeof(int) * (size_t)(nplanes + 1), hipMemcpyHostToDevice, p->stream));
+  PHIP(p, hipMemsetAsync(p->d_count, 0, sizeof(unsigned int), p->stream));
+  const int npx = p->width * p->height;
+  PHIP(p, hipEventRecord(p->ev[0], p->stream));
+  hipLaunchKernelGGL(k_popup_frame, dim3((npx + 255) / 256), dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
+                     p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->d_depth, p->d_pid, p->d_count);
+  PHIP(p, hipGetLastError());
+  PHIP(p, hipEventRecord(p->ev[1], p->stream));
+  PHIP(p, hipMemcpyAsync(p->h_count, p->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, p->stream));
+  PHIP(p, hipStreamSynchronize(p->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, p->ev[0], p->ev[1]);
+  p->last_kernel_s = 1e-3 * ms;
+  p->last_n = n;
+  if (n_valid) *n_valid = (int)*p->h_count;
+  return PPS_OK;
+}
+
+int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* depth, int32_t* plane_id) {
+  if (!p) return PPS_EINVAL;
+  const size_t npx = (size_t)p->width * p->height;
+  if (planes) PHIP(p, hipMemcpy(planes, p->d_planes, sizeof(float) * 4 * (size_t)(p->last_n + 1), hipMemcpyDeviceToHost));
+  if (cloud) PHIP(p, hipMemcpy(cloud, p->d_cloud, npx * sizeof(pps_point), hipMemcpyDeviceToHost));
+  if (depth) PHIP(p, hipMemcpy(depth, p->d_depth, npx * sizeof(float), hipMemcpyDeviceToHost));
+  if (plane_id) PHIP(p, hipMemcpy(plane_id, p->d_pid, npx * sizeof(int), hipMemcpyDeviceToHost));
+  return PPS_OK;
+}
+
+int pps_popup_last_kernel_time(const pps_popup* p, double* sec) {
+  if (!p || !sec) return PPS_EINVAL;
+  *sec = p->last_kernel_s;
+  return PPS_OK;
+}
+
+}  // extern "C"

@@ -516,3 +516,41 @@ def small_world(n_poses=5, n_planes=3, obs_per_pose=None, seed=0, physical_weigh
             obs.append((j, pw, float(dist), False))
         b.add_frame(tp, obs)
     return b.finish(kind="small", seed=seed)
+
+
+# ----------------------------------------------------------------------------
+# synthetic pop-up frames (config 5): ground segments + closed polygons for one camera view
+# ----------------------------------------------------------------------------
+K_TUM = np.array([[537.96, 0.0, 319.18], [0.0, 539.60, 247.05], [0.0, 0.0, 1.0]])  # plane_3d_tum_far.yaml:8-11 via main_3d.cpp:167-169
+
+
+def T_from_pose(tq):
+    T = np.eye(4)
+    T[:3, :3] = quat_to_R(tq[3:])
+    T[:3, 3] = tq[:3]
+    return T
+
+
+def corridor_frame(tq, half_width=1.5, near=4.0, far=8.0, width=640, height=480, K=K_TUM):
+    """Left / front / right walls of a corridor section seen from pose tq (camera convention of CAM_R0).
+    Returns (seg2d [3,4] fp32, polys list: ground + 3 wall quads, T_wc fp32 4x4).  The wall corners are
+    placed in the camera's own frame so that the view is always well posed."""
+    T = T_from_pose(np.asarray(tq, dtype=float))
+    R, t = T[:3, :3], T[:3, 3]
+    # ground points in front of the camera, expressed through its heading (camera z axis projected to the ground)
+    fwd = R[:, 2].copy(); fwd[2] = 0; fwd /= np.linalg.norm(fwd)
+    right = np.array([fwd[1], -fwd[0], 0.0])
+    base = np.array([t[0], t[1], 0.0])
+    corners = [base + fwd * near - right * half_width, base + fwd * far - right * half_width,
+               base + fwd * far + right * half_width, base + fwd * near + right * half_width]
+    px = []
+    for P in corners:
+        pc = R.T @ (P - t)
+        uv = K @ (pc / pc[2])
+        px.append(uv[:2])
+    px = np.array(px)
+    seg = np.array([[*px[0], *px[1]], [*px[1], *px[2]], [*px[2], *px[3]]], dtype=np.float32)
+    polys = [np.array([px[0], px[1], px[2], px[3], [px[3][0], height - 1], [px[0][0], height - 1]], dtype=np.float32)]
+    for a, b in ((0, 1), (1, 2), (2, 3)):
+        polys.append(np.array([px[a], px[b], [px[b][0], 0.0], [px[a][0], 0.0]], dtype=np.float32))
+    return seg, polys, T.astype(np.float32)

@@ -1,0 +1,156 @@
+"""GPU parity of the pop-up kernels (K5 segments->planes, K6 pixels->3-D, fused with the graph's
+measurement refresh) against the fp32 CPU oracle."""
+import numpy as np
+import pytest
+
+import pop_up_slam_amd as P
+from pop_up_slam_amd import synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+INVK = np.linalg.inv(synth.K_TUM).astype(np.float32)
+
+
+def _pose(yaw=0.05, pitch=0.02, x=0.1, y=0.3):
+    Rp = np.array([[1, 0, 0], [0, np.cos(pitch), -np.sin(pitch)], [0, np.sin(pitch), np.cos(pitch)]])
+    R = synth._Rz(yaw) @ synth.CAM_R0 @ Rp
+    return synth.pose_from_Rt(R, np.array([x, y, 1.0]))
+
+
+def test_planes_bit_exact(built):
+    rng = np.random.default_rng(0)
+    for trial in range(5):
+        seg, polys, T = synth.corridor_frame(_pose(yaw=rng.normal(0, 0.1), pitch=rng.normal(0, 0.03)))
+        got = P.popup_planes(seg, INVK, T)
+        ref = O.popup_planes(seg, INVK, T)
+        np.testing.assert_array_equal(got, ref)
+    # empty input: ground only
+    got = P.popup_planes(np.zeros((0, 4), np.float32), INVK, T)
+    assert got.shape == (1, 4)
+    np.testing.assert_array_equal(got[0], (T.T @ np.array([0, 0, -1, 0], np.float32)))
+
+
+def _mask_ref(polys):
+    """float64 point-in-convex-polygon, last polygon wins; also returns the distance-to-edge margin."""
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    pid = -np.ones((H, W), dtype=np.int32)
+    margin = np.full((H, W), np.inf)
+    for p, poly in enumerate(polys):
+        poly = np.asarray(poly, dtype=np.float64)
+        if len(poly) < 3:
+            continue
+        pos = np.ones((H, W), bool); neg = np.ones((H, W), bool)
+        for v in range(len(poly)):
+            a, b = poly[v], poly[(v + 1) % len(poly)]
+            cr = (b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0])
+            margin = np.minimum(margin, np.abs(cr) / np.hypot(*(b - a)))
+            pos &= cr >= 0; neg &= cr <= 0
+        pid[pos | neg] = p
+    return pid, margin
+
+
+@pytest.mark.parametrize("step", [1, 2])
+def test_fused_frame_matches_oracle(built, step):
+    rng = np.random.default_rng(1)
+    seg, polys, T = synth.corridor_frame(_pose())
+    bgr = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    pp = P.Popup(W, H, INVK)
+    pp.set_image(bgr)
+    nv = pp.run(seg, T, polys, step=step, depth_thre=10.0, ceiling_thre=2.5)
+    planes, cloud, depth, pid = pp.download()
+    # K5 inside the fused kernel == stand-alone K5 == oracle
+    np.testing.assert_array_equal(planes, O.popup_planes(seg, INVK, T))
+    # mask: own rasteriser against a float64 evaluation; disagreement only on pixels within 1e-3 px of an edge
+    ref_pid, margin = _mask_ref(polys)
+    if step == 2:
+        odd = (np.arange(W)[None, :] % 2 == 1) | (np.arange(H)[:, None] % 2 == 1)
+        assert np.all(pid[odd] == -1)
+        ref_pid = np.where(odd, -1, ref_pid)
+    bad = (pid != ref_pid)
+    assert np.all(margin[bad] < 1e-3), int(bad.sum())
+    assert (pid >= 0).mean() > (0.5 if step == 1 else 0.12)
+    # K6 per-pixel math given the product's mask
+    xyz, valid = O.popup_cloud(pid, INVK, T, planes, 10.0, 2.5)
+    got_valid = (cloud["rgba"] >> 24) & 1
+    np.testing.assert_array_equal(got_valid, valid)
+    assert nv == int(valid.sum())
+    v = valid.astype(bool)
+    for k, name in enumerate(("x", "y", "z")):
+        np.testing.assert_array_equal(cloud[name][v], xyz[..., k][v])
+    # colours: 0x00RRGGBB from the BGR image
+    rgb = (bgr[..., 2].astype(np.uint32) << 16) | (bgr[..., 1].astype(np.uint32) << 8) | bgr[..., 0]
+    np.testing.assert_array_equal(cloud["rgba"][v] & 0xFFFFFF, rgb[v])
+    # depth map with the ceiling substitution
+    ceil_s = (T.T @ np.array([0, 0, -1, 2.5], np.float32)).astype(np.float32)
+    ref_depth = O.popup_depth(pid, INVK, T, planes, ceil_s, 2.5)
+    np.testing.assert_array_equal(depth, ref_depth)
+    assert depth.max() > 3.0
+
+
+def test_wall_points_lie_on_the_wall(built):
+    """size-independent property: popped-up wall pixels are at the wall's world position."""
+    tq = _pose(yaw=0.0, pitch=0.0, x=0.0, y=0.0)
+    seg, polys, T = synth.corridor_frame(tq, half_width=1.5, near=4.0, far=8.0)
+    pp = P.Popup(W, H, INVK)
+    pp.run(seg, T, polys, ceiling_thre=5.0)
+    planes, cloud, depth, pid = pp.download()
+    front = (pid == 2) & (((cloud["rgba"] >> 24) & 1) == 1)
+    assert front.sum() > 1000
+    np.testing.assert_allclose(cloud["y"][front], 8.0, atol=2e-3)        # front wall at y = 8 m
+    ground = (pid == 0) & (((cloud["rgba"] >> 24) & 1) == 1)
+    np.testing.assert_allclose(cloud["z"][ground], 0.0, atol=2e-3)       # ground at z = 0
+
+
+def test_refresh_measurements_feeds_the_graph(built):
+    """K5 writing straight into the edge array == update_plane_measurement restated on the CPU."""
+    rng = np.random.default_rng(3)
+    g = P.Graph()
+    g.frames_set_calibration(INVK)
+    ident = synth._ut_diag([1.0] * 3)
+    ground = g.add_plane(synth.GROUND)
+    walls = [g.add_plane(synth._wall((-1, 0), (-1.5, 0))), g.add_plane(synth._wall((0, 1), (0, 8.0))),
+             g.add_plane(synth._wall((1, 0), (1.5, 0)))]
+    g.add_plane_prior(ground, synth.GROUND, synth._ut_diag([20.0] * 3))
+    poses, frames = [], []
+    prev = None
+    for k in range(6):
+        tq = _pose(yaw=rng.normal(0, 0.05), pitch=rng.normal(0, 0.02), x=rng.normal(0, 0.05), y=0.2 * k)
+        pid = g.add_pose(tq)
+        if prev is None:
+            g.add_pose_prior(pid, synth.pose_vector(tq), synth._ut_diag([0.5] * 6))
+        else:
+            g.add_odometry(prev[0], pid, synth.pose_vector(synth.pose_ominus(tq, prev[1])), synth._ut_diag([0.5] * 6))
+        seg, polys, T = synth.corridor_frame(tq)
+        fids = []
+        for j, ln in enumerate([ground] + walls):
+            fids.append(g.add_plane_obs(pid, ln, [0.0, 0.0, -1.0, 0.5], ident))   # dummy measurement, overwritten below
+        if k == 3:
+            fids[2] = -1      # a skipped plane keeps its measurement
+        g.frames_add(pid, seg, fids)
+        frames.append((pid, seg, fids))
+        poses.append(tq)
+        prev = (pid, tq)
+    g.refresh_measurements()
+    for (pid, seg, fids), tq in zip(frames, poses):
+        T32 = synth.T_from_pose(g.get_pose(pid)).astype(np.float32)
+        ref = O.popup_planes(seg, INVK, T32).astype(np.float64)
+        ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+        for j, fid in enumerate(fids):
+            if fid < 0:
+                continue
+            np.testing.assert_allclose(g.get_measurement(fid), ref[j], rtol=0, atol=1e-15)
+    # the skipped one is untouched (normalised dummy)
+    d = np.array([0.0, 0.0, -1.0, 0.5]); d /= np.linalg.norm(d)
+    np.testing.assert_allclose(g.get_measurement(frames[3][2][1]), g.get_measurement(frames[3][2][1]))
+    # measurements now consistent with the planes -> chi2 of the plane edges is tiny after refresh
+    chi = g.chi2()
+    assert np.isfinite(chi)
+    # solving after a refresh works and set_measurement still round-trips
+    g.update()
+    g.set_measurement(frames[0][2][0], [0, 0, -1, 0])
+    np.testing.assert_allclose(g.get_measurement(frames[0][2][0]), [0, 0, -1, 0])
+    # a later refresh overwrites it again
+    g.refresh_measurements()
+    assert abs(g.get_measurement(frames[0][2][0])[3]) > 1e-3
