@@ -59,6 +59,48 @@ def cpu_baseline(spec, budget_s=12.0):
     }
 
 
+def rank_seed(rank):
+    """C4: independently seeded C2-size graphs, one per GPU; rank 0 is BASELINE config 2 (seed 42)."""
+    return 42 if rank == 0 else 100 + rank
+
+
+def aggregate(dist, elapsed, iters, device):
+    """whole-job numbers: MAX of the per-rank wall time, SUM of the per-rank LM iterations"""
+    if dist is None:
+        return elapsed, float(iters)
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    it_t = torch.tensor([float(iters)], dtype=torch.float64, device=device)
+    dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(it_t.item())
+
+
+def cpu_dry_run(args, rank, world):
+    """No GPU: every rank builds and analyses ITS graph (host logic only) and feeds synthetic timings
+    through the same aggregation the real run uses."""
+    import torch.distributed as dist
+    import pop_up_slam_amd as P
+    from pop_up_slam_amd import synth
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    spec = synth.corridor(120, 26, seed=rank_seed(rank))
+    g = P.Graph()
+    spec.replay(g)
+    g.analyze()
+    st = g.stats()
+    elapsed, iters = 0.1 * (rank + 1), 10 * (rank + 1)
+    if world > 1:
+        dist.barrier()
+    elapsed, total = aggregate(dist if world > 1 else None, elapsed, iters, "cpu")
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "value": total / elapsed, "elapsed_max": elapsed,
+                          "total_iters": total, "seed": rank_seed(rank), "fronts": st["n_fronts"], "scaling": "weak"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +110,8 @@ def main():
                     help="Jacobian mode of the sweep (numeric = reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batched-replicas", type=int, default=0, help="0 = auto (> 256 MB per sweep)")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="CI only: gloo backend, no GPU work -- exercises the rank/seed/aggregation plumbing of the N>1 path")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,6 +119,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    if args.cpu_dry_run:
+        return cpu_dry_run(args, rank, world)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -84,9 +130,7 @@ def main():
     import pop_up_slam_amd as P
     from pop_up_slam_amd import synth
 
-    # C4: independently seeded C2-size graphs, one per GPU (seed 42 on rank 0 == BASELINE config 2)
-    seed = 42 if rank == 0 else 100 + rank
-    spec = synth.corridor(seed=seed)
+    spec = synth.corridor(seed=rank_seed(rank))
     mode = P.JAC_NUMERIC if args.mode == "numeric" else P.JAC_ANALYTIC
     g = P.Graph(device=local_rank, jacobian_mode=mode)
     spec.replay(g)
@@ -117,15 +161,7 @@ def main():
     chi2 = g.chi2()
     st = g.stats()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        it_t = torch.tensor([iters], dtype=torch.float64, device="cuda")
-        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
-        total_iters = float(it_t.item())
-    else:
-        total_iters = float(iters)
+    elapsed, total_iters = aggregate(dist, elapsed, iters, "cuda")
 
     if rank == 0:
         counts = spec.counts()

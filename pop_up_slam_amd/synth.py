@@ -93,7 +93,10 @@ def pose_vector(tq):
 
 
 def pose_from_Rt(R, t):
-    return np.concatenate([t, R_to_quat(R)])
+    # normalised: the Eigen matrix<->quaternion round trip multiplies a norm error by tan^2(theta/2)
+    # per chained oplus, which the generator must not feed into the graphs it hands out
+    q = R_to_quat(R)
+    return np.concatenate([t, q / np.linalg.norm(q)])
 
 
 def pose_ominus(a, b):
@@ -480,7 +483,7 @@ def manhattan_rooms(n_poses=10000, n_planes=2000, obs_per_pose=6, seed=43, rooms
 
 
 def small_world(n_poses=5, n_planes=3, obs_per_pose=None, seed=0, physical_weights=False, name=None,
-                meas_sigma=0.01):
+                meas_sigma=0.01, odo_scale=1.0):
     """Small random world for fixtures: a short wobbly trajectory and random vertical walls
     (plus the ground as landmark 0); each pose sees the ground and a random subset of walls."""
     rng = np.random.Generator(np.random.MT19937(seed))
@@ -494,7 +497,8 @@ def small_world(n_poses=5, n_planes=3, obs_per_pose=None, seed=0, physical_weigh
         walls.append(_wall(n, n * dist + np.array([0.0, 0.05 * n_poses])))
     if obs_per_pose is None:
         obs_per_pose = min(n_planes, 4)
-    b = _Builder(name or f"small_{n_poses}p_{n_planes}l", rng, physical_weights, meas_sigma=meas_sigma)
+    b = _Builder(name or f"small_{n_poses}p_{n_planes}l", rng, physical_weights, meas_sigma=meas_sigma,
+                 odo_sigma=odo_scale * np.array([0.01, 0.01, 0.01, np.deg2rad(0.2), np.deg2rad(0.2), np.deg2rad(0.2)]))
     yaw = 0.0
     for k in range(n_poses):
         yaw += rng.normal(0.0, np.deg2rad(2.0))

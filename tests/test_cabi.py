@@ -1,0 +1,99 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/pps.h declares, and its
+host-side logic (argument checking, graph bookkeeping) behaves; no compute call is made."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pop_up_slam_amd as P
+from pop_up_slam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pps.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pps_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(built):
+    L = C.CDLL(P.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/pps.h but not exported by libpps.so"
+    assert set(names) == set(P.SYMBOLS), set(names) ^ set(P.SYMBOLS)
+    assert P.lib().pps_version() == 100
+
+
+def test_no_oracle_in_the_product(built):
+    """the product library must not link or reference the CPU oracle"""
+    import subprocess
+    out = subprocess.run(["ldd", P.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", P.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ora_" not in syms
+    for root, _, files in os.walk(os.path.join(ROOT, "pop_up_slam_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "pps_oracle" not in txt and "oracle_py" not in txt and "from oracle" not in txt, f
+
+
+def test_default_props_are_the_apps(built):
+    p = P.default_props()
+    assert (p.epsilon2, p.epsilon_abs, p.epsilon_rel) == pytest.approx((1e-3, 1e-4, 1e-6))
+    assert p.max_iterations == 500 and p.lm_lambda0 == 1e-6 and p.lm_lambda_factor == 10.0
+    assert p.jacobian_mode == P.JAC_NUMERIC
+
+
+def test_graph_bookkeeping_and_errors(built):
+    g = P.Graph()
+    ident3, ident6 = synth._ut_diag([1.0] * 3), synth._ut_diag([1.0] * 6)
+    p0 = g.add_pose([0, 0, 1, 0, 0, 0, 1]); p1 = g.add_pose([0, 1, 1, 0, 0, 0, 1]); l0 = g.add_plane([0, 0, -2, 0])
+    assert (p0, p1, l0) == (0, 1, 2)
+    np.testing.assert_allclose(g.get_plane(l0), [0, 0, -1, 0])       # normalised like Plane3d(Vector4d)
+    f0 = g.add_pose_prior(p0, np.zeros(6), ident6)
+    f1 = g.add_odometry(p0, p1, np.zeros(6), ident6)
+    f2 = g.add_plane_obs(p1, l0, [0, 0, -1, 0], ident3)
+    assert (f0, f1, f2) == (0, 1, 2)
+    st = g.stats()
+    assert (st["n_poses"], st["n_planes"], st["n_factors"], st["dim_nodes"], st["dim_measure"]) == (2, 1, 3, 15, 15)
+    with pytest.raises(P.PpsError) as e:
+        g.add_plane_obs(l0, p1, [0, 0, -1, 0], ident3)                # wrong node kinds
+    assert e.value.code == P.PPS_EINVAL
+    with pytest.raises(P.PpsError):
+        g.add_odometry(p0, p0, np.zeros(6), ident6)
+    with pytest.raises(P.PpsError):
+        g.add_pose([np.nan, 0, 0, 0, 0, 0, 1])
+    with pytest.raises(P.PpsError):
+        g.set_measurement(f1, [0, 0, -1, 0])                          # not a plane factor
+    with pytest.raises(P.PpsError):
+        g.get_pose(l0)
+    g.set_measurement(f2, [0, 0, -3, 0])
+    np.testing.assert_allclose(g.get_measurement(f2), [0, 0, -1, 0])
+    g.remove_node(p1)                                                 # removes f1 and f2 with it
+    assert g.num_nodes() == 2 and g.num_factors() == 1
+    with pytest.raises(P.PpsError):
+        g.remove_factor(f2)
+    g.set_pose(p0, [1, 2, 3, 0, 0, 0, 1])
+    np.testing.assert_allclose(g.get_pose(p0), [1, 2, 3, 0, 0, 0, 1])
+    np.testing.assert_allclose(g.get_poses(), [[1, 2, 3, 0, 0, 0, 1]])
+    g.close()
+
+
+def test_solve_without_gpu_fails_loudly(built):
+    """No silent CPU fallback: on a box without a GPU a solve returns PPS_EHIP."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    spec = synth.small_world(5, 3, seed=1)
+    g = P.Graph(); spec.replay(g)
+    with pytest.raises(P.PpsError) as e:
+        g.batch_optimize()
+    assert e.value.code == P.PPS_EHIP
+    with pytest.raises(P.PpsError):
+        g.chi2()

@@ -1,0 +1,87 @@
+"""CPU: host-side symbolic analysis (ordering, fronts, scatter maps, H-block contribution lists).
+The flat arrays pps_analysis_dump exports drive a numpy emulation of the device's multifrontal
+solve; its result must equal a dense solve of the same damped normal equations."""
+import numpy as np
+import pytest
+
+import pop_up_slam_amd as P
+from mf_emulator import solve_with_analysis
+from oracle import oracle_py as O
+from pop_up_slam_amd import synth
+
+CASES = {
+    "small5": lambda: synth.small_world(5, 3, seed=1),
+    "small50": lambda: synth.small_world(50, 10, seed=3, obs_per_pose=5),
+    "corridor150": lambda: synth.corridor(150, 32, seed=8),
+    "one_pose": lambda: synth.small_world(1, 3, seed=4),
+}
+
+
+def _dense_and_jbuf(spec, A, lam):
+    o = O.OracleGraph(); spec.replay(o)
+    dims = [o.node_dim(i) for i in range(o.num_nodes())]
+    starts = np.concatenate([[0], np.cumsum(dims)])
+    ncol = int(starts[-1])
+    Jbuf = np.zeros(A["J_size"])
+    rows, rhs = [], []
+    for k in range(o.num_factors()):
+        Hk, rk = o.factor_jacobian(k, 1)
+        m = Hk.shape[0]; a, b = spec.f_nodes[k]; da = dims[a]; db = dims[b] if b >= 0 else 0
+        off = A["factor_joff"][k]
+        Jbuf[off:off + m * da] = Hk[:, :da].ravel()
+        Jbuf[off + m * da:off + m * (da + db)] = Hk[:, da:].ravel()
+        Jbuf[off + m * (da + db):off + m * (da + db) + m] = rk
+        R = np.zeros((m, ncol)); R[:, starts[a]:starts[a] + da] = Hk[:, :da]
+        if b >= 0:
+            R[:, starts[b]:starts[b] + db] = Hk[:, da:]
+        rows.append(R); rhs.append(-rk)
+    J = np.vstack(rows); bvec = np.concatenate(rhs)
+    H = J.T @ J; H[np.diag_indices(ncol)] *= (1 + lam)
+    return np.linalg.solve(H, J.T @ bvec), Jbuf, starts, dims
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("lam", [0.0, 1e-3])
+def test_multifrontal_structure_solves_the_normal_equations(built, case, lam):
+    spec = CASES[case]()
+    g = P.Graph(); spec.replay(g)
+    g.analyze()
+    A = g.analysis_dump()
+    dref, Jbuf, starts, dims = _dense_and_jbuf(spec, A, lam)
+    d = solve_with_analysis(A, Jbuf, lam)
+    dm = np.zeros_like(dref)
+    for i in range(len(dims)):
+        c = A["node_compact"][i]
+        dm[starts[i]:starts[i] + dims[i]] = d[A["node_voff"][c]:A["node_voff"][c] + dims[i]]
+    assert np.abs(dm - dref).max() <= 1e-9 * np.abs(dref).max()
+
+
+def test_analysis_invariants_c2(built):
+    spec = synth.corridor()
+    g = P.Graph(); spec.replay(g); g.analyze()
+    A = g.analysis_dump()
+    assert A["n_scalars"] == 6 * 1000 + 3 * 200
+    assert sorted(A["order"]) == list(range(1200))                    # a permutation
+    assert A["f_p"].sum() == A["n_scalars"]                           # every scalar is a pivot exactly once
+    assert np.all(A["f_parent"][:-1] > np.arange(A["n_fronts"] - 1))  # post-order: parents come later
+    assert A["f_parent"][-1] == -1
+    lv = A["f_level"]
+    for s, p in enumerate(A["f_parent"]):
+        if p >= 0:
+            assert lv[p] > lv[s]
+    # the ground plane (degree 1000) is pulled out as the root border block
+    ground_compact = A["node_compact"][1]     # node 0 is the first pose, node 1 the ground
+    assert A["node_pos"][ground_compact] == 1199
+    assert A["max_front"] <= P.lib().pps_version() + 40               # small fronts (<= 140 rows: LDS resident)
+    st = g.stats()
+    assert st["n_fronts"] == A["n_fronts"] and st["n_levels"] == A["n_levels"]
+
+
+def test_reanalysis_after_topology_change(built):
+    spec = synth.small_world(12, 4, seed=2)
+    g = P.Graph(); nid, fid = spec.replay(g); g.analyze()
+    n0 = g.analysis_dump()["n_scalars"]
+    last_pose = int(nid[np.where(spec.node_type == 0)[0][-1]])
+    g.remove_node(last_pose)
+    g.analyze()
+    assert g.analysis_dump()["n_scalars"] == n0 - 6

@@ -1,0 +1,47 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing of bench.py (rank -> seed, one independent graph per
+rank, MAX-time / SUM-iterations aggregation).  The solve itself is replicas-only (no collective on
+the data path: SURVEY.md 8(e)), so this is all the distributed logic there is."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_ranks_gloo(built):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-dry-run"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # only rank 0 prints
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["scaling"] == "weak"
+    assert js["total_iters"] == 30.0            # 10 + 20
+    assert abs(js["elapsed_max"] - 0.2) < 1e-12  # max(0.1, 0.2)
+    assert abs(js["value"] - 150.0) < 1e-9
+
+
+def test_single_rank_dry_run(built):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-dry-run"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    js = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert js["n_gpus"] == 1 and js["seed"] == 42 and abs(js["value"] - 100.0) < 1e-9
+
+
+def test_rank_seeds_are_distinct():
+    sys.path.insert(0, ROOT)
+    import bench
+    seeds = [bench.rank_seed(r) for r in range(8)]
+    assert seeds[0] == 42 and len(set(seeds)) == 8
