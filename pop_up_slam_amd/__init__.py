@@ -346,9 +346,19 @@ def parse_analysis_dump(buf):
     k = 0
     for name in _DUMP_SCALARS:
         out[name] = int(buf[k]); k += 1
-    for name in _DUMP_VECTORS:
+    def vec():
+        nonlocal k
         n = int(buf[k]); k += 1
-        out[name] = np.array(buf[k:k + n], dtype=np.int64); k += n
+        v = np.array(buf[k:k + n], dtype=np.int64); k += n
+        return v
+    for name in _DUMP_VECTORS[:-2]:
+        out[name] = vec()
+    for name in ("n_stages", "n_groups", "n_glevels"):
+        out[name] = int(buf[k]); k += 1
+    for name in ("stage_grp_off", "grp_lvl_off", "glvl_front_off", "glvl_fronts", "stage_max_front", "stage_max_width"):
+        out[name] = vec()
+    for name in _DUMP_VECTORS[-2:]:
+        out[name] = vec()
     assert k == len(buf), (k, len(buf))
     return out
 

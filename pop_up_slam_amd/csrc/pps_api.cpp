@@ -64,6 +64,8 @@ struct pps_graph {
   std::vector<int> pose_ids, plane_ids;   // slot -> node id
   std::vector<int> fslot_ids[4];          // per type: slot -> factor id
   std::vector<int> level_max_front;
+  bool use_band = false;                  // wave-per-front band kernels (fronts <= 127 rows)
+  std::vector<int> stage_max_piv, stage_nw_factor, stage_nw_solve;
   // device
   bool dev_ready = false;
   hipStream_t stream = nullptr;
@@ -182,12 +184,32 @@ int run_analysis(pps_graph* g) {
   }
   if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
   if (const char* e = getenv("PPS_MAX_PIVOTS")) g->aprm.max_pivots = atoi(e);
+  if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
+  if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
   const char* msg = "";
   if (!analyze(sn, sf, g->aprm, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
   g->level_max_front.assign(g->an.n_levels, 0);
   for (int s = 0; s < g->an.n_fronts; s++) {
     int& m = g->level_max_front[g->an.f_level[s]];
     m = std::max(m, g->an.f_p[s] + g->an.f_b[s]);
+  }
+  {
+    const Analysis& A = g->an;
+    const int Bn = std::max(1, g->aprm.band_levels);
+    g->stage_max_piv.assign(A.n_stages, 1);
+    for (int s = 0; s < A.n_fronts; s++) { int& m = g->stage_max_piv[A.f_level[s] / Bn]; m = std::max(m, A.f_p[s]); }
+    int max_piv = 0;
+    for (int m : g->stage_max_piv) max_piv = std::max(max_piv, m);
+    g->use_band = A.max_front <= band_front_limit() && max_piv <= 64 && !getenv("PPS_NO_BAND");
+    g->stage_nw_factor.assign(A.n_stages, 1); g->stage_nw_solve.assign(A.n_stages, 1);
+    const size_t lds_budget = 150 * 1024;
+    int max_waves = 8;
+    if (const char* e = getenv("PPS_BAND_WAVES")) max_waves = std::max(1, std::min(8, atoi(e)));
+    for (int st = 0; st < A.n_stages; st++) {
+      const int want = std::max(1, std::min(max_waves, A.stage_max_width[st]));
+      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st])));
+      g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_solve_lds_bytes(g->stage_max_piv[st])));
+    }
   }
   g->analyzed = true;
   g->stats.n_fronts = g->an.n_fronts; g->stats.n_levels = g->an.n_levels; g->stats.max_front = g->an.max_front;
@@ -340,11 +362,24 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.seg_blk, A.seg_blk)); TRY(dev_upload(g, &d.seg_c0, A.seg_c0)); TRY(dev_upload(g, &d.seg_cnt, A.seg_cnt));
   TRY(dev_upload(g, &d.seg_hoff, A.seg_hoff));
   TRY(dev_upload(g, &d.contrib, A.contrib));
+  {
+    std::vector<int> mseg;
+    for (int bk = 0; bk < A.n_blocks; bk++) if (A.blk_nseg[bk] > 1) mseg.push_back(bk);
+    d.n_mseg = (int)mseg.size();
+    TRY(dev_upload(g, &d.mseg_blk, mseg));
+  }
+  TRY(dev_upload(g, &d.f_el_off, A.f_el_off)); TRY(dev_upload(g, &d.el_src, A.el_src)); TRY(dev_upload(g, &d.el_tgt, A.el_tgt));
+  TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off)); TRY(dev_upload(g, &d.ea_tgt, A.ea_tgt));
+  TRY(dev_upload(g, &d.blk_doff, A.blk_doff)); TRY(dev_upload(g, &d.blk_dst, A.blk_dst));
+  TRY(dev_alloc(g, &d.Hf, A.el_src.size()));
+  TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
+  TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &d.result_dev, 4));
+  if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
   // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
-  if (A.max_front > lds_front_limit()) {
+  if (!g->use_band && A.max_front > lds_front_limit()) {
     const int fa = A.max_front + 1;
     d.gwork_stride = (int64_t)fa * (fa | 1);
     int widest = 0;
@@ -403,6 +438,22 @@ int do_linearize(pps_graph* g) {
 // delta = (J'J + lambda diag(J'J))^-1 J'b  (Optimizer::compute_gauss_newton_step, Optimizer.cpp:49-67)
 int do_solve(pps_graph* g, double lambda) {
   const Analysis& A = g->an;
+  if (g->use_band) {
+    {
+      PhaseTimer t(g, &g->stats.t_factor);
+      for (int st = 0; st < A.n_stages; st++)
+        HIP_TRY(g, launch_band_factor(g->dev, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
+                                      A.stage_max_front[st], lambda, g->stream));
+    }
+    {
+      PhaseTimer t(g, &g->stats.t_backsolve);
+      for (int st = A.n_stages - 1; st >= 0; st--)
+        HIP_TRY(g, launch_band_solve(g->dev, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
+                                     g->stage_max_piv[st], g->stream));
+    }
+    g->stats.n_factorize++;
+    return PPS_OK;
+  }
   {
     PhaseTimer t(g, &g->stats.t_factor);
     for (int l = 0; l < A.n_levels; l++)
@@ -709,6 +760,25 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
   g->stats.t_total = now_s() - t0;
+  if (g->dev.trace) {
+    const Analysis& A = g->an;
+    std::vector<long long> tr((size_t)A.n_fronts * 8);
+    (void)hipMemcpy(tr.data(), g->dev.trace, tr.size() * 8, hipMemcpyDeviceToHost);
+    double acc[5] = {0, 0, 0, 0, 0};
+    std::vector<double> lvl_tot(A.n_levels, 0.0); std::vector<int> lvl_n(A.n_levels, 0);
+    for (int s2 = 0; s2 < A.n_fronts; s2++) {
+      for (int k = 0; k < 5; k++) acc[k] += (double)(tr[(size_t)s2 * 8 + k + 1] - tr[(size_t)s2 * 8 + k]);
+      lvl_tot[A.f_level[s2]] += (double)(tr[(size_t)s2 * 8 + 5] - tr[(size_t)s2 * 8]); lvl_n[A.f_level[s2]]++;
+    }
+    { double pn = 0, tr2 = 0; for (int s2 = 0; s2 < A.n_fronts; s2++) { pn += (double)tr[(size_t)s2 * 8 + 6]; tr2 += (double)tr[(size_t)s2 * 8 + 7]; }
+      fprintf(stderr, "PPS_TRACE elimination split: panel %.0f trailing %.0f cycles per front\n", pn / A.n_fronts, tr2 / A.n_fronts); }
+    fprintf(stderr, "PPS_TRACE mean cycles per front: zero %.0f gather %.0f extend-add %.0f eliminate %.0f store %.0f\n",
+            acc[0] / A.n_fronts, acc[1] / A.n_fronts, acc[2] / A.n_fronts, acc[3] / A.n_fronts, acc[4] / A.n_fronts);
+    for (int l = 0; l < A.n_levels; l++) fprintf(stderr, "  level %d: %d fronts, mean total %.0f cycles\n", l, lvl_n[l], lvl_tot[l] / std::max(1, lvl_n[l]));
+    long long tmin = tr[0], tmax = tr[5];
+    for (int s2 = 0; s2 < A.n_fronts; s2++) { tmin = std::min(tmin, tr[(size_t)s2 * 8]); tmax = std::max(tmax, tr[(size_t)s2 * 8 + 5]); }
+    fprintf(stderr, "  first start -> last end: %lld cycles\n", tmax - tmin);
+  }
   if (iterations) *iterations = num_iter;
   if (any_notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite");
   return PPS_OK;

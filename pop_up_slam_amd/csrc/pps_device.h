@@ -50,10 +50,18 @@ struct DevGraph {
   int *seg_blk = nullptr, *seg_c0 = nullptr, *seg_cnt = nullptr;
   int64_t* seg_hoff = nullptr;
   int* contrib = nullptr;
+  int n_mseg = 0; int* mseg_blk = nullptr;   // blocks with more than one segment (pre-reduced by k_hreduce)
+  // wave-per-front path: flat gather / scatter lists and the band schedule
+  int *f_el_off = nullptr, *el_src = nullptr, *el_tgt = nullptr;
+  int *blk_doff = nullptr, *blk_dst = nullptr;
+  double* Hf = nullptr;      // H in front gather order: front s reads Hf[f_el_off[s] .. f_el_off[s+1])
+  int64_t* f_ea_off = nullptr; int* ea_tgt = nullptr;
+  int *grp_lvl_off = nullptr, *glvl_front_off = nullptr, *glvl_fronts = nullptr;
   // ---- reductions / status ----
   double* chi2_partials = nullptr;   // one per block of the residual sweep
   int chi2_blocks = 0;
   double* result_dev = nullptr;      // [0] chi2, [1] |delta|^2, [2] not-PD flag (as double), [3] reserved
+  long long* trace = nullptr;        // PPS_TRACE=1: 8 timestamps (s_memtime) per front of the last factorisation
   double* gwork = nullptr;           // global-memory front workspace for fronts that exceed LDS
   int64_t gwork_stride = 0;
 };
@@ -64,6 +72,12 @@ hipError_t launch_hblocks(const DevGraph& d, hipStream_t st);
 hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
                                hipStream_t st);
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);
+// wave-per-front band kernels: one workgroup per group of the stage, `nwaves` fronts in flight per workgroup
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st);
+hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_piv, hipStream_t st);
+size_t band_solve_lds_bytes(int max_piv);
+int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
+size_t band_lds_bytes(int max_front);           // LDS bytes one wave needs for the factor kernel
 // est <- lin ; lin <- lin (+) delta          (LM trial: Optimizer.cpp:414-416)
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st);
 // est <- lin (+) delta                        (GN step: Optimizer.cpp:183)

@@ -13,6 +13,17 @@
 
 namespace pps {
 
+// Values that are wave-uniform by construction (they derive from threadIdx.x >> 6) but that the
+// compiler must treat as divergent: pin them into SGPRs so loops, branches and address arithmetic
+// built on them are scalar instead of exec-masked "waterfall" code.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long long uni64(long long x) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(x & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+
 // ------------------------------------------------------------------------------------------
 // K1: one thread per factor; SoA loads (coalesced across the wave), state gathered by index.
 // ------------------------------------------------------------------------------------------
@@ -225,6 +236,140 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const doubl
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ------------------------------------------------------------------------------------------
+// K1, lane-parallel central differences (the reference's numericalDiff, one evaluation per lane):
+// 32 lanes per factor = 2 factors per wavefront.  Lane 2q evaluates the residual at x (+) eps e_q,
+// lane 2q+1 at x (-) eps e_q, lane 2*ncols the nominal residual; a lane pair differences through
+// one DPP-style shuffle and lane 2q stores column q.  All lanes of a group read the same edge record
+// (a broadcast load), state is gathered by index from the SoA arrays.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void perturb6(const double p[7], int q, double sgn, double o[7]) {
+  double dl[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) dl[k] = (k == q) ? sgn * kNumDiffEps : 0.0;
+  pose_exmap(p, dl, o);
+}
+__device__ __forceinline__ void perturb3(const double p[4], int q, double sgn, double o[4]) {
+  double dl[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) dl[k] = (k == q) ? sgn * kNumDiffEps : 0.0;
+  plane_exmap(p, dl, o);
+}
+
+constexpr int kLaneGroup = 32;
+constexpr int kLanesPerBlock = 256;
+constexpr int kFactorsPerBlock = kLanesPerBlock / kLaneGroup;
+
+__global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, const double* __restrict__ pose,
+                                                                    const double* __restrict__ plane, int nb_obs, int nb_odo,
+                                                                    int nb_pp) {
+  const int grp = threadIdx.x / kLaneGroup, gl = threadIdx.x % kLaneGroup;
+  const int q = gl >> 1;                       // perturbed column
+  const double sgn = (gl & 1) ? -1.0 : 1.0;
+  const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+  int b = blockIdx.x;
+  if (b < nb_obs) {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_obs) return;
+    double pz[7], pl[4], ms[4], w[6], e[3], y[3];
+    load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
+    load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+    load_soa<4>(d.obs_meas, d.n_obs, i, ms);
+    load_soa<6>(d.obs_w, d.n_obs, i, w);
+    if (q < 6) { double pp[7]; perturb6(pz, q, sgn, pp); res_plane_obs(pp, pl, ms, e); }
+    else if (q < 9) { double pp[4]; perturb3(pl, q - 6, sgn, pp); res_plane_obs(pz, pp, ms, e); }
+    else res_plane_obs(pz, pl, ms, e);
+    whiten<3>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 6) out[r * 6 + q] = dcol;
+        else if (q < 9) out[18 + r * 3 + (q - 6)] = dcol;
+        else if (gl == 18) out[27 + r] = y[r];
+      }
+    }
+    return;
+  }
+  b -= nb_obs;
+  if (b < nb_odo) {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_odo) return;
+    double p1[7], p2[7], ms[6], w[21], e[6], y[6];
+    load_pose(pose, d.pose_ld, d.odo_a[i], p1);
+    load_pose(pose, d.pose_ld, d.odo_b[i], p2);
+    load_soa<6>(d.odo_meas, d.n_odo, i, ms);
+    load_soa<21>(d.odo_w, d.n_odo, i, w);
+    if (q < 6) { double pp[7]; perturb6(p1, q, sgn, pp); res_odometry(pp, p2, ms, e); }
+    else if (q < 12) { double pp[7]; perturb6(p2, q - 6, sgn, pp); res_odometry(p1, pp, ms, e); }
+    else res_odometry(p1, p2, ms, e);
+    whiten<6>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_odo + (size_t)i * 78;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 6) out[r * 6 + q] = dcol;
+        else if (q < 12) out[36 + r * 6 + (q - 6)] = dcol;
+        else if (gl == 24) out[72 + r] = y[r];
+      }
+    }
+    return;
+  }
+  b -= nb_odo;
+  if (b < nb_pp) {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_pp) return;
+    double pz[7], ms[6], w[21], e[6], y[6];
+    load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
+    load_soa<6>(d.pp_meas, d.n_pp, i, ms);
+    load_soa<21>(d.pp_w, d.n_pp, i, w);
+    if (q < 6) { double pp[7]; perturb6(pz, q, sgn, pp); res_pose_prior(pp, ms, e); }
+    else res_pose_prior(pz, ms, e);
+    whiten<6>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_pp + (size_t)i * 42;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 6) out[r * 6 + q] = dcol;
+        else if (gl == 12) out[36 + r] = y[r];
+      }
+    }
+    return;
+  }
+  b -= nb_pp;
+  {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_lp) return;
+    double pl[4], ms[4], w[6], e[3], y[3];
+    load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
+    load_soa<4>(d.lp_meas, d.n_lp, i, ms);
+    load_soa<6>(d.lp_w, d.n_lp, i, w);
+    if (q < 3) { double pp[4]; perturb3(pl, q, sgn, pp); res_plane_prior(pp, ms, e); }
+    else res_plane_prior(pl, ms, e);
+    whiten<3>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_lp + (size_t)i * 12;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 3) out[r * 3 + q] = dcol;
+        else if (gl == 6) out[9 + r] = y[r];
+      }
+    }
+  }
+}
+
+// below this many factors the lane-parallel form wins (latency); above it the thread-per-factor
+// form has the higher throughput (no idle lanes)
+constexpr int kLaneParallelMaxFactors = 200000;
+
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st) {
   const int nb_obs = cdiv(d.n_obs, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock), nb_pp = cdiv(d.n_pp, kLinBlock),
             nb_lp = cdiv(d.n_lp, kLinBlock);
@@ -232,6 +377,13 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   if (nb == 0) return hipSuccess;
   const double* pose = at_estimate ? d.pose_est : d.pose_lin;
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
+  if (mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors) {
+    const int lb_obs = cdiv(d.n_obs, kFactorsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
+              lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
+    hipLaunchKernelGGL(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
+                       lb_obs, lb_odo, lb_pp);
+    return hipGetLastError();
+  }
   if (mode == 1) hipLaunchKernelGGL(k_linearize<1>, dim3(nb), dim3(kLinBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
   else           hipLaunchKernelGGL(k_linearize<0>, dim3(nb), dim3(kLinBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
   return hipGetLastError();
@@ -290,37 +442,73 @@ hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double*
 // K2: one wavefront per H-block segment; lane = block entry, loop over <= seg_len contributions.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
-  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int seg = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (seg >= d.n_segs) return;
-  const int blk = d.seg_blk[seg];
-  const int rows = d.blk_rows[blk], cols = d.blk_cols[blk], size = d.blk_size[blk];
-  if (lane >= size) return;
+  const int blk = uni(d.seg_blk[seg]);
+  const int rows = uni(d.blk_rows[blk]), cols = uni(d.blk_cols[blk]), size = uni(d.blk_size[blk]);
+  const int c0 = uni(d.seg_c0[seg]), cnt = uni(d.seg_cnt[seg]);
+  // one contribution descriptor per lane, fetched in a single coalesced load (cnt <= 64)
+  int4 mine = make_int4(0, 0, 0, 0);
+  if (lane < cnt) mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
   const int rc = rows * cols;
+  const bool act = lane < size;
   const bool is_g = lane >= rc;
   const int i = is_g ? lane - rc : lane / cols;
-  const int j = is_g ? 0 : lane % cols;
-  const int c0 = d.seg_c0[seg], cnt = d.seg_cnt[seg];
-  const int4* __restrict__ ctr = reinterpret_cast<const int4*>(d.contrib);
+  const int j = is_g ? 0 : lane - (lane / cols) * cols;
   const double* __restrict__ J = d.J;
   double acc = 0.0;
-  for (int c = c0; c < c0 + cnt; c++) {
-    const int4 cc = ctr[c];
-    const double* jv = J + cc.x + i;
-    if (!is_g) {
-      const double* ju = J + cc.y + j;
-      for (int k = 0; k < cc.w; k++) acc += jv[k * rows] * ju[k * cols];
-    } else {
-      const double* r = J + cc.z;
-      for (int k = 0; k < cc.w; k++) acc -= jv[k * rows] * r[k];   // b = -r (isam/Jacobian.h:98)
+  for (int c = 0; c < cnt; c += 4) {
+    double a[4][6], bb[4][6];
+    int m[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int cc = c + u < cnt ? c + u : cnt - 1;      // clamp: the tail re-reads a valid descriptor, weight 0 below
+      const int jv = __builtin_amdgcn_readlane(mine.x, cc), ju = __builtin_amdgcn_readlane(mine.y, cc);
+      const int ro = __builtin_amdgcn_readlane(mine.z, cc);
+      m[u] = c + u < cnt ? __builtin_amdgcn_readlane(mine.w, cc) : 0;
+      const double* pa = J + jv + i;
+      const double* pb = is_g ? J + ro : J + ju + j;
+      const int sb = is_g ? 1 : cols;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const bool ok = act && k < m[u];
+        a[u][k] = ok ? pa[k * rows] : 0.0;
+        bb[u][k] = ok ? pb[k * sb] : 0.0;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += a[u][k] * bb[u][k];
   }
+  if (!act) return;
+  if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
   d.H[d.seg_hoff[seg] + lane] = acc;
+  if (uni(d.blk_nseg[blk]) == 1) {                        // final value: also place it where its front will gather it
+    const int dst = d.blk_dst[d.blk_doff[blk] + lane];
+    if (dst >= 0) d.Hf[dst] = acc;
+  }
+}
+
+// fold the partial sums of multi-segment blocks (the ground plane's diagonal) into their first slot
+__global__ __launch_bounds__(64) void k_hreduce(DevGraph d) {
+  const int blk = d.mseg_blk[blockIdx.x];
+  const int size = d.blk_size[blk], nseg = d.blk_nseg[blk];
+  double* __restrict__ h = d.H + d.blk_hoff[blk];
+  const int lane = threadIdx.x;
+  if (lane >= size) return;
+  double v = 0.0;
+  for (int q = 0; q < nseg; q++) v += h[(size_t)q * size + lane];
+  h[lane] = v;
+  const int dst = d.blk_dst[d.blk_doff[blk] + lane];
+  if (dst >= 0) d.Hf[dst] = v;
 }
 
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st) {
   if (d.n_segs == 0) return hipSuccess;
   hipLaunchKernelGGL(k_hblocks, dim3(cdiv(d.n_segs, 4)), dim3(256), 0, st, d);
+  if (d.n_mseg > 0) hipLaunchKernelGGL(k_hreduce, dim3(d.n_mseg), dim3(64), 0, st, d);
   return hipGetLastError();
 }
 
@@ -355,13 +543,12 @@ __global__ __launch_bounds__(256) void k_front_factor(DevGraph d, int level_begi
     const int a0 = d.f_asm_off[s], a1 = d.f_asm_off[s + 1];
     for (int a = a0 + wave; a < a1; a += nw) {
       const int blk = d.asm_blk[a], lrow = d.asm_lrow[a], lcol = d.asm_lcol[a];
-      const int rows = d.blk_rows[blk], cols = d.blk_cols[blk], size = d.blk_size[blk], nseg = d.blk_nseg[blk];
+      const int rows = d.blk_rows[blk], cols = d.blk_cols[blk], size = d.blk_size[blk];
       const double* __restrict__ h = d.H + d.blk_hoff[blk];
       const int rc = rows * cols;
       const bool diag = size > rc;
       if (lane < size) {
-        double v = 0.0;
-        for (int q = 0; q < nseg; q++) v += h[(size_t)q * size + lane];
+        double v = h[lane];   // k_hreduce has folded multi-segment blocks into their first slot
         if (lane < rc) {
           const int i = lane / cols, j = lane % cols;
           if (!diag || i >= j) {
@@ -441,6 +628,310 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
   } else {
     hipLaunchKernelGGL(k_front_factor<false>, dim3(level_count), dim3(256), 0, st, d, level_begin, lambda);
   }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K3, wave-per-front form.  The tree levels are cut into bands; inside a band every connected
+// sub-tree ("group") is walked by one workgroup: wave w takes fronts w, w+nw, ... of the current
+// local level, a workgroup barrier separates the levels, update matrices travel through global
+// memory (same CU, workgroup-scope visibility).  A front is a packed lower triangle in LDS
+// (index(i,j) = i(i+1)/2 + j, last row = right-hand side); lane i owns row i (and i+64), so the
+// elimination needs no barrier at all: column k is scaled, written back and re-read as LDS
+// broadcasts by the same wave, in program order.
+// ------------------------------------------------------------------------------------------
+constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
+
+int band_front_limit() { return kBandMaxRows - 1; }
+size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return fa * (fa + 1) / 2 * sizeof(double); }
+
+__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// 1/sqrt(x) to fp64 round-off: hardware estimate + two Newton steps (shorter than div + sqrt on the pivot chain)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// broadcast lane `l` (wave-uniform) of a double through two v_readlane_b32
+__device__ __forceinline__ double readlane_d(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+// One row of 16x16 tiles (I, J = o, o+16, ..., I) of the trailing lower triangle gets its rank-nb
+// update C -= P_I P_J^T: all LDS reads are issued unconditionally from clamped (always valid)
+// addresses and masked by selects afterwards, so the NT tiles' loads overlap; then NT back-to-back
+// v_mfma_f64_16x16x4_f64; then the masked stores.
+template <int NT>
+__device__ __forceinline__ void trailing_tile_row(double* __restrict__ F, int fa, int o, int I, int K, int nb, int lane) {
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int kk = K + lq;                                   // this lane's k index of the MFMA operands
+  const bool kvalid = lq < nb;
+  const int ar = I + l16;
+  const bool aok = kvalid && ar < fa;
+  const double araw = F[aok ? tri(ar) + kk : 0];
+  const double av = aok ? -araw : 0.0;
+  int crt[4]; bool rok[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { const int cr = I + lq + 4 * r; rok[r] = cr < fa; crt[r] = rok[r] ? tri(cr) : 0; }   // D layout: row (l/16)+4r, col l%16
+  double bv[NT];
+  double4_t c[NT];
+  bool cok[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int br = o + 16 * t + l16;
+    const bool bok = kvalid && br < fa;
+    const double braw = F[bok ? tri(br) + kk : 0];
+    bv[t] = bok ? braw : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      cok[t][r] = rok[r] && br <= I + lq + 4 * r;
+      const double craw = F[cok[t][r] ? crt[r] + br : 0];
+      c[t][r] = cok[t][r] ? craw : 0.0;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], c[t], 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int cc = o + 16 * t + l16;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (cok[t][r]) F[crt[r] + cc] = c[t][r];
+  }
+}
+
+__device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, double lambda, double* __restrict__ F) {
+  const int lane = threadIdx.x & 63;
+  const int s = uni(s_in);
+  const int p = uni(d.f_p[s]), b = uni(d.f_b[s]);
+  const int f = p + b, fa = f + 1;
+  const int ntri = tri(fa);
+#define PPS_TR(k) do { if (d.trace && lane == 0) d.trace[(size_t)s * 8 + (k)] = clock64(); } while (0)
+  PPS_TR(0);
+  for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  PPS_TR(1);
+  // ---- original entries: Hf is in gather order, so value and target index are two independent
+  // coalesced streams; 8 elements per lane are fetched before the first LDS update ----
+  {
+    const int e0 = uni(d.f_el_off[s]), e1 = uni(d.f_el_off[s + 1]);
+    const double damp = 1.0 + lambda;
+    const int* __restrict__ tgp = d.el_tgt;
+    const double* __restrict__ hf = d.Hf;
+    for (int e = e0 + lane; e < e1; e += 64 * 8) {
+      int tg[8]; double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < e1 ? tgp[x] : -1; v[u] = x < e1 ? hf[x] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];   // Cholesky.cpp:94-97
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  PPS_TR(2);
+  // ---- extend-add of the children's packed update matrices (same batching) ----
+  const int ci0 = uni(d.f_child_off[s]), ci1 = uni(d.f_child_off[s + 1]);
+  for (int ci = ci0; ci < ci1; ci++) {
+    const int c = uni(d.child[ci]);
+    const int bc1 = uni(d.f_b[c]) + 1;
+    const int n = tri(bc1);
+    const double* __restrict__ Uc = d.U + uni64(d.f_Uoff[c]);
+    const int* __restrict__ tgc = d.ea_tgt + uni64(d.f_ea_off[c]);
+    for (int e = lane; e < n; e += 64 * 8) {
+      int tg[8]; double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < n ? tgc[x] : -1; v[u] = x < n ? Uc[x] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tg[u] >= 0) F[tg[u]] += v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  PPS_TR(3);
+  // ---- eliminate the p pivot columns, four at a time ----
+  // Panel: lane i holds rows i and i+64 of the 4 panel columns in registers; the 4x4 diagonal block is
+  // broadcast with v_readlane, so the panel factorisation never waits on LDS.  Trailing update: the
+  // rank-4 update C -= P_I * P_J^T of every 16x16 tile of the remaining lower triangle is ONE
+  // v_mfma_f64_16x16x4_f64 (A = -P_I, B = P_J^T), operands gathered from the packed triangle in LDS.
+  const int r0 = lane, r1 = lane + 64;
+  const int t0 = tri(r0), t1 = tri(r1);
+  long long cyc_panel = 0, cyc_trail = 0;
+  for (int K = 0; K < p; K += 4) {
+    const long long tk0 = d.trace ? clock64() : 0;
+    double a0[4], a1[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int c = K + m;
+      const bool v0 = c < p && r0 >= c && r0 < fa, v1 = c < p && r1 >= c && r1 < fa;
+      const double x0 = F[v0 ? t0 + c : 0], x1 = F[v1 ? t1 + c : 0];
+      a0[m] = v0 ? x0 : 0.0;
+      a1[m] = v1 ? x1 : 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int c = K + m;
+      if (c < p) {                                         // wave-uniform
+        const double dmm = (c < 64) ? readlane_d(a0[m], c) : readlane_d(a1[m], c - 64);
+        double dinv = 0.0;
+        if (dmm > 0.0) dinv = rsqrt_nr(dmm);
+        else if (lane == 0) d.result_dev[2] = 1.0;         // not positive definite
+        if (r0 >= c) a0[m] *= dinv;                        // the diagonal becomes sqrt(dmm)
+        if (r1 >= c) a1[m] *= dinv;
+#pragma unroll
+        for (int n = m + 1; n < 4; n++) {
+          const int cn = K + n;
+          if (cn < p) {
+            const double lnm = (cn < 64) ? readlane_d(a0[m], cn) : readlane_d(a1[m], cn - 64);
+            if (r0 >= cn) a0[n] -= a0[m] * lnm;
+            if (r1 >= cn) a1[n] -= a1[m] * lnm;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int c = K + m;
+      if (c < p) {
+        if (r0 >= c && r0 < fa) F[t0 + c] = a0[m];
+        if (r1 >= c && r1 < fa) F[t1 + c] = a1[m];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long long tk1 = d.trace ? clock64() : 0;
+    const int o = K + 4 < p ? K + 4 : p;                   // first trailing column
+    const int nb = o - K;                                  // panel width (1..4)
+    for (int I = o; I < fa; I += 16) {
+      const int nt = ((I - o) >> 4) + 1;                   // tiles (I, J <= I) of this tile row, wave-uniform
+      switch (nt) {
+        case 1: trailing_tile_row<1>(F, fa, o, I, K, nb, lane); break;
+        case 2: trailing_tile_row<2>(F, fa, o, I, K, nb, lane); break;
+        case 3: trailing_tile_row<3>(F, fa, o, I, K, nb, lane); break;
+        case 4: trailing_tile_row<4>(F, fa, o, I, K, nb, lane); break;
+        case 5: trailing_tile_row<5>(F, fa, o, I, K, nb, lane); break;
+        case 6: trailing_tile_row<6>(F, fa, o, I, K, nb, lane); break;
+        case 7: trailing_tile_row<7>(F, fa, o, I, K, nb, lane); break;
+        default: trailing_tile_row<8>(F, fa, o, I, K, nb, lane); break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
+  }
+  PPS_TR(4);
+  if (d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
+  // ---- factor panel (f+1) x p row-major (diagonal = sqrt) and packed update matrix ----
+  double* __restrict__ Lp = d.L + uni64(d.f_Loff[s]);
+  if (lane < p) {                                          // p <= 64: lane = column
+    for (int i0 = 0; i0 < fa; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; v[u] = F[(i < fa && lane <= i) ? tri(i) + lane : 0]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; if (i < fa && lane <= i) Lp[(size_t)i * p + lane] = v[u]; }
+    }
+  }
+  double* __restrict__ Us = d.U + uni64(d.f_Uoff[s]);
+  for (int i0 = p; i0 < fa; i0 += 8) {
+    for (int j = p + lane; j < fa; j += 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; v[u] = F[(i < fa && j <= i) ? tri(i) + j : 0]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; if (i < fa && j <= i) Us[tri(i - p) + j - p] = v[u]; }
+    }
+  }
+  PPS_TR(5);
+}
+
+__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  const int g = grp_begin + blockIdx.x;
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* F = lds + (size_t)wave * lds_doubles_per_wave;
+  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
+  for (int l = l0; l < l1; l++) {
+    const int i1 = d.glvl_front_off[l + 1];
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) wave_front_factor(d, d.glvl_fronts[i], lambda, F);
+    __syncthreads();   // children of the next local level are complete and visible (same CU)
+  }
+}
+
+// x_p = L_A^-T (y - L_B^T x_b) for one front, one wave (p <= 64).  All global loads are issued in
+// batches that do not depend on each other; the back-substitution chain itself runs in registers
+// (lane j holds t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + packed L_A.
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int s_in, double* __restrict__ W) {
+  const int lane = threadIdx.x & 63;
+  const int s = uni(s_in);
+  const int p = uni(d.f_p[s]), b = uni(d.f_b[s]), f = p + b;
+  const double* __restrict__ Lp = d.L + uni64(d.f_Loff[s]);
+  const int* __restrict__ bi = d.bidx + uni(d.f_bidx_off[s]);
+  double* xb = W;
+  double* LA = W + kBandMaxRows;
+  for (int i = lane; i < b; i += 64) xb[i] = d.delta[bi[i]];
+  // stage L_A (packed lower triangle): p independent coalesced row loads
+#pragma unroll 8
+  for (int i = 0; i < p; i++) {
+    if (lane <= i) LA[tri(i) + lane] = Lp[(size_t)i * p + lane];
+  }
+  __builtin_amdgcn_wave_barrier();
+  double tj = 0.0, dinv = 0.0;
+  if (lane < p) {
+    double acc = Lp[(size_t)f * p + lane];
+#pragma unroll 8
+    for (int i = 0; i < b; i++) acc -= Lp[(size_t)(p + i) * p + lane] * xb[i];
+    tj = acc;
+    dinv = 1.0 / LA[tri(lane) + lane];
+  }
+#pragma unroll 4
+  for (int k = p - 1; k >= 0; k--) {
+    const double lkj = (lane < k) ? LA[tri(k) + lane] : 0.0;     // independent of the chain
+    const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
+    tj = (lane == k) ? xk : tj - lkj * xk;
+  }
+  if (lane < p) d.delta[uni(d.f_poff[s]) + lane] = tj;
+}
+
+__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  const int g = grp_begin + blockIdx.x;
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* W = lds + (size_t)wave * lds_doubles_per_wave;
+  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
+  for (int l = l1 - 1; l >= l0; l--) {
+    const int i1 = d.glvl_front_off[l + 1];
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) wave_front_solve(d, d.glvl_fronts[i], W);
+    __syncthreads();   // delta of this local level is visible to the children
+  }
+}
+
+static bool g_band_attr_set = false;
+
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st) {
+  if (grp_count == 0) return hipSuccess;
+  if (!g_band_attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e != hipSuccess) return e;
+    g_band_attr_set = true;
+  }
+  const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
+  hipLaunchKernelGGL(k_band_factor, dim3(grp_count), dim3(64 * nwaves), (size_t)per_wave * nwaves * sizeof(double), st, d, grp_begin, lambda, per_wave);
+  return hipGetLastError();
+}
+
+size_t band_solve_lds_bytes(int max_piv) { return (size_t)(kBandMaxRows + max_piv * (max_piv + 1) / 2) * sizeof(double); }
+
+hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_piv, hipStream_t st) {
+  if (grp_count == 0) return hipSuccess;
+  // t + xb + packed L_A (at most max_piv pivots)
+  const int per_wave = (int)(band_solve_lds_bytes(max_piv) / sizeof(double));
+  hipLaunchKernelGGL(k_band_solve, dim3(grp_count), dim3(64 * nwaves), (size_t)per_wave * nwaves * sizeof(double), st, d, grp_begin, per_wave);
   return hipGetLastError();
 }
 

@@ -283,6 +283,57 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       std::vector<int> w(A.level_off.begin(), A.level_off.end() - 1);
       for (int s = 0; s < F; s++) A.level_fronts[w[A.f_level[s]]++] = s;
     }
+    // ---- band schedule ----
+    {
+      const int Bn = std::max(1, prm.band_levels);
+      A.n_stages = (A.n_levels + Bn - 1) / Bn;
+      std::vector<int> grp(F, -1), ll(F, 0);
+      std::vector<int> grp_stage;
+      for (int s = F - 1; s >= 0; s--) {       // parents before children (post-order reversed)
+        const int par = A.f_parent[s];
+        const int band = A.f_level[s] / Bn;
+        if (par < 0 || A.f_level[par] / Bn != band) { grp[s] = (int)grp_stage.size(); grp_stage.push_back(band); }
+        else grp[s] = grp[par];
+      }
+      for (int s = 0; s < F; s++) {             // children before parents
+        int l = 0;
+        for (int c : kids[s]) if (grp[c] == grp[s]) l = std::max(l, ll[c] + 1);
+        ll[s] = l;
+      }
+      const int G = (int)grp_stage.size();
+      // order groups by stage
+      std::vector<int> gorder(G), gnew(G);
+      std::iota(gorder.begin(), gorder.end(), 0);
+      std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return grp_stage[a] < grp_stage[b]; });
+      for (int i = 0; i < G; i++) gnew[gorder[i]] = i;
+      A.n_groups = G;
+      A.stage_grp_off.assign(A.n_stages + 1, 0);
+      for (int g2 = 0; g2 < G; g2++) A.stage_grp_off[grp_stage[g2] + 1]++;
+      for (int st = 0; st < A.n_stages; st++) A.stage_grp_off[st + 1] += A.stage_grp_off[st];
+      std::vector<int> g_nl(G, 0);
+      for (int s = 0; s < F; s++) g_nl[gnew[grp[s]]] = std::max(g_nl[gnew[grp[s]]], ll[s] + 1);
+      A.grp_lvl_off.assign(G + 1, 0);
+      for (int g2 = 0; g2 < G; g2++) A.grp_lvl_off[g2 + 1] = A.grp_lvl_off[g2] + g_nl[g2];
+      A.n_glevels = A.grp_lvl_off[G];
+      A.glvl_front_off.assign(A.n_glevels + 1, 0);
+      for (int s = 0; s < F; s++) A.glvl_front_off[A.grp_lvl_off[gnew[grp[s]]] + ll[s] + 1]++;
+      for (int i = 0; i < A.n_glevels; i++) A.glvl_front_off[i + 1] += A.glvl_front_off[i];
+      A.glvl_fronts.assign(F, 0);
+      std::vector<int> w(A.glvl_front_off.begin(), A.glvl_front_off.end() - 1);
+      for (int s = 0; s < F; s++) A.glvl_fronts[w[A.grp_lvl_off[gnew[grp[s]]] + ll[s]]++] = s;
+      A.stage_max_front.assign(A.n_stages, 0);
+      A.stage_max_width.assign(A.n_stages, 0);
+      for (int s = 0; s < F; s++) {
+        const int st = A.f_level[s] / Bn;
+        A.stage_max_front[st] = std::max(A.stage_max_front[st], 0);
+      }
+      for (int g2 = 0; g2 < G; g2++) {
+        int st = 0;
+        while (g2 >= A.stage_grp_off[st + 1]) st++;
+        for (int l = A.grp_lvl_off[g2]; l < A.grp_lvl_off[g2 + 1]; l++)
+          A.stage_max_width[st] = std::max(A.stage_max_width[st], A.glvl_front_off[l + 1] - A.glvl_front_off[l]);
+      }
+    }
     // children CSR
     A.f_child_off.assign(F + 1, 0);
     for (int s = 0; s < F; s++) A.f_child_off[s + 1] = A.f_child_off[s] + (int)kids[s].size();
@@ -303,6 +354,10 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       A.max_front = std::max(A.max_front, f);
       A.f_Loff[s] = A.L_size; A.L_size += (int64_t)(f + 1) * A.f_p[s];
       A.f_Uoff[s] = A.U_size; A.U_size += (int64_t)(b + 1) * (b + 1);
+    }
+    for (int s = 0; s < F; s++) {
+      const int st = A.f_level[s] / std::max(1, prm.band_levels);
+      A.stage_max_front[st] = std::max(A.stage_max_front[st], A.f_p[s] + A.f_b[s]);
     }
     // child -> parent scatter maps
     A.f_cmap_off.assign(F + 1, 0);
@@ -325,6 +380,16 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
       for (int v : bnd[s]) loc[v] = -1;
     }
+    // packed update matrix of c -> packed index in the parent front
+    A.f_ea_off.assign(F + 1, 0);
+    A.ea_tgt.clear();
+    for (int s = 0; s < F; s++) {
+      A.f_ea_off[s] = (int64_t)A.ea_tgt.size();
+      const std::vector<int>& m = cm[s];    // empty for the root
+      for (size_t i = 0; i < m.size(); i++)
+        for (size_t j = 0; j <= i; j++) A.ea_tgt.push_back(m[i] * (m[i] + 1) / 2 + m[j]);
+    }
+    A.f_ea_off[F] = (int64_t)A.ea_tgt.size();
     for (int s = 0; s < F; s++) {
       A.f_cmap_off[s] = (int)A.cmap.size();
       A.cmap.insert(A.cmap.end(), cm[s].begin(), cm[s].end());
@@ -396,6 +461,11 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
     std::vector<int> blk_v(A.asm_lrow), blk_u(A.asm_lcol);
     A.asm_blk.clear(); A.asm_lrow.clear(); A.asm_lcol.clear();
     A.f_asm_off.assign(F + 1, 0);
+    A.f_el_off.assign(1, 0); A.el_src.clear(); A.el_tgt.clear();
+    A.blk_doff.assign(A.n_blocks + 1, 0);
+    for (int bk = 0; bk < A.n_blocks; bk++) A.blk_doff[bk + 1] = A.blk_doff[bk] + A.blk_size[bk];
+    A.blk_dst.assign(A.blk_doff[A.n_blocks], -1);
+    if (A.H_size > 0x3fffffffLL) { *msg = "H too large for int32 gather offsets"; return false; }
     for (int s = 0; s < F; s++) {
       int off = 0;
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
@@ -406,6 +476,31 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
         A.asm_blk.push_back(blk); A.asm_lrow.push_back(loc[v]); A.asm_lcol.push_back(loc[u]);
       }
       A.f_asm_off[s + 1] = (int)A.asm_blk.size();
+      // flat element list (lower triangle of diagonal blocks, full off-diagonal blocks, g entries)
+      {
+        const int fsz = A.f_p[s] + A.f_b[s];
+        auto tri = [](int i) { return i * (i + 1) / 2; };
+        for (int blk : asm_of[s]) {
+          const int v = blk_v[blk], u = blk_u[blk];
+          const int rows = A.blk_rows[blk], cols = A.blk_cols[blk];
+          const int lrow = loc[v], lcol = loc[u];
+          const bool diag = (v == u);
+          for (int i = 0; i < rows; i++)
+            for (int j = 0; j < cols; j++) {
+              if (diag && j > i) continue;
+              A.blk_dst[A.blk_doff[blk] + i * cols + j] = (int)A.el_src.size();
+              A.el_src.push_back((int)(A.blk_hoff[blk] + i * cols + j));
+              A.el_tgt.push_back((tri(lrow + i) + lcol + j) | ((diag && i == j) ? (1 << 30) : 0));
+            }
+          if (diag)
+            for (int i = 0; i < rows; i++) {
+              A.blk_dst[A.blk_doff[blk] + rows * cols + i] = (int)A.el_src.size();
+              A.el_src.push_back((int)(A.blk_hoff[blk] + rows * cols + i));
+              A.el_tgt.push_back(tri(fsz) + lcol + i);
+            }
+        }
+        A.f_el_off.push_back((int)A.el_src.size());
+      }
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
       for (int v : bnd[s]) loc[v] = -1;
     }
@@ -429,6 +524,8 @@ void dump_analysis(const Analysis& a, std::vector<int32_t>& out) {
   putv(a.blk_rows); putv(a.blk_cols); putv(a.blk_size); putv(a.blk_nseg); putv64(a.blk_hoff);
   putv(a.seg_blk); putv(a.seg_c0); putv(a.seg_cnt); putv64(a.seg_hoff);
   putv(a.contrib);
+  put(a.n_stages); put(a.n_groups); put(a.n_glevels);
+  putv(a.stage_grp_off); putv(a.grp_lvl_off); putv(a.glvl_front_off); putv(a.glvl_fronts); putv(a.stage_max_front); putv(a.stage_max_width);
 }
 
 }  // namespace pps

@@ -31,6 +31,7 @@ struct AnalysisParams {
   int leaf_poses = 4;      // a sub-chain with <= leaf_poses poses becomes one leaf front
   int max_pivots = 48;     // split supernodes with more pivot scalars into a chain
   int seg_len = 32;        // contributions reduced per wave in the H-block kernel
+  int band_levels = 4;     // tree levels walked by one workgroup inside one launch ("band")
   int dense_min = 64;      // a node is "dense" if degree > max(dense_min, dense_mult*sqrt(N))
   double dense_mult = 8.0;
 };
@@ -59,6 +60,26 @@ struct Analysis {
   std::vector<int> f_asm_off;       // [n_fronts+1] -> asm_* (original entries gathered by the front)
   std::vector<int> asm_blk, asm_lrow, asm_lcol;
   int64_t L_size = 0, U_size = 0;
+
+  // ---- band schedule: levels [B*s, B*s+B) form stage s; inside a stage the connected sub-trees are
+  // "groups", each walked by ONE workgroup (one wave per front, workgroup barrier between local levels) ----
+  int n_stages = 0, n_groups = 0, n_glevels = 0;
+  std::vector<int> stage_grp_off;    // [n_stages+1] -> groups
+  std::vector<int> grp_lvl_off;      // [n_groups+1] -> local levels
+  std::vector<int> glvl_front_off;   // [n_glevels+1] -> glvl_fronts
+  std::vector<int> glvl_fronts;      // [n_fronts]
+  std::vector<int> stage_max_front;  // [n_stages] largest front (scalars, without the rhs row)
+  std::vector<int> stage_max_width;  // [n_stages] widest local level (fronts)
+
+  // ---- flat gather / scatter lists of the wave-per-front kernels (front = packed lower triangle,
+  // index(i,j) = i(i+1)/2 + j, last row = right-hand side) ----
+  std::vector<int> blk_doff;         // [n_blocks+1] -> blk_dst : block element -> index in the front-ordered H ("Hf"), -1 = unused
+  std::vector<int> blk_dst;
+  std::vector<int> f_el_off;         // [n_fronts+1] -> el_src / el_tgt : original H entries of the front (= index range of Hf)
+  std::vector<int> el_src;           // offset into the H buffer (first segment slot of the block)
+  std::vector<int> el_tgt;           // packed front index; bit 30 set = diagonal element (scaled by 1+lambda)
+  std::vector<int64_t> f_ea_off;     // [n_fronts+1] -> ea_tgt : this front's packed update matrix -> packed index in its parent
+  std::vector<int> ea_tgt;
 
   // ---- block-sparse H = J'J (lower triangle in elimination order) ----
   int n_blocks = 0;
