@@ -377,6 +377,9 @@ int upload_all(pps_graph* g) {
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &d.result_dev, 4));
+  TRY(dev_alloc(g, &d.dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
+  HIP_TRY(g, hipMemset(d.dn_partials, 0, ((size_t)(d.n_pose + d.n_plane + 255) / 256 + 1) * 8));
+  TRY(dev_alloc(g, &d.ticket, 1)); HIP_TRY(g, hipMemset(d.ticket, 0, 4));
   if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
   // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
   if (!g->use_band && A.max_front > lds_front_limit()) {
@@ -469,6 +472,13 @@ int do_solve(pps_graph* g, double lambda) {
   return PPS_OK;
 }
 
+// est <-> lin by pointer: a rejected LM trial (estimate_to_linpoint, Optimizer.cpp:454) and the final
+// linpoint_to_estimate (:466) need no data movement because the other copy is dead afterwards
+void swap_state(pps_graph* g) {
+  std::swap(g->dev.pose_est, g->dev.pose_lin);
+  std::swap(g->dev.plane_est, g->dev.plane_lin);
+}
+
 int copy_state(pps_graph* g, bool est_to_lin) {
   const DevGraph& d = g->dev;
   double *ps = est_to_lin ? d.pose_est : d.pose_lin, *pd = est_to_lin ? d.pose_lin : d.pose_est;
@@ -480,6 +490,7 @@ int copy_state(pps_graph* g, bool est_to_lin) {
 
 // chi2 (and |delta|^2, not-PD flag) -> host
 int read_result(pps_graph* g, bool at_estimate, double* chi2, double* dnorm, bool* notpd) {
+  if (g->n_live_factors == 0) { *chi2 = 0.0; if (dnorm) *dnorm = 0.0; if (notpd) *notpd = false; return PPS_OK; }
   {
     PhaseTimer t(g, &g->stats.t_retract_chi2);
     HIP_TRY(g, launch_chi2(g->dev, at_estimate, g->host_result, g->stream));
@@ -745,15 +756,15 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
     } else {
       g->stats.lm_trials_rejected++;
       lambda *= prop.lm_lambda_factor;
-      rc = copy_state(g, true); if (rc != PPS_OK) return rc;      // estimate_to_linpoint: restore (:454)
+      swap_state(g);                                              // estimate_to_linpoint: restore (:454)
     }
     rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
     dnorm = std::sqrt(slot1[1]);
     any_notpd = any_notpd || slot1[2] != 0.0;
   }
-  if (trial_pending) { rc = copy_state(g, true); if (rc != PPS_OK) return rc; }   // undo the speculative step
-  rc = copy_state(g, false); if (rc != PPS_OK) return rc;         // linpoint_to_estimate (:466)
+  if (trial_pending) swap_state(g);                               // undo the speculative step
+  swap_state(g);                                                  // linpoint_to_estimate (:466)
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->dev_values_newer = true;
   resolve_k1_events(g);

@@ -60,6 +60,8 @@ struct DevGraph {
   // ---- reductions / status ----
   double* chi2_partials = nullptr;   // one per block of the residual sweep
   int chi2_blocks = 0;
+  double* dn_partials = nullptr;     // |delta|^2 per block of the retraction kernel
+  unsigned int* ticket = nullptr;    // last-block election of the chi2 reduction
   double* result_dev = nullptr;      // [0] chi2, [1] |delta|^2, [2] not-PD flag (as double), [3] reserved
   long long* trace = nullptr;        // PPS_TRACE=1: 8 timestamps (s_memtime) per front of the last factorisation
   double* gwork = nullptr;           // global-memory front workspace for fronts that exceed LDS
@@ -82,7 +84,8 @@ size_t band_lds_bytes(int max_front);           // LDS bytes one wave needs for 
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st);
 // est <- lin (+) delta                        (GN step: Optimizer.cpp:183)
 hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st);
-// chi2 at lin (at_estimate=false) or est; result_dev[0] = chi2, [1] = |delta|^2; then copied to host_result
+// chi2 at lin (at_estimate=false) or est.  The last block writes {chi2, |delta|^2 (from the preceding
+// retraction), not-PD flag} straight into `host_result` (pinned host memory)
 hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, hipStream_t st);
 hipError_t launch_clear_status(const DevGraph& d, hipStream_t st);
 

@@ -13,6 +13,9 @@
 
 namespace pps {
 
+// PPS_TRACE=1 instrumentation: lane 0 stamps s_memtime at phase boundaries of a front
+#define PPS_TR(k) do { if (d.trace && lane == 0) d.trace[(size_t)s * 8 + (k)] = clock64(); } while (0)
+
 // Values that are wave-uniform by construction (they derive from threadIdx.x >> 6) but that the
 // compiler must treat as divergent: pin them into SGPRs so loops, branches and address arithmetic
 // built on them are scalar instead of exec-masked "waterfall" code.
@@ -276,9 +279,17 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
     load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
     load_soa<4>(d.obs_meas, d.n_obs, i, ms);
     load_soa<6>(d.obs_w, d.n_obs, i, w);
-    if (q < 6) { double pp[7]; perturb6(pz, q, sgn, pp); res_plane_obs(pp, pl, ms, e); }
-    else if (q < 9) { double pp[4]; perturb3(pl, q - 6, sgn, pp); res_plane_obs(pz, pp, ms, e); }
-    else res_plane_obs(pz, pl, ms, e);
+    {
+      // every lane takes the same path: a perturbation that does not apply is the zero step, which is the
+      // exact identity for a pose; the plane keeps its stored value unless it is the perturbed node
+      double pp[7], lp[4];
+      perturb6(pz, q, sgn, pp);                       // q >= 6: zero delta -> pp == pz bit for bit
+      perturb3(pl, q - 6, sgn, lp);
+      const bool pert_plane = q >= 6 && q < 9;
+#pragma unroll
+      for (int k = 0; k < 4; k++) lp[k] = pert_plane ? lp[k] : pl[k];
+      res_plane_obs(pp, lp, ms, e);
+    }
     whiten<3>(w, e, y);
     double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
 #pragma unroll
@@ -302,9 +313,12 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
     load_pose(pose, d.pose_ld, d.odo_b[i], p2);
     load_soa<6>(d.odo_meas, d.n_odo, i, ms);
     load_soa<21>(d.odo_w, d.n_odo, i, w);
-    if (q < 6) { double pp[7]; perturb6(p1, q, sgn, pp); res_odometry(pp, p2, ms, e); }
-    else if (q < 12) { double pp[7]; perturb6(p2, q - 6, sgn, pp); res_odometry(p1, pp, ms, e); }
-    else res_odometry(p1, p2, ms, e);
+    {
+      double pa[7], pb[7];
+      perturb6(p1, q, sgn, pa);                       // out-of-range q: zero step == identity
+      perturb6(p2, q - 6, sgn, pb);
+      res_odometry(pa, pb, ms, e);
+    }
     whiten<6>(w, e, y);
     double* __restrict__ out = d.J + d.joff_odo + (size_t)i * 78;
 #pragma unroll
@@ -327,8 +341,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
     load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
     load_soa<6>(d.pp_meas, d.n_pp, i, ms);
     load_soa<21>(d.pp_w, d.n_pp, i, w);
-    if (q < 6) { double pp[7]; perturb6(pz, q, sgn, pp); res_pose_prior(pp, ms, e); }
-    else res_pose_prior(pz, ms, e);
+    { double pp[7]; perturb6(pz, q, sgn, pp); res_pose_prior(pp, ms, e); }
     whiten<6>(w, e, y);
     double* __restrict__ out = d.J + d.joff_pp + (size_t)i * 42;
 #pragma unroll
@@ -350,8 +363,13 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
     load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
     load_soa<4>(d.lp_meas, d.n_lp, i, ms);
     load_soa<6>(d.lp_w, d.n_lp, i, w);
-    if (q < 3) { double pp[4]; perturb3(pl, q, sgn, pp); res_plane_prior(pp, ms, e); }
-    else res_plane_prior(pl, ms, e);
+    {
+      double lp[4];
+      perturb3(pl, q, sgn, lp);
+#pragma unroll
+      for (int k = 0; k < 4; k++) lp[k] = q < 3 ? lp[k] : pl[k];
+      res_plane_prior(lp, ms, e);
+    }
     whiten<3>(w, e, y);
     double* __restrict__ out = d.J + d.joff_lp + (size_t)i * 12;
 #pragma unroll
@@ -499,7 +517,13 @@ __global__ __launch_bounds__(64) void k_hreduce(DevGraph d) {
   const int lane = threadIdx.x;
   if (lane >= size) return;
   double v = 0.0;
-  for (int q = 0; q < nseg; q++) v += h[(size_t)q * size + lane];
+  for (int q = 0; q < nseg; q += 16) {
+    double x[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) x[u] = (q + u < nseg) ? h[(size_t)(q + u) * size + lane] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) v += x[u];
+  }
   h[lane] = v;
   const int dst = d.blk_dst[d.blk_doff[blk] + lane];
   if (dst >= 0) d.Hf[dst] = v;
@@ -643,7 +667,7 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
 constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
 
 int band_front_limit() { return kBandMaxRows - 1; }
-size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return fa * (fa + 1) / 2 * sizeof(double); }
+size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return (fa * (fa + 1) / 2 + 64 * 5) * sizeof(double); }   // packed triangle + panel buffer
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 
@@ -713,7 +737,6 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
   const int p = uni(d.f_p[s]), b = uni(d.f_b[s]);
   const int f = p + b, fa = f + 1;
   const int ntri = tri(fa);
-#define PPS_TR(k) do { if (d.trace && lane == 0) d.trace[(size_t)s * 8 + (k)] = clock64(); } while (0)
   PPS_TR(0);
   for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
   __builtin_amdgcn_wave_barrier();
@@ -849,6 +872,167 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
   PPS_TR(5);
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident variant for fronts of <= 64 rows (all of C2, most of C3).  After assembly in LDS
+// the whole front lives in the lanes' registers as the ten 16x16 tiles of the lower triangle, each in
+// the MFMA accumulator layout (lane l, reg r <-> row (l/16)+4r, col l%16), so a rank-4 update of a
+// tile is a single register-to-register v_mfma_f64_16x16x4_f64.  Per 4-column block only the panel
+// moves through LDS: tile columns K..K+3 -> P[row][4] -> one lane per row solves its row against the
+// 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
+// P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
+// ------------------------------------------------------------------------------------------
+constexpr int kPStride = 5;                       // doubles per panel row: conflict-free operand gathers
+constexpr int kRegRows = 64;
+
+__device__ __forceinline__ constexpr int tile_id(int ti, int tj) { return ti * (ti + 1) / 2 + tj; }
+
+template <int TJ>
+__device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[10], double* __restrict__ P, int c0, int lane) {
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int m = l16 - c0;
+  if (m >= 0 && m < 4) {
+#pragma unroll
+    for (int ti = TJ; ti < 4; ti++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) P[(16 * ti + lq + 4 * r) * kPStride + m] = c[tile_id(ti, TJ)][r];
+  }
+}
+
+template <int TJ>
+__device__ __forceinline__ void reg_trailing(double4_t (&c)[10], const double* __restrict__ P, int nb, int lane) {
+  const int l16 = lane & 15, lq = lane >> 4;
+  const bool kvalid = lq < nb;
+  double opnd[4];
+#pragma unroll
+  for (int t = TJ; t < 4; t++) { const double x = P[(16 * t + l16) * kPStride + lq]; opnd[t] = kvalid ? x : 0.0; }
+#pragma unroll
+  for (int ti = TJ; ti < 4; ti++)
+#pragma unroll
+    for (int tj = TJ; tj <= ti; tj++)
+      c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int s, int p, int b, double lambda, double* __restrict__ F,
+                                                      double* __restrict__ P) {
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int f = p + b, fa = f + 1;
+  const int ntri = tri(fa);
+  PPS_TR(0);
+  for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  PPS_TR(1);
+  {
+    const int e0 = uni(d.f_el_off[s]), e1 = uni(d.f_el_off[s + 1]);
+    const double damp = 1.0 + lambda;
+    const int* __restrict__ tgp = d.el_tgt;
+    const double* __restrict__ hf = d.Hf;
+    for (int e = e0 + lane; e < e1; e += 64 * 8) {
+      int tg[8]; double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < e1 ? tgp[x] : -1; v[u] = x < e1 ? hf[x] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];   // Cholesky.cpp:94-97
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  PPS_TR(2);
+  const int ci0 = uni(d.f_child_off[s]), ci1 = uni(d.f_child_off[s + 1]);
+  for (int ci = ci0; ci < ci1; ci++) {
+    const int c = uni(d.child[ci]);
+    const int n = tri(uni(d.f_b[c]) + 1);
+    const double* __restrict__ Uc = d.U + uni64(d.f_Uoff[c]);
+    const int* __restrict__ tgc = d.ea_tgt + uni64(d.f_ea_off[c]);
+    for (int e = lane; e < n; e += 64 * 8) {
+      int tg[8]; double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < n ? tgc[x] : -1; v[u] = x < n ? Uc[x] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tg[u] >= 0) F[tg[u]] += v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  PPS_TR(3);
+  // ---- packed triangle -> register tiles ----
+  double4_t c[10];
+#pragma unroll
+  for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+    for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
+        const bool ok = row < fa && col <= row;
+        const double x = F[ok ? tri(row) + col : 0];
+        c[tile_id(ti, tj)][r] = ok ? x : 0.0;
+      }
+  double* __restrict__ Lp = d.L + uni64(d.f_Loff[s]);
+  long long cyc_panel = 0, cyc_trail = 0;
+  for (int K = 0; K < p; K += 4) {
+    const long long tk0 = d.trace ? clock64() : 0;
+    const int nb = p - K < 4 ? p - K : 4;
+    const int tjK = K >> 4, c0 = K & 15;
+    switch (tjK) {
+      case 0: reg_extract_panel<0>(c, P, c0, lane); break;
+      case 1: reg_extract_panel<1>(c, P, c0, lane); break;
+      case 2: reg_extract_panel<2>(c, P, c0, lane); break;
+      default: reg_extract_panel<3>(c, P, c0, lane); break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- panel: lane = row ----
+    double r0 = P[lane * kPStride + 0], r1 = P[lane * kPStride + 1], r2 = P[lane * kPStride + 2], r3 = P[lane * kPStride + 3];
+    const double d00 = readlane_d(r0, K);
+    const double d10 = readlane_d(r0, K + 1), d11 = readlane_d(r1, K + 1);
+    const double d20 = readlane_d(r0, K + 2), d21 = readlane_d(r1, K + 2), d22 = readlane_d(r2, K + 2);
+    const double d30 = readlane_d(r0, K + 3), d31 = readlane_d(r1, K + 3), d32 = readlane_d(r2, K + 3), d33 = readlane_d(r3, K + 3);
+    bool bad = false;
+    double i0 = 0, i1 = 0, i2 = 0, i3 = 0, l10 = 0, l20 = 0, l30 = 0, l21 = 0, l31 = 0, l32 = 0;
+    { bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? rsqrt_nr(d00) : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
+    if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
+    if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
+    if (nb > 3) { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; bad |= !(t > 0.0); i3 = t > 0.0 ? rsqrt_nr(t) : 0.0; }
+    if (bad && lane == 0) d.result_dev[2] = 1.0;           // not positive definite
+    const double x0 = r0 * i0;
+    const double x1 = (r1 - x0 * l10) * i1;
+    const double x2 = (r2 - x0 * l20 - x1 * l21) * i2;
+    const double x3 = (r3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+    P[lane * kPStride + 0] = x0; P[lane * kPStride + 1] = x1; P[lane * kPStride + 2] = x2; P[lane * kPStride + 3] = x3;
+    if (lane < fa) {
+      double* __restrict__ lrow = Lp + (size_t)lane * p + K;
+      if (lane >= K) lrow[0] = x0;
+      if (nb > 1 && lane >= K + 1) lrow[1] = x1;
+      if (nb > 2 && lane >= K + 2) lrow[2] = x2;
+      if (nb > 3 && lane >= K + 3) lrow[3] = x3;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long long tk1 = d.trace ? clock64() : 0;
+    switch (tjK) {
+      case 0: reg_trailing<0>(c, P, nb, lane); break;
+      case 1: reg_trailing<1>(c, P, nb, lane); break;
+      case 2: reg_trailing<2>(c, P, nb, lane); break;
+      default: reg_trailing<3>(c, P, nb, lane); break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
+  }
+  PPS_TR(4);
+  if (d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
+  // ---- update matrix: live part of the tiles -> packed global ----
+  double* __restrict__ Us = d.U + uni64(d.f_Uoff[s]);
+#pragma unroll
+  for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+    for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
+        if (row < fa && col <= row && col >= p) Us[tri(row - p) + col - p] = c[tile_id(ti, tj)][r];
+      }
+  PPS_TR(5);
+}
+
 __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   const int g = grp_begin + blockIdx.x;
@@ -857,7 +1041,12 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
   for (int l = l0; l < l1; l++) {
     const int i1 = d.glvl_front_off[l + 1];
-    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) wave_front_factor(d, d.glvl_fronts[i], lambda, F);
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+      const int s = uni(d.glvl_fronts[i]);
+      const int p = uni(d.f_p[s]), b = uni(d.f_b[s]);
+      if (p + b + 1 <= kRegRows) wave_front_factor_reg(d, s, p, b, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      else wave_front_factor(d, s, lambda, F);
+    }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
   }
 }
@@ -970,13 +1159,15 @@ hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_
 // ------------------------------------------------------------------------------------------
 template <bool TRIAL>
 __global__ __launch_bounds__(256) void k_retract(DevGraph d) {
+  __shared__ double red[4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double dn = 0.0;
   if (i < d.n_pose) {
     double p[7], o[7], dl[6];
     load_pose(d.pose_lin, d.pose_ld, i, p);
     const int off = d.pose_voff[i];
 #pragma unroll
-    for (int k = 0; k < 6; k++) dl[k] = d.delta[off + k];
+    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
     pose_exmap(p, dl, o);
     if (TRIAL) {
 #pragma unroll
@@ -991,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_retract(DevGraph d) {
     load_plane(d.plane_lin, d.plane_ld, l, p);
     const int off = d.plane_voff[l];
 #pragma unroll
-    for (int k = 0; k < 3; k++) dl[k] = d.delta[off + k];
+    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
     plane_exmap(p, dl, o);
     if (TRIAL) {
 #pragma unroll
@@ -1001,6 +1192,12 @@ __global__ __launch_bounds__(256) void k_retract(DevGraph d) {
       for (int k = 0; k < 4; k++) d.plane_est[(size_t)k * d.plane_ld + l] = o[k];
     }
   }
+  // |delta|^2 partial of this block (summed by the last block of the following k_chi2)
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
+  __syncthreads();
+  if (threadIdx.x == 0) d.dn_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st) {
@@ -1019,7 +1216,8 @@ hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st) {
 constexpr int kChiBlock = 256;
 
 __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __restrict__ pose,
-                                                    const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp) {
+                                                    const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
+                                                    int n_dn, double* __restrict__ out) {
   __shared__ double red[kChiBlock / 64];
   int b = blockIdx.x;
   double s = 0.0;
@@ -1078,25 +1276,35 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
+  __shared__ bool last;
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int k = 0; k < kChiBlock / 64; k++) t += red[k];
     d.chi2_partials[blockIdx.x] = t;
+    // publish, then take a ticket: the block that draws the last one reduces everything
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicAdd(d.ticket, 1u) == gridDim.x - 1;
   }
-}
-
-__global__ __launch_bounds__(256) void k_finalize(DevGraph d, int nblocks) {
-  __shared__ double red[2][4];
-  double s = 0.0, dn = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) s += d.chi2_partials[i];
-  for (int i = threadIdx.x; i < d.n_scalars; i += 256) { const double x = d.delta[i]; dn += x * x; }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  double cs = 0.0, dn = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += kChiBlock) cs += __hip_atomic_load(&d.chi2_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < n_dn; i += kChiBlock) dn += __hip_atomic_load(&d.dn_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); dn += __shfl_down(dn, o, 64); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = dn; }
+  for (int o = 32; o > 0; o >>= 1) { cs += __shfl_down(cs, o, 64); dn += __shfl_down(dn, o, 64); }
+  __shared__ double red2[2][kChiBlock / 64];
+  if ((threadIdx.x & 63) == 0) { red2[0][threadIdx.x >> 6] = cs; red2[1][threadIdx.x >> 6] = dn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    d.result_dev[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    d.result_dev[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    double a = 0.0, b2 = 0.0;
+    for (int k = 0; k < kChiBlock / 64; k++) { a += red2[0][k]; b2 += red2[1][k]; }
+    const double npd = __hip_atomic_load(&d.result_dev[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d.result_dev[0] = a; d.result_dev[1] = b2;
+    out[0] = a; out[1] = b2; out[2] = npd; out[3] = 0.0;   // `out` is pinned host memory: one PCIe write, no copy kernel
+    *d.ticket = 0u;
   }
 }
 
@@ -1106,11 +1314,10 @@ hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result,
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   const double* pose = at_estimate ? d.pose_est : d.pose_lin;
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
-  if (nb > 0) hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, d, nb);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  return hipMemcpyAsync(host_result, d.result_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (nb == 0) return hipErrorInvalidValue;
+  const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
+  hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result);
+  return hipGetLastError();
 }
 
 hipError_t launch_clear_status(const DevGraph& d, hipStream_t st) {

@@ -31,7 +31,7 @@ struct AnalysisParams {
   int leaf_poses = 4;      // a sub-chain with <= leaf_poses poses becomes one leaf front
   int max_pivots = 48;     // split supernodes with more pivot scalars into a chain
   int seg_len = 32;        // contributions reduced per wave in the H-block kernel
-  int band_levels = 4;     // tree levels walked by one workgroup inside one launch ("band")
+  int band_levels = 3;     // tree levels walked by one workgroup inside one launch ("band")
   int dense_min = 64;      // a node is "dense" if degree > max(dense_min, dense_mult*sqrt(N))
   double dense_mult = 8.0;
 };
