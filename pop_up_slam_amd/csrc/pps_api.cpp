@@ -72,6 +72,12 @@ struct pps_graph {
   DevGraph dev;
   std::vector<void*> allocs;
   double* host_result = nullptr;   // pinned, 8 doubles
+  double seq = 0.0;                // sequence number the chi2 kernel publishes last (host polls it)
+  // speculative solve of the LM reject branch (lambda * factor) on a second stream, into a second set of L/U/delta
+  hipStream_t stream_b = nullptr;
+  hipEvent_t ev_h_ready = nullptr, ev_spec_done = nullptr;
+  double *spec_L = nullptr, *spec_U = nullptr, *spec_delta = nullptr;
+  bool spec_enabled = true;
   double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
   int snap_version = -1, upload_version = 0;
   int profiling = 0;               // 0 off, 1 = K1 event pairs without host syncs, 2 = every phase (adds syncs)
@@ -142,6 +148,10 @@ int ensure_device(pps_graph* g) {
   HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->host_result), 8 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(g, hipEventCreate(&g->ev[0]));
   HIP_TRY(g, hipEventCreate(&g->ev[1]));
+  HIP_TRY(g, hipStreamCreateWithFlags(&g->stream_b, hipStreamNonBlocking));
+  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_h_ready, hipEventDisableTiming));
+  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_spec_done, hipEventDisableTiming));
+  g->spec_enabled = !getenv("PPS_NO_SPEC");
   g->dev_ready = true;
   return PPS_OK;
 }
@@ -299,7 +309,9 @@ int upload_all(pps_graph* g) {
   if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
   if (g->dev_meas_newer) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
+  if (g->stream_b) HIP_TRY(g, hipStreamSynchronize(g->stream_b));
   free_device(g);
+  g->spec_L = g->spec_U = g->spec_delta = nullptr;
   g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
   g->frames_dirty = true;
   g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
@@ -345,6 +357,9 @@ int upload_all(pps_graph* g) {
   TRY(dev_alloc(g, &d.J, (size_t)A.J_size)); TRY(dev_alloc(g, &d.H, (size_t)A.H_size));
   TRY(dev_alloc(g, &d.L, (size_t)A.L_size)); TRY(dev_alloc(g, &d.U, (size_t)A.U_size));
   TRY(dev_alloc(g, &d.delta, (size_t)A.n_scalars));
+  TRY(dev_alloc(g, &g->spec_L, (size_t)A.L_size)); TRY(dev_alloc(g, &g->spec_U, (size_t)A.U_size));
+  TRY(dev_alloc(g, &g->spec_delta, (size_t)A.n_scalars));
+  HIP_TRY(g, hipMemsetAsync(g->spec_delta, 0, (size_t)std::max(1, A.n_scalars) * 8, g->stream));
   HIP_TRY(g, hipMemsetAsync(d.delta, 0, (size_t)std::max(1, A.n_scalars) * 8, g->stream));
   d.n_scalars = A.n_scalars;
   d.n_fronts = A.n_fronts; d.n_levels = A.n_levels; d.max_front = A.max_front; d.n_segs = A.n_segs; d.n_blocks = A.n_blocks;
@@ -439,6 +454,17 @@ int do_linearize(pps_graph* g) {
 }
 
 // delta = (J'J + lambda diag(J'J))^-1 J'b  (Optimizer::compute_gauss_newton_step, Optimizer.cpp:49-67)
+int do_solve_on(pps_graph* g, const DevGraph& dv, double lambda, hipStream_t st_) {
+  const Analysis& A = g->an;
+  for (int st = 0; st < A.n_stages; st++)
+    HIP_TRY(g, launch_band_factor(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
+                                  A.stage_max_front[st], lambda, st_));
+  for (int st = A.n_stages - 1; st >= 0; st--)
+    HIP_TRY(g, launch_band_solve(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
+                                 g->stage_max_piv[st], st_));
+  return PPS_OK;
+}
+
 int do_solve(pps_graph* g, double lambda) {
   const Analysis& A = g->an;
   if (g->use_band) {
@@ -472,6 +498,22 @@ int do_solve(pps_graph* g, double lambda) {
   return PPS_OK;
 }
 
+// Wait for the result record with sequence number `seq`: spin on the pinned word the chi2 kernel writes
+// last (a few microseconds), falling back to a stream sync if it does not show up (launch failure).
+int wait_result(pps_graph* g, volatile double* slot, double seq) {
+  const double t0 = now_s();
+  unsigned spins = 0;
+  while (slot[3] != seq) {
+    if ((++spins & 0x3ff) == 0 && now_s() - t0 > 0.5) {
+      HIP_TRY(g, hipStreamSynchronize(g->stream));
+      if (slot[3] != seq) return fail(g, PPS_EHIP, "result record did not arrive");
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return PPS_OK;
+}
+
 // est <-> lin by pointer: a rejected LM trial (estimate_to_linpoint, Optimizer.cpp:454) and the final
 // linpoint_to_estimate (:466) need no data movement because the other copy is dead afterwards
 void swap_state(pps_graph* g) {
@@ -493,7 +535,7 @@ int read_result(pps_graph* g, bool at_estimate, double* chi2, double* dnorm, boo
   if (g->n_live_factors == 0) { *chi2 = 0.0; if (dnorm) *dnorm = 0.0; if (notpd) *notpd = false; return PPS_OK; }
   {
     PhaseTimer t(g, &g->stats.t_retract_chi2);
-    HIP_TRY(g, launch_chi2(g->dev, at_estimate, g->host_result, g->stream));
+    HIP_TRY(g, launch_chi2(g->dev, at_estimate, g->host_result, 0.0, g->stream));
   }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   *chi2 = g->host_result[0];
@@ -560,6 +602,9 @@ int pps_graph_destroy(pps_graph* g) {
     if (g->ev[0]) (void)hipEventDestroy(g->ev[0]);
     if (g->ev[1]) (void)hipEventDestroy(g->ev[1]);
     for (hipEvent_t e : g->k1_events) (void)hipEventDestroy(e);
+    if (g->stream_b) { (void)hipStreamSynchronize(g->stream_b); (void)hipStreamDestroy(g->stream_b); }
+    if (g->ev_h_ready) (void)hipEventDestroy(g->ev_h_ready);
+    if (g->ev_spec_done) (void)hipEventDestroy(g->ev_spec_done);
     (void)hipStreamDestroy(g->stream);
   }
   delete g;
@@ -723,18 +768,46 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   // speculatively (est <- lin, lin <- lin (+) delta) and its chi2 is reduced, so a single result
   // record carries everything the loop condition and the accept test need; if the loop ends on
   // |delta| <= eps2 the speculative step is undone (lin <- est).
+  auto enqueue_trial_only = [&]() -> int {
+    PhaseTimer t(g, &g->stats.t_retract_chi2);
+    HIP_TRY(g, launch_retract_trial(g->dev, g->stream));                       // linpoint_to_estimate + self_exmap (:414-416)
+    g->seq += 1.0;
+    HIP_TRY(g, launch_chi2(g->dev, false, slot1, g->seq, g->stream));          // weighted_errors(LINPOINT) (:417)
+    return PPS_OK;
+  };
   auto enqueue_trial = [&](double lam) -> int {
     int r = do_solve(g, lam); if (r != PPS_OK) return r;                       // compute_gauss_newton_step (:395,458)
-    { PhaseTimer t(g, &g->stats.t_retract_chi2);
-      HIP_TRY(g, launch_retract_trial(g->dev, g->stream));                     // linpoint_to_estimate + self_exmap (:414-416)
-      HIP_TRY(g, launch_chi2(g->dev, false, slot1, g->stream)); }              // weighted_errors(LINPOINT) (:417)
+    return enqueue_trial_only();
+  };
+  // Reject-branch speculation: a rejected trial only changes lambda (same J, same H), so right after
+  // every relinearisation the step for lambda * factor is factored and solved on a second stream, into a
+  // second L/U/delta set, while the main solve runs.  The first rejection after an accepted step then
+  // costs one retraction + chi2 instead of a factorisation; arithmetic and lambda schedule are exactly
+  // the reference's.  (One level deep only: a second consecutive rejection solves on the main stream.)
+  const bool spec = g->spec_enabled && g->use_band && g->profiling < 2;
+  bool spec_inflight = false;
+  double spec_lambda = 0.0;
+  auto launch_spec = [&](double lam) -> int {
+    if (!spec) return PPS_OK;
+    DevGraph dv = g->dev;
+    dv.L = g->spec_L; dv.U = g->spec_U; dv.delta = g->spec_delta;
+    HIP_TRY(g, hipStreamWaitEvent(g->stream_b, g->ev_h_ready, 0));
+    int r = do_solve_on(g, dv, lam, g->stream_b); if (r != PPS_OK) return r;
+    HIP_TRY(g, hipEventRecord(g->ev_spec_done, g->stream_b));
+    spec_inflight = true; spec_lambda = lam;
+    g->stats.n_factorize++;
     return PPS_OK;
   };
   rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:376)
   rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:379)
-  HIP_TRY(g, launch_chi2(g->dev, false, slot0, g->stream));       // r = weighted_errors(LINPOINT); error = |r|^2 (:382-385)
-  rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;
-  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  if (spec) HIP_TRY(g, hipEventRecord(g->ev_h_ready, g->stream));
+  g->seq += 1.0;
+  const double seq0 = g->seq;
+  HIP_TRY(g, launch_chi2(g->dev, false, slot0, seq0, g->stream)); // r = weighted_errors(LINPOINT); error = |r|^2 (:382-385)
+  rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;        // the critical path goes to the queue first ...
+  rc = launch_spec(lambda * prop.lm_lambda_factor); if (rc != PPS_OK) return rc;   // ... the speculation second
+  rc = wait_result(g, slot0, seq0); if (rc != PPS_OK) return rc;
+  rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc;
   double error = slot0[0];
   g->stats.chi2_initial = error;
   double dnorm = std::sqrt(slot1[1]);
@@ -752,17 +825,35 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
       if (error_diff < prop.epsilon_rel * error) { error = error_new; trial_pending = false; break; }   // (:431-434)
       lambda /= prop.lm_lambda_factor;
       error = error_new;
-      rc = do_linearize(g); if (rc != PPS_OK) return rc;          // relinearise around the accepted point (:444)
+      // relinearise around the accepted point (:444); K2 overwrites H, which an unfinished speculative
+      // solve would still be reading (it started together with the main solve, so this never blocks)
+      if (spec_inflight) HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
+      spec_inflight = false;
+      rc = do_linearize(g); if (rc != PPS_OK) return rc;
+      if (spec) HIP_TRY(g, hipEventRecord(g->ev_h_ready, g->stream));
+      rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;    // (:458)
+      rc = launch_spec(lambda * prop.lm_lambda_factor); if (rc != PPS_OK) return rc;
     } else {
       g->stats.lm_trials_rejected++;
       lambda *= prop.lm_lambda_factor;
       swap_state(g);                                              // estimate_to_linpoint: restore (:454)
+      if (spec_inflight && spec_lambda == lambda) {
+        // the step for this lambda has been computed alongside the previous solve: adopt its buffers
+        HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
+        std::swap(g->dev.L, g->spec_L); std::swap(g->dev.U, g->spec_U); std::swap(g->dev.delta, g->spec_delta);
+        spec_inflight = false;
+        rc = enqueue_trial_only(); if (rc != PPS_OK) return rc;
+      } else {
+        if (spec_inflight) HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
+        spec_inflight = false;
+        rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;  // (:458)
+      }
     }
-    rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;
-    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc;
     dnorm = std::sqrt(slot1[1]);
     any_notpd = any_notpd || slot1[2] != 0.0;
   }
+  if (spec) HIP_TRY(g, hipStreamSynchronize(g->stream_b));       // no speculative work may outlive the call
   if (trial_pending) swap_state(g);                               // undo the speculative step
   swap_state(g);                                                  // linpoint_to_estimate (:466)
   HIP_TRY(g, hipStreamSynchronize(g->stream));

@@ -86,7 +86,7 @@ hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st);
 hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st);
 // chi2 at lin (at_estimate=false) or est.  The last block writes {chi2, |delta|^2 (from the preceding
 // retraction), not-PD flag} straight into `host_result` (pinned host memory)
-hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, hipStream_t st);
+hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, double seq, hipStream_t st);
 hipError_t launch_clear_status(const DevGraph& d, hipStream_t st);
 
 // Largest front (scalars incl. rhs row) the LDS path of the factor kernel accepts.

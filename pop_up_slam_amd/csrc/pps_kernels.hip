@@ -1217,7 +1217,7 @@ constexpr int kChiBlock = 256;
 
 __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __restrict__ pose,
                                                     const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
-                                                    int n_dn, double* __restrict__ out) {
+                                                    int n_dn, double* __restrict__ out, double seq) {
   __shared__ double red[kChiBlock / 64];
   int b = blockIdx.x;
   double s = 0.0;
@@ -1303,12 +1303,14 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
     for (int k = 0; k < kChiBlock / 64; k++) { a += red2[0][k]; b2 += red2[1][k]; }
     const double npd = __hip_atomic_load(&d.result_dev[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     d.result_dev[0] = a; d.result_dev[1] = b2;
-    out[0] = a; out[1] = b2; out[2] = npd; out[3] = 0.0;   // `out` is pinned host memory: one PCIe write, no copy kernel
+    out[0] = a; out[1] = b2; out[2] = npd;                 // `out` is pinned host memory: no copy kernel
+    // the sequence number goes last, with system-scope release: the host polls it instead of paying a stream sync
+    __hip_atomic_store(&out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     *d.ticket = 0u;
   }
 }
 
-hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, hipStream_t st) {
+hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, double seq, hipStream_t st) {
   const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock),
             nb_lp = cdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
@@ -1316,7 +1318,7 @@ hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result,
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
   if (nb == 0) return hipErrorInvalidValue;
   const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
-  hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result);
+  hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
   return hipGetLastError();
 }
 
