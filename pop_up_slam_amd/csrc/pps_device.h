@@ -57,6 +57,7 @@ struct DevGraph {
   double* Hf = nullptr;      // H in front gather order: front s reads Hf[f_el_off[s] .. f_el_off[s+1])
   int64_t* f_ea_off = nullptr; int* ea_tgt = nullptr;
   int *grp_lvl_off = nullptr, *glvl_front_off = nullptr, *glvl_fronts = nullptr;
+  int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
   // ---- reductions / status ----
   double* chi2_partials = nullptr;   // one per block of the residual sweep
   int chi2_blocks = 0;

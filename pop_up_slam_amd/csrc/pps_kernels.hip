@@ -463,9 +463,11 @@ __global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
   const int seg = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (seg >= d.n_segs) return;
-  const int blk = uni(d.seg_blk[seg]);
-  const int rows = uni(d.blk_rows[blk]), cols = uni(d.blk_cols[blk]), size = uni(d.blk_size[blk]);
-  const int c0 = uni(d.seg_c0[seg]), cnt = uni(d.seg_cnt[seg]);
+  // one coalesced load of the packed segment record, fields broadcast with v_readlane
+  const int rec = d.srec[(size_t)seg * 8 + (lane & 7)];
+  const int rows = __builtin_amdgcn_readlane(rec, 0), cols = __builtin_amdgcn_readlane(rec, 1), size = __builtin_amdgcn_readlane(rec, 2);
+  const int c0 = __builtin_amdgcn_readlane(rec, 3), cnt = __builtin_amdgcn_readlane(rec, 4);
+  const int hoff = __builtin_amdgcn_readlane(rec, 5), doff = __builtin_amdgcn_readlane(rec, 6), nsegb = __builtin_amdgcn_readlane(rec, 7);
   // one contribution descriptor per lane, fetched in a single coalesced load (cnt <= 64)
   int4 mine = make_int4(0, 0, 0, 0);
   if (lane < cnt) mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
@@ -502,9 +504,9 @@ __global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
   }
   if (!act) return;
   if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
-  d.H[d.seg_hoff[seg] + lane] = acc;
-  if (uni(d.blk_nseg[blk]) == 1) {                        // final value: also place it where its front will gather it
-    const int dst = d.blk_dst[d.blk_doff[blk] + lane];
+  d.H[hoff + lane] = acc;
+  if (nsegb == 1) {                                       // final value: also place it where its front will gather it
+    const int dst = d.blk_dst[doff + lane];
     if (dst >= 0) d.Hf[dst] = acc;
   }
 }
@@ -912,9 +914,10 @@ __device__ __forceinline__ void reg_trailing(double4_t (&c)[10], const double* _
       c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
 }
 
-__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int s, int p, int b, double lambda, double* __restrict__ F,
+__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
                                                       double* __restrict__ P) {
   const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readlane(rec, 0), p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
   const int l16 = lane & 15, lq = lane >> 4;
   const int f = p + b, fa = f + 1;
   const int ntri = tri(fa);
@@ -923,7 +926,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int s, 
   __builtin_amdgcn_wave_barrier();
   PPS_TR(1);
   {
-    const int e0 = uni(d.f_el_off[s]), e1 = uni(d.f_el_off[s + 1]);
+    const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
     const double damp = 1.0 + lambda;
     const int* __restrict__ tgp = d.el_tgt;
     const double* __restrict__ hf = d.Hf;
@@ -938,12 +941,16 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int s, 
   }
   __builtin_amdgcn_wave_barrier();
   PPS_TR(2);
-  const int ci0 = uni(d.f_child_off[s]), ci1 = uni(d.f_child_off[s + 1]);
-  for (int ci = ci0; ci < ci1; ci++) {
-    const int c = uni(d.child[ci]);
-    const int n = tri(uni(d.f_b[c]) + 1);
-    const double* __restrict__ Uc = d.U + uni64(d.f_Uoff[c]);
-    const int* __restrict__ tgc = d.ea_tgt + uni64(d.f_ea_off[c]);
+  const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
+  for (int cb = 0; cb < nch; cb += 8) {
+   // child records of up to 8 children in one coalesced load
+   const int crv = (lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0;
+   for (int cj = 0; cj < 8 && cb + cj < nch; cj++) {
+    const int n = __builtin_amdgcn_readlane(crv, 8 * cj);
+    const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
+    const long long eo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 4) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 3);
+    const double* __restrict__ Uc = d.U + uo;
+    const int* __restrict__ tgc = d.ea_tgt + eo;
     for (int e = lane; e < n; e += 64 * 8) {
       int tg[8]; double v[8];
 #pragma unroll
@@ -953,6 +960,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int s, 
         if (tg[u] >= 0) F[tg[u]] += v[u];
     }
     __builtin_amdgcn_wave_barrier();
+   }
   }
   PPS_TR(3);
   // ---- packed triangle -> register tiles ----
@@ -968,7 +976,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int s, 
         const double x = F[ok ? tri(row) + col : 0];
         c[tile_id(ti, tj)][r] = ok ? x : 0.0;
       }
-  double* __restrict__ Lp = d.L + uni64(d.f_Loff[s]);
+  double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   long long cyc_panel = 0, cyc_trail = 0;
   for (int K = 0; K < p; K += 4) {
     const long long tk0 = d.trace ? clock64() : 0;
@@ -1020,7 +1028,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int s, 
   PPS_TR(4);
   if (d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
   // ---- update matrix: live part of the tiles -> packed global ----
-  double* __restrict__ Us = d.U + uni64(d.f_Uoff[s]);
+  double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
 #pragma unroll
   for (int ti = 0; ti < 4; ti++)
 #pragma unroll
@@ -1042,9 +1050,10 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
   for (int l = l0; l < l1; l++) {
     const int i1 = d.glvl_front_off[l + 1];
     for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
-      const int s = uni(d.glvl_fronts[i]);
-      const int p = uni(d.f_p[s]), b = uni(d.f_b[s]);
-      if (p + b + 1 <= kRegRows) wave_front_factor_reg(d, s, p, b, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
+      const int s = __builtin_amdgcn_readlane(rec, 0);
+      const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
+      if (fa <= kRegRows) wave_front_factor_reg(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
       else wave_front_factor(d, s, lambda, F);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
@@ -1054,19 +1063,21 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
 // x_p = L_A^-T (y - L_B^T x_b) for one front, one wave (p <= 64).  All global loads are issued in
 // batches that do not depend on each other; the back-substitution chain itself runs in registers
 // (lane j holds t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + packed L_A.
-__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int s_in, double* __restrict__ W) {
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W) {
   const int lane = threadIdx.x & 63;
-  const int s = uni(s_in);
-  const int p = uni(d.f_p[s]), b = uni(d.f_b[s]), f = p + b;
-  const double* __restrict__ Lp = d.L + uni64(d.f_Loff[s]);
-  const int* __restrict__ bi = d.bidx + uni(d.f_bidx_off[s]);
+  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
+  const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
+  const int* __restrict__ bi = d.bidx + __builtin_amdgcn_readlane(rec, 8);
   double* xb = W;
   double* LA = W + kBandMaxRows;
   for (int i = lane; i < b; i += 64) xb[i] = d.delta[bi[i]];
   // stage L_A (packed lower triangle): p independent coalesced row loads
-#pragma unroll 8
-  for (int i = 0; i < p; i++) {
-    if (lane <= i) LA[tri(i) + lane] = Lp[(size_t)i * p + lane];
+  for (int i0 = 0; i0 < p; i0 += 8) {                     // unconditional (clamped) loads: 8 rows in flight
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = i0 + u < p ? i0 + u : p - 1; x[u] = Lp[(size_t)i * p + (lane <= i ? lane : 0)]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = i0 + u; if (i < p && lane <= i) LA[tri(i) + lane] = x[u]; }
   }
   __builtin_amdgcn_wave_barrier();
   double tj = 0.0, dinv = 0.0;
@@ -1083,7 +1094,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int s_in, do
     const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
     tj = (lane == k) ? xk : tj - lkj * xk;
   }
-  if (lane < p) d.delta[uni(d.f_poff[s]) + lane] = tj;
+  if (lane < p) d.delta[__builtin_amdgcn_readlane(rec, 7) + lane] = tj;
 }
 
 __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, int lds_doubles_per_wave) {
@@ -1094,7 +1105,10 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, i
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
   for (int l = l1 - 1; l >= l0; l--) {
     const int i1 = d.glvl_front_off[l + 1];
-    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) wave_front_solve(d, d.glvl_fronts[i], W);
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+      wave_front_solve(d, rec, W);
+    }
     __syncthreads();   // delta of this local level is visible to the children
   }
 }

@@ -504,6 +504,37 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
       for (int v : bnd[s]) loc[v] = -1;
     }
+      // ---- packed records ----
+    {
+      A.frec.assign((size_t)F * 16, 0);
+      A.crec.clear();
+      std::vector<int> pos_of(F, -1);
+      for (int i = 0; i < F; i++) pos_of[A.glvl_fronts[i]] = i;
+      for (int i = 0; i < F; i++) {
+        const int s2 = A.glvl_fronts[i];
+        int* r = &A.frec[(size_t)i * 16];
+        r[0] = s2; r[1] = A.f_p[s2]; r[2] = A.f_b[s2]; r[3] = A.f_el_off[s2]; r[4] = A.f_el_off[s2 + 1];
+        r[5] = (int)(A.crec.size() / 8); r[6] = A.f_child_off[s2 + 1] - A.f_child_off[s2];
+        r[7] = A.f_poff[s2]; r[8] = A.f_bidx_off[s2];
+        r[9] = (int)(A.f_Loff[s2] & 0xffffffffLL); r[10] = (int)(A.f_Loff[s2] >> 32);
+        r[11] = (int)(A.f_Uoff[s2] & 0xffffffffLL); r[12] = (int)(A.f_Uoff[s2] >> 32);
+        r[13] = (A.f_b[s2] + 1) * (A.f_b[s2] + 2) / 2;
+        for (int ci = A.f_child_off[s2]; ci < A.f_child_off[s2 + 1]; ci++) {
+          const int c = A.child[ci];
+          const int bc1 = A.f_b[c] + 1;
+          int cr[8] = {bc1 * (bc1 + 1) / 2, (int)(A.f_Uoff[c] & 0xffffffffLL), (int)(A.f_Uoff[c] >> 32),
+                       (int)(A.f_ea_off[c] & 0xffffffffLL), (int)(A.f_ea_off[c] >> 32), c, 0, 0};
+          A.crec.insert(A.crec.end(), cr, cr + 8);
+        }
+      }
+      A.srec.assign((size_t)A.n_segs * 8, 0);
+      for (int sg = 0; sg < A.n_segs; sg++) {
+        const int bk = A.seg_blk[sg];
+        int* r = &A.srec[(size_t)sg * 8];
+        r[0] = A.blk_rows[bk]; r[1] = A.blk_cols[bk]; r[2] = A.blk_size[bk]; r[3] = A.seg_c0[sg]; r[4] = A.seg_cnt[sg];
+        r[5] = (int)A.seg_hoff[sg]; r[6] = A.blk_doff[bk]; r[7] = A.blk_nseg[bk];
+      }
+    }
   }
   return true;
 }

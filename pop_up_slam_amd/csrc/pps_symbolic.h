@@ -81,6 +81,14 @@ struct Analysis {
   std::vector<int64_t> f_ea_off;     // [n_fronts+1] -> ea_tgt : this front's packed update matrix -> packed index in its parent
   std::vector<int> ea_tgt;
 
+  // ---- packed metadata records: one coalesced load per wave instead of a chain of dependent loads ----
+  // frec: 16 ints per front, in band-schedule order (index = position in glvl_fronts):
+  //   0 front id, 1 p, 2 b, 3 el_off0, 4 el_off1, 5 first child record, 6 child count, 7 poff, 8 bidx_off,
+  //   9/10 Loff lo/hi, 11/12 Uoff lo/hi, 13 number of packed entries of the own update matrix
+  // crec: 8 ints per child edge: 0 packed entries of the child's update matrix, 1/2 its Uoff lo/hi, 3/4 its ea_off lo/hi
+  // srec: 8 ints per H segment: 0 rows, 1 cols, 2 size, 3 c0, 4 cnt, 5 hoff (segment slot), 6 blk_doff, 7 nseg of the block
+  std::vector<int> frec, crec, srec;
+
   // ---- block-sparse H = J'J (lower triangle in elimination order) ----
   int n_blocks = 0;
   std::vector<int> blk_rows, blk_cols;   // dims (rows = later node, cols = earlier node); diagonal blocks carry g appended
