@@ -144,11 +144,28 @@ int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
 int ensure_device(pps_graph* g) {
   if (g->dev_ready) return PPS_OK;
   HIP_TRY(g, hipSetDevice(g->props.device));
-  HIP_TRY(g, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  {
+    // The main and the speculative solve each keep a few dozen workgroups busy; give the two streams
+    // disjoint halves of the CUs so that they do not share SIMDs / LDS (opt-in: PPS_CU_MASK=1).
+    hipDeviceProp_t prop;
+    HIP_TRY(g, hipGetDeviceProperties(&prop, g->props.device));
+    const int ncu = prop.multiProcessorCount;
+    const char* e = getenv("PPS_CU_MASK");
+    const bool masked = (e && atoi(e) != 0) && ncu >= 64 && ncu % 64 == 0;   // measured: no gain on MI355X (143.7 vs 138.9 us/iter), off by default
+    if (masked) {
+      const int words = ncu / 32;
+      std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
+      for (int w = 0; w < words; w++) (w < words / 2 ? ma : mb)[w] = 0xffffffffu;
+      HIP_TRY(g, hipExtStreamCreateWithCUMask(&g->stream, (uint32_t)words, ma.data()));
+      HIP_TRY(g, hipExtStreamCreateWithCUMask(&g->stream_b, (uint32_t)words, mb.data()));
+    } else {
+      HIP_TRY(g, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+      HIP_TRY(g, hipStreamCreateWithFlags(&g->stream_b, hipStreamNonBlocking));
+    }
+  }
   HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->host_result), 8 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(g, hipEventCreate(&g->ev[0]));
   HIP_TRY(g, hipEventCreate(&g->ev[1]));
-  HIP_TRY(g, hipStreamCreateWithFlags(&g->stream_b, hipStreamNonBlocking));
   HIP_TRY(g, hipEventCreateWithFlags(&g->ev_h_ready, hipEventDisableTiming));
   HIP_TRY(g, hipEventCreateWithFlags(&g->ev_spec_done, hipEventDisableTiming));
   g->spec_enabled = !getenv("PPS_NO_SPEC");

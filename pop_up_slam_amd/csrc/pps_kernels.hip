@@ -922,29 +922,36 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   const int f = p + b, fa = f + 1;
   const int ntri = tri(fa);
   PPS_TR(0);
+  const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
+  const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
+  const double damp = 1.0 + lambda;
+  const int* __restrict__ tgp = d.el_tgt;
+  const double* __restrict__ hf = d.Hf;
+  // first gather batch and the child records are requested before the LDS triangle is cleared, so the
+  // clearing hides under their latency
+  int tg0[8]; double v0[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) { const int x = e0 + lane + 64 * u; tg0[u] = x < e1 ? tgp[x] : -1; v0[u] = x < e1 ? hf[x] : 0.0; }
+  const int crv0 = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;
   for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
   __builtin_amdgcn_wave_barrier();
   PPS_TR(1);
-  {
-    const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
-    const double damp = 1.0 + lambda;
-    const int* __restrict__ tgp = d.el_tgt;
-    const double* __restrict__ hf = d.Hf;
-    for (int e = e0 + lane; e < e1; e += 64 * 8) {
-      int tg[8]; double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < e1 ? tgp[x] : -1; v[u] = x < e1 ? hf[x] : 0.0; }
+  for (int u = 0; u < 8; u++)
+    if (tg0[u] >= 0) F[tg0[u] & 0x3fffffff] += (tg0[u] & (1 << 30)) ? v0[u] * damp : v0[u];   // Cholesky.cpp:94-97
+  for (int e = e0 + lane + 64 * 8; e < e1; e += 64 * 8) {
+    int tg[8]; double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];   // Cholesky.cpp:94-97
-    }
+    for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < e1 ? tgp[x] : -1; v[u] = x < e1 ? hf[x] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];
   }
   __builtin_amdgcn_wave_barrier();
   PPS_TR(2);
-  const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
   for (int cb = 0; cb < nch; cb += 8) {
-   // child records of up to 8 children in one coalesced load
-   const int crv = (lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0;
+   // child records of up to 8 children in one coalesced load (the first batch was requested above)
+   const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);
    for (int cj = 0; cj < 8 && cb + cj < nch; cj++) {
     const int n = __builtin_amdgcn_readlane(crv, 8 * cj);
     const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
