@@ -359,7 +359,7 @@ def corridor(n_poses=1000, n_planes=200, obs_per_pose=5, seed=42, physical_weigh
 
 
 def manhattan_rooms(n_poses=10000, n_planes=2000, obs_per_pose=6, seed=43, rooms_x=20, rooms_y=10,
-                    room=5.0, physical_weights=False, name=None):
+                    room=5.0, physical_weights=False, name=None, odo_scale=0.03):
     """C3: lawn-mower path through a rooms_x x rooms_y grid of square rooms.  Planes =
     ground + axis-aligned vertical faces (four wall faces per room plus interior
     box faces until n_planes is reached).  Each pose observes the ground and the
@@ -472,7 +472,11 @@ def manhattan_rooms(n_poses=10000, n_planes=2000, obs_per_pose=6, seed=43, rooms
             if done:
                 break
         assert n_seen[j] > 0, j
-    b = _Builder(name or f"rooms_{n_poses}p_{n_planes}l", rng, physical_weights)
+    # odo_scale: the reference never batch-solves from 10 000 frames of raw dead reckoning (it optimises
+    # every frame, Mapping.cpp:551-554); 3 % of the C2 odometry noise keeps the dead-reckoned start
+    # inside LM's basin while the graph keeps its size and loop structure
+    b = _Builder(name or f"rooms_{n_poses}p_{n_planes}l", rng, physical_weights,
+                 odo_sigma=odo_scale * np.array([0.01, 0.01, 0.01, np.deg2rad(0.2), np.deg2rad(0.2), np.deg2rad(0.2)]))
     for k in range(n_poses):
         obs = [("g", GROUND, 1.0, True)]
         for j, dist in obs_sets[k]:

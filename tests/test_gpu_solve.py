@@ -82,3 +82,33 @@ def test_c2_corridor_final_chi2(built):
     st = g.stats()
     print("C2: gpu chi2 %.12g (%d it, %.3f s) oracle %.12g (%d it)" % (c, it, st["t_total"], co, ito))
     assert abs(c - co) <= 1e-5 * abs(co), (c, co)
+
+
+def test_c3_manhattan_rooms_final_chi2(built):
+    """BASELINE config 3: 10 000 poses / 2 000 planes / 60 000 plane edges (fronts up to 76 rows: exercises
+    the LDS-tile factor path next to the register-tile one)."""
+    spec = synth.manhattan_rooms()
+    assert (spec.n_poses, spec.n_planes, spec.counts()[synth.F_PLANE_OBS]) == (10000, 2000, 60000)
+    g, o, *_ = _pair(spec)
+    it = g.batch_optimize()
+    ito = o.batch_optimize()
+    c, co = g.chi2(), o.chi2()
+    st = g.stats()
+    print("C3: gpu chi2 %.12g (%d it, %.3f s, %d fronts, max front %d) oracle %.12g (%d it)" % (c, it, st["t_total"], st["n_fronts"], st["max_front"], co, ito))
+    assert it == ito
+    assert abs(c - co) <= 1e-5 * abs(co), (c, co)
+
+
+def test_c4_independent_seeds(built):
+    """BASELINE config 4 (one C2-size graph per GPU): the per-rank graphs of bench.py, solved one after the
+    other on this GPU, each against the oracle."""
+    import bench
+    for rank in (1, 5):
+        spec = synth.corridor(seed=bench.rank_seed(rank))
+        g, o, *_ = _pair(spec)
+        it, ito = g.batch_optimize(), o.batch_optimize()
+        c, co = g.chi2(), o.chi2()
+        print("C4 rank %d: gpu chi2 %.12g (%d it) oracle %.12g (%d it) rel %.2e" % (rank, c, it, co, ito, abs(c - co) / co))
+        # some seeds need several hundred LM trials; accept/reject knife edges then amplify round-off, so the
+        # trial COUNT may differ while the final chi2 stays inside the north_star tolerance
+        assert abs(c - co) <= 1e-5 * abs(co), (rank, it, ito, c, co)
