@@ -171,17 +171,37 @@ def main():
         achieved = bytes_per_launch / k1_avg / 1e9 if k1_avg > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "k_linearize", "launches": k1_launches, "avg_launch_us": k1_avg * 1e6,
+                    "kernel": "k_linearize_lanes" if mode == P.JAC_NUMERIC else "k_linearize<1,0>+<1,1>",
+                    "launches": k1_launches, "avg_launch_us": k1_avg * 1e6,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "note": "single C2 graph: 2.8 MB per sweep, cache-resident and launch-latency bound"}
-        # batched variant: replicate the edge arrays until one sweep moves > 256 MB
+                    "note": "K1 inside the timed solves (HIP event pairs on the solver's stream). One C2 graph is 2.8 MB per "
+                            "sweep: cache-resident and latency bound, so HBM traffic is not meaningful here (traffic: null); "
+                            "see roofline_batched for the same kernel family over > 256 MB"}
+        # batched variant: replicate the edge arrays until one sweep moves > 256 MB; the plane-edge launch
+        # (5 of every 6 factors) is the dominant kernel, the odometry launch is reported next to it
         reps = args.batched_replicas or int(np.ceil(300e6 / bytes_per_launch))
-        sec, npl, nod = g.bench_sweep(mode, reps, 10)
-        bb = npl * B_PLANE_EDGE + nod * B_ODO_EDGE
-        roofline_batched = {"bound": "hbm", "achieved": bb / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": bb / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_sweep_bench",
-                            "replicas": reps, "plane_edges": npl, "odometry_edges": nod,
-                            "algorithmic_bytes_per_launch": bb, "avg_launch_us": sec * 1e6}
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_k1_sweep.json")) as f:
+                pmc = json.load(f).get("v2", {})
+        except OSError:
+            pass
+        roofline_batched = {}
+        for mname, mcode in (("analytic", P.JAC_ANALYTIC), ("numeric", P.JAC_NUMERIC)):
+            (sec_all, sec_pl, sec_od), npl, nod = g.bench_sweep(mcode, reps, 10)
+            ent = {}
+            for part, sec_k, nbytes, kname in (("plane_edges", sec_pl, npl * B_PLANE_EDGE, "k_sweep_bench<%d,0>" % mcode),
+                                               ("odometry", sec_od, nod * B_ODO_EDGE, "k_sweep_bench<%d,1>" % mcode)):
+                rec = pmc.get(f"{mname}_{part}")
+                traffic = None
+                if rec and reps == 108:      # PMC passes were taken at 108 replicas (profiles/r1_pmc_k1_sweep.json)
+                    traffic = rec["hbm_bytes_corrected"]
+                ent[part] = {"bound": "hbm", "achieved": nbytes / sec_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": nbytes / sec_k / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
+                             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec_k * 1e6}
+            ent["both_launches_us"] = sec_all * 1e6
+            ent["replicas"], ent["n_plane_edges"], ent["n_odometry_edges"] = reps, npl, nod
+            roofline_batched[mname] = ent
         out = {
             "metric": "graph-solve iters/sec + final chi2, 1k-pose/5k-edge plane graph",
             "value": total_iters / elapsed, "unit": "LM iters/s",
@@ -196,11 +216,29 @@ def main():
             "fronts": st["n_fronts"], "levels": st["n_levels"], "max_front": st["max_front"],
             "roofline": roofline, "roofline_batched": roofline_batched,
         }
+        if world == 1:
+            # the closed-form Jacobian mode on the same graph (not the reference's arithmetic; reported, not the headline)
+            other = P.JAC_ANALYTIC if mode == P.JAC_NUMERIC else P.JAC_NUMERIC
+            g2 = P.Graph(device=local_rank, jacobian_mode=other)
+            spec.replay(g2)
+            g2.save_state()
+            for _ in range(max(1, args.warmup)):
+                g2.restore_state(); g2.batch_optimize()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter(); it2 = 0
+            for _ in range(args.steps):
+                g2.restore_state(); it2 += g2.batch_optimize()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            out["other_mode"] = {"jacobian_mode": "analytic" if other == P.JAC_ANALYTIC else "numeric",
+                                 "value": it2 / e2, "unit": "LM iters/s", "final_chi2": g2.chi2()}
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(spec)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
             out["chi2_rel_err_vs_cpu"] = abs(chi2 - cb["final_chi2"]) / abs(cb["final_chi2"])
+            if "other_mode" in out:
+                out["other_mode"]["chi2_rel_err_vs_cpu"] = abs(out["other_mode"]["final_chi2"] - cb["final_chi2"]) / abs(cb["final_chi2"])
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -161,9 +161,10 @@ int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed);
 
 /* ---- K1 micro-benchmark entry: the Jacobian sweep over a batch of replicated graphs --- */
 /* Replicates the handle's plane-observation and odometry edges `replicas` times in device
- * memory (state shared), runs `iters` sweeps and returns the mean kernel time (HIP events, seconds)
- * and the number of plane / odometry edges per sweep.  Used for the HBM roofline figure. */
-int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec_per_sweep,
+ * memory (state shared), runs `iters` sweeps and returns mean kernel times (HIP events, seconds):
+ * sec[0] = both launches, sec[1] = plane-edge launch alone, sec[2] = odometry launch alone; plus the
+ * number of plane / odometry edges per sweep.  Used for the HBM roofline figure. */
+int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double sec_per_sweep[3],
                     int64_t* n_plane_edges, int64_t* n_odo_edges);
 
 /* ---- pop-up (fp32), /root/reference/pop_up_wall --------------------------------------- */

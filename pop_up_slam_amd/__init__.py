@@ -328,9 +328,9 @@ class Graph:
         return parse_analysis_dump(buf)
 
     def bench_sweep(self, mode=JAC_NUMERIC, replicas=1, iters=10):
-        sec = C.c_double(); npl = C.c_int64(); nod = C.c_int64()
-        self._ck(self.L.pps_bench_sweep(self.h, mode, replicas, iters, C.byref(sec), C.byref(npl), C.byref(nod)))
-        return sec.value, npl.value, nod.value
+        sec = (C.c_double * 3)(); npl = C.c_int64(); nod = C.c_int64()
+        self._ck(self.L.pps_bench_sweep(self.h, mode, replicas, iters, sec, C.byref(npl), C.byref(nod)))
+        return tuple(sec), npl.value, nod.value
 
 
 _DUMP_SCALARS = ["n_nodes", "n_scalars", "n_fronts", "n_levels", "max_front", "n_blocks", "n_segs", "L_size",

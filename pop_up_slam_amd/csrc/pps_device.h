@@ -94,6 +94,7 @@ hipError_t launch_clear_status(const DevGraph& d, hipStream_t st);
 int lds_front_limit();
 
 // K1 micro-benchmark over replicated edge arrays (pps_bench_sweep)
-hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, hipStream_t st);
+// part: 0 = plane-edge launch, 1 = odometry launch, -1 = both
+hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, int part, hipStream_t st);
 
 }  // namespace pps

@@ -186,24 +186,67 @@ __device__ __forceinline__ void lin_plane_prior(const double pl[4], const double
 
 constexpr int kLinBlock = 128;
 
-template <int MODE>
+// A wave's 64 factor records (N doubles each, contiguous in global memory) are staged through LDS
+// (row stride N+1: conflict-free) and written back as one contiguous 64*N-double stream with 16-byte
+// stores per lane, instead of 64 scattered N*8-byte records per store instruction.
+template <int N>
+__device__ __forceinline__ void store_records_coalesced(const double (&v)[N], double* __restrict__ gbase, int n_valid,
+                                                         double* __restrict__ lds_wave) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < N; k++) lds_wave[lane * (N + 1) + k] = v[k];
+  __builtin_amdgcn_wave_barrier();
+  const int total = n_valid * N;                    // doubles this wave owns (N even -> total even)
+#pragma unroll
+  for (int k = 0; k < (N + 1) / 2; k++) {
+    const int idx = 2 * (lane + 64 * k);
+    if (idx < total) {
+      const int r0 = idx / N, c0 = idx - r0 * N;
+      const int r1 = (idx + 1) / N, c1 = idx + 1 - r1 * N;
+      double2 o;
+      o.x = lds_wave[r0 * (N + 1) + c0];
+      o.y = lds_wave[r1 * (N + 1) + c1];
+      *reinterpret_cast<double2*>(gbase + idx) = o;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// PART 0: plane-observation edges (16 KB of staging LDS per wave); PART 1: odometry edges and priors
+// (40 KB per wave in analytic mode) -- separate launches so that the big edge class keeps its occupancy.
+template <int MODE, int PART>
 __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const double* __restrict__ pose,
                                                           const double* __restrict__ plane, int nb_obs, int nb_odo,
                                                           int nb_pp) {
-  int b = blockIdx.x;
+  extern __shared__ double lin_lds[];
+  double* lds_wave = lin_lds + (size_t)(threadIdx.x >> 6) * 64 * (PART == 0 ? 31 : 79);
+  int b = blockIdx.x + (PART == 0 ? 0 : nb_obs);
   if (b < nb_obs) {
-    const int i = b * kLinBlock + threadIdx.x;
-    if (i >= d.n_obs) return;
-    double pz[7], pl[4], ms[4], w[6];
+    const int i0 = b * kLinBlock + (threadIdx.x & ~63);            // first factor of this wave
+    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_obs - 1);   // clamped: every lane stays active for the staged store
+    double pz[7], pl[4], ms[4], w[6], out[30];
     load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
     load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
     load_soa<4>(d.obs_meas, d.n_obs, i, ms);
     load_soa<6>(d.obs_w, d.n_obs, i, w);
-    lin_plane_obs<MODE>(pz, pl, ms, w, d.J + d.joff_obs + (size_t)i * 30);
+    lin_plane_obs<MODE>(pz, pl, ms, w, out);
+    if (i0 < d.n_obs) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs - i0), lds_wave);
     return;
   }
   b -= nb_obs;
   if (b < nb_odo) {
+    if (MODE == 1) {
+      const int i0 = b * kLinBlock + (threadIdx.x & ~63);
+      const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
+      double p1[7], p2[7], ms[6], w[21], out[78];
+      load_pose(pose, d.pose_ld, d.odo_a[i], p1);
+      load_pose(pose, d.pose_ld, d.odo_b[i], p2);
+      load_soa<6>(d.odo_meas, d.n_odo, i, ms);
+      load_soa<21>(d.odo_w, d.n_odo, i, w);
+      lin_odometry<MODE>(p1, p2, ms, w, out);
+      if (i0 < d.n_odo) store_records_coalesced<78>(out, d.J + d.joff_odo + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+      return;
+    }
     const int i = b * kLinBlock + threadIdx.x;
     if (i >= d.n_odo) return;
     double p1[7], p2[7], ms[6], w[21];
@@ -402,18 +445,25 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
                        lb_obs, lb_odo, lb_pp);
     return hipGetLastError();
   }
-  if (mode == 1) hipLaunchKernelGGL(k_linearize<1>, dim3(nb), dim3(kLinBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
-  else           hipLaunchKernelGGL(k_linearize<0>, dim3(nb), dim3(kLinBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+  const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
+  const int nb_rest = nb - nb_obs;
+  if (mode == 1) {
+    if (nb_obs) hipLaunchKernelGGL((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+    if (nb_rest) hipLaunchKernelGGL((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+  } else {
+    if (nb_obs) hipLaunchKernelGGL((k_linearize<0, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+    if (nb_rest) hipLaunchKernelGGL((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+  }
   return hipGetLastError();
 }
 
 // K1 over replicated plane/odometry edges (roofline micro-benchmark): replica r writes its own J slab.
-template <int MODE>
+template <int MODE, int PART>
 __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* __restrict__ Jbig, int nb_obs_per,
                                                             int nb_odo_per, int replicas) {
-  const int per = nb_obs_per + nb_odo_per;
+  const int per = PART == 0 ? nb_obs_per : nb_odo_per;
   const int rep = blockIdx.x / per;
-  int b = blockIdx.x % per;
+  int b = blockIdx.x % per + (PART == 0 ? 0 : nb_obs_per);
   const size_t slab = (size_t)d.n_obs * 30 + (size_t)d.n_odo * 78;
   double* Jr = Jbig + (size_t)rep * slab;
   // replicas read shifted copies of the edge arrays so that no two replicas share cache lines
@@ -425,18 +475,33 @@ __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* _
   const double* odo_w = d.odo_w + (size_t)rep * 21 * d.n_odo;
   const int* odo_a = d.odo_a + (size_t)rep * d.n_odo;
   const int* odo_b = d.odo_b + (size_t)rep * d.n_odo;
+  extern __shared__ double lin_lds[];
+  double* lds_wave = lin_lds + (size_t)(threadIdx.x >> 6) * 64 * (PART == 0 ? 31 : 79);
   if (b < nb_obs_per) {
-    const int i = b * kLinBlock + threadIdx.x;
-    if (i >= d.n_obs) return;
-    double pz[7], pl[4], ms[4], w[6];
+    const int i0 = b * kLinBlock + (threadIdx.x & ~63);
+    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_obs - 1);
+    double pz[7], pl[4], ms[4], w[6], out[30];
     load_pose(d.pose_lin, d.pose_ld, obs_pose[i], pz);
     load_plane(d.plane_lin, d.plane_ld, obs_plane[i], pl);
     load_soa<4>(obs_meas, d.n_obs, i, ms);
     load_soa<6>(obs_w, d.n_obs, i, w);
-    lin_plane_obs<MODE>(pz, pl, ms, w, Jr + (size_t)i * 30);
+    lin_plane_obs<MODE>(pz, pl, ms, w, out);
+    if (i0 < d.n_obs) store_records_coalesced<30>(out, Jr + (size_t)i0 * 30, min(64, d.n_obs - i0), lds_wave);
     return;
   }
   b -= nb_obs_per;
+  if (MODE == 1) {
+    const int i0 = b * kLinBlock + (threadIdx.x & ~63);
+    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
+    double p1[7], p2[7], ms[6], w[21], out[78];
+    load_pose(d.pose_lin, d.pose_ld, odo_a[i], p1);
+    load_pose(d.pose_lin, d.pose_ld, odo_b[i], p2);
+    load_soa<6>(odo_meas, d.n_odo, i, ms);
+    load_soa<21>(odo_w, d.n_odo, i, w);
+    lin_odometry<MODE>(p1, p2, ms, w, out);
+    if (i0 < d.n_odo) store_records_coalesced<78>(out, Jr + (size_t)d.n_obs * 30 + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+    return;
+  }
   const int i = b * kLinBlock + threadIdx.x;
   if (i >= d.n_odo) return;
   double p1[7], p2[7], ms[6], w[21];
@@ -447,12 +512,17 @@ __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* _
   lin_odometry<MODE>(p1, p2, ms, w, Jr + (size_t)d.n_obs * 30 + (size_t)i * 78);
 }
 
-hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, hipStream_t st) {
+hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, int part, hipStream_t st) {
   const int nb_obs = cdiv(d.n_obs, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock);
-  const int nb = (nb_obs + nb_odo) * replicas;
-  if (nb == 0) return hipSuccess;
-  if (mode == 1) hipLaunchKernelGGL(k_sweep_bench<1>, dim3(nb), dim3(kLinBlock), 0, st, d, Jbig, nb_obs, nb_odo, replicas);
-  else           hipLaunchKernelGGL(k_sweep_bench<0>, dim3(nb), dim3(kLinBlock), 0, st, d, Jbig, nb_obs, nb_odo, replicas);
+  const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
+  if (nb_obs + nb_odo == 0) return hipSuccess;
+  if (mode == 1) {
+    if (nb_obs && part != 1) hipLaunchKernelGGL((k_sweep_bench<1, 0>), dim3(nb_obs * replicas), dim3(kLinBlock), lds0, st, d, Jbig, nb_obs, nb_odo, replicas);
+    if (nb_odo && part != 0) hipLaunchKernelGGL((k_sweep_bench<1, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), lds1, st, d, Jbig, nb_obs, nb_odo, replicas);
+  } else {
+    if (nb_obs && part != 1) hipLaunchKernelGGL((k_sweep_bench<0, 0>), dim3(nb_obs * replicas), dim3(kLinBlock), lds0, st, d, Jbig, nb_obs, nb_odo, replicas);
+    if (nb_odo && part != 0) hipLaunchKernelGGL((k_sweep_bench<0, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), 0, st, d, Jbig, nb_obs, nb_odo, replicas);
+  }
   return hipGetLastError();
 }
 
