@@ -70,7 +70,14 @@ struct pps_graph {
   bool dev_ready = false;
   hipStream_t stream = nullptr;
   DevGraph dev;
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;        // fallback allocations (arena full), freed at the next full upload
+  // Device memory comes from two growable arenas that are re-used across uploads (a SLAM front end changes
+  // the topology every frame; hipMalloc/hipFree per array per frame would dominate): `up` holds the arrays
+  // that are uploaded (mirrored in a host staging buffer and sent with ONE copy), `scr` the scratch arrays.
+  struct Arena { char* base = nullptr; size_t cap = 0, off = 0, spill = 0; };
+  Arena up, scr;
+  std::vector<char> stage;          // host mirror of `up`
+  size_t stage_lo = 0, stage_hi = 0;   // dirty range of the mirror
   double* host_result = nullptr;   // pinned, 8 doubles
   double seq = 0.0;                // sequence number the chi2 kernel publishes last (host polls it)
   // speculative solve of the LM reject branch (lambda * factor) on a second stream, into a second set of L/U/delta
@@ -119,25 +126,66 @@ int hip_fail(pps_graph* g, hipError_t e, const char* what) {
 void free_device(pps_graph* g) {
   for (void* p : g->allocs) (void)hipFree(p);
   g->allocs.clear();
+  // arenas are kept; grow them when the last layout spilled into fallback allocations
+  for (pps_graph::Arena* a : {&g->up, &g->scr}) {
+    const size_t want = a->off + a->spill;
+    if (a->spill > 0 || a->base == nullptr) {
+      if (a->base) (void)hipFree(a->base);
+      a->cap = std::max<size_t>(size_t(1) << 20, 2 * want);
+      if (hipMalloc(reinterpret_cast<void**>(&a->base), a->cap) != hipSuccess) { a->base = nullptr; a->cap = 0; }
+    }
+    a->off = 0; a->spill = 0;
+  }
+  if (g->stage.size() < g->up.cap) g->stage.resize(g->up.cap);
+  g->stage_lo = g->stage_hi = 0;
   g->dev = DevGraph();
 }
 
+void release_arenas(pps_graph* g) {
+  for (pps_graph::Arena* a : {&g->up, &g->scr}) { if (a->base) (void)hipFree(a->base); a->base = nullptr; a->cap = a->off = a->spill = 0; }
+}
+
 template <class T>
-int dev_alloc(pps_graph* g, T** out, size_t count) {
+int arena_alloc(pps_graph* g, pps_graph::Arena& a, T** out, size_t count) {
   *out = nullptr;
   if (count == 0) count = 1;
+  const size_t bytes = count * sizeof(T);
+  const size_t o = (a.off + 255) & ~size_t(255);
+  if (a.base && o + bytes <= a.cap) { a.off = o + bytes; *out = reinterpret_cast<T*>(a.base + o); return PPS_OK; }
+  a.spill += bytes + 256;
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, count * sizeof(T));
+  hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) return hip_fail(g, e, "hipMalloc");
   g->allocs.push_back(p);
   *out = static_cast<T*>(p);
   return PPS_OK;
 }
+
+template <class T>
+int dev_alloc(pps_graph* g, T** out, size_t count) { return arena_alloc(g, g->scr, out, count); }
+
 template <class T>
 int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
-  int rc = dev_alloc(g, out, v.size());
+  int rc = arena_alloc(g, g->up, out, v.size());
   if (rc != PPS_OK) return rc;
-  if (!v.empty()) HIP_TRY(g, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (v.empty()) return PPS_OK;
+  char* p = reinterpret_cast<char*>(*out);
+  if (g->up.base && p >= g->up.base && p < g->up.base + g->up.cap) {      // staged: goes out with the next flush
+    const size_t o = (size_t)(p - g->up.base);
+    memcpy(g->stage.data() + o, v.data(), v.size() * sizeof(T));
+    if (g->stage_hi == g->stage_lo) { g->stage_lo = o; g->stage_hi = o + v.size() * sizeof(T); }
+    else { g->stage_lo = std::min(g->stage_lo, o); g->stage_hi = std::max(g->stage_hi, o + v.size() * sizeof(T)); }
+  } else {
+    HIP_TRY(g, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  return PPS_OK;
+}
+
+// send the staged part of the upload arena in one copy
+int flush_uploads(pps_graph* g) {
+  if (g->stage_hi > g->stage_lo)
+    HIP_TRY(g, hipMemcpy(g->up.base + g->stage_lo, g->stage.data() + g->stage_lo, g->stage_hi - g->stage_lo, hipMemcpyHostToDevice));
+  g->stage_lo = g->stage_hi = 0;
   return PPS_OK;
 }
 
@@ -424,7 +472,8 @@ int upload_all(pps_graph* g) {
     TRY(dev_alloc(g, &d.gwork, (size_t)d.gwork_stride * std::max(1, widest)));
   }
 #undef TRY
-  HIP_TRY(g, hipStreamSynchronize(g->stream));   // host staging vectors go out of scope
+  rc = flush_uploads(g); if (rc != PPS_OK) return rc;
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->topo_dirty = false;
   g->meas_dirty = false;
   rc = upload_state(g);
@@ -616,6 +665,7 @@ int pps_graph_destroy(pps_graph* g) {
     (void)hipSetDevice(g->props.device);
     (void)hipStreamSynchronize(g->stream);
     free_device(g);
+    release_arenas(g);
     if (g->host_result) (void)hipHostFree(g->host_result);
     if (g->ev[0]) (void)hipEventDestroy(g->ev[0]);
     if (g->ev[1]) (void)hipEventDestroy(g->ev[1]);
@@ -1181,6 +1231,7 @@ int pps_refresh_measurements(pps_graph* g) {
     rc = dev_upload(g, &g->d_frame_pose_slot, pslot); if (rc != PPS_OK) return rc;
     rc = dev_upload(g, &g->d_frame_seg_off, g->fr_seg_off); if (rc != PPS_OK) return rc;
     rc = dev_upload(g, &g->d_fr_seg, g->fr_seg); if (rc != PPS_OK) return rc;
+    rc = flush_uploads(g); if (rc != PPS_OK) return rc;
     g->frames_dirty = false;
   }
   RefreshArgs a{};

@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256) void k_refresh_measurements(RefreshArgs a) {
   else seg_to_plane(a.seg2d + 4 * (size_t)(a.frame_seg_off[f] + j - 1), a.invK, T, gs, pl);
   double v[4] = {(double)pl[0], (double)pl[1], (double)pl[2], (double)pl[3]};
   const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+  // A ground ray that no longer hits the ground (segment at or above the horizon of the refreshed pose)
+  // gives inf/NaN; the reference would push that NaN into the factor (it only logs NaN planes at
+  // creation, main_3d.cpp:434-435) and lose the graph.  Keep the previous measurement instead.
+  if (!(nrm > 0.0) || !(nrm < 1e300)) return;
 #pragma unroll
   for (int k = 0; k < 4; k++) a.obs_meas[(size_t)k * a.n_obs + slot] = v[k] / nrm;
 }

@@ -1,0 +1,167 @@
+"""Config-5 pipeline: per-frame plane pop-up fused with the incremental graph solve.
+
+Mirrors what the reference does for every keyframe (all citations relative to
+/root/reference):
+  main_3d.cpp:366-385      constant-velocity / odometry pose guess  last (+) odo
+  main_3d.cpp:431,454      popup_plane::get_plane_equation + generate_cloud      -> K5 + K6 (one launch)
+  Mapping.cpp:464-530      processFrame: new pose node, odometry factor, new landmarks, plane edges
+  Mapping.cpp:551-554      batch_optimization() every 5th frame, update() otherwise
+  main_3d.cpp:504, Mapping.cpp:590-607   update_plane_measurement for ALL stored frames -> one K5 launch
+Data association is given (synthetic landmark ids): `findClosestPlane` is out of scope.
+
+The same driver runs against the product (pop_up_slam_amd.Graph + Popup, everything numeric on the GPU)
+or against any backend pair with the same surface -- the tests drive the CPU oracle through it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import synth
+
+
+@dataclass
+class Frame:
+    true_pose: np.ndarray          # (7,) ground truth, used only by the generator
+    odo: np.ndarray                # (7,) measured relative pose (first frame: the initial pose itself)
+    seg2d: np.ndarray              # (n,4) fp32 ground segments, segment i <-> landmark ids[i]
+    ids: list                      # landmark keys of the n walls
+    polys: list                    # n+1 polygons (ground first)
+    dist: np.ndarray               # (n+1,) plane distance to the camera (sigma model, Mapping.cpp:507-512)
+
+
+def popup_sequence(n_frames=1000, seed=7, width=640, height=480, K=synth.K_TUM, step=0.10):
+    """Synthetic corridor drive: 1 m wall panels every 1.25 m on both sides plus a cross panel every fourth
+    section; a frame observes the ground and every panel whose two ground end points are 3..7 m ahead and
+    project inside (a margin around) the image -- 3 to 7 ground segments per frame."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    sec = 1.25
+    n_sec = int(np.ceil((n_frames * step + 12.0) / sec))
+    panels = []   # (key, p0 (x,y), p1 (x,y))
+    for i in range(n_sec):
+        y0 = i * sec
+        off_l, off_r = 1.5 + 0.3 * rng.random(), 1.5 + 0.3 * rng.random()
+        panels.append((3 * i, np.array([-off_l, y0 + 0.1]), np.array([-off_l, y0 + 1.1])))
+        panels.append((3 * i + 1, np.array([off_r, y0 + 1.1]), np.array([off_r, y0 + 0.1])))
+        if i % 4 == 3:
+            panels.append((3 * i + 2, np.array([-1.0, y0 + 1.2]), np.array([1.0, y0 + 1.2])))
+    frames = []
+    yaw = 0.0
+    prev = None
+    for k in range(n_frames):
+        yaw = 0.95 * yaw + rng.normal(0.0, np.deg2rad(0.5))
+        R = synth._Rz(yaw) @ synth.CAM_R0
+        t = np.array([rng.normal(0.0, 0.01), step * k, 1.0])
+        tp = synth.pose_from_Rt(R, t)
+        seg, ids, dist = [], [], [1.0]
+        for key, p0, p1 in panels:
+            px, ok = [], True
+            for P in (p0, p1):
+                pc = R.T @ (np.array([P[0], P[1], 0.0]) - t)
+                if not (3.0 <= pc[2] <= 7.0):
+                    ok = False
+                    break
+                uv = K @ (pc / pc[2])
+                if not (-40 <= uv[0] <= width + 40):
+                    ok = False
+                    break
+                px.append(uv[:2])
+            if ok:
+                seg.append([*px[0], *px[1]])
+                ids.append(key)
+                mid = 0.5 * (p0 + p1)
+                dist.append(float(np.hypot(mid[0] - t[0], mid[1] - t[1])))
+        seg = np.array(seg, dtype=np.float32).reshape(-1, 4)
+        vmax = float(seg[:, [1, 3]].max()) if len(seg) else height * 0.6
+        polys = [np.array([[0, vmax], [width - 1, vmax], [width - 1, height - 1], [0, height - 1]], dtype=np.float32)]
+        for s in seg:
+            polys.append(np.array([[s[0], s[1]], [s[2], s[3]], [s[2], 0.0], [s[0], 0.0]], dtype=np.float32))
+        if prev is None:
+            odo = tp.copy()
+        else:
+            odo = synth.pose_exmap(synth.pose_ominus(tp, prev), rng.normal(0, 1, 6) * np.array([0.01] * 3 + [np.deg2rad(0.2)] * 3))
+        frames.append(Frame(tp, odo, seg, ids, polys, np.array(dist)))
+        prev = tp
+    return frames
+
+
+class PopupSlamPipeline:
+    """Per-frame driver.  `graph` needs the add_*/update/batch_optimize/get_pose surface; `popup_fn(seg, T32,
+    polys)` returns the (n+1,4) fp32 sensor-frame planes of a frame (and may pop up pixels as a side effect);
+    `refresh_fn(pipeline)` re-derives all stored measurements from the latest poses."""
+
+    POSE_UT = synth._ut_diag([0.5] * 6)
+    GROUND_UT = synth._ut_diag([20.0] * 3)
+
+    def __init__(self, graph, popup_fn, refresh_fn, pose_oplus, plane_transform_from, pose_vector):
+        self.g = graph
+        self.popup_fn, self.refresh_fn = popup_fn, refresh_fn
+        self.pose_oplus, self.plane_transform_from, self.pose_vector = pose_oplus, plane_transform_from, pose_vector
+        self.pose_nodes, self.landmarks = [], {}
+        self.frames = []          # (pose node, seg2d, fids)
+        self.k = 0
+
+    def process(self, fr: Frame):
+        g = self.g
+        if self.pose_nodes:
+            est = self.pose_oplus(g.get_pose(self.pose_nodes[-1]), fr.odo)       # main_3d.cpp:366-385
+        else:
+            est = fr.odo.copy()
+        T32 = synth.T_from_pose(est).astype(np.float32)
+        planes = self.popup_fn(fr.seg2d, T32, fr.polys)                          # K5 (+K6)
+        if self.pose_nodes:
+            p = g.add_pose(est)
+            g.add_odometry(self.pose_nodes[-1], p, self.pose_vector(fr.odo), self.POSE_UT)
+        else:
+            p = g.add_pose(est)
+            g.add_pose_prior(p, self.pose_vector(est), self.POSE_UT)
+        self.pose_nodes.append(p)
+        fids = []
+        keys = ["g"] + list(fr.ids)
+        for j, key in enumerate(keys):
+            m = planes[j].astype(np.float64)
+            m = m / np.linalg.norm(m)                                            # Plane3d(Vector4d)
+            if key not in self.landmarks:
+                self.landmarks[key] = g.add_plane(self.plane_transform_from(m, est))   # Mapping.cpp:496-499
+                if key == "g":
+                    g.add_plane_prior(self.landmarks[key], synth.GROUND, self.GROUND_UT)   # :500-504
+            sig = synth.plane_sigma(float(fr.dist[j]))
+            fids.append(g.add_plane_obs(p, self.landmarks[key], m, synth._ut_diag([1.0 / sig] * 3)))
+        self.frames.append((p, fr.seg2d, fids))
+        if self.k % 5 == 0:                                                      # Mapping.cpp:551-554
+            it = g.batch_optimize()
+        else:
+            g.update()
+            it = -1
+        self.refresh_fn(self, p, fr.seg2d, fids)                                 # main_3d.cpp:504
+        self.k += 1
+        return it
+
+
+def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, with_image=True, seed=0):
+    """Product pipeline: Graph + Popup on the GPU; pop-up results stay on the device."""
+    import pop_up_slam_amd as P
+    invK = np.linalg.inv(K).astype(np.float32)
+    g = P.Graph(jacobian_mode=jacobian_mode)
+    g.frames_set_calibration(invK)
+    pp = P.Popup(width, height, invK)
+    if with_image:
+        rng = np.random.default_rng(seed)
+        pp.set_image(rng.integers(0, 256, size=(height, width, 3), dtype=np.uint8))
+    stats = {"popup_kernel_s": 0.0, "points": 0}
+
+    def popup_fn(seg, T32, polys):
+        stats["points"] += pp.run(seg, T32, polys, step=step, depth_thre=10.0, ceiling_thre=2.5)
+        stats["popup_kernel_s"] += pp.last_kernel_time()
+        planes = np.zeros((len(seg) + 1, 4), dtype=np.float32)
+        import ctypes as C
+        pp._ck(pp.L.pps_popup_download(pp.h, planes.ctypes.data_as(C.POINTER(C.c_float)), None, None, None))
+        return planes
+
+    def refresh_fn(pl, pose_node, seg, fids):
+        g.frames_add(pose_node, seg, fids)
+        g.refresh_measurements()
+
+    pl = PopupSlamPipeline(g, popup_fn, refresh_fn, synth.pose_oplus, synth.plane_transform_from, synth.pose_vector)
+    return pl, g, pp, stats
