@@ -140,6 +140,16 @@ public:
   Vector3d normal() const { const double n = std::sqrt(_abcd[0] * _abcd[0] + _abcd[1] * _abcd[1] + _abcd[2] * _abcd[2]); return {_abcd[0] / n, _abcd[1] / n, _abcd[2] / n}; }
   double d() const { return -_abcd[3] / std::sqrt(_abcd[0] * _abcd[0] + _abcd[1] * _abcd[1] + _abcd[2] * _abcd[2]); }
   double distance() const { return std::fabs(d()); }
+  Vector3d point0() const { const Vector3d n = normal(); const double dd = d(); return {dd * n[0], dd * n[1], dd * n[2]}; }   // :161-163
+  double distance(const Vector3d& pt) const {                                                                                  // :165-167
+    const Vector3d n = normal(), p0 = point0();
+    return std::fabs(n[0] * (pt[0] - p0[0]) + n[1] * (pt[1] - p0[1]) + n[2] * (pt[2] - p0[2]));
+  }
+  Vector3d project_to_plane(const Vector3d& pt) const {   // :169-174, used by Mapper_mono::reproj_to_newplane (Mapping.cpp:609-632)
+    const Vector3d n = normal();
+    const double k = n[0] * pt[0] + n[1] * pt[1] + n[2] * pt[2] - d();
+    return {pt[0] - n[0] * k, pt[1] - n[1] * k, pt[2] - n[2] * k};
+  }
   static Vector4d tmul(const Matrix4d& T, const Vector4d& v) {   // T^T v
     Vector4d o{};
     for (int k = 0; k < 4; k++) o[k] = T[0 * 4 + k] * v[0] + T[1 * 4 + k] * v[1] + T[2 * 4 + k] * v[2] + T[3 * 4 + k] * v[3];

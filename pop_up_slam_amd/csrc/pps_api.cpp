@@ -296,6 +296,7 @@ int run_analysis(pps_graph* g) {
 // pull the device estimate back into the host node table
 int download_state(pps_graph* g) {
   if (!g->dev_values_newer) return PPS_OK;
+  HIP_TRY(g, hipSetDevice(g->props.device));
   const DevGraph& d = g->dev;
   std::vector<double> bp((size_t)7 * d.pose_ld), bl((size_t)4 * d.plane_ld);
   if (d.n_pose) HIP_TRY(g, hipMemcpyAsync(bp.data(), d.pose_est, bp.size() * 8, hipMemcpyDeviceToHost, g->stream));
@@ -341,6 +342,7 @@ void pack_soa(const pps_graph* g, int type, const double HostFactor::*dummy, boo
 // pull device-refreshed plane-observation measurements back into the host factor table
 int download_measurements(pps_graph* g) {
   if (!g->dev_meas_newer) return PPS_OK;
+  HIP_TRY(g, hipSetDevice(g->props.device));
   const DevGraph& d = g->dev;
   const size_t n = g->fslot_ids[F_PLANE_OBS].size();
   std::vector<double> m((size_t)4 * n);
@@ -484,6 +486,7 @@ int upload_all(pps_graph* g) {
 int prepare_solve(pps_graph* g) {
   int rc;
   if (g->n_live_nodes == 0) return fail(g, PPS_ESTATE, "empty graph");
+  if (g->dev_ready) HIP_TRY(g, hipSetDevice(g->props.device));   // handles may be driven from any host thread
   if (g->topo_dirty || !g->dev_ready || g->dev.n_scalars == 0) { rc = upload_all(g); if (rc != PPS_OK) return rc; }
   if (g->host_values_newer) { rc = upload_state(g); if (rc != PPS_OK) return rc; }
   if (g->meas_dirty) { rc = upload_measurements(g); if (rc != PPS_OK) return rc; }

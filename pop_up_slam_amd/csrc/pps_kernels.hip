@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void k_front_factor(DevGraph d, int level_begi
   }
 }
 
-static bool g_attr_set = false;
+static bool g_attr_set[64] = {false};   // per device ordinal
 
 hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
                                hipStream_t st) {
@@ -714,11 +714,13 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
   const int fa = level_max_front + 1;
   const size_t bytes = (size_t)fa * (fa | 1) * 8;
   if (bytes <= (size_t)kLdsLimitBytes) {
-    if (!g_attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!g_attr_set[dev & 63]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_factor<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
       if (e != hipSuccess) return e;
-      g_attr_set = true;
+      g_attr_set[dev & 63] = true;
     }
     hipLaunchKernelGGL(k_front_factor<true>, dim3(level_count), dim3(256), bytes, st, d, level_begin, lambda);
   } else {
@@ -1190,15 +1192,17 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, i
   }
 }
 
-static bool g_band_attr_set = false;
+static bool g_band_attr_set[64] = {false};   // per device ordinal
 
 hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st) {
   if (grp_count == 0) return hipSuccess;
-  if (!g_band_attr_set) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!g_band_attr_set[dev & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
-    g_band_attr_set = true;
+    g_band_attr_set[dev & 63] = true;
   }
   const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
   hipLaunchKernelGGL(k_band_factor, dim3(grp_count), dim3(64 * nwaves), (size_t)per_wave * nwaves * sizeof(double), st, d, grp_begin, lambda, per_wave);

@@ -323,6 +323,7 @@ const char* pps_popup_last_error(const pps_popup* p) { return p ? p->err.c_str()
 int pps_popup_set_image(pps_popup* p, const unsigned char* bgr) {
   if (!p) return PPS_EINVAL;
   if (!bgr) { p->has_image = false; return PPS_OK; }
+  PHIP(p, hipSetDevice(p->device));
   PHIP(p, hipMemcpy(p->d_bgr, bgr, (size_t)p->width * p->height * 3, hipMemcpyHostToDevice));
   p->has_image = true;
   return PPS_OK;
@@ -335,6 +336,7 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   if (nplanes > n + 1) return pfail(p, PPS_EINVAL, "more polygons than planes");
   if (poly_off[nplanes] > kMaxVerts) return pfail(p, PPS_EINVAL, "too many polygon vertices (max 512)");
   if (step != 1 && step != 2) return pfail(p, PPS_EINVAL, "step must be 1 or 2");
+  PHIP(p, hipSetDevice(p->device));
   if ((n > 0 && !seg2d) || (poly_off[nplanes] > 0 && !polys)) return PPS_EINVAL;
   PopupParams prm{};
   memcpy(prm.invK, p->invK, sizeof prm.invK);
@@ -363,6 +365,7 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
 
 int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* depth, int32_t* plane_id) {
   if (!p) return PPS_EINVAL;
+  PHIP(p, hipSetDevice(p->device));
   const size_t npx = (size_t)p->width * p->height;
   if (planes) PHIP(p, hipMemcpy(planes, p->d_planes, sizeof(float) * 4 * (size_t)(p->last_n + 1), hipMemcpyDeviceToHost));
   if (cloud) PHIP(p, hipMemcpy(cloud, p->d_cloud, npx * sizeof(pps_point), hipMemcpyDeviceToHost));

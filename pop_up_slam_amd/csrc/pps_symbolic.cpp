@@ -557,6 +557,8 @@ void dump_analysis(const Analysis& a, std::vector<int32_t>& out) {
   putv(a.contrib);
   put(a.n_stages); put(a.n_groups); put(a.n_glevels);
   putv(a.stage_grp_off); putv(a.grp_lvl_off); putv(a.glvl_front_off); putv(a.glvl_fronts); putv(a.stage_max_front); putv(a.stage_max_width);
+  putv(a.f_el_off); putv(a.el_src); putv(a.el_tgt); putv64(a.f_ea_off); putv(a.ea_tgt); putv(a.blk_doff); putv(a.blk_dst);
+  putv(a.frec); putv(a.crec); putv(a.srec);
 }
 
 }  // namespace pps

@@ -70,3 +70,73 @@ def solve_with_analysis(A, Jbuf, lam):
         x = np.linalg.solve(L[:p, :].T, t)
         delta[A["f_poff"][s]:A["f_poff"][s] + p] = x
     return delta
+
+
+def _tri(i):
+    return i * (i + 1) // 2
+
+
+def solve_with_band_schedule(A, Jbuf, lam):
+    """Emulates the wave-per-front band kernels from the arrays THEY read: packed segment / front / child
+    records, the front-ordered H (Hf) with its flat gather targets, the packed extend-add targets and the
+    stage -> group -> local level -> front schedule.  Returns delta in elimination order."""
+    srec = A["srec"].reshape(-1, 8)
+    ctr = A["contrib"].reshape(-1, 4)
+    H = np.zeros(A["H_size"]); Hf = np.zeros(len(A["el_src"]))
+    for rows, cols, size, c0, cnt, hoff, doff, nsegb in srec:
+        acc = np.zeros(size)
+        for c in range(c0, c0 + cnt):
+            jv, ju, roff, m = ctr[c]
+            Jv = Jbuf[jv:jv + m * rows].reshape(m, rows)
+            acc[:rows * cols] += (Jv.T @ Jbuf[ju:ju + m * cols].reshape(m, cols)).ravel()
+            if size > rows * cols:
+                acc[rows * cols:] -= Jv.T @ Jbuf[roff:roff + m]
+        H[hoff:hoff + size] = acc
+        if nsegb == 1:
+            dst = A["blk_dst"][doff:doff + size]
+            Hf[dst[dst >= 0]] = acc[dst >= 0]
+    for blk in np.where(A["blk_nseg"] > 1)[0]:                      # k_hreduce
+        size, ns, ho = A["blk_size"][blk], A["blk_nseg"][blk], A["blk_hoff"][blk]
+        v = H[ho:ho + ns * size].reshape(ns, size).sum(axis=0)
+        dst = A["blk_dst"][A["blk_doff"][blk]:A["blk_doff"][blk] + size]
+        Hf[dst[dst >= 0]] = v[dst >= 0]
+    frec = A["frec"].reshape(-1, 16); crec = A["crec"].reshape(-1, 8)
+    Lst, Ust, done = {}, {}, set()
+    order = []
+    for st in range(A["n_stages"]):
+        for g in range(A["stage_grp_off"][st], A["stage_grp_off"][st + 1]):
+            for l in range(A["grp_lvl_off"][g], A["grp_lvl_off"][g + 1]):
+                for i in range(A["glvl_front_off"][l], A["glvl_front_off"][l + 1]):
+                    order.append(i)
+                    r = frec[i]
+                    s, p, b, e0, e1, cr0, nch = r[0], r[1], r[2], r[3], r[4], r[5], r[6]
+                    assert s == A["glvl_fronts"][i] and p == A["f_p"][s] and b == A["f_b"][s]
+                    f = p + b; fa = f + 1
+                    F = np.zeros(_tri(fa))
+                    tg = A["el_tgt"][e0:e1]
+                    v = Hf[e0:e1] * np.where(tg & (1 << 30), 1.0 + lam, 1.0)
+                    np.add.at(F, tg & 0x3fffffff, v)
+                    for cj in range(nch):
+                        n, ulo, uhi, elo, ehi, c = crec[cr0 + cj][:6]
+                        assert c in done, "child not finished before its parent (band schedule order)"
+                        assert n == _tri(A["f_b"][c] + 1) and ((uhi << 32) | ulo) == A["f_Uoff"][c]
+                        eo = (ehi << 32) | elo
+                        np.add.at(F, A["ea_tgt"][eo:eo + n], Ust[c])
+                    M = np.zeros((fa, fa))
+                    M[np.tril_indices(fa)] = F
+                    M = M + np.tril(M, -1).T
+                    La = np.linalg.cholesky(M[:p, :p])
+                    Lb = np.linalg.solve(La, M[p:, :p].T).T
+                    U = M[p:, p:] - Lb @ Lb.T
+                    Ust[s] = U[np.tril_indices(b + 1)]
+                    Lst[s] = np.vstack([La, Lb])
+                    done.add(s)
+    assert len(done) == A["n_fronts"]
+    delta = np.zeros(A["n_scalars"])
+    for i in reversed(order):
+        r = frec[i]
+        s, p, b, poff, boff = r[0], r[1], r[2], r[7], r[8]
+        L = Lst[s]
+        t = L[p + b, :] - L[p:p + b, :].T @ delta[A["bidx"][boff:boff + b]]
+        delta[poff:poff + p] = np.linalg.solve(L[:p, :].T, t)
+    return delta

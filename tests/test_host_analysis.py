@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import pop_up_slam_amd as P
-from mf_emulator import solve_with_analysis
+from mf_emulator import solve_with_analysis, solve_with_band_schedule
 from oracle import oracle_py as O
 from pop_up_slam_amd import synth
 
@@ -48,12 +48,14 @@ def test_multifrontal_structure_solves_the_normal_equations(built, case, lam):
     g.analyze()
     A = g.analysis_dump()
     dref, Jbuf, starts, dims = _dense_and_jbuf(spec, A, lam)
-    d = solve_with_analysis(A, Jbuf, lam)
-    dm = np.zeros_like(dref)
-    for i in range(len(dims)):
-        c = A["node_compact"][i]
-        dm[starts[i]:starts[i] + dims[i]] = d[A["node_voff"][c]:A["node_voff"][c] + dims[i]]
-    assert np.abs(dm - dref).max() <= 1e-9 * np.abs(dref).max()
+    # (1) the level-per-launch arrays, (2) the arrays of the wave-per-front band kernels
+    for solver in (solve_with_analysis, solve_with_band_schedule):
+        d = solver(A, Jbuf, lam)
+        dm = np.zeros_like(dref)
+        for i in range(len(dims)):
+            c = A["node_compact"][i]
+            dm[starts[i]:starts[i] + dims[i]] = d[A["node_voff"][c]:A["node_voff"][c] + dims[i]]
+        assert np.abs(dm - dref).max() <= 1e-9 * np.abs(dref).max(), solver.__name__
 
 
 def test_analysis_invariants_c2(built):
@@ -85,3 +87,27 @@ def test_reanalysis_after_topology_change(built):
     g.remove_node(last_pose)
     g.analyze()
     assert g.analysis_dump()["n_scalars"] == n0 - 6
+
+
+def test_band_schedule_invariants(built):
+    spec = synth.manhattan_rooms(1500, 300, seed=5)
+    g = P.Graph(); spec.replay(g); g.analyze()
+    A = g.analysis_dump()
+    assert sorted(A["glvl_fronts"]) == list(range(A["n_fronts"]))         # every front scheduled exactly once
+    assert A["stage_grp_off"][-1] == A["n_groups"] and A["grp_lvl_off"][-1] == A["n_glevels"]
+    # a group's fronts all come from one band of tree levels, and parents sit in the same or a later stage
+    stage_of = {}
+    for st in range(A["n_stages"]):
+        for grp in range(A["stage_grp_off"][st], A["stage_grp_off"][st + 1]):
+            for l in range(A["grp_lvl_off"][grp], A["grp_lvl_off"][grp + 1]):
+                for i in range(A["glvl_front_off"][l], A["glvl_front_off"][l + 1]):
+                    stage_of[A["glvl_fronts"][i]] = st
+    for s, par in enumerate(A["f_parent"]):
+        if par >= 0:
+            assert stage_of[par] >= stage_of[s]
+    assert A["stage_max_front"].max() == A["max_front"]
+    # gather targets stay inside the packed triangle of their front
+    for s in range(A["n_fronts"]):
+        fa = A["f_p"][s] + A["f_b"][s] + 1
+        tg = A["el_tgt"][A["f_el_off"][s]:A["f_el_off"][s + 1]] & 0x3fffffff
+        assert tg.size == 0 or tg.max() < fa * (fa + 1) // 2
