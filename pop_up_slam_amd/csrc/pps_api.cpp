@@ -260,6 +260,7 @@ int run_analysis(pps_graph* g) {
   if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
   if (const char* e = getenv("PPS_MAX_PIVOTS")) g->aprm.max_pivots = atoi(e);
   if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
+  if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
   const char* msg = "";
   if (!analyze(sn, sf, g->aprm, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);

@@ -79,45 +79,60 @@ struct Builder {
         if (lj > i + 1) { cross.emplace_back(i, lj); diff[i + 1] += 6; diff[lj] -= 6; }
       }
     }
-    int lo = std::max(1, n / 3), hi = std::min(n - 2, (2 * n) / 3);
-    if (hi < lo) { lo = hi = n / 2; }
-    int best = -1, best_cost = 1 << 30, run = 0;
     std::vector<int> cost(n, 0);
-    for (int m = 0; m < n; m++) { run += diff[m]; cost[m] = run; }
-    for (int m = lo; m <= hi; m++) {
-      const int c = cost[m];
-      if (c < best_cost || (c == best_cost && std::abs(m - n / 2) < std::abs(best - n / 2))) { best_cost = c; best = m; }
+    { int run = 0; for (int m2 = 0; m2 < n; m2++) { run += diff[m2]; cost[m2] = run; } }
+    // cut positions: arity-1 cuts near the quantiles, each moved inside its window to the cheapest position
+    int K = std::max(2, prm.arity);
+    while (K > 2 && n < 2 * K + 1) K--;        // too short for that many parts
+    std::vector<int> cuts;
+    for (int c = 1; c < K; c++) {
+      const int centre = (int)((long long)n * c / K);
+      const int half = std::max(0, n / (6 * K));
+      int lo = std::max(1, centre - half), hi = std::min(n - 2, centre + half);
+      if (!cuts.empty()) lo = std::max(lo, cuts.back() + 2);
+      if (hi < lo) { if (lo <= n - 2) hi = lo; else continue; }
+      int best = lo, best_cost = cost[lo];
+      for (int m2 = lo; m2 <= hi; m2++)
+        if (cost[m2] < best_cost || (cost[m2] == best_cost && std::abs(m2 - centre) < std::abs(best - centre))) { best_cost = cost[m2]; best = m2; }
+      cuts.push_back(best);
     }
-    const int m = best;
-    std::vector<char> in_sep(n, 0);
-    in_sep[m] = 1;
+    if (cuts.empty()) cuts.push_back(std::min(std::max(1, n / 2), n - 1));
+    const int nparts = (int)cuts.size() + 1;
+    // part index of every pose (-1 = separator)
+    std::vector<int> part(n, 0);
+    {
+      size_t ci = 0;
+      for (int i = 0; i < n; i++) {
+        while (ci < cuts.size() && i > cuts[ci]) ci++;
+        part[i] = (ci < cuts.size() && i == cuts[ci]) ? -1 : (int)ci;
+      }
+    }
     for (auto& e : cross)
-      if (e.first < m && e.second > m) in_sep[e.second] = 1;
-    std::vector<int> lposes, rposes, lplanes, rplanes, sep_planes, sep_poses;
+      if (part[e.first] != part[e.second] && part[e.first] >= 0 && part[e.second] >= 0) part[e.second] = -1;
+    std::vector<std::vector<int>> pposes(nparts), pplanes(nparts);
+    std::vector<int> sep_planes, sep_poses;
     for (int i = 0; i < n; i++) {
-      if (in_sep[i]) sep_poses.push_back(poses[i]);
-      else if (i < m) lposes.push_back(poses[i]);
-      else rposes.push_back(poses[i]);
+      if (part[i] < 0) sep_poses.push_back(poses[i]);
+      else pposes[part[i]].push_back(poses[i]);
     }
     for (size_t k = 0; k < planes.size(); k++) {
       const int pl = planes[k];
-      // which sides still hold an observer once the separator poses are gone?
-      bool has_l = false, has_r = false;
+      // which parts still hold an observer once the separator poses are gone?
+      int seen = -1; bool multi = false;
       for (int q = adj_off[pl]; q < adj_off[pl + 1]; q++) {
         const int li = lidx[adj[q]];
-        if (li < 0 || in_sep[li]) continue;
-        if (li < m) has_l = true; else has_r = true;
+        if (li < 0 || part[li] < 0) continue;
+        if (seen < 0) seen = part[li];
+        else if (seen != part[li]) { multi = true; break; }
       }
-      if (has_l && has_r) sep_planes.push_back(pl);
-      else if (has_l) lplanes.push_back(pl);
-      else if (has_r) rplanes.push_back(pl);
-      else sep_planes.push_back(pl);   // attached to separator poses (or ancestors) only
+      if (multi || seen < 0) sep_planes.push_back(pl);   // spans a cut, or attached to separator poses (or ancestors) only
+      else pplanes[seen].push_back(pl);
     }
     for (int i = 0; i < n; i++) lidx[poses[i]] = -1;
     for (int pl : sep_planes) tree[t].piv.push_back(pl);
     for (int po : sep_poses) tree[t].piv.push_back(po);
-    if (!lposes.empty()) { const int c = dissect(std::move(lposes), std::move(lplanes)); tree[t].kids.push_back(c); }
-    if (!rposes.empty()) { const int c = dissect(std::move(rposes), std::move(rplanes)); tree[t].kids.push_back(c); }
+    for (int q = 0; q < nparts; q++)
+      if (!pposes[q].empty()) { const int c = dissect(std::move(pposes[q]), std::move(pplanes[q])); tree[t].kids.push_back(c); }
     return t;
   }
 };

@@ -29,6 +29,7 @@ struct SymFactor { int type; int a, b; int joff; };       // compact node ids (b
 
 struct AnalysisParams {
   int leaf_poses = 4;      // a sub-chain with <= leaf_poses poses becomes one leaf front
+  int arity = 2;           // sub-chains per dissection step (2 = bisection; 4 = three cut poses form ONE separator front)
   int max_pivots = 48;     // split supernodes with more pivot scalars into a chain
   int seg_len = 32;        // contributions reduced per wave in the H-block kernel
   int band_levels = 3;     // tree levels walked by one workgroup inside one launch ("band")
