@@ -199,6 +199,10 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
 /* any output may be NULL: planes (n+1)x4 sensor-frame, cloud width*height pps_point, depth width*height,
  * plane_id width*height (-1 = none) */
 int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* depth, int32_t* plane_id);
+/* ground_seg3d_lines_world of the last run (popup_plane.cpp:569-578): n x 6 = (x0,y0,0,x1,y1,0), the
+ * world-frame ground end points of every segment -- columns 0,1 of all_3d_bound_polygons_world (:494-495),
+ * which data association compares (Mapping.cpp:355-360). */
+int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world);
 /* device time of the last pps_popup_run kernel (HIP events), seconds */
 int pps_popup_last_kernel_time(const pps_popup* p, double* sec);
 
@@ -212,6 +216,32 @@ int pps_frames_add(pps_graph* g, int pose_id, int n_seg, const float* seg2d, con
 int pps_refresh_measurements(pps_graph* g);
 /* read back a plane factor's current measurement (FactorT::measurement(), Factor.h:203) */
 int pps_get_measurement(pps_graph* g, int fid, double meas4[4]);
+
+/* ---- plane data association: Mapper_mono::findClosestPlane (src/Mapping.cpp:256-397) ------------
+ * The handle keeps one record per landmark (what findClosestPlane reads of a Map_plane, Map_plane.h:28-44);
+ * the landmark's plane itself is read from the solver state on the device.  Landmark order (= tie-break
+ * order, = all_landmarks index) is the order of first registration. */
+typedef struct pps_assoc_params {   /* Mapping.h:70-77; tum yaml: 10000, 2, -1, 35, 1000 */
+  double edge_asso_2ddist;          /* 50   mean 2-D end-point distance gate [px] */
+  double edge_asso_planedist;       /* 4    plane distance gate [m] */
+  double edge_asso_proj;            /* 0.5  minimum mutual 1-D overlap of the ground segments */
+  double edge_asso_angle;           /* 60   normal angle gate [deg] */
+  int assoc_near_frames;            /* 5    only landmarks seen within this many frames */
+} pps_assoc_params;
+void pps_assoc_default_params(pps_assoc_params* p);
+/* copy_plane (Map_plane.cpp:11-22) after an observation: (re)write the landmark's latest frame
+ * properties; the first call for a plane id registers it (all_landmarks.push_back, Mapping.cpp:485-488).
+ * seg2d = ground edge end points in the image (u0,v0,u1,v1); seg3d_xy = their world x,y (x0,y0,x1,y1);
+ * both may be NULL for the ground plane. */
+int pps_landmark_update(pps_graph* g, int plane_id, int frame_plane_indice, int frame_seq_id, const float seg2d[4],
+                        const float seg3d_xy[4]);
+int pps_landmark_set_merged(pps_graph* g, int plane_id);      /* deteted_by_merge = true (Mapping.cpp:697) */
+/* n query planes of one frame against all landmarks, one launch.  planes_local n x 4 (sensor frame,
+ * Map_plane::temp_value), est_pose = latest pose (+) odometry (Mapping.cpp:413-416).
+ * best_plane_id[i] = plane node id of the match or -1; best_err[i] = its score (-1: none / ground). */
+int pps_find_closest_planes(pps_graph* g, const double est_pose[7], int frame_seq_id, int n, const double* planes_local,
+                            const int* frame_plane_indice, const float* seg2d, const float* seg3d_xy,
+                            const pps_assoc_params* prm, int* best_plane_id, double* best_err);
 
 #ifdef __cplusplus
 }

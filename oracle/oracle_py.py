@@ -81,6 +81,9 @@ def lib():
             ("ora_pose_oplus", [dp, dp, dp], None),
             ("ora_pose_ominus", [dp, dp, dp], None),
             ("ora_popup_planes", [fp, C.c_int, fp, fp, fp], None),
+            ("ora_popup_planes_ex", [fp, C.c_int, fp, fp, fp, fp], None),
+            ("ora_find_closest_plane", [dp, dp, C.c_int, C.c_int, fp, fp, C.c_void_p, C.c_int, C.c_void_p, ip, dp], None),
+            ("ora_point_proj_to_lineseg", [fp, fp, fp], C.c_float),
             ("ora_popup_cloud", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_float, C.c_float, fp,
                                  C.POINTER(C.c_ubyte)], None),
             ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
@@ -242,6 +245,44 @@ def popup_planes(seg2d, invK, T_wc):
     out = np.zeros((n + 1, 4), dtype=np.float32)
     lib().ora_popup_planes(ps, n, pk, pt, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def popup_planes_ex(seg2d, invK, T_wc):
+    """planes (n+1,4) and ground_seg3d_lines_world (n,6)."""
+    seg, ps = _f(seg2d); n = seg.reshape(-1, 4).shape[0]
+    k, pk = _f(invK); t, pt = _f(T_wc)
+    out = np.zeros((n + 1, 4), dtype=np.float32); s3 = np.zeros((n, 6), dtype=np.float32)
+    lib().ora_popup_planes_ex(ps, n, pk, pt, out.ctypes.data_as(C.POINTER(C.c_float)), s3.ctypes.data_as(C.POINTER(C.c_float)))
+    return out, s3
+
+
+class OraAssocParams(C.Structure):
+    _fields_ = [("edge_asso_2ddist", C.c_double), ("edge_asso_planedist", C.c_double), ("edge_asso_proj", C.c_double),
+                ("edge_asso_angle", C.c_double), ("assoc_near_frames", C.c_int)]
+
+
+class OraLandmark(C.Structure):
+    _fields_ = [("plane", C.c_double * 4), ("frame_plane_indice", C.c_int), ("frame_seq_id", C.c_int), ("deleted", C.c_int),
+                ("seg2d", C.c_float * 4), ("seg3d", C.c_float * 4)]
+
+
+ASSOC_DEFAULT = dict(edge_asso_2ddist=50.0, edge_asso_planedist=4.0, edge_asso_proj=0.5, edge_asso_angle=60.0, assoc_near_frames=5)
+
+
+def find_closest_plane(est_pose, plane_local, fpi, frame_seq_id, seg2d, seg3d, landmarks, **params):
+    """landmarks: list of dicts(plane, fpi, seq, deleted, seg2d, seg3d).  Returns (index or -1, score)."""
+    prm = OraAssocParams(**{**ASSOC_DEFAULT, **params})
+    arr = (OraLandmark * max(1, len(landmarks)))()
+    for i, L in enumerate(landmarks):
+        arr[i].plane[:] = [float(x) for x in L["plane"]]
+        arr[i].frame_plane_indice = int(L["fpi"]); arr[i].frame_seq_id = int(L["seq"]); arr[i].deleted = int(L.get("deleted", 0))
+        arr[i].seg2d[:] = [float(x) for x in L["seg2d"]]; arr[i].seg3d[:] = [float(x) for x in L["seg3d"]]
+    _, pp = _d(est_pose); _, pl = _d(plane_local); s2, p2 = _f(seg2d); s3, p3 = _f(seg3d)
+    best = C.c_int(); err = C.c_double()
+    lib().ora_find_closest_plane(pp, pl, int(fpi), int(frame_seq_id), p2, p3, C.cast(arr, C.c_void_p), len(landmarks),
+                                 C.cast(C.byref(prm), C.c_void_p), C.cast(C.byref(best), C.POINTER(C.c_int)),
+                                 C.cast(C.byref(err), C.POINTER(C.c_double)))
+    return best.value, err.value
 
 
 def popup_cloud(plane_id, invK, T_wc, planes_sensor, depth_thre=10.0, ceiling_thre=2.5):

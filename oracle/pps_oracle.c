@@ -1260,12 +1260,107 @@ void ora_pose_ominus(const double a[7], const double b[7], double out[7]) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* plane data association, src/Mapping.cpp:256-397                             */
+/* ------------------------------------------------------------------------- */
+
+/* Plane3d::normal / d / point0 / distance(point)  (src/isam_plane3d.h:148-171) */
+static double plane_norm3(const double* p) { return sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]); }
+static void plane_normal(const double* p, double n[3]) {
+  const double l = plane_norm3(p);
+  for (int k = 0; k < 3; k++) n[k] = p[k] / l;
+}
+static double plane_d(const double* p) { return -p[3] / plane_norm3(p); }
+static void plane_point0(const double* p, double x[3]) {
+  double n[3]; plane_normal(p, n);
+  const double d = plane_d(p);
+  for (int k = 0; k < 3; k++) x[k] = d * n[k];
+}
+static double plane_distance_to(const double* p, const double pt[3]) {
+  double n[3], x0[3]; plane_normal(p, n); plane_point0(p, x0);
+  return fabs(n[0] * (pt[0] - x0[0]) + n[1] * (pt[1] - x0[1]) + n[2] * (pt[2] - x0[2]));
+}
+static float norm2f(float x, float y) { return sqrtf(x * x + y * y); }
+
+/* Mapping.cpp:112-126: parameter t of the projection of the query on the segment, clamped to [0,1];
+ * a degenerate segment returns the distance to its first point instead (kept as is). */
+float ora_point_proj_to_lineseg(const float b[2], const float e[2], const float q[2]) {
+  const float length = norm2f(e[0] - b[0], e[1] - b[1]);
+  if (length < 0.001) return norm2f(q[0] - b[0], q[1] - b[1]);
+  const float t = ((q[0] - b[0]) * (e[0] - b[0]) + (q[1] - b[1]) * (e[1] - b[1])) / length / length;
+  if (t > 1.0) return 1.0f;
+  if (t < 0.0) return 0.0f;
+  return t;
+}
+
+void ora_find_closest_plane(const double est_pose[7], const double plane_local[4], int fpi, int frame_seq_id,
+                            const float seg2d[4], const float seg3d[4], const ora_landmark* lm, int n_lm,
+                            const ora_assoc_params* prm, int* best, double* best_err) {
+  int numMatches = 0, bestMatch = -1;
+  double bestReprojError = -1;
+  pose_t pose; pose_from_tq(est_pose, &pose);
+  plane_t cur_local, cur_world;
+  memcpy(cur_local.p, plane_local, 32);
+  plane_transform_from(&cur_local, &pose, &cur_world);                       /* :264 */
+  double n_cur[3]; plane_normal(cur_world.p, n_cur);
+  for (int c = 0; c < n_lm; c++) {
+    const ora_landmark* L = &lm[c];
+    if (L->deleted) continue;                                                 /* :275 */
+    if (fpi == 0 && L->frame_plane_indice == 0) { numMatches++; bestMatch = c; break; }   /* :277-281 */
+    if ((fpi == 0 && L->frame_plane_indice >= 1) || (fpi >= 1 && L->frame_plane_indice == 0)) continue;  /* :282-284 */
+    plane_t old_world, old_local;
+    memcpy(old_world.p, L->plane, 32);
+    plane_transform_to(&old_world, &pose, &old_local);                        /* :291 */
+    if (frame_seq_id - L->frame_seq_id > prm->assoc_near_frames) continue;    /* :295 */
+    double n_old[3]; plane_normal(old_world.p, n_old);
+    const double angle = acos(n_cur[0] * n_old[0] + n_cur[1] * n_old[1] + n_cur[2] * n_old[2]) * 180.0 / PI_;  /* :298 */
+    if (angle > prm->edge_asso_angle) continue;                               /* :304 */
+    double thre2d = prm->edge_asso_2ddist, thre_cov = prm->edge_asso_proj;
+    if (angle < 25.0) {                                                       /* :309-315 */
+      thre_cov = prm->edge_asso_proj / 3;
+      thre2d = prm->edge_asso_2ddist * 1.5;
+      if (angle <= 10.0) thre_cov = prm->edge_asso_proj / 2;
+    }
+    double x0[3]; plane_point0(old_local.p, x0);
+    const double plane_dist = plane_distance_to(cur_local.p, x0);             /* :318 */
+    if (plane_dist > prm->edge_asso_planedist) continue;                      /* :324 */
+    if (plane_dist < 1.5) thre_cov = thre_cov / 2;                            /* :326 */
+    float d2 = 0, d2c = 0;                                                     /* :330-346, fp32 */
+    for (int i = 0; i < 2; i++) {
+      const float a = norm2f(seg2d[2 * i] - L->seg2d[0], seg2d[2 * i + 1] - L->seg2d[1]);
+      const float b = norm2f(seg2d[2 * i] - L->seg2d[2], seg2d[2 * i + 1] - L->seg2d[3]);
+      d2 += (a < b ? a : b);
+    }
+    d2 = d2 / 2;
+    for (int i = 0; i < 2; i++) {
+      const float a = norm2f(seg2d[0] - L->seg2d[2 * i], seg2d[1] - L->seg2d[2 * i + 1]);
+      const float b = norm2f(seg2d[2] - L->seg2d[2 * i], seg2d[3] - L->seg2d[2 * i + 1]);
+      d2c += (a < b ? a : b);
+    }
+    d2c = d2c / 2;
+    if (d2 > thre2d || d2c > thre2d) continue;                                /* :350 */
+    const float o_bg = ora_point_proj_to_lineseg(seg3d, seg3d + 2, L->seg3d);           /* :355-360 */
+    const float o_ed = ora_point_proj_to_lineseg(seg3d, seg3d + 2, L->seg3d + 2);
+    const float cov_on = fabsf(o_bg - o_ed);
+    const float n_bg = ora_point_proj_to_lineseg(L->seg3d, L->seg3d + 2, seg3d);
+    const float n_ed = ora_point_proj_to_lineseg(L->seg3d, L->seg3d + 2, seg3d + 2);
+    const float cov_no = fabsf(n_bg - n_ed);
+    if (cov_on < thre_cov || cov_no < thre_cov) continue;                     /* :364 */
+    numMatches++;
+    double total = angle / prm->edge_asso_angle * 3 + (1 - cov_on) + (1 - cov_no);      /* :368 */
+    total += (d2 > d2c ? d2 : d2c) / thre2d + plane_dist / 4;                             /* :369 */
+    if (numMatches == 1 || total < bestReprojError) { bestMatch = c; bestReprojError = total; }   /* :374-377 */
+  }
+  *best = bestMatch;
+  *best_err = bestReprojError;
+}
+
+/* ------------------------------------------------------------------------- */
 /* pop-up (fp32), /root/reference/pop_up_wall                                  */
 /* ------------------------------------------------------------------------- */
 
 /* popup_plane::update_plane_equation_from_seg (libs/popup_plane.cpp:654-705),
  * ray_plane_interact (libs/matrix_utils.cpp:189-193) */
-void ora_popup_planes(const float* seg2d, int n, const float invK[9], const float T[16], float* out) {
+void ora_popup_planes_ex(const float* seg2d, int n, const float invK[9], const float T[16], float* out, float* seg3d_world) {
   if (n <= 0) return;
   /* ground_plane_sensor = T^T * (0,0,-1,0) */
   float gs[4];
@@ -1283,6 +1378,10 @@ void ora_popup_planes(const float* seg2d, int n, const float invK[9], const floa
       for (int i = 0; i < 4; i++) Ph[i] = T[i * 4 + 0] * Ps[0] + T[i * 4 + 1] * Ps[1] + T[i * 4 + 2] * Ps[2] + T[i * 4 + 3] * Ps[3];
       for (int i = 0; i < 3; i++) Pw[e][i] = Ph[i] / Ph[3];   /* homo_to_real_coord */
     }
+    Pw[0][2] = 0.f; Pw[1][2] = 0.f;   /* "make it exact zero", popup_plane.cpp:575-578 */
+    if (seg3d_world)                  /* ground_seg3d_lines_world row (x0,y0,0,x1,y1,0) */
+      for (int e = 0; e < 2; e++)
+        for (int i = 0; i < 3; i++) seg3d_world[sgi * 6 + 3 * e + i] = Pw[e][i];
     float t1[3] = {Pw[1][0] - Pw[0][0], Pw[1][1] - Pw[0][1], Pw[1][2] - Pw[0][2]};
     float t2[3] = {0.f, 0.f, -1.f};
     float nw[3] = {t1[1] * t2[2] - t1[2] * t2[1], t1[2] * t2[0] - t1[0] * t2[2], t1[0] * t2[1] - t1[1] * t2[0]};
@@ -1291,6 +1390,9 @@ void ora_popup_planes(const float* seg2d, int n, const float invK[9], const floa
     for (int k = 0; k < 4; k++)
       out[(sgi + 1) * 4 + k] = T[0 * 4 + k] * pw[0] + T[1 * 4 + k] * pw[1] + T[2 * 4 + k] * pw[2] + T[3 * 4 + k] * pw[3];
   }
+}
+void ora_popup_planes(const float* seg2d, int n, const float invK[9], const float T[16], float* out) {
+  ora_popup_planes_ex(seg2d, n, invK, T, out, NULL);
 }
 
 /* generate_cloud per-pixel math + matrixToCloud filters (libs/popup_plane.cpp:826-831, 948-960) */

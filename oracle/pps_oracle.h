@@ -99,10 +99,33 @@ void ora_pose_from_vector(const double v6[6], double tq[7]);                    
 void ora_pose_oplus(const double a[7], const double d[7], double out[7]);                /* Pose3d.h:222-224 */
 void ora_pose_ominus(const double a[7], const double b[7], double out[7]);               /* Pose3d.h:233-235 */
 
+/* ---- plane data association: Mapper_mono::findClosestPlane (src/Mapping.cpp:256-397) ---------- */
+typedef struct ora_assoc_params {   /* Mapping.h:70-77 defaults: 50, 4, 0.5, 60, 5 */
+  double edge_asso_2ddist, edge_asso_planedist, edge_asso_proj, edge_asso_angle;
+  int assoc_near_frames;
+} ora_assoc_params;
+typedef struct ora_landmark {       /* what findClosestPlane reads of a Map_plane (Map_plane.h:28-44) */
+  double plane[4];                  /* plane_vertex->value(), world frame */
+  int frame_plane_indice;           /* 0 = ground, >= 1 wall */
+  int frame_seq_id;
+  int deleted;                      /* deteted_by_merge */
+  float seg2d[4];                   /* plane_bound_close_2D_polys columns 0,1 (u0,v0,u1,v1) */
+  float seg3d[4];                   /* plane_bound_close_3D_polys columns 0,1, x and y only (x0,y0,x1,y1) */
+} ora_landmark;
+/* best = index into lm[] or -1; best_err = bestReprojError (-1 when nothing scored / ground short-cut) */
+void ora_find_closest_plane(const double est_pose[7], const double plane_local[4], int frame_plane_indice,
+                            int frame_seq_id, const float seg2d[4], const float seg3d[4], const ora_landmark* lm,
+                            int n_lm, const ora_assoc_params* prm, int* best, double* best_err);
+/* Mapping.cpp:112-126 */
+float ora_point_proj_to_lineseg(const float begin_pt[2], const float end_pt[2], const float query_pt[2]);
+
 /* pop-up (fp32) restatement: pop_up_wall/libs/popup_plane.cpp:654-705.
  * seg2d: n x 4 (u1 v1 u2 v2) row-major, invK 3x3 row-major, T_wc 4x4 row-major.
  * planes_out: (n+1) x 4, row 0 = ground plane in the sensor frame. */
 void ora_popup_planes(const float* seg2d, int n, const float invK[9], const float T_wc[16], float* planes_out);
+/* same, also returning ground_seg3d_lines_world (n x 6: x0,y0,0,x1,y1,0; popup_plane.cpp:569-578) */
+void ora_popup_planes_ex(const float* seg2d, int n, const float invK[9], const float T_wc[16], float* planes_out,
+                         float* seg3d_world);
 /* per-pixel pop-up: generate_cloud + matrixToCloud (popup_plane.cpp:807-863,925-985) given a
  * per-pixel plane-id mask (-1 = none).  xyz_out: 3 floats per pixel (world), valid_out: 1 = kept. */
 void ora_popup_cloud(const int* plane_id, int width, int height, const float invK[9], const float T_wc[16],

@@ -60,6 +60,12 @@ class PpsError(RuntimeError):
 _LIB = None
 
 # every symbol include/pps.h declares (checked by tests/test_cabi.py)
+class PpsAssocParams(C.Structure):
+    """pps_assoc_params (include/pps.h); defaults = Mapping.h:70-77 via pps_assoc_default_params."""
+    _fields_ = [("edge_asso_2ddist", C.c_double), ("edge_asso_planedist", C.c_double), ("edge_asso_proj", C.c_double),
+                ("edge_asso_angle", C.c_double), ("assoc_near_frames", C.c_int)]
+
+
 SYMBOLS = [
     "pps_default_props", "pps_version", "pps_last_error", "pps_graph_create", "pps_graph_destroy",
     "pps_get_props", "pps_set_props", "pps_add_pose", "pps_add_plane", "pps_add_pose_prior",
@@ -72,6 +78,8 @@ SYMBOLS = [
     "pps_popup_planes", "pps_popup_create", "pps_popup_destroy", "pps_popup_last_error", "pps_popup_set_image",
     "pps_popup_run", "pps_popup_download", "pps_popup_last_kernel_time",
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
+    "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
+    "pps_find_closest_planes",
 ]
 
 
@@ -138,6 +146,12 @@ def lib():
         L.pps_frames_add.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _ip, _ip]
         L.pps_refresh_measurements.argtypes = [C.c_void_p]
         L.pps_get_measurement.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.pps_popup_download_segments3d.argtypes = [C.c_void_p, _fp]
+        L.pps_assoc_default_params.argtypes = [C.POINTER(PpsAssocParams)]
+        L.pps_assoc_default_params.restype = None
+        L.pps_landmark_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _fp]
+        L.pps_landmark_set_merged.argtypes = [C.c_void_p, C.c_int]
+        L.pps_find_closest_planes.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _ip, _fp, _fp, C.POINTER(PpsAssocParams), _ip, _dp]
         _LIB = L
     return _LIB
 
@@ -292,6 +306,33 @@ class Graph:
     def get_measurement(self, fid):
         out = np.zeros(4); self._ck(self.L.pps_get_measurement(self.h, fid, out.ctypes.data_as(_dp))); return out
 
+    # ---- data association (Mapper_mono::findClosestPlane) ----
+    def landmark_update(self, plane_id, frame_plane_indice, frame_seq_id, seg2d=None, seg3d_xy=None):
+        s2 = None if seg2d is None else np.ascontiguousarray(seg2d, dtype=np.float32).reshape(4)
+        s3 = None if seg3d_xy is None else np.ascontiguousarray(seg3d_xy, dtype=np.float32).reshape(4)
+        self._ck(self.L.pps_landmark_update(self.h, int(plane_id), int(frame_plane_indice), int(frame_seq_id),
+                                            None if s2 is None else s2.ctypes.data_as(_fp),
+                                            None if s3 is None else s3.ctypes.data_as(_fp)))
+
+    def landmark_set_merged(self, plane_id):
+        self._ck(self.L.pps_landmark_set_merged(self.h, int(plane_id)))
+
+    def find_closest_planes(self, est_pose, frame_seq_id, planes_local, frame_plane_indice, seg2d, seg3d_xy, **params):
+        """One launch for all query planes of a frame.  Returns (plane ids or -1, scores)."""
+        prm = PpsAssocParams(); self.L.pps_assoc_default_params(C.byref(prm))
+        for k, v in params.items():
+            setattr(prm, k, v)
+        pl = np.ascontiguousarray(planes_local, dtype=np.float64).reshape(-1, 4); n = len(pl)
+        fpi = np.ascontiguousarray(frame_plane_indice, dtype=np.int32).reshape(n)
+        s2 = np.ascontiguousarray(seg2d, dtype=np.float32).reshape(n, 4)
+        s3 = np.ascontiguousarray(seg3d_xy, dtype=np.float32).reshape(n, 4)
+        pose = np.ascontiguousarray(est_pose, dtype=np.float64).reshape(7)
+        best = np.full(n, -1, dtype=np.int32); err = np.full(n, -1.0)
+        self._ck(self.L.pps_find_closest_planes(self.h, pose.ctypes.data_as(_dp), int(frame_seq_id), n, pl.ctypes.data_as(_dp),
+                                                fpi.ctypes.data_as(_ip), s2.ctypes.data_as(_fp), s3.ctypes.data_as(_fp),
+                                                C.byref(prm), best.ctypes.data_as(_ip), err.ctypes.data_as(_dp)))
+        return best, err
+
     def save_state(self):
         self._ck(self.L.pps_save_state(self.h))
 
@@ -443,6 +484,12 @@ class Popup:
         self._ck(self.L.pps_popup_download(self.h, planes.ctypes.data_as(_fp), cloud.ctypes.data_as(C.c_void_p),
                                            depth.ctypes.data_as(_fp), pid.ctypes.data_as(C.POINTER(C.c_int32))))
         return planes, cloud.reshape(self.h_, self.w), depth, pid
+
+    def segments3d(self):
+        """ground_seg3d_lines_world of the last run: (n,6) world ground end points."""
+        out = np.zeros((self.n, 6), dtype=np.float32)
+        self._ck(self.L.pps_popup_download_segments3d(self.h, out.ctypes.data_as(_fp)))
+        return out
 
     def last_kernel_time(self):
         s = C.c_double(); self._ck(self.L.pps_popup_last_kernel_time(self.h, C.byref(s))); return s.value

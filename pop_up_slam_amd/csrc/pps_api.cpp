@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pps.h"
@@ -102,6 +103,15 @@ struct pps_graph {
   int *d_item_frame = nullptr, *d_item_plane = nullptr, *d_item_slot = nullptr, *d_frame_pose_slot = nullptr, *d_frame_seg_off = nullptr;
   float* d_fr_seg = nullptr;
   bool dev_meas_newer = false;       // device edge measurements are newer than the host copies
+  // landmark records for data association (pps_landmark_update / pps_find_closest_planes)
+  struct Landmark { int plane_id, fpi, seq, deleted; float seg2d[4], seg3d[4]; };
+  std::vector<Landmark> lms;
+  std::unordered_map<int, int> lm_of_plane;
+  bool lms_dirty = true;
+  int lms_upload_version = -1;       // upload_version the slots of d_lms were resolved against
+  pps::AssocLandmark* d_lms = nullptr; size_t d_lms_cap = 0;
+  pps::AssocQuery* d_queries = nullptr; pps::AssocResult* d_results = nullptr; size_t d_q_cap = 0;
+  double* d_lm_planes = nullptr; size_t d_lm_planes_cap = 0;   // [4][n] landmark planes when the solver state is not current
   // stats / trace
   pps_stats stats{};
   std::vector<double> tr_lambda, tr_chi2;
@@ -675,6 +685,10 @@ int pps_graph_destroy(pps_graph* g) {
     if (g->ev[1]) (void)hipEventDestroy(g->ev[1]);
     for (hipEvent_t e : g->k1_events) (void)hipEventDestroy(e);
     if (g->stream_b) { (void)hipStreamSynchronize(g->stream_b); (void)hipStreamDestroy(g->stream_b); }
+    if (g->d_lms) (void)hipFree(g->d_lms);
+    if (g->d_queries) (void)hipFree(g->d_queries);
+    if (g->d_results) (void)hipFree(g->d_results);
+    if (g->d_lm_planes) (void)hipFree(g->d_lm_planes);
     if (g->ev_h_ready) (void)hipEventDestroy(g->ev_h_ready);
     if (g->ev_spec_done) (void)hipEventDestroy(g->ev_spec_done);
     (void)hipStreamDestroy(g->stream);
@@ -1257,6 +1271,125 @@ int pps_get_measurement(pps_graph* g, int fid, double meas4[4]) {
   if (f.type != F_PLANE_OBS && f.type != F_PLANE_PRIOR) return fail(g, PPS_EINVAL, "get_measurement: not a plane factor");
   if (g->dev_meas_newer) { int rc = download_measurements(g); if (rc != PPS_OK) return rc; }
   memcpy(meas4, f.meas, 4 * sizeof(double));
+  return PPS_OK;
+}
+
+
+// ---- plane data association (Mapper_mono::findClosestPlane, src/Mapping.cpp:256-397) ----
+
+void pps_assoc_default_params(pps_assoc_params* p) {
+  if (!p) return;
+  p->edge_asso_2ddist = 50; p->edge_asso_planedist = 4; p->edge_asso_proj = 0.5; p->edge_asso_angle = 60.0;   // Mapping.h:72-76
+  p->assoc_near_frames = 5;
+}
+
+int pps_landmark_update(pps_graph* g, int plane_id, int frame_plane_indice, int frame_seq_id, const float seg2d[4],
+                        const float seg3d_xy[4]) {
+  if (!g) return PPS_EINVAL;
+  if (!live_node(g, plane_id, NODE_PLANE)) return fail(g, PPS_EINVAL, "landmark_update: unknown plane id");
+  auto it = g->lm_of_plane.find(plane_id);
+  int idx;
+  if (it == g->lm_of_plane.end()) {
+    idx = (int)g->lms.size();
+    g->lms.push_back(pps_graph::Landmark{plane_id, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}});
+    g->lm_of_plane[plane_id] = idx;
+  } else idx = it->second;
+  pps_graph::Landmark& L = g->lms[idx];
+  L.fpi = frame_plane_indice; L.seq = frame_seq_id;
+  for (int k = 0; k < 4; k++) { L.seg2d[k] = seg2d ? seg2d[k] : 0.f; L.seg3d[k] = seg3d_xy ? seg3d_xy[k] : 0.f; }
+  g->lms_dirty = true;
+  return PPS_OK;
+}
+
+int pps_landmark_set_merged(pps_graph* g, int plane_id) {
+  if (!g) return PPS_EINVAL;
+  auto it = g->lm_of_plane.find(plane_id);
+  if (it == g->lm_of_plane.end()) return fail(g, PPS_EINVAL, "landmark_set_merged: plane id is not a landmark");
+  g->lms[it->second].deleted = 1;
+  g->lms_dirty = true;
+  return PPS_OK;
+}
+
+int pps_find_closest_planes(pps_graph* g, const double est_pose[7], int frame_seq_id, int n, const double* planes_local,
+                            const int* frame_plane_indice, const float* seg2d, const float* seg3d_xy,
+                            const pps_assoc_params* prm, int* best_plane_id, double* best_err) {
+  if (!g || !est_pose || n < 0 || (n > 0 && (!planes_local || !frame_plane_indice || !seg2d || !seg3d_xy)) || !best_plane_id || !best_err)
+    return PPS_EINVAL;
+  pps_assoc_params P;
+  if (prm) P = *prm; else pps_assoc_default_params(&P);
+  if (n == 0) return PPS_OK;
+  const int nl = (int)g->lms.size();
+  if (nl == 0) { for (int i = 0; i < n; i++) { best_plane_id[i] = -1; best_err[i] = -1.0; } return PPS_OK; }
+  int rc = ensure_device(g);
+  if (rc != PPS_OK) return rc;
+  HIP_TRY(g, hipSetDevice(g->props.device));
+  // landmark planes: straight from the solver state when it is current, else a packed copy of the host values
+  const bool state_current = g->dev_ready && !g->topo_dirty && !g->host_values_newer && g->dev.n_plane > 0;
+  AssocArgs a{};
+  if (!state_current) {
+    if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
+    if ((size_t)nl > g->d_lm_planes_cap) {
+      if (g->d_lm_planes) (void)hipFree(g->d_lm_planes);
+      g->d_lm_planes_cap = std::max<size_t>(256, 2 * (size_t)nl);
+      HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->d_lm_planes), 4 * g->d_lm_planes_cap * sizeof(double)));
+    }
+    std::vector<double> pl(4 * (size_t)nl, 0.0);
+    for (int i = 0; i < nl; i++) {
+      const HostNode& nd = g->nodes[g->lms[i].plane_id];
+      for (int k = 0; k < 4; k++) pl[(size_t)k * nl + i] = nd.v[k];
+    }
+    HIP_TRY(g, hipMemcpyAsync(g->d_lm_planes, pl.data(), pl.size() * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));   // `pl` leaves scope
+    a.plane_est = g->d_lm_planes; a.plane_ld = nl;
+  } else {
+    a.plane_est = g->dev.plane_est; a.plane_ld = g->dev.plane_ld;
+  }
+  if (g->lms_dirty || g->lms_upload_version != (state_current ? g->upload_version : -2)) {
+    if ((size_t)nl > g->d_lms_cap) {
+      if (g->d_lms) (void)hipFree(g->d_lms);
+      g->d_lms_cap = std::max<size_t>(256, 2 * (size_t)nl);
+      HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->d_lms), g->d_lms_cap * sizeof(AssocLandmark)));
+    }
+    std::vector<AssocLandmark> rec(nl);
+    for (int i = 0; i < nl; i++) {
+      const pps_graph::Landmark& L = g->lms[i];
+      const HostNode& nd = g->nodes[L.plane_id];
+      rec[i].plane_slot = nd.deleted ? -1 : (state_current ? nd.slot : i);
+      rec[i].frame_plane_indice = L.fpi; rec[i].frame_seq_id = L.seq; rec[i].deleted = L.deleted;
+      memcpy(rec[i].seg2d, L.seg2d, sizeof L.seg2d); memcpy(rec[i].seg3d, L.seg3d, sizeof L.seg3d);
+    }
+    HIP_TRY(g, hipMemcpyAsync(g->d_lms, rec.data(), rec.size() * sizeof(AssocLandmark), hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    g->lms_dirty = false;
+    g->lms_upload_version = state_current ? g->upload_version : -2;
+  }
+  if ((size_t)n > g->d_q_cap) {
+    if (g->d_queries) (void)hipFree(g->d_queries);
+    if (g->d_results) (void)hipFree(g->d_results);
+    g->d_q_cap = std::max<size_t>(64, 2 * (size_t)n);
+    HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->d_queries), g->d_q_cap * sizeof(AssocQuery)));
+    HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->d_results), g->d_q_cap * sizeof(AssocResult)));
+  }
+  std::vector<AssocQuery> q(n);
+  for (int i = 0; i < n; i++) {
+    memcpy(q[i].plane_local, planes_local + 4 * i, 4 * sizeof(double));
+    memcpy(q[i].seg2d, seg2d + 4 * i, 4 * sizeof(float)); memcpy(q[i].seg3d, seg3d_xy + 4 * i, 4 * sizeof(float));
+    q[i].frame_plane_indice = frame_plane_indice[i]; q[i].frame_seq_id = frame_seq_id;
+    memset(q[i].pad, 0, sizeof q[i].pad);
+  }
+  HIP_TRY(g, hipMemcpyAsync(g->d_queries, q.data(), q.size() * sizeof(AssocQuery), hipMemcpyHostToDevice, g->stream));
+  a.n_queries = n; a.n_landmarks = nl; a.queries = g->d_queries; a.landmarks = g->d_lms; a.results = g->d_results;
+  memcpy(a.pose, est_pose, sizeof a.pose);
+  a.edge_asso_2ddist = P.edge_asso_2ddist; a.edge_asso_planedist = P.edge_asso_planedist;
+  a.edge_asso_proj = P.edge_asso_proj; a.edge_asso_angle = P.edge_asso_angle; a.assoc_near_frames = P.assoc_near_frames;
+  HIP_TRY(g, launch_assoc(a, g->stream));
+  std::vector<AssocResult> r(n);
+  HIP_TRY(g, hipMemcpyAsync(r.data(), g->d_results, r.size() * sizeof(AssocResult), hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  for (int i = 0; i < n; i++) {
+    best_plane_id[i] = r[i].best >= 0 ? g->lms[r[i].best].plane_id : -1;
+    best_err[i] = r[i].err;
+  }
   return PPS_OK;
 }
 

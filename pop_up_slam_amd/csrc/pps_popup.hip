@@ -28,7 +28,7 @@ constexpr int kMaxVerts = 512;
 
 // one wall plane from a ground segment; exact operation order of the reference (and of the oracle)
 __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
-                                             const float gs[4], float out[4]) {
+                                             const float gs[4], float out[4], float* __restrict__ seg3d_world = nullptr) {
   float Pw[2][3];
 #pragma unroll
   for (int e = 0; e < 2; e++) {
@@ -43,6 +43,10 @@ __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, cons
     for (int i = 0; i < 4; i++) Ph[i] = T[i * 4 + 0] * Ps[0] + T[i * 4 + 1] * Ps[1] + T[i * 4 + 2] * Ps[2] + T[i * 4 + 3] * Ps[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pw[e][i] = Ph[i] / Ph[3];
+  }
+  if (seg3d_world) {   // ground_seg3d_lines_world row, z forced to exact zero (popup_plane.cpp:569-578)
+    seg3d_world[0] = Pw[0][0]; seg3d_world[1] = Pw[0][1]; seg3d_world[2] = 0.f;
+    seg3d_world[3] = Pw[1][0]; seg3d_world[4] = Pw[1][1]; seg3d_world[5] = 0.f;
   }
   const float t1[3] = {Pw[1][0] - Pw[0][0], Pw[1][1] - Pw[0][1], Pw[1][2] - Pw[0][2]};
   const float t2[3] = {0.f, 0.f, -1.f};
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
     float gs[4], pl[4];
     ground_plane_sensor(prm.T, gs);
     if (tid == 0) { pl[0] = gs[0]; pl[1] = gs[1]; pl[2] = gs[2]; pl[3] = gs[3]; }
-    else seg_to_plane(seg2d + 4 * (tid - 1), prm.invK, prm.T, gs, pl);
+    else seg_to_plane(seg2d + 4 * (tid - 1), prm.invK, prm.T, gs, pl,
+                      (blockIdx.x == 0 && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * (tid - 1) : nullptr);
 #pragma unroll
     for (int k = 0; k < 4; k++) s_planes[tid][k] = pl[k];
     if (blockIdx.x == 0 && planes_out) {
@@ -240,7 +245,7 @@ struct pps_popup {
   pps_point* d_cloud = nullptr;
   float* d_depth = nullptr;
   int* d_pid = nullptr;
-  float* d_planes = nullptr;   // (kMaxPlanes+1) x 4
+  float* d_planes = nullptr;   // (kMaxPlanes+1) x 4 plane equations, then kMaxPlanes x 6 world ground segments
   float* d_seg = nullptr;      // kMaxPlanes x 4
   float* d_polys = nullptr;    // 2*kMaxVerts
   int* d_off = nullptr;        // kMaxPlanes+2
@@ -293,7 +298,7 @@ int pps_popup_create(int device, int width, int height, const float invK[9], pps
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_cloud), npx * sizeof(pps_point));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_depth), npx * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_pid), npx * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * 4 * (kMaxPlanes + 1));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * (4 * (kMaxPlanes + 1) + 6 * kMaxPlanes));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_seg), sizeof(float) * 4 * kMaxPlanes);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_polys), sizeof(float) * 2 * kMaxVerts);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_off), sizeof(int) * (kMaxPlanes + 2));
@@ -371,6 +376,14 @@ int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* dep
   if (cloud) PHIP(p, hipMemcpy(cloud, p->d_cloud, npx * sizeof(pps_point), hipMemcpyDeviceToHost));
   if (depth) PHIP(p, hipMemcpy(depth, p->d_depth, npx * sizeof(float), hipMemcpyDeviceToHost));
   if (plane_id) PHIP(p, hipMemcpy(plane_id, p->d_pid, npx * sizeof(int), hipMemcpyDeviceToHost));
+  return PPS_OK;
+}
+
+int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world) {
+  if (!p || !seg3d_world) return PPS_EINVAL;
+  PHIP(p, hipSetDevice(p->device));
+  if (p->last_n > 0)
+    PHIP(p, hipMemcpy(seg3d_world, p->d_planes + 4 * (kMaxPlanes + 1), sizeof(float) * 6 * (size_t)p->last_n, hipMemcpyDeviceToHost));
   return PPS_OK;
 }
 

@@ -28,3 +28,38 @@ struct RefreshArgs {
 hipError_t launch_refresh_measurements(const RefreshArgs& a, hipStream_t st);
 
 }  // namespace pps
+
+namespace pps {
+
+// Mapper_mono::findClosestPlane on the device (src/Mapping.cpp:256-397): one workgroup per query plane,
+// the landmarks are scored in parallel and reduced with the sequential loop's first-wins semantics.
+struct AssocLandmark {       // 48 bytes, one record per all_landmarks entry
+  int plane_slot;            // slot of the landmark's plane node in plane_est (-1: node gone)
+  int frame_plane_indice;    // 0 = ground, >= 1 wall
+  int frame_seq_id;
+  int deleted;               // deteted_by_merge
+  float seg2d[4];            // plane_bound_close_2D_polys columns 0,1
+  float seg3d[4];            // plane_bound_close_3D_polys columns 0,1 (x,y)
+};
+struct AssocQuery {          // 88 bytes
+  double plane_local[4];
+  float seg2d[4];
+  float seg3d[4];
+  int frame_plane_indice;
+  int frame_seq_id;
+  int pad[4];
+};
+struct AssocResult { double err; int best; int n_matches; };
+struct AssocArgs {
+  int n_queries, n_landmarks;
+  const AssocQuery* queries;
+  const AssocLandmark* landmarks;
+  AssocResult* results;
+  double pose[7];
+  double edge_asso_2ddist, edge_asso_planedist, edge_asso_proj, edge_asso_angle;
+  int assoc_near_frames;
+  const double* plane_est; int plane_ld;
+};
+hipError_t launch_assoc(const AssocArgs& a, hipStream_t st);
+
+}  // namespace pps

@@ -7,7 +7,10 @@ Mirrors what the reference does for every keyframe (all citations relative to
   Mapping.cpp:464-530      processFrame: new pose node, odometry factor, new landmarks, plane edges
   Mapping.cpp:551-554      batch_optimization() every 5th frame, update() otherwise
   main_3d.cpp:504, Mapping.cpp:590-607   update_plane_measurement for ALL stored frames -> one K5 launch
-Data association is given (synthetic landmark ids): `findClosestPlane` is out of scope.
+Data association: either given (synthetic landmark ids, `assoc_fn=None`) or computed per frame like
+  Mapping.cpp:256-397,411-458   findClosestPlane for every new plane (one launch on the device for the whole
+                                frame) + the host-side one-to-one resolution, landmark records refreshed by
+                                copy_plane (Mapping.cpp:526).
 
 The same driver runs against the product (pop_up_slam_amd.Graph + Popup, everything numeric on the GPU)
 or against any backend pair with the same surface -- the tests drive the CPU oracle through it.
@@ -94,13 +97,51 @@ class PopupSlamPipeline:
     POSE_UT = synth._ut_diag([0.5] * 6)
     GROUND_UT = synth._ut_diag([20.0] * 3)
 
-    def __init__(self, graph, popup_fn, refresh_fn, pose_oplus, plane_transform_from, pose_vector):
+    def __init__(self, graph, popup_fn, refresh_fn, pose_oplus, plane_transform_from, pose_vector, assoc_fn=None,
+                 landmark_fn=None):
+        """assoc_fn(est_pose, frame_seq_id, planes_local (n,4) f64, fpi (n,), seg2d (n,4) f32, seg3d_xy (n,4) f32)
+        -> (landmark keys or -1, scores); landmark_fn(key, fpi, frame_seq_id, seg2d, seg3d_xy) records copy_plane.
+        With assoc_fn, popup_fn must return (planes, seg3d_world (n,6)) and landmark keys are plane node ids."""
         self.g = graph
         self.popup_fn, self.refresh_fn = popup_fn, refresh_fn
         self.pose_oplus, self.plane_transform_from, self.pose_vector = pose_oplus, plane_transform_from, pose_vector
+        self.assoc_fn, self.landmark_fn = assoc_fn, landmark_fn
         self.pose_nodes, self.landmarks = [], {}
         self.frames = []          # (pose node, seg2d, fids)
+        self.assoc_log = []       # per frame: landmark key chosen for every plane (association mode)
         self.k = 0
+
+    def _associate(self, est, fr, planes, seg3d):
+        """Mapping.cpp:411-458: closest landmark per plane, then force one-to-one matches inside the frame (the
+        longer 2-D ground edge keeps the landmark, the other plane becomes a new one).  Returns per plane either
+        an existing landmark key or ('new', k)."""
+        n = len(planes)
+        pl64 = planes.astype(np.float64)
+        pl64 = pl64 / np.linalg.norm(pl64, axis=1, keepdims=True)           # Map_plane::temp_value = Plane3d(row)
+        fpi = np.arange(n, dtype=np.int32)                                   # frame_plane_indice: 0 = ground
+        seg2d = np.vstack([np.zeros((1, 4), np.float32), fr.seg2d.reshape(-1, 4)])
+        seg3d_xy = np.vstack([np.zeros((1, 4), np.float32), seg3d.reshape(-1, 6)[:, [0, 1, 3, 4]]]).astype(np.float32)
+        ids, errs = self.assoc_fn(est, self.k, pl64, fpi, seg2d, seg3d_xy)
+        assoc, n_new = [None] * n, 0
+        for i in range(n):
+            if ids[i] > -1:
+                conflict = False
+                for j in range(i):
+                    if assoc[j] == ids[i]:
+                        raw_len = np.linalg.norm((seg2d[j, 0:2] - seg2d[j, 2:4]).astype(np.float32))
+                        new_len = np.linalg.norm((seg2d[i, 0:2] - seg2d[i, 2:4]).astype(np.float32))
+                        if new_len > raw_len:
+                            assoc[j] = ("new", n_new); n_new += 1
+                            assoc[i] = ids[i]
+                        else:
+                            assoc[i] = ("new", n_new); n_new += 1
+                        conflict = True
+                        break
+                if not conflict:
+                    assoc[i] = ids[i]
+            else:
+                assoc[i] = ("new", n_new); n_new += 1
+        return assoc, seg2d, seg3d_xy
 
     def process(self, fr: Frame):
         g = self.g
@@ -110,6 +151,11 @@ class PopupSlamPipeline:
             est = fr.odo.copy()
         T32 = synth.T_from_pose(est).astype(np.float32)
         planes = self.popup_fn(fr.seg2d, T32, fr.polys)                          # K5 (+K6)
+        seg3d = None
+        if isinstance(planes, tuple):
+            planes, seg3d = planes
+        if self.assoc_fn is not None:
+            return self._process_associated(fr, est, planes, seg3d)
         if self.pose_nodes:
             p = g.add_pose(est)
             g.add_odometry(self.pose_nodes[-1], p, self.pose_vector(fr.odo), self.POSE_UT)
@@ -139,7 +185,48 @@ class PopupSlamPipeline:
         return it
 
 
-def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, with_image=True, seed=0):
+    def _process_associated(self, fr, est, planes, seg3d):
+        """processFrame with data association (Mapping.cpp:411-554); landmark keys are plane node ids."""
+        g = self.g
+        assoc, seg2d, seg3d_xy = self._associate(est, fr, planes, seg3d)
+        p = g.add_pose(est)
+        if self.pose_nodes:
+            g.add_odometry(self.pose_nodes[-1], p, self.pose_vector(fr.odo), self.POSE_UT)
+        else:
+            g.add_pose_prior(p, self.pose_vector(est), self.POSE_UT)
+        self.pose_nodes.append(p)
+        new_nodes = {}
+        fids, chosen = [], []
+        for j in range(len(planes)):
+            m = planes[j].astype(np.float64)
+            m = m / np.linalg.norm(m)
+            a = assoc[j]
+            if isinstance(a, tuple):                                              # new landmark (:481-505)
+                if a not in new_nodes:
+                    new_nodes[a] = g.add_plane(self.plane_transform_from(m, est))
+                    if j == 0:
+                        g.add_plane_prior(new_nodes[a], synth.GROUND, self.GROUND_UT)
+                node = new_nodes[a]
+            else:
+                node = int(a)
+            sig = synth.plane_sigma(float(fr.dist[j]))
+            fids.append(g.add_plane_obs(p, node, m, synth._ut_diag([1.0 / sig] * 3)))
+            self.landmark_fn(node, j, self.k, seg2d[j], seg3d_xy[j])              # copy_plane (:526)
+            chosen.append(node)
+        self.assoc_log.append(chosen)
+        self.frames.append((p, fr.seg2d, fids))
+        if self.k % 5 == 0:
+            it = g.batch_optimize()
+        else:
+            g.update()
+            it = -1
+        self.refresh_fn(self, p, fr.seg2d, fids)
+        self.k += 1
+        return it
+
+
+def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, with_image=True, seed=0, associate=False,
+                 assoc_params=None):
     """Product pipeline: Graph + Popup on the GPU; pop-up results stay on the device."""
     import pop_up_slam_amd as P
     invK = np.linalg.inv(K).astype(np.float32)
@@ -157,11 +244,22 @@ def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, 
         planes = np.zeros((len(seg) + 1, 4), dtype=np.float32)
         import ctypes as C
         pp._ck(pp.L.pps_popup_download(pp.h, planes.ctypes.data_as(C.POINTER(C.c_float)), None, None, None))
+        if associate:
+            return planes, pp.segments3d()
         return planes
 
     def refresh_fn(pl, pose_node, seg, fids):
         g.frames_add(pose_node, seg, fids)
         g.refresh_measurements()
 
-    pl = PopupSlamPipeline(g, popup_fn, refresh_fn, synth.pose_oplus, synth.plane_transform_from, synth.pose_vector)
+    assoc_fn = landmark_fn = None
+    if associate:
+        prm = dict(assoc_params or {})
+
+        def assoc_fn(est, seq, planes_local, fpi, seg2d, seg3d_xy):
+            return g.find_closest_planes(est, seq, planes_local, fpi, seg2d, seg3d_xy, **prm)
+
+        landmark_fn = g.landmark_update
+    pl = PopupSlamPipeline(g, popup_fn, refresh_fn, synth.pose_oplus, synth.plane_transform_from, synth.pose_vector,
+                           assoc_fn=assoc_fn, landmark_fn=landmark_fn)
     return pl, g, pp, stats

@@ -562,3 +562,73 @@ def corridor_frame(tq, half_width=1.5, near=4.0, far=8.0, width=640, height=480,
     for a, b in ((0, 1), (1, 2), (2, 3)):
         polys.append(np.array([px[a], px[b], [px[b][0], 0.0], [px[a][0], 0.0]], dtype=np.float32))
     return seg, polys, T.astype(np.float32)
+
+
+def assoc_scene(n_landmarks=200, n_queries=8, seed=0, K=K_TUM, near_frames=5):
+    """Synthetic input of Mapper_mono::findClosestPlane (Mapping.cpp:256-397): a landmark table as
+    processFrame leaves it (world plane, ground/wall class, last frame id, last 2-D ground edge, world ground
+    edge) and the planes popped up in one new frame.  Queries are noisy re-observations of stored landmarks
+    (some of them near-duplicates, so several candidates pass the gates), brand-new walls, and the ground.
+    Returns a dict of arrays; `truth[i]` is the landmark index a query was derived from (-1: new wall)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    frame = 50
+    yaw = rng.normal(0.0, 0.2)
+    R = _Rz(yaw) @ CAM_R0
+    t = np.array([rng.normal(0, 0.2), rng.normal(0, 0.2), 1.0])
+    pose = pose_from_Rt(R, t)
+
+    def project(Pxy):
+        pc = R.T @ (np.array([Pxy[0], Pxy[1], 0.0]) - t)
+        uv = K @ (pc / pc[2])
+        return uv[:2]
+
+    def wall_from_edge(p0, p1):
+        # wall normal = (P1-P0) x n_ground, d = -n.P0 (popup_plane.cpp:586-590), stored normalised
+        t1 = np.array([p1[0] - p0[0], p1[1] - p0[1], 0.0])
+        n = np.cross(t1, np.array([0.0, 0.0, -1.0]))
+        pl = np.array([n[0], n[1], n[2], -n @ np.array([p0[0], p0[1], 0.0])])
+        return pl / np.linalg.norm(pl)
+
+    lms = [dict(plane=GROUND.copy(), fpi=0, seq=frame - 1, deleted=0, seg2d=np.zeros(4, np.float32), seg3d=np.zeros(4, np.float32))]
+    fwd = np.array([-np.sin(yaw), np.cos(yaw)])          # camera looks along world +y rotated by yaw
+    left = np.array([-fwd[1], fwd[0]])
+    while len(lms) < n_landmarks:
+        if len(lms) % 7 == 3 and len(lms) > 4:           # near-duplicate of an earlier wall
+            src = lms[int(rng.integers(1, len(lms)))]
+            p0 = src["_p0"] + rng.normal(0, 0.05, 2); p1 = src["_p1"] + rng.normal(0, 0.05, 2)
+        else:
+            c = t[:2] + fwd * rng.uniform(2.5, 9.0) + left * rng.uniform(-3.0, 3.0)
+            ang = yaw + rng.choice([0.0, np.pi / 2]) + rng.normal(0, 0.15)
+            d = np.array([-np.sin(ang), np.cos(ang)]) * rng.uniform(0.4, 1.2)
+            p0, p1 = c - d, c + d
+        pc0 = R.T @ (np.array([p0[0], p0[1], 0.0]) - t); pc1 = R.T @ (np.array([p1[0], p1[1], 0.0]) - t)
+        if pc0[2] < 1.0 or pc1[2] < 1.0:
+            continue
+        seq = frame - 1 - int(rng.integers(0, near_frames + 3))
+        seg2d = np.concatenate([project(p0), project(p1)]) + rng.normal(0, 2.0, 4)
+        lms.append(dict(plane=wall_from_edge(p0, p1), fpi=1 + int(rng.integers(0, 5)), seq=seq, deleted=int(rng.random() < 0.05),
+                        seg2d=seg2d.astype(np.float32), seg3d=np.array([*p0, *p1], dtype=np.float32), _p0=p0, _p1=p1))
+    q_planes, q_fpi, q_seg2d, q_seg3d, truth = [], [], [], [], []
+    for i in range(n_queries):
+        if i == 0:
+            q_planes.append(plane_transform_to(GROUND, pose)); q_fpi.append(0)
+            q_seg2d.append(np.zeros(4)); q_seg3d.append(np.zeros(4)); truth.append(0)
+            continue
+        if i % 4 == 3:                                    # unseen wall far to the side
+            c = t[:2] + fwd * rng.uniform(3, 8) + left * rng.choice([-1, 1]) * rng.uniform(6.0, 9.0)
+            d = fwd * rng.uniform(0.4, 1.0)
+            p0, p1 = c - d, c + d
+            truth.append(-1)
+        else:
+            j = int(rng.integers(1, len(lms)))
+            p0 = lms[j]["_p0"] + rng.normal(0, 0.04, 2); p1 = lms[j]["_p1"] + rng.normal(0, 0.04, 2)
+            if rng.random() < 0.3:
+                p0, p1 = p1, p0                            # reversed edge direction: the normal flips
+            truth.append(j)
+        q_planes.append(plane_transform_to(wall_from_edge(p0, p1), pose)); q_fpi.append(1 + (i % 5))
+        q_seg2d.append(np.concatenate([project(p0), project(p1)]) + rng.normal(0, 1.0, 4))
+        q_seg3d.append(np.array([*p0, *p1]))
+    for L in lms:
+        L.pop("_p0", None); L.pop("_p1", None)
+    return dict(pose=pose, frame_seq_id=frame, landmarks=lms, planes_local=np.array(q_planes), fpi=np.array(q_fpi, dtype=np.int32),
+                seg2d=np.array(q_seg2d, dtype=np.float32), seg3d=np.array(q_seg3d, dtype=np.float32), truth=np.array(truth))

@@ -13,21 +13,9 @@ INVK = np.linalg.inv(synth.K_TUM).astype(np.float32)
 
 
 def _oracle_pipeline():
-    g = O.OracleGraph()
-
-    def popup_fn(seg, T32, polys):
-        return O.popup_planes(seg, INVK, T32)
-
-    def refresh_fn(pl, pose_node, seg, fids):
-        for p, sg, fs in pl.frames:      # Mapper_mono::update_plane_measurement, Mapping.cpp:590-607
-            T32 = synth.T_from_pose(g.get_pose(p)).astype(np.float32)
-            planes = O.popup_planes(sg, INVK, T32).astype(np.float64)
-            for j, fid in enumerate(fs):
-                nrm = np.linalg.norm(planes[j])
-                if np.isfinite(nrm) and nrm > 0:      # same guard as k_refresh_measurements: keep the old value otherwise
-                    g.set_measurement(fid, planes[j] / nrm)
-
-    return pipeline.PopupSlamPipeline(g, popup_fn, refresh_fn, O.pose_oplus, O.plane_transform_from, O.pose_vector), g
+    from tests.assoc_helpers import oracle_pipeline
+    pl, g, _ = oracle_pipeline()
+    return pl, g
 
 
 def test_popup_fused_with_incremental_solve(built):
