@@ -243,6 +243,18 @@ int pps_find_closest_planes(pps_graph* g, const double est_pose[7], int frame_se
                             const int* frame_plane_indice, const float* seg2d, const float* seg3d_xy,
                             const pps_assoc_params* prm, int* best_plane_id, double* best_err);
 
+/* ---- graph text format: Slam::save (isamlib/Slam.cpp:84-89) / Graph::write (include/isam/Graph.h:120-131) ----
+ * One line per factor, then one line per node, in insertion order:
+ *   Pose3d_Pose3d_Factor 3 4 (x, y, z; yaw, pitch, roll) {s11,s12,...,s66}
+ *   Pose3d_Plane3d_Factor 4 17 (a, b, c; d) {s11,s12,s13,s22,s23,s33}
+ *   Pose3d_Factor 0 (...) {...}            pose prior AND plane prior (name quirk, isam_plane3d.h:438)
+ *   Pose3d_Node 4 (x, y, z; yaw, pitch, roll)     Plane3d_Node 17 (a, b, c; d)
+ * precision <= 0: 6 significant digits like the reference's ostream default (lossy); 17 round-trips doubles.
+ * pps_graph_load reads this format back into a new handle (the reference has no reader for it); node ids are
+ * re-assigned densely in file order. */
+int pps_graph_save(pps_graph* g, const char* path, int precision);
+int pps_graph_load(const char* path, const pps_props* props, pps_graph** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -377,6 +377,8 @@ public:
   double chi2() { double c = 0; detail::check(pps_chi2(_g, &c), _g, "pps_chi2"); return c; }   // :266-268
   int num_nodes() const { int n = 0; pps_num_nodes(_g, &n); return n; }
   int num_factors() const { int n = 0; pps_num_factors(_g, &n); return n; }
+  // Slam::save (Slam.cpp:84-89): factors then nodes, the reference's text format (6 significant digits)
+  void save(const std::string fname) const { detail::check(pps_graph_save(_g, fname.c_str(), 0), _g, "pps_graph_save"); }
 };
 
 // ---- out-of-line members that need Slam ---------------------------------------------------------

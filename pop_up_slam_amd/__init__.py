@@ -79,7 +79,7 @@ SYMBOLS = [
     "pps_popup_run", "pps_popup_download", "pps_popup_last_kernel_time",
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
-    "pps_find_closest_planes",
+    "pps_find_closest_planes", "pps_graph_save", "pps_graph_load",
 ]
 
 
@@ -151,6 +151,8 @@ def lib():
         L.pps_assoc_default_params.restype = None
         L.pps_landmark_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _fp]
         L.pps_landmark_set_merged.argtypes = [C.c_void_p, C.c_int]
+        L.pps_graph_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.pps_graph_load.argtypes = [C.c_char_p, C.POINTER(PpsProps), C.POINTER(C.c_void_p)]
         L.pps_find_closest_planes.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _ip, _fp, _fp, C.POINTER(PpsAssocParams), _ip, _dp]
         _LIB = L
     return _LIB
@@ -183,6 +185,23 @@ class Graph:
         if rc != PPS_OK:
             raise PpsError(rc, "pps_graph_create failed")
         self.h = h
+
+    @classmethod
+    def load(cls, path, **props):
+        """Read a graph written by save() (Slam::save text format) into a new handle."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.props = default_props(**props)
+        h = C.c_void_p()
+        rc = self.L.pps_graph_load(os.fsencode(path), C.byref(self.props), C.byref(h))
+        if rc != PPS_OK:
+            raise PpsError(rc, f"pps_graph_load({path}) failed")
+        self.h = h
+        return self
+
+    def save(self, path, precision=0):
+        """Slam::save (Slam.cpp:84-89); precision 0 = the reference's 6 significant digits, 17 = lossless."""
+        self._ck(self.L.pps_graph_save(self.h, os.fsencode(path), int(precision)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -1,0 +1,38 @@
+"""GPU: public iSAM pose-graph logs (tests/golden/isam_data) solved through the C-ABI against the oracle and the
+noise-free ground truth.  Loop closures put ~20 (sphere400) / ~50 (sphere2500) pose-pose edges across every
+cut of the chain, so the separators are hundreds of scalars wide: this exercises the split-supernode chains and
+the large-front kernels that the plane-SLAM graphs (fronts <= 105 rows) never reach."""
+import os
+
+import numpy as np
+import pytest
+
+import pop_up_slam_amd as P
+from oracle import oracle_py as O
+from pop_up_slam_amd import graphio
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "isam_data")
+
+
+@pytest.mark.parametrize("name,mode", [("sphere400", 0), ("sphere400", 1), ("sphere2500", 1)])
+def test_sphere(built, name, mode):
+    spec = graphio.load_edge3_log(os.path.join(DATA, name + ".txt"))
+    g = P.Graph(jacobian_mode=mode); spec.replay(g)
+    o = O.OracleGraph(); spec.replay(o)
+    c0, c0o = g.chi2(), o.chi2()
+    assert abs(c0 - c0o) <= 1e-9 * c0o
+    it, ito = g.batch_optimize(), o.batch_optimize()
+    c, co = g.chi2(), o.chi2()
+    dof = 6 * len(spec.f_type) - 6 * spec.n_poses
+    st = g.stats()
+    print("%s mode %d: chi2 %.6g -> %.8g (%d it) oracle %.8g (%d it) rel %.1e normalised %.4f; fronts %d levels %d max front %d; %.1f ms/it"
+          % (name, mode, c0, c, it, co, ito, abs(c - co) / co, c / dof, st["n_fronts"], st["n_levels"], st["max_front"],
+             1e3 * st["t_total"] / max(1, it)))
+    assert abs(c - co) <= 1e-5 * co
+    assert it == ito
+    assert 0.9 < c / dof < 1.1
+    if name == "sphere2500":
+        gt = graphio.trajectory_from_log(os.path.join(DATA, "sphere2500_groundtruth.txt"))
+        est = g.get_poses()
+        assert np.sqrt(((est[:, :3] - gt[:, :3]) ** 2).sum(1).mean()) < 1.5

@@ -1,0 +1,98 @@
+"""Pose-graph logs of the bundled iSAM library (tests/golden/isam_data, see its README) through the loader's
+conventions, and the oracle on them: the only externally produced data with ground truth the reference tree
+holds for this path.  These runs PIN the odometry factor (residual, sqrt-information handling), the LM loop and
+the sparse solver of the oracle against independent data: a correct implementation must bring the normalised
+chi-square of the simulated noise to ~1 and the trajectory to the noise-free ground truth."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from pop_up_slam_amd import graphio, synth
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "isam_data")
+
+
+def test_loader_conventions():
+    spec = graphio.load_edge3_log(os.path.join(DATA, "sphere400.txt"))
+    assert spec.n_poses == 400 and spec.counts()[synth.F_ODOMETRY] == 779 and spec.counts()[synth.F_POSE_PRIOR] == 1
+    # first line: EDGE3 0 1 0.81945 -0.262967 0.0276042 0.00500987 0.0155643 0.36856 10 ... 100 0 0 100 0 25
+    k = 1                                                       # factor 0 is the prior (Loader::add_prior)
+    assert tuple(spec.f_nodes[k]) == (0, 1)
+    # file order roll pitch yaw -> library order yaw pitch roll (Loader.cpp:321,332)
+    np.testing.assert_allclose(spec.f_meas[k], [0.81945, -0.262967, 0.0276042, 0.36856, 0.0155643, 0.00500987], atol=1e-12)
+    U = np.zeros((6, 6)); U[np.triu_indices(6)] = spec.f_sqrtinf[k]
+    # rotational block reversed: diag (i66, i55, i44) = (25, 100, 100)  (Loader.cpp:347-349)
+    np.testing.assert_array_equal(np.diag(U), [10, 10, 10, 25, 100, 100])
+    np.testing.assert_array_equal(spec.f_sqrtinf[0], synth._ut_diag([100.0] * 6))       # prior 100*I at the origin
+    np.testing.assert_allclose(spec.node_init[0], [0, 0, 0, 0, 0, 0, 1])
+    # second pose initialised by composing the first odometry edge (slam3d.h:144-146)
+    m = spec.f_meas[k]
+    d = graphio._pose_from_xyzypr(m[0], m[1], m[2], m[3], m[4], m[5])
+    np.testing.assert_allclose(spec.node_init[1], synth.pose_oplus(spec.node_init[0], d), atol=1e-15)
+    # loop closures are ordinary odometry factors between earlier and later poses
+    far = [tuple(n) for n, t in zip(spec.f_nodes, spec.f_type) if t == synth.F_ODOMETRY and n[1] - n[0] != 1]
+    assert len(far) == 380 and far[0] == (0, 20)
+
+
+def test_oracle_on_sphere400():
+    spec = graphio.load_edge3_log(os.path.join(DATA, "sphere400.txt"))
+    o = O.OracleGraph(); spec.replay(o)
+    c0 = o.chi2()
+    it = o.batch_optimize()
+    dof = 6 * len(spec.f_type) - 6 * spec.n_poses
+    print("sphere400: chi2 %.6g -> %.6g in %d LM iterations, normalised %.4f" % (c0, o.chi2(), it, o.chi2() / dof))
+    assert c0 > 1e6 and it <= 10
+    assert 0.9 < o.chi2() / dof < 1.1
+
+
+def test_oracle_on_sphere2500_against_ground_truth():
+    spec = graphio.load_edge3_log(os.path.join(DATA, "sphere2500.txt"))
+    gt = graphio.trajectory_from_log(os.path.join(DATA, "sphere2500_groundtruth.txt"))
+    assert spec.n_poses == 2500 and len(gt) == 2500
+    o = O.OracleGraph(); spec.replay(o)
+    it = o.batch_optimize()
+    dof = 6 * len(spec.f_type) - 6 * spec.n_poses
+    est = np.array([o.get_pose(i) for i in range(spec.n_poses)])
+    rmse0 = np.sqrt(((spec.node_init[:, :3] - gt[:, :3]) ** 2).sum(1).mean())
+    rmse = np.sqrt(((est[:, :3] - gt[:, :3]) ** 2).sum(1).mean())
+    print("sphere2500: %d LM iterations, normalised chi2 %.4f, RMSE to ground truth %.2f m -> %.3f m" % (it, o.chi2() / dof, rmse0, rmse))
+    assert 0.95 < o.chi2() / dof < 1.05
+    assert rmse0 > 30 and rmse < 1.5
+    # orientation: from tens of degrees (dead reckoning) down to the noise floor of the constraints
+    # (sigma = 1/25 rad = 2.3 deg in yaw, 1/100 rad in pitch / roll)
+    ang = lambda q: np.degrees(2 * np.arccos(np.abs((q * gt[:, 3:]).sum(1)).clip(0, 1))).mean()
+    print("            mean orientation error %.2f deg -> %.2f deg" % (ang(spec.node_init[:, 3:]), ang(est[:, 3:])))
+    assert ang(spec.node_init[:, 3:]) > 10 and ang(est[:, 3:]) < 2.5
+
+
+def test_save_format(tmp_path, built):
+    """Slam::save text format (Slam.cpp:84-89, Graph.h:120-131): reference layout at 6 digits, lossless at 17"""
+    import pop_up_slam_amd as P
+    spec = synth.small_world(5, 3, seed=1)
+    g = P.Graph(); spec.replay(g)
+    p6, p17 = str(tmp_path / "g6.txt"), str(tmp_path / "g17.txt")
+    g.save(p6); g.save(p17, 17)
+    lines = open(p6).read().splitlines()
+    assert len(lines) == g.num_factors() + g.num_nodes()
+    assert lines[0].startswith("Pose3d_Factor 0 (") and lines[0].count(",") == 4 + 20 and "; " in lines[0]
+    assert lines[1] == "Pose3d_Factor 1 (0, 0, -1; 0) {20,0,0,20,0,20}"          # plane prior: name quirk isam_plane3d.h:438
+    assert any(l.startswith("Pose3d_Plane3d_Factor 0 1 (") for l in lines)
+    assert any(l.startswith("Pose3d_Pose3d_Factor 0 4 (") for l in lines)
+    assert lines[g.num_factors()].startswith("Pose3d_Node 0 (") and any(l.startswith("Plane3d_Node 1 (") for l in lines)
+    h = P.Graph.load(p17)
+    assert (h.num_nodes(), h.num_factors()) == (g.num_nodes(), g.num_factors())
+    for i in range(g.num_nodes()):
+        a, b = (g.get_pose(i), h.get_pose(i)) if spec.node_type[i] == synth.NODE_POSE else (g.get_plane(i), h.get_plane(i))
+        assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-15
+    # a reloaded checkpoint saves to the same text
+    p17b = str(tmp_path / "g17b.txt")
+    h.save(p17b, 17)
+    la, lb = open(p17).read().splitlines(), open(p17b).read().splitlines()
+    assert len(la) == len(lb)
+    for x, y in zip(la, lb):
+        if x != y:      # Euler -> quaternion -> Euler may move the last digit
+            fx = np.array([float(t) for t in x.replace("(", " ").replace(")", " ").replace(";", " ").replace(",", " ").replace("{", " ").replace("}", " ").split()[1:]])
+            fy = np.array([float(t) for t in y.replace("(", " ").replace(")", " ").replace(";", " ").replace(",", " ").replace("{", " ").replace("}", " ").split()[1:]])
+            np.testing.assert_allclose(fx, fy, atol=1e-14)
