@@ -91,6 +91,16 @@ int pps_add_odometry(pps_graph* g, int pose1, int pose2, const double meas6[6], 
 /* Pose3d_Plane3d_Factor    src/isam_plane3d.h:221-308 (relative = false, Mapping.cpp:21,513) */
 int pps_add_plane_obs(pps_graph* g, int pose, int plane, const double meas4[4], const double sqrtinf_ut[6], int* fid);
 /* Plane3d_Factor           src/isam_plane3d.h:428-474 */
+/* Pose3d_Plane3d_Factor2 (src/isam_plane3d.h:314-424; the mapper's disabled call Mapping.cpp:515-521): a plane
+ * observation whose measured plane is re-popped from the 2-D ground edge at every residual evaluation
+ * (isam::get_wall_plane_equation, src/isam_plane3d.cpp:20-55, fp64) instead of being stored.  ray6 = the
+ * 3x2 ground_edge_ray (column-major: ray of end point 0, ray of end point 1) from pps_edge_ray.  meas4 is
+ * kept like FactorT::_measure but does not enter the error.  Its Jacobian is taken by central differences in
+ * both jacobian modes (the pose perturbation moves the measurement).  Not for the ground plane. */
+int pps_add_plane_obs2(pps_graph* g, int pose_id, int plane_id, const double meas4[4], const double ray6[6],
+                       const double sqrtinf_ut[6], int* fid);
+/* Pose3d_Plane3d_Factor2::precompute_edge_ray (src/isam_plane3d.h:361-373): fp32 invK * (u,v,1), cast to fp64 */
+int pps_edge_ray(const float invK[9], const float seg2d[4], double ray6[6]);
 int pps_add_plane_prior(pps_graph* g, int plane, const double meas4[4], const double sqrtinf_ut[6], int* fid);
 
 /* FactorT::set_measurement (Factor.h:206) for plane factors; batched form for

@@ -50,6 +50,9 @@ def lib():
             ("ora_add_odometry", [C.c_void_p, C.c_int, C.c_int, dp, dp], C.c_int),
             ("ora_add_plane_obs", [C.c_void_p, C.c_int, C.c_int, dp, dp], C.c_int),
             ("ora_add_plane_prior", [C.c_void_p, C.c_int, dp, dp], C.c_int),
+            ("ora_add_plane_obs2", [C.c_void_p, C.c_int, C.c_int, dp, dp, dp], C.c_int),
+            ("ora_edge_ray", [fp, fp, dp], None),
+            ("ora_repop_wall_plane", [dp, dp, dp], None),
             ("ora_set_measurement", [C.c_void_p, C.c_int, dp], None),
             ("ora_remove_factor", [C.c_void_p, C.c_int], None),
             ("ora_remove_node", [C.c_void_p, C.c_int], None),
@@ -140,6 +143,10 @@ class OracleGraph:
 
     def add_plane_obs(self, pose, plane, meas4, ut6):
         a, p = _d(meas4); b, q = _d(ut6); return self.L.ora_add_plane_obs(self.h, pose, plane, p, q)
+
+    def add_plane_obs2(self, pose, plane, meas4, ray6, ut6):
+        a, p = _d(meas4); r, pr = _d(ray6); b, q = _d(ut6)
+        return self.L.ora_add_plane_obs2(self.h, pose, plane, p, pr, q)
 
     def add_plane_prior(self, plane, meas4, ut6):
         a, p = _d(meas4); b, q = _d(ut6); return self.L.ora_add_plane_prior(self.h, plane, p, q)
@@ -245,6 +252,16 @@ def popup_planes(seg2d, invK, T_wc):
     out = np.zeros((n + 1, 4), dtype=np.float32)
     lib().ora_popup_planes(ps, n, pk, pt, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def edge_ray(invK, seg2d):
+    k, pk = _f(invK); s, ps = _f(seg2d); out = np.zeros(6)
+    lib().ora_edge_ray(pk, ps, out.ctypes.data_as(C.POINTER(C.c_double))); return out
+
+
+def repop_wall_plane(tq, ray6):
+    a, pa = _d(tq); r, pr = _d(ray6); out = np.zeros(4)
+    lib().ora_repop_wall_plane(pa, pr, out.ctypes.data_as(C.POINTER(C.c_double))); return out
 
 
 def popup_planes_ex(seg2d, invK, T_wc):

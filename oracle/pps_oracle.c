@@ -293,6 +293,8 @@ typedef struct {
   int n[2];
   double meas[6];       /* pose: x,y,z,yaw,pitch,roll ; plane: a,b,c,d (normalised) */
   double sqrtinf[36];   /* dim x dim row-major upper triangular */
+  int repop;            /* Pose3d_Plane3d_Factor2: measurement re-popped from `ray` at every evaluation */
+  double ray[6];        /* ground_edge_ray, column-major 3x2 (src/isam_plane3d.h:318,361-373) */
 } factor_t;
 
 typedef struct { double lambda, chi2; int accepted; } trace_t;
@@ -416,6 +418,41 @@ int ora_add_plane_obs(ora_graph* g, int pose, int plane, const double meas4[4], 
   normalize4(f->meas);
   return g->nfactors - 1;
 }
+/* Pose3d_Plane3d_Factor2 (src/isam_plane3d.h:314-424) */
+int ora_add_plane_obs2(ora_graph* g, int pose, int plane, const double meas4[4], const double ray6[6], const double ut[6]) {
+  int id = ora_add_plane_obs(g, pose, plane, meas4, ut);
+  g->factors[id].repop = 1;
+  memcpy(g->factors[id].ray, ray6, 6 * sizeof(double));
+  return id;
+}
+/* precompute_edge_ray (src/isam_plane3d.h:361-373): fp32 invK * (u,v,1), cast to double */
+void ora_edge_ray(const float invK[9], const float seg2d[4], double ray6[6]) {
+  for (int e = 0; e < 2; e++) {
+    const float u = seg2d[2 * e], v = seg2d[2 * e + 1];
+    for (int i = 0; i < 3; i++) ray6[3 * e + i] = (double)(invK[i * 3 + 0] * u + invK[i * 3 + 1] * v + invK[i * 3 + 2] * 1.f);
+  }
+}
+/* isam::get_wall_plane_equation for one segment (src/isam_plane3d.cpp:20-55) + normalisation (isam_plane3d.h:392-393) */
+static void repop_wall_plane(const pose_t* pose, const double ray[6], double out[4]) {
+  double R[9], gs[4], P[2][3];
+  quat_to_R(pose->q, R);
+  /* ground_plane_sensor = transToWorld^T * (0,0,-1,0) */
+  for (int k = 0; k < 3; k++) gs[k] = R[0 * 3 + k] * 0.0 + R[1 * 3 + k] * 0.0 + R[2 * 3 + k] * -1.0 + 0.0 * 0.0;
+  gs[3] = pose->t[0] * 0.0 + pose->t[1] * 0.0 + pose->t[2] * -1.0 + 1.0 * 0.0;
+  for (int j = 0; j < 2; j++) {
+    const double* r = ray + 3 * j;
+    const double frac = -gs[3] / (gs[0] * r[0] + gs[1] * r[1] + gs[2] * r[2]);   /* ray_plane_interact :13-17 */
+    for (int k = 0; k < 3; k++) P[j][k] = frac * r[k];
+  }
+  const double t1[3] = {P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2]};
+  const double n[3] = {t1[1] * gs[2] - t1[2] * gs[1], t1[2] * gs[0] - t1[0] * gs[2], t1[0] * gs[1] - t1[1] * gs[0]};
+  out[0] = n[0]; out[1] = n[1]; out[2] = n[2];
+  out[3] = -(n[0] * P[0][0] + n[1] * P[0][1] + n[2] * P[0][2]);
+  normalize4(out);
+}
+void ora_repop_wall_plane(const double tq[7], const double ray6[6], double out4[4]) {
+  pose_t p; pose_from_tq(tq, &p); repop_wall_plane(&p, ray6, out4);
+}
 int ora_add_plane_prior(ora_graph* g, int plane, const double meas4[4], const double ut[6]) {
   factor_t* f = new_factor(g, F_PLANE_PRIOR, 3, ut);
   f->nn = 1; f->n[0] = plane; f->n[1] = -1;
@@ -480,7 +517,12 @@ static void basic_error(ora_graph* g, const factor_t* f, int sel, double* e) {
       const plane_t* gp = node_plane(&g->nodes[f->n[1]], sel);
       plane_t local;
       plane_transform_to(gp, &pose, &local);
-      quat_logmap_diff(local.p, f->meas, e);
+      if (f->repop) {   /* Factor2: src/isam_plane3d.h:390-394 */
+        double ms[4];
+        repop_wall_plane(&pose, f->ray, ms);
+        quat_logmap_diff(local.p, ms, e);
+      } else
+        quat_logmap_diff(local.p, f->meas, e);
       break;
     }
     case F_PLANE_PRIOR: { /* src/isam_plane3d.h:449-473 */
@@ -754,7 +796,7 @@ static int factor_cols(const ora_graph* g, const factor_t* f) {
 /* Factor::jacobian (isam/Factor.h:126-139): H then r = error(LINPOINT) */
 static void factor_jacobian(ora_graph* g, const factor_t* f, int analytic, double* H, double* r) {
   int ncols = factor_cols(g, f), m = f->dim;
-  if (!analytic) {
+  if (!analytic || f->repop) {   /* Factor2 has no closed form here: numerical like the reference */
     numerical_jacobian(g, f, H, ncols);
   } else {
     double He[6 * 12];

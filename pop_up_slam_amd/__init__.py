@@ -60,6 +60,16 @@ class PpsError(RuntimeError):
 _LIB = None
 
 # every symbol include/pps.h declares (checked by tests/test_cabi.py)
+def edge_ray(invK, seg2d):
+    """Pose3d_Plane3d_Factor2::precompute_edge_ray: fp32 invK * (u,v,1) per end point, as 6 doubles."""
+    k = np.ascontiguousarray(invK, dtype=np.float32).reshape(9); sg = np.ascontiguousarray(seg2d, dtype=np.float32).reshape(4)
+    out = np.zeros(6)
+    rc = lib().pps_edge_ray(k.ctypes.data_as(_fp), sg.ctypes.data_as(_fp), out.ctypes.data_as(_dp))
+    if rc != PPS_OK:
+        raise PpsError(rc, "pps_edge_ray")
+    return out
+
+
 class PpsAssocParams(C.Structure):
     """pps_assoc_params (include/pps.h); defaults = Mapping.h:70-77 via pps_assoc_default_params."""
     _fields_ = [("edge_asso_2ddist", C.c_double), ("edge_asso_planedist", C.c_double), ("edge_asso_proj", C.c_double),
@@ -79,7 +89,7 @@ SYMBOLS = [
     "pps_popup_run", "pps_popup_download", "pps_popup_last_kernel_time",
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
-    "pps_find_closest_planes", "pps_graph_save", "pps_graph_load",
+    "pps_find_closest_planes", "pps_graph_save", "pps_graph_load", "pps_add_plane_obs2", "pps_edge_ray",
 ]
 
 
@@ -151,6 +161,8 @@ def lib():
         L.pps_assoc_default_params.restype = None
         L.pps_landmark_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _fp]
         L.pps_landmark_set_merged.argtypes = [C.c_void_p, C.c_int]
+        L.pps_add_plane_obs2.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _ip]
+        L.pps_edge_ray.argtypes = [_fp, _fp, _dp]
         L.pps_graph_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.pps_graph_load.argtypes = [C.c_char_p, C.POINTER(PpsProps), C.POINTER(C.c_void_p)]
         L.pps_find_closest_planes.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _ip, _fp, _fp, C.POINTER(PpsAssocParams), _ip, _dp]
@@ -241,6 +253,11 @@ class Graph:
     def add_plane_obs(self, pose, plane, meas4, ut6):
         a, p = _d(meas4, 4); b, q = _d(ut6, 6); i = C.c_int()
         self._ck(self.L.pps_add_plane_obs(self.h, pose, plane, p, q, C.byref(i))); return i.value
+
+    def add_plane_obs2(self, pose, plane, meas4, ray6, ut6):
+        """Pose3d_Plane3d_Factor2: the measurement is re-popped from the ground-edge rays at every evaluation."""
+        a, p = _d(meas4, 4); r, pr = _d(ray6, 6); b, q = _d(ut6, 6); i = C.c_int()
+        self._ck(self.L.pps_add_plane_obs2(self.h, pose, plane, p, pr, q, C.byref(i))); return i.value
 
     def add_plane_prior(self, plane, meas4, ut6):
         a, p = _d(meas4, 4); b, q = _d(ut6, 6); i = C.c_int()

@@ -40,6 +40,8 @@ struct HostFactor {
   double w[21];
   bool deleted;
   int slot;      // index in its type's device arrays
+  int repop;     // plane observation that re-pops its measurement from `ray` (Pose3d_Plane3d_Factor2)
+  double ray[6]; // K^-1 (u,v,1) of the two ground-edge end points
 };
 
 double now_s() {
@@ -103,6 +105,7 @@ struct pps_graph {
   int *d_item_frame = nullptr, *d_item_plane = nullptr, *d_item_slot = nullptr, *d_frame_pose_slot = nullptr, *d_frame_seg_off = nullptr;
   float* d_fr_seg = nullptr;
   bool dev_meas_newer = false;       // device edge measurements are newer than the host copies
+  int n_obs_fixed = 0;               // plane observations with a stored measurement (slots below this)
   // landmark records for data association (pps_landmark_update / pps_find_closest_planes)
   struct Landmark { int plane_id, fpi, seq, deleted; float seg2d[4], seg3d[4]; };
   std::vector<Landmark> lms;
@@ -244,12 +247,17 @@ int run_analysis(pps_graph* g) {
     if (n.type == NODE_POSE) { n.slot = (int)g->pose_ids.size(); g->pose_ids.push_back((int)i); sn.push_back({NODE_POSE, 6, n.slot}); }
     else { n.slot = (int)g->plane_ids.size(); g->plane_ids.push_back((int)i); sn.push_back({NODE_PLANE, 3, -1}); }
   }
-  for (size_t i = 0; i < g->factors.size(); i++) {
-    HostFactor& f = g->factors[i];
-    if (f.deleted) { f.slot = -1; continue; }
-    f.slot = (int)g->fslot_ids[f.type].size();
-    g->fslot_ids[f.type].push_back((int)i);
-  }
+  // plane observations with a fixed measurement first, the re-popping ones (Factor2) behind them
+  for (int pass = 0; pass < 2; pass++)
+    for (size_t i = 0; i < g->factors.size(); i++) {
+      HostFactor& f = g->factors[i];
+      if (f.deleted) { f.slot = -1; continue; }
+      if ((f.type == F_PLANE_OBS && f.repop) != (pass == 1)) continue;
+      f.slot = (int)g->fslot_ids[f.type].size();
+      g->fslot_ids[f.type].push_back((int)i);
+    }
+  g->n_obs_fixed = 0;
+  for (int id : g->fslot_ids[F_PLANE_OBS]) g->n_obs_fixed += g->factors[id].repop ? 0 : 1;
   const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(),
                 n_obs = g->fslot_ids[F_PLANE_OBS].size();
   const int64_t joff_obs = 0, joff_odo = n_obs * 30, joff_pp = joff_odo + n_odo * 78, joff_lp = joff_pp + n_pp * 42;
@@ -422,6 +430,17 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.obs_pose, idx_of(F_PLANE_OBS, false))); TRY(dev_upload(g, &d.obs_plane, idx_of(F_PLANE_OBS, true)));
   pack_soa<4>(g, F_PLANE_OBS, nullptr, false, tmp); TRY(dev_upload(g, &d.obs_meas, tmp));
   pack_soa<6>(g, F_PLANE_OBS, nullptr, true, tmp); TRY(dev_upload(g, &d.obs_w, tmp));
+  d.n_obs_fixed = g->n_obs_fixed;
+  {
+    const std::vector<int>& ids = g->fslot_ids[F_PLANE_OBS];
+    const size_t n2 = ids.size() - (size_t)g->n_obs_fixed;
+    if (n2 > 0) {
+      tmp.assign(6 * n2, 0.0);
+      for (size_t k = 0; k < n2; k++)
+        for (int c = 0; c < 6; c++) tmp[(size_t)c * n2 + k] = g->factors[ids[g->n_obs_fixed + k]].ray[c];
+      TRY(dev_upload(g, &d.obs_ray, tmp));
+    }
+  }
   TRY(dev_upload(g, &d.odo_a, idx_of(F_ODOMETRY, false))); TRY(dev_upload(g, &d.odo_b, idx_of(F_ODOMETRY, true)));
   pack_soa<6>(g, F_ODOMETRY, nullptr, false, tmp); TRY(dev_upload(g, &d.odo_meas, tmp));
   pack_soa<21>(g, F_ODOMETRY, nullptr, true, tmp); TRY(dev_upload(g, &d.odo_w, tmp));
@@ -765,6 +784,31 @@ int pps_add_plane_obs(pps_graph* g, int pose, int plane, const double meas4[4], 
   if (!live_node(g, pose, NODE_POSE) || !live_node(g, plane, NODE_PLANE)) return fail(g, PPS_EINVAL, "plane obs: bad node ids");
   return add_factor(g, F_PLANE_OBS, pose, plane, meas4, 4, ut, 6, fid);
 }
+// Pose3d_Plane3d_Factor2 (src/isam_plane3d.h:314-424): same nodes / noise / log-map residual, but the measured
+// plane is re-derived from the edge's two ground rays and the CURRENT pose at every evaluation.
+int pps_add_plane_obs2(pps_graph* g, int pose, int plane, const double meas4[4], const double ray6[6], const double ut[6],
+                       int* fid) {
+  if (!g || !ray6) return PPS_EINVAL;
+  for (int k = 0; k < 6; k++) if (!std::isfinite(ray6[k])) return fail(g, PPS_EINVAL, "non-finite edge ray");
+  int id = -1;
+  int rc = pps_add_plane_obs(g, pose, plane, meas4, ut, &id);
+  if (rc != PPS_OK) return rc;
+  g->factors[id].repop = 1;
+  memcpy(g->factors[id].ray, ray6, sizeof g->factors[id].ray);
+  if (fid) *fid = id;
+  return PPS_OK;
+}
+
+// precompute_edge_ray (src/isam_plane3d.h:361-373): fp32 product invK * (u,v,1) per end point, cast to fp64
+int pps_edge_ray(const float invK[9], const float seg2d[4], double ray6[6]) {
+  if (!invK || !seg2d || !ray6) return PPS_EINVAL;
+  for (int e = 0; e < 2; e++) {
+    const float u = seg2d[2 * e], v = seg2d[2 * e + 1];
+    for (int i = 0; i < 3; i++) ray6[3 * e + i] = (double)(invK[i * 3 + 0] * u + invK[i * 3 + 1] * v + invK[i * 3 + 2] * 1.f);
+  }
+  return PPS_OK;
+}
+
 int pps_add_plane_prior(pps_graph* g, int plane, const double meas4[4], const double ut[6], int* fid) {
   if (!g) return PPS_EINVAL;
   if (!live_node(g, plane, NODE_PLANE)) return fail(g, PPS_EINVAL, "plane prior: unknown plane id");
@@ -1145,6 +1189,7 @@ int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec
   if (!g || replicas < 1 || iters < 1 || !sec_per_sweep) return PPS_EINVAL;
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
+  if (g->dev.n_obs_fixed != g->dev.n_obs) return fail(g, PPS_ESTATE, "bench_sweep: graph holds re-popping plane edges (Factor2)");
   DevGraph d = g->dev;   // shallow copy with replicated edge arrays
   std::vector<void*> tmp;
   auto rep = [&](auto** ptr, size_t count_per) -> int {
@@ -1238,7 +1283,7 @@ int pps_refresh_measurements(pps_graph* g) {
     std::vector<int> slot(g->fr_item_fid.size()), pslot(g->fr_pose.size());
     for (size_t i = 0; i < slot.size(); i++) {
       const int fid = g->fr_item_fid[i];
-      slot[i] = (fid >= 0 && !g->factors[fid].deleted) ? g->factors[fid].slot : -1;
+      slot[i] = (fid >= 0 && !g->factors[fid].deleted && !g->factors[fid].repop) ? g->factors[fid].slot : -1;
       if (slot[i] >= 0 && g->nodes[g->fr_pose[g->fr_item_frame[i]]].deleted) slot[i] = -1;
     }
     for (size_t f = 0; f < pslot.size(); f++) pslot[f] = g->nodes[g->fr_pose[f]].deleted ? 0 : g->nodes[g->fr_pose[f]].slot;

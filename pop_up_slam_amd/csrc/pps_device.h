@@ -25,6 +25,9 @@ struct DevGraph {
   // ---- factors (SoA, leading dimension = count) ----
   int n_obs = 0, n_odo = 0, n_pp = 0, n_lp = 0;
   int *obs_pose = nullptr, *obs_plane = nullptr; double *obs_meas = nullptr, *obs_w = nullptr;
+  // plane edges [n_obs_fixed, n_obs) re-pop their measurement from two ground-edge rays at every evaluation
+  // (Pose3d_Plane3d_Factor2); obs_ray is SoA [6][n_obs - n_obs_fixed]
+  int n_obs_fixed = 0; double* obs_ray = nullptr;
   int *odo_a = nullptr, *odo_b = nullptr;         double *odo_meas = nullptr, *odo_w = nullptr;
   int *pp_pose = nullptr;                          double *pp_meas = nullptr, *pp_w = nullptr;
   int *lp_plane = nullptr;                         double *lp_meas = nullptr, *lp_w = nullptr;

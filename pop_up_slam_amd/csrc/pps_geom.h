@@ -202,6 +202,39 @@ PPS_HD void res_plane_obs(const double pose[7], const double plane[4], const dou
   log_diff(u, meas, e, dq);
 }
 
+// isam::get_wall_plane_equation (src/isam_plane3d.cpp:20-55) for one segment + the normalisation of
+// Pose3d_Plane3d_Factor2::basic_error (src/isam_plane3d.h:392-394): the wall plane, in the sensor frame, whose
+// ground edge is seen along the two rays `ray` (K^-1 (u,v,1) of the edge's end points, precompute_edge_ray
+// :361-373), for the camera pose `pose`.  fp64 like the reference's twin of the fp32 pop-up.
+PPS_HD void repop_wall_plane(const double pose[7], const double ray[6], double out[4]) {
+  double R[9];
+  quat_to_R(pose + 3, R);
+  // ground_plane_sensor = wTo^T (0,0,-1,0)
+  double gs[4];
+  gs[0] = R[0] * 0.0 + R[3] * 0.0 + R[6] * -1.0 + 0.0 * 0.0;
+  gs[1] = R[1] * 0.0 + R[4] * 0.0 + R[7] * -1.0 + 0.0 * 0.0;
+  gs[2] = R[2] * 0.0 + R[5] * 0.0 + R[8] * -1.0 + 0.0 * 0.0;
+  gs[3] = pose[0] * 0.0 + pose[1] * 0.0 + pose[2] * -1.0 + 1.0 * 0.0;
+  double P[2][3];
+  for (int j = 0; j < 2; j++) {
+    const double* r = ray + 3 * j;
+    const double frac = -gs[3] / (gs[0] * r[0] + gs[1] * r[1] + gs[2] * r[2]);   // ray_plane_interact :13-17
+    P[j][0] = frac * r[0]; P[j][1] = frac * r[1]; P[j][2] = frac * r[2];
+  }
+  const double t1[3] = {P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2]};
+  const double n[3] = {t1[1] * gs[2] - t1[2] * gs[1], t1[2] * gs[0] - t1[0] * gs[2], t1[0] * gs[1] - t1[1] * gs[0]};
+  out[0] = n[0]; out[1] = n[1]; out[2] = n[2];
+  out[3] = -(n[0] * P[0][0] + n[1] * P[0][1] + n[2] * P[0][2]);
+  normalize4(out);
+}
+
+// Pose3d_Plane3d_Factor2::basic_error (src/isam_plane3d.h:381-420): the measurement is re-popped at every evaluation
+PPS_HD void res_plane_obs2(const double pose[7], const double plane[4], const double ray[6], double e[3]) {
+  double ms[4];
+  repop_wall_plane(pose, ray, ms);
+  res_plane_obs(pose, plane, ms, e);
+}
+
 // Plane3d_Factor::basic_error  (src/isam_plane3d.h:449-473)
 PPS_HD void res_plane_prior(const double plane[4], const double meas[4], double e[3]) {
   double dq[4];

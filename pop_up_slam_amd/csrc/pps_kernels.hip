@@ -223,14 +223,14 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const doubl
   int b = blockIdx.x + (PART == 0 ? 0 : nb_obs);
   if (b < nb_obs) {
     const int i0 = b * kLinBlock + (threadIdx.x & ~63);            // first factor of this wave
-    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_obs - 1);   // clamped: every lane stays active for the staged store
+    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_obs_fixed - 1);   // clamped: every lane stays active for the staged store
     double pz[7], pl[4], ms[4], w[6], out[30];
     load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
     load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
     load_soa<4>(d.obs_meas, d.n_obs, i, ms);
     load_soa<6>(d.obs_w, d.n_obs, i, w);
     lin_plane_obs<MODE>(pz, pl, ms, w, out);
-    if (i0 < d.n_obs) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs - i0), lds_wave);
+    if (i0 < d.n_obs_fixed) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs_fixed - i0), lds_wave);
     return;
   }
   b -= nb_obs;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
   int b = blockIdx.x;
   if (b < nb_obs) {
     const int i = b * kFactorsPerBlock + grp;
-    if (i >= d.n_obs) return;
+    if (i >= d.n_obs_fixed) return;
     double pz[7], pl[4], ms[4], w[6], e[3], y[3];
     load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
     load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
@@ -431,15 +431,57 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
 // form has the higher throughput (no idle lanes)
 constexpr int kLaneParallelMaxFactors = 200000;
 
+// Pose3d_Plane3d_Factor2 edges (slots [n_obs_fixed, n_obs)): central differences in both Jacobian modes -- the
+// measurement moves with the pose perturbation (the reference differentiates it numerically too).
+__global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double* __restrict__ pose,
+                                                        const double* __restrict__ plane) {
+  const int n2 = d.n_obs - d.n_obs_fixed;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n2) return;
+  const int i = d.n_obs_fixed + k;
+  double pz[7], pl[4], ray[6], w[6], e[3], r[3], Jp[18], Jl[9];
+  load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
+  load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+  load_soa<6>(d.obs_ray, n2, k, ray);
+  load_soa<6>(d.obs_w, d.n_obs, i, w);
+  res_plane_obs2(pz, pl, ray, e);
+  whiten<3>(w, e, r);
+  const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+  for (int j = 0; j < 6; j++) {
+    double dl[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[3], ym[3];
+    dl[j] = kNumDiffEps;
+    pose_exmap(pz, dl, pp); res_plane_obs2(pp, pl, ray, e); whiten<3>(w, e, yp);
+    dl[j] = -kNumDiffEps;
+    pose_exmap(pz, dl, pp); res_plane_obs2(pp, pl, ray, e); whiten<3>(w, e, ym);
+    for (int q = 0; q < 3; q++) Jp[q * 6 + j] = (yp[q] - ym[q]) * inv2e;
+  }
+  for (int j = 0; j < 3; j++) {
+    double dl[3] = {0, 0, 0}, pp[4], yp[3], ym[3];
+    dl[j] = kNumDiffEps;
+    plane_exmap(pl, dl, pp); res_plane_obs2(pz, pp, ray, e); whiten<3>(w, e, yp);
+    dl[j] = -kNumDiffEps;
+    plane_exmap(pl, dl, pp); res_plane_obs2(pz, pp, ray, e); whiten<3>(w, e, ym);
+    for (int q = 0; q < 3; q++) Jl[q * 3 + j] = (yp[q] - ym[q]) * inv2e;
+  }
+  double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
+  for (int q = 0; q < 18; q++) out[q] = Jp[q];
+  for (int q = 0; q < 9; q++) out[18 + q] = Jl[q];
+  for (int q = 0; q < 3; q++) out[27 + q] = r[q];
+}
+
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st) {
-  const int nb_obs = cdiv(d.n_obs, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock), nb_pp = cdiv(d.n_pp, kLinBlock),
+  if (d.n_obs > d.n_obs_fixed) {
+    hipLaunchKernelGGL(k_linearize_repop, dim3(cdiv(d.n_obs - d.n_obs_fixed, 64)), dim3(64), 0, st, d,
+                       at_estimate ? d.pose_est : d.pose_lin, at_estimate ? d.plane_est : d.plane_lin);
+  }
+  const int nb_obs = cdiv(d.n_obs_fixed, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock), nb_pp = cdiv(d.n_pp, kLinBlock),
             nb_lp = cdiv(d.n_lp, kLinBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if (nb == 0) return hipSuccess;
   const double* pose = at_estimate ? d.pose_est : d.pose_lin;
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
   if (mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors) {
-    const int lb_obs = cdiv(d.n_obs, kFactorsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
+    const int lb_obs = cdiv(d.n_obs_fixed, kFactorsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
               lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
     hipLaunchKernelGGL(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
                        lb_obs, lb_odo, lb_pp);
@@ -1322,7 +1364,12 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
       double pz[7], pl[4], ms[4], w[6], e[3], r[3];
       load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
       load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
-      load_soa<4>(d.obs_meas, d.n_obs, i, ms);
+      if (i < d.n_obs_fixed) load_soa<4>(d.obs_meas, d.n_obs, i, ms);
+      else {                                  // Pose3d_Plane3d_Factor2: re-pop the measurement at this pose
+        double ray[6];
+        load_soa<6>(d.obs_ray, d.n_obs - d.n_obs_fixed, i - d.n_obs_fixed, ray);
+        repop_wall_plane(pz, ray, ms);
+      }
       load_soa<6>(d.obs_w, d.n_obs, i, w);
       res_plane_obs(pz, pl, ms, e);
       whiten<3>(w, e, r);

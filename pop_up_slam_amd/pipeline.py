@@ -98,7 +98,7 @@ class PopupSlamPipeline:
     GROUND_UT = synth._ut_diag([20.0] * 3)
 
     def __init__(self, graph, popup_fn, refresh_fn, pose_oplus, plane_transform_from, pose_vector, assoc_fn=None,
-                 landmark_fn=None):
+                 landmark_fn=None, ray_fn=None):
         """assoc_fn(est_pose, frame_seq_id, planes_local (n,4) f64, fpi (n,), seg2d (n,4) f32, seg3d_xy (n,4) f32)
         -> (landmark keys or -1, scores); landmark_fn(key, fpi, frame_seq_id, seg2d, seg3d_xy) records copy_plane.
         With assoc_fn, popup_fn must return (planes, seg3d_world (n,6)) and landmark keys are plane node ids."""
@@ -106,6 +106,9 @@ class PopupSlamPipeline:
         self.popup_fn, self.refresh_fn = popup_fn, refresh_fn
         self.pose_oplus, self.plane_transform_from, self.pose_vector = pose_oplus, plane_transform_from, pose_vector
         self.assoc_fn, self.landmark_fn = assoc_fn, landmark_fn
+        # ray_fn(seg2d row) -> 6 doubles: wall edges become Pose3d_Plane3d_Factor2 (measurement re-popped inside the
+        # residual, isam_plane3d.h:314-424 / the mapper's disabled call Mapping.cpp:515-521); they need no refresh
+        self.ray_fn = ray_fn
         self.pose_nodes, self.landmarks = [], {}
         self.frames = []          # (pose node, seg2d, fids)
         self.assoc_log = []       # per frame: landmark key chosen for every plane (association mode)
@@ -173,7 +176,11 @@ class PopupSlamPipeline:
                 if key == "g":
                     g.add_plane_prior(self.landmarks[key], synth.GROUND, self.GROUND_UT)   # :500-504
             sig = synth.plane_sigma(float(fr.dist[j]))
-            fids.append(g.add_plane_obs(p, self.landmarks[key], m, synth._ut_diag([1.0 / sig] * 3)))
+            if self.ray_fn is not None and j > 0:
+                g.add_plane_obs2(p, self.landmarks[key], m, self.ray_fn(fr.seg2d[j - 1]), synth._ut_diag([1.0 / sig] * 3))
+                fids.append(-1)
+            else:
+                fids.append(g.add_plane_obs(p, self.landmarks[key], m, synth._ut_diag([1.0 / sig] * 3)))
         self.frames.append((p, fr.seg2d, fids))
         if self.k % 5 == 0:                                                      # Mapping.cpp:551-554
             it = g.batch_optimize()
@@ -226,7 +233,7 @@ class PopupSlamPipeline:
 
 
 def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, with_image=True, seed=0, associate=False,
-                 assoc_params=None):
+                 assoc_params=None, repop=False):
     """Product pipeline: Graph + Popup on the GPU; pop-up results stay on the device."""
     import pop_up_slam_amd as P
     invK = np.linalg.inv(K).astype(np.float32)
@@ -261,5 +268,5 @@ def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, 
 
         landmark_fn = g.landmark_update
     pl = PopupSlamPipeline(g, popup_fn, refresh_fn, synth.pose_oplus, synth.plane_transform_from, synth.pose_vector,
-                           assoc_fn=assoc_fn, landmark_fn=landmark_fn)
+                           assoc_fn=assoc_fn, landmark_fn=landmark_fn, ray_fn=(lambda sg: P.edge_ray(invK, sg)) if repop else None)
     return pl, g, pp, stats

@@ -32,7 +32,7 @@ class OracleLandmarks:
         return np.array(ids), np.array(errs)
 
 
-def oracle_pipeline(associate=False, assoc_params=None):
+def oracle_pipeline(associate=False, assoc_params=None, repop=False):
     g = O.OracleGraph()
     lm = OracleLandmarks(g)
     prm = dict(assoc_params or {})
@@ -47,11 +47,14 @@ def oracle_pipeline(associate=False, assoc_params=None):
             T32 = synth.T_from_pose(g.get_pose(p)).astype(np.float32)
             planes = O.popup_planes(sg, INVK, T32).astype(np.float64)
             for j, fid in enumerate(fs):
+                if fid < 0:
+                    continue
                 nrm = np.linalg.norm(planes[j])
                 if np.isfinite(nrm) and nrm > 0:      # same guard as k_refresh_measurements: keep the old value otherwise
                     g.set_measurement(fid, planes[j] / nrm)
 
     pl = pipeline.PopupSlamPipeline(g, popup_fn, refresh_fn, O.pose_oplus, O.plane_transform_from, O.pose_vector,
                                     assoc_fn=(lambda *a: lm.find(*a, **prm)) if associate else None,
-                                    landmark_fn=lm.update if associate else None)
+                                    landmark_fn=lm.update if associate else None,
+                                    ray_fn=(lambda sg: O.edge_ray(INVK, sg)) if repop else None)
     return pl, g, lm
