@@ -68,6 +68,9 @@ struct pps_graph {
   std::vector<int> fslot_ids[4];          // per type: slot -> factor id
   std::vector<int> level_max_front;
   bool use_band = false;                  // wave-per-front band kernels (fronts <= 127 rows)
+  bool use_dense = false;                 // dense-front kernels (pps_dense.hip) when the band kernels do not apply
+  std::vector<int> level_max_b;           // widest boundary per level
+  int max_el_per_front = 0;
   std::vector<int> stage_max_piv, stage_nw_factor, stage_nw_solve;
   // device
   bool dev_ready = false;
@@ -295,6 +298,13 @@ int run_analysis(pps_graph* g) {
     int max_piv = 0;
     for (int m : g->stage_max_piv) max_piv = std::max(max_piv, m);
     g->use_band = A.max_front <= band_front_limit() && max_piv <= 64 && !getenv("PPS_NO_BAND");
+    g->use_dense = !g->use_band && max_piv <= dense_front_max_pivots() && !getenv("PPS_NO_DENSE");
+    g->level_max_b.assign(A.n_levels, 0);
+    g->max_el_per_front = 0;
+    for (int s = 0; s < A.n_fronts; s++) {
+      g->level_max_b[A.f_level[s]] = std::max(g->level_max_b[A.f_level[s]], A.f_b[s]);
+      g->max_el_per_front = std::max(g->max_el_per_front, A.f_el_off[s + 1] - A.f_el_off[s]);
+    }
     g->stage_nw_factor.assign(A.n_stages, 1); g->stage_nw_solve.assign(A.n_stages, 1);
     const size_t lds_budget = 150 * 1024;
     int max_waves = 8;
@@ -495,7 +505,7 @@ int upload_all(pps_graph* g) {
   TRY(dev_alloc(g, &d.ticket, 1)); HIP_TRY(g, hipMemset(d.ticket, 0, 4));
   if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
   // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
-  if (!g->use_band && A.max_front > lds_front_limit()) {
+  if (!g->use_band && !g->use_dense && A.max_front > lds_front_limit()) {
     const int fa = A.max_front + 1;
     d.gwork_stride = (int64_t)fa * (fa | 1);
     int widest = 0;
@@ -579,6 +589,23 @@ int do_solve(pps_graph* g, double lambda) {
       for (int st = A.n_stages - 1; st >= 0; st--)
         HIP_TRY(g, launch_band_solve(g->dev, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
                                      g->stage_max_piv[st], g->stream));
+    }
+    g->stats.n_factorize++;
+    return PPS_OK;
+  }
+  if (g->use_dense) {
+    {
+      PhaseTimer t(g, &g->stats.t_factor);
+      HIP_TRY(g, hipMemsetAsync(g->dev.L, 0, (size_t)A.L_size * 8, g->stream));
+      HIP_TRY(g, launch_dense_hpush(g->dev, g->max_el_per_front, lambda, g->stream));
+      for (int l = 0; l < A.n_levels; l++)
+        HIP_TRY(g, launch_dense_factor_level(g->dev, A.level_off[l], A.level_off[l + 1] - A.level_off[l], g->level_max_front[l],
+                                             g->level_max_b[l], l > 0, g->stream));
+    }
+    {
+      PhaseTimer t(g, &g->stats.t_backsolve);
+      for (int l = A.n_levels - 1; l >= 0; l--)
+        HIP_TRY(g, launch_dense_solve_level(g->dev, A.level_off[l], A.level_off[l + 1] - A.level_off[l], g->level_max_b[l], g->stream));
     }
     g->stats.n_factorize++;
     return PPS_OK;

@@ -93,6 +93,14 @@ hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st);
 hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, double seq, hipStream_t st);
 hipError_t launch_clear_status(const DevGraph& d, hipStream_t st);
 
+// dense-front form (pps_dense.hip): fronts of hundreds of rows, every step spread over many workgroups.
+// L must be zeroed before launch_dense_hpush; levels run leaves -> root (factor) and root -> leaves (solve).
+int dense_front_max_pivots();
+hipError_t launch_dense_hpush(const DevGraph& d, int max_el_per_front, double lambda, hipStream_t st);
+hipError_t launch_dense_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, int level_max_b,
+                                     bool has_children, hipStream_t st);
+hipError_t launch_dense_solve_level(const DevGraph& d, int level_begin, int level_count, int level_max_b, hipStream_t st);
+
 // Largest front (scalars incl. rhs row) the LDS path of the factor kernel accepts.
 int lds_front_limit();
 

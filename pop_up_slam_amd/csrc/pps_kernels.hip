@@ -10,6 +10,7 @@
 //       k_chi2, k_finalize  residual-only sweep + chi^2 reduction (Slam::weighted_errors/chi2, Slam.cpp:254-268)
 #include "pps_device.h"
 #include "pps_geom.h"
+#include "pps_regtile.h"
 
 namespace pps {
 
@@ -787,23 +788,6 @@ size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; 
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// 1/sqrt(x) to fp64 round-off: hardware estimate + two Newton steps (shorter than div + sqrt on the pivot chain)
-__device__ __forceinline__ double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y;
-}
-
-// broadcast lane `l` (wave-uniform) of a double through two v_readlane_b32
-__device__ __forceinline__ double readlane_d(double x, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
-  return __hiloint2double(hi, lo);
-}
-
 // One row of 16x16 tiles (I, J = o, o+16, ..., I) of the trailing lower triangle gets its rank-nb
 // update C -= P_I P_J^T: all LDS reads are issued unconditionally from clamped (always valid)
 // addresses and masked by selects afterwards, so the NT tiles' loads overlap; then NT back-to-back
@@ -997,37 +981,6 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
 // P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
 // ------------------------------------------------------------------------------------------
-constexpr int kPStride = 5;                       // doubles per panel row: conflict-free operand gathers
-constexpr int kRegRows = 64;
-
-__device__ __forceinline__ constexpr int tile_id(int ti, int tj) { return ti * (ti + 1) / 2 + tj; }
-
-template <int TJ>
-__device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[10], double* __restrict__ P, int c0, int lane) {
-  const int l16 = lane & 15, lq = lane >> 4;
-  const int m = l16 - c0;
-  if (m >= 0 && m < 4) {
-#pragma unroll
-    for (int ti = TJ; ti < 4; ti++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) P[(16 * ti + lq + 4 * r) * kPStride + m] = c[tile_id(ti, TJ)][r];
-  }
-}
-
-template <int TJ>
-__device__ __forceinline__ void reg_trailing(double4_t (&c)[10], const double* __restrict__ P, int nb, int lane) {
-  const int l16 = lane & 15, lq = lane >> 4;
-  const bool kvalid = lq < nb;
-  double opnd[4];
-#pragma unroll
-  for (int t = TJ; t < 4; t++) { const double x = P[(16 * t + l16) * kPStride + lq]; opnd[t] = kvalid ? x : 0.0; }
-#pragma unroll
-  for (int ti = TJ; ti < 4; ti++)
-#pragma unroll
-    for (int tj = TJ; tj <= ti; tj++)
-      c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
-}
-
 __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
                                                       double* __restrict__ P) {
   const int lane = threadIdx.x & 63;

@@ -1,0 +1,58 @@
+// pps_regtile.h -- a <= 64-row symmetric matrix held by ONE wavefront as ten 16x16 fp64 tiles in the MFMA
+// accumulator layout, and the pieces of its blocked Cholesky (shared by the band kernels and the dense-front panel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pps {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// 1/sqrt(x) to fp64 round-off: hardware estimate + two Newton steps (shorter than div + sqrt on the pivot chain)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// broadcast lane `l` (wave-uniform) of a double through two v_readlane_b32
+__device__ __forceinline__ double readlane_d(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+
+constexpr int kPStride = 5;                       // doubles per panel row: conflict-free operand gathers
+constexpr int kRegRows = 64;
+
+__device__ __forceinline__ constexpr int tile_id(int ti, int tj) { return ti * (ti + 1) / 2 + tj; }
+
+template <int TJ>
+__device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[10], double* __restrict__ P, int c0, int lane) {
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int m = l16 - c0;
+  if (m >= 0 && m < 4) {
+#pragma unroll
+    for (int ti = TJ; ti < 4; ti++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) P[(16 * ti + lq + 4 * r) * kPStride + m] = c[tile_id(ti, TJ)][r];
+  }
+}
+
+template <int TJ>
+__device__ __forceinline__ void reg_trailing(double4_t (&c)[10], const double* __restrict__ P, int nb, int lane) {
+  const int l16 = lane & 15, lq = lane >> 4;
+  const bool kvalid = lq < nb;
+  double opnd[4];
+#pragma unroll
+  for (int t = TJ; t < 4; t++) { const double x = P[(16 * t + l16) * kPStride + lq]; opnd[t] = kvalid ? x : 0.0; }
+#pragma unroll
+  for (int ti = TJ; ti < 4; ti++)
+#pragma unroll
+    for (int tj = TJ; tj <= ti; tj++)
+      c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
+}
+
+
+}  // namespace pps

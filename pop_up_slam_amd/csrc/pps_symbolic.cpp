@@ -2,6 +2,9 @@
 #include "pps_symbolic.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -147,8 +150,17 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
   const int N = (int)nodes.size();
   A.n_nodes = N;
   if (N == 0) { *msg = "empty graph"; return false; }
+  const bool timing = getenv("PPS_ANALYSIS_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[analysis] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   Builder B(nodes, factors, prm);
   B.build_adjacency();
+  lap("adjacency");
   B.lidx.assign(N, -1);
   B.dense.assign(N, 0);
 
@@ -185,6 +197,7 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       for (int u : dense_nodes) if (nodes[u].type == NODE_POSE) B.tree[root].piv.push_back(u);
       if (top >= 0) B.tree[root].kids.push_back(top);
     }
+    lap("dissection");
     // ---- 2./3. post-order over the separator tree; oversized supernodes are emitted as a chain of
     // fronts (first chunk child-most: it receives the tnode's children) ----
     std::vector<int> post;
@@ -239,6 +252,7 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
     if (pos != N) { *msg = "internal: ordering does not cover all nodes"; return false; }
     A.n_scalars = voff;
 
+    lap("post-order / chains");
     // ---- 4. boundaries ----
     std::vector<std::vector<int>> bnd(F);
     std::vector<std::vector<int>> kids(F);
@@ -298,6 +312,7 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       std::vector<int> w(A.level_off.begin(), A.level_off.end() - 1);
       for (int s = 0; s < F; s++) A.level_fronts[w[A.f_level[s]]++] = s;
     }
+    lap("boundaries");
     // ---- band schedule ----
     {
       const int Bn = std::max(1, prm.band_levels);
@@ -411,6 +426,7 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
     }
     A.f_cmap_off[F] = (int)A.cmap.size();
 
+    lap("band schedule");
     // ---- 5. block-sparse H and contribution lists ----
     struct Ctr { int64_t key; int jv, ju, roff, m; };
     std::vector<Ctr> ctr;
@@ -435,7 +451,29 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
     std::vector<char> has_diag(N, 0);
     for (auto& c : ctr) if (c.key / N == c.key % N) has_diag[c.key / N] = 1;
     for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({(int64_t)p * N + p, 0, 0, 0, 0});
-    std::stable_sort(ctr.begin(), ctr.end(), [](const Ctr& x, const Ctr& y) { return x.key < y.key; });
+    // stable sort by (row position, column position): counting sort on the row, then a stable insertion sort on
+    // the column inside each row (rows hold a handful of blocks; the dense nodes' rows fall back to std::stable_sort)
+    {
+      std::vector<int> row_off(N + 1, 0);
+      for (const auto& c : ctr) row_off[c.key / N + 1]++;
+      for (int p = 0; p < N; p++) row_off[p + 1] += row_off[p];
+      std::vector<Ctr> sorted(ctr.size());
+      std::vector<int> fill(row_off.begin(), row_off.end() - 1);
+      for (const auto& c : ctr) sorted[fill[c.key / N]++] = c;
+      for (int p = 0; p < N; p++) {
+        Ctr* b = sorted.data() + row_off[p];
+        const int n = row_off[p + 1] - row_off[p];
+        if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.key < y.key; }); continue; }
+        for (int i = 1; i < n; i++) {
+          const Ctr c = b[i];
+          int j = i - 1;
+          while (j >= 0 && b[j].key > c.key) { b[j + 1] = b[j]; j--; }
+          b[j + 1] = c;
+        }
+      }
+      ctr.swap(sorted);
+    }
+    lap("  contributions sorted");
     A.contrib.clear();
     A.contrib.reserve(ctr.size() * 4);
     std::vector<std::vector<int>> asm_of(F);   // block ids per front
@@ -472,14 +510,18 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       A.asm_lrow.push_back(v); A.asm_lcol.push_back(u);   // temporarily indexed by block id
       i = j;
     }
+    lap("  blocks / segments");
     // per-front assembly lists with local offsets
     std::vector<int> blk_v(A.asm_lrow), blk_u(A.asm_lcol);
     A.asm_blk.clear(); A.asm_lrow.clear(); A.asm_lcol.clear();
     A.f_asm_off.assign(F + 1, 0);
     A.f_el_off.assign(1, 0); A.el_src.clear(); A.el_tgt.clear();
+    A.f_el_off.reserve(F + 1);
     A.blk_doff.assign(A.n_blocks + 1, 0);
     for (int bk = 0; bk < A.n_blocks; bk++) A.blk_doff[bk + 1] = A.blk_doff[bk] + A.blk_size[bk];
     A.blk_dst.assign(A.blk_doff[A.n_blocks], -1);
+    A.el_src.reserve(A.blk_doff[A.n_blocks]); A.el_tgt.reserve(A.blk_doff[A.n_blocks]);
+    A.asm_blk.reserve(A.n_blocks); A.asm_lrow.reserve(A.n_blocks); A.asm_lcol.reserve(A.n_blocks);
     if (A.H_size > 0x3fffffffLL) { *msg = "H too large for int32 gather offsets"; return false; }
     for (int s = 0; s < F; s++) {
       int off = 0;
@@ -519,6 +561,7 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
       for (int v : bnd[s]) loc[v] = -1;
     }
+      lap("H blocks / lists");
       // ---- packed records ----
     {
       A.frec.assign((size_t)F * 16, 0);
@@ -549,6 +592,7 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
         r[0] = A.blk_rows[bk]; r[1] = A.blk_cols[bk]; r[2] = A.blk_size[bk]; r[3] = A.seg_c0[sg]; r[4] = A.seg_cnt[sg];
         r[5] = (int)A.seg_hoff[sg]; r[6] = A.blk_doff[bk]; r[7] = A.blk_nseg[bk];
       }
+      lap("packed records");
     }
   }
   return true;

@@ -83,7 +83,13 @@ def popup_sequence(n_frames=1000, seed=7, width=640, height=480, K=synth.K_TUM, 
         if prev is None:
             odo = tp.copy()
         else:
-            odo = synth.pose_exmap(synth.pose_ominus(tp, prev), rng.normal(0, 1, 6) * np.array([0.01] * 3 + [np.deg2rad(0.2)] * 3))
+            # wheeled platform: odometry noise lives in the ground plane only (camera x = lateral, z = forward,
+            # rotation about camera y = heading).  Height and tilt are unobservable in this pipeline -- the ground
+            # edge is re-popped from the estimate itself (Mapping.cpp:590-607), and the pop-up scale IS the camera
+            # height -- so any pitch noise integrates into height (0.1 m * sin(pitch error) per step), the map scale
+            # drifts ~30 % over 900 frames and the frame loop diverges (in the oracle as well).
+            sig = np.array([0.01, 0.0, 0.01, 0.0, np.deg2rad(0.2), 0.0])
+            odo = synth.pose_exmap(synth.pose_ominus(tp, prev), rng.normal(0, 1, 6) * sig)
         frames.append(Frame(tp, odo, seg, ids, polys, np.array(dist)))
         prev = tp
     return frames
@@ -94,7 +100,10 @@ class PopupSlamPipeline:
     polys)` returns the (n+1,4) fp32 sensor-frame planes of a frame (and may pop up pixels as a side effect);
     `refresh_fn(pipeline)` re-derives all stored measurements from the latest poses."""
 
-    POSE_UT = synth._ut_diag([0.5] * 6)
+    # pose sigmas (x, y, z, yaw, pitch, roll of the relative pose in CAMERA axes; yaml pose_sigma_*, Mapping.cpp:54-63):
+    # 2 like plane_3d_tum_far.yaml:16-21 in the directions the walls observe (lateral x, forward z, heading = rotation
+    # about camera y = "pitch"); 0.02 for height / tilt, which this pipeline cannot observe.
+    POSE_UT = synth._ut_diag([0.5, 50.0, 0.5, 50.0, 0.5, 50.0])
     GROUND_UT = synth._ut_diag([20.0] * 3)
 
     def __init__(self, graph, popup_fn, refresh_fn, pose_oplus, plane_transform_from, pose_vector, assoc_fn=None,
