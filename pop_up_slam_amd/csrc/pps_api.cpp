@@ -71,6 +71,9 @@ struct pps_graph {
   bool use_dense = false;                 // dense-front kernels (pps_dense.hip) when the band kernels do not apply
   std::vector<int> level_max_b;           // widest boundary per level
   int max_el_per_front = 0;
+  // dense-front work lists: per level a prefix sum over its fronts (count+1 entries at level_off[l] + l)
+  std::vector<int> dw_asm, dw_pan, dw_trl;
+  int *d_dw_asm = nullptr, *d_dw_pan = nullptr, *d_dw_trl = nullptr;
   std::vector<int> stage_max_piv, stage_nw_factor, stage_nw_solve;
   // device
   bool dev_ready = false;
@@ -285,6 +288,13 @@ int run_analysis(pps_graph* g) {
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
   const char* msg = "";
   if (!analyze(sn, sf, g->aprm, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+  // fronts beyond the wave-per-front kernels (loop-closure separators) run in the dense-front form, whose cost is
+  // per tree level: split their supernodes into 64-pivot chunks instead of 48 (a quarter fewer levels)
+  if (g->an.max_front > band_front_limit() && g->aprm.max_pivots < dense_front_max_pivots() && !getenv("PPS_MAX_PIVOTS")) {
+    AnalysisParams wide = g->aprm;
+    wide.max_pivots = dense_front_max_pivots();
+    if (!analyze(sn, sf, wide, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+  }
   g->level_max_front.assign(g->an.n_levels, 0);
   for (int s = 0; s < g->an.n_fronts; s++) {
     int& m = g->level_max_front[g->an.f_level[s]];
@@ -305,6 +315,19 @@ int run_analysis(pps_graph* g) {
       g->level_max_b[A.f_level[s]] = std::max(g->level_max_b[A.f_level[s]], A.f_b[s]);
       g->max_el_per_front = std::max(g->max_el_per_front, A.f_el_off[s + 1] - A.f_el_off[s]);
     }
+    g->dw_asm.clear(); g->dw_pan.clear(); g->dw_trl.clear();
+    if (g->use_dense)
+      for (int l = 0; l < A.n_levels; l++) {
+        int a = 0, pn = 0, t = 0;
+        g->dw_asm.push_back(0); g->dw_pan.push_back(0); g->dw_trl.push_back(0);
+        for (int k = A.level_off[l]; k < A.level_off[l + 1]; k++) {
+          const int s = A.level_fronts[k];
+          const int fa = A.f_p[s] + A.f_b[s] + 1, b1 = A.f_b[s] + 1;
+          const int T32 = (fa + 31) / 32, T64 = (b1 + 63) / 64;
+          a += T32 * ((A.f_p[s] + 31) / 32); pn += (fa - A.f_p[s] + 255) / 256; t += T64 * (T64 + 1) / 2;
+          g->dw_asm.push_back(a); g->dw_pan.push_back(pn); g->dw_trl.push_back(t);
+        }
+      }
     g->stage_nw_factor.assign(A.n_stages, 1); g->stage_nw_solve.assign(A.n_stages, 1);
     const size_t lds_budget = 150 * 1024;
     int max_waves = 8;
@@ -497,6 +520,7 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
   TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec));
+  if (g->use_dense) { TRY(dev_upload(g, &g->d_dw_asm, g->dw_asm)); TRY(dev_upload(g, &g->d_dw_pan, g->dw_pan)); TRY(dev_upload(g, &g->d_dw_trl, g->dw_trl)); }
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &d.result_dev, 4));
@@ -598,9 +622,11 @@ int do_solve(pps_graph* g, double lambda) {
       PhaseTimer t(g, &g->stats.t_factor);
       HIP_TRY(g, hipMemsetAsync(g->dev.L, 0, (size_t)A.L_size * 8, g->stream));
       HIP_TRY(g, launch_dense_hpush(g->dev, g->max_el_per_front, lambda, g->stream));
-      for (int l = 0; l < A.n_levels; l++)
-        HIP_TRY(g, launch_dense_factor_level(g->dev, A.level_off[l], A.level_off[l + 1] - A.level_off[l], g->level_max_front[l],
-                                             g->level_max_b[l], l > 0, g->stream));
+      for (int l = 0; l < A.n_levels; l++) {
+        const int base = A.level_off[l] + l, cnt = A.level_off[l + 1] - A.level_off[l];
+        HIP_TRY(g, launch_dense_factor_level(g->dev, A.level_off[l], cnt, g->d_dw_asm + base, g->dw_asm[base + cnt], g->d_dw_pan + base,
+                                             g->dw_pan[base + cnt], g->d_dw_trl + base, g->dw_trl[base + cnt], g->stream));
+      }
     }
     {
       PhaseTimer t(g, &g->stats.t_backsolve);

@@ -38,6 +38,15 @@ __device__ __forceinline__ int tri_row(int t) {           // largest r with r(r+
   return r;
 }
 
+// Workgroup -> (front of the level, work item inside the front): `off` is the level's prefix sum of per-front work
+// item counts (count+1 entries, wave-uniform binary search), so that no empty workgroups are launched.
+__device__ __forceinline__ int locate(const int* __restrict__ off, int count, int wg, int* item) {
+  int lo = 0, hi = count;                 // invariant: off[lo] <= wg < off[hi]
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= wg) lo = mid; else hi = mid; }
+  *item = wg - off[lo];
+  return lo;
+}
+
 // ---- original entries of every front -> its (zeroed) factor panel --------------------------------------------------
 // Hf[e] belongs at packed-triangle index el_tgt[e] of the front; all such entries sit in pivot columns (an H block
 // is assembled where its column node is eliminated) or in the rhs row.  Diagonal entries carry bit 30: LM damping
@@ -57,14 +66,16 @@ __global__ __launch_bounds__(256) void k_dense_hpush(DevGraph d, double lambda) 
   }
 }
 
-// ---- extend-add, pull form: one 32x32 tile of the front's lower triangle per workgroup ---------------------------------
-__global__ __launch_bounds__(256) void k_dense_assemble(DevGraph d, int level_begin) {
+// ---- extend-add into the factor panel, pull form: one 32x32 tile of the (f+1) x p panel per workgroup ------------------
+// (the update-matrix part of the front is pulled by k_dense_trailing, which then writes U exactly once)
+__global__ __launch_bounds__(256) void k_dense_assemble(DevGraph d, int level_begin, const int* __restrict__ off, int count) {
   __shared__ int invr[32], invc[32];
-  const int s = d.level_fronts[level_begin + blockIdx.y];
-  const int p = d.f_p[s], b = d.f_b[s], fa = p + b + 1, b1 = b + 1;
-  const int T = (fa + 31) / 32;
-  if ((int)blockIdx.x >= T * (T + 1) / 2) return;
-  const int ti = tri_row(blockIdx.x), tj = blockIdx.x - ti * (ti + 1) / 2;
+  int item;
+  const int s = d.level_fronts[level_begin + locate(off, count, blockIdx.x, &item)];
+  const int p = d.f_p[s], b = d.f_b[s], fa = p + b + 1;
+  const int TC = (p + 31) / 32;
+  const int ti = item / TC, tj = item - ti * TC;
+  if (tj > ti) return;                               // entirely above the diagonal
   const int r0 = ti * 32, c0 = tj * 32;
   const int tid = threadIdx.x;
   const int cc = c0 + (tid & 31);
@@ -95,13 +106,10 @@ __global__ __launch_bounds__(256) void k_dense_assemble(DevGraph d, int level_be
     __syncthreads();
   }
   double* __restrict__ Lp = d.L + d.f_Loff[s];
-  double* __restrict__ Us = d.U + d.f_Uoff[s];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int rr = r0 + (tid >> 5) + 8 * e;
-    if (rr >= fa || cc > rr) continue;
-    if (cc < p) Lp[(size_t)rr * p + cc] += acc[e];
-    else Us[(size_t)(rr - p) * b1 + (cc - p)] = acc[e];
+    if (rr < fa && cc <= rr && cc < p && acc[e] != 0.0) Lp[(size_t)rr * p + cc] += acc[e];
   }
 }
 
@@ -109,19 +117,18 @@ __global__ __launch_bounds__(256) void k_dense_assemble(DevGraph d, int level_be
 // The p x p diagonal block (p <= 64) is factored by wave 0 alone, register-resident: ten 16x16 tiles in MFMA
 // accumulator layout, 4-column panels through a 64 x 5 LDS buffer, 4x4 diagonal blocks broadcast with v_readlane,
 // rank-4 trailing updates as single v_mfma_f64_16x16x4_f64 (pps_regtile.h) -- no workgroup barrier inside.
-__global__ __launch_bounds__(256) void k_dense_panel(DevGraph d, int level_begin, int dbg) {
+__global__ __launch_bounds__(256) void k_dense_panel(DevGraph d, int level_begin, const int* __restrict__ off, int count) {
   __shared__ double A[kMaxPiv * kLdA];
   __shared__ double rinv[kMaxPiv];
   __shared__ double P[64 * kPStride];
-  const int s = d.level_fronts[level_begin + blockIdx.y];
+  int slab;
+  const int s = d.level_fronts[level_begin + locate(off, count, blockIdx.x, &slab)];
   const int p = d.f_p[s], b = d.f_b[s], fa = p + b + 1;
-  const int nslab = (fa - p + 255) / 256;
-  if ((int)blockIdx.x >= nslab) return;
   double* __restrict__ Lp = d.L + d.f_Loff[s];
   const int tid = threadIdx.x;
   for (int i = tid; i < kMaxPiv * kLdA; i += 256) A[i] = 0.0;
   __syncthreads();
-  if (tid < 64 && !(dbg & 1)) {
+  if (tid < 64) {
     const int lane = tid, l16 = lane & 15, lq = lane >> 4;
     double4_t c[10];
 #pragma unroll
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void k_dense_panel(DevGraph d, int level_begin
       if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
       if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
       if (nb > 3) { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; bad |= !(t > 0.0); i3 = t > 0.0 ? rsqrt_nr(t) : 0.0; }
-      if (bad && lane == 0 && blockIdx.x == 0) d.result_dev[2] = 1.0;          // not positive definite
+      if (bad && lane == 0 && slab == 0) d.result_dev[2] = 1.0;                // not positive definite
       const double x0 = r0 * i0;
       const double x1 = (r1 - x0 * l10) * i1;
       const double x2 = (r2 - x0 * l20 - x1 * l21) * i2;
@@ -181,11 +188,11 @@ __global__ __launch_bounds__(256) void k_dense_panel(DevGraph d, int level_begin
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0)
+  if (slab == 0)
     for (int i = tid; i < p * p; i += 256) { const int r = i / p, c = i - r * p; Lp[i] = A[r * kLdA + c]; }
   // one row per thread: x L_A^T = b  <=>  x_j = (b_j - sum_{k<j} x_k L_A[j][k]) / L_A[j][j]
-  const int r = p + blockIdx.x * 256 + tid;
-  if (r < fa && !(dbg & 2)) {
+  const int r = p + slab * 256 + tid;
+  if (r < fa) {
     double x[kMaxPiv];
     double* __restrict__ row = Lp + (size_t)r * p;
 #pragma unroll
@@ -205,43 +212,88 @@ __global__ __launch_bounds__(256) void k_dense_panel(DevGraph d, int level_begin
 }
 
 // ---- trailing update: U -= L_B L_B^T on 64x64 tiles of the lower triangle; wave w owns 16 rows, 4 MFMA tiles ---------
-__global__ __launch_bounds__(256) void k_dense_trailing(DevGraph d, int level_begin) {
-  const int s = d.level_fronts[level_begin + blockIdx.y];
+// The two 64 x p row panels of the tile are contiguous in L (row-major, stride p): staged into LDS with coalesced
+// loads, MFMA operands gathered from there.
+__global__ __launch_bounds__(256) void k_dense_trailing(DevGraph d, int level_begin, const int* __restrict__ off, int count) {
+  extern __shared__ double pan[];
+  int item;
+  const int s = d.level_fronts[level_begin + locate(off, count, blockIdx.x, &item)];
   const int p = d.f_p[s], b = d.f_b[s], b1 = b + 1;
-  const int T = (b1 + 63) / 64;
-  if ((int)blockIdx.x >= T * (T + 1) / 2) return;
-  const int ti = tri_row(blockIdx.x), tj = blockIdx.x - ti * (ti + 1) / 2;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ti = tri_row(item), tj = item - ti * (ti + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l16 = lane & 15, lq = lane >> 4;
-  const int R0 = ti * 64 + 16 * w, C0 = tj * 64;
-  if (R0 >= b1) return;
+  const int ld = p + 1;
   const double* __restrict__ Lb = d.L + d.f_Loff[s] + (size_t)p * p;     // rows p.. of the panel = L_B (+ rhs row)
-  double* __restrict__ Us = d.U + d.f_Uoff[s];
+  double* __restrict__ PA = pan;
+  double* __restrict__ PB = (ti == tj) ? pan : pan + 64 * ld;
+  {
+    const int ra = ti * 64, na = min(64, b1 - ra) * p;
+    const double* __restrict__ src = Lb + (size_t)ra * p;
+    for (int i = tid; i < 64 * p; i += 256) { const int r = i / p, k = i - r * p; PA[r * ld + k] = i < na ? src[i] : 0.0; }
+    if (ti != tj) {
+      const int rb = tj * 64, nb = min(64, b1 - rb) * p;
+      const double* __restrict__ src2 = Lb + (size_t)rb * p;
+      for (int i = tid; i < 64 * p; i += 256) { const int r = i / p, k = i - r * p; PB[r * ld + k] = i < nb ? src2[i] : 0.0; }
+    }
+  }
+  __syncthreads();
+  const int R0 = ti * 64 + 16 * w, C0 = tj * 64;
   double4_t acc[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int ar = R0 + l16;
-  const bool aok = ar < b1;
-  for (int k0 = 0; k0 < p; k0 += 4) {
-    const int k = k0 + lq;
-    const bool kok = k < p;
-    const double araw = Lb[(aok && kok) ? (size_t)ar * p + k : 0];
-    const double av = (aok && kok) ? -araw : 0.0;
+  if (R0 < b1) {
+    const double* __restrict__ pa = PA + (16 * w + l16) * ld + lq;
+    const double* __restrict__ pb = PB + l16 * ld + lq;
+    for (int k0 = 0; k0 < p; k0 += 4) {
+      const bool kok = k0 + lq < p;
+      const double araw = pa[kok ? k0 : 0];
+      const double av = kok ? -araw : 0.0;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int br = C0 + 16 * t + l16;
-      const bool bok = br < b1 && kok;
-      const double braw = Lb[bok ? (size_t)br * p + k : 0];
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bok ? braw : 0.0, acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; t++) {
+        const double braw = pb[16 * t * ld + (kok ? k0 : 0)];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, kok ? braw : 0.0, acc[t], 0, 0, 0);
+      }
     }
   }
+  // children's update matrices, pulled through inverse maps of this tile's 64 rows / 64 columns (front-local
+  // indices p + ...); U is then written exactly once
+  __shared__ int invr[64], invc[64];
+  for (int ci = d.f_child_off[s]; ci < d.f_child_off[s + 1]; ci++) {
+    const int c = d.child[ci];
+    const int bc1 = d.f_b[c] + 1;
+    const int* __restrict__ cm = d.cmap + d.f_cmap_off[c];
+    const double* __restrict__ Uc = d.U + d.f_Uoff[c];
+    __syncthreads();
+    if (tid < 64) { invr[tid] = -1; invc[tid] = -1; }
+    __syncthreads();
+    const int fr0 = p + ti * 64, fc0 = p + tj * 64;
+    for (int i = tid; i < bc1; i += 256) {
+      const int m = cm[i];
+      if (m >= fr0 && m < fr0 + 64) invr[m - fr0] = i;
+      if (m >= fc0 && m < fc0 + 64) invc[m - fc0] = i;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int ic = invc[16 * t + l16];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ir = invr[16 * w + lq + 4 * r];
+        if (ir >= 0 && ic >= 0 && C0 + 16 * t + l16 <= R0 + lq + 4 * r) {
+          const int hi = ir > ic ? ir : ic, lo = ir > ic ? ic : ir;
+          acc[t][r] += Uc[(size_t)hi * bc1 + lo];
+        }
+      }
+    }
+  }
+  double* __restrict__ Us = d.U + d.f_Uoff[s];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
     const int cc = C0 + 16 * t + l16;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int rr = R0 + lq + 4 * r;                       // D layout: row (lane/16) + 4r, column lane%16
-      if (rr < b1 && cc <= rr) Us[(size_t)rr * b1 + cc] += acc[t][r];
+      if (rr < b1 && cc <= rr) Us[(size_t)rr * b1 + cc] = acc[t][r];
     }
   }
 }
@@ -303,16 +355,13 @@ hipError_t launch_dense_hpush(const DevGraph& d, int max_el_per_front, double la
   return hipGetLastError();
 }
 
-hipError_t launch_dense_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, int level_max_b,
-                                     bool has_children, hipStream_t st) {
+hipError_t launch_dense_factor_level(const DevGraph& d, int level_begin, int level_count, const int* off_asm, int n_asm,
+                                     const int* off_pan, int n_pan, const int* off_trl, int n_trl, hipStream_t st) {
   if (level_count == 0) return hipSuccess;
-  const int fa = level_max_front + 1;
-  const int T32 = cdiv(fa, 32);
-  hipLaunchKernelGGL(k_dense_assemble, dim3(T32 * (T32 + 1) / 2, level_count), dim3(256), 0, st, d, level_begin);
-  static const int dbg = getenv("PPS_DENSE_DBG") ? atoi(getenv("PPS_DENSE_DBG")) : 0;
-  hipLaunchKernelGGL(k_dense_panel, dim3(std::max(1, cdiv(fa, 256)), level_count), dim3(256), 0, st, d, level_begin, dbg);
-  const int T64 = cdiv(level_max_b + 1, 64);
-  hipLaunchKernelGGL(k_dense_trailing, dim3(T64 * (T64 + 1) / 2, level_count), dim3(256), 0, st, d, level_begin);
+  if (n_asm) hipLaunchKernelGGL(k_dense_assemble, dim3(n_asm), dim3(256), 0, st, d, level_begin, off_asm, level_count);
+  if (n_pan) hipLaunchKernelGGL(k_dense_panel, dim3(n_pan), dim3(256), 0, st, d, level_begin, off_pan, level_count);
+  if (n_trl) hipLaunchKernelGGL(k_dense_trailing, dim3(n_trl), dim3(256), (size_t)2 * 64 * (kMaxPiv + 1) * sizeof(double), st, d,
+                                level_begin, off_trl, level_count);
   return hipGetLastError();
 }
 

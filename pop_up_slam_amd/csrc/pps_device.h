@@ -97,8 +97,10 @@ hipError_t launch_clear_status(const DevGraph& d, hipStream_t st);
 // L must be zeroed before launch_dense_hpush; levels run leaves -> root (factor) and root -> leaves (solve).
 int dense_front_max_pivots();
 hipError_t launch_dense_hpush(const DevGraph& d, int max_el_per_front, double lambda, hipStream_t st);
-hipError_t launch_dense_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, int level_max_b,
-                                     bool has_children, hipStream_t st);
+// off_*: device prefix sums (level_count+1 entries) of the per-front work items of the three kernels of a level:
+// 32x32 assembly tiles of the (f+1)-row lower triangle, 256-row panel slabs, 64x64 tiles of the (b+1)-row update matrix
+hipError_t launch_dense_factor_level(const DevGraph& d, int level_begin, int level_count, const int* off_asm, int n_asm,
+                                     const int* off_pan, int n_pan, const int* off_trl, int n_trl, hipStream_t st);
 hipError_t launch_dense_solve_level(const DevGraph& d, int level_begin, int level_count, int level_max_b, hipStream_t st);
 
 // Largest front (scalars incl. rhs row) the LDS path of the factor kernel accepts.
