@@ -174,6 +174,8 @@ int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed);
  * memory (state shared), runs `iters` sweeps and returns mean kernel times (HIP events, seconds):
  * sec[0] = both launches, sec[1] = plane-edge launch alone, sec[2] = odometry launch alone; plus the
  * number of plane / odometry edges per sweep.  Used for the HBM roofline figure. */
+/* K1 of the handle's own graph, `iters` back-to-back launches on the solver's stream between two HIP events */
+int pps_time_linearize(pps_graph* g, int mode, int iters, double* sec_per_launch);
 int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double sec_per_sweep[3],
                     int64_t* n_plane_edges, int64_t* n_odo_edges);
 

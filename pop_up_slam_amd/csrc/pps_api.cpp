@@ -283,6 +283,9 @@ int run_analysis(pps_graph* g) {
   }
   if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
   if (const char* e = getenv("PPS_MAX_PIVOTS")) g->aprm.max_pivots = atoi(e);
+  // band depth: 3 levels per launch when the solve is latency bound (C2: 512 fronts), 2 when the lower levels are
+  // throughput bound (C3: 5 360 fronts; 637 vs 710 us per LM iteration)
+  g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 3;
   if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
   if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
@@ -926,11 +929,17 @@ int pps_update(pps_graph* g) {
   { PhaseTimer t(g, &g->stats.t_retract_chi2); HIP_TRY(g, launch_retract_apply(g->dev, g->stream)); }   // apply_exmap (:183)
   double chi2, dn; bool notpd;
   rc = read_result(g, true, &chi2, &dn, &notpd); if (rc != PPS_OK) return rc;
-  g->dev_values_newer = true;
   resolve_k1_events(g);
+  if (notpd) {
+    // the step is garbage: put the estimate back (lin still holds it) instead of handing NaNs to the caller
+    rc = copy_state(g, false); if (rc != PPS_OK) return rc;
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    g->stats.t_total = now_s() - t0;
+    return fail(g, PPS_ENOTPD, "normal equations not positive definite");
+  }
+  g->dev_values_newer = true;
   g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
   g->stats.t_total = now_s() - t0;
-  if (notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite");
   return PPS_OK;
 }
 
@@ -1234,6 +1243,23 @@ int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed) 
   for (const auto& f : g->factors) v.push_back(f.deleted ? -1 : (int32_t)(base[f.type] + (int64_t)f.slot * kJSize[f.type]));
   *needed = (int64_t)v.size();
   if (out && cap >= (int64_t)v.size()) memcpy(out, v.data(), v.size() * sizeof(int32_t));
+  return PPS_OK;
+}
+
+// K1 alone on the solver's stream: `iters` back-to-back sweeps of the handle's graph between two HIP events
+// (an event pair around ONE ~10 us launch also measures the command processor's event handling, about as long again)
+int pps_time_linearize(pps_graph* g, int mode, int iters, double* sec_per_launch) {
+  if (!g || iters < 1 || !sec_per_launch) return PPS_EINVAL;
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  for (int k = 0; k < 3; k++) HIP_TRY(g, launch_linearize(g->dev, mode, false, g->stream));
+  HIP_TRY(g, hipEventRecord(g->ev[0], g->stream));
+  for (int k = 0; k < iters; k++) HIP_TRY(g, launch_linearize(g->dev, mode, false, g->stream));
+  HIP_TRY(g, hipEventRecord(g->ev[1], g->stream));
+  HIP_TRY(g, hipEventSynchronize(g->ev[1]));
+  float ms = 0;
+  HIP_TRY(g, hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
+  *sec_per_launch = 1e-3 * ms / iters;
   return PPS_OK;
 }
 
