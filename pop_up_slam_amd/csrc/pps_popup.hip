@@ -13,7 +13,9 @@
 // (Mapper_mono::update_plane_measurement, pop_planar_slam/src/Mapping.cpp:590-607).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +27,7 @@ namespace pps {
 
 constexpr int kMaxPlanes = 64;
 constexpr int kMaxVerts = 512;
+constexpr int kMaxPxPerThread = 8;     // pixels per thread of k_popup_frame on large images
 
 // one wall plane from a ground segment; exact operation order of the reference (and of the oracle)
 __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
@@ -80,12 +83,13 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
                                                      int nplanes, const unsigned char* __restrict__ bgr,
                                                      float* __restrict__ planes_out, pps_point* __restrict__ cloud,
                                                      float* __restrict__ depth, int* __restrict__ plane_id,
-                                                     unsigned int* __restrict__ n_valid) {
+                                                     unsigned int* __restrict__ n_valid, int px_per_thread) {
   __shared__ float s_planes[kMaxPlanes + 1][4];
   __shared__ float s_poly[2 * kMaxVerts];
   __shared__ int s_off[kMaxPlanes + 2];
   __shared__ float s_ceil[4];
   __shared__ unsigned int s_cnt;
+  __shared__ float s_bbox[kMaxPlanes + 1][4];
   const int tid = threadIdx.x;
   // ---- K5: plane equations of this frame (every workgroup; block 0 publishes them) ----
   if (tid <= n && tid <= kMaxPlanes) {
@@ -114,75 +118,96 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
   for (int i = tid; i < 2 * nverts; i += 256) s_poly[i] = polys[i];
   __syncthreads();
 
-  const int idx = blockIdx.x * 256 + tid;
-  const int W = prm.width, H = prm.height;
-  bool keep = false;
-  if (idx < W * H) {
-    const int y = idx / W, x = idx - y * W;
-    int pid = -1;
-    if (prm.step == 1 || (((x | y) & 1) == 0)) {
-      const float fx = (float)x, fy = (float)y;
-      // ---- pixel -> plane: last convex polygon containing the pixel centre (edges inclusive) ----
-      for (int p = 0; p < nplanes; p++) {
-        const int v0 = s_off[p], v1 = s_off[p + 1];
-        if (v1 - v0 < 3) continue;
-        bool pos = true, neg = true;
-        for (int v = v0; v < v1; v++) {
-          const int w = (v + 1 < v1) ? v + 1 : v0;
-          const float ax = s_poly[2 * v], ay = s_poly[2 * v + 1];
-          const float bx = s_poly[2 * w], by = s_poly[2 * w + 1];
-          const float cr = (bx - ax) * (fy - ay) - (by - ay) * (fx - ax);
-          pos = pos && (cr >= 0.f);
-          neg = neg && (cr <= 0.f);
-        }
-        if (pos || neg) pid = p;
-      }
+  // bounding boxes (one pixel of slack: the inclusive cross-product test below decides, the box only skips
+  // polygons that are nowhere near the pixel)
+  if (tid < nplanes) {
+    const int v0 = s_off[tid], v1 = s_off[tid + 1];
+    float x0 = 3.0e38f, y0 = 3.0e38f, x1 = -3.0e38f, y1 = -3.0e38f;
+    for (int v = v0; v < v1; v++) {
+      x0 = fminf(x0, s_poly[2 * v]); x1 = fmaxf(x1, s_poly[2 * v]);
+      y0 = fminf(y0, s_poly[2 * v + 1]); y1 = fmaxf(y1, s_poly[2 * v + 1]);
     }
-    pps_point pt;
-    pt.x = pt.y = pt.z = 0.f;
-    pt.rgba = 0u;
-    float dep = 0.f;
-    if (pid >= 0) {
-      // ---- K6: ray-plane intersection (ray_plane_interact), world transform, filters ----
-      const float fx = (float)x, fy = (float)y;
-      const float* pl = s_planes[pid];
-      float ray[3];
-#pragma unroll
-      for (int i = 0; i < 3; i++) ray[i] = prm.invK[i * 3 + 0] * fx + prm.invK[i * 3 + 1] * fy + prm.invK[i * 3 + 2] * 1.f;
-      const float frac = -pl[3] / (pl[0] * ray[0] + pl[1] * ray[1] + pl[2] * ray[2]);
-      const float Ps[3] = {frac * ray[0], frac * ray[1], frac * ray[2]};
-      float Pw[3];
-#pragma unroll
-      for (int i = 0; i < 3; i++) Pw[i] = prm.T[i * 4 + 0] * Ps[0] + prm.T[i * 4 + 1] * Ps[1] + prm.T[i * 4 + 2] * Ps[2];
-#pragma unroll
-      for (int i = 0; i < 3; i++) Pw[i] += prm.T[i * 4 + 3];
-      keep = !(Ps[2] < 0.f) && !(Ps[2] > prm.depth_thre) && !(Pw[2] < -0.2f);
-      if (keep) {
-        pt.x = Pw[0]; pt.y = Pw[1];
-        pt.z = Pw[2] < prm.ceiling_thre ? Pw[2] : prm.ceiling_thre;
-        unsigned int rgb = 0u;
-        if (bgr) {
-          const unsigned char* c = bgr + 3 * (size_t)idx;
-          rgb = ((unsigned int)c[2] << 16) | ((unsigned int)c[1] << 8) | (unsigned int)c[0];
-        }
-        pt.rgba = (1u << 24) | rgb;
-      }
-      // depth map (get_depth_map_good): ceiling plane substituted above the ceiling threshold
-      if (Pw[2] < prm.ceiling_thre) {
-        if (!(Ps[2] < 0.f)) dep = Ps[2];
-      } else {
-        const float fc = -s_ceil[3] / (s_ceil[0] * ray[0] + s_ceil[1] * ray[1] + s_ceil[2] * ray[2]);
-        const float z = fc * ray[2];
-        if (!(z < 0.f)) dep = z;
-      }
-    }
-    cloud[idx] = pt;                     // one 16-byte store per lane
-    if (depth) depth[idx] = dep;
-    if (plane_id) plane_id[idx] = pid;
+    s_bbox[tid][0] = x0 - 1.f; s_bbox[tid][1] = y0 - 1.f; s_bbox[tid][2] = x1 + 1.f; s_bbox[tid][3] = y1 + 1.f;
   }
+  __syncthreads();
+
+  const int W = prm.width, H = prm.height;
+  unsigned int kept = 0;
+  // px_per_thread pixels per thread, 256 apart: on large images the plane / polygon set-up above is paid once per
+  // few thousand pixels; small images keep one or two so that the launch still covers the chip
+#pragma unroll 1
+  for (int it = 0; it < px_per_thread; it++) {
+    const int idx = (blockIdx.x * px_per_thread + it) * 256 + tid;
+    bool keep = false;
+    if (idx < W * H) {
+      const int y = idx / W, x = idx - y * W;
+      int pid = -1;
+      const float fx = (float)x, fy = (float)y;
+      if (prm.step == 1 || (((x | y) & 1) == 0)) {
+        // ---- pixel -> plane: LAST convex polygon containing the pixel centre (edges inclusive): scan backwards ----
+        for (int p = nplanes - 1; p >= 0; p--) {
+          const int v0 = s_off[p], v1 = s_off[p + 1];
+          if (v1 - v0 < 3) continue;
+          if (fx < s_bbox[p][0] || fy < s_bbox[p][1] || fx > s_bbox[p][2] || fy > s_bbox[p][3]) continue;
+          bool pos = true, neg = true;
+          for (int v = v0; v < v1; v++) {
+            const int w = (v + 1 < v1) ? v + 1 : v0;
+            const float ax = s_poly[2 * v], ay = s_poly[2 * v + 1];
+            const float bx = s_poly[2 * w], by = s_poly[2 * w + 1];
+            const float cr = (bx - ax) * (fy - ay) - (by - ay) * (fx - ax);
+            pos = pos && (cr >= 0.f);
+            neg = neg && (cr <= 0.f);
+          }
+          if (pos || neg) { pid = p; break; }
+        }
+      }
+      pps_point pt;
+      pt.x = pt.y = pt.z = 0.f;
+      pt.rgba = 0u;
+      float dep = 0.f;
+      if (pid >= 0) {
+        // ---- K6: ray-plane intersection (ray_plane_interact), world transform, filters ----
+        const float* pl = s_planes[pid];
+        float ray[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) ray[i] = prm.invK[i * 3 + 0] * fx + prm.invK[i * 3 + 1] * fy + prm.invK[i * 3 + 2] * 1.f;
+        const float frac = -pl[3] / (pl[0] * ray[0] + pl[1] * ray[1] + pl[2] * ray[2]);
+        const float Ps[3] = {frac * ray[0], frac * ray[1], frac * ray[2]};
+        float Pw[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) Pw[i] = prm.T[i * 4 + 0] * Ps[0] + prm.T[i * 4 + 1] * Ps[1] + prm.T[i * 4 + 2] * Ps[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) Pw[i] += prm.T[i * 4 + 3];
+        keep = !(Ps[2] < 0.f) && !(Ps[2] > prm.depth_thre) && !(Pw[2] < -0.2f);
+        if (keep) {
+          pt.x = Pw[0]; pt.y = Pw[1];
+          pt.z = Pw[2] < prm.ceiling_thre ? Pw[2] : prm.ceiling_thre;
+          unsigned int rgb = 0u;
+          if (bgr) {
+            const unsigned char* c = bgr + 3 * (size_t)idx;
+            rgb = ((unsigned int)c[2] << 16) | ((unsigned int)c[1] << 8) | (unsigned int)c[0];
+          }
+          pt.rgba = (1u << 24) | rgb;
+        }
+        // depth map (get_depth_map_good): ceiling plane substituted above the ceiling threshold
+        if (Pw[2] < prm.ceiling_thre) {
+          if (!(Ps[2] < 0.f)) dep = Ps[2];
+        } else {
+          const float fc = -s_ceil[3] / (s_ceil[0] * ray[0] + s_ceil[1] * ray[1] + s_ceil[2] * ray[2]);
+          const float z = fc * ray[2];
+          if (!(z < 0.f)) dep = z;
+        }
+      }
+      cloud[idx] = pt;                     // one 16-byte store per lane
+      if (depth) depth[idx] = dep;
+      if (plane_id) plane_id[idx] = pid;
+    }
+    kept += (unsigned int)__popcll(__ballot(keep));
+  }
+  const bool keep = false;
+  (void)keep;
   // ---- count kept points: wave ballot, one LDS atomic per wave, one global atomic per block ----
-  const unsigned long long m = __ballot(keep);
-  if ((tid & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned int)__popcll(m));
+  if ((tid & 63) == 0 && kept) atomicAdd(&s_cnt, kept);
   __syncthreads();
   if (tid == 0 && s_cnt) atomicAdd(n_valid, s_cnt);
 }
@@ -354,8 +379,11 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   PHIP(p, hipMemsetAsync(p->d_count, 0, sizeof(unsigned int), p->stream));
   const int npx = p->width * p->height;
   PHIP(p, hipEventRecord(p->ev[0], p->stream));
-  hipLaunchKernelGGL(k_popup_frame, dim3((npx + 255) / 256), dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
-                     p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->d_depth, p->d_pid, p->d_count);
+  // enough workgroups to cover 256 CUs a few times over, then more pixels per thread
+  int pxt = std::max(1, std::min(kMaxPxPerThread, npx / (256 * 600)));   // 640x480 -> 2, 1080p and up -> 8
+  if (const char* e = getenv("PPS_POPUP_PXT")) pxt = std::max(1, std::min(64, atoi(e)));
+  hipLaunchKernelGGL(k_popup_frame, dim3((npx + 256 * pxt - 1) / (256 * pxt)), dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
+                     p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->d_depth, p->d_pid, p->d_count, pxt);
   PHIP(p, hipGetLastError());
   PHIP(p, hipEventRecord(p->ev[1], p->stream));
   PHIP(p, hipMemcpyAsync(p->h_count, p->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, p->stream));
