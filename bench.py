@@ -238,6 +238,23 @@ def main():
             out["other_mode"] = {"jacobian_mode": "analytic" if other == P.JAC_ANALYTIC else "numeric",
                                  "value": it2 / e2, "unit": "LM iters/s", "final_chi2": g2.chi2()}
         if world == 1:
+            # K3 (the kernels most of a solve's device time goes to): flops of one multifrontal factorisation against the
+            # fp64 MFMA peak.  The fronts are <= 51 rows on a 10-level tree, so this is a dependency chain (tree depth x
+            # per-front latency), not a throughput kernel -- the fraction says how far from a compute bound it sits.
+            A = g.analysis_dump()
+            fl = 0
+            for p_, b_ in zip(A["f_p"].tolist(), A["f_b"].tolist()):
+                fa = p_ + b_ + 1
+                for k in range(p_):
+                    fl += (fa - k - 1) * (fa - k) + (fa - k - 1)
+            g.restore_state(); g.set_profiling(2); g.batch_optimize(); st2 = g.stats(); g.set_profiling(1)
+            t_fac = st2["t_factor"] / max(1, st2["n_factorize"])
+            out["roofline_k3"] = {"bound": "mfma", "kernel": "k_band_factor (one factorisation = %d launches)" % int(A["n_stages"]),
+                                  "achieved": fl / t_fac / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / t_fac / 1e12 / 78.6,
+                                  "flops_per_factorisation": fl, "us_per_factorisation": 1e6 * t_fac,
+                                  "us_per_backsolve": 1e6 * st2["t_backsolve"] / max(1, st2["n_factorize"]),
+                                  "note": "latency bound by construction (512 fronts of <= 51 rows, 10 levels); peak = fp64 matrix "
+                                          "rate of MI355X (public spec; the CDNA4 guide lists none)"}
             # headroom on one GPU: one C2 solve keeps a few dozen of the 256 CUs busy, so independent graphs (one handle
             # + one host thread each, no shared state) overlap.  Reported next to the headline, which stays the
             # one-graph-per-GPU configuration BASELINE.json names.

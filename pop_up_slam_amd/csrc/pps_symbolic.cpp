@@ -32,17 +32,26 @@ struct Builder {
       : nodes(n), factors(f), prm(p), N((int)n.size()) {}
 
   void build_adjacency() {
-    std::vector<std::pair<int, int>> e;
-    e.reserve(factors.size() * 2);
+    // CSR of the undirected node graph, neighbours sorted and unique: counting sort on the first end point, small
+    // sorts inside each row
+    std::vector<int> cnt(N + 1, 0);
     for (const auto& f : factors)
-      if (f.b >= 0 && f.a != f.b) { e.emplace_back(f.a, f.b); e.emplace_back(f.b, f.a); }
-    std::sort(e.begin(), e.end());
-    e.erase(std::unique(e.begin(), e.end()), e.end());
+      if (f.b >= 0 && f.a != f.b) { cnt[f.a + 1]++; cnt[f.b + 1]++; }
+    for (int i = 0; i < N; i++) cnt[i + 1] += cnt[i];
+    std::vector<int> raw(cnt[N]), fill(cnt.begin(), cnt.end() - 1);
+    for (const auto& f : factors)
+      if (f.b >= 0 && f.a != f.b) { raw[fill[f.a]++] = f.b; raw[fill[f.b]++] = f.a; }
     adj_off.assign(N + 1, 0);
-    for (auto& p : e) adj_off[p.first + 1]++;
-    for (int i = 0; i < N; i++) adj_off[i + 1] += adj_off[i];
-    adj.resize(e.size());
-    for (size_t i = 0; i < e.size(); i++) adj[i] = e[i].second;   // already grouped & sorted by first
+    adj.clear();
+    adj.reserve(raw.size());
+    for (int u = 0; u < N; u++) {
+      int* b = raw.data() + cnt[u];
+      int* e = raw.data() + cnt[u + 1];
+      std::sort(b, e);
+      e = std::unique(b, e);
+      adj.insert(adj.end(), b, e);
+      adj_off[u + 1] = (int)adj.size();
+    }
   }
   int degree(int u) const { return adj_off[u + 1] - adj_off[u]; }
 
@@ -413,6 +422,11 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
     // packed update matrix of c -> packed index in the parent front
     A.f_ea_off.assign(F + 1, 0);
     A.ea_tgt.clear();
+    {
+      size_t total = 0;
+      for (int s = 0; s < F; s++) total += cm[s].size() * (cm[s].size() + 1) / 2;
+      A.ea_tgt.reserve(total);
+    }
     for (int s = 0; s < F; s++) {
       A.f_ea_off[s] = (int64_t)A.ea_tgt.size();
       const std::vector<int>& m = cm[s];    // empty for the root
