@@ -74,7 +74,7 @@ struct pps_graph {
   // dense-front work lists: per level a prefix sum over its fronts (count+1 entries at level_off[l] + l)
   std::vector<int> dw_asm, dw_pan, dw_trl;
   int *d_dw_asm = nullptr, *d_dw_pan = nullptr, *d_dw_trl = nullptr;
-  std::vector<int> stage_max_piv, stage_nw_factor, stage_nw_solve;
+  std::vector<int> stage_max_piv, stage_nw_factor, stage_nw_solve, stage_max_grp_fronts, stage_max_panel;
   // device
   bool dev_ready = false;
   hipStream_t stream = nullptr;
@@ -332,13 +332,20 @@ int run_analysis(pps_graph* g) {
         }
       }
     g->stage_nw_factor.assign(A.n_stages, 1); g->stage_nw_solve.assign(A.n_stages, 1);
+    g->stage_max_grp_fronts.assign(A.n_stages, 1); g->stage_max_panel.assign(A.n_stages, 1);
+    for (int s = 0; s < A.n_fronts; s++) { int& m = g->stage_max_panel[A.f_level[s] / Bn]; m = std::max(m, (A.f_p[s] + A.f_b[s] + 1) * A.f_p[s]); }
     const size_t lds_budget = 150 * 1024;
     int max_waves = 8;
     if (const char* e = getenv("PPS_BAND_WAVES")) max_waves = std::max(1, std::min(8, atoi(e)));
     for (int st = 0; st < A.n_stages; st++) {
       const int want = std::max(1, std::min(max_waves, A.stage_max_width[st]));
       g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st])));
-      g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_solve_lds_bytes(g->stage_max_piv[st])));
+      int mg = 1;
+      for (int gi = A.stage_grp_off[st]; gi < A.stage_grp_off[st + 1]; gi++)
+        mg = std::max(mg, A.glvl_front_off[A.grp_lvl_off[gi + 1]] - A.glvl_front_off[A.grp_lvl_off[gi]]);
+      g->stage_max_grp_fronts[st] = mg;
+      const size_t xbytes = (size_t)mg * band_max_rows() * sizeof(double);
+      g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, (lds_budget - std::min(lds_budget / 2, xbytes)) / band_solve_lds_bytes(g->stage_max_panel[st])));
     }
   }
   g->analyzed = true;
@@ -591,20 +598,41 @@ int do_linearize(pps_graph* g) {
 }
 
 // delta = (J'J + lambda diag(J'J))^-1 J'b  (Optimizer::compute_gauss_newton_step, Optimizer.cpp:49-67)
+// The root stage (one group) is factored and back-substituted in one launch; its LDS must fit both phases with the
+// factor's wave count.
+static bool root_fusable(const pps_graph* g) {
+  const Analysis& A = g->an;
+  const int st = A.n_stages - 1;
+  if (st < 0 || !getenv("PPS_ROOT_FUSE")) return false;      // opt-in: measured neutral on C2 / C3 (121.5 vs 120.5 us per iteration)
+  const size_t need = band_solve_lds_bytes(g->stage_max_panel[st]) * g->stage_nw_factor[st] +
+                      (size_t)g->stage_max_grp_fronts[st] * band_max_rows() * sizeof(double);
+  return need <= 150 * 1024;
+}
+
 int do_solve_on(pps_graph* g, const DevGraph& dv, double lambda, hipStream_t st_) {
   const Analysis& A = g->an;
-  for (int st = 0; st < A.n_stages; st++)
+  const bool fuse = root_fusable(g);
+  for (int st = 0; st < A.n_stages; st++) {
+    const bool last = fuse && st == A.n_stages - 1;
     HIP_TRY(g, launch_band_factor(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
-                                  A.stage_max_front[st], lambda, st_));
-  for (int st = A.n_stages - 1; st >= 0; st--)
+                                  A.stage_max_front[st], lambda, st_, last ? g->stage_max_panel[st] : 0,
+                                  last ? g->stage_max_grp_fronts[st] : 0));
+  }
+  for (int st = A.n_stages - 1 - (fuse ? 1 : 0); st >= 0; st--)
     HIP_TRY(g, launch_band_solve(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
-                                 g->stage_max_piv[st], st_));
+                                 g->stage_max_panel[st], g->stage_max_grp_fronts[st], st_));
   return PPS_OK;
 }
 
 int do_solve(pps_graph* g, double lambda) {
   const Analysis& A = g->an;
   if (g->use_band) {
+    if (g->profiling < 2) {            // no per-phase timing: root stage fused (factor + solve in one launch)
+      int rc = do_solve_on(g, g->dev, lambda, g->stream);
+      if (rc != PPS_OK) return rc;
+      g->stats.n_factorize++;
+      return PPS_OK;
+    }
     {
       PhaseTimer t(g, &g->stats.t_factor);
       for (int st = 0; st < A.n_stages; st++)
@@ -615,7 +643,7 @@ int do_solve(pps_graph* g, double lambda) {
       PhaseTimer t(g, &g->stats.t_backsolve);
       for (int st = A.n_stages - 1; st >= 0; st--)
         HIP_TRY(g, launch_band_solve(g->dev, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
-                                     g->stage_max_piv[st], g->stream));
+                                     g->stage_max_panel[st], g->stage_max_grp_fronts[st], g->stream));
     }
     g->stats.n_factorize++;
     return PPS_OK;

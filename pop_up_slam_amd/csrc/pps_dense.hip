@@ -179,10 +179,10 @@ __global__ __launch_bounds__(256) void k_dense_panel(DevGraph d, int level_begin
       if (lane == 0) { rinv[K] = i0; if (nb > 1) rinv[K + 1] = i1; if (nb > 2) rinv[K + 2] = i2; if (nb > 3) rinv[K + 3] = i3; }
       __builtin_amdgcn_wave_barrier();
       switch (tjK) {
-        case 0: reg_trailing<0>(c, P, nb, lane); break;
-        case 1: reg_trailing<1>(c, P, nb, lane); break;
-        case 2: reg_trailing<2>(c, P, nb, lane); break;
-        default: reg_trailing<3>(c, P, nb, lane); break;
+        case 0: reg_trailing<0>(c, P, nb, lane, (K + 4) >> 4); break;
+        case 1: reg_trailing<1>(c, P, nb, lane, (K + 4) >> 4); break;
+        case 2: reg_trailing<2>(c, P, nb, lane, (K + 4) >> 4); break;
+        default: reg_trailing<3>(c, P, nb, lane, (K + 4) >> 4); break;
       }
       __builtin_amdgcn_wave_barrier();
     }

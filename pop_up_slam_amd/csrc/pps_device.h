@@ -79,9 +79,12 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
                                hipStream_t st);
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);
 // wave-per-front band kernels: one workgroup per group of the stage, `nwaves` fronts in flight per workgroup
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st);
-hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_piv, hipStream_t st);
-size_t band_solve_lds_bytes(int max_piv);
+// fused_solve_panel > 0: the back-substitution of the same groups follows inside the launch (used for the root stage)
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
+                              int fused_solve_panel = 0, int fused_solve_group_fronts = 0);
+hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st);
+int band_max_rows();
+size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
 size_t band_lds_bytes(int max_front);           // LDS bytes one wave needs for the factor kernel
 // est <- lin ; lin <- lin (+) delta          (LM trial: Optimizer.cpp:414-416)

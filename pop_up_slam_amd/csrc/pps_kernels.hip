@@ -784,6 +784,7 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
 constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
 
 int band_front_limit() { return kBandMaxRows - 1; }
+int band_max_rows() { return kBandMaxRows; }
 size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return (fa * (fa + 1) / 2 + 64 * 5) * sizeof(double); }   // packed triangle + panel buffer
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
@@ -1091,10 +1092,10 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     __builtin_amdgcn_wave_barrier();
     const long long tk1 = d.trace ? clock64() : 0;
     switch (tjK) {
-      case 0: reg_trailing<0>(c, P, nb, lane); break;
-      case 1: reg_trailing<1>(c, P, nb, lane); break;
-      case 2: reg_trailing<2>(c, P, nb, lane); break;
-      default: reg_trailing<3>(c, P, nb, lane); break;
+      case 0: reg_trailing<0>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 1: reg_trailing<1>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 2: reg_trailing<2>(c, P, nb, lane, (K + 4) >> 4); break;
+      default: reg_trailing<3>(c, P, nb, lane, (K + 4) >> 4); break;
     }
     __builtin_amdgcn_wave_barrier();
     if (d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
@@ -1115,7 +1116,82 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   PPS_TR(5);
 }
 
-__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave) {
+
+// x_p = L_A^-T (y - L_B^T x_b) for one front, one wave (p <= 64).  The factor panel ((f+1) x p, contiguous) is
+// copied to LDS in batches of 16 independent coalesced loads per lane -- two round trips for a C2 front instead of one
+// per 8 rows -- and everything after that reads LDS; the back-substitution chain runs in registers (lane j holds
+// t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + the panel.
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
+  const int lane = threadIdx.x & 63;
+  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
+  const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
+  const int pslot = __builtin_amdgcn_readlane(rec, 14);
+  // boundary values: from the parent's local solution vector in LDS (through cmap) when the parent was solved by this
+  // workgroup, else gathered from delta.  The index load does not depend on the parent and is issued first.
+  const int* __restrict__ ix = pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8);
+  double* xb = W;
+  double* PL = W + kBandMaxRows;
+  const int ix0 = lane < b ? ix[lane] : 0, ix1 = lane + 64 < b ? ix[lane + 64] : 0;
+  double g0 = 0.0, g1 = 0.0;
+  if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }          // clamped index 0 when out of range: harmless
+  const int n = (f + 1) * p;
+  for (int e0 = 0; e0 < n; e0 += 64 * 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; v[u] = Lp[e < n ? e : n - 1]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; if (e < n) PL[e] = v[u]; }
+  }
+  if (pslot >= 0) {
+    const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows;
+    g0 = Xp[ix0]; g1 = Xp[ix1];
+  }
+  if (lane < b) xb[lane] = g0;
+  if (lane + 64 < b) xb[lane + 64] = g1;
+  __builtin_amdgcn_wave_barrier();
+  double tj = 0.0, dinv = 0.0;
+  if (lane < p) {
+    double acc = PL[f * p + lane];
+    const double* __restrict__ lb = PL + p * p + lane;
+#pragma unroll 4
+    for (int i = 0; i < b; i++) acc -= lb[i * p] * xb[i];
+    tj = acc;
+    dinv = 1.0 / PL[lane * p + lane];
+  }
+#pragma unroll 4
+  for (int k = p - 1; k >= 0; k--) {
+    const double lkj = (lane < k) ? PL[k * p + lane] : 0.0;      // independent of the chain
+    const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
+    tj = (lane == k) ? xk : tj - lkj * xk;
+  }
+  if (lane < p) d.delta[__builtin_amdgcn_readlane(rec, 7) + lane] = tj;
+  // own local solution [x_p | x_b] for the children inside this group
+  double* __restrict__ Xs = X + (size_t)slot * kBandMaxRows;
+  if (lane < p) Xs[lane] = tj;
+  if (lane < b) Xs[p + lane] = g0;
+  if (lane + 64 < b) Xs[p + lane + 64] = g1;
+}
+
+__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  const int g = grp_begin + blockIdx.x;
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* W = lds + (size_t)wave * lds_doubles_per_wave;
+  double* X = lds + (size_t)nw * lds_doubles_per_wave;          // one local solution vector per front of the group
+  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
+  const int g0 = d.glvl_front_off[l0];
+  for (int l = l1 - 1; l >= l0; l--) {
+    const int i1 = d.glvl_front_off[l + 1];
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+      wave_front_solve(d, rec, W, X, i - g0);
+    }
+    __syncthreads();   // delta of this local level is visible to the children
+  }
+}
+
+__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave,
+                                                     int solve_doubles_per_wave) {
   extern __shared__ double lds[];
   const int g = grp_begin + blockIdx.x;
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -1132,64 +1208,27 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
   }
-}
-
-// x_p = L_A^-T (y - L_B^T x_b) for one front, one wave (p <= 64).  All global loads are issued in
-// batches that do not depend on each other; the back-substitution chain itself runs in registers
-// (lane j holds t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + packed L_A.
-__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W) {
-  const int lane = threadIdx.x & 63;
-  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
-  const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
-  const int* __restrict__ bi = d.bidx + __builtin_amdgcn_readlane(rec, 8);
-  double* xb = W;
-  double* LA = W + kBandMaxRows;
-  for (int i = lane; i < b; i += 64) xb[i] = d.delta[bi[i]];
-  // stage L_A (packed lower triangle): p independent coalesced row loads
-  for (int i0 = 0; i0 < p; i0 += 8) {                     // unconditional (clamped) loads: 8 rows in flight
-    double x[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = i0 + u < p ? i0 + u : p - 1; x[u] = Lp[(size_t)i * p + (lane <= i ? lane : 0)]; }
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = i0 + u; if (i < p && lane <= i) LA[tri(i) + lane] = x[u]; }
-  }
-  __builtin_amdgcn_wave_barrier();
-  double tj = 0.0, dinv = 0.0;
-  if (lane < p) {
-    double acc = Lp[(size_t)f * p + lane];
-#pragma unroll 8
-    for (int i = 0; i < b; i++) acc -= Lp[(size_t)(p + i) * p + lane] * xb[i];
-    tj = acc;
-    dinv = 1.0 / LA[tri(lane) + lane];
-  }
-#pragma unroll 4
-  for (int k = p - 1; k >= 0; k--) {
-    const double lkj = (lane < k) ? LA[tri(k) + lane] : 0.0;     // independent of the chain
-    const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
-    tj = (lane == k) ? xk : tj - lkj * xk;
-  }
-  if (lane < p) d.delta[__builtin_amdgcn_readlane(rec, 7) + lane] = tj;
-}
-
-__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, int lds_doubles_per_wave) {
-  extern __shared__ double lds[];
-  const int g = grp_begin + blockIdx.x;
-  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
-  double* W = lds + (size_t)wave * lds_doubles_per_wave;
-  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
-  for (int l = l1 - 1; l >= l0; l--) {
-    const int i1 = d.glvl_front_off[l + 1];
-    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
-      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
-      wave_front_solve(d, rec, W);
+  // root stage: the back-substitution of the same group follows at once (one launch less per solve); the factor's
+  // LDS is dead by now and is re-partitioned for the solve
+  if (solve_doubles_per_wave > 0) {
+    double* W = lds + (size_t)wave * solve_doubles_per_wave;
+    double* X = lds + (size_t)nw * solve_doubles_per_wave;
+    const int g0 = d.glvl_front_off[l0];
+    for (int l = l1 - 1; l >= l0; l--) {
+      const int i1 = d.glvl_front_off[l + 1];
+      for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+        const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+        wave_front_solve(d, rec, W, X, i - g0);
+      }
+      __syncthreads();
     }
-    __syncthreads();   // delta of this local level is visible to the children
   }
 }
 
 static bool g_band_attr_set[64] = {false};   // per device ordinal
 
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st) {
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
+                              int fused_solve_panel, int fused_solve_group_fronts) {
   if (grp_count == 0) return hipSuccess;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1200,17 +1239,24 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     g_band_attr_set[dev & 63] = true;
   }
   const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
-  hipLaunchKernelGGL(k_band_factor, dim3(grp_count), dim3(64 * nwaves), (size_t)per_wave * nwaves * sizeof(double), st, d, grp_begin, lambda, per_wave);
+  size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
+  int solve_per_wave = 0;
+  if (fused_solve_panel > 0) {       // the stage's back-substitution runs in the same launch (root stage)
+    solve_per_wave = (int)(band_solve_lds_bytes(fused_solve_panel) / sizeof(double));
+    bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
+  }
+  hipLaunchKernelGGL(k_band_factor, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, solve_per_wave);
   return hipGetLastError();
 }
 
-size_t band_solve_lds_bytes(int max_piv) { return (size_t)(kBandMaxRows + max_piv * (max_piv + 1) / 2) * sizeof(double); }
+size_t band_solve_lds_bytes(int max_panel) { return (size_t)(kBandMaxRows + max_panel) * sizeof(double); }   // xb + the factor panel
 
-hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_piv, hipStream_t st) {
+hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st) {
   if (grp_count == 0) return hipSuccess;
-  // t + xb + packed L_A (at most max_piv pivots)
-  const int per_wave = (int)(band_solve_lds_bytes(max_piv) / sizeof(double));
-  hipLaunchKernelGGL(k_band_solve, dim3(grp_count), dim3(64 * nwaves), (size_t)per_wave * nwaves * sizeof(double), st, d, grp_begin, per_wave);
+  // per wave: xb + the largest factor panel of the stage; per workgroup: one local solution vector per front of a group
+  const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
+  hipLaunchKernelGGL(k_band_solve, dim3(grp_count), dim3(64 * nwaves),
+                     ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double), st, d, grp_begin, per_wave);
   return hipGetLastError();
 }
 

@@ -40,19 +40,39 @@ __device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[10], doub
   }
 }
 
+// Rank-nb update of every live tile.  The tiles of the NEXT panel's tile column (TJN = TJ or TJ+1) are issued first:
+// the next iteration extracts its panel from them and then spends ~1000 cycles of VALU / LDS work on the panel
+// factorisation, during which the remaining (independent) MFMAs drain in the matrix core instead of being waited for.
 template <int TJ>
-__device__ __forceinline__ void reg_trailing(double4_t (&c)[10], const double* __restrict__ P, int nb, int lane) {
+__device__ __forceinline__ void reg_trailing(double4_t (&c)[10], const double* __restrict__ P, int nb, int lane, int tjn = TJ) {
   const int l16 = lane & 15, lq = lane >> 4;
   const bool kvalid = lq < nb;
   double opnd[4];
 #pragma unroll
   for (int t = TJ; t < 4; t++) { const double x = P[(16 * t + l16) * kPStride + lq]; opnd[t] = kvalid ? x : 0.0; }
+  if (tjn == TJ) {
 #pragma unroll
-  for (int ti = TJ; ti < 4; ti++)
+    for (int ti = TJ; ti < 4; ti++)
+      c[tile_id(ti, TJ)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[TJ], c[tile_id(ti, TJ)], 0, 0, 0);
 #pragma unroll
-    for (int tj = TJ; tj <= ti; tj++)
-      c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
+    for (int ti = TJ + 1; ti < 4; ti++)
+#pragma unroll
+      for (int tj = TJ + 1; tj <= ti; tj++)
+        c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
+  } else {
+    if (TJ + 1 < 4) {
+#pragma unroll
+      for (int ti = TJ + 1; ti < 4; ti++)
+        c[tile_id(ti, TJ + 1 < 4 ? TJ + 1 : 3)] =
+            __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[TJ + 1 < 4 ? TJ + 1 : 3], c[tile_id(ti, TJ + 1 < 4 ? TJ + 1 : 3)], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = TJ; ti < 4; ti++)
+#pragma unroll
+      for (int tj = TJ; tj <= ti; tj++)
+        if (tj != TJ + 1)
+          c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
+  }
 }
-
 
 }  // namespace pps

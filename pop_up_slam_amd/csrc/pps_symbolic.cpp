@@ -591,6 +591,22 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
         r[9] = (int)(A.f_Loff[s2] & 0xffffffffLL); r[10] = (int)(A.f_Loff[s2] >> 32);
         r[11] = (int)(A.f_Uoff[s2] & 0xffffffffLL); r[12] = (int)(A.f_Uoff[s2] >> 32);
         r[13] = (A.f_b[s2] + 1) * (A.f_b[s2] + 2) / 2;
+        // solve hand-down: a front whose parent sits in the same group reads its boundary values from the parent's
+        // local solution vector (LDS) through cmap instead of gathering them from delta
+        r[14] = -1;
+        r[15] = A.f_cmap_off[s2];
+        {
+          const int par = A.f_parent[s2];
+          const int Bn2 = std::max(1, prm.band_levels);
+          if (par >= 0 && A.f_level[par] / Bn2 == A.f_level[s2] / Bn2) {
+            // slot = position inside the group (groups are contiguous in glvl_fronts: first position of the group's
+            // first local level)
+            const int ip = pos_of[par];
+            const int l = (int)(std::upper_bound(A.glvl_front_off.begin(), A.glvl_front_off.end(), ip) - A.glvl_front_off.begin()) - 1;
+            const int g2 = (int)(std::upper_bound(A.grp_lvl_off.begin(), A.grp_lvl_off.end(), l) - A.grp_lvl_off.begin()) - 1;
+            r[14] = ip - A.glvl_front_off[A.grp_lvl_off[g2]];
+          }
+        }
         for (int ci = A.f_child_off[s2]; ci < A.f_child_off[s2 + 1]; ci++) {
           const int c = A.child[ci];
           const int bc1 = A.f_b[c] + 1;

@@ -85,7 +85,9 @@ struct Analysis {
   // ---- packed metadata records: one coalesced load per wave instead of a chain of dependent loads ----
   // frec: 16 ints per front, in band-schedule order (index = position in glvl_fronts):
   //   0 front id, 1 p, 2 b, 3 el_off0, 4 el_off1, 5 first child record, 6 child count, 7 poff, 8 bidx_off,
-  //   9/10 Loff lo/hi, 11/12 Uoff lo/hi, 13 number of packed entries of the own update matrix
+  //   9/10 Loff lo/hi, 11/12 Uoff lo/hi, 13 number of packed entries of the own update matrix,
+  //   14 position of the parent inside the group (counted from the group's first front) when it belongs to the same
+  //   group (else -1), 15 cmap_off
   // crec: 8 ints per child edge: 0 packed entries of the child's update matrix, 1/2 its Uoff lo/hi, 3/4 its ea_off lo/hi
   // srec: 8 ints per H segment: 0 rows, 1 cols, 2 size, 3 c0, 4 cnt, 5 hoff (segment slot), 6 blk_doff, 7 nseg of the block
   std::vector<int> frec, crec, srec;

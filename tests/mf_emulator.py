@@ -133,10 +133,27 @@ def solve_with_band_schedule(A, Jbuf, lam):
                     done.add(s)
     assert len(done) == A["n_fronts"]
     delta = np.zeros(A["n_scalars"])
+    # back-substitution with the hand-down of the solve kernel: a front whose parent is in the same group takes its
+    # boundary values from the parent's local solution vector [x_p | x_b] through cmap (record fields 14, 15)
+    glo = A["glvl_front_off"]
+    xloc = {}
     for i in reversed(order):
         r = frec[i]
         s, p, b, poff, boff = r[0], r[1], r[2], r[7], r[8]
         L = Lst[s]
-        t = L[p + b, :] - L[p:p + b, :].T @ delta[A["bidx"][boff:boff + b]]
-        delta[poff:poff + p] = np.linalg.solve(L[:p, :].T, t)
+        xb_ref = delta[A["bidx"][boff:boff + b]]
+        if r[14] >= 0:
+            lvl = int(np.searchsorted(glo, i, side="right")) - 1          # own local level -> group -> its first position
+            grp = int(np.searchsorted(A["grp_lvl_off"], lvl, side="right")) - 1
+            par_pos = glo[A["grp_lvl_off"][grp]] + r[14]
+            assert par_pos > i and frec[par_pos][0] == A["f_parent"][s]
+            cm = A["cmap"][r[15]:r[15] + b]
+            xb = xloc[par_pos][cm]
+            assert np.array_equal(xb, xb_ref), (i, s)
+        else:
+            xb = xb_ref
+        t = L[p + b, :] - L[p:p + b, :].T @ xb
+        xp = np.linalg.solve(L[:p, :].T, t)
+        delta[poff:poff + p] = xp
+        xloc[i] = np.concatenate([xp, xb])
     return delta
