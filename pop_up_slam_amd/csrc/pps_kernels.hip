@@ -591,15 +591,16 @@ __global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
   const int j = is_g ? 0 : lane - (lane / cols) * cols;
   const double* __restrict__ J = d.J;
   double acc = 0.0;
-  for (int c = 0; c < cnt; c += 4) {
+  int c = 0;
+  for (; c + 4 <= cnt; c += 4) {                          // four contributions' loads in flight
     double a[4][6], bb[4][6];
     int m[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int cc = c + u < cnt ? c + u : cnt - 1;      // clamp: the tail re-reads a valid descriptor, weight 0 below
+      const int cc = c + u;
       const int jv = __builtin_amdgcn_readlane(mine.x, cc), ju = __builtin_amdgcn_readlane(mine.y, cc);
       const int ro = __builtin_amdgcn_readlane(mine.z, cc);
-      m[u] = c + u < cnt ? __builtin_amdgcn_readlane(mine.w, cc) : 0;
+      m[u] = __builtin_amdgcn_readlane(mine.w, cc);
       const double* pa = J + jv + i;
       const double* pb = is_g ? J + ro : J + ju + j;
       const int sb = is_g ? 1 : cols;
@@ -614,6 +615,22 @@ __global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
     for (int u = 0; u < 4; u++)
 #pragma unroll
       for (int k = 0; k < 6; k++) acc += a[u][k] * bb[u][k];
+  }
+  for (; c < cnt; c++) {                                  // tail, and the single-contribution segments (most pose-plane blocks)
+    const int jv = __builtin_amdgcn_readlane(mine.x, c), ju = __builtin_amdgcn_readlane(mine.y, c);
+    const int ro = __builtin_amdgcn_readlane(mine.z, c), mm = __builtin_amdgcn_readlane(mine.w, c);
+    const double* pa = J + jv + i;
+    const double* pb = is_g ? J + ro : J + ju + j;
+    const int sb = is_g ? 1 : cols;
+    double a[6], bb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const bool ok = act && k < mm;
+      a[k] = ok ? pa[k * rows] : 0.0;
+      bb[k] = ok ? pb[k * sb] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc += a[k] * bb[k];
   }
   if (!act) return;
   if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
