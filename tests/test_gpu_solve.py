@@ -122,3 +122,32 @@ def test_c4_independent_seeds(built):
             assert all(b <= a for a, b in zip(acc, acc[1:]))
         else:
             assert abs(c - co) <= 1e-5 * abs(co), (rank, it, ito, c, co)
+
+
+def test_mid_and_large_graphs(built):
+    """5 000 poses against the oracle (dead reckoning drifts over this length: the first LM trials are all rejected --
+    on both sides, trial for trial); then 50 000 poses / 250 000 plane edges (50x C2, minutes for the oracle) through
+    size-independent properties: LM never increases chi2, the result is finite and self-consistent."""
+    spec = synth.corridor(5000, 1000, seed=7)
+    g, o, *_ = _pair(spec)
+    it, ito = g.batch_optimize(), o.batch_optimize()
+    c, co = g.chi2(), o.chi2()
+    print("5k poses: gpu chi2 %.12g (%d it) oracle %.12g (%d it)" % (c, it, co, ito))
+    assert it == ito and abs(c - co) <= 1e-5 * co
+    for (lam, chi, acc), (lo, cho, aco) in zip(g.trace(), o.trace()):
+        assert acc == aco and lam == lo and abs(chi - cho) <= 1e-6 * cho
+
+    spec = synth.corridor(50000, 10000, seed=7)
+    g = P.Graph(); spec.replay(g)
+    c0 = g.chi2()
+    it = g.batch_optimize()
+    c1 = g.chi2()
+    st = g.stats()
+    tr = g.trace()
+    print("50k poses: chi2 %.6g -> %.6g in %d LM trials (%d fronts, %d levels, max front %d), %.2f ms per trial"
+          % (c0, c1, it, st["n_fronts"], st["n_levels"], st["max_front"], 1e3 * st["t_total"] / max(1, it)))
+    assert it == len(tr) >= 1 and np.isfinite(c1) and c1 <= c0 * (1 + 1e-12)
+    acc = [c0] + [chi for (_lam, chi, ok) in tr if ok]
+    assert all(b <= a for a, b in zip(acc, acc[1:]))
+    assert abs(acc[-1] - c1) <= 1e-9 * c1                  # the state left behind is the last accepted one
+    assert st["n_fronts"] > 20000 and st["max_front"] <= 64
