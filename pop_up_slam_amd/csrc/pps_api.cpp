@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -289,7 +290,9 @@ int run_analysis(pps_graph* g) {
   if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
   if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
+  g->aprm.band_rows = band_front_limit();
   const char* msg = "";
+  try {
   if (!analyze(sn, sf, g->aprm, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
   // fronts beyond the wave-per-front kernels (loop-closure separators) run in the dense-front form, whose cost is
   // per tree level: split their supernodes into 64-pivot chunks instead of 48 (a quarter fewer levels)
@@ -297,6 +300,10 @@ int run_analysis(pps_graph* g) {
     AnalysisParams wide = g->aprm;
     wide.max_pivots = dense_front_max_pivots();
     if (!analyze(sn, sf, wide, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+  }
+  } catch (const std::bad_alloc&) {
+    g->an = Analysis();
+    return fail(g, PPS_ENOMEM, "symbolic analysis ran out of host memory (fronts too wide for this ordering)");
   }
   g->level_max_front.assign(g->an.n_levels, 0);
   for (int s = 0; s < g->an.n_fronts; s++) {
@@ -311,7 +318,9 @@ int run_analysis(pps_graph* g) {
     int max_piv = 0;
     for (int m : g->stage_max_piv) max_piv = std::max(max_piv, m);
     g->use_band = A.max_front <= band_front_limit() && max_piv <= 64 && !getenv("PPS_NO_BAND");
-    g->use_dense = !g->use_band && max_piv <= dense_front_max_pivots() && !getenv("PPS_NO_DENSE");
+    // the dense-front solve keeps a front's boundary values in LDS: 15 000 scalars is the ceiling (2-D loop-closure
+    // meshes such as torus10000 reach 24 540 under this chain-based dissection and are refused, see below)
+    g->use_dense = !g->use_band && max_piv <= dense_front_max_pivots() && A.max_front <= 15000 && !getenv("PPS_NO_DENSE");
     g->level_max_b.assign(A.n_levels, 0);
     g->max_el_per_front = 0;
     for (int s = 0; s < A.n_fronts; s++) {
@@ -348,6 +357,9 @@ int run_analysis(pps_graph* g) {
       g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, (lds_budget - std::min(lds_budget / 2, xbytes)) / band_solve_lds_bytes(g->stage_max_panel[st])));
     }
   }
+  if (!g->use_band && !g->use_dense && g->an.max_front > 4096)
+    return fail(g, PPS_ENOMEM, "fronts too wide for this ordering (max front " + std::to_string(g->an.max_front) +
+                               " scalars): the pose chain is not a good dissection backbone for this graph");
   g->analyzed = true;
   g->stats.n_fronts = g->an.n_fronts; g->stats.n_levels = g->an.n_levels; g->stats.max_front = g->an.max_front;
   g->stats.nnz_L = g->an.L_size;

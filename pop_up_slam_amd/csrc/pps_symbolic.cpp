@@ -420,20 +420,22 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       for (int v : bnd[s]) loc[v] = -1;
     }
     // packed update matrix of c -> packed index in the parent front
+    // (only the wave-per-front kernels read these lists; a graph with wider fronts runs in the dense-front form, which
+    // pulls through cmap -- its (b+1)^2/2 entries per front would be gigabytes for loop-closure separators)
     A.f_ea_off.assign(F + 1, 0);
     A.ea_tgt.clear();
-    {
+    if (A.max_front <= prm.band_rows) {
       size_t total = 0;
       for (int s = 0; s < F; s++) total += cm[s].size() * (cm[s].size() + 1) / 2;
       A.ea_tgt.reserve(total);
+      for (int s = 0; s < F; s++) {
+        A.f_ea_off[s] = (int64_t)A.ea_tgt.size();
+        const std::vector<int>& m = cm[s];    // empty for the root
+        for (size_t i = 0; i < m.size(); i++)
+          for (size_t j = 0; j <= i; j++) A.ea_tgt.push_back(m[i] * (m[i] + 1) / 2 + m[j]);
+      }
+      A.f_ea_off[F] = (int64_t)A.ea_tgt.size();
     }
-    for (int s = 0; s < F; s++) {
-      A.f_ea_off[s] = (int64_t)A.ea_tgt.size();
-      const std::vector<int>& m = cm[s];    // empty for the root
-      for (size_t i = 0; i < m.size(); i++)
-        for (size_t j = 0; j <= i; j++) A.ea_tgt.push_back(m[i] * (m[i] + 1) / 2 + m[j]);
-    }
-    A.f_ea_off[F] = (int64_t)A.ea_tgt.size();
     for (int s = 0; s < F; s++) {
       A.f_cmap_off[s] = (int)A.cmap.size();
       A.cmap.insert(A.cmap.end(), cm[s].begin(), cm[s].end());
