@@ -291,6 +291,7 @@ int run_analysis(pps_graph* g) {
   if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
   g->aprm.band_rows = band_front_limit();
+  if (const char* e = getenv("PPS_ORDERING")) g->aprm.ordering = atoi(e);
   const char* msg = "";
   try {
   if (!analyze(sn, sf, g->aprm, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);

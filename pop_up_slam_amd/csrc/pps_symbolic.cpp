@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <functional>
 #include <numeric>
+#include <queue>
 
 namespace pps {
 namespace {
@@ -56,6 +57,91 @@ struct Builder {
   int degree(int u) const { return adj_off[u + 1] - adj_off[u]; }
 
   int new_tnode() { tree.emplace_back(); return (int)tree.size() - 1; }
+
+  // General fill-reducing ordering for graphs the pose chain does not dissect well (pose graphs with many loop
+  // closures, 2-D meshes): minimum degree on the node graph (degrees in scalars, lazy heap, adjacency lists merged
+  // at every elimination), elimination tree from the filled column structures, fundamental supernodes (a node joins
+  // its parent when it is the parent's only child and their structures coincide).  `live` = the nodes to order (the
+  // current adjacency must already be restricted to them).  Returns the root tnode id (several components: the last
+  // root adopts the others).
+  int mindeg_tree(const std::vector<int>& live) {
+    std::vector<std::vector<int>> nb(N);
+    for (int u : live) nb[u].assign(adj.begin() + adj_off[u], adj.begin() + adj_off[u + 1]);
+    std::vector<int> deg(N, 0);
+    std::vector<char> gone(N, 1);
+    using HE = std::pair<int, int>;
+    std::priority_queue<HE, std::vector<HE>, std::greater<HE>> heap;
+    for (int u : live) {
+      gone[u] = 0;
+      int d = 0;
+      for (int v : nb[u]) d += nodes[v].dim;
+      deg[u] = d;
+      heap.emplace(d, u);
+    }
+    std::vector<int> order, pos(N, -1);
+    std::vector<std::vector<int>> strct(N);     // filled structure of the column at elimination time
+    std::vector<int> tmp;
+    while (!heap.empty()) {
+      const HE e = heap.top(); heap.pop();
+      const int v = e.second;
+      if (gone[v] || e.first != deg[v]) continue;    // stale entry
+      gone[v] = 1;
+      pos[v] = (int)order.size();
+      order.push_back(v);
+      strct[v].swap(nb[v]);
+      const std::vector<int>& Nv = strct[v];
+      for (int u : Nv) {
+        std::vector<int>& U = nb[u];
+        tmp.clear();
+        size_t i = 0, j = 0;
+        while (i < U.size() || j < Nv.size()) {        // sorted merge, dropping u and v
+          int x;
+          if (j >= Nv.size() || (i < U.size() && U[i] <= Nv[j])) { x = U[i]; if (j < Nv.size() && Nv[j] == x) j++; i++; }
+          else { x = Nv[j]; j++; }
+          if (x != u && x != v) tmp.push_back(x);
+        }
+        U.assign(tmp.begin(), tmp.end());
+        int d = 0;
+        for (int x : U) d += nodes[x].dim;
+        deg[u] = d;
+        heap.emplace(d, u);
+      }
+    }
+    const int n = (int)order.size();
+    // elimination tree: the parent of v is the member of its structure that is eliminated first
+    std::vector<int> parent(N, -1), nchild(N, 0);
+    for (int v : order) {
+      int best = -1;
+      for (int u : strct[v]) if (best < 0 || pos[u] < pos[best]) best = u;
+      parent[v] = best;
+      if (best >= 0) nchild[best]++;
+    }
+    // supernodes along the elimination order
+    std::vector<int> sn_of(N, -1);
+    std::vector<int> sn_tnode;
+    for (int k = 0; k < n; k++) {
+      const int v = order[k];
+      if (sn_of[v] < 0) { sn_of[v] = new_tnode(); }
+      tree[sn_of[v]].piv.push_back(v);
+      const int par = parent[v];
+      if (par >= 0 && nchild[par] == 1 && pos[par] == pos[v] + 1 && strct[par].size() + 1 == strct[v].size())
+        sn_of[par] = sn_of[v];                         // same front: struct(v) = {par} + struct(par)
+    }
+    // supernode tree
+    std::vector<int> roots;
+    for (int k = 0; k < n; k++) {
+      const int v = order[k];
+      const int t = sn_of[v];
+      if (tree[t].piv.back() != v) continue;           // only the last node of a supernode links upwards
+      const int par = parent[v];
+      if (par < 0) roots.push_back(t);
+      else tree[sn_of[par]].kids.push_back(t);
+    }
+    if (roots.empty()) return -1;
+    const int top = roots.back();
+    for (size_t r = 0; r + 1 < roots.size(); r++) tree[top].kids.push_back(roots[r]);
+    return top;
+  }
 
   // poses: node ids sorted by rank; planes: node ids.  Returns tnode id.
   int dissect(std::vector<int> poses, std::vector<int> planes) {
@@ -151,8 +237,9 @@ struct Builder {
 
 }  // namespace
 
-bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
-             Analysis& A, const char** msg) {
+namespace {
+bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
+                  Analysis& A, const char** msg, bool general_ordering) {
   static const char* kOk = "";
   *msg = kOk;
   A = Analysis();
@@ -195,7 +282,15 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
     B.adj_off.swap(off);
     B.adj.swap(a2);
     int top = -1;
-    if (!poses.empty() || !planes.empty()) top = B.dissect(poses, planes);
+    if (!poses.empty() || !planes.empty()) {
+      if (general_ordering) {
+        std::vector<int> live(poses);
+        live.insert(live.end(), planes.begin(), planes.end());
+        top = B.mindeg_tree(live);
+      } else {
+        top = B.dissect(poses, planes);
+      }
+    }
     B.adj_off.swap(full_off);
     B.adj.swap(full_adj);
     int root = top;
@@ -626,6 +721,27 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
       }
       lap("packed records");
     }
+  }
+  return true;
+}
+
+double factor_flops(const Analysis& A) {
+  double fl = 0;
+  for (int s = 0; s < A.n_fronts; s++) { const double f = A.f_p[s] + A.f_b[s] + 1.0; fl += A.f_p[s] * f * f; }
+  return fl;
+}
+}  // namespace
+
+// Ordering choice: the pose-chain dissection is the natural backbone of plane-SLAM graphs (fronts of a few dozen rows);
+// when it leaves fronts beyond the wave-per-front kernels (pose graphs with many loop closures, 2-D meshes) the
+// general minimum-degree ordering is analysed as well and the cheaper factorisation (flops) wins.
+bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
+             Analysis& A, const char** msg) {
+  if (!analyze_with(nodes, factors, prm, A, msg, prm.ordering == 1)) return false;
+  if (prm.ordering == 0 && A.max_front > prm.band_rows) {
+    Analysis G;
+    const char* m2 = "";
+    if (analyze_with(nodes, factors, prm, G, &m2, true) && factor_flops(G) < factor_flops(A)) A = std::move(G);
   }
   return true;
 }

@@ -33,6 +33,8 @@ struct AnalysisParams {
   int max_pivots = 48;     // split supernodes with more pivot scalars into a chain
   int seg_len = 32;        // contributions reduced per wave in the H-block kernel
   int band_levels = 3;     // tree levels walked by one workgroup inside one launch ("band")
+  int ordering = 0;        // 0 = pose-chain dissection, minimum degree as well when its fronts exceed band_rows (cheaper wins);
+                           // 1 = minimum degree only; 2 = chain dissection only
   int band_rows = 127;     // largest front of the wave-per-front kernels: graphs beyond it skip the packed extend-add lists
   int dense_min = 64;      // a node is "dense" if degree > max(dense_min, dense_mult*sqrt(N))
   double dense_mult = 8.0;

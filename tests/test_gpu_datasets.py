@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "isam_data")
 
 
-@pytest.mark.parametrize("name,mode", [("sphere400", 0), ("sphere400", 1), ("sphere2500", 1)])
+@pytest.mark.parametrize("name,mode", [("sphere400", 0), ("sphere400", 1), ("sphere2500", 1), ("torus10000", 1)])
 def test_sphere(built, name, mode):
     spec = graphio.load_edge3_log(os.path.join(DATA, name + ".txt"))
     g = P.Graph(jacobian_mode=mode); spec.replay(g)
-    o = O.OracleGraph(); spec.replay(o)
+    o = O.OracleGraph(analytic=mode); spec.replay(o)
     c0, c0o = g.chi2(), o.chi2()
     assert abs(c0 - c0o) <= 1e-9 * c0o
     it, ito = g.batch_optimize(), o.batch_optimize()
@@ -31,7 +31,8 @@ def test_sphere(built, name, mode):
              1e3 * st["t_total"] / max(1, it)))
     assert abs(c - co) <= 1e-5 * co
     assert it == ito
-    assert 0.9 < c / dof < 1.1
+    if name.startswith("sphere"):
+        assert 0.9 < c / dof < 1.1          # (the torus file's stated weights do not match its noise: 0.50 on both sides)
     if name == "sphere2500":
         gt = graphio.trajectory_from_log(os.path.join(DATA, "sphere2500_groundtruth.txt"))
         est = g.get_poses()
