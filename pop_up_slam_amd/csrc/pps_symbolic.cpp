@@ -117,15 +117,21 @@ struct Builder {
       if (best >= 0) nchild[best]++;
     }
     // supernodes along the elimination order
-    std::vector<int> sn_of(N, -1);
-    std::vector<int> sn_tnode;
+    // (relaxed: an only child also joins when the parent's structure is at most a quarter larger -- a few explicit
+    // zeros in the child's columns buy fewer, fuller fronts and a shallower tree -- up to max_pivots scalars per front)
+    std::vector<int> sn_of(N, -1), sn_dim;
     for (int k = 0; k < n; k++) {
       const int v = order[k];
-      if (sn_of[v] < 0) { sn_of[v] = new_tnode(); }
+      if (sn_of[v] < 0) { sn_of[v] = new_tnode(); sn_dim.resize(tree.size(), 0); }
       tree[sn_of[v]].piv.push_back(v);
+      sn_dim[sn_of[v]] += nodes[v].dim;
       const int par = parent[v];
-      if (par >= 0 && nchild[par] == 1 && pos[par] == pos[v] + 1 && strct[par].size() + 1 == strct[v].size())
-        sn_of[par] = sn_of[v];                         // same front: struct(v) = {par} + struct(par)
+      if (par >= 0 && nchild[par] == 1 && pos[par] == pos[v] + 1) {
+        const size_t sv = strct[v].size(), sp = strct[par].size() + 1;      // struct(v) is a subset of {par} + struct(par)
+        const bool fundamental = sp == sv;
+        const bool relaxed = sp <= sv + std::max<size_t>(2, sv / 4) && sn_dim[sn_of[v]] + nodes[par].dim <= prm.max_pivots;
+        if (fundamental || relaxed) sn_of[par] = sn_of[v];
+      }
     }
     // supernode tree
     std::vector<int> roots;
