@@ -103,25 +103,24 @@ def test_c4_independent_seeds(built):
     """BASELINE config 4 (one C2-size graph per GPU): the per-rank graphs of bench.py, solved one after the
     other on this GPU, each against the oracle."""
     import bench
-    # ranks 2/4 (seeds 102/104) converge like C2 (chi2_0 ~ 7 -> 0.023 in 113/123 trials): chi2 must agree to the
-    # north_star tolerance.  Ranks 1/7 (seeds 101/107) start at chi2_0 = 31/67 and wander for hundreds of trials
-    # along accept/reject knife edges that amplify round-off chaotically (the elimination order alone changes the
-    # path and where the relative-decrease test stops it), so only LM's own guarantees are checked there: chi2
-    # never increases and the run ends finite.
-    for rank in (2, 4, 1, 7):
-        spec = synth.corridor(seed=bench.rank_seed(rank))
+    # the C4 graphs of bench.py (well-conditioned seeds: 55-79 LM trials): chi2 within the north_star tolerance and the
+    # same trial count.  Seeds 101 / 107 start at chi2_0 = 31 / 67 and wander for hundreds of trials along accept/reject
+    # knife edges that amplify round-off chaotically (the elimination order alone changes the path and where the
+    # relative-decrease test stops it), so only LM's own guarantees are checked there: chi2 never increases, finite.
+    for seed in bench.C4_SEEDS[1:] + [101, 107]:
+        spec = synth.corridor(seed=seed)
         g, o, *_ = _pair(spec)
         c0 = g.chi2()
         it, ito = g.batch_optimize(), o.batch_optimize()
         c, co = g.chi2(), o.chi2()
-        print("C4 rank %d: gpu chi2 %.12g (%d it) oracle %.12g (%d it) rel %.2e" % (rank, c, it, co, ito, abs(c - co) / co))
-        if rank in (1, 7):
+        print("C4 seed %d: gpu chi2 %.12g (%d it) oracle %.12g (%d it) rel %.2e" % (seed, c, it, co, ito, abs(c - co) / co))
+        if seed in (101, 107):
             assert np.isfinite(c) and c < c0 and 1 <= it <= 500
             tr = g.trace()
             acc = [chi for (_lam, chi, ok) in tr if ok]
             assert all(b <= a for a, b in zip(acc, acc[1:]))
         else:
-            assert abs(c - co) <= 1e-5 * abs(co), (rank, it, ito, c, co)
+            assert abs(c - co) <= 1e-5 * abs(co) and it == ito, (seed, it, ito, c, co)
 
 
 def test_mid_and_large_graphs(built):
