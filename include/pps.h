@@ -263,7 +263,9 @@ int pps_find_closest_planes(pps_graph* g, const double est_pose[7], int frame_se
  *   Pose3d_Node 4 (x, y, z; yaw, pitch, roll)     Plane3d_Node 17 (a, b, c; d)
  * precision <= 0: 6 significant digits like the reference's ostream default (lossy); 17 round-trips doubles.
  * pps_graph_load reads this format back into a new handle (the reference has no reader for it); node ids are
- * re-assigned densely in file order. */
+ * re-assigned densely in file order.  A Factor2 edge (pps_add_plane_obs2) prints like the reference's -- same name,
+ * stored measurement (isam_plane3d.h:327) -- so its ground-edge rays are not part of the file and it reloads as a
+ * plain observation. */
 int pps_graph_save(pps_graph* g, const char* path, int precision);
 int pps_graph_load(const char* path, const pps_props* props, pps_graph** out);
 
