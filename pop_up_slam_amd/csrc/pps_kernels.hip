@@ -1,13 +1,20 @@
 // pps_kernels.hip -- gfx950 kernels of the plane-SLAM graph solve.
 //
-//   K1  k_linearize      per-edge residual + Jacobian sweep (reference: Slam::jacobian_partial,
-//                        isamlib/Slam.cpp:395-432 + numericalDiff.cpp:41-87)             HBM-bound
-//   K2  k_hblocks        block-sparse J'J / J'b reduction (cholmod_ssmult/sdmult,
-//                        isamlib/Cholesky.cpp:87-89,120)
-//   K3  k_front_factor   multifrontal partial Cholesky, one workgroup per front, front in LDS
-//       k_front_solve    back-substitution, root to leaves (cholmod_factorize/solve, Cholesky.cpp:100-128)
-//   K4  k_retract_*      exmap per node (Slam::self_exmap/apply_exmap, Slam.cpp:216-234)
-//       k_chi2, k_finalize  residual-only sweep + chi^2 reduction (Slam::weighted_errors/chi2, Slam.cpp:254-268)
+//   K1  k_linearize<MODE,PART>, k_linearize_lanes, k_linearize_repop
+//                        per-edge residual + Jacobian sweep (reference: Slam::jacobian_partial,
+//                        isamlib/Slam.cpp:395-432 + numericalDiff.cpp:41-87)             HBM-bound (analytic mode)
+//   K2  k_hblocks, k_hreduce
+//                        block-sparse J'J / J'b reduction (cholmod_ssmult/sdmult, isamlib/Cholesky.cpp:87-89,120)
+//   K3  k_band_factor, k_band_solve
+//                        multifrontal Cholesky, one wavefront per front, a workgroup walks a sub-tree of a band of
+//                        tree levels (cholmod_factorize/solve, Cholesky.cpp:100-128).  Fronts <= 64 rows live in
+//                        registers as 16x16 fp64 MFMA tiles (pps_regtile.h), up to 128 rows in LDS tiles.
+//       k_front_factor, k_front_solve
+//                        level-per-launch fallback (one workgroup per front) when neither the band kernels nor the
+//                        dense-front kernels (pps_dense.hip) apply
+//   K4  k_retract<TRIAL> exmap per node (Slam::self_exmap/apply_exmap, Slam.cpp:216-234)
+//       k_chi2           residual-only sweep + chi^2 reduction, last block writes the pinned result record
+//                        (Slam::weighted_errors/chi2, Slam.cpp:254-268)
 #include "pps_device.h"
 #include "pps_geom.h"
 #include "pps_regtile.h"
