@@ -269,6 +269,11 @@ int pps_find_closest_planes(pps_graph* g, const double est_pose[7], int frame_se
 int pps_graph_save(pps_graph* g, const char* path, int precision);
 int pps_graph_load(const char* path, const pps_props* props, pps_graph** out);
 
+/* Mapper_mono::reproj_to_newplane (src/Mapping.cpp:609-632): stored polygon vertices (fp32 world points) projected onto
+ * the CURRENT estimate of their landmark plane -- Plane3d::project_to_plane (src/isam_plane3d.h:173-178) in fp64, result
+ * cast back to fp32.  plane_ids[i] is the plane node of point i; points of removed (merged) landmarks are copied through. */
+int pps_reproject_points(pps_graph* g, int n, const int* plane_ids, const float* pts_xyz, float* out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

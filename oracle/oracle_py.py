@@ -87,6 +87,7 @@ def lib():
             ("ora_popup_planes_ex", [fp, C.c_int, fp, fp, fp, fp], None),
             ("ora_find_closest_plane", [dp, dp, C.c_int, C.c_int, fp, fp, C.c_void_p, C.c_int, C.c_void_p, ip, dp], None),
             ("ora_point_proj_to_lineseg", [fp, fp, fp], C.c_float),
+            ("ora_project_to_plane", [dp, fp, fp], None),
             ("ora_popup_cloud", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_float, C.c_float, fp,
                                  C.POINTER(C.c_ubyte)], None),
             ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
@@ -252,6 +253,11 @@ def popup_planes(seg2d, invK, T_wc):
     out = np.zeros((n + 1, 4), dtype=np.float32)
     lib().ora_popup_planes(ps, n, pk, pt, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def project_to_plane(abcd, pt):
+    a, pa = _d(abcd); p, pp = _f(pt); out = np.zeros(3, dtype=np.float32)
+    lib().ora_project_to_plane(pa, pp, out.ctypes.data_as(C.POINTER(C.c_float))); return out
 
 
 def edge_ray(invK, seg2d):

@@ -1334,6 +1334,15 @@ float ora_point_proj_to_lineseg(const float b[2], const float e[2], const float 
   return t;
 }
 
+/* Plane3d::project_to_plane (src/isam_plane3d.h:173-178) as used by reproj_to_newplane (Mapping.cpp:617-618) */
+void ora_project_to_plane(const double abcd[4], const float pt[3], float out[3]) {
+  double n[3]; plane_normal(abcd, n);
+  const double d = plane_d(abcd);
+  const double x = pt[0], y = pt[1], z = pt[2];
+  const double s = (n[0] * x + n[1] * y + n[2] * z) - d;
+  out[0] = (float)(x - n[0] * s); out[1] = (float)(y - n[1] * s); out[2] = (float)(z - n[2] * s);
+}
+
 void ora_find_closest_plane(const double est_pose[7], const double plane_local[4], int fpi, int frame_seq_id,
                             const float seg2d[4], const float seg3d[4], const ora_landmark* lm, int n_lm,
                             const ora_assoc_params* prm, int* best, double* best_err) {

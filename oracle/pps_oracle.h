@@ -127,6 +127,8 @@ void ora_find_closest_plane(const double est_pose[7], const double plane_local[4
                             int n_lm, const ora_assoc_params* prm, int* best, double* best_err);
 /* Mapping.cpp:112-126 */
 float ora_point_proj_to_lineseg(const float begin_pt[2], const float end_pt[2], const float query_pt[2]);
+/* Plane3d::project_to_plane on an fp32 point (Mapping.cpp:617-618): fp64 arithmetic, cast back to fp32 */
+void ora_project_to_plane(const double abcd[4], const float pt[3], float out[3]);
 
 /* pop-up (fp32) restatement: pop_up_wall/libs/popup_plane.cpp:654-705.
  * seg2d: n x 4 (u1 v1 u2 v2) row-major, invK 3x3 row-major, T_wc 4x4 row-major.

@@ -90,7 +90,7 @@ SYMBOLS = [
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
     "pps_find_closest_planes", "pps_graph_save", "pps_graph_load", "pps_add_plane_obs2", "pps_edge_ray",
-    "pps_time_linearize",
+    "pps_time_linearize", "pps_reproject_points",
 ]
 
 
@@ -165,6 +165,7 @@ def lib():
         L.pps_add_plane_obs2.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _ip]
         L.pps_edge_ray.argtypes = [_fp, _fp, _dp]
         L.pps_time_linearize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.pps_reproject_points.argtypes = [C.c_void_p, C.c_int, _ip, _fp, _fp]
         L.pps_graph_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.pps_graph_load.argtypes = [C.c_char_p, C.POINTER(PpsProps), C.POINTER(C.c_void_p)]
         L.pps_find_closest_planes.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _ip, _fp, _fp, C.POINTER(PpsAssocParams), _ip, _dp]
@@ -374,6 +375,14 @@ class Graph:
     def time_linearize(self, mode=JAC_NUMERIC, iters=200):
         """seconds per K1 launch, back-to-back launches on the solver's stream between two HIP events"""
         s = C.c_double(); self._ck(self.L.pps_time_linearize(self.h, int(mode), int(iters), C.byref(s))); return s.value
+
+    def reproject_points(self, plane_ids, pts):
+        """Mapper_mono::reproj_to_newplane: fp32 points projected onto the current estimate of their landmark planes."""
+        ids = np.ascontiguousarray(plane_ids, dtype=np.int32); p = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+        assert len(ids) == len(p)
+        out = np.zeros_like(p)
+        self._ck(self.L.pps_reproject_points(self.h, len(ids), ids.ctypes.data_as(_ip), p.ctypes.data_as(_fp), out.ctypes.data_as(_fp)))
+        return out
 
     def save_state(self):
         self._ck(self.L.pps_save_state(self.h))

@@ -1689,4 +1689,27 @@ int pps_graph_load(const char* path, const pps_props* props, pps_graph** out) {
   return PPS_OK;
 }
 
+
+// Mapper_mono::reproj_to_newplane (src/Mapping.cpp:609-632): polygon vertices onto the optimised planes
+int pps_reproject_points(pps_graph* g, int n, const int* plane_ids, const float* pts_xyz, float* out_xyz) {
+  if (!g || n < 0 || (n > 0 && (!plane_ids || !pts_xyz || !out_xyz))) return PPS_EINVAL;
+  if (n == 0) return PPS_OK;
+  int rc = prepare_solve(g);
+  if (rc != PPS_OK) return rc;
+  std::vector<int> slot(n);
+  for (int i = 0; i < n; i++) slot[i] = live_node(g, plane_ids[i], NODE_PLANE) ? g->nodes[plane_ids[i]].slot : -1;
+  int* d_slot = nullptr; float *d_in = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_slot), (size_t)n * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)3 * n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)3 * n * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_slot, slot.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, g->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, pts_xyz, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, g->stream);
+  if (e == hipSuccess) e = launch_reproject(n, d_slot, d_in, g->dev.plane_est, g->dev.plane_ld, d_out, g->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_xyz, d_out, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost, g->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+  (void)hipFree(d_slot); (void)hipFree(d_in); (void)hipFree(d_out);
+  if (e != hipSuccess) return hip_fail(g, e, "pps_reproject_points");
+  return PPS_OK;
+}
+
 }  // extern "C"

@@ -161,7 +161,30 @@ __global__ __launch_bounds__(kAssocThreads) void k_assoc(AssocArgs a) {
   }
 }
 
+// Mapper_mono::reproj_to_newplane (src/Mapping.cpp:609-632): stored polygon vertices projected onto the optimised plane of
+// their landmark, Plane3d::project_to_plane (src/isam_plane3d.h:173-178) in fp64 on the fp32 vertex, result cast to fp32.
+__global__ __launch_bounds__(256) void k_reproject(int n, const int* __restrict__ slot, const float* __restrict__ pts,
+                                                   const double* __restrict__ plane_est, int plane_ld, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int sl = slot[i];
+  const double x = (double)pts[3 * i], y = (double)pts[3 * i + 1], z = (double)pts[3 * i + 2];
+  if (sl < 0) { out[3 * i] = pts[3 * i]; out[3 * i + 1] = pts[3 * i + 1]; out[3 * i + 2] = pts[3 * i + 2]; return; }   // merged / unknown landmark: untouched
+  double p[4];
+  for (int k = 0; k < 4; k++) p[k] = plane_est[(size_t)k * plane_ld + sl];
+  const double l = norm3(p);
+  const double nx = p[0] / l, ny = p[1] / l, nz = p[2] / l, dd = -p[3] / l;
+  const double s = (nx * x + ny * y + nz * z) - dd;
+  out[3 * i] = (float)(x - nx * s); out[3 * i + 1] = (float)(y - ny * s); out[3 * i + 2] = (float)(z - nz * s);
+}
+
 }  // namespace
+
+hipError_t launch_reproject(int n, const int* slot, const float* pts, const double* plane_est, int plane_ld, float* out, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_reproject, dim3((n + 255) / 256), dim3(256), 0, st, n, slot, pts, plane_est, plane_ld, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_assoc(const AssocArgs& a, hipStream_t st) {
   if (a.n_queries <= 0) return hipSuccess;

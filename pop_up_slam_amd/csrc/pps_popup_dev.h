@@ -61,5 +61,7 @@ struct AssocArgs {
   const double* plane_est; int plane_ld;
 };
 hipError_t launch_assoc(const AssocArgs& a, hipStream_t st);
+// reproj_to_newplane: point i projected onto the plane in slot[i] of the plane state (slot < 0: copied through)
+hipError_t launch_reproject(int n, const int* slot, const float* pts, const double* plane_est, int plane_ld, float* out, hipStream_t st);
 
 }  // namespace pps

@@ -120,3 +120,29 @@ def test_handles_are_independent(built):
     ga.close()
     assert np.isfinite(gb.chi2())                              # closing one handle leaves the other alive
     gb.batch_optimize()
+
+
+def test_reproject_points_onto_optimised_planes(built):
+    """Mapper_mono::reproj_to_newplane (Mapping.cpp:609-632): polygon vertices onto the current plane estimates"""
+    spec = synth.small_world(20, 6, seed=4, obs_per_pose=4)
+    g, o, ng, fg, no, fo = _pair(spec)
+    g.batch_optimize(); o.batch_optimize()
+    planes = [i for i in range(len(spec.node_type)) if spec.node_type[i] == synth.NODE_PLANE]
+    rng = np.random.default_rng(0)
+    ids = rng.choice(planes, size=300)
+    pts = rng.uniform(-5, 5, size=(300, 3)).astype(np.float32)
+    out = g.reproject_points([int(ng[i]) for i in ids], pts)
+    for k in range(300):
+        ref = O.project_to_plane(o.get_plane(int(no[ids[k]])), pts[k])
+        np.testing.assert_allclose(out[k], ref, atol=2e-6)               # estimates agree to 1e-9, fp32 output
+        pl = g.get_plane(int(ng[ids[k]]))
+        n = pl[:3] / np.linalg.norm(pl[:3])
+        assert abs(n @ out[k].astype(np.float64) + pl[3] / np.linalg.norm(pl[:3])) < 1e-5      # lies on the plane
+    # idempotent, and points of a removed landmark come back untouched
+    np.testing.assert_allclose(g.reproject_points([int(ng[i]) for i in ids], out), out, atol=1e-6)
+    dead = int(ng[planes[-1]])
+    for k in range(len(spec.f_type)):
+        if spec.f_type[k] in (synth.F_PLANE_OBS, synth.F_PLANE_PRIOR) and (spec.f_nodes[k][1] == planes[-1] or spec.f_nodes[k][0] == planes[-1]):
+            g.remove_factor(int(fg[k]))
+    g.remove_node(dead)
+    np.testing.assert_array_equal(g.reproject_points([dead] * 4, pts[:4]), pts[:4])
