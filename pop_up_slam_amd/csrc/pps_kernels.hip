@@ -1214,6 +1214,9 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, i
   }
 }
 
+// REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the fused
+// root solve are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
+template <bool REG_ONLY>
 __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave,
                                                      int solve_doubles_per_wave) {
   extern __shared__ double lds[];
@@ -1227,11 +1230,12 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      if (fa <= kRegRows) wave_front_factor_reg(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      if (REG_ONLY || fa <= kRegRows) wave_front_factor_reg(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
       else wave_front_factor(d, s, lambda, F);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
   }
+  if (REG_ONLY) return;
   // root stage: the back-substitution of the same group follows at once (one launch less per solve); the factor's
   // LDS is dead by now and is re-partitioned for the solve
   if (solve_doubles_per_wave > 0) {
@@ -1257,7 +1261,8 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!g_band_attr_set[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
@@ -1269,7 +1274,10 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     solve_per_wave = (int)(band_solve_lds_bytes(fused_solve_panel) / sizeof(double));
     bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
   }
-  hipLaunchKernelGGL(k_band_factor, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, solve_per_wave);
+  if (max_front + 1 <= kRegRows && solve_per_wave == 0)
+    hipLaunchKernelGGL(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, 0);
+  else
+    hipLaunchKernelGGL(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, solve_per_wave);
   return hipGetLastError();
 }
 
