@@ -1006,6 +1006,7 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
 // P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
 // ------------------------------------------------------------------------------------------
+template <int NT>
 __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
                                                       double* __restrict__ P) {
   const int lane = threadIdx.x & 63;
@@ -1063,9 +1064,9 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   }
   PPS_TR(3);
   // ---- packed triangle -> register tiles ----
-  double4_t c[10];
+  double4_t c[NT * (NT + 1) / 2];
 #pragma unroll
-  for (int ti = 0; ti < 4; ti++)
+  for (int ti = 0; ti < NT; ti++)
 #pragma unroll
     for (int tj = 0; tj <= ti; tj++)
 #pragma unroll
@@ -1082,10 +1083,10 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     const int nb = p - K < 4 ? p - K : 4;
     const int tjK = K >> 4, c0 = K & 15;
     switch (tjK) {
-      case 0: reg_extract_panel<0>(c, P, c0, lane); break;
-      case 1: reg_extract_panel<1>(c, P, c0, lane); break;
-      case 2: reg_extract_panel<2>(c, P, c0, lane); break;
-      default: reg_extract_panel<3>(c, P, c0, lane); break;
+      case 0: reg_extract_panel<0, NT>(c, P, c0, lane); break;
+      case 1: reg_extract_panel<1, NT>(c, P, c0, lane); break;
+      case 2: reg_extract_panel<2, NT>(c, P, c0, lane); break;
+      default: if (NT > 3) reg_extract_panel<(NT > 3 ? 3 : 2), NT>(c, P, c0, lane); break;
     }
     __builtin_amdgcn_wave_barrier();
     // ---- panel: lane = row ----
@@ -1116,10 +1117,10 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     __builtin_amdgcn_wave_barrier();
     const long long tk1 = d.trace ? clock64() : 0;
     switch (tjK) {
-      case 0: reg_trailing<0>(c, P, nb, lane, (K + 4) >> 4); break;
-      case 1: reg_trailing<1>(c, P, nb, lane, (K + 4) >> 4); break;
-      case 2: reg_trailing<2>(c, P, nb, lane, (K + 4) >> 4); break;
-      default: reg_trailing<3>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 0: reg_trailing<0, NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 1: reg_trailing<1, NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 2: reg_trailing<2, NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      default: if (NT > 3) reg_trailing<(NT > 3 ? 3 : 2), NT>(c, P, nb, lane, (K + 4) >> 4); break;
     }
     __builtin_amdgcn_wave_barrier();
     if (d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
@@ -1129,7 +1130,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   // ---- update matrix: live part of the tiles -> packed global ----
   double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
 #pragma unroll
-  for (int ti = 0; ti < 4; ti++)
+  for (int ti = 0; ti < NT; ti++)
 #pragma unroll
     for (int tj = 0; tj <= ti; tj++)
 #pragma unroll
@@ -1230,7 +1231,8 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      if (REG_ONLY || fa <= kRegRows) wave_front_factor_reg(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      if (REG_ONLY && fa <= 48) wave_front_factor_reg<3>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      else if (REG_ONLY || fa <= kRegRows) wave_front_factor_reg<4>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
       else wave_front_factor(d, s, lambda, F);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)

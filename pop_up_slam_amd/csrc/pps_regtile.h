@@ -28,13 +28,14 @@ constexpr int kRegRows = 64;
 
 __device__ __forceinline__ constexpr int tile_id(int ti, int tj) { return ti * (ti + 1) / 2 + tj; }
 
-template <int TJ>
-__device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[10], double* __restrict__ P, int c0, int lane) {
+// NT = tile rows held (4: up to 64 rows, 10 tiles; 3: up to 48 rows, 6 tiles -- same tile_id numbering)
+template <int TJ, int NT = 4>
+__device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[NT * (NT + 1) / 2], double* __restrict__ P, int c0, int lane) {
   const int l16 = lane & 15, lq = lane >> 4;
   const int m = l16 - c0;
   if (m >= 0 && m < 4) {
 #pragma unroll
-    for (int ti = TJ; ti < 4; ti++)
+    for (int ti = TJ; ti < NT; ti++)
 #pragma unroll
       for (int r = 0; r < 4; r++) P[(16 * ti + lq + 4 * r) * kPStride + m] = c[tile_id(ti, TJ)][r];
   }
@@ -43,31 +44,31 @@ __device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[10], doub
 // Rank-nb update of every live tile.  The tiles of the NEXT panel's tile column (TJN = TJ or TJ+1) are issued first:
 // the next iteration extracts its panel from them and then spends ~1000 cycles of VALU / LDS work on the panel
 // factorisation, during which the remaining (independent) MFMAs drain in the matrix core instead of being waited for.
-template <int TJ>
-__device__ __forceinline__ void reg_trailing(double4_t (&c)[10], const double* __restrict__ P, int nb, int lane, int tjn = TJ) {
+template <int TJ, int NT = 4>
+__device__ __forceinline__ void reg_trailing(double4_t (&c)[NT * (NT + 1) / 2], const double* __restrict__ P, int nb, int lane, int tjn = TJ) {
   const int l16 = lane & 15, lq = lane >> 4;
   const bool kvalid = lq < nb;
   double opnd[4];
 #pragma unroll
-  for (int t = TJ; t < 4; t++) { const double x = P[(16 * t + l16) * kPStride + lq]; opnd[t] = kvalid ? x : 0.0; }
+  for (int t = TJ; t < NT; t++) { const double x = P[(16 * t + l16) * kPStride + lq]; opnd[t] = kvalid ? x : 0.0; }
   if (tjn == TJ) {
 #pragma unroll
-    for (int ti = TJ; ti < 4; ti++)
+    for (int ti = TJ; ti < NT; ti++)
       c[tile_id(ti, TJ)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[TJ], c[tile_id(ti, TJ)], 0, 0, 0);
 #pragma unroll
-    for (int ti = TJ + 1; ti < 4; ti++)
+    for (int ti = TJ + 1; ti < NT; ti++)
 #pragma unroll
       for (int tj = TJ + 1; tj <= ti; tj++)
         c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[tj], c[tile_id(ti, tj)], 0, 0, 0);
   } else {
-    if (TJ + 1 < 4) {
+    if (TJ + 1 < NT) {
 #pragma unroll
-      for (int ti = TJ + 1; ti < 4; ti++)
-        c[tile_id(ti, TJ + 1 < 4 ? TJ + 1 : 3)] =
-            __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[TJ + 1 < 4 ? TJ + 1 : 3], c[tile_id(ti, TJ + 1 < 4 ? TJ + 1 : 3)], 0, 0, 0);
+      for (int ti = TJ + 1; ti < NT; ti++)
+        c[tile_id(ti, TJ + 1 < NT ? TJ + 1 : NT - 1)] =
+            __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd[ti], opnd[TJ + 1 < NT ? TJ + 1 : NT - 1], c[tile_id(ti, TJ + 1 < NT ? TJ + 1 : NT - 1)], 0, 0, 0);
     }
 #pragma unroll
-    for (int ti = TJ; ti < 4; ti++)
+    for (int ti = TJ; ti < NT; ti++)
 #pragma unroll
       for (int tj = TJ; tj <= ti; tj++)
         if (tj != TJ + 1)
