@@ -1085,8 +1085,8 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     switch (tjK) {
       case 0: reg_extract_panel<0, NT>(c, P, c0, lane); break;
       case 1: reg_extract_panel<1, NT>(c, P, c0, lane); break;
-      case 2: reg_extract_panel<2, NT>(c, P, c0, lane); break;
-      default: if (NT > 3) reg_extract_panel<(NT > 3 ? 3 : 2), NT>(c, P, c0, lane); break;
+      case 2: if (NT > 2) reg_extract_panel<(NT > 2 ? 2 : 1), NT>(c, P, c0, lane); break;
+      default: if (NT > 3) reg_extract_panel<(NT > 3 ? 3 : NT - 1), NT>(c, P, c0, lane); break;
     }
     __builtin_amdgcn_wave_barrier();
     // ---- panel: lane = row ----
@@ -1119,8 +1119,8 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     switch (tjK) {
       case 0: reg_trailing<0, NT>(c, P, nb, lane, (K + 4) >> 4); break;
       case 1: reg_trailing<1, NT>(c, P, nb, lane, (K + 4) >> 4); break;
-      case 2: reg_trailing<2, NT>(c, P, nb, lane, (K + 4) >> 4); break;
-      default: if (NT > 3) reg_trailing<(NT > 3 ? 3 : 2), NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 2: if (NT > 2) reg_trailing<(NT > 2 ? 2 : 1), NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      default: if (NT > 3) reg_trailing<(NT > 3 ? 3 : NT - 1), NT>(c, P, nb, lane, (K + 4) >> 4); break;
     }
     __builtin_amdgcn_wave_barrier();
     if (d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
@@ -1231,7 +1231,8 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      if (REG_ONLY && fa <= 48) wave_front_factor_reg<3>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      if (REG_ONLY && fa <= 32) wave_front_factor_reg<2>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
       else if (REG_ONLY || fa <= kRegRows) wave_front_factor_reg<4>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
       else wave_front_factor(d, s, lambda, F);
     }
