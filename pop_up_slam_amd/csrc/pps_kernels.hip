@@ -1006,7 +1006,8 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
 // P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
 // ------------------------------------------------------------------------------------------
-template <int NT>
+// TR: in-kernel phase trace (PPS_TRACE=1) compiled in
+template <int NT, bool TR>
 __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
                                                       double* __restrict__ P) {
   const int lane = threadIdx.x & 63;
@@ -1014,7 +1015,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   const int l16 = lane & 15, lq = lane >> 4;
   const int f = p + b, fa = f + 1;
   const int ntri = tri(fa);
-  PPS_TR(0);
+  if (TR) PPS_TR(0);
   const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
   const double damp = 1.0 + lambda;
@@ -1028,7 +1029,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   const int crv0 = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;
   for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
   __builtin_amdgcn_wave_barrier();
-  PPS_TR(1);
+  if (TR) PPS_TR(1);
 #pragma unroll
   for (int u = 0; u < 8; u++)
     if (tg0[u] >= 0) F[tg0[u] & 0x3fffffff] += (tg0[u] & (1 << 30)) ? v0[u] * damp : v0[u];   // Cholesky.cpp:94-97
@@ -1041,7 +1042,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];
   }
   __builtin_amdgcn_wave_barrier();
-  PPS_TR(2);
+  if (TR) PPS_TR(2);
   for (int cb = 0; cb < nch; cb += 8) {
    // child records of up to 8 children in one coalesced load (the first batch was requested above)
    const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);
@@ -1062,7 +1063,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     __builtin_amdgcn_wave_barrier();
    }
   }
-  PPS_TR(3);
+  if (TR) PPS_TR(3);
   // ---- packed triangle -> register tiles ----
   double4_t c[NT * (NT + 1) / 2];
 #pragma unroll
@@ -1079,7 +1080,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   long long cyc_panel = 0, cyc_trail = 0;
   for (int K = 0; K < p; K += 4) {
-    const long long tk0 = d.trace ? clock64() : 0;
+    const long long tk0 = (TR && d.trace) ? clock64() : 0;
     const int nb = p - K < 4 ? p - K : 4;
     const int tjK = K >> 4, c0 = K & 15;
     switch (tjK) {
@@ -1115,7 +1116,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       if (nb > 3 && lane >= K + 3) lrow[3] = x3;
     }
     __builtin_amdgcn_wave_barrier();
-    const long long tk1 = d.trace ? clock64() : 0;
+    const long long tk1 = (TR && d.trace) ? clock64() : 0;
     switch (tjK) {
       case 0: reg_trailing<0, NT>(c, P, nb, lane, (K + 4) >> 4); break;
       case 1: reg_trailing<1, NT>(c, P, nb, lane, (K + 4) >> 4); break;
@@ -1123,10 +1124,10 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       default: if (NT > 3) reg_trailing<(NT > 3 ? 3 : NT - 1), NT>(c, P, nb, lane, (K + 4) >> 4); break;
     }
     __builtin_amdgcn_wave_barrier();
-    if (d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
+    if (TR && d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
   }
-  PPS_TR(4);
-  if (d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
+  if (TR) PPS_TR(4);
+  if (TR && d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
   // ---- update matrix: live part of the tiles -> packed global ----
   double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
 #pragma unroll
@@ -1138,7 +1139,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
         const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
         if (row < fa && col <= row && col >= p) Us[tri(row - p) + col - p] = c[tile_id(ti, tj)][r];
       }
-  PPS_TR(5);
+  if (TR) PPS_TR(5);
 }
 
 
@@ -1231,9 +1232,10 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      if (REG_ONLY && fa <= 32) wave_front_factor_reg<2>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
-      else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
-      else if (REG_ONLY || fa <= kRegRows) wave_front_factor_reg<4>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      if (REG_ONLY && fa <= 32) wave_front_factor_reg<2, false>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3, false>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      else if (REG_ONLY) wave_front_factor_reg<4, false>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
       else wave_front_factor(d, s, lambda, F);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
@@ -1277,7 +1279,7 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     solve_per_wave = (int)(band_solve_lds_bytes(fused_solve_panel) / sizeof(double));
     bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
   }
-  if (max_front + 1 <= kRegRows && solve_per_wave == 0)
+  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
     hipLaunchKernelGGL(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, 0);
   else
     hipLaunchKernelGGL(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, solve_per_wave);
