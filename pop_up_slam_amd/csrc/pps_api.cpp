@@ -284,9 +284,9 @@ int run_analysis(pps_graph* g) {
   }
   if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
   if (const char* e = getenv("PPS_MAX_PIVOTS")) g->aprm.max_pivots = atoi(e);
-  // band depth: 3 levels per launch when the solve is latency bound (C2: 512 fronts), 2 when the lower levels are
-  // throughput bound (C3: 5 360 fronts; 637 vs 710 us per LM iteration)
-  g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 3;
+  // band depth: 4 levels per launch when the solve is latency bound (C2: 512 fronts; 113.3 vs 115.0 us per LM iteration
+  // with 3), 2 when the lower levels are throughput bound (C3: 5 360 fronts; 637 vs 710 us)
+  g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 4;
   if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
   if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
