@@ -88,11 +88,15 @@ struct pps_graph {
   Arena up, scr;
   std::vector<char> stage;          // host mirror of `up`
   size_t stage_lo = 0, stage_hi = 0;   // dirty range of the mirror
-  double* host_result = nullptr;   // pinned, 8 doubles
+  double* host_result = nullptr;   // pinned, 12 doubles: chi2 at the linearisation point | trial | speculative trial
   double seq = 0.0;                // sequence number the chi2 kernel publishes last (host polls it)
   // speculative solve of the LM reject branch (lambda * factor) on a second stream, into a second set of L/U/delta
   hipStream_t stream_b = nullptr;
-  hipEvent_t ev_h_ready = nullptr, ev_spec_done = nullptr;
+  hipEvent_t ev_h_ready = nullptr, ev_spec_done = nullptr, ev_retracted = nullptr, ev_spec_trial_done = nullptr;
+  // speculative trial: the step for lambda * factor applied to a third state copy and its chi2, on the second stream
+  double *spec_pose = nullptr, *spec_plane = nullptr, *spec_chi2_partials = nullptr, *spec_dn_partials = nullptr;
+  unsigned int* spec_ticket = nullptr;
+  double seq2 = 0.0;
   double *spec_L = nullptr, *spec_U = nullptr, *spec_delta = nullptr;
   bool spec_enabled = true;
   double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
@@ -231,11 +235,13 @@ int ensure_device(pps_graph* g) {
       HIP_TRY(g, hipStreamCreateWithFlags(&g->stream_b, hipStreamNonBlocking));
     }
   }
-  HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->host_result), 8 * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->host_result), 12 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(g, hipEventCreate(&g->ev[0]));
   HIP_TRY(g, hipEventCreate(&g->ev[1]));
   HIP_TRY(g, hipEventCreateWithFlags(&g->ev_h_ready, hipEventDisableTiming));
   HIP_TRY(g, hipEventCreateWithFlags(&g->ev_spec_done, hipEventDisableTiming));
+  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_retracted, hipEventDisableTiming));
+  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_spec_trial_done, hipEventDisableTiming));
   g->spec_enabled = !getenv("PPS_NO_SPEC");
   g->dev_ready = true;
   return PPS_OK;
@@ -454,6 +460,7 @@ int upload_all(pps_graph* g) {
   if (g->stream_b) HIP_TRY(g, hipStreamSynchronize(g->stream_b));
   free_device(g);
   g->spec_L = g->spec_U = g->spec_delta = nullptr;
+  g->spec_pose = g->spec_plane = g->spec_chi2_partials = g->spec_dn_partials = nullptr; g->spec_ticket = nullptr;
   g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
   g->frames_dirty = true;
   g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
@@ -550,6 +557,10 @@ int upload_all(pps_graph* g) {
   TRY(dev_alloc(g, &d.dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
   HIP_TRY(g, hipMemset(d.dn_partials, 0, ((size_t)(d.n_pose + d.n_plane + 255) / 256 + 1) * 8));
   TRY(dev_alloc(g, &d.ticket, 1)); HIP_TRY(g, hipMemset(d.ticket, 0, 4));
+  TRY(dev_alloc(g, &g->spec_pose, (size_t)7 * d.pose_ld + 1)); TRY(dev_alloc(g, &g->spec_plane, (size_t)4 * d.plane_ld + 1));
+  TRY(dev_alloc(g, &g->spec_chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
+  TRY(dev_alloc(g, &g->spec_dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
+  TRY(dev_alloc(g, &g->spec_ticket, 1)); HIP_TRY(g, hipMemset(g->spec_ticket, 0, 4));
   if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
   // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
   if (!g->use_band && !g->use_dense && A.max_front > lds_front_limit()) {
@@ -807,6 +818,8 @@ int pps_graph_destroy(pps_graph* g) {
     if (g->d_lm_planes) (void)hipFree(g->d_lm_planes);
     if (g->ev_h_ready) (void)hipEventDestroy(g->ev_h_ready);
     if (g->ev_spec_done) (void)hipEventDestroy(g->ev_spec_done);
+    if (g->ev_retracted) (void)hipEventDestroy(g->ev_retracted);
+    if (g->ev_spec_trial_done) (void)hipEventDestroy(g->ev_spec_trial_done);
     (void)hipStreamDestroy(g->stream);
   }
   delete g;
@@ -997,13 +1010,21 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   double lambda = prop.lm_lambda0;
   double* slot0 = g->host_result;       // chi2 at the linearisation point
   double* slot1 = g->host_result + 4;   // speculative trial: |delta|^2 of the step and chi2 after it
+  double* slot2 = g->host_result + 8;   // the same for the step computed with lambda * factor on the second stream
   // One stream, one host sync per LM trial.  After every solve the trial step is applied
   // speculatively (est <- lin, lin <- lin (+) delta) and its chi2 is reduced, so a single result
   // record carries everything the loop condition and the accept test need; if the loop ends on
   // |delta| <= eps2 the speculative step is undone (lin <- est).
+  bool spec_trial_pending = false;      // kernels of a speculative trial may still be in flight on the second stream
+  bool spec_trial_inflight = false;     // ... and their result (slot2) belongs to the step in spec_delta
   auto enqueue_trial_only = [&]() -> int {
     PhaseTimer t(g, &g->stats.t_retract_chi2);
+    if (spec_trial_pending) {          // the second stream's retraction read this state: let it finish first (it long has)
+      HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_trial_done, 0));
+      spec_trial_pending = false;
+    }
     HIP_TRY(g, launch_retract_trial(g->dev, g->stream));                       // linpoint_to_estimate + self_exmap (:414-416)
+    HIP_TRY(g, hipEventRecord(g->ev_retracted, g->stream));                    // est now holds the pre-trial point
     g->seq += 1.0;
     HIP_TRY(g, launch_chi2(g->dev, false, slot1, g->seq, g->stream));          // weighted_errors(LINPOINT) (:417)
     return PPS_OK;
@@ -1018,6 +1039,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   // costs one retraction + chi2 instead of a factorisation; arithmetic and lambda schedule are exactly
   // the reference's.  (One level deep only: a second consecutive rejection solves on the main stream.)
   const bool spec = g->spec_enabled && g->use_band && g->profiling < 2;
+  const bool spec_trial_enabled = spec && !getenv("PPS_NO_SPEC_TRIAL");
   bool spec_inflight = false;
   double spec_lambda = 0.0;
   auto launch_spec = [&](double lam) -> int {
@@ -1029,6 +1051,19 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
     HIP_TRY(g, hipEventRecord(g->ev_spec_done, g->stream_b));
     spec_inflight = true; spec_lambda = lam;
     g->stats.n_factorize++;
+    // ... and the trial itself: once the main stream has retracted (est = pre-trial point x), x (+) delta' goes into
+    // the third state copy and its chi2 into slot2, so that a rejection of the main trial finds the next trial's
+    // verdict already on the host -- no launch, no round trip.  Same kernels' arithmetic as the main trial.
+    if (spec_trial_enabled) {
+      DevGraph dt = g->dev;
+      dt.delta = g->spec_delta; dt.chi2_partials = g->spec_chi2_partials; dt.dn_partials = g->spec_dn_partials; dt.ticket = g->spec_ticket;
+      HIP_TRY(g, hipStreamWaitEvent(g->stream_b, g->ev_retracted, 0));
+      HIP_TRY(g, launch_retract_to(dt, g->dev.pose_est, g->dev.plane_est, g->spec_pose, g->spec_plane, g->stream_b));
+      g->seq2 += 1.0;
+      HIP_TRY(g, launch_chi2_at(dt, g->spec_pose, g->spec_plane, slot2, g->seq2, g->stream_b));
+      HIP_TRY(g, hipEventRecord(g->ev_spec_trial_done, g->stream_b));
+      spec_trial_inflight = true; spec_trial_pending = true;
+    }
     return PPS_OK;
   };
   rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:376)
@@ -1046,6 +1081,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   double dnorm = std::sqrt(slot1[1]);
   bool any_notpd = slot1[2] != 0.0;
   bool trial_pending = true;
+  bool have_result = false;
   while ((prop.max_iterations <= 0 || num_iter < prop.max_iterations) && dnorm > prop.epsilon2 && error > prop.epsilon_abs) {
     num_iter++;
     const double error_new = slot1[0];
@@ -1061,7 +1097,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
       // relinearise around the accepted point (:444); K2 overwrites H, which an unfinished speculative
       // solve would still be reading (it started together with the main solve, so this never blocks)
       if (spec_inflight) HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
-      spec_inflight = false;
+      spec_inflight = false; spec_trial_inflight = false;
       rc = do_linearize(g); if (rc != PPS_OK) return rc;
       if (spec) HIP_TRY(g, hipEventRecord(g->ev_h_ready, g->stream));
       rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;    // (:458)
@@ -1075,14 +1111,28 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
         HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
         std::swap(g->dev.L, g->spec_L); std::swap(g->dev.U, g->spec_U); std::swap(g->dev.delta, g->spec_delta);
         spec_inflight = false;
-        rc = enqueue_trial_only(); if (rc != PPS_OK) return rc;
+        if (spec_trial_inflight) {
+          // the trial for this lambda has been evaluated as well: rotate its state in (lin <- x (+) delta', est stays x;
+          // the buffer of the rejected trial becomes the next spare) and take its verdict from slot2
+          rc = wait_result(g, slot2, g->seq2); if (rc != PPS_OK) return rc;
+          double* const rej_pose = g->dev.pose_est; double* const rej_plane = g->dev.plane_est;   // after swap_state: the rejected x (+) delta
+          g->dev.pose_est = g->dev.pose_lin; g->dev.plane_est = g->dev.plane_lin;                   // x
+          g->dev.pose_lin = g->spec_pose; g->dev.plane_lin = g->spec_plane;                         // x (+) delta'
+          g->spec_pose = rej_pose; g->spec_plane = rej_plane;
+          slot1[0] = slot2[0]; slot1[1] = slot2[1]; slot1[2] = slot2[2];
+          spec_trial_inflight = false;
+          have_result = true;
+        } else {
+          rc = enqueue_trial_only(); if (rc != PPS_OK) return rc;
+        }
       } else {
         if (spec_inflight) HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
-        spec_inflight = false;
+        spec_inflight = false; spec_trial_inflight = false;
         rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;  // (:458)
       }
     }
-    rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc;
+    if (!have_result) { rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc; }
+    have_result = false;
     dnorm = std::sqrt(slot1[1]);
     any_notpd = any_notpd || slot1[2] != 0.0;
   }

@@ -1373,6 +1373,48 @@ __global__ __launch_bounds__(256) void k_retract(DevGraph d) {
   if (threadIdx.x == 0) d.dn_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// out <- base (+) delta, nothing else touched: the speculative LM trial (step computed for lambda * factor on the
+// second stream) is applied to a third copy of the state; |delta|^2 partials go to d.dn_partials
+__global__ __launch_bounds__(256) void k_retract_to(DevGraph d, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
+                                                    double* __restrict__ out_pose, double* __restrict__ out_plane) {
+  __shared__ double red[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double dn = 0.0;
+  if (i < d.n_pose) {
+    double p[7], o[7], dl[6];
+    load_pose(base_pose, d.pose_ld, i, p);
+    const int off = d.pose_voff[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    pose_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 7; k++) out_pose[(size_t)k * d.pose_ld + i] = o[k];
+  } else if (i < d.n_pose + d.n_plane) {
+    const int l = i - d.n_pose;
+    double p[4], o[4], dl[3];
+    load_plane(base_plane, d.plane_ld, l, p);
+    const int off = d.plane_voff[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    plane_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out_plane[(size_t)k * d.plane_ld + l] = o[k];
+  }
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
+  __syncthreads();
+  if (threadIdx.x == 0) d.dn_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+hipError_t launch_retract_to(const DevGraph& d, const double* base_pose, const double* base_plane, double* out_pose, double* out_plane,
+                             hipStream_t st) {
+  const int n = d.n_pose + d.n_plane;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_retract_to, dim3(cdiv(n, 256)), dim3(256), 0, st, d, base_pose, base_plane, out_pose, out_plane);
+  return hipGetLastError();
+}
+
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
   if (n == 0) return hipSuccess;
@@ -1494,6 +1536,18 @@ hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result,
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   const double* pose = at_estimate ? d.pose_est : d.pose_lin;
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
+  if (nb == 0) return hipErrorInvalidValue;
+  const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
+  hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
+  return hipGetLastError();
+}
+
+// chi2 at an explicit state (d.chi2_partials / d.ticket / d.dn_partials are the caller's: a second reduction may run
+// concurrently on another stream with its own set)
+hipError_t launch_chi2_at(const DevGraph& d, const double* pose, const double* plane, double* host_result, double seq, hipStream_t st) {
+  const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock),
+            nb_lp = cdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if (nb == 0) return hipErrorInvalidValue;
   const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
   hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
