@@ -34,13 +34,14 @@ B_ODO_EDGE = 840     # 216 B read + 624 B written per odometry edge
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(spec, budget_s=12.0):
-    """Reference-faithful CPU path (numeric Jacobians, re-ordering every factorisation, 1 thread)."""
+def cpu_baseline(spec, budget_s=12.0, optimised=False):
+    """Reference-faithful CPU path (numeric Jacobians, re-ordering every factorisation, 1 thread); `optimised`: the same
+    solver with closed-form Jacobians and the ordering computed once (what a tuned CPU build of the reference could do)."""
     from oracle import oracle_py as O
     iters, secs, runs, chi2 = 0, 0.0, 0, None
     phases = np.zeros(4)
     while secs < budget_s and runs < 8:
-        o = O.OracleGraph()
+        o = O.OracleGraph(analytic=1, cache_ordering=1) if optimised else O.OracleGraph()
         spec.replay(o)
         t0 = time.perf_counter()
         it = o.batch_optimize()
@@ -52,7 +53,8 @@ def cpu_baseline(spec, budget_s=12.0):
     return {
         "value": iters / secs, "unit": "LM iters/s", "cores": 1, "kind": "port",
         "sample": f"{runs} full LM solves of the same C2 graph ({iters} iterations, {secs:.1f} s), oracle/pps_oracle.c -O3, "
-                  f"numeric Jacobians + per-call re-ordering as the reference",
+                  + ("closed-form Jacobians + ordering computed once" if optimised else
+                     "numeric Jacobians + per-call re-ordering as the reference"),
         "final_chi2": chi2, "host_cores_total": os.cpu_count(),
         "phase_split_s": {"linearise": phases[0] / runs, "factor_solve": phases[1] / runs,
                           "retract_chi2": phases[2] / runs, "ordering": phases[3] / runs},
@@ -314,6 +316,9 @@ def main():
             cb = cpu_baseline(spec)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            cbo = cpu_baseline(spec, budget_s=4.0, optimised=True)      # the claim is shown against both
+            out["cpu_baseline_optimised"] = cbo
+            out["speedup_vs_cpu_baseline_optimised"] = out["value"] / cbo["value"]
             out["chi2_rel_err_vs_cpu"] = abs(chi2 - cb["final_chi2"]) / abs(cb["final_chi2"])
             if "other_mode" in out:
                 out["other_mode"]["chi2_rel_err_vs_cpu"] = abs(out["other_mode"]["final_chi2"] - cb["final_chi2"]) / abs(cb["final_chi2"])
