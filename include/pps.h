@@ -211,6 +211,9 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
 /* any output may be NULL: planes (n+1)x4 sensor-frame, cloud width*height pps_point, depth width*height,
  * plane_id width*height (-1 = none) */
 int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* depth, int32_t* plane_id);
+/* switch the optional per-pixel outputs of pps_popup_run off / on (default: both on).  The cloud alone is 16 B per pixel
+ * (what generate_cloud produces); the depth map (get_depth_map_good) and the plane-id map add 4 B each. */
+int pps_popup_set_outputs(pps_popup* p, int want_depth, int want_plane_id);
 /* ground_seg3d_lines_world of the last run (popup_plane.cpp:569-578): n x 6 = (x0,y0,0,x1,y1,0), the
  * world-frame ground end points of every segment -- columns 0,1 of all_3d_bound_polygons_world (:494-495),
  * which data association compares (Mapping.cpp:355-360). */

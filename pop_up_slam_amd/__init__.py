@@ -90,7 +90,7 @@ SYMBOLS = [
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
     "pps_find_closest_planes", "pps_graph_save", "pps_graph_load", "pps_add_plane_obs2", "pps_edge_ray",
-    "pps_time_linearize", "pps_reproject_points",
+    "pps_time_linearize", "pps_reproject_points", "pps_popup_set_outputs",
 ]
 
 
@@ -158,6 +158,7 @@ def lib():
         L.pps_refresh_measurements.argtypes = [C.c_void_p]
         L.pps_get_measurement.argtypes = [C.c_void_p, C.c_int, _dp]
         L.pps_popup_download_segments3d.argtypes = [C.c_void_p, _fp]
+        L.pps_popup_set_outputs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.pps_assoc_default_params.argtypes = [C.POINTER(PpsAssocParams)]
         L.pps_assoc_default_params.restype = None
         L.pps_landmark_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _fp]
@@ -535,6 +536,10 @@ class Popup:
         self._ck(self.L.pps_popup_download(self.h, planes.ctypes.data_as(_fp), cloud.ctypes.data_as(C.c_void_p),
                                            depth.ctypes.data_as(_fp), pid.ctypes.data_as(C.POINTER(C.c_int32))))
         return planes, cloud.reshape(self.h_, self.w), depth, pid
+
+    def set_outputs(self, depth=True, plane_id=True):
+        """optional per-pixel outputs of run(): the cloud alone is 16 B per pixel, depth and plane id add 4 B each"""
+        self._ck(self.L.pps_popup_set_outputs(self.h, int(depth), int(plane_id)))
 
     def segments3d(self):
         """ground_seg3d_lines_world of the last run: (n,6) world ground end points."""

@@ -27,7 +27,6 @@ namespace pps {
 
 constexpr int kMaxPlanes = 64;
 constexpr int kMaxVerts = 512;
-constexpr int kMaxPxPerThread = 8;     // pixels per thread of k_popup_frame on large images
 
 // one wall plane from a ground segment; exact operation order of the reference (and of the oracle)
 __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
@@ -77,13 +76,14 @@ __global__ __launch_bounds__(64) void k_popup_planes(const float* __restrict__ s
   for (int k = 0; k < 4; k++) planes_out[4 * j + k] = pl[k];
 }
 
-// Fused K5 + K6.  grid = ceil(W*H / 256), one thread per pixel.
+// Fused K5 + K6.  grid = (ceil(W / 256), ceil(H / PX)): a thread owns one column of PX consecutive rows.
+template <int PX>
 __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const float* __restrict__ seg2d, int n,
                                                      const float* __restrict__ polys, const int* __restrict__ poly_off,
                                                      int nplanes, const unsigned char* __restrict__ bgr,
                                                      float* __restrict__ planes_out, pps_point* __restrict__ cloud,
                                                      float* __restrict__ depth, int* __restrict__ plane_id,
-                                                     unsigned int* __restrict__ n_valid, int px_per_thread) {
+                                                     unsigned int* __restrict__ n_valid) {
   __shared__ float s_planes[kMaxPlanes + 1][4];
   __shared__ float s_poly[2 * kMaxVerts];
   __shared__ int s_off[kMaxPlanes + 2];
@@ -133,41 +133,64 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
 
   const int W = prm.width, H = prm.height;
   unsigned int kept = 0;
-  // px_per_thread pixels per thread, 256 apart: on large images the plane / polygon set-up above is paid once per
-  // few thousand pixels; small images keep one or two so that the launch still covers the chip
-#pragma unroll 1
-  for (int it = 0; it < px_per_thread; it++) {
-    const int idx = (blockIdx.x * px_per_thread + it) * 256 + tid;
-    bool keep = false;
-    if (idx < W * H) {
-      const int y = idx / W, x = idx - y * W;
-      int pid = -1;
-      const float fx = (float)x, fy = (float)y;
-      if (prm.step == 1 || (((x | y) & 1) == 0)) {
-        // ---- pixel -> plane: LAST convex polygon containing the pixel centre (edges inclusive): scan backwards ----
-        for (int p = nplanes - 1; p >= 0; p--) {
-          const int v0 = s_off[p], v1 = s_off[p + 1];
-          if (v1 - v0 < 3) continue;
-          if (fx < s_bbox[p][0] || fy < s_bbox[p][1] || fx > s_bbox[p][2] || fy > s_bbox[p][3]) continue;
-          bool pos = true, neg = true;
-          for (int v = v0; v < v1; v++) {
-            const int w = (v + 1 < v1) ? v + 1 : v0;
-            const float ax = s_poly[2 * v], ay = s_poly[2 * v + 1];
-            const float bx = s_poly[2 * w], by = s_poly[2 * w + 1];
-            const float cr = (bx - ax) * (fy - ay) - (by - ay) * (fx - ax);
-            pos = pos && (cr >= 0.f);
-            neg = neg && (cr <= 0.f);
-          }
-          if (pos || neg) { pid = p; break; }
+  // Column strip: the thread owns one x and kPxRows consecutive rows (blockIdx.y), so everything of the polygon test
+  // that depends on x only -- the box test, (bx-ax), (by-ay), (by-ay)*(fx-ax) -- and the polygon vertices (LDS
+  // broadcasts) are computed / fetched once per edge for all rows.  The per-pixel expressions are the reference's,
+  // operation for operation (hoisting does not change any rounding).
+  const int x = blockIdx.x * 256 + tid;
+  const int y0 = blockIdx.y * PX;
+  const bool xin = x < W;
+  const float fx = (float)x;
+  const bool xsel = prm.step == 1 || (x & 1) == 0;
+  int pid[PX];
+#pragma unroll
+  for (int k = 0; k < PX; k++) pid[k] = -1;
+  if (xin && xsel) {
+    for (int p = nplanes - 1; p >= 0; p--) {                 // LAST polygon containing the pixel wins: scan backwards
+      const int v0 = s_off[p], v1 = s_off[p + 1];
+      if (v1 - v0 < 3) continue;
+      if (fx < s_bbox[p][0] || fx > s_bbox[p][2]) continue;
+      unsigned int pos = 0xffffffffu, neg = 0xffffffffu;      // bit k: row k still on the non-negative / non-positive side
+      for (int v = v0; v < v1; v++) {
+        const int w = (v + 1 < v1) ? v + 1 : v0;
+        const float ax = s_poly[2 * v], ay = s_poly[2 * v + 1];
+        const float bx = s_poly[2 * w], by = s_poly[2 * w + 1];
+        const float A = bx - ax, B = by - ay;
+        const float t2 = B * (fx - ax);
+#pragma unroll
+        for (int k = 0; k < PX; k++) {
+          const float fy = (float)(y0 + k);
+          const float cr = A * (fy - ay) - t2;
+          if (!(cr >= 0.f)) pos &= ~(1u << k);
+          if (!(cr <= 0.f)) neg &= ~(1u << k);
         }
       }
+      const unsigned int in = pos | neg;
+      bool all_set = true;
+#pragma unroll
+      for (int k = 0; k < PX; k++) {
+        const float fy = (float)(y0 + k);
+        if (pid[k] < 0 && ((in >> k) & 1u) && !(fy < s_bbox[p][1] || fy > s_bbox[p][3])) pid[k] = p;
+        all_set = all_set && pid[k] >= 0;
+      }
+      if (all_set) break;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PX; k++) {
+    const int y = y0 + k;
+    bool keep = false;
+    if (xin && y < H) {
+      const int idx = y * W + x;
+      const float fy = (float)y;
+      const int pd = (prm.step == 1 || (y & 1) == 0) ? pid[k] : -1;
       pps_point pt;
       pt.x = pt.y = pt.z = 0.f;
       pt.rgba = 0u;
       float dep = 0.f;
-      if (pid >= 0) {
+      if (pd >= 0) {
         // ---- K6: ray-plane intersection (ray_plane_interact), world transform, filters ----
-        const float* pl = s_planes[pid];
+        const float* pl = s_planes[pd];
         float ray[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) ray[i] = prm.invK[i * 3 + 0] * fx + prm.invK[i * 3 + 1] * fy + prm.invK[i * 3 + 2] * 1.f;
@@ -198,15 +221,12 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
           if (!(z < 0.f)) dep = z;
         }
       }
-      cloud[idx] = pt;                     // one 16-byte store per lane
+      cloud[idx] = pt;                     // one 16-byte store per lane, a row segment per wave
       if (depth) depth[idx] = dep;
-      if (plane_id) plane_id[idx] = pid;
+      if (plane_id) plane_id[idx] = pd;
     }
     kept += (unsigned int)__popcll(__ballot(keep));
   }
-  const bool keep = false;
-  (void)keep;
-  // ---- count kept points: wave ballot, one LDS atomic per wave, one global atomic per block ----
   if ((tid & 63) == 0 && kept) atomicAdd(&s_cnt, kept);
   __syncthreads();
   if (tid == 0 && s_cnt) atomicAdd(n_valid, s_cnt);
@@ -270,6 +290,7 @@ struct pps_popup {
   pps_point* d_cloud = nullptr;
   float* d_depth = nullptr;
   int* d_pid = nullptr;
+  bool want_depth = true, want_pid = true;   // optional per-pixel outputs (pps_popup_set_outputs)
   float* d_planes = nullptr;   // (kMaxPlanes+1) x 4 plane equations, then kMaxPlanes x 6 world ground segments
   float* d_seg = nullptr;      // kMaxPlanes x 4
   float* d_polys = nullptr;    // 2*kMaxVerts
@@ -379,11 +400,18 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   PHIP(p, hipMemsetAsync(p->d_count, 0, sizeof(unsigned int), p->stream));
   const int npx = p->width * p->height;
   PHIP(p, hipEventRecord(p->ev[0], p->stream));
-  // enough workgroups to cover 256 CUs a few times over, then more pixels per thread
-  int pxt = std::max(1, std::min(kMaxPxPerThread, npx / (256 * 600)));   // 640x480 -> 2, 1080p and up -> 8
-  if (const char* e = getenv("PPS_POPUP_PXT")) pxt = std::max(1, std::min(64, atoi(e)));
-  hipLaunchKernelGGL(k_popup_frame, dim3((npx + 256 * pxt - 1) / (256 * pxt)), dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
-                     p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->d_depth, p->d_pid, p->d_count, pxt);
+  // column strips of 256 x PX pixels: 2 rows per thread on small frames (640x480: 720 workgroups), 8 from ~1 Mpixel up
+  int pxt = npx >= (1 << 20) ? 8 : 2;
+  if (const char* e = getenv("PPS_POPUP_PXT")) pxt = atoi(e) >= 8 ? 8 : 2;
+  const dim3 grid((p->width + 255) / 256, (p->height + pxt - 1) / pxt);
+  if (pxt == 8)
+    hipLaunchKernelGGL(k_popup_frame<8>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
+                       p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
+                       p->want_pid ? p->d_pid : nullptr, p->d_count);
+  else
+    hipLaunchKernelGGL(k_popup_frame<2>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
+                       p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
+                       p->want_pid ? p->d_pid : nullptr, p->d_count);
   PHIP(p, hipGetLastError());
   PHIP(p, hipEventRecord(p->ev[1], p->stream));
   PHIP(p, hipMemcpyAsync(p->h_count, p->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, p->stream));
@@ -402,8 +430,16 @@ int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* dep
   const size_t npx = (size_t)p->width * p->height;
   if (planes) PHIP(p, hipMemcpy(planes, p->d_planes, sizeof(float) * 4 * (size_t)(p->last_n + 1), hipMemcpyDeviceToHost));
   if (cloud) PHIP(p, hipMemcpy(cloud, p->d_cloud, npx * sizeof(pps_point), hipMemcpyDeviceToHost));
+  if (depth && !p->want_depth) return pfail(p, PPS_ESTATE, "depth output is switched off (pps_popup_set_outputs)");
+  if (plane_id && !p->want_pid) return pfail(p, PPS_ESTATE, "plane-id output is switched off (pps_popup_set_outputs)");
   if (depth) PHIP(p, hipMemcpy(depth, p->d_depth, npx * sizeof(float), hipMemcpyDeviceToHost));
   if (plane_id) PHIP(p, hipMemcpy(plane_id, p->d_pid, npx * sizeof(int), hipMemcpyDeviceToHost));
+  return PPS_OK;
+}
+
+int pps_popup_set_outputs(pps_popup* p, int want_depth, int want_plane_id) {
+  if (!p) return PPS_EINVAL;
+  p->want_depth = want_depth != 0; p->want_pid = want_plane_id != 0;
   return PPS_OK;
 }
 

@@ -249,6 +249,7 @@ def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, 
     g = P.Graph(jacobian_mode=jacobian_mode)
     g.frames_set_calibration(invK)
     pp = P.Popup(width, height, invK)
+    pp.set_outputs(depth=False, plane_id=False)      # the frame loop consumes the planes and the cloud only
     if with_image:
         rng = np.random.default_rng(seed)
         pp.set_image(rng.integers(0, 256, size=(height, width, 3), dtype=np.uint8))

@@ -15,6 +15,8 @@ for (w, h) in ((640, 480), (1920, 1080), (3840, 2160), (7680, 4320)):
     pose = synth.pose_from_Rt(synth.CAM_R0, np.array([0.0, 0.0, 1.0]))
     seg, polys, _ = synth.corridor_frame(pose, width=w, height=h, K=K)
     pp = P.Popup(w, h, invK)
+    if len(sys.argv) > 1 and sys.argv[1] == "cloud":
+        pp.set_outputs(depth=False, plane_id=False)
     rng = np.random.default_rng(0)
     pp.set_image(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
     T32 = synth.T_from_pose(pose).astype(np.float32)
