@@ -579,7 +579,7 @@ hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double*
 // ------------------------------------------------------------------------------------------
 // K2: one wavefront per H-block segment; lane = block entry, loop over <= seg_len contributions.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
+__global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) {
   const int seg = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (seg >= d.n_segs) return;
@@ -599,11 +599,11 @@ __global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
   const double* __restrict__ J = d.J;
   double acc = 0.0;
   int c = 0;
-  for (; c + 4 <= cnt; c += 4) {                          // four contributions' loads in flight
-    double a[4][6], bb[4][6];
-    int m[4];
+  for (; c + 2 <= cnt; c += 2) {                          // two contributions' loads in flight (64 VGPRs: 8 waves per SIMD)
+    double a[2][6], bb[2][6];
+    int m[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < 2; u++) {
       const int cc = c + u;
       const int jv = __builtin_amdgcn_readlane(mine.x, cc), ju = __builtin_amdgcn_readlane(mine.y, cc);
       const int ro = __builtin_amdgcn_readlane(mine.z, cc);
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_hblocks(DevGraph d) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 2; u++)
 #pragma unroll
       for (int k = 0; k < 6; k++) acc += a[u][k] * bb[u][k];
   }
