@@ -293,6 +293,10 @@ int run_analysis(pps_graph* g) {
   // band depth: 4 levels per launch when the solve is latency bound (C2: 512 fronts; 113.3 vs 115.0 us per LM iteration
   // with 3), 2 when the lower levels are throughput bound (C3: 5 360 fronts; 637 vs 710 us)
   g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 4;
+  // H-block segments (contributions reduced by one wave of K2): short on small graphs, where the few long segments
+  // (ground plane, 32 contributions = 16 dependent load rounds) are K2's critical path; long on large ones, where the
+  // number of waves is (C2: 23.3 -> 18.7 us with 8; C3: 82 -> 102 us)
+  g->aprm.seg_len = g->pose_ids.size() >= 4000 ? 32 : 8;
   if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
   if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);

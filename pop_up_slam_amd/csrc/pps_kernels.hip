@@ -593,6 +593,8 @@ __global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) {
   if (lane < cnt) mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
   const int rc = rows * cols;
   const bool act = lane < size;
+  // where the finished entry goes in front-gather order: does not depend on the values, so the load is issued now
+  const int dst = (act && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
   const bool is_g = lane >= rc;
   const int i = is_g ? lane - rc : lane / cols;
   const int j = is_g ? 0 : lane - (lane / cols) * cols;
@@ -642,10 +644,7 @@ __global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) {
   if (!act) return;
   if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
   d.H[hoff + lane] = acc;
-  if (nsegb == 1) {                                       // final value: also place it where its front will gather it
-    const int dst = d.blk_dst[doff + lane];
-    if (dst >= 0) d.Hf[dst] = acc;
-  }
+  if (dst >= 0) d.Hf[dst] = acc;                          // final value (single-segment block): also where its front gathers it
 }
 
 // fold the partial sums of multi-segment blocks (the ground plane's diagonal) into their first slot
