@@ -277,6 +277,57 @@ int pps_graph_load(const char* path, const pps_props* props, pps_graph** out);
  * cast back to fp32.  plane_ids[i] is the plane node of point i; points of removed (merged) landmarks are copied through. */
 int pps_reproject_points(pps_graph* g, int n, const int* plane_ids, const float* pts_xyz, float* out_xyz);
 
+/* ---- ground-edge selection: popup_plane::edge_get_polygons (pop_up_wall/libs/select_edge.cpp:66-409) -------------
+ * The step before the pop-up: the CNN label map (u8, ground = 255) and the raw LSD line segments of a frame become
+ * the ground / wall boundary polyline pps_popup_run and pps_frames_add take.  Per-pixel work runs on the device:
+ * [half-size nearest resize], dilate, erode and inversion of the label map in one kernel (select_edge.cpp:69-78),
+ * then the marching-squares cells of skimage.measure.find_contours(label, 0) in raster order (the reference calls it
+ * through boost::python, pop_up_fun.py:85-106).  The contour linking and the segment selection (steps 1-6 of
+ * select_edge.cpp and interval_tree_optimization, pop_up_fun.py:109-204) are sequential work on a few hundred
+ * segments and run on the host inside the same call.  LSD detection itself (line_lbd, OpenCV) is not part of this
+ * library: lsd_lines are an input, as they are for edge_get_polygons. */
+typedef struct pps_edge_params {
+  int downsample_contour;                    /* popup_plane.h:82 (false) */
+  int dilation_distance, erosion_distance;   /* popup_plane.cpp:32-33 (11, 11) */
+  /* popup_plane.h:184-192: 15 15 50 20 30 10 20 10 15 */
+  double pre_vertical_thre, pre_minium_len, pre_contour_close_thre, interval_overlap_thre, post_short_thre,
+         post_bind_dist_thre, post_merge_dist_thre, post_merge_angle_thre, post_extend_thre;
+  /* popup_plane.h:194-200: 5 10 10 20 0.6 0.8 100 */
+  double pre_boundary_thre, pre_merge_angle_thre, pre_merge_dist_thre, pre_proj_angle_thre, pre_proj_cover_thre,
+         pre_proj_cover_large_thre, pre_proj_dist_thre;
+} pps_edge_params;
+void pps_edge_default_params(pps_edge_params* p);
+
+typedef struct pps_edges pps_edges;   /* per-camera context: device buffers for one label-map size */
+int pps_edges_create(int device, int width, int height, pps_edges** out);
+int pps_edges_destroy(pps_edges* e);
+const char* pps_edges_last_error(const pps_edges* e);
+/* label_map: width*height u8, a host pointer or (label_on_device != 0) a device pointer on the context's device.
+ * lsd_lines n_lines x 4 (x1 y1 x2 y2), host.  Outputs (host, caller-allocated, 2*n_lines+2 rows each):
+ *   open_segs       n_open x 4    ground_seg2d_lines_actual
+ *   closed_segs     n_closed x 4  ground_seg2d_lines_connect (connecting pieces inserted)
+ *   open_in_closed  n_open        row of each open segment in closed_segs (actual_walls_in_closepoly_ind)
+ * No boundary in the label map / no line survives: n_open = n_closed = 0, PPS_OK (the reference prints
+ * "cannot find ground edges"). */
+int pps_edges_select(pps_edges* e, const unsigned char* label_map, int label_on_device, const float* lsd_lines,
+                     int n_lines, const pps_edge_params* prm, float* open_segs, int* n_open, float* closed_segs,
+                     int* n_closed, float* open_in_closed);
+/* intermediate results of the last pps_edges_select, for tests and debugging: the pre-processed label map
+ * (w x h bytes, ground = 0), the sub-sampled ground contour as (x, y) pairs, the number of contours found and the
+ * length of the chosen one */
+int pps_edges_download_label(pps_edges* e, unsigned char* out, int* w, int* h);
+int pps_edges_contour(pps_edges* e, float* xy, int cap, int* n, int* n_contours, int* n_points);
+/* device time of the kernels of the last pps_edges_select (HIP events), seconds */
+int pps_edges_last_kernel_time(const pps_edges* e, double* sec);
+/* The two host stages of pps_edges_select on their own (no device needed; used by the CPU tests):
+ * cell segments (n x 4 int16: from row, from column, to row, to column, in raster order of the cells) -> sub-sampled
+ * ground contour; contour + LSD lines -> selection. */
+int pps_edges_host_contour(const int16_t* cell_segs, int n, float scale, float* xy, int cap, int* n_xy, int* n_contours,
+                           int* n_points);
+int pps_edges_host_select(const float* contour_xy, int n_contour, int width, int height, const float* lsd_lines, int n_lines,
+                          const pps_edge_params* prm, float* open_segs, int* n_open, float* closed_segs, int* n_closed,
+                          float* open_in_closed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,12 @@ def lib():
             ("ora_popup_cloud", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_float, C.c_float, fp,
                                  C.POINTER(C.c_ubyte)], None),
             ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
+            ("ora_edge_default_params", [C.c_void_p], None),
+            ("ora_label_preprocess", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), ip, ip], None),
+            ("ora_ground_contour", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp, C.c_int, ip, ip], C.c_int),
+            ("ora_interval_tree_optimization", [fp, C.c_int, C.c_double, fp], C.c_int),
+            ("ora_select_edges_from_contour", [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_void_p, fp, ip, fp, ip, fp], C.c_int),
+            ("ora_select_ground_edges", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, fp, C.c_int, C.c_void_p, fp, ip, fp, ip, fp], C.c_int),
         ]:
             fn = getattr(L, name)
             fn.argtypes = args
@@ -325,3 +331,84 @@ def popup_depth(plane_id, invK, T_wc, planes_sensor, ceiling_plane_sensor, ceili
     lib().ora_popup_depth(pid.ctypes.data_as(C.POINTER(C.c_int)), w, h, pk, pt, pp, pl.reshape(-1, 4).shape[0],
                           pc, ceiling_thre, depth.ctypes.data_as(C.POINTER(C.c_float)))
     return depth
+
+
+# ---- ground-edge selection (pps_edges_oracle.c) --------------------------------------------------------------------
+class OraEdgeParams(C.Structure):
+    _fields_ = [("downsample_contour", C.c_int), ("dilation_distance", C.c_int), ("erosion_distance", C.c_int)] + [
+        (k, C.c_double) for k in ("pre_vertical_thre", "pre_minium_len", "pre_contour_close_thre", "interval_overlap_thre",
+                                  "post_short_thre", "post_bind_dist_thre", "post_merge_dist_thre", "post_merge_angle_thre",
+                                  "post_extend_thre", "pre_boundary_thre", "pre_merge_angle_thre", "pre_merge_dist_thre",
+                                  "pre_proj_angle_thre", "pre_proj_cover_thre", "pre_proj_cover_large_thre",
+                                  "pre_proj_dist_thre")]
+
+
+def edge_params(**kw):
+    p = OraEdgeParams()
+    lib().ora_edge_default_params(C.cast(C.byref(p), C.c_void_p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_ubyte))
+
+
+def label_preprocess(label, prm=None):
+    prm = prm or edge_params()
+    lab, pl = _u8(label); h, w = lab.shape
+    out = np.zeros(h * w, dtype=np.uint8); ow = C.c_int(); oh = C.c_int()
+    lib().ora_label_preprocess(pl, w, h, C.cast(C.byref(prm), C.c_void_p), out.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                               C.cast(C.byref(ow), C.POINTER(C.c_int)), C.cast(C.byref(oh), C.POINTER(C.c_int)))
+    return out[:ow.value * oh.value].reshape(oh.value, ow.value).copy()
+
+
+def ground_contour(pre, downsample=False):
+    """-> (sub-sampled contour (n, 2) as (x, y), number of contours, points of the chosen contour)"""
+    a, pa = _u8(pre); h, w = a.shape
+    cap = 4 * (w + h) + 64
+    xy = np.zeros((cap, 2), dtype=np.float32); nc = C.c_int(); npnt = C.c_int()
+    n = lib().ora_ground_contour(pa, w, h, int(bool(downsample)), xy.ctypes.data_as(C.POINTER(C.c_float)), cap,
+                                 C.cast(C.byref(nc), C.POINTER(C.c_int)), C.cast(C.byref(npnt), C.POINTER(C.c_int)))
+    return xy[:min(n, cap)].copy(), nc.value, npnt.value
+
+
+def interval_tree_optimization(lines, overlap_thre=20.0):
+    l, pl = _f(lines); n = l.reshape(-1, 4).shape[0]
+    out = np.zeros(((2 * n + 2) * (n + 2), 4), dtype=np.float32)
+    m = lib().ora_interval_tree_optimization(pl, n, float(overlap_thre), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:m].copy()
+
+
+def _edge_outputs(n):
+    cap = 2 * n + 2
+    return (np.zeros((cap, 4), dtype=np.float32), np.zeros((cap, 4), dtype=np.float32), np.zeros(cap, dtype=np.float32),
+            C.c_int(), C.c_int())
+
+
+def select_edges_from_contour(cxy, width, height, lsd, prm=None):
+    prm = prm or edge_params()
+    c, pc = _f(cxy); l, pl = _f(lsd); n = l.reshape(-1, 4).shape[0]
+    o, cl, idx, no, ncl = _edge_outputs(n)
+    fpp = C.POINTER(C.c_float); ipp = C.POINTER(C.c_int)
+    lib().ora_select_edges_from_contour(pc, c.reshape(-1, 2).shape[0], int(width), int(height), pl, n,
+                                        C.cast(C.byref(prm), C.c_void_p), o.ctypes.data_as(fpp), C.cast(C.byref(no), ipp),
+                                        cl.ctypes.data_as(fpp), C.cast(C.byref(ncl), ipp), idx.ctypes.data_as(fpp))
+    return o[:no.value].copy(), cl[:ncl.value].copy(), idx[:no.value].copy()
+
+
+def select_ground_edges(label, lsd, prm=None):
+    """edge_get_polygons: -> (open segments, closed polyline, index of each open segment in the closed list)"""
+    prm = prm or edge_params()
+    lab, pl_ = _u8(label); h, w = lab.shape
+    l, pl = _f(lsd); n = l.reshape(-1, 4).shape[0]
+    o, cl, idx, no, ncl = _edge_outputs(n)
+    fpp = C.POINTER(C.c_float); ipp = C.POINTER(C.c_int)
+    lib().ora_select_ground_edges(pl_, w, h, pl, n, C.cast(C.byref(prm), C.c_void_p), o.ctypes.data_as(fpp),
+                                  C.cast(C.byref(no), ipp), cl.ctypes.data_as(fpp), C.cast(C.byref(ncl), ipp),
+                                  idx.ctypes.data_as(fpp))
+    return o[:no.value].copy(), cl[:ncl.value].copy(), idx[:no.value].copy()

@@ -147,6 +147,37 @@ void ora_popup_depth(const int* plane_id, int width, int height, const float inv
                      const float* planes_sensor, int nplanes, const float ceiling_plane_sensor[4],
                      float ceiling_thre, float* depth_out);
 
+/* ---- ground-edge selection: popup_plane::edge_get_polygons (pop_up_wall/libs/select_edge.cpp:66-409) with its
+ * Python helpers (pop_up_python/.../pop_up_fun.py:85-204); restated in pps_edges_oracle.c ---------------- */
+typedef struct ora_edge_params {
+  int downsample_contour;                    /* popup_plane.h:82 */
+  int dilation_distance, erosion_distance;   /* popup_plane.cpp:32-33 */
+  /* popup_plane.h:184-192 (ROS-settable) */
+  double pre_vertical_thre, pre_minium_len, pre_contour_close_thre, interval_overlap_thre, post_short_thre,
+         post_bind_dist_thre, post_merge_dist_thre, post_merge_angle_thre, post_extend_thre;
+  /* popup_plane.h:194-200 */
+  double pre_boundary_thre, pre_merge_angle_thre, pre_merge_dist_thre, pre_proj_angle_thre, pre_proj_cover_thre,
+         pre_proj_cover_large_thre, pre_proj_dist_thre;
+} ora_edge_params;
+void ora_edge_default_params(ora_edge_params* p);
+/* select_edge.cpp:69-78: [half-size nearest], dilate, erode, 255 - x.  out holds ow*oh bytes (<= w*h) */
+void ora_label_preprocess(const unsigned char* label, int w, int h, const ora_edge_params* prm, unsigned char* out,
+                          int* ow, int* oh);
+/* pop_up_fun.py:85-106 on a pre-processed map: returns the number of sub-sampled contour points (x, y) */
+int ora_ground_contour(const unsigned char* pre, int w, int h, int downsample, float* xy, int cap, int* n_contours,
+                       int* n_points);
+/* pop_up_fun.py:109-204; out holds up to (2n+2)(n+2) rows of 4 */
+int ora_interval_tree_optimization(const float* lines, int n, double overlap_thre, float* out);
+/* select_edge.cpp:92-405 given the sub-sampled contour; segment outputs hold up to 2*n_lsd+2 rows of 4 */
+int ora_select_edges_from_contour(const float* cxy, int ncont, int width, int height, const float* lsd, int n_lsd,
+                                  const ora_edge_params* prm, float* open_segs, int* n_open, float* closed_segs,
+                                  int* n_closed, float* open_in_closed);
+/* the whole of edge_get_polygons: label map (ground = 255) + LSD lines (n x 4: x1 y1 x2 y2) -> open segments, closed
+ * polyline, index of each open segment in the closed list */
+int ora_select_ground_edges(const unsigned char* label, int w, int h, const float* lsd, int n_lsd,
+                            const ora_edge_params* prm, float* open_segs, int* n_open, float* closed_segs, int* n_closed,
+                            float* open_in_closed);
+
 #ifdef __cplusplus
 }
 #endif

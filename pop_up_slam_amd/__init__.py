@@ -70,6 +70,16 @@ def edge_ray(invK, seg2d):
     return out
 
 
+class PpsEdgeParams(C.Structure):
+    """pps_edge_params (include/pps.h): popup_plane.h:82,184-200."""
+    _fields_ = [("downsample_contour", C.c_int), ("dilation_distance", C.c_int), ("erosion_distance", C.c_int)] + [
+        (k, C.c_double) for k in ("pre_vertical_thre", "pre_minium_len", "pre_contour_close_thre", "interval_overlap_thre",
+                                  "post_short_thre", "post_bind_dist_thre", "post_merge_dist_thre", "post_merge_angle_thre",
+                                  "post_extend_thre", "pre_boundary_thre", "pre_merge_angle_thre", "pre_merge_dist_thre",
+                                  "pre_proj_angle_thre", "pre_proj_cover_thre", "pre_proj_cover_large_thre",
+                                  "pre_proj_dist_thre")]
+
+
 class PpsAssocParams(C.Structure):
     """pps_assoc_params (include/pps.h); defaults = Mapping.h:70-77 via pps_assoc_default_params."""
     _fields_ = [("edge_asso_2ddist", C.c_double), ("edge_asso_planedist", C.c_double), ("edge_asso_proj", C.c_double),
@@ -91,6 +101,9 @@ SYMBOLS = [
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
     "pps_find_closest_planes", "pps_graph_save", "pps_graph_load", "pps_add_plane_obs2", "pps_edge_ray",
     "pps_time_linearize", "pps_reproject_points", "pps_popup_set_outputs",
+    "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
+    "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
+    "pps_edges_host_select",
 ]
 
 
@@ -160,6 +173,16 @@ def lib():
         L.pps_popup_download_segments3d.argtypes = [C.c_void_p, _fp]
         L.pps_popup_set_outputs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.pps_assoc_default_params.argtypes = [C.POINTER(PpsAssocParams)]
+        L.pps_edge_default_params.argtypes = [C.POINTER(PpsEdgeParams)]; L.pps_edge_default_params.restype = None
+        L.pps_edges_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pps_edges_destroy.argtypes = [C.c_void_p]
+        L.pps_edges_last_error.argtypes = [C.c_void_p]; L.pps_edges_last_error.restype = C.c_char_p
+        L.pps_edges_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _fp, C.c_int, C.POINTER(PpsEdgeParams), _fp, _ip, _fp, _ip, _fp]
+        L.pps_edges_download_label.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), _ip, _ip]
+        L.pps_edges_contour.argtypes = [C.c_void_p, _fp, C.c_int, _ip, _ip, _ip]
+        L.pps_edges_last_kernel_time.argtypes = [C.c_void_p, _dp]
+        L.pps_edges_host_contour.argtypes = [C.POINTER(C.c_int16), C.c_int, C.c_float, _fp, C.c_int, _ip, _ip, _ip]
+        L.pps_edges_host_select.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.POINTER(PpsEdgeParams), _fp, _ip, _fp, _ip, _fp]
         L.pps_assoc_default_params.restype = None
         L.pps_landmark_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _fp]
         L.pps_landmark_set_merged.argtypes = [C.c_void_p, C.c_int]
@@ -549,3 +572,103 @@ class Popup:
 
     def last_kernel_time(self):
         s = C.c_double(); self._ck(self.L.pps_popup_last_kernel_time(self.h, C.byref(s))); return s.value
+
+
+def edge_params(**kw):
+    """pps_edge_params with the reference's defaults, fields overridden by keyword."""
+    p = PpsEdgeParams(); lib().pps_edge_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Edges:
+    """Ground-edge selection context (popup_plane::get_ground_edges after the LSD detector), label-map-size bound."""
+
+    def __init__(self, width, height, device=0):
+        self.L = lib()
+        self.w, self.h_ = int(width), int(height)
+        h = C.c_void_p()
+        rc = self.L.pps_edges_create(device, self.w, self.h_, C.byref(h))
+        if rc != PPS_OK:
+            raise PpsError(rc, "pps_edges_create failed")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pps_edges_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != PPS_OK:
+            raise PpsError(rc, self.L.pps_edges_last_error(self.h).decode())
+
+    def select(self, label_map, lsd_lines, prm=None, device_ptr=None):
+        """edge_get_polygons: -> (open segments (n, 4), closed polyline (m, 4), row of each open segment in the closed list).
+        label_map: (height, width) u8 array with ground = 255, or pass device_ptr (int) for a map already in HBM."""
+        l = np.ascontiguousarray(lsd_lines, dtype=np.float32).reshape(-1, 4); n = l.shape[0]
+        cap = 2 * n + 2
+        o = np.zeros((cap, 4), dtype=np.float32); cl = np.zeros((cap, 4), dtype=np.float32); idx = np.zeros(cap, dtype=np.float32)
+        no = C.c_int(); ncl = C.c_int()
+        if device_ptr is None:
+            lab = np.ascontiguousarray(label_map, dtype=np.uint8)
+            if lab.shape != (self.h_, self.w):
+                raise ValueError("label map shape %r != (%d, %d)" % (lab.shape, self.h_, self.w))
+            src, on_dev = lab.ctypes.data_as(C.c_void_p), 0
+        else:
+            src, on_dev = C.c_void_p(int(device_ptr)), 1
+        self._ck(self.L.pps_edges_select(self.h, src, on_dev, l.ctypes.data_as(_fp), n, C.byref(prm) if prm is not None else None,
+                                         o.ctypes.data_as(_fp), C.byref(no), cl.ctypes.data_as(_fp), C.byref(ncl),
+                                         idx.ctypes.data_as(_fp)))
+        return o[:no.value].copy(), cl[:ncl.value].copy(), idx[:no.value].copy()
+
+    def label(self):
+        """pre-processed label map of the last select (ground = 0)"""
+        out = np.zeros(self.w * self.h_, dtype=np.uint8); w = C.c_int(); h = C.c_int()
+        self._ck(self.L.pps_edges_download_label(self.h, out.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(w), C.byref(h)))
+        return out[:w.value * h.value].reshape(h.value, w.value).copy()
+
+    def contour(self):
+        """-> (sub-sampled ground contour (n, 2) as (x, y), contours found, points of the chosen contour)"""
+        cap = 4 * (self.w + self.h_) + 64
+        xy = np.zeros((cap, 2), dtype=np.float32); n = C.c_int(); nc = C.c_int(); npnt = C.c_int()
+        self._ck(self.L.pps_edges_contour(self.h, xy.ctypes.data_as(_fp), cap, C.byref(n), C.byref(nc), C.byref(npnt)))
+        return xy[:min(n.value, cap)].copy(), nc.value, npnt.value
+
+    def last_kernel_time(self):
+        s = C.c_double(); self._ck(self.L.pps_edges_last_kernel_time(self.h, C.byref(s))); return s.value
+
+
+def edges_host_contour(cell_segs, scale=1.0):
+    """host stage 1 of Edges.select: cell segments (n, 4) int16 -> (sub-sampled contour (m, 2), contours, points)"""
+    sg = np.ascontiguousarray(cell_segs, dtype=np.int16).reshape(-1, 4); L = lib()
+    cap = 1 + sg.shape[0] // 10 + 64
+    xy = np.zeros((cap, 2), dtype=np.float32); n = C.c_int(); nc = C.c_int(); npnt = C.c_int()
+    rc = L.pps_edges_host_contour(sg.ctypes.data_as(C.POINTER(C.c_int16)), sg.shape[0], float(scale), xy.ctypes.data_as(_fp), cap,
+                                  C.byref(n), C.byref(nc), C.byref(npnt))
+    if rc != PPS_OK:
+        raise PpsError(rc, "pps_edges_host_contour")
+    return xy[:min(n.value, cap)].copy(), nc.value, npnt.value
+
+
+def edges_host_select(contour_xy, width, height, lsd_lines, prm=None):
+    """host stage 2 of Edges.select: contour + LSD lines -> (open, closed, open_in_closed)"""
+    c = np.ascontiguousarray(contour_xy, dtype=np.float32).reshape(-1, 2)
+    l = np.ascontiguousarray(lsd_lines, dtype=np.float32).reshape(-1, 4); n = l.shape[0]; L = lib()
+    cap = 2 * n + 2
+    o = np.zeros((cap, 4), dtype=np.float32); cl = np.zeros((cap, 4), dtype=np.float32); idx = np.zeros(cap, dtype=np.float32)
+    no = C.c_int(); ncl = C.c_int()
+    rc = L.pps_edges_host_select(c.ctypes.data_as(_fp), c.shape[0], int(width), int(height), l.ctypes.data_as(_fp), n,
+                                 C.byref(prm) if prm is not None else None, o.ctypes.data_as(_fp), C.byref(no),
+                                 cl.ctypes.data_as(_fp), C.byref(ncl), idx.ctypes.data_as(_fp))
+    if rc != PPS_OK:
+        raise PpsError(rc, "pps_edges_host_select")
+    return o[:no.value].copy(), cl[:ncl.value].copy(), idx[:no.value].copy()
