@@ -4,12 +4,14 @@
 //
 // K7a k_label_close   [half-size nearest] -> dilate -> erode -> 255 - x in ONE pass over the label map
 //                     (select_edge.cpp:69-78: cv::resize / dilate / erode / convertTo are four full-image passes
-//                     there).  A 64 x 16 tile with the halo of both structuring elements is staged in LDS; the four
-//                     separable max / min passes run LDS -> LDS.  Algorithmic traffic: 1 B read + 1 B written per pixel.
-// K7b k_cells_count / k_cells_emit   the marching-squares cells of skimage.measure.find_contours(label, 0), in the
-//                     raster order the Python code walks them (the contour linking that follows depends on that
-//                     order): one workgroup per cell row counts its segments, a second launch places every row at the
-//                     prefix sum of the rows above it and orders the segments of a row with a workgroup scan.
+//                     there).  A 64 x 32 tile with the halo of both structuring elements is staged in LDS; the four
+//                     separable max / min passes run LDS -> LDS, a thread producing four neighbouring window extrema
+//                     from one shared partial result.  Algorithmic traffic: 1 B read + 1 B written per pixel.  The tile
+//                     also classifies its marching-squares cells and adds their segment counts to a per-row counter.
+// K7b k_cells_emit    the marching-squares cells of skimage.measure.find_contours(label, 0), in the raster order the
+//                     Python code walks them (the contour linking that follows depends on that order): one workgroup
+//                     per cell row starts at the prefix sum of the rows above it and orders the segments of its row
+//                     with a workgroup scan.
 // The linking of the segments into contours and the selection itself are host work (pps_edges_host.cpp).
 #include <hip/hip_runtime.h>
 
@@ -24,7 +26,7 @@
 
 namespace {
 
-constexpr int kTileX = 64, kTileY = 16, kCloseThreads = 256;
+constexpr int kTileX = 64, kTileY = 32, kCloseThreads = 256;
 constexpr int kMaxElement = 31;   // largest structuring element side the LDS tile is sized for
 
 struct CloseArgs {
@@ -32,68 +34,143 @@ struct CloseArgs {
   int half;                               // 1: work on the half-size nearest-neighbour copy (src(2x, 2y))
   unsigned char* dst; int w, h;           // pre-processed map
   int kd, ke;                             // dilate / erode element side
+  int* row_count;                         // [h - 1] segments per cell row, zero on entry (atomically accumulated)
 };
+
+// LDS geometry of k_label_close for elements kd / ke: pitch and rows of one buffer (two buffers are used).  The output
+// region is (kTileX + 1) x (kTileY + 1): one extra column / row so that the cells along the tile's right / lower
+// border can be classified here; +3 because a thread produces strips of four values and may run past the end.
+__host__ __device__ inline int close_pitch(int kd, int ke) { return (kTileX + 1 + (kd - 1) + (ke - 1) + 3 + 3) & ~3; }
+__host__ __device__ inline int close_rows(int kd, int ke) { return kTileY + 1 + (kd - 1) + (ke - 1) + 3; }
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+// four neighbouring window extrema at once: out[j] = op over p[(j + i) * stride], i < k.  The k - 3 values shared by
+// all four windows are reduced once (k + 8 operations for four results instead of 4 k).
+template <bool MAX, int K>
+__device__ __forceinline__ void window4(const unsigned char* __restrict__ p, int stride, int k_rt, int out[4]) {
+  const int k = K > 0 ? K : k_rt;
+  auto op = [](int x, int y) { return MAX ? imax(x, y) : imin(x, y); };
+  if (k >= 4) {
+    int core = p[3 * stride];
+    if (K > 0) {
+#pragma unroll
+      for (int i = 4; i < K; i++) core = op(core, p[i * stride]);
+    } else {
+      for (int i = 4; i < k; i++) core = op(core, p[i * stride]);
+    }
+    const int b0 = p[0], b1 = p[stride], b2 = p[2 * stride];
+    const int c0 = p[k * stride], c1 = p[(k + 1) * stride], c2 = p[(k + 2) * stride];
+    const int b12 = op(b1, b2), c01 = op(c0, c1);
+    out[0] = op(core, op(b0, b12));
+    out[1] = op(core, op(b12, c0));
+    out[2] = op(core, op(b2, c01));
+    out[3] = op(core, op(c01, c2));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int v = p[j * stride];
+      for (int i = 1; i < k; i++) v = op(v, p[(j + i) * stride]);
+      out[j] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ int cell_segments(const unsigned char* __restrict__ img, int w, int r0, int c0, pps_edges_host::CellSeg out[2]);
+
+template <int KD, int KE>
 __global__ __launch_bounds__(kCloseThreads) void k_label_close(CloseArgs a) {
   extern __shared__ unsigned char lds[];
-  // element windows: [-ad, bd] for the dilation, [-ae, be] for the erosion (default anchor = side / 2)
-  const int ad = a.kd / 2, bd = a.kd - 1 - ad, ae = a.ke / 2, be = a.ke - 1 - ae;
-  const int RX = kTileX + (a.kd - 1) + (a.ke - 1), RY = kTileY + (a.kd - 1) + (a.ke - 1);   // source region
-  const int DX = kTileX + (a.ke - 1), DY = kTileY + (a.ke - 1);                               // dilated region
+  const int kd = KD > 0 ? KD : a.kd, ke = KE > 0 ? KE : a.ke;
+  // element windows: [-ad, kd-1-ad] for the dilation, [-ae, ke-1-ae] for the erosion (default anchor = side / 2)
+  const int ad = kd / 2, ae = ke / 2;
+  const int OX = kTileX + 1, OY = kTileY + 1;              // closed values wanted (own pixels + the cell halo)
+  const int DX = OX + (ke - 1), DY = OY + (ke - 1);        // dilated values wanted
+  const int RX = DX + (kd - 1), RY = DY + (kd - 1);        // source region
+  const int P = close_pitch(kd, ke);
   unsigned char* A = lds;
-  unsigned char* B = lds + RX * RY;
+  unsigned char* B = lds + P * close_rows(kd, ke);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int x0 = blockIdx.x * kTileX, y0 = blockIdx.y * kTileY;
   const int sx0 = x0 - ae - ad, sy0 = y0 - ae - ad;
-  // 1. source region; outside the image 0, which the maximum ignores
-  for (int i = threadIdx.x; i < RX * RY; i += kCloseThreads) {
-    const int yy = i / RX, xx = i - yy * RX;
-    const int x = sx0 + xx, y = sy0 + yy;
-    unsigned char v = 0;
-    if (x >= 0 && x < a.w && y >= 0 && y < a.h) {
-      const int sx = a.half ? imin(2 * x, a.sw - 1) : x, sy = a.half ? imin(2 * y, a.sh - 1) : y;
-      v = a.src[(size_t)sy * a.sw + sx];
+  // 1. source region -> A; outside the image 0, which the maximum ignores
+#pragma unroll 4
+  for (int yy = wv; yy < RY; yy += kCloseThreads / 64) {
+    const int y = sy0 + yy;
+    const bool yin = y >= 0 && y < a.h;
+    const size_t row = (size_t)(a.half ? imin(2 * y, a.sh - 1) : y) * a.sw;
+    for (int xx = lane; xx < RX; xx += 64) {
+      const int x = sx0 + xx;
+      unsigned char v = 0;
+      if (yin && x >= 0 && x < a.w) v = a.src[row + (a.half ? imin(2 * x, a.sw - 1) : x)];
+      A[yy * P + xx] = v;
     }
-    A[i] = v;
   }
   __syncthreads();
-  // 2. maximum along x: B (RY x DX)
-  for (int i = threadIdx.x; i < RY * DX; i += kCloseThreads) {
-    const int yy = i / DX, xx = i - yy * DX;
-    int v = 0;
-    for (int j = 0; j < a.kd; j++) v = imax(v, A[yy * RX + xx + j]);
-    B[i] = (unsigned char)v;
+  int o[4];
+  // 2. maximum along x: A -> B (RY rows x DX)
+  {
+    const int SX = (DX + 3) >> 2;
+    for (int i = tid; i < RY * SX; i += kCloseThreads) {
+      const int yy = i / SX, xs = (i - yy * SX) << 2;
+      window4<true, KD>(A + yy * P + xs, 1, kd, o);
+      *reinterpret_cast<uchar4*>(B + yy * P + xs) = make_uchar4((unsigned char)o[0], (unsigned char)o[1], (unsigned char)o[2], (unsigned char)o[3]);
+    }
   }
   __syncthreads();
-  // 3. maximum along y: A (DY x DX); a position outside the image is 255, which the minimum ignores
-  for (int i = threadIdx.x; i < DY * DX; i += kCloseThreads) {
-    const int yy = i / DX, xx = i - yy * DX;
-    const int x = x0 - ae + xx, y = y0 - ae + yy;
-    int v = 0;
-    for (int j = 0; j < a.kd; j++) v = imax(v, B[(yy + j) * DX + xx]);
-    A[i] = (x >= 0 && x < a.w && y >= 0 && y < a.h) ? (unsigned char)v : (unsigned char)255;
+  // 3. maximum along y: B -> A (DY x DX); a position outside the image becomes 255, which the minimum ignores
+  {
+    const int SY = (DY + 3) >> 2;
+    for (int i = tid; i < SY * DX; i += kCloseThreads) {
+      const int ys = (i / DX) << 2, xx = i - (i / DX) * DX;
+      window4<true, KD>(B + ys * P + xx, P, kd, o);
+      const int x = x0 - ae + xx;
+      const bool xin = x >= 0 && x < a.w;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int y = y0 - ae + ys + j;
+        A[(ys + j) * P + xx] = (xin && y >= 0 && y < a.h) ? (unsigned char)o[j] : (unsigned char)255;
+      }
+    }
   }
   __syncthreads();
-  // 4. minimum along x: B (DY x kTileX)
-  for (int i = threadIdx.x; i < DY * kTileX; i += kCloseThreads) {
-    const int yy = i / kTileX, xx = i - yy * kTileX;
-    int v = 255;
-    for (int j = 0; j < a.ke; j++) v = imin(v, A[yy * DX + xx + j]);
-    B[i] = (unsigned char)v;
+  // 4. minimum along x: A -> B (DY x OX)
+  {
+    const int SX = (OX + 3) >> 2;
+    for (int i = tid; i < DY * SX; i += kCloseThreads) {
+      const int yy = i / SX, xs = (i - yy * SX) << 2;
+      window4<false, KE>(A + yy * P + xs, 1, ke, o);
+      *reinterpret_cast<uchar4*>(B + yy * P + xs) = make_uchar4((unsigned char)o[0], (unsigned char)o[1], (unsigned char)o[2], (unsigned char)o[3]);
+    }
   }
   __syncthreads();
-  // 5. minimum along y, inverted: ground 255 -> 0
-  for (int i = threadIdx.x; i < kTileY * kTileX; i += kCloseThreads) {
-    const int yy = i / kTileX, xx = i - yy * kTileX;
-    const int x = x0 + xx, y = y0 + yy;
-    if (x >= a.w || y >= a.h) continue;
-    int v = 255;
-    for (int j = 0; j < a.ke; j++) v = imin(v, B[(yy + j) * kTileX + xx]);
-    a.dst[(size_t)y * a.w + x] = (unsigned char)(255 - v);
+  // 5. minimum along y, inverted (ground 255 -> 0): B -> A (OY x OX) and, for the tile's own pixels, -> dst
+  {
+    const int SY = (OY + 3) >> 2;
+    for (int i = tid; i < SY * OX; i += kCloseThreads) {
+      const int ys = (i / OX) << 2, xx = i - (i / OX) * OX;
+      window4<false, KE>(B + ys * P + xx, P, ke, o);
+      const int x = x0 + xx;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int yy = ys + j, y = y0 + yy;
+        const unsigned char v = (unsigned char)(255 - o[j]);
+        A[yy * P + xx] = v;
+        if (xx < kTileX && yy < kTileY && x < a.w && y < a.h) a.dst[(size_t)y * a.w + x] = v;
+      }
+    }
   }
-  (void)bd; (void)be;
+  __syncthreads();
+  // 6. segments per cell row of this tile (k_cells_emit places the rows)
+  for (int yy = wv; yy < kTileY; yy += kCloseThreads / 64) {
+    const int y = y0 + yy, x = x0 + lane;
+    if (y + 1 >= a.h) break;
+    pps_edges_host::CellSeg tmp[2];
+    int n = x + 1 < a.w ? cell_segments(A, P, yy, lane, tmp) : 0;
+    for (int s = 32; s > 0; s >>= 1) n += __shfl_down(n, s);
+    if (lane == 0 && n) atomicAdd(a.row_count + y, n);
+  }
 }
 
 // The segments of one 2x2 cell at level 0: a vertex is "high" when > 0 and an edge crossing sits on the zero end of
@@ -131,52 +208,35 @@ __device__ __forceinline__ int cell_segments(const unsigned char* __restrict__ i
 
 constexpr int kRowThreads = 256;
 
-__device__ __forceinline__ int block_sum(int v, int* scratch) {   // all threads get the total
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) scratch[wave] = v;
-  __syncthreads();
-  int t = 0;
-  for (int k = 0; k < kRowThreads / 64; k++) t += scratch[k];
-  return t;
-}
+constexpr int kEmitRowsPerGroup = kRowThreads / 64;
 
-__global__ __launch_bounds__(kRowThreads) void k_cells_count(const unsigned char* __restrict__ img, int w, int h, int* __restrict__ row_count) {
-  __shared__ int scratch[kRowThreads / 64];
-  const int r0 = blockIdx.x;
-  int n = 0;
-  pps_edges_host::CellSeg tmp[2];
-  for (int c0 = threadIdx.x; c0 + 1 < w; c0 += kRowThreads) n += cell_segments(img, w, r0, c0, tmp);
-  const int total = block_sum(n, scratch);
-  if (threadIdx.x == 0) row_count[r0] = total;
-}
-
+// One wavefront per cell row, no LDS and no workgroup barrier: a lane owns a run of consecutive cells, counts their
+// segments, a shuffle scan places the runs, and the lane classifies its cells a second time to write them in order.
 __global__ __launch_bounds__(kRowThreads) void k_cells_emit(const unsigned char* __restrict__ img, int w, int h,
-                                                            const int* __restrict__ row_count,
+                                                            const int* __restrict__ row_count, int* __restrict__ next_row_count, int n_counters,
                                                             pps_edges_host::CellSeg* __restrict__ segs) {
-  __shared__ int scratch[kRowThreads / 64];
-  __shared__ int wave_off[kRowThreads / 64];
-  const int r0 = blockIdx.x;
+  // the counters of the next call (k_label_close accumulates into zeros); all of them: the next map may be larger
+  for (int r = blockIdx.x * kRowThreads + threadIdx.x; r < n_counters; r += gridDim.x * kRowThreads) next_row_count[r] = 0;
+  const int lane = threadIdx.x & 63;
+  const int r0 = blockIdx.x * kEmitRowsPerGroup + (threadIdx.x >> 6);
+  if (r0 + 1 >= h || row_count[r0] == 0) return;   // most rows hold no boundary
   int above = 0;
-  for (int r = threadIdx.x; r < r0; r += kRowThreads) above += row_count[r];
-  int base = block_sum(above, scratch);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int cb = 0; cb + 1 < w; cb += kRowThreads) {
-    const int c0 = cb + threadIdx.x;
-    pps_edges_host::CellSeg mine[2];
-    const int n = c0 + 1 < w ? cell_segments(img, w, r0, c0, mine) : 0;
-    // exclusive scan over the workgroup: inside a wave by shuffles, across waves through LDS
-    int incl = n;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    __syncthreads();
-    if (lane == 63) wave_off[wave] = incl;
-    __syncthreads();
-    int before = 0, chunk = 0;
-    for (int k = 0; k < kRowThreads / 64; k++) { if (k < wave) before += wave_off[k]; chunk += wave_off[k]; }
-    const int at = base + before + incl - n;
-    for (int k = 0; k < n; k++) segs[at + k] = mine[k];
-    base += chunk;
+  for (int r = lane; r < r0; r += 64) above += row_count[r];
+  for (int o = 32; o > 0; o >>= 1) above += __shfl_xor(above, o);
+  const int per_lane = (w - 1 + 63) / 64;
+  const int c_begin = lane * per_lane, c_end = imin(c_begin + per_lane, w - 1);
+  pps_edges_host::CellSeg tmp[2];
+  int n = 0;
+  for (int c = c_begin; c < c_end; c++) n += cell_segments(img, w, r0, c, tmp);
+  int incl = n;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  int at = above + incl - n;
+  if (n == 0) return;
+  for (int c = c_begin; c < c_end; c++) {
+    const int k = cell_segments(img, w, r0, c, tmp);
+    if (k > 0) segs[at] = tmp[0];
+    if (k > 1) segs[at + 1] = tmp[1];
+    at += k;
   }
 }
 
@@ -189,7 +249,8 @@ struct pps_edges {
   hipEvent_t ev[2] = {nullptr, nullptr};
   unsigned char* d_label = nullptr;   // width x height
   unsigned char* d_pre = nullptr;     // pre-processed map (<= width x height)
-  int* d_row_count = nullptr;         // height - 1
+  int* d_row_count[2] = {nullptr, nullptr};   // height each; alternate between calls (the idle one is zeroed by k_cells_emit)
+  int flip = 0;
   pps_edges_host::CellSeg* d_segs = nullptr;   // 2 (width - 1)(height - 1)
   int pre_w = 0, pre_h = 0;
   std::vector<int> row_count;
@@ -229,7 +290,10 @@ int pps_edges_create(int device, int width, int height, pps_edges** out) {
   if (st == hipSuccess) st = hipEventCreate(&e->ev[1]);
   if (st == hipSuccess) st = hipMalloc(reinterpret_cast<void**>(&e->d_label), px);
   if (st == hipSuccess) st = hipMalloc(reinterpret_cast<void**>(&e->d_pre), px);
-  if (st == hipSuccess) st = hipMalloc(reinterpret_cast<void**>(&e->d_row_count), sizeof(int) * (size_t)height);
+  for (int k = 0; k < 2 && st == hipSuccess; k++) {
+    st = hipMalloc(reinterpret_cast<void**>(&e->d_row_count[k]), sizeof(int) * (size_t)height);
+    if (st == hipSuccess) st = hipMemset(e->d_row_count[k], 0, sizeof(int) * (size_t)height);
+  }
   if (st == hipSuccess) st = hipMalloc(reinterpret_cast<void**>(&e->d_segs), sizeof(pps_edges_host::CellSeg) * 2 * px);
   if (st != hipSuccess) { pps_edges_destroy(e); return PPS_EHIP; }
   *out = e;
@@ -240,7 +304,7 @@ int pps_edges_destroy(pps_edges* e) {
   if (!e) return PPS_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  (void)hipFree(e->d_label); (void)hipFree(e->d_pre); (void)hipFree(e->d_row_count); (void)hipFree(e->d_segs);
+  (void)hipFree(e->d_label); (void)hipFree(e->d_pre); (void)hipFree(e->d_row_count[0]); (void)hipFree(e->d_row_count[1]); (void)hipFree(e->d_segs);
   if (e->ev[0]) (void)hipEventDestroy(e->ev[0]);
   if (e->ev[1]) (void)hipEventDestroy(e->ev[1]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -272,18 +336,22 @@ int pps_edges_select(pps_edges* e, const unsigned char* label_map, int label_on_
   const int h = prm.downsample_contour ? (int)std::lrint(e->height * 0.5) : e->height;
   if (w < 2 || h < 2) return efail(e, PPS_EINVAL, "label map too small");
   e->pre_w = w; e->pre_h = h;
-  CloseArgs ca{d_src, e->width, e->height, prm.downsample_contour ? 1 : 0, e->d_pre, w, h, kd, ke};
-  const int RX = kTileX + kd - 1 + ke - 1, RY = kTileY + kd - 1 + ke - 1;
+  int* rc = e->d_row_count[e->flip];
+  int* rc_next = e->d_row_count[e->flip ^ 1];
+  e->flip ^= 1;
+  CloseArgs ca{d_src, e->width, e->height, prm.downsample_contour ? 1 : 0, e->d_pre, w, h, kd, ke, rc};
+  const dim3 grid((w + kTileX - 1) / kTileX, (h + kTileY - 1) / kTileY);
+  const size_t lds_bytes = 2 * (size_t)close_pitch(kd, ke) * close_rows(kd, ke);
   EHIP(e, hipEventRecord(e->ev[0], e->stream));
-  hipLaunchKernelGGL(k_label_close, dim3((w + kTileX - 1) / kTileX, (h + kTileY - 1) / kTileY), dim3(kCloseThreads), 2 * (size_t)RX * RY,
-                     e->stream, ca);
-  hipLaunchKernelGGL(k_cells_count, dim3(h - 1), dim3(kRowThreads), 0, e->stream, e->d_pre, w, h, e->d_row_count);
-  hipLaunchKernelGGL(k_cells_emit, dim3(h - 1), dim3(kRowThreads), 0, e->stream, e->d_pre, w, h, e->d_row_count, e->d_segs);
+  if (kd == 11 && ke == 11) hipLaunchKernelGGL((k_label_close<11, 11>), grid, dim3(kCloseThreads), lds_bytes, e->stream, ca);
+  else if (kd == 8 && ke == 8) hipLaunchKernelGGL((k_label_close<8, 8>), grid, dim3(kCloseThreads), lds_bytes, e->stream, ca);
+  else hipLaunchKernelGGL((k_label_close<0, 0>), grid, dim3(kCloseThreads), lds_bytes, e->stream, ca);
+  hipLaunchKernelGGL(k_cells_emit, dim3((h - 1 + kEmitRowsPerGroup - 1) / kEmitRowsPerGroup), dim3(kRowThreads), 0, e->stream, e->d_pre, w, h, rc, rc_next, e->height, e->d_segs);
   EHIP(e, hipGetLastError());
   EHIP(e, hipEventRecord(e->ev[1], e->stream));
   try {
     e->row_count.resize((size_t)h - 1);
-    EHIP(e, hipMemcpyAsync(e->row_count.data(), e->d_row_count, sizeof(int) * (size_t)(h - 1), hipMemcpyDeviceToHost, e->stream));
+    EHIP(e, hipMemcpyAsync(e->row_count.data(), rc, sizeof(int) * (size_t)(h - 1), hipMemcpyDeviceToHost, e->stream));
     EHIP(e, hipStreamSynchronize(e->stream));
     size_t nseg = 0;
     for (int c : e->row_count) nseg += (size_t)c;

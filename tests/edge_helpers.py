@@ -114,3 +114,41 @@ class DeviceBytes:
         if self.ptr:
             self.hip.hipFree(self.ptr)
             self.ptr = None
+
+
+def corridor_view(yaw_deg=0.0, lateral=0.0, seed=0, width=640, height=480):
+    """One rendered frame of a corridor end (left wall, end wall, right wall): the label map a CNN would give, LSD-like
+    lines (the three boundary pieces clipped to the image, integer end points, jitter, clutter), the true ground
+    segments and the camera pose.  -> (label, lines, true_seg2d [3,4], T_wc 4x4 fp32, invK 3x3 fp32)"""
+    from pop_up_slam_amd import synth
+    rng = np.random.default_rng(seed)
+    R = synth._Rz(np.deg2rad(yaw_deg)) @ synth.CAM_R0
+    tq = synth.pose_from_Rt(R, np.array([lateral, 0.0, 1.0]))
+    seg, _, T = synth.corridor_frame(tq, half_width=1.5, near=2.0, far=6.0, width=width, height=height)
+    kx = np.array([seg[0, 0], seg[0, 2], seg[1, 2], seg[2, 2]], dtype=float)
+    ky = np.array([seg[0, 1], seg[0, 3], seg[1, 3], seg[2, 3]], dtype=float)
+    xs = np.arange(width)
+    by = np.interp(xs, kx, ky)
+    lab = (np.arange(height)[:, None] > by[None, :]).astype(np.uint8) * 255
+    lines = []
+    for s in seg:
+        a, b = np.array(s[:2], float), np.array(s[2:], float)
+        ts = [t for t in np.linspace(0, 1, 201) if 2 <= a[0] + t * (b[0] - a[0]) <= width - 3 and 2 <= a[1] + t * (b[1] - a[1]) <= height - 3]
+        p, q = a + ts[0] * (b - a), a + ts[-1] * (b - a)
+        lines.append(np.round(np.concatenate([p, q]) + rng.normal(0, 0.7, 4)))
+    for _ in range(10):
+        x0, y0 = rng.uniform(0, width), rng.uniform(0, 0.5 * height); ang = rng.uniform(0, np.pi); ln = rng.uniform(5, 120)
+        lines.append(np.round([x0, y0, np.clip(x0 + ln * np.cos(ang), 0, width - 1), np.clip(y0 + ln * np.sin(ang), 0, height - 1)]))
+    invK = np.linalg.inv(synth.K_TUM).astype(np.float32)
+    return lab, np.array(lines, np.float32), seg, T, invK
+
+
+def planes_agree(got, want, max_angle_deg=3.0, max_offset=0.08):
+    """unit-normal plane rows (a, b, c, d), sign-insensitive"""
+    assert got.shape == want.shape
+    for g, w in zip(got.astype(float), want.astype(float)):
+        g = g / np.linalg.norm(g[:3]); w = w / np.linalg.norm(w[:3])
+        if g[:3] @ w[:3] < 0:
+            g = -g
+        ang = np.degrees(np.arccos(np.clip(g[:3] @ w[:3], -1, 1)))
+        assert ang < max_angle_deg and abs(g[3] - w[3]) < max_offset, (g, w, ang)

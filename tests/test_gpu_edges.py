@@ -114,3 +114,18 @@ def test_bad_arguments(built):
         ed.select(np.zeros((10, 10), np.uint8), np.zeros((0, 4), np.float32))
     with pytest.raises(P.PpsError):
         ed.label() if False else P.Edges(64, 48).label()
+
+
+@pytest.mark.parametrize("yaw,lateral", [(0.0, 0.0), (8.0, 0.3), (-12.0, -0.4)])
+def test_label_and_lines_to_wall_planes(built, yaw, lateral):
+    """image -> graph front end on the device: label map + lines -> ground edges (pps_edges_select) -> wall planes
+    (pps_popup_planes); the same frame through the oracle gives the same segments, and the planes are the true walls"""
+    from test_oracle_edges import TUM
+    lab, lines, true_seg, T, invK = E.corridor_view(yaw, lateral, seed=3)
+    ed = P.Edges(640, 480)
+    open_segs, closed, idx = ed.select(lab, lines, P.edge_params(**TUM))
+    want = O.select_ground_edges(lab, lines, O.edge_params(**TUM))
+    for a, b in zip(want, (open_segs, closed, idx)):
+        assert np.array_equal(a, b)
+    assert closed.shape == (3, 4)
+    E.planes_agree(P.popup_planes(closed, invK, T), P.popup_planes(true_seg, invK, T))

@@ -184,3 +184,12 @@ def test_host_select_matches_oracle(seed):
         assert (np.diff(o[:, 0]) >= 0).all()
         assert np.array_equal(c[1:, :2], c[:-1, 2:])
         assert np.array_equal(c[idx.astype(int)], o)
+
+
+@pytest.mark.parametrize("yaw,lateral", [(0.0, 0.0), (8.0, 0.3), (-12.0, -0.4)])
+def test_label_and_lines_to_wall_planes(yaw, lateral):
+    """image -> graph front end on one rendered corridor frame: the selected ground edges, popped up, give the three walls"""
+    lab, lines, true_seg, T, invK = E.corridor_view(yaw, lateral, seed=3)
+    open_segs, closed, idx = O.select_ground_edges(lab, lines, O.edge_params(**TUM))
+    assert open_segs.shape == (3, 4) and closed.shape == (3, 4)
+    E.planes_agree(O.popup_planes(closed, invK, T), O.popup_planes(true_seg, invK, T))
