@@ -86,7 +86,8 @@ struct pps_graph {
   // that are uploaded (mirrored in a host staging buffer and sent with ONE copy), `scr` the scratch arrays.
   struct Arena { char* base = nullptr; size_t cap = 0, off = 0, spill = 0; };
   Arena up, scr;
-  std::vector<char> stage;          // host mirror of `up`
+  char* stage = nullptr;            // pinned host mirror of `up` (one H2D copy per upload, at link rate)
+  size_t stage_cap = 0;
   size_t stage_lo = 0, stage_hi = 0;   // dirty range of the mirror
   double* host_result = nullptr;   // pinned, 12 doubles: chi2 at the linearisation point | trial | speculative trial
   double seq = 0.0;                // sequence number the chi2 kernel publishes last (host polls it)
@@ -160,13 +161,19 @@ void free_device(pps_graph* g) {
     }
     a->off = 0; a->spill = 0;
   }
-  if (g->stage.size() < g->up.cap) g->stage.resize(g->up.cap);
+  if (g->stage_cap < g->up.cap) {
+    if (g->stage) (void)hipHostFree(g->stage);
+    g->stage = nullptr; g->stage_cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&g->stage), g->up.cap, hipHostMallocDefault) == hipSuccess) g->stage_cap = g->up.cap;
+  }
   g->stage_lo = g->stage_hi = 0;
   g->dev = DevGraph();
 }
 
 void release_arenas(pps_graph* g) {
   for (pps_graph::Arena* a : {&g->up, &g->scr}) { if (a->base) (void)hipFree(a->base); a->base = nullptr; a->cap = a->off = a->spill = 0; }
+  if (g->stage) (void)hipHostFree(g->stage);
+  g->stage = nullptr; g->stage_cap = 0;
 }
 
 template <class T>
@@ -194,9 +201,9 @@ int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
   if (rc != PPS_OK) return rc;
   if (v.empty()) return PPS_OK;
   char* p = reinterpret_cast<char*>(*out);
-  if (g->up.base && p >= g->up.base && p < g->up.base + g->up.cap) {      // staged: goes out with the next flush
+  if (g->stage && g->up.base && p >= g->up.base && p < g->up.base + g->up.cap) {      // staged: goes out with the next flush
     const size_t o = (size_t)(p - g->up.base);
-    memcpy(g->stage.data() + o, v.data(), v.size() * sizeof(T));
+    memcpy(g->stage + o, v.data(), v.size() * sizeof(T));
     if (g->stage_hi == g->stage_lo) { g->stage_lo = o; g->stage_hi = o + v.size() * sizeof(T); }
     else { g->stage_lo = std::min(g->stage_lo, o); g->stage_hi = std::max(g->stage_hi, o + v.size() * sizeof(T)); }
   } else {
@@ -208,7 +215,7 @@ int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
 // send the staged part of the upload arena in one copy
 int flush_uploads(pps_graph* g) {
   if (g->stage_hi > g->stage_lo)
-    HIP_TRY(g, hipMemcpy(g->up.base + g->stage_lo, g->stage.data() + g->stage_lo, g->stage_hi - g->stage_lo, hipMemcpyHostToDevice));
+    HIP_TRY(g, hipMemcpy(g->up.base + g->stage_lo, g->stage + g->stage_lo, g->stage_hi - g->stage_lo, hipMemcpyHostToDevice));
   g->stage_lo = g->stage_hi = 0;
   return PPS_OK;
 }
@@ -547,8 +554,8 @@ int upload_all(pps_graph* g) {
     d.n_mseg = (int)mseg.size();
     TRY(dev_upload(g, &d.mseg_blk, mseg));
   }
-  TRY(dev_upload(g, &d.f_el_off, A.f_el_off)); TRY(dev_upload(g, &d.el_src, A.el_src)); TRY(dev_upload(g, &d.el_tgt, A.el_tgt));
-  TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off)); TRY(dev_upload(g, &d.ea_tgt, A.ea_tgt));
+  TRY(dev_upload(g, &d.f_el_off, A.f_el_off)); TRY(dev_upload(g, &d.el_tgt, A.el_tgt));   // (el_src: host bookkeeping only)
+  TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
   TRY(dev_upload(g, &d.blk_doff, A.blk_doff)); TRY(dev_upload(g, &d.blk_dst, A.blk_dst));
   TRY(dev_alloc(g, &d.Hf, A.el_src.size()));
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
@@ -577,6 +584,7 @@ int upload_all(pps_graph* g) {
   }
 #undef TRY
   rc = flush_uploads(g); if (rc != PPS_OK) return rc;
+  if (A.ea_total > 0) HIP_TRY(g, launch_expand_ea(d, A.n_fronts, g->stream));
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->topo_dirty = false;
   g->meas_dirty = false;

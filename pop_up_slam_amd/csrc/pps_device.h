@@ -83,6 +83,8 @@ hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_
 hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
                               int fused_solve_panel = 0, int fused_solve_group_fronts = 0);
 hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st);
+// ea_tgt (packed update matrix of a front -> packed index in its parent) expanded from cmap / f_cmap_off / f_ea_off
+hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st);
 int band_max_rows();
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels

@@ -806,6 +806,27 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
 // ------------------------------------------------------------------------------------------
 constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
 
+// One workgroup per front: row i of its (b+1)-row packed update matrix goes to row cmap[i] of the parent.
+__global__ __launch_bounds__(64) void k_expand_ea(DevGraph d) {
+  const int s = blockIdx.x;
+  const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
+  const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
+  int* __restrict__ out = d.ea_tgt + d.f_ea_off[s];
+  const int n = len * (len + 1) / 2;
+  int i = 0;                                  // row of entry e: tri(i) <= e < tri(i+1)
+  for (int e = threadIdx.x; e < n; e += 64) {
+    while ((i + 1) * (i + 2) / 2 <= e) i++;
+    const int j = e - i * (i + 1) / 2;
+    out[e] = m[i] * (m[i] + 1) / 2 + m[j];
+  }
+}
+
+hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
+  if (n_fronts <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_expand_ea, dim3(n_fronts), dim3(64), 0, st, d);
+  return hipGetLastError();
+}
+
 int band_front_limit() { return kBandMaxRows - 1; }
 int band_max_rows() { return kBandMaxRows; }
 size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return (fa * (fa + 1) / 2 + 64 * 5) * sizeof(double); }   // packed triangle + panel buffer

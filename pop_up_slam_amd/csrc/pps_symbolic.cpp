@@ -525,17 +525,15 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     // pulls through cmap -- its (b+1)^2/2 entries per front would be gigabytes for loop-closure separators)
     A.f_ea_off.assign(F + 1, 0);
     A.ea_tgt.clear();
+    // Only the offsets are computed here: the lists themselves (sum of (b+1)(b+2)/2 entries, ~0.3 M for a
+    // 1000-pose graph) are expanded from cmap on the device (k_expand_ea) -- or by expand_ea_tgt() for the dump.
+    A.ea_total = 0;
     if (A.max_front <= prm.band_rows) {
-      size_t total = 0;
-      for (int s = 0; s < F; s++) total += cm[s].size() * (cm[s].size() + 1) / 2;
-      A.ea_tgt.reserve(total);
       for (int s = 0; s < F; s++) {
-        A.f_ea_off[s] = (int64_t)A.ea_tgt.size();
-        const std::vector<int>& m = cm[s];    // empty for the root
-        for (size_t i = 0; i < m.size(); i++)
-          for (size_t j = 0; j <= i; j++) A.ea_tgt.push_back(m[i] * (m[i] + 1) / 2 + m[j]);
+        A.f_ea_off[s] = A.ea_total;
+        A.ea_total += (int64_t)(cm[s].size() * (cm[s].size() + 1) / 2);    // cm[root] is empty
       }
-      A.f_ea_off[F] = (int64_t)A.ea_tgt.size();
+      A.f_ea_off[F] = A.ea_total;
     }
     for (int s = 0; s < F; s++) {
       A.f_cmap_off[s] = (int)A.cmap.size();
@@ -752,7 +750,22 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
   return true;
 }
 
-void dump_analysis(const Analysis& a, std::vector<int32_t>& out) {
+void expand_ea_tgt(Analysis& A) {
+  A.ea_tgt.clear();
+  if (A.ea_total <= 0) return;
+  A.ea_tgt.resize((size_t)A.ea_total);
+  for (int s = 0; s < A.n_fronts; s++) {
+    const int* m = A.cmap.data() + A.f_cmap_off[s];
+    const int len = A.f_cmap_off[s + 1] - A.f_cmap_off[s];
+    int* out = A.ea_tgt.data() + A.f_ea_off[s];
+    for (int i = 0; i < len; i++)
+      for (int j = 0; j <= i; j++) *out++ = m[i] * (m[i] + 1) / 2 + m[j];
+  }
+}
+
+void dump_analysis(const Analysis& a_in, std::vector<int32_t>& out) {
+  Analysis a = a_in;            // (test hook: the copy is fine)
+  if (a.ea_tgt.empty()) expand_ea_tgt(a);
   out.clear();
   auto put = [&](int64_t v) { out.push_back((int32_t)v); };
   auto putv = [&](const std::vector<int>& v) { put((int64_t)v.size()); for (int x : v) out.push_back(x); };

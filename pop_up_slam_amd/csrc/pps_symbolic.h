@@ -83,7 +83,8 @@ struct Analysis {
   std::vector<int> el_src;           // offset into the H buffer (first segment slot of the block)
   std::vector<int> el_tgt;           // packed front index; bit 30 set = diagonal element (scaled by 1+lambda)
   std::vector<int64_t> f_ea_off;     // [n_fronts+1] -> ea_tgt : this front's packed update matrix -> packed index in its parent
-  std::vector<int> ea_tgt;
+  std::vector<int> ea_tgt;           // left empty by analyze(): expanded on the device, or by expand_ea_tgt() for the dump
+  int64_t ea_total = 0;              // its length
 
   // ---- packed metadata records: one coalesced load per wave instead of a chain of dependent loads ----
   // frec: 16 ints per front, in band-schedule order (index = position in glvl_fronts):
@@ -113,6 +114,8 @@ struct Analysis {
 bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
              Analysis& out, const char** msg);
 
+// ea_tgt from cmap / f_ea_off on the host (what k_expand_ea does on the device)
+void expand_ea_tgt(Analysis& a);
 // Serialise the analysis into one int32 vector for host-logic tests (pps_analysis_dump).
 void dump_analysis(const Analysis& a, std::vector<int32_t>& out);
 
