@@ -48,6 +48,7 @@ struct DevGraph {
   int *f_cmap_off = nullptr, *cmap = nullptr;
   int *level_fronts = nullptr;
   int *f_asm_off = nullptr, *asm_blk = nullptr, *asm_lrow = nullptr, *asm_lcol = nullptr;
+  int *asm_el0 = nullptr, *asm_fsz = nullptr;   // per assembled block: first index in Hf, rows of its front
   int *blk_rows = nullptr, *blk_cols = nullptr, *blk_size = nullptr, *blk_nseg = nullptr;
   int64_t* blk_hoff = nullptr;
   int *seg_blk = nullptr, *seg_c0 = nullptr, *seg_cnt = nullptr;
@@ -85,6 +86,9 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
 hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st);
 // ea_tgt (packed update matrix of a front -> packed index in its parent) expanded from cmap / f_cmap_off / f_ea_off
 hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st);
+// el_tgt / blk_dst (H block element <-> front-ordered H <-> packed front index) expanded from the per-block records;
+// blk_dst must be filled with -1 beforehand
+hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st);
 int band_max_rows();
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels

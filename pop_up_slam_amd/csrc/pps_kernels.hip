@@ -821,6 +821,34 @@ __global__ __launch_bounds__(64) void k_expand_ea(DevGraph d) {
   }
 }
 
+// One thread per assembled H block: its elements in the order the front gathers them (lower triangle of a diagonal
+// block, a full off-diagonal block, then the gradient entries of a diagonal block).
+__global__ __launch_bounds__(256) void k_expand_el(DevGraph d, int n_asm) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_asm) return;
+  const int blk = d.asm_blk[a], rows = d.blk_rows[blk], cols = d.blk_cols[blk];
+  const int lrow = d.asm_lrow[a], lcol = d.asm_lcol[a];
+  const bool diag = d.blk_size[blk] != rows * cols;
+  int* __restrict__ dst = d.blk_dst + d.blk_doff[blk];
+  int e = d.asm_el0[a];
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) {
+      if (diag && j > i) continue;
+      dst[i * cols + j] = e;
+      d.el_tgt[e++] = (((lrow + i) * (lrow + i + 1)) / 2 + lcol + j) | ((diag && i == j) ? (1 << 30) : 0);
+    }
+  if (diag) {
+    const int fsz = d.asm_fsz[a];
+    for (int i = 0; i < rows; i++) { dst[rows * cols + i] = e; d.el_tgt[e++] = (fsz * (fsz + 1)) / 2 + lcol + i; }
+  }
+}
+
+hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st) {
+  if (n_asm <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_expand_el, dim3((n_asm + 255) / 256), dim3(256), 0, st, d, n_asm);
+  return hipGetLastError();
+}
+
 hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
   if (n_fronts <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_expand_ea, dim3(n_fronts), dim3(64), 0, st, d);

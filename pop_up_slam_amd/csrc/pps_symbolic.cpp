@@ -248,18 +248,19 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
                   Analysis& A, const char** msg, bool general_ordering) {
   static const char* kOk = "";
   *msg = kOk;
+  const bool timing = getenv("PPS_ANALYSIS_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
   A = Analysis();
   const int N = (int)nodes.size();
   A.n_nodes = N;
   if (N == 0) { *msg = "empty graph"; return false; }
-  const bool timing = getenv("PPS_ANALYSIS_TIMING") != nullptr;
-  auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!timing) return;
     const auto t = std::chrono::steady_clock::now();
     fprintf(stderr, "[analysis] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
   };
+  lap("reset");
   Builder B(nodes, factors, prm);
   B.build_adjacency();
   lap("adjacency");
@@ -543,7 +544,7 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
 
     lap("band schedule");
     // ---- 5. block-sparse H and contribution lists ----
-    struct Ctr { int64_t key; int jv, ju, roff, m; };
+    struct Ctr { int pv, pu, jv, ju, roff, m; };   // (row position, column position) of the H block, then the J slices
     std::vector<Ctr> ctr;
     ctr.reserve(factors.size() * 3);
     A.J_size = 0;
@@ -553,36 +554,36 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
       const int db = f.b >= 0 ? nodes[f.b].dim : 0;
       const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
       A.J_size = std::max<int64_t>(A.J_size, (int64_t)roff + m);
-      const int64_t pa = A.node_pos[f.a];
-      ctr.push_back({pa * N + pa, ja, ja, roff, m});
+      const int pa = A.node_pos[f.a];
+      ctr.push_back({pa, pa, ja, ja, roff, m});
       if (f.b >= 0) {
-        const int64_t pb = A.node_pos[f.b];
-        ctr.push_back({pb * N + pb, jb, jb, roff, m});
-        if (pa > pb) ctr.push_back({pa * N + pb, ja, jb, roff, m});   // rows = later node
-        else         ctr.push_back({pb * N + pa, jb, ja, roff, m});
+        const int pb = A.node_pos[f.b];
+        ctr.push_back({pb, pb, jb, jb, roff, m});
+        if (pa > pb) ctr.push_back({pa, pb, ja, jb, roff, m});   // rows = later node
+        else         ctr.push_back({pb, pa, jb, ja, roff, m});
       }
     }
     // every node needs a diagonal block even when it has no factor (it will then fail as not PD)
     std::vector<char> has_diag(N, 0);
-    for (auto& c : ctr) if (c.key / N == c.key % N) has_diag[c.key / N] = 1;
-    for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({(int64_t)p * N + p, 0, 0, 0, 0});
+    for (auto& c : ctr) if (c.pv == c.pu) has_diag[c.pv] = 1;
+    for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({p, p, 0, 0, 0, 0});
     // stable sort by (row position, column position): counting sort on the row, then a stable insertion sort on
     // the column inside each row (rows hold a handful of blocks; the dense nodes' rows fall back to std::stable_sort)
     {
       std::vector<int> row_off(N + 1, 0);
-      for (const auto& c : ctr) row_off[c.key / N + 1]++;
+      for (const auto& c : ctr) row_off[c.pv + 1]++;
       for (int p = 0; p < N; p++) row_off[p + 1] += row_off[p];
       std::vector<Ctr> sorted(ctr.size());
       std::vector<int> fill(row_off.begin(), row_off.end() - 1);
-      for (const auto& c : ctr) sorted[fill[c.key / N]++] = c;
+      for (const auto& c : ctr) sorted[fill[c.pv]++] = c;
       for (int p = 0; p < N; p++) {
         Ctr* b = sorted.data() + row_off[p];
         const int n = row_off[p + 1] - row_off[p];
-        if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.key < y.key; }); continue; }
+        if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pu < y.pu; }); continue; }
         for (int i = 1; i < n; i++) {
           const Ctr c = b[i];
           int j = i - 1;
-          while (j >= 0 && b[j].key > c.key) { b[j + 1] = b[j]; j--; }
+          while (j >= 0 && b[j].pu > c.pu) { b[j + 1] = b[j]; j--; }
           b[j + 1] = c;
         }
       }
@@ -595,8 +596,8 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     A.H_size = 0;
     for (size_t i = 0; i < ctr.size();) {
       size_t j = i;
-      while (j < ctr.size() && ctr[j].key == ctr[i].key) j++;
-      const int pv = (int)(ctr[i].key / N), pu = (int)(ctr[i].key % N);
+      while (j < ctr.size() && ctr[j].pv == ctr[i].pv && ctr[j].pu == ctr[i].pu) j++;
+      const int pv = ctr[i].pv, pu = ctr[i].pu;
       const int v = A.order[pv], u = A.order[pu];
       const int rows = nodes[v].dim, cols = nodes[u].dim;
       const int size = rows * cols + (v == u ? rows : 0);
@@ -630,12 +631,12 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     std::vector<int> blk_v(A.asm_lrow), blk_u(A.asm_lcol);
     A.asm_blk.clear(); A.asm_lrow.clear(); A.asm_lcol.clear();
     A.f_asm_off.assign(F + 1, 0);
-    A.f_el_off.assign(1, 0); A.el_src.clear(); A.el_tgt.clear();
+    A.f_el_off.assign(1, 0); A.el_tgt.clear(); A.el_total = 0; A.asm_el0.clear(); A.asm_fsz.clear();
     A.f_el_off.reserve(F + 1);
     A.blk_doff.assign(A.n_blocks + 1, 0);
     for (int bk = 0; bk < A.n_blocks; bk++) A.blk_doff[bk + 1] = A.blk_doff[bk] + A.blk_size[bk];
-    A.blk_dst.assign(A.blk_doff[A.n_blocks], -1);
-    A.el_src.reserve(A.blk_doff[A.n_blocks]); A.el_tgt.reserve(A.blk_doff[A.n_blocks]);
+    A.blk_dst.clear();
+    A.asm_el0.reserve(A.n_blocks); A.asm_fsz.reserve(A.n_blocks);
     A.asm_blk.reserve(A.n_blocks); A.asm_lrow.reserve(A.n_blocks); A.asm_lcol.reserve(A.n_blocks);
     if (A.H_size > 0x3fffffffLL) { *msg = "H too large for int32 gather offsets"; return false; }
     for (int s = 0; s < F; s++) {
@@ -648,30 +649,19 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
         A.asm_blk.push_back(blk); A.asm_lrow.push_back(loc[v]); A.asm_lcol.push_back(loc[u]);
       }
       A.f_asm_off[s + 1] = (int)A.asm_blk.size();
-      // flat element list (lower triangle of diagonal blocks, full off-diagonal blocks, g entries)
+      // flat element list of the front (lower triangle of diagonal blocks, full off-diagonal blocks, g entries): only
+      // where each assembled block starts is recorded here; el_tgt / blk_dst are expanded from that on the device
+      // (k_expand_el) or by expand_el_lists() for the dump
       {
         const int fsz = A.f_p[s] + A.f_b[s];
-        auto tri = [](int i) { return i * (i + 1) / 2; };
         for (int blk : asm_of[s]) {
-          const int v = blk_v[blk], u = blk_u[blk];
           const int rows = A.blk_rows[blk], cols = A.blk_cols[blk];
-          const int lrow = loc[v], lcol = loc[u];
-          const bool diag = (v == u);
-          for (int i = 0; i < rows; i++)
-            for (int j = 0; j < cols; j++) {
-              if (diag && j > i) continue;
-              A.blk_dst[A.blk_doff[blk] + i * cols + j] = (int)A.el_src.size();
-              A.el_src.push_back((int)(A.blk_hoff[blk] + i * cols + j));
-              A.el_tgt.push_back((tri(lrow + i) + lcol + j) | ((diag && i == j) ? (1 << 30) : 0));
-            }
-          if (diag)
-            for (int i = 0; i < rows; i++) {
-              A.blk_dst[A.blk_doff[blk] + rows * cols + i] = (int)A.el_src.size();
-              A.el_src.push_back((int)(A.blk_hoff[blk] + rows * cols + i));
-              A.el_tgt.push_back(tri(fsz) + lcol + i);
-            }
+          const bool diag = blk_v[blk] == blk_u[blk];
+          A.asm_el0.push_back((int)A.el_total);
+          A.asm_fsz.push_back(fsz);
+          A.el_total += diag ? rows * (rows + 1) / 2 + rows : rows * cols;
         }
-        A.f_el_off.push_back((int)A.el_src.size());
+        A.f_el_off.push_back((int)A.el_total);
       }
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
       for (int v : bnd[s]) loc[v] = -1;
@@ -750,6 +740,29 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
   return true;
 }
 
+void expand_el_lists(Analysis& A) {
+  auto tri = [](int i) { return i * (i + 1) / 2; };
+  A.el_tgt.assign((size_t)A.el_total, 0);
+  A.blk_dst.assign((size_t)A.blk_doff[A.n_blocks], -1);
+  for (size_t a = 0; a < A.asm_blk.size(); a++) {
+    const int blk = A.asm_blk[a], rows = A.blk_rows[blk], cols = A.blk_cols[blk];
+    const int lrow = A.asm_lrow[a], lcol = A.asm_lcol[a];
+    const bool diag = A.blk_size[blk] != rows * cols;
+    int e = A.asm_el0[a];
+    for (int i = 0; i < rows; i++)
+      for (int j = 0; j < cols; j++) {
+        if (diag && j > i) continue;
+        A.blk_dst[A.blk_doff[blk] + i * cols + j] = e;
+        A.el_tgt[e++] = (tri(lrow + i) + lcol + j) | ((diag && i == j) ? (1 << 30) : 0);
+      }
+    if (diag)
+      for (int i = 0; i < rows; i++) {
+        A.blk_dst[A.blk_doff[blk] + rows * cols + i] = e;
+        A.el_tgt[e++] = tri(A.asm_fsz[a]) + lcol + i;
+      }
+  }
+}
+
 void expand_ea_tgt(Analysis& A) {
   A.ea_tgt.clear();
   if (A.ea_total <= 0) return;
@@ -766,6 +779,8 @@ void expand_ea_tgt(Analysis& A) {
 void dump_analysis(const Analysis& a_in, std::vector<int32_t>& out) {
   Analysis a = a_in;            // (test hook: the copy is fine)
   if (a.ea_tgt.empty()) expand_ea_tgt(a);
+  if (a.el_tgt.empty()) expand_el_lists(a);
+  a.el_src.assign((size_t)a.el_total, 0);   // (kept in the dump layout; only its length is used)
   out.clear();
   auto put = [&](int64_t v) { out.push_back((int32_t)v); };
   auto putv = [&](const std::vector<int>& v) { put((int64_t)v.size()); for (int x : v) out.push_back(x); };

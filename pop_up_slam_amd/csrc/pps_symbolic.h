@@ -63,6 +63,8 @@ struct Analysis {
   std::vector<int> level_fronts;
   std::vector<int> f_asm_off;       // [n_fronts+1] -> asm_* (original entries gathered by the front)
   std::vector<int> asm_blk, asm_lrow, asm_lcol;
+  std::vector<int> asm_el0, asm_fsz;  // per assembled block: first index in the front-ordered H, rows of its front
+  int64_t el_total = 0;              // length of el_tgt / Hf
   int64_t L_size = 0, U_size = 0;
 
   // ---- band schedule: levels [B*s, B*s+B) form stage s; inside a stage the connected sub-trees are
@@ -78,10 +80,10 @@ struct Analysis {
   // ---- flat gather / scatter lists of the wave-per-front kernels (front = packed lower triangle,
   // index(i,j) = i(i+1)/2 + j, last row = right-hand side) ----
   std::vector<int> blk_doff;         // [n_blocks+1] -> blk_dst : block element -> index in the front-ordered H ("Hf"), -1 = unused
-  std::vector<int> blk_dst;
+  std::vector<int> blk_dst;          // left empty by analyze(): expanded on the device, or by expand_el_lists() for the dump
   std::vector<int> f_el_off;         // [n_fronts+1] -> el_src / el_tgt : original H entries of the front (= index range of Hf)
-  std::vector<int> el_src;           // offset into the H buffer (first segment slot of the block)
-  std::vector<int> el_tgt;           // packed front index; bit 30 set = diagonal element (scaled by 1+lambda)
+  std::vector<int> el_src;           // (dump layout only)
+  std::vector<int> el_tgt;           // packed front index; bit 30 set = diagonal element (scaled by 1+lambda); expanded like blk_dst
   std::vector<int64_t> f_ea_off;     // [n_fronts+1] -> ea_tgt : this front's packed update matrix -> packed index in its parent
   std::vector<int> ea_tgt;           // left empty by analyze(): expanded on the device, or by expand_ea_tgt() for the dump
   int64_t ea_total = 0;              // its length
@@ -116,6 +118,8 @@ bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& fa
 
 // ea_tgt from cmap / f_ea_off on the host (what k_expand_ea does on the device)
 void expand_ea_tgt(Analysis& a);
+// el_tgt / blk_dst from the per-block records (what k_expand_el does on the device)
+void expand_el_lists(Analysis& a);
 // Serialise the analysis into one int32 vector for host-logic tests (pps_analysis_dump).
 void dump_analysis(const Analysis& a, std::vector<int32_t>& out);
 
