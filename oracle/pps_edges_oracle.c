@@ -14,8 +14,9 @@
  *   - intervaltree 2.x: half-open intervals, search(begin, end), split_overlaps(), Interval ordering
  *     (begin, end, data).
  * PARITY UNPINNED: the reference has no tests or golden vectors for this stage and none of those libraries are in
- * this image.  The morphology is cross-checked against scipy.ndimage (tests/test_oracle_edges.py); everything
- * else is pinned by hand-worked cases and invariants only.
+ * this image.  Cross-checks: oracle/numpy_edges.py, an independent numpy / scipy formulation of the whole stage whose
+ * outputs are committed as tests/golden/edges_cases.json; scipy.ndimage for the morphology; hand-worked cases and
+ * invariants (tests/test_oracle_edges.py).
  *
  * Known ambiguity: for an EVEN structuring element (the down-sampled path uses 8x8) the window is taken as
  * [-k/2, k - 1 - k/2] for both dilate and erode, OpenCV's documented formula; the default path (11x11) is symmetric

@@ -193,3 +193,24 @@ def test_label_and_lines_to_wall_planes(yaw, lateral):
     open_segs, closed, idx = O.select_ground_edges(lab, lines, O.edge_params(**TUM))
     assert open_segs.shape == (3, 4) and closed.shape == (3, 4)
     E.planes_agree(O.popup_planes(closed, invK, T), O.popup_planes(true_seg, invK, T))
+
+
+def test_numpy_golden_cases():
+    """tests/golden/edges_cases.json comes from oracle/numpy_edges.py, a third formulation of the whole stage (scipy
+    morphology, vectorised cells, dict / deque contour linking, tuple-set interval cover); the C oracle reproduces it"""
+    cases = json.load(open(os.path.join(E.GOLD, "..", "edges_cases.json")))
+    assert len(cases) >= 16
+    n_open = 0
+    for cs in cases:
+        lab, lines = E.random_scene(cs["seed"], n_knots=cs["n_knots"], holes=cs["holes"])
+        prm = O.edge_params(**{k: (int(v) if k == "downsample_contour" else v) for k, v in cs["params"].items()})
+        pre = O.label_preprocess(lab, prm)
+        xy, nc, npnt = O.ground_contour(pre, cs["params"].get("downsample_contour", 0))
+        assert (nc, npnt) == (cs["n_contours"], cs["n_points"])
+        assert np.array_equal(xy.ravel(), np.array(cs["contour"], np.float32))
+        o, c, w = O.select_ground_edges(lab, lines, prm)
+        assert np.array_equal(o.ravel(), np.array(cs["open"], np.float32))
+        assert np.array_equal(c.ravel(), np.array(cs["closed"], np.float32))
+        assert np.array_equal(w, np.array(cs["open_in_closed"], np.float32))
+        n_open += len(o)
+    assert n_open > 30
