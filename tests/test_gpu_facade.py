@@ -97,3 +97,30 @@ def test_mapper_style_replay_through_cpp_facade(built, tmp_path, analytic):
     for a, b in zip(poses, ref_poses):
         np.testing.assert_allclose(a[:3], b[:3], atol=1e-7)
         assert min(np.abs(a[3:] - b[3:]).max(), np.abs(a[3:] + b[3:]).max()) < 1e-7
+
+
+def test_c5_frame_loop_in_cpp_matches_the_python_pipeline(built, tmp_path):
+    """BASELINE config 5 with the host loop in C++ (tools/cpp/c5_replay.cpp: pop-up at the predicted pose, graph
+    construction through include/pps_isam.hpp, solve, measurement refresh) against the same frames through the Python
+    pipeline: same graph, same LM schedule, chi2 equal to rounding (the facade composes poses through 4x4 matrices)"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import c5_bench_cpp as B
+    from pop_up_slam_amd import pipeline
+    frames = pipeline.popup_sequence(60)
+    script, exe = str(tmp_path / "frames.bin"), str(tmp_path / "c5_replay")
+    B.write_script(script, frames)
+    B.build(exe)
+    out = subprocess.run([exe, script, "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    pl, g, pp, stats = pipeline.gpu_pipeline(step=2)
+    iters = 0
+    for fr in frames:
+        it = pl.process(fr)
+        iters += max(it, 0)
+    assert res["nodes"] == g.num_nodes() and res["factors"] == g.num_factors()
+    assert abs(res["final_chi2"] - g.chi2()) <= 1e-5 * g.chi2()
+    assert abs(res["lm_iterations"] - iters) <= 2
+    assert abs(res["points_per_frame"] - stats["points"] / len(frames)) < 1.0
