@@ -302,7 +302,9 @@ typedef struct pps_edges pps_edges;   /* per-camera context: device buffers for 
 int pps_edges_create(int device, int width, int height, pps_edges** out);
 int pps_edges_destroy(pps_edges* e);
 const char* pps_edges_last_error(const pps_edges* e);
-/* label_map: width*height u8, a host pointer or (label_on_device != 0) a device pointer on the context's device.
+/* label_map: width*height u8, a host pointer or (label_on_device != 0) a device pointer on the context's device (the
+ * kernels run on the context's own stream: the producer of a device-resident map must have finished, e.g. by an event
+ * or stream synchronisation on the caller's side).
  * lsd_lines n_lines x 4 (x1 y1 x2 y2), host.  Outputs (host, caller-allocated, 2*n_lines+2 rows each):
  *   open_segs       n_open x 4    ground_seg2d_lines_actual
  *   closed_segs     n_closed x 4  ground_seg2d_lines_connect (connecting pieces inserted)
