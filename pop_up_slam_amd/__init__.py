@@ -262,6 +262,9 @@ class Graph:
             setattr(self.props, k, v)
         self._ck(self.L.pps_set_props(self.h, C.byref(self.props)))
 
+    def get_props(self):
+        p = PpsProps(); self._ck(self.L.pps_get_props(self.h, C.byref(p))); return p
+
     # ---- nodes / factors ----
     def add_pose(self, tq):
         a, p = _d(tq, 7); i = C.c_int(); self._ck(self.L.pps_add_pose(self.h, p, C.byref(i))); return i.value

@@ -97,3 +97,14 @@ def test_solve_without_gpu_fails_loudly(built):
     assert e.value.code == P.PPS_EHIP
     with pytest.raises(P.PpsError):
         g.chi2()
+
+
+def test_props_round_trip(built):
+    """Properties (Properties.h:37-110): defaults are the reference's LM settings with the mapper's overrides; set / get"""
+    g = P.Graph()
+    d = g.get_props()
+    assert d.max_iterations == 500 and d.lm_lambda0 == 1e-6 and d.lm_lambda_factor == 10.0
+    g.set_props(max_iterations=7, epsilon_rel=1e-9, jacobian_mode=P.JAC_ANALYTIC)
+    q = g.get_props()
+    assert (q.max_iterations, q.epsilon_rel, q.jacobian_mode) == (7, 1e-9, P.JAC_ANALYTIC)
+    assert q.epsilon2 == d.epsilon2 and q.device == d.device
