@@ -37,3 +37,33 @@ def test_sphere(built, name, mode):
         gt = graphio.trajectory_from_log(os.path.join(DATA, "sphere2500_groundtruth.txt"))
         est = g.get_poses()
         assert np.sqrt(((est[:, :3] - gt[:, :3]) ** 2).sum(1).mean()) < 1.5
+
+
+def test_sphere400_edits_on_the_dense_front_path(built):
+    """topology edits on a graph that runs in the dense-front form: drop loop closures, re-solve, add some back, one
+    Gauss-Newton step, re-solve -- every stage against the oracle"""
+    spec = graphio.load_edge3_log(os.path.join(DATA, "sphere400.txt"))
+    g = P.Graph(jacobian_mode=1); ng, fg = spec.replay(g)
+    o = O.OracleGraph(analytic=1); no, fo = spec.replay(o)
+    g.set_props(max_iterations=4); o.set_props(max_iterations=4) if hasattr(o, "set_props") else None
+    rng = np.random.default_rng(0)
+    loops = [k for k in range(len(spec.f_type)) if spec.f_type[k] == 1 and abs(int(spec.f_nodes[k][0]) - int(spec.f_nodes[k][1])) > 1]
+    assert len(loops) > 100
+
+    def agree(tol=1e-7):
+        c, co = g.chi2(), o.chi2()
+        assert abs(c - co) <= tol * co, (c, co)
+
+    g.update(); o.update(); agree()
+    drop = [int(k) for k in rng.choice(loops, size=60, replace=False)]
+    for k in drop:
+        g.remove_factor(int(fg[k])); o.remove_factor(int(fo[k]))
+    agree(1e-10)
+    g.update(); o.update(); agree()
+    for k in drop[:25]:
+        a, b = int(spec.f_nodes[k][0]), int(spec.f_nodes[k][1])
+        g.add_odometry(int(ng[a]), int(ng[b]), spec.f_meas[k, :6], spec.f_sqrtinf[k, :21])
+        o.add_odometry(int(no[a]), int(no[b]), spec.f_meas[k, :6], spec.f_sqrtinf[k, :21])
+    g.update(); o.update(); agree()
+    g.update(); o.update(); agree()
+    assert g.stats()["max_front"] > 127          # still the dense-front form
