@@ -108,3 +108,25 @@ def test_props_round_trip(built):
     q = g.get_props()
     assert (q.max_iterations, q.epsilon_rel, q.jacobian_mode) == (7, 1e-9, P.JAC_ANALYTIC)
     assert q.epsilon2 == d.epsilon2 and q.device == d.device
+
+
+def test_header_is_plain_c_and_links(built, tmp_path):
+    """include/pps.h is the boundary other host languages bind: it must compile as strict C99 and link against libpps.so"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "pps.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  pps_props p; pps_edge_params e; pps_assoc_params a; pps_graph* g = 0;\n'
+                   '  pps_default_props(&p); pps_edge_default_params(&e); pps_assoc_default_params(&a);\n'
+                   '  if (pps_graph_create(&p, &g) != PPS_OK) return 1;\n'
+                   '  double tq[7] = {0, 0, 0, 0, 0, 0, 1}; int id = -1, n = 0;\n'
+                   '  if (pps_add_pose(g, tq, &id) != PPS_OK || pps_num_nodes(g, &n) != PPS_OK || n != 1) return 2;\n'
+                   '  printf("%d %d %d %g\\n", pps_version(), p.max_iterations, e.dilation_distance, a.edge_asso_angle);\n'
+                   '  return pps_graph_destroy(g);\n}\n')
+    exe = tmp_path / "hdr"
+    lib = os.path.join(ROOT, "pop_up_slam_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", lib, "-lpps", "-Wl,-rpath," + lib])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[1:] == ["500", "11", "60"]
