@@ -204,8 +204,11 @@ def main():
                     "in_solve_event_pairs": {"launches": k1_launches, "avg_us": k1_pairs * 1e6},
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "note": "K1 of the C2 graph on the solver's stream: 400 back-to-back launches between two HIP events "
-                            "(agrees with the rocprofv3 kernel duration; an event pair around every single launch of one "
-                            "extra solve, in_solve_event_pairs, also measures the event handling itself). One C2 "
+                            "(rocprofv3 of this command reports 9.1-9.6 us for these launches and ~11.9 us for the launches "
+                            "inside the solves, where the speculation stream is active and the state has just been rewritten: "
+                            "its mean over both kinds is ~11.3 us, profiles/r1_v7_kernel_stats_c2.txt; an event pair around "
+                            "every single launch of one extra solve, in_solve_event_pairs, also measures the event handling "
+                            "itself). One C2 "
                             "graph is 2.8 MB per sweep: cache-resident and latency bound, so HBM traffic is not meaningful "
                             "here (traffic: null); see roofline_batched for the same kernel family over > 256 MB"}
         # batched variant: replicate the edge arrays until one sweep moves > 256 MB; the plane-edge launch
