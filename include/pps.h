@@ -214,6 +214,10 @@ int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* dep
 /* switch the optional per-pixel outputs of pps_popup_run off / on (default: both on).  The cloud alone is 16 B per pixel
  * (what generate_cloud produces); the depth map (get_depth_map_good) and the plane-id map add 4 B each. */
 int pps_popup_set_outputs(pps_popup* p, int want_depth, int want_plane_id);
+/* Tail of get_depth_map_good for the half-resolution pop-up (popup_plane.cpp:913-917, as main_3d.cpp:454 calls it): after
+ * a pps_popup_run with step = 2 the depth map is defined on the even pixels only; this spreads it over the full frame the
+ * way the reference does (resize 0.5, x 4, resize 2: bilinear from the half-size map).  Even image sizes only. */
+int pps_popup_fill_depth(pps_popup* p);
 /* ground_seg3d_lines_world of the last run (popup_plane.cpp:569-578): n x 6 = (x0,y0,0,x1,y1,0), the
  * world-frame ground end points of every segment -- columns 0,1 of all_3d_bound_polygons_world (:494-495),
  * which data association compares (Mapping.cpp:355-360). */

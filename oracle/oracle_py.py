@@ -91,6 +91,7 @@ def lib():
             ("ora_popup_cloud", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, C.c_float, C.c_float, fp,
                                  C.POINTER(C.c_ubyte)], None),
             ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
+            ("ora_depth_fill_half", [fp, C.c_int, C.c_int, fp], None),
             ("ora_edge_default_params", [C.c_void_p], None),
             ("ora_label_preprocess", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), ip, ip], None),
             ("ora_ground_contour", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp, C.c_int, ip, ip], C.c_int),
@@ -322,6 +323,14 @@ def popup_cloud(plane_id, invK, T_wc, planes_sensor, depth_thre=10.0, ceiling_th
                           depth_thre, ceiling_thre, xyz.ctypes.data_as(C.POINTER(C.c_float)),
                           valid.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return xyz, valid
+
+
+def depth_fill_half(sparse):
+    """popup_plane.cpp:913-917: even-pixel depth map -> resize 0.5, x 4, resize 2"""
+    a, pa = _f(sparse); h, w = a.shape
+    out = np.zeros((h, w), dtype=np.float32)
+    lib().ora_depth_fill_half(pa, w, h, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
 
 
 def popup_depth(plane_id, invK, T_wc, planes_sensor, ceiling_plane_sensor, ceiling_thre=2.5):

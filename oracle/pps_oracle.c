@@ -1500,3 +1500,39 @@ void ora_popup_depth(const int* plane_id, int width, int height, const float inv
       }
     }
 }
+
+
+/* popup_plane.cpp:913-917.  cv::resize(src, dst, Size(), 0.5, 0.5) with the default INTER_LINEAR takes the INTER_AREA
+ * path for an exact factor of 2: dst = (s00 + s01 + s10 + s11) * 0.25.  convertTo(-1, 4) multiplies by 4.
+ * cv::resize(..., 2, 2): fx = (float)((dx + 0.5) * 0.5 - 0.5), sx = floor(fx), fx -= sx, clamped at both borders;
+ * a horizontal pass S[sx] * (1 - fx) + S[sx + 1] * fx on two source rows, then the vertical blend. */
+void ora_depth_fill_half(const float* sparse, int w, int h, float* out) {
+  const int hw = w / 2, hh = h / 2;
+  float* half = (float*)malloc(sizeof(float) * (size_t)hw * hh);
+  for (int y = 0; y < hh; y++)
+    for (int x = 0; x < hw; x++) {
+      const float* s = sparse + (size_t)(2 * y) * w + 2 * x;
+      const float sum = s[0] + s[1] + s[w] + s[w + 1];
+      half[(size_t)y * hw + x] = sum * 0.25f * 4.0f;
+    }
+  for (int Y = 0; Y < h; Y++) {
+    float fy = (float)((Y + 0.5) * 0.5 - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    if (sy < 0) { fy = 0; sy = 0; }
+    if (sy >= hh - 1) { fy = 0; sy = hh - 1; }
+    const int sy1 = sy + 1 < hh ? sy + 1 : hh - 1;
+    for (int X = 0; X < w; X++) {
+      float fx = (float)((X + 0.5) * 0.5 - 0.5);
+      int sx = (int)floorf(fx);
+      fx -= sx;
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= hw - 1) { fx = 0; sx = hw - 1; }
+      const int sx1 = sx + 1 < hw ? sx + 1 : hw - 1;
+      const float r0 = half[(size_t)sy * hw + sx] * (1.f - fx) + half[(size_t)sy * hw + sx1] * fx;
+      const float r1 = half[(size_t)sy1 * hw + sx] * (1.f - fx) + half[(size_t)sy1 * hw + sx1] * fx;
+      out[(size_t)Y * w + X] = r0 * (1.f - fy) + r1 * fy;
+    }
+  }
+  free(half);
+}

@@ -147,6 +147,10 @@ void ora_popup_depth(const int* plane_id, int width, int height, const float inv
                      const float* planes_sensor, int nplanes, const float ceiling_plane_sensor[4],
                      float ceiling_thre, float* depth_out);
 
+/* popup_plane.cpp:913-917: depth map known on the even pixels -> cv::resize 0.5 (INTER_AREA for a factor of exactly 2), x 4,
+ * cv::resize 2 (INTER_LINEAR).  w, h even. */
+void ora_depth_fill_half(const float* sparse, int w, int h, float* out);
+
 /* ---- ground-edge selection: popup_plane::edge_get_polygons (pop_up_wall/libs/select_edge.cpp:66-409) with its
  * Python helpers (pop_up_python/.../pop_up_fun.py:85-204); restated in pps_edges_oracle.c ---------------- */
 typedef struct ora_edge_params {

@@ -103,7 +103,7 @@ SYMBOLS = [
     "pps_time_linearize", "pps_reproject_points", "pps_popup_set_outputs",
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
-    "pps_edges_host_select",
+    "pps_edges_host_select", "pps_popup_fill_depth",
 ]
 
 
@@ -166,6 +166,7 @@ def lib():
         L.pps_popup_run.argtypes = [C.c_void_p, _fp, C.c_int, _fp, _fp, _ip, C.c_int, C.c_int, C.c_float, C.c_float, _ip]
         L.pps_popup_download.argtypes = [C.c_void_p, _fp, C.c_void_p, _fp, C.POINTER(C.c_int32)]
         L.pps_popup_last_kernel_time.argtypes = [C.c_void_p, _dp]
+        L.pps_popup_fill_depth.argtypes = [C.c_void_p]
         L.pps_frames_set_calibration.argtypes = [C.c_void_p, _fp]
         L.pps_frames_add.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _ip, _ip]
         L.pps_refresh_measurements.argtypes = [C.c_void_p]
@@ -527,6 +528,10 @@ class Popup:
     def _ck(self, rc):
         if rc != PPS_OK:
             raise PpsError(rc, self.L.pps_popup_last_error(self.h).decode())
+
+    def fill_depth(self):
+        """after run(step=2): spread the even-pixel depth map over the full frame (get_depth_map_good's resize chain)"""
+        self._ck(self.L.pps_popup_fill_depth(self.h))
 
     def set_image(self, bgr):
         if bgr is None:

@@ -289,6 +289,8 @@ struct pps_popup {
   unsigned char* d_bgr = nullptr; bool has_image = false;
   pps_point* d_cloud = nullptr;
   float* d_depth = nullptr;
+  float* d_depth_fill = nullptr;   // second depth buffer of pps_popup_fill_depth (allocated on first use)
+  int last_step = 1;
   int* d_pid = nullptr;
   bool want_depth = true, want_pid = true;   // optional per-pixel outputs (pps_popup_set_outputs)
   float* d_planes = nullptr;   // (kMaxPlanes+1) x 4 plane equations, then kMaxPlanes x 6 world ground segments
@@ -359,7 +361,7 @@ int pps_popup_destroy(pps_popup* p) {
   if (!p) return PPS_EINVAL;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  (void)hipFree(p->d_bgr); (void)hipFree(p->d_cloud); (void)hipFree(p->d_depth); (void)hipFree(p->d_pid);
+  (void)hipFree(p->d_bgr); (void)hipFree(p->d_cloud); (void)hipFree(p->d_depth); (void)hipFree(p->d_depth_fill); (void)hipFree(p->d_pid);
   (void)hipFree(p->d_planes); (void)hipFree(p->d_seg); (void)hipFree(p->d_polys); (void)hipFree(p->d_off); (void)hipFree(p->d_count);
   if (p->h_count) (void)hipHostFree(p->h_count);
   if (p->ev[0]) (void)hipEventDestroy(p->ev[0]);
@@ -419,8 +421,47 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   float ms = 0;
   (void)hipEventElapsedTime(&ms, p->ev[0], p->ev[1]);
   p->last_kernel_s = 1e-3 * ms;
-  p->last_n = n;
+  p->last_n = n; p->last_step = step;
   if (n_valid) *n_valid = (int)*p->h_count;
+  return PPS_OK;
+}
+
+// Tail of get_depth_map_good for the half-resolution pop-up (popup_plane.cpp:913-917): the depth map holds values on the
+// even pixels only; cv::resize(0.5) -- INTER_AREA for an exact factor 2: the mean of a 2x2 block, three of whose pixels
+// are 0 -- times 4 gives back the value at (2x, 2y); cv::resize(2, INTER_LINEAR) then spreads the half-size map over the
+// full frame: source coordinate (X + 0.5) / 2 - 0.5, clamped at the borders, weights 0.25 / 0.75.
+__global__ __launch_bounds__(256) void k_depth_fill(const float* __restrict__ sparse, float* __restrict__ out, int w, int h) {
+  const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+  if (X >= w) return;
+  const int hw = w / 2, hh = h / 2;
+  float fx = (float)((X + 0.5) * 0.5 - 0.5), fy = (float)((Y + 0.5) * 0.5 - 0.5);
+  int sx = (int)floorf(fx), sy = (int)floorf(fy);
+  fx -= sx; fy -= sy;
+  if (sx < 0) { fx = 0; sx = 0; }
+  if (sx >= hw - 1) { fx = 0; sx = hw - 1; }
+  if (sy < 0) { fy = 0; sy = 0; }
+  if (sy >= hh - 1) { fy = 0; sy = hh - 1; }
+  const int sx1 = sx + 1 < hw ? sx + 1 : hw - 1, sy1 = sy + 1 < hh ? sy + 1 : hh - 1;
+  const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+  auto S = [&](int y, int x) { return sparse[(size_t)(2 * y) * w + 2 * x] * 0.25f * 4.0f; };
+  const float r0 = S(sy, sx) * a0 + S(sy, sx1) * a1;
+  const float r1 = S(sy1, sx) * a0 + S(sy1, sx1) * a1;
+  out[(size_t)Y * w + X] = r0 * b0 + r1 * b1;
+}
+
+int pps_popup_fill_depth(pps_popup* p) {
+  if (!p) return PPS_EINVAL;
+  if (!p->want_depth) return pfail(p, PPS_ESTATE, "depth output is switched off (pps_popup_set_outputs)");
+  if (p->last_step != 2) return pfail(p, PPS_ESTATE, "pps_popup_fill_depth follows a pps_popup_run with step = 2");
+  if ((p->width | p->height) & 1) return pfail(p, PPS_EINVAL, "pps_popup_fill_depth needs an even image size");
+  PHIP(p, hipSetDevice(p->device));
+  const size_t npx = (size_t)p->width * p->height;
+  if (!p->d_depth_fill) PHIP(p, hipMalloc(reinterpret_cast<void**>(&p->d_depth_fill), npx * sizeof(float)));
+  hipLaunchKernelGGL(k_depth_fill, dim3((p->width + 255) / 256, p->height), dim3(256), 0, p->stream, p->d_depth, p->d_depth_fill, p->width, p->height);
+  PHIP(p, hipGetLastError());
+  PHIP(p, hipStreamSynchronize(p->stream));
+  std::swap(p->d_depth, p->d_depth_fill);
+  p->last_step = 1;                       // the map is dense now
   return PPS_OK;
 }
 

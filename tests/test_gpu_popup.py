@@ -87,6 +87,14 @@ def test_fused_frame_matches_oracle(built, step):
     ref_depth = O.popup_depth(pid, INVK, T, planes, ceil_s, 2.5)
     np.testing.assert_array_equal(depth, ref_depth)
     assert depth.max() > 3.0
+    if step == 2:
+        # the half-resolution tail of get_depth_map_good (popup_plane.cpp:913-917): even-pixel map -> full frame
+        pp.fill_depth()
+        filled = pp.download()[2]
+        np.testing.assert_array_equal(filled, O.depth_fill_half(ref_depth))
+        assert (filled > 0).mean() > 3.5 * (ref_depth > 0).mean()
+        with pytest.raises(P.PpsError):
+            pp.fill_depth()            # the map is dense now: a second fill has nothing to work on
 
 
 def test_wall_points_lie_on_the_wall(built):

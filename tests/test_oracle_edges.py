@@ -214,3 +214,31 @@ def test_numpy_golden_cases():
         assert np.array_equal(w, np.array(cs["open_in_closed"], np.float32))
         n_open += len(o)
     assert n_open > 30
+
+
+def test_depth_fill_half_against_numpy():
+    """get_depth_map_good's resize chain for the half-resolution pop-up (popup_plane.cpp:913-917): the oracle against a
+    vectorised numpy evaluation of the same OpenCV formulas, and two invariants"""
+    rng = np.random.default_rng(4)
+    h, w = 48, 64
+    sparse = np.zeros((h, w), np.float32)
+    sparse[::2, ::2] = rng.uniform(0.5, 9.0, (h // 2, w // 2)).astype(np.float32)
+    sparse[10:20:2, 10:30:2] = 0                      # a hole (no plane there)
+    out = O.depth_fill_half(sparse)
+    half = sparse[::2, ::2]                           # mean of a 2x2 block with three zeros, times 4
+    def axis(n_full, n_half):
+        f = ((np.arange(n_full) + 0.5) * 0.5 - 0.5).astype(np.float32)
+        s = np.floor(f).astype(int)
+        f = (f - s).astype(np.float32)
+        lo = s < 0; f[lo] = 0; s[lo] = 0
+        hi = s >= n_half - 1; f[hi] = 0; s[hi] = n_half - 1
+        return s, np.minimum(s + 1, n_half - 1), f
+    sy, sy1, fy = axis(h, h // 2); sx, sx1, fx = axis(w, w // 2)
+    one = np.float32(1)
+    r0 = half[sy][:, sx] * (one - fx)[None, :] + half[sy][:, sx1] * fx[None, :]
+    r1 = half[sy1][:, sx] * (one - fx)[None, :] + half[sy1][:, sx1] * fx[None, :]
+    want = r0 * (one - fy)[:, None] + r1 * fy[:, None]
+    assert np.array_equal(out, want.astype(np.float32))
+    flat = np.zeros((h, w), np.float32); flat[::2, ::2] = 3.25
+    assert np.array_equal(O.depth_fill_half(flat), np.full((h, w), 3.25, np.float32))      # a constant field stays constant
+    assert out.min() >= 0 and out.max() <= sparse.max()                                     # convex combinations only
