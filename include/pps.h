@@ -214,6 +214,15 @@ int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* dep
 /* switch the optional per-pixel outputs of pps_popup_run off / on (default: both on).  The cloud alone is 16 B per pixel
  * (what generate_cloud produces); the depth map (get_depth_map_good) and the plane-id map add 4 B each. */
 int pps_popup_set_outputs(pps_popup* p, int want_depth, int want_plane_id);
+/* The rest of get_plane_equation's per-plane outputs for the last run (popup_plane.cpp:616-640), n+1 entries, plane 0 = ground:
+ *   dist_to_cam  all_plane_dist_to_cam: camera height for the ground, distance from the camera footprint to the world
+ *                ground segment for a wall (what the mapper's sigma model reads, Mapping.cpp:507-512)
+ *   good         1 for the ground and for every wall whose two ground points lie in front of the camera, closer than
+ *                plane_cam_dist_thre (popup_plane.h:86: 10) and -- if actual_plane_indices is given (n_actual > 0; plane
+ *                indices >= 1, e.g. open_in_closed + 1 of pps_edges_select) -- not a manually connected edge: good_plane_indices
+ * Either output may be NULL. */
+int pps_popup_plane_info(pps_popup* p, float plane_cam_dist_thre, const int* actual_plane_indices, int n_actual,
+                         float* dist_to_cam, int32_t* good);
 /* Tail of get_depth_map_good for the half-resolution pop-up (popup_plane.cpp:913-917, as main_3d.cpp:454 calls it): after
  * a pps_popup_run with step = 2 the depth map is defined on the even pixels only; this spreads it over the full frame the
  * way the reference does (resize 0.5, x 4, resize 2: bilinear from the half-size map).  Even image sizes only. */

@@ -92,6 +92,7 @@ def lib():
                                  C.POINTER(C.c_ubyte)], None),
             ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
             ("ora_depth_fill_half", [fp, C.c_int, C.c_int, fp], None),
+            ("ora_popup_plane_info", [fp, C.c_int, fp, fp, C.c_float, ip, C.c_int, fp, ip], None),
             ("ora_edge_default_params", [C.c_void_p], None),
             ("ora_label_preprocess", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), ip, ip], None),
             ("ora_ground_contour", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp, C.c_int, ip, ip], C.c_int),
@@ -323,6 +324,17 @@ def popup_cloud(plane_id, invK, T_wc, planes_sensor, depth_thre=10.0, ceiling_th
                           depth_thre, ceiling_thre, xyz.ctypes.data_as(C.POINTER(C.c_float)),
                           valid.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return xyz, valid
+
+
+def popup_plane_info(seg2d, invK, T_wc, plane_cam_dist_thre=10.0, actual=None):
+    """popup_plane.cpp:616-640 -> (all_plane_dist_to_cam (n+1), good flags (n+1))"""
+    seg, ps = _f(seg2d); n = seg.reshape(-1, 4).shape[0]
+    k, pk = _f(invK); t, pt = _f(T_wc)
+    act = np.ascontiguousarray(actual if actual is not None else [], dtype=np.int32)
+    dist = np.zeros(n + 1, dtype=np.float32); good = np.zeros(n + 1, dtype=np.int32)
+    lib().ora_popup_plane_info(ps, n, pk, pt, float(plane_cam_dist_thre), act.ctypes.data_as(C.POINTER(C.c_int)), len(act),
+                               dist.ctypes.data_as(C.POINTER(C.c_float)), good.ctypes.data_as(C.POINTER(C.c_int)))
+    return dist, good
 
 
 def depth_fill_half(sparse):

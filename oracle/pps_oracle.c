@@ -1536,3 +1536,46 @@ void ora_depth_fill_half(const float* sparse, int w, int h, float* out) {
   }
   free(half);
 }
+
+
+/* matrix_utils.cpp:290-304 */
+static float point_dist_lineseg_f(const float b[2], const float e[2], const float q[2]) {
+  const float length = sqrtf((e[0] - b[0]) * (e[0] - b[0]) + (e[1] - b[1]) * (e[1] - b[1]));
+  if (length < 0.001) return sqrtf((q[0] - b[0]) * (q[0] - b[0]) + (q[1] - b[1]) * (q[1] - b[1]));
+  const float t = ((q[0] - b[0]) * (e[0] - b[0]) + (q[1] - b[1]) * (e[1] - b[1])) / length / length;
+  if (t < 0.0) return sqrtf((q[0] - b[0]) * (q[0] - b[0]) + (q[1] - b[1]) * (q[1] - b[1]));
+  else if (t > 1.0) return sqrtf((q[0] - e[0]) * (q[0] - e[0]) + (q[1] - e[1]) * (q[1] - e[1]));
+  const float p[2] = {b[0] + t * (e[0] - b[0]), b[1] + t * (e[1] - b[1])};
+  return sqrtf((q[0] - p[0]) * (q[0] - p[0]) + (q[1] - p[1]) * (q[1] - p[1]));
+}
+
+/* popup_plane.cpp:616-640 */
+void ora_popup_plane_info(const float* seg2d, int n, const float invK[9], const float T[16], float plane_cam_dist_thre,
+                          const int* actual, int n_actual, float* dist_to_cam, int* good) {
+  float gs[4];
+  for (int k = 0; k < 4; k++) gs[k] = T[0 * 4 + k] * 0.f + T[1 * 4 + k] * 0.f + T[2 * 4 + k] * -1.f + T[3 * 4 + k] * 0.f;
+  dist_to_cam[0] = T[2 * 4 + 3];
+  good[0] = 1;
+  const float cam[2] = {T[0 * 4 + 3], T[1 * 4 + 3]};
+  for (int sgi = 0; sgi < n; sgi++) {
+    float Pw[2][2], zs[2];
+    for (int e = 0; e < 2; e++) {
+      const float u = seg2d[sgi * 4 + 2 * e], v = seg2d[sgi * 4 + 2 * e + 1];
+      float ray[3];
+      for (int i = 0; i < 3; i++) ray[i] = invK[i * 3 + 0] * u + invK[i * 3 + 1] * v + invK[i * 3 + 2] * 1.f;
+      const float frac = -gs[3] / (gs[0] * ray[0] + gs[1] * ray[1] + gs[2] * ray[2]);
+      const float Ps[4] = {frac * ray[0], frac * ray[1], frac * ray[2], 1.f};
+      zs[e] = Ps[2];                        /* ground_seg3d_lines_sensor(seg, 2 / 5) */
+      float Ph[4];
+      for (int i = 0; i < 4; i++) Ph[i] = T[i * 4 + 0] * Ps[0] + T[i * 4 + 1] * Ps[1] + T[i * 4 + 2] * Ps[2] + T[i * 4 + 3] * Ps[3];
+      Pw[e][0] = Ph[0] / Ph[3]; Pw[e][1] = Ph[1] / Ph[3];
+    }
+    dist_to_cam[sgi + 1] = point_dist_lineseg_f(Pw[0], Pw[1], cam);
+    int ok = zs[0] > 0 && zs[1] > 0 && dist_to_cam[sgi + 1] < plane_cam_dist_thre;
+    if (ok && n_actual > 0) {
+      ok = 0;
+      for (int k = 0; k < n_actual; k++) if (actual[k] == sgi + 1) ok = 1;
+    }
+    good[sgi + 1] = ok;
+  }
+}

@@ -147,6 +147,10 @@ void ora_popup_depth(const int* plane_id, int width, int height, const float inv
                      const float* planes_sensor, int nplanes, const float ceiling_plane_sensor[4],
                      float ceiling_thre, float* depth_out);
 
+/* popup_plane.cpp:616-640: all_plane_dist_to_cam (n+1) and good-plane flags (n+1; ground always good).  actual: plane indices
+ * (>= 1) of the non-connecting edges, n_actual = 0: all edges count */
+void ora_popup_plane_info(const float* seg2d, int n, const float invK[9], const float T_wc[16], float plane_cam_dist_thre,
+                          const int* actual, int n_actual, float* dist_to_cam, int* good);
 /* popup_plane.cpp:913-917: depth map known on the even pixels -> cv::resize 0.5 (INTER_AREA for a factor of exactly 2), x 4,
  * cv::resize 2 (INTER_LINEAR).  w, h even. */
 void ora_depth_fill_half(const float* sparse, int w, int h, float* out);

@@ -103,7 +103,7 @@ SYMBOLS = [
     "pps_time_linearize", "pps_reproject_points", "pps_popup_set_outputs",
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
-    "pps_edges_host_select", "pps_popup_fill_depth",
+    "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info",
 ]
 
 
@@ -167,6 +167,7 @@ def lib():
         L.pps_popup_download.argtypes = [C.c_void_p, _fp, C.c_void_p, _fp, C.POINTER(C.c_int32)]
         L.pps_popup_last_kernel_time.argtypes = [C.c_void_p, _dp]
         L.pps_popup_fill_depth.argtypes = [C.c_void_p]
+        L.pps_popup_plane_info.argtypes = [C.c_void_p, C.c_float, _ip, C.c_int, _fp, _ip]
         L.pps_frames_set_calibration.argtypes = [C.c_void_p, _fp]
         L.pps_frames_add.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp, _ip, _ip]
         L.pps_refresh_measurements.argtypes = [C.c_void_p]
@@ -528,6 +529,14 @@ class Popup:
     def _ck(self, rc):
         if rc != PPS_OK:
             raise PpsError(rc, self.L.pps_popup_last_error(self.h).decode())
+
+    def plane_info(self, plane_cam_dist_thre=10.0, actual_plane_indices=None):
+        """all_plane_dist_to_cam and the good-plane flags of the last run (n+1 entries, plane 0 = ground)"""
+        dist = np.zeros(self.n + 1, dtype=np.float32); good = np.zeros(self.n + 1, dtype=np.int32)
+        act = np.ascontiguousarray(actual_plane_indices if actual_plane_indices is not None else [], dtype=np.int32)
+        self._ck(self.L.pps_popup_plane_info(self.h, float(plane_cam_dist_thre), act.ctypes.data_as(_ip) if len(act) else None, len(act),
+                                             dist.ctypes.data_as(_fp), good.ctypes.data_as(_ip)))
+        return dist, good
 
     def fill_depth(self):
         """after run(step=2): spread the even-pixel depth map over the full frame (get_depth_map_good's resize chain)"""

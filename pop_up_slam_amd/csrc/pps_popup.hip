@@ -30,8 +30,9 @@ constexpr int kMaxVerts = 512;
 
 // one wall plane from a ground segment; exact operation order of the reference (and of the oracle)
 __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
-                                             const float gs[4], float out[4], float* __restrict__ seg3d_world = nullptr) {
-  float Pw[2][3];
+                                             const float gs[4], float out[4], float* __restrict__ seg3d_world = nullptr,
+                                             float* __restrict__ info = nullptr) {
+  float Pw[2][3], zs[2];
 #pragma unroll
   for (int e = 0; e < 2; e++) {
     const float u = seg[2 * e], v = seg[2 * e + 1];
@@ -40,11 +41,31 @@ __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, cons
     for (int i = 0; i < 3; i++) ray[i] = invK[i * 3 + 0] * u + invK[i * 3 + 1] * v + invK[i * 3 + 2] * 1.f;
     const float frac = -gs[3] / (gs[0] * ray[0] + gs[1] * ray[1] + gs[2] * ray[2]);
     const float Ps[4] = {frac * ray[0], frac * ray[1], frac * ray[2], 1.f};
+    zs[e] = Ps[2];
     float Ph[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) Ph[i] = T[i * 4 + 0] * Ps[0] + T[i * 4 + 1] * Ps[1] + T[i * 4 + 2] * Ps[2] + T[i * 4 + 3] * Ps[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) Pw[e][i] = Ph[i] / Ph[3];
+  }
+  if (info) {
+    // all_plane_dist_to_cam: camera footprint to the world ground segment (point_dist_lineseg, matrix_utils.cpp:290-304), and
+    // whether both end points lie in front of the camera (popup_plane.cpp:616-627)
+    const float bx = Pw[0][0], by = Pw[0][1], ex = Pw[1][0], ey = Pw[1][1], qx = T[3], qy = T[7];
+    const float len = sqrtf((ex - bx) * (ex - bx) + (ey - by) * (ey - by));
+    float dcam;
+    if (len < 0.001) dcam = sqrtf((qx - bx) * (qx - bx) + (qy - by) * (qy - by));
+    else {
+      const float t = ((qx - bx) * (ex - bx) + (qy - by) * (ey - by)) / len / len;
+      if (t < 0.0) dcam = sqrtf((qx - bx) * (qx - bx) + (qy - by) * (qy - by));
+      else if (t > 1.0) dcam = sqrtf((qx - ex) * (qx - ex) + (qy - ey) * (qy - ey));
+      else {
+        const float px = bx + t * (ex - bx), py = by + t * (ey - by);
+        dcam = sqrtf((qx - px) * (qx - px) + (qy - py) * (qy - py));
+      }
+    }
+    info[0] = dcam;
+    info[1] = (zs[0] > 0 && zs[1] > 0) ? 1.f : 0.f;
   }
   if (seg3d_world) {   // ground_seg3d_lines_world row, z forced to exact zero (popup_plane.cpp:569-578)
     seg3d_world[0] = Pw[0][0]; seg3d_world[1] = Pw[0][1]; seg3d_world[2] = 0.f;
@@ -97,7 +118,8 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
     ground_plane_sensor(prm.T, gs);
     if (tid == 0) { pl[0] = gs[0]; pl[1] = gs[1]; pl[2] = gs[2]; pl[3] = gs[3]; }
     else seg_to_plane(seg2d + 4 * (tid - 1), prm.invK, prm.T, gs, pl,
-                      (blockIdx.x == 0 && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * (tid - 1) : nullptr);
+                      (blockIdx.x == 0 && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * (tid - 1) : nullptr,
+                      (blockIdx.x == 0 && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * (tid - 1) : nullptr);
 #pragma unroll
     for (int k = 0; k < 4; k++) s_planes[tid][k] = pl[k];
     if (blockIdx.x == 0 && planes_out) {
@@ -291,6 +313,7 @@ struct pps_popup {
   float* d_depth = nullptr;
   float* d_depth_fill = nullptr;   // second depth buffer of pps_popup_fill_depth (allocated on first use)
   int last_step = 1;
+  float last_T[16] = {0};          // pose of the last run
   int* d_pid = nullptr;
   bool want_depth = true, want_pid = true;   // optional per-pixel outputs (pps_popup_set_outputs)
   float* d_planes = nullptr;   // (kMaxPlanes+1) x 4 plane equations, then kMaxPlanes x 6 world ground segments
@@ -346,7 +369,7 @@ int pps_popup_create(int device, int width, int height, const float invK[9], pps
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_cloud), npx * sizeof(pps_point));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_depth), npx * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_pid), npx * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * (4 * (kMaxPlanes + 1) + 6 * kMaxPlanes));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * (4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * kMaxPlanes));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_seg), sizeof(float) * 4 * kMaxPlanes);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_polys), sizeof(float) * 2 * kMaxVerts);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_off), sizeof(int) * (kMaxPlanes + 2));
@@ -422,6 +445,7 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   (void)hipEventElapsedTime(&ms, p->ev[0], p->ev[1]);
   p->last_kernel_s = 1e-3 * ms;
   p->last_n = n; p->last_step = step;
+  memcpy(p->last_T, T_wc, sizeof p->last_T);
   if (n_valid) *n_valid = (int)*p->h_count;
   return PPS_OK;
 }
@@ -481,6 +505,28 @@ int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* dep
 int pps_popup_set_outputs(pps_popup* p, int want_depth, int want_plane_id) {
   if (!p) return PPS_EINVAL;
   p->want_depth = want_depth != 0; p->want_pid = want_plane_id != 0;
+  return PPS_OK;
+}
+
+int pps_popup_plane_info(pps_popup* p, float plane_cam_dist_thre, const int* actual_plane_indices, int n_actual, float* dist_to_cam,
+                         int32_t* good) {
+  if (!p || (!dist_to_cam && !good) || n_actual < 0 || (n_actual > 0 && !actual_plane_indices)) return PPS_EINVAL;
+  PHIP(p, hipSetDevice(p->device));
+  const int n = p->last_n;
+  std::vector<float> info(2 * (size_t)(n > 0 ? n : 1));
+  if (n > 0) PHIP(p, hipMemcpy(info.data(), p->d_planes + 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost));
+  if (dist_to_cam) dist_to_cam[0] = p->last_T[11];                 // the ground: camera height (transToWolrd(2,3), :617)
+  if (good) good[0] = 1;                                           // "always push ground plane" (:620)
+  for (int sgi = 0; sgi < n; sgi++) {
+    if (dist_to_cam) dist_to_cam[sgi + 1] = info[2 * sgi];
+    if (!good) continue;
+    bool ok = info[2 * sgi + 1] != 0.f && info[2 * sgi] < plane_cam_dist_thre;   // :624-627
+    if (ok && n_actual > 0) {                                      // manually connected edges are not popped up (:629-633)
+      ok = false;
+      for (int k = 0; k < n_actual; k++) ok = ok || actual_plane_indices[k] == sgi + 1;
+    }
+    good[sgi + 1] = ok ? 1 : 0;
+  }
   return PPS_OK;
 }
 

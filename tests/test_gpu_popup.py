@@ -162,3 +162,22 @@ def test_refresh_measurements_feeds_the_graph(built):
     # a later refresh overwrites it again
     g.refresh_measurements()
     assert abs(g.get_measurement(frames[0][2][0])[3]) > 1e-3
+
+
+def test_plane_info_matches_oracle(built):
+    """all_plane_dist_to_cam and good_plane_indices of get_plane_equation (popup_plane.cpp:616-640)"""
+    for yaw, far in ((0.0, 8.0), (0.2, 14.0), (-0.15, 6.0)):
+        tq = _pose(yaw=yaw, pitch=0.02, x=0.3, y=-0.2)
+        seg, polys, T = synth.corridor_frame(tq, half_width=1.5, near=4.0, far=far)
+        seg = np.vstack([seg, [[300.0, 100.0, 340.0, 90.0]]]).astype(np.float32)   # a segment above the horizon: behind the camera
+        polys = polys + [np.zeros((0, 2), np.float32)]
+        pp = P.Popup(W, H, INVK)
+        pp.run(seg, T, polys, ceiling_thre=2.5)
+        for thre, actual in ((10.0, None), (7.0, None), (10.0, [1, 3]), (100.0, [2, 4])):
+            dist, good = pp.plane_info(thre, actual)
+            rdist, rgood = O.popup_plane_info(seg, INVK, T, thre, actual)
+            np.testing.assert_array_equal(dist, rdist)
+            np.testing.assert_array_equal(good, rgood)
+        dist, good = pp.plane_info(10.0)
+        assert good[0] == 1 and good[4] == 0                   # ground always; the segment behind the camera never
+        assert abs(dist[0] - T[2, 3]) == 0 and (far > 10.5) == (good[2] == 0)     # the end wall drops out beyond 10 m

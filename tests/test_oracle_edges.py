@@ -242,3 +242,17 @@ def test_depth_fill_half_against_numpy():
     flat = np.zeros((h, w), np.float32); flat[::2, ::2] = 3.25
     assert np.array_equal(O.depth_fill_half(flat), np.full((h, w), 3.25, np.float32))      # a constant field stays constant
     assert out.min() >= 0 and out.max() <= sparse.max()                                     # convex combinations only
+
+
+def test_plane_info_hand_case():
+    """popup_plane.cpp:616-640 on a straight-ahead corridor view: camera at the origin, walls at x = -1.5 / +1.5 from 4 m to
+    8 m and an end wall at 8 m"""
+    from pop_up_slam_amd import synth
+    tq = synth.pose_from_Rt(synth.CAM_R0, np.array([0.0, 0.0, 1.0]))
+    seg, _, T = synth.corridor_frame(tq, half_width=1.5, near=4.0, far=8.0)
+    invK = np.linalg.inv(synth.K_TUM).astype(np.float32)
+    dist, good = O.popup_plane_info(seg, invK, T, 10.0)
+    assert np.allclose(dist, [1.0, np.hypot(1.5, 4.0), 8.0, np.hypot(1.5, 4.0)], atol=2e-3)
+    assert list(good) == [1, 1, 1, 1]
+    assert list(O.popup_plane_info(seg, invK, T, 5.0)[1]) == [1, 1, 0, 1]          # the end wall is 8 m away
+    assert list(O.popup_plane_info(seg, invK, T, 10.0, [2])[1]) == [1, 0, 1, 0]    # only plane 2 is an actual (not connecting) edge
