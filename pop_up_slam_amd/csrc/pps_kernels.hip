@@ -1146,15 +1146,19 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     const double d30 = readlane_d(r0, K + 3), d31 = readlane_d(r1, K + 3), d32 = readlane_d(r2, K + 3), d33 = readlane_d(r3, K + 3);
     bool bad = false;
     double i0 = 0, i1 = 0, i2 = 0, i3 = 0, l10 = 0, l20 = 0, l30 = 0, l21 = 0, l31 = 0, l32 = 0;
-    { bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? rsqrt_nr(d00) : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
-    if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
-    if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
-    if (nb > 3) { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; bad |= !(t > 0.0); i3 = t > 0.0 ? rsqrt_nr(t) : 0.0; }
+    double x0, x1, x2, x3;
+    {
+#pragma clang fp contract(fast)     // the serial pivot chain: a - b * c is one operation here
+      { bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? rsqrt_nr(d00) : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
+      if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
+      if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
+      if (nb > 3) { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; bad |= !(t > 0.0); i3 = t > 0.0 ? rsqrt_nr(t) : 0.0; }
+      x0 = r0 * i0;
+      x1 = (r1 - x0 * l10) * i1;
+      x2 = (r2 - x0 * l20 - x1 * l21) * i2;
+      x3 = (r3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+    }
     if (bad && lane == 0) d.result_dev[2] = 1.0;           // not positive definite
-    const double x0 = r0 * i0;
-    const double x1 = (r1 - x0 * l10) * i1;
-    const double x2 = (r2 - x0 * l20 - x1 * l21) * i2;
-    const double x3 = (r3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
     P[lane * kPStride + 0] = x0; P[lane * kPStride + 1] = x1; P[lane * kPStride + 2] = x2; P[lane * kPStride + 3] = x3;
     if (lane < fa) {
       double* __restrict__ lrow = Lp + (size_t)lane * p + K;
@@ -1224,19 +1228,25 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane + 64 < b) xb[lane + 64] = g1;
   __builtin_amdgcn_wave_barrier();
   double tj = 0.0, dinv = 0.0;
-  if (lane < p) {
-    double acc = PL[f * p + lane];
-    const double* __restrict__ lb = PL + p * p + lane;
+  {
+#pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
+    if (lane < p) {
+      // y - L_B^T x_b in two interleaved partial sums (half the dependent chain)
+      double acc = PL[f * p + lane], acc2 = 0.0;
+      const double* __restrict__ lb = PL + p * p + lane;
+      int i = 0;
+#pragma unroll 2
+      for (; i + 2 <= b; i += 2) { acc -= lb[i * p] * xb[i]; acc2 -= lb[(i + 1) * p] * xb[i + 1]; }
+      if (i < b) acc -= lb[i * p] * xb[i];
+      tj = acc + acc2;
+      dinv = 1.0 / PL[lane * p + lane];
+    }
 #pragma unroll 4
-    for (int i = 0; i < b; i++) acc -= lb[i * p] * xb[i];
-    tj = acc;
-    dinv = 1.0 / PL[lane * p + lane];
-  }
-#pragma unroll 4
-  for (int k = p - 1; k >= 0; k--) {
-    const double lkj = (lane < k) ? PL[k * p + lane] : 0.0;      // independent of the chain
-    const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
-    tj = (lane == k) ? xk : tj - lkj * xk;
+    for (int k = p - 1; k >= 0; k--) {
+      const double lkj = (lane < k) ? PL[k * p + lane] : 0.0;      // independent of the chain
+      const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
+      tj = (lane == k) ? xk : tj - lkj * xk;
+    }
   }
   if (lane < p) d.delta[__builtin_amdgcn_readlane(rec, 7) + lane] = tj;
   // own local solution [x_p | x_b] for the children inside this group

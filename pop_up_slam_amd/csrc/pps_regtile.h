@@ -7,11 +7,17 @@ namespace pps {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// 1/sqrt(x) to fp64 round-off: hardware estimate + two Newton steps (shorter than div + sqrt on the pivot chain)
+// 1/sqrt(x) to fp64 round-off: hardware estimate + two Newton steps (shorter than div + sqrt on the pivot chain).
+// Written with explicit fused multiply-adds -- three dependent operations per step instead of five: this sits on the
+// serial pivot chain of every panel (the library is otherwise built with -ffp-contract=off for the fp32 pop-up parity).
 __device__ __forceinline__ double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const double t = x * y, hy = 0.5 * y;
+    const double e = __builtin_fma(-t, hy, 0.5);       // 0.5 - 0.5 x y^2
+    y = __builtin_fma(y, e, y);
+  }
   return y;
 }
 
