@@ -146,3 +146,34 @@ def test_reproject_points_onto_optimised_planes(built):
             g.remove_factor(int(fg[k]))
     g.remove_node(dead)
     np.testing.assert_array_equal(g.reproject_points([dead] * 4, pts[:4]), pts[:4])
+
+
+def test_handles_release_their_memory(built):
+    """create / solve / destroy in a loop (graph, pop-up and edge-selection contexts): device memory returns to where it was"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    spec = synth.small_world(40, 8, seed=3, obs_per_pose=4)
+    invK = np.linalg.inv(synth.K_TUM).astype(np.float32)
+
+    def cycle():
+        g = P.Graph(); spec.replay(g); g.batch_optimize(); g.close() if hasattr(g, "close") else None
+        pp = P.Popup(640, 480, invK); pp.close()
+        ed = P.Edges(640, 480); ed.select(np.zeros((480, 640), np.uint8), np.zeros((0, 4), np.float32)); ed.close()
+        del g, pp, ed
+
+    for _ in range(3):
+        cycle()                      # warm-up: runtime pools, code objects
+    import gc
+    gc.collect()
+    before = free_bytes()
+    for _ in range(40):
+        cycle()
+    gc.collect()
+    after = free_bytes()
+    assert before - after < (8 << 20), (before, after)      # no growth beyond allocator granularity
