@@ -177,3 +177,29 @@ def test_handles_release_their_memory(built):
     gc.collect()
     after = free_bytes()
     assert before - after < (8 << 20), (before, after)      # no growth beyond allocator granularity
+
+
+def test_handles_on_different_host_threads(built):
+    """one handle per host thread, solved concurrently (the boundary's threading contract): every thread gets
+    the result of its own graph, equal to the single-threaded run"""
+    import threading
+    specs = [synth.small_world(30 + 3 * k, 6 + k % 3, seed=20 + k, obs_per_pose=3 + k % 2) for k in range(6)]
+    want = []
+    for sp in specs:
+        g = P.Graph(); sp.replay(g); it = g.batch_optimize(); want.append((it, g.chi2()))
+    got = [None] * len(specs)
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                g = P.Graph(); specs[k].replay(g); it = g.batch_optimize(); got[k] = (it, g.chi2())
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(len(specs))]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs, errs
+    for k in range(len(specs)):
+        assert got[k][0] == want[k][0] and got[k][1] == want[k][1], (k, got[k], want[k])
