@@ -8,7 +8,8 @@ import pop_up_slam_amd as P
 from oracle import oracle_py as O
 import edge_helpers as E
 
-for (w, h) in ((640, 480), (1920, 1080), (3840, 2160)):
+SIZES = {"vga": (640, 480), "hd": (1920, 1080), "4k": (3840, 2160)}
+for (w, h) in ([SIZES[a] for a in sys.argv[1:]] or list(SIZES.values())):
     lab, lines = E.random_scene(3, w, h, holes=20)
     ed = P.Edges(w, h)
     for _ in range(3):
