@@ -25,8 +25,8 @@ class OraProps(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libpps_oracle.so")
-    src = os.path.join(_HERE, "pps_oracle.c")
-    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    srcs = [os.path.join(_HERE, f) for f in ("pps_oracle.c", "pps_edges_oracle.c", "pps_raster_oracle.c", "pps_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -92,6 +92,8 @@ def lib():
                                  C.POINTER(C.c_ubyte)], None),
             ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
             ("ora_depth_fill_half", [fp, C.c_int, C.c_int, fp], None),
+            ("ora_popup_mask", [fp, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip], None),
+            ("ora_fill_convex_poly", [ip, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte)], None),
             ("ora_popup_plane_info", [fp, C.c_int, fp, fp, C.c_float, ip, C.c_int, fp, ip], None),
             ("ora_edge_default_params", [C.c_void_p], None),
             ("ora_label_preprocess", [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), ip, ip], None),
@@ -343,6 +345,30 @@ def depth_fill_half(sparse):
     out = np.zeros((h, w), dtype=np.float32)
     lib().ora_depth_fill_half(pa, w, h, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def popup_mask(polys, width, height, step=1):
+    """closed_polygons_homo_pts per polygon (popup_plane.cpp:81-116) -> plane-id map, later planes overwrite, -1 = none"""
+    off = np.zeros(len(polys) + 1, dtype=np.int32)
+    for i, p in enumerate(polys):
+        off[i + 1] = off[i] + len(p)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1, 2) for p in polys] +
+                                               [np.zeros((0, 2), np.float32)]), dtype=np.float32)
+    if flat.size == 0:
+        flat = np.zeros((1, 2), np.float32)
+    pid = np.zeros((height, width), dtype=np.int32)
+    lib().ora_popup_mask(flat.ctypes.data_as(C.POINTER(C.c_float)), off.ctypes.data_as(C.POINTER(C.c_int)), len(polys),
+                         width, height, step, pid.ctypes.data_as(C.POINTER(C.c_int)))
+    return pid
+
+
+def fill_convex_poly(pts, width, height):
+    """cv::fillConvexPoly on integer points -> uint8 image (0 / 255)"""
+    q = np.ascontiguousarray(pts, dtype=np.int32).reshape(-1, 2)
+    img = np.zeros((height, width), dtype=np.uint8)
+    lib().ora_fill_convex_poly(q.ctypes.data_as(C.POINTER(C.c_int)), len(q), width, height,
+                               img.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return img
 
 
 def popup_depth(plane_id, invK, T_wc, planes_sensor, ceiling_plane_sensor, ceiling_thre=2.5):

@@ -154,6 +154,12 @@ void ora_popup_plane_info(const float* seg2d, int n, const float invK[9], const 
 /* popup_plane.cpp:913-917: depth map known on the even pixels -> cv::resize 0.5 (INTER_AREA for a factor of exactly 2), x 4,
  * cv::resize 2 (INTER_LINEAR).  w, h even. */
 void ora_depth_fill_half(const float* sparse, int w, int h, float* out);
+/* pps_raster_oracle.c: popup_plane::closed_polygons_homo_pts (popup_plane.cpp:81-116) per polygon -- float -> int
+ * truncation, boundingRect, cv::fillConvexPoly (restated from OpenCV's published drawing.cpp), findNonZero -- composed
+ * into a plane-id map (later planes overwrite, -1 = none).  step 2 = downsample_poly. */
+void ora_popup_mask(const float* polys, const int* poly_off, int nplanes, int width, int height, int step, int* plane_id);
+/* cv::fillConvexPoly(img, pts, npts, 255) on a zeroed width x height CV_8U image */
+void ora_fill_convex_poly(const int* pts_xy, int npts, int width, int height, unsigned char* img);
 
 /* ---- ground-edge selection: popup_plane::edge_get_polygons (pop_up_wall/libs/select_edge.cpp:66-409) with its
  * Python helpers (pop_up_python/.../pop_up_fun.py:85-204); restated in pps_edges_oracle.c ---------------- */

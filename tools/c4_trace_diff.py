@@ -1,0 +1,105 @@
+"""Item 1 of VERDICT r1: LM traces of the HIP path and the CPU oracle side by side on SURVEY's C4 seeds (100-107).
+
+Two steps:
+  --write-fixture   (CPU, minutes) runs the oracle on every seed twice -- with the application's stopping rules
+                    (Mapping.cpp:32-43) and "tight" (epsilon_rel = epsilon_abs = 0, epsilon2 = 1e-9: LM runs until it
+                    stalls) -- and stores traces, final chi2 and the tight final state in tests/golden/c4_oracle.npz.
+  default           (GPU) runs the HIP path the same two ways and reports, per seed: the first trial whose accept/reject
+                    verdict, lambda or chi2 (rel > 1e-9) differs from the oracle's, the final chi2 of both under the
+                    default rules, and chi2 / state distance at the tight optimum.  JSON lines on stdout.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FIXTURE = os.path.join(ROOT, "tests", "golden", "c4_oracle.npz")
+SEEDS = list(range(100, 108))
+TIGHT = dict(epsilon_rel=0.0, epsilon_abs=0.0, epsilon2=1e-9, max_iterations=3000)
+
+
+def first_divergence(tr, tro, rel=1e-9):
+    for k, ((lam, chi, acc), (lo, cho, aco)) in enumerate(zip(tr, tro)):
+        if acc != aco or lam != lo or abs(chi - cho) > rel * abs(cho):
+            return {"trial": k, "gpu": [lam, chi, int(acc)], "oracle": [lo, cho, int(aco)],
+                    "rel": abs(chi - cho) / abs(cho) if cho else None}
+    return None if len(tr) == len(tro) else {"trial": min(len(tr), len(tro)), "length": [len(tr), len(tro)]}
+
+
+def final_state(g, spec, nid):
+    poses = np.array([g.get_pose(int(a)) for a, t in zip(nid, spec.node_type) if t == 0])
+    planes = np.array([g.get_plane(int(a)) for a, t in zip(nid, spec.node_type) if t != 0])
+    return poses, planes
+
+
+def write_fixture(seeds):
+    from pop_up_slam_amd import synth
+    from oracle import oracle_py as O
+    out = {}
+    for seed in seeds:
+        spec = synth.corridor(seed=seed)
+        o = O.OracleGraph(); nid, _ = spec.replay(o)
+        c0 = o.chi2()
+        it = o.batch_optimize()
+        out[f"s{seed}_chi2_0"] = np.float64(c0)
+        out[f"s{seed}_trace"] = np.array(o.trace(), dtype=np.float64)           # trials x (lambda, chi2, accepted)
+        out[f"s{seed}_chi2"] = np.float64(o.chi2())
+        o2 = O.OracleGraph(**TIGHT); nid2, _ = spec.replay(o2)
+        it2 = o2.batch_optimize()
+        out[f"s{seed}_tight_trace"] = np.array(o2.trace(), dtype=np.float64)
+        out[f"s{seed}_tight_chi2"] = np.float64(o2.chi2())
+        poses, planes = final_state(o2, spec, nid2)
+        out[f"s{seed}_tight_poses"] = poses
+        out[f"s{seed}_tight_planes"] = planes
+        print(f"seed {seed}: chi2_0 {c0:.6g}; default {it} trials -> {float(out[f's{seed}_chi2']):.12g}; "
+              f"tight {it2} trials -> {float(out[f's{seed}_tight_chi2']):.12g}", flush=True)
+    np.savez_compressed(FIXTURE, seeds=np.array(seeds), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, nargs="*", default=SEEDS)
+    ap.add_argument("--write-fixture", action="store_true")
+    args = ap.parse_args()
+    if args.write_fixture:
+        return write_fixture(args.seeds)
+    import pop_up_slam_amd as P
+    from pop_up_slam_amd import synth
+    fx = np.load(FIXTURE)
+    for seed in args.seeds:
+        spec = synth.corridor(seed=seed)
+        tro = [tuple(r) for r in fx[f"s{seed}_trace"]]
+        co, co2 = float(fx[f"s{seed}_chi2"]), float(fx[f"s{seed}_tight_chi2"])
+        rec = {"seed": seed, "chi2_0": float(fx[f"s{seed}_chi2_0"]),
+               "oracle": {"trials": len(tro), "chi2": co}, "oracle_tight": {"trials": len(fx[f"s{seed}_tight_trace"]), "chi2": co2}}
+        g = P.Graph(); spec.replay(g)
+        it = g.batch_optimize(); tr = g.trace(); c = g.chi2()
+        rec["gpu"] = {"trials": it, "chi2": c}
+        rec["rel_default"] = abs(c - co) / abs(co)
+        d = first_divergence(tr, tro)
+        rec["first_divergence"] = d
+        k = d["trial"] if d else min(len(tr), len(tro))
+        rec["max_rel_before_divergence"] = max([abs(a[1] - b[1]) / abs(b[1]) for a, b in list(zip(tr, tro))[:k]] or [0.0])
+        if d:
+            lo_, hi_ = max(0, k - 2), k + 3
+            rec["window"] = {"gpu": [list(map(float, t)) for t in tr[lo_:hi_]], "oracle": [list(map(float, t)) for t in tro[lo_:hi_]]}
+        g2 = P.Graph(**TIGHT); nid2, _ = spec.replay(g2)
+        it2 = g2.batch_optimize(); c2 = g2.chi2()
+        rec["gpu_tight"] = {"trials": it2, "chi2": c2}
+        rec["rel_tight"] = abs(c2 - co2) / abs(co2)
+        tr2 = g2.trace(); tro2 = [tuple(r) for r in fx[f"s{seed}_tight_trace"]]
+        rec["first_divergence_tight"] = first_divergence(tr2, tro2)
+        poses, planes = final_state(g2, spec, nid2)
+        rec["state_maxabs_tight"] = {"poses": float(np.max(np.abs(poses - fx[f"s{seed}_tight_poses"]))),
+                                     "planes": float(np.max(np.abs(planes - fx[f"s{seed}_tight_planes"])))}
+        g.close(); g2.close()
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
