@@ -202,8 +202,13 @@ int pps_popup_set_image(pps_popup* p, const unsigned char* bgr);
  *   seg2d    n x 4 ground segments; plane i >= 1 comes from segment i-1, plane 0 = ground
  *   polys    closed 2-D polygons (x,y) of the planes to pop up (all_closed_2d_bound_polygons,
  *            popup_plane.h:70-76), poly_off[nplanes+1] vertex offsets; an empty polygon skips the plane.
- *            A pixel belongs to the LAST convex polygon that contains it (edges inclusive).
- *   step     1 = every pixel, 2 = every second pixel in x and y (downsample_poly, popup_plane.cpp:86-108)
+ *            The pixels of a polygon are the ones popup_plane::closed_polygons_homo_pts yields (popup_plane.cpp:81-116):
+ *            vertices truncated to integers like cv::Point(float, float), shifted into their bounding box, rasterised
+ *            with cv::fillConvexPoly's rules (8-connected Bresenham outline + 16.16 fixed-point scanline spans) --
+ *            bit for bit, for any vertex list (|coordinate| < 2^15), convex or not.  Planes are written in order, so
+ *            a pixel keeps the LAST polygon that covers it (generate_cloud / get_depth_map_good, :820-850, :893-911).
+ *   step     1 = every pixel; 2 = downsample_poly (:86-87,104-108): the polygon is halved BEFORE the truncation,
+ *            rasterised at half size and the pixel coordinates doubled -- even pixels only
  * Filters (matrixToCloud :948-960): z_s < 0, z_s > depth_thre, z_w < -0.2 dropped; z_w clamped to
  * ceiling_thre.  Depth: z_s, with the ceiling plane substituted above ceiling_thre (:903-916). */
 int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys,
@@ -233,6 +238,10 @@ int pps_popup_fill_depth(pps_popup* p);
 int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world);
 /* device time of the last pps_popup_run kernel (HIP events), seconds */
 int pps_popup_last_kernel_time(const pps_popup* p, double* sec);
+/* The polygon -> pixel-set rules of pps_popup_run (closed_polygons_homo_pts / cv::fillConvexPoly, popup_plane.cpp:81-116)
+ * evaluated on the host by the same interval code the kernel runs (no device needed; used by the CPU tests):
+ * plane_id width*height, -1 = none. */
+int pps_popup_mask_host(const float* polys, const int* poly_off, int nplanes, int width, int height, int step, int32_t* plane_id);
 
 /* ---- pop-up feeding the graph: Mapper_mono::update_plane_measurement (Mapping.cpp:590-607) ------
  * Frames register their 2-D ground segments once; pps_refresh_measurements then re-derives every

@@ -103,7 +103,7 @@ SYMBOLS = [
     "pps_time_linearize", "pps_reproject_points", "pps_popup_set_outputs",
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
-    "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info",
+    "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
 ]
 
 
@@ -166,6 +166,7 @@ def lib():
         L.pps_popup_run.argtypes = [C.c_void_p, _fp, C.c_int, _fp, _fp, _ip, C.c_int, C.c_int, C.c_float, C.c_float, _ip]
         L.pps_popup_download.argtypes = [C.c_void_p, _fp, C.c_void_p, _fp, C.POINTER(C.c_int32)]
         L.pps_popup_last_kernel_time.argtypes = [C.c_void_p, _dp]
+        L.pps_popup_mask_host.argtypes = [_fp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.pps_popup_fill_depth.argtypes = [C.c_void_p]
         L.pps_popup_plane_info.argtypes = [C.c_void_p, C.c_float, _ip, C.c_int, _fp, _ip]
         L.pps_frames_set_calibration.argtypes = [C.c_void_p, _fp]
@@ -589,6 +590,28 @@ class Popup:
 
     def last_kernel_time(self):
         s = C.c_double(); self._ck(self.L.pps_popup_last_kernel_time(self.h, C.byref(s))); return s.value
+
+
+def _flatten_polys(polys):
+    off = np.zeros(len(polys) + 1, dtype=np.int32)
+    for i, p in enumerate(polys):
+        off[i + 1] = off[i] + len(p)
+    flat = np.zeros((max(1, off[-1]), 2), dtype=np.float32)
+    for i, p in enumerate(polys):
+        if len(p):
+            flat[off[i]:off[i + 1]] = np.asarray(p, dtype=np.float32).reshape(-1, 2)
+    return flat, off
+
+
+def popup_mask_host(polys, width, height, step=1):
+    """pps_popup_mask_host: the kernel's polygon -> pixel-set interval code run on the host (no device needed)"""
+    flat, off = _flatten_polys(polys)
+    pid = np.zeros((height, width), dtype=np.int32)
+    rc = lib().pps_popup_mask_host(flat.ctypes.data_as(_fp), off.ctypes.data_as(_ip), len(polys), width, height, step,
+                                   pid.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise PpsError(rc, "pps_popup_mask_host")
+    return pid
 
 
 def edge_params(**kw):

@@ -22,6 +22,7 @@
 
 #include "../../include/pps.h"
 #include "pps_popup_dev.h"
+#include "pps_raster.h"
 
 namespace pps {
 
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(64) void k_popup_planes(const float* __restrict__ s
 }
 
 // Fused K5 + K6.  grid = (ceil(W / 256), ceil(H / PX)): a thread owns one column of PX consecutive rows.
+// Pixel sets: cv::fillConvexPoly semantics of closed_polygons_homo_pts (pps_raster.h); every workgroup derives the
+// column intervals of its PX rows for every polygon into LDS, a pixel then compares its column with those intervals.
 template <int PX>
 __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const float* __restrict__ seg2d, int n,
                                                      const float* __restrict__ polys, const int* __restrict__ poly_off,
@@ -107,10 +110,14 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
                                                      unsigned int* __restrict__ n_valid) {
   __shared__ float s_planes[kMaxPlanes + 1][4];
   __shared__ float s_poly[2 * kMaxVerts];
+  __shared__ int2 s_q[kMaxVerts];                 // vertices as the integer points fillConvexPoly sees (box coordinates)
+  __shared__ RasterLine s_line[kMaxVerts];        // outline edge ending at vertex v
   __shared__ int s_off[kMaxPlanes + 2];
+  __shared__ int4 s_box[kMaxPlanes];              // boundingRect of the truncated polygon: x, y, width, height
+  __shared__ unsigned int s_iv[(kMaxVerts + kMaxPlanes) * PX];   // per (polygon, row): lo | hi << 16, scaled image columns
+  __shared__ int s_ivcnt[kMaxPlanes * PX];
   __shared__ float s_ceil[4];
   __shared__ unsigned int s_cnt;
-  __shared__ float s_bbox[kMaxPlanes + 1][4];
   const int tid = threadIdx.x;
   // ---- K5: plane equations of this frame (every workgroup; block 0 publishes them) ----
   if (tid <= n && tid <= kMaxPlanes) {
@@ -137,62 +144,120 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
   for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
   __syncthreads();
   const int nverts = s_off[nplanes];
-  for (int i = tid; i < 2 * nverts; i += 256) s_poly[i] = polys[i];
+  const int S = prm.step;                                       // 2 = downsample_poly
+  for (int i = tid; i < 2 * nverts; i += 256) s_poly[i] = S == 2 ? polys[i] / 2 : polys[i];   // new_polys_close / 2 (:86-87)
   __syncthreads();
-
-  // bounding boxes (one pixel of slack: the inclusive cross-product test below decides, the box only skips
-  // polygons that are nowhere near the pixel)
+  // boundingRect of the truncated points (matrix_to_points + boundingRect, popup_plane.cpp:89-91)
   if (tid < nplanes) {
     const int v0 = s_off[tid], v1 = s_off[tid + 1];
-    float x0 = 3.0e38f, y0 = 3.0e38f, x1 = -3.0e38f, y1 = -3.0e38f;
+    int x0 = 0, y0b = 0, x1 = -1, y1 = -1;
     for (int v = v0; v < v1; v++) {
-      x0 = fminf(x0, s_poly[2 * v]); x1 = fmaxf(x1, s_poly[2 * v]);
-      y0 = fminf(y0, s_poly[2 * v + 1]); y1 = fmaxf(y1, s_poly[2 * v + 1]);
+      const int x = (int)s_poly[2 * v], y = (int)s_poly[2 * v + 1];
+      if (v == v0) { x0 = x1 = x; y0b = y1 = y; }
+      x0 = min(x0, x); x1 = max(x1, x); y0b = min(y0b, y); y1 = max(y1, y);
     }
-    s_bbox[tid][0] = x0 - 1.f; s_bbox[tid][1] = y0 - 1.f; s_bbox[tid][2] = x1 + 1.f; s_bbox[tid][3] = y1 + 1.f;
+    s_box[tid] = make_int4(x0, y0b, x1 - x0 + 1, y1 - y0b + 1);
+  }
+  __syncthreads();
+  // polygon - box origin in fp32, truncated again (:92-96)
+  for (int v = tid; v < nverts; v += 256) {
+    int p = 0;
+    while (s_off[p + 1] <= v) p++;
+    const int4 bx = s_box[p];
+    s_q[v] = make_int2((int)(s_poly[2 * v] - (float)bx.x), (int)(s_poly[2 * v + 1] - (float)bx.y));
+  }
+  __syncthreads();
+  // outline: the edge that ends at vertex v starts at the previous vertex (the last one for the first)
+  for (int v = tid; v < nverts; v += 256) {
+    int p = 0;
+    while (s_off[p + 1] <= v) p++;
+    const int4 bx = s_box[p];
+    const int u = v > s_off[p] ? v - 1 : s_off[p + 1] - 1;
+    s_line[v] = raster_line(bx.z, bx.w, s_q[u].x, s_q[u].y, s_q[v].x, s_q[v].y);
+  }
+  __syncthreads();
+  const int W = prm.width, H = prm.height;
+  const int Ws = (W + S - 1) / S;                               // columns a scaled coordinate may take inside the frame
+  const int y0 = blockIdx.y * PX;
+  // one interval per (polygon, row, [fill span | outline edge]); slot 0 of a (polygon, row) list is the fill span
+  const int n_items = (nverts + nplanes) * PX;
+  for (int it = tid; it < n_items; it += 256) {
+    int p = 0;
+    while ((s_off[p + 1] + p + 1) * PX <= it) p++;
+    const int v0 = s_off[p], npts = s_off[p + 1] - v0;
+    const int loc = it - (v0 + p) * PX;
+    const int k = loc / (npts + 1), i = loc - k * (npts + 1);
+    const int4 bx = s_box[p];
+    const int Y = y0 + k;
+    unsigned int out = 1u;                                       // lo = 1 > hi = 0: empty
+    if (npts > 0 && Y < H && Y % S == 0) {
+      const int cy = Y / S - bx.y;
+      if (cy >= 0 && cy < bx.w) {
+        int lo = 0, hi = -1;
+        const bool hit = i == 0 ? raster_fill_row(s_q + v0, npts, bx.z, bx.w, cy, lo, hi) : raster_line_row(s_line[v0 + i - 1], cy, lo, hi);
+        if (hit) {
+          lo = max(lo, 0) + bx.x; hi = min(hi, bx.z - 1) + bx.x;   // inside the box image, then frame columns (:104-113)
+          lo = max(lo, 0); hi = min(hi, Ws - 1);
+          if (lo <= hi) out = (unsigned int)lo | ((unsigned int)hi << 16);
+        }
+      }
+    }
+    s_iv[it] = out;
+  }
+  __syncthreads();
+  // merge the intervals of a (polygon, row) into disjoint runs (usually one); long lists stay as they are
+  for (int it = tid; it < nplanes * PX; it += 256) {
+    const int p = it / PX, k = it - p * PX;
+    const int npts = s_off[p + 1] - s_off[p];
+    unsigned int* iv = s_iv + (s_off[p] + p) * PX + k * (npts + 1);
+    int cnt = npts > 0 ? npts + 1 : 0;
+    if (cnt <= 17) {
+      for (int a = 1; a < cnt; a++) {                              // empty intervals (lo = 1, hi = 0) sort anywhere: they merge away
+        const unsigned int key = iv[a];
+        int b = a - 1;
+        while (b >= 0 && (iv[b] & 0xffffu) > (key & 0xffffu)) { iv[b + 1] = iv[b]; b--; }
+        iv[b + 1] = key;
+      }
+      int m = 0;
+      for (int a = 0; a < cnt; a++) {
+        const unsigned int lo = iv[a] & 0xffffu, hi = iv[a] >> 16;
+        if (lo > hi) continue;
+        if (m > 0 && lo <= (iv[m - 1] >> 16) + 1u) { if (hi > (iv[m - 1] >> 16)) iv[m - 1] = (iv[m - 1] & 0xffffu) | (hi << 16); }
+        else iv[m++] = iv[a];
+      }
+      cnt = m;
+    }
+    s_ivcnt[it] = cnt;
   }
   __syncthreads();
 
-  const int W = prm.width, H = prm.height;
   unsigned int kept = 0;
-  // Column strip: the thread owns one x and kPxRows consecutive rows (blockIdx.y), so everything of the polygon test
-  // that depends on x only -- the box test, (bx-ax), (by-ay), (by-ay)*(fx-ax) -- and the polygon vertices (LDS
-  // broadcasts) are computed / fetched once per edge for all rows.  The per-pixel expressions are the reference's,
-  // operation for operation (hoisting does not change any rounding).
+  // Column strip: the thread owns one x and PX consecutive rows (blockIdx.y); the rows are the same for all lanes, so the
+  // interval reads are LDS broadcasts.
   const int x = blockIdx.x * 256 + tid;
-  const int y0 = blockIdx.y * PX;
   const bool xin = x < W;
   const float fx = (float)x;
-  const bool xsel = prm.step == 1 || (x & 1) == 0;
+  const bool xsel = x % S == 0;
+  const unsigned int xs = (unsigned int)(x / S);
   int pid[PX];
 #pragma unroll
   for (int k = 0; k < PX; k++) pid[k] = -1;
   if (xin && xsel) {
-    for (int p = nplanes - 1; p >= 0; p--) {                 // LAST polygon containing the pixel wins: scan backwards
-      const int v0 = s_off[p], v1 = s_off[p + 1];
-      if (v1 - v0 < 3) continue;
-      if (fx < s_bbox[p][0] || fx > s_bbox[p][2]) continue;
-      unsigned int pos = 0xffffffffu, neg = 0xffffffffu;      // bit k: row k still on the non-negative / non-positive side
-      for (int v = v0; v < v1; v++) {
-        const int w = (v + 1 < v1) ? v + 1 : v0;
-        const float ax = s_poly[2 * v], ay = s_poly[2 * v + 1];
-        const float bx = s_poly[2 * w], by = s_poly[2 * w + 1];
-        const float A = bx - ax, B = by - ay;
-        const float t2 = B * (fx - ax);
-#pragma unroll
-        for (int k = 0; k < PX; k++) {
-          const float fy = (float)(y0 + k);
-          const float cr = A * (fy - ay) - t2;
-          if (!(cr >= 0.f)) pos &= ~(1u << k);
-          if (!(cr <= 0.f)) neg &= ~(1u << k);
-        }
-      }
-      const unsigned int in = pos | neg;
+    for (int p = nplanes - 1; p >= 0; p--) {                 // a later plane overwrites an earlier one: scan backwards
+      const int4 bx = s_box[p];
+      if ((int)xs < bx.x || (int)xs >= bx.x + bx.z) continue;
+      const int npts = s_off[p + 1] - s_off[p];
+      const unsigned int* iv = s_iv + (s_off[p] + p) * PX;
       bool all_set = true;
 #pragma unroll
       for (int k = 0; k < PX; k++) {
-        const float fy = (float)(y0 + k);
-        if (pid[k] < 0 && ((in >> k) & 1u) && !(fy < s_bbox[p][1] || fy > s_bbox[p][3])) pid[k] = p;
+        if (pid[k] < 0) {
+          const int cnt = s_ivcnt[p * PX + k];
+          const unsigned int* r = iv + k * (npts + 1);
+          bool in = false;
+          for (int a = 0; a < cnt; a++) { const unsigned int v = r[a]; in = in || (xs >= (v & 0xffffu) && xs <= (v >> 16)); }
+          if (in) pid[k] = p;
+        }
         all_set = all_set && pid[k] >= 0;
       }
       if (all_set) break;
@@ -205,7 +270,7 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
     if (xin && y < H) {
       const int idx = y * W + x;
       const float fy = (float)y;
-      const int pd = (prm.step == 1 || (y & 1) == 0) ? pid[k] : -1;
+      const int pd = pid[k];        // rows that are not a multiple of the step hold no intervals
       pps_point pt;
       pt.x = pt.y = pt.z = 0.f;
       pt.rgba = 0u;
@@ -355,7 +420,7 @@ int pps_popup_planes(int device, const float* seg2d, int n, const float invK[9],
 }
 
 int pps_popup_create(int device, int width, int height, const float invK[9], pps_popup** out) {
-  if (!out || !invK || width <= 0 || height <= 0) return PPS_EINVAL;
+  if (!out || !invK || width <= 0 || height <= 0 || width > 32768 || height > 32768) return PPS_EINVAL;
   pps_popup* p = new (std::nothrow) pps_popup();
   if (!p) return PPS_ENOMEM;
   p->device = device; p->width = width; p->height = height;
@@ -535,6 +600,43 @@ int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world) {
   PHIP(p, hipSetDevice(p->device));
   if (p->last_n > 0)
     PHIP(p, hipMemcpy(seg3d_world, p->d_planes + 4 * (kMaxPlanes + 1), sizeof(float) * 6 * (size_t)p->last_n, hipMemcpyDeviceToHost));
+  return PPS_OK;
+}
+
+// The interval derivation of k_popup_frame (pps_raster.h), compiled for the host and run row by row: what the kernel's
+// setup phase computes, without a device.  Test hook only -- pps_popup_run never comes here.
+int pps_popup_mask_host(const float* polys, const int* poly_off, int nplanes, int width, int height, int step, int32_t* plane_id) {
+  if (!poly_off || !plane_id || nplanes < 0 || width <= 0 || height <= 0 || (step != 1 && step != 2)) return PPS_EINVAL;
+  if (poly_off[nplanes] > 0 && !polys) return PPS_EINVAL;
+  for (size_t i = 0; i < (size_t)width * height; i++) plane_id[i] = -1;
+  const int Ws = (width + step - 1) / step;
+  for (int p = 0; p < nplanes; p++) {
+    const int v0 = poly_off[p], npts = poly_off[p + 1] - v0;
+    if (npts < 1) continue;
+    std::vector<float> P(2 * (size_t)npts);
+    for (int i = 0; i < 2 * npts; i++) P[i] = step == 2 ? polys[2 * (size_t)v0 + i] / 2 : polys[2 * (size_t)v0 + i];
+    int x0 = (int)P[0], x1 = x0, y0 = (int)P[1], y1 = y0;
+    for (int i = 0; i < npts; i++) {
+      const int x = (int)P[2 * i], y = (int)P[2 * i + 1];
+      x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y);
+    }
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    std::vector<int2> q(npts);
+    for (int i = 0; i < npts; i++) q[i] = make_int2((int)(P[2 * i] - (float)x0), (int)(P[2 * i + 1] - (float)y0));
+    std::vector<RasterLine> lines(npts);
+    for (int i = 0; i < npts; i++) { const int u = i > 0 ? i - 1 : npts - 1; lines[i] = raster_line(bw, bh, q[u].x, q[u].y, q[i].x, q[i].y); }
+    for (int Y = 0; Y < height; Y += step) {
+      const int cy = Y / step - y0;
+      if (cy < 0 || cy >= bh) continue;
+      for (int i = 0; i <= npts; i++) {
+        int lo = 0, hi = -1;
+        const bool hit = i == 0 ? raster_fill_row(q.data(), npts, bw, bh, cy, lo, hi) : raster_line_row(lines[i - 1], cy, lo, hi);
+        if (!hit) continue;
+        lo = std::max(std::max(lo, 0) + x0, 0); hi = std::min(std::min(hi, bw - 1) + x0, Ws - 1);
+        for (int xs = lo; xs <= hi; xs++) plane_id[(size_t)Y * width + (size_t)xs * step] = p;
+      }
+    }
+  }
   return PPS_OK;
 }
 
