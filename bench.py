@@ -34,36 +34,67 @@ B_ODO_EDGE = 840     # 216 B read + 624 B written per odometry edge
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(spec, budget_s=12.0, optimised=False):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(spec, budget_s=12.0, optimised=False, threads=1, min_runs=5, max_runs=9):
     """Reference-faithful CPU path (numeric Jacobians, re-ordering every factorisation, 1 thread); `optimised`: the same
-    solver with closed-form Jacobians and the ordering computed once (what a tuned CPU build of the reference could do)."""
+    solver with closed-form Jacobians and the ordering computed once (what a tuned CPU build of the reference could do);
+    `threads` > 1: its Jacobian sweep on that many OpenMP threads (the sparse Cholesky stays sequential, as CHOLMOD's
+    simplicial code is).  SURVEY 8(d): the process is pinned (one core for the 1-thread variants), the value is the MEDIAN
+    over >= 5 full solves."""
     from oracle import oracle_py as O
-    iters, secs, runs, chi2 = 0, 0.0, 0, None
+    saved = None
+    try:
+        saved = os.sched_getaffinity(0)
+        cores = sorted(saved)
+        os.sched_setaffinity(0, set(cores[-threads:]) if threads > 1 else {cores[-1]})
+    except (AttributeError, OSError):
+        saved = None
+    rates, iters, secs, chi2 = [], 0, 0.0, None
     phases = np.zeros(4)
-    while secs < budget_s and runs < 8:
-        o = O.OracleGraph(analytic=1, cache_ordering=1) if optimised else O.OracleGraph()
-        spec.replay(o)
-        t0 = time.perf_counter()
-        it = o.batch_optimize()
-        secs += time.perf_counter() - t0
-        iters += it
-        runs += 1
-        chi2 = o.chi2()
-        phases += o.timers()
+    try:
+        while len(rates) < min_runs or (secs < budget_s and len(rates) < max_runs):
+            kw = dict(analytic=1, cache_ordering=1, threads=threads) if optimised else {}
+            o = O.OracleGraph(**kw)
+            spec.replay(o)
+            t0 = time.perf_counter()
+            it = o.batch_optimize()
+            dt = time.perf_counter() - t0
+            rates.append(it / dt)
+            secs += dt
+            iters += it
+            chi2 = o.chi2()
+            phases += o.timers()
+    finally:
+        if saved is not None:
+            os.sched_setaffinity(0, saved)
+    runs = len(rates)
     return {
-        "value": iters / secs, "unit": "LM iters/s", "cores": 1, "kind": "port",
-        "sample": f"{runs} full LM solves of the same C2 graph ({iters} iterations, {secs:.1f} s), oracle/pps_oracle.c -O3, "
-                  + ("closed-form Jacobians + ordering computed once" if optimised else
-                     "numeric Jacobians + per-call re-ordering as the reference"),
-        "final_chi2": chi2, "host_cores_total": os.cpu_count(),
+        "value": float(np.median(rates)), "unit": "LM iters/s", "cores": threads, "kind": "port",
+        "sample": f"median of {runs} full LM solves of the same C2 graph ({iters} iterations, {secs:.1f} s), oracle/pps_oracle.c -O3, "
+                  + ("closed-form Jacobians + ordering computed once" + (f", Jacobian sweep on {threads} OpenMP threads" if threads > 1 else "")
+                     if optimised else "numeric Jacobians + per-call re-ordering as the reference")
+                  + (", process pinned" if saved is not None else ", pinning unavailable"),
+        "min": float(np.min(rates)), "max": float(np.max(rates)), "runs": runs,
+        "final_chi2": chi2, "host_cores_total": os.cpu_count(), "host_cpu": cpu_model(),
         "phase_split_s": {"linearise": phases[0] / runs, "factor_solve": phases[1] / runs,
                           "retract_chi2": phases[2] / runs, "ordering": phases[3] / runs},
     }
 
 
-# C4: independently seeded C2-size graphs.  Seed 42 is BASELINE config 2; the others are the first generator seeds
-# whose LM run is as well conditioned as seed 42's (55-79 trials to chi2 = 0.023; most seeds -- 101, 103, 105-109 ...
-# -- start from a worse dead-reckoned guess and zig-zag for 200-500 trials, which makes a poor unit of work).
+# C4 TIMING set: independently seeded C2-size graphs.  Seed 42 is BASELINE config 2; the others are the first generator
+# seeds whose LM run is as short as seed 42's (55-79 trials to chi2 = 0.023) -- a balanced unit of work for a scaling
+# curve.  PARITY on C4 is judged on SURVEY's seeds 100-107 (tests/test_gpu_solve.py::test_c4_survey_seeds_against_the_oracle),
+# most of which zig-zag for 100-500 trials and half of which are chaotic even between two CPU builds of the oracle.
 C4_SEEDS = [42, 135, 110, 143, 225, 154, 169, 185]
 
 
@@ -145,9 +176,9 @@ def main():
     from pop_up_slam_amd import synth
 
     mode = P.JAC_NUMERIC if args.mode == "numeric" else P.JAC_ANALYTIC
-    # N = 1: the C2 graph (seed 42).  N > 1: every rank holds the eight C4 graphs and solves graph (step + rank) mod 8 --
-    # at any moment the GPUs work on different, independently seeded graphs, and over 8 steps every rank has done the
-    # same work (a fixed graph per rank would time the slowest seed: 55 vs 79 LM trials per solve).
+    # N = 1: the C2 graph (seed 42).  N > 1: every rank holds the eight C4 timing graphs and a step solves all of them
+    # once, rank r starting at graph r -- at any moment the GPUs work on different, independently seeded graphs, and every
+    # rank does the same work per step (a fixed graph per rank would time the slowest seed: 55 vs 79 LM trials per solve).
     seeds = [rank_seed(0)] if world == 1 else [rank_seed((k + rank) % len(C4_SEEDS)) for k in range(len(C4_SEEDS))]
     graphs = []
     for sd in seeds:
@@ -167,20 +198,27 @@ def main():
 
     for gk in graphs[1:]:                    # every handle analysed / uploaded / run once before the clock starts
         gk.restore_state(); gk.batch_optimize()
+
+    def step():
+        """N = 1: one LM solve of the C2 graph.  N > 1: this rank's eight C4 graphs solved once each, starting with graph
+        `rank` -- every rank does exactly the same work in every step, whatever K is."""
+        n = 0
+        for gk in graphs:
+            gk.restore_state()
+            n += gk.batch_optimize()
+        return n
+
     for i in range(args.warmup):
-        gk = graphs[i % len(graphs)]
-        gk.restore_state()
-        gk.batch_optimize()
+        step()
     barrier()
     t0 = time.perf_counter()
     iters = 0
     k1_time, k1_launches = 0.0, 0
     for i in range(args.steps):
-        gk = graphs[i % len(graphs)]
-        gk.restore_state()
-        iters += gk.batch_optimize()
+        iters += step()
     barrier()
     elapsed = time.perf_counter() - t0
+    solves = args.steps * len(graphs)
     # outside the timed region: one more solve of this rank's first graph with an event pair around every K1 launch
     g.restore_state(); g.set_profiling(1); g.batch_optimize(); g.set_profiling(0)
     chi2 = g.chi2()
@@ -244,10 +282,11 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2 synthetic corridor: 1000 SE3 poses, 200 planes, 5000 plane edges, 999 odometry edges "
                                    "(BASELINE.json configs[1], seed 42)" + ("" if world == 1 else
-                                   "; N > 1 = config 4: eight independently seeded C2 graphs (seeds %s), rank r solves graph "
-                                   "(step + r) mod 8, no collective" % C4_SEEDS),
-                       "jacobian_mode": args.mode, "lm_iterations_per_solve": iters / args.steps,
-                       "graphs_per_sec": world * args.steps / elapsed},
+                                   "; N > 1 = config 4: eight independently seeded C2 graphs per rank (timing seeds %s: the "
+                                   "short, balanced LM runs; parity on SURVEY's seeds 100-107 is a test, not a bench line), one "
+                                   "step = all eight solved once, rank r starting at graph r, no collective" % C4_SEEDS),
+                       "jacobian_mode": args.mode, "lm_solves_per_step": len(graphs), "lm_iterations_per_solve": iters / solves,
+                       "graphs_per_sec": world * solves / elapsed},
             "final_chi2": chi2, "chi2_initial": st["chi2_initial"],
             "fronts": st["n_fronts"], "levels": st["n_levels"], "max_front": st["max_front"],
             "roofline": roofline, "roofline_batched": roofline_batched,
@@ -322,6 +361,10 @@ def main():
             cbo = cpu_baseline(spec, budget_s=4.0, optimised=True)      # the claim is shown against both
             out["cpu_baseline_optimised"] = cbo
             out["speedup_vs_cpu_baseline_optimised"] = out["value"] / cbo["value"]
+            nth = max(2, min(8, (os.cpu_count() or 2) // 2))
+            cbm = cpu_baseline(spec, budget_s=4.0, optimised=True, threads=nth)
+            out["cpu_baseline_optimised_mt"] = cbm
+            out["speedup_vs_cpu_baseline_optimised_mt"] = out["value"] / cbm["value"]
             out["chi2_rel_err_vs_cpu"] = abs(chi2 - cb["final_chi2"]) / abs(cb["final_chi2"])
             if "other_mode" in out:
                 out["other_mode"]["chi2_rel_err_vs_cpu"] = abs(out["other_mode"]["final_chi2"] - cb["final_chi2"]) / abs(cb["final_chi2"])

@@ -151,6 +151,8 @@ typedef struct pps_stats {
   /* device time (HIP events) of the last solve call, seconds, summed over launches */
   double t_linearize, t_assemble, t_factor, t_backsolve, t_retract_chi2;
   int    n_linearize, n_factorize;         /* launches of the sweep / factorizations        */
+  int    lm_trials_notpd;                  /* LM trials whose factorisation hit a non-positive pivot (the step is then
+                                              rejected like any other bad step; PPS_ENOTPD only if the last trial did) */
 } pps_stats;
 int pps_get_stats(const pps_graph* g, pps_stats* out);
 /* LM trace of the last batch_optimize: per trial (lambda, chi2_new, accepted); returns count via n */

@@ -19,7 +19,7 @@ class OraProps(C.Structure):
     _fields_ = [
         ("epsilon2", C.c_double), ("epsilon_abs", C.c_double), ("epsilon_rel", C.c_double),
         ("max_iterations", C.c_int), ("lm_lambda0", C.c_double), ("lm_lambda_factor", C.c_double),
-        ("analytic", C.c_int), ("cache_ordering", C.c_int),
+        ("analytic", C.c_int), ("cache_ordering", C.c_int), ("threads", C.c_int),
     ]
 
 

@@ -327,6 +327,7 @@ void ora_default_props(ora_props* p) {
   p->lm_lambda_factor = 10.;
   p->analytic = 0;
   p->cache_ordering = 0;
+  p->threads = 1;
 }
 
 ora_graph* ora_create(const ora_props* p) {
@@ -851,14 +852,32 @@ static void build_jacobian(ora_graph* g) {
     g->Jp = (int*)realloc(g->Jp, sizeof(int) * (size_t)(rows + 1));
     g->Jrhs = (double*)realloc(g->Jrhs, sizeof(double) * (size_t)(rows + 1));
   }
-  int row = 0;
+  /* row / entry offset of every factor first, so that the factors can be linearised independently */
+  int* frow = (int*)malloc(sizeof(int) * (size_t)(g->nfactors + 1));
+  long* fnz = (long*)malloc(sizeof(long) * (size_t)(g->nfactors + 1));
+  int row = 0, any_numeric = !g->prop.analytic;
   long nz = 0;
   g->Jp[0] = 0;
+  for (int i = 0; i < g->nfactors; i++) {
+    factor_t* f = &g->factors[i];
+    frow[i] = row; fnz[i] = nz;
+    if (f->deleted) continue;
+    if (f->repop) any_numeric = 1;
+    row += f->dim; nz += (long)f->dim * factor_cols(g, f);
+  }
+  /* numericalDiff perturbs the nodes in place (like the reference): only the closed-form sweep may run in parallel */
+  const int nthreads = (g->prop.threads > 1 && !any_numeric) ? g->prop.threads : 1;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1)
+#endif
   for (int i = 0; i < g->nfactors; i++) {
     factor_t* f = &g->factors[i];
     if (f->deleted) continue;
     double H[6 * 12], r[6];
     int ncols = factor_cols(g, f);
+    int row = frow[i];
+    long nz = fnz[i];
     factor_jacobian(g, f, g->prop.analytic, H, r);
     /* terms are appended in node order of the factor; SparseVector keeps indices sorted */
     int order[2] = {0, 1};
@@ -878,8 +897,8 @@ static void build_jacobian(ora_graph* g) {
       g->Jrhs[row + rr] = -r[rr];
       g->Jp[row + rr + 1] = (int)nz;
     }
-    row += f->dim;
   }
+  free(frow); free(fnz);
   g->J_rows = rows;
   g->J_cols = g->dim_nodes;
 }

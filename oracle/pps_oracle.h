@@ -43,6 +43,7 @@ typedef struct ora_props {
   double lm_lambda_factor;/* 10                                    */
   int    analytic;        /* 0 = reference-faithful central differences (numericalDiff.cpp) */
   int    cache_ordering;  /* 0 = re-order every factorisation like Cholesky.cpp:98 */
+  int    threads;         /* > 1: the closed-form Jacobian sweep (analytic = 1) runs on that many OpenMP threads; the reference has one */
 } ora_props;
 
 void ora_default_props(ora_props* p);

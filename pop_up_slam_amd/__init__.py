@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpps.so")
+# PPS_LIB selects another build of the same library (e.g. the diagnostic libpps_nofma.so of `make nofma`)
+LIB_PATH = os.environ.get("PPS_LIB") or os.path.join(_HERE, "libpps.so")
 
 PPS_OK, PPS_EINVAL, PPS_ENOTPD, PPS_EHIP, PPS_ENOMEM, PPS_ESTATE = range(6)
 JAC_NUMERIC, JAC_ANALYTIC = 0, 1
@@ -44,7 +45,7 @@ class PpsStats(C.Structure):
         ("t_total", C.c_double), ("t_analysis", C.c_double), ("t_upload", C.c_double),
         ("t_linearize", C.c_double), ("t_assemble", C.c_double), ("t_factor", C.c_double),
         ("t_backsolve", C.c_double), ("t_retract_chi2", C.c_double),
-        ("n_linearize", C.c_int), ("n_factorize", C.c_int),
+        ("n_linearize", C.c_int), ("n_factorize", C.c_int), ("lm_trials_notpd", C.c_int),
     ]
 
     def asdict(self):

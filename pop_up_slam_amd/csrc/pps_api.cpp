@@ -101,6 +101,7 @@ struct pps_graph {
   unsigned int* spec_ticket = nullptr;
   double seq2 = 0.0;
   double *spec_L = nullptr, *spec_U = nullptr, *spec_delta = nullptr;
+  double* spec_result = nullptr;   // result_dev of the speculative set: its own not-PD flag
   bool spec_enabled = true;
   double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
   int snap_version = -1, upload_version = 0;
@@ -472,7 +473,7 @@ int upload_all(pps_graph* g) {
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   if (g->stream_b) HIP_TRY(g, hipStreamSynchronize(g->stream_b));
   free_device(g);
-  g->spec_L = g->spec_U = g->spec_delta = nullptr;
+  g->spec_L = g->spec_U = g->spec_delta = nullptr; g->spec_result = nullptr;
   g->spec_pose = g->spec_plane = g->spec_chi2_partials = g->spec_dn_partials = nullptr; g->spec_ticket = nullptr;
   g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
   g->frames_dirty = true;
@@ -567,7 +568,7 @@ int upload_all(pps_graph* g) {
   if (g->use_dense) { TRY(dev_upload(g, &g->d_dw_asm, g->dw_asm)); TRY(dev_upload(g, &g->d_dw_pan, g->dw_pan)); TRY(dev_upload(g, &g->d_dw_trl, g->dw_trl)); }
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
-  TRY(dev_alloc(g, &d.result_dev, 4));
+  TRY(dev_alloc(g, &d.result_dev, 4)); TRY(dev_alloc(g, &g->spec_result, 4));
   TRY(dev_alloc(g, &d.dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
   HIP_TRY(g, hipMemset(d.dn_partials, 0, ((size_t)(d.n_pose + d.n_plane + 255) / 256 + 1) * 8));
   TRY(dev_alloc(g, &d.ticket, 1)); HIP_TRY(g, hipMemset(d.ticket, 0, 4));
@@ -782,7 +783,7 @@ void reset_solve_stats(pps_graph* g) {
   pps_stats& s = g->stats;
   s.t_linearize = s.t_assemble = s.t_factor = s.t_backsolve = s.t_retract_chi2 = 0;
   s.n_linearize = s.n_factorize = 0;
-  s.lm_iterations = s.lm_trials_accepted = s.lm_trials_rejected = 0;
+  s.lm_iterations = s.lm_trials_accepted = s.lm_trials_rejected = s.lm_trials_notpd = 0;
   s.t_analysis = s.t_upload = 0;
 }
 
@@ -1037,6 +1038,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   if (rc != PPS_OK) return rc;
   const pps_props& prop = g->props;
   HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+  HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));
   int num_iter = 0;
   double lambda = prop.lm_lambda0;
   double* slot0 = g->host_result;       // chi2 at the linearisation point
@@ -1076,7 +1078,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   auto launch_spec = [&](double lam) -> int {
     if (!spec) return PPS_OK;
     DevGraph dv = g->dev;
-    dv.L = g->spec_L; dv.U = g->spec_U; dv.delta = g->spec_delta;
+    dv.L = g->spec_L; dv.U = g->spec_U; dv.delta = g->spec_delta; dv.result_dev = g->spec_result;   // its own not-PD flag
     HIP_TRY(g, hipStreamWaitEvent(g->stream_b, g->ev_h_ready, 0));
     int r = do_solve_on(g, dv, lam, g->stream_b); if (r != PPS_OK) return r;
     HIP_TRY(g, hipEventRecord(g->ev_spec_done, g->stream_b));
@@ -1088,6 +1090,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
     if (spec_trial_enabled) {
       DevGraph dt = g->dev;
       dt.delta = g->spec_delta; dt.chi2_partials = g->spec_chi2_partials; dt.dn_partials = g->spec_dn_partials; dt.ticket = g->spec_ticket;
+      dt.result_dev = g->spec_result;
       HIP_TRY(g, hipStreamWaitEvent(g->stream_b, g->ev_retracted, 0));
       HIP_TRY(g, launch_retract_to(dt, g->dev.pose_est, g->dev.plane_est, g->spec_pose, g->spec_plane, g->stream_b));
       g->seq2 += 1.0;
@@ -1110,7 +1113,11 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   double error = slot0[0];
   g->stats.chi2_initial = error;
   double dnorm = std::sqrt(slot1[1]);
-  bool any_notpd = slot1[2] != 0.0;
+  // Not-PD is a property of ONE factorisation (one lambda): every result record carries the flag of the solve that produced
+  // its step, and the chi2 kernel clears it.  CHOLMOD is silent here and LM simply rejects such a step and raises lambda
+  // (Optimizer.cpp:448-455), so only a solve whose LAST trial was still not PD reports PPS_ENOTPD.
+  bool last_notpd = slot1[2] != 0.0;
+  int n_notpd = last_notpd ? 1 : 0;
   bool trial_pending = true;
   bool have_result = false;
   while ((prop.max_iterations <= 0 || num_iter < prop.max_iterations) && dnorm > prop.epsilon2 && error > prop.epsilon_abs) {
@@ -1141,6 +1148,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
         // the step for this lambda has been computed alongside the previous solve: adopt its buffers
         HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
         std::swap(g->dev.L, g->spec_L); std::swap(g->dev.U, g->spec_U); std::swap(g->dev.delta, g->spec_delta);
+        std::swap(g->dev.result_dev, g->spec_result);
         spec_inflight = false;
         if (spec_trial_inflight) {
           // the trial for this lambda has been evaluated as well: rotate its state in (lin <- x (+) delta', est stays x;
@@ -1165,7 +1173,8 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
     if (!have_result) { rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc; }
     have_result = false;
     dnorm = std::sqrt(slot1[1]);
-    any_notpd = any_notpd || slot1[2] != 0.0;
+    last_notpd = slot1[2] != 0.0;
+    n_notpd += last_notpd ? 1 : 0;
   }
   if (spec) HIP_TRY(g, hipStreamSynchronize(g->stream_b));       // no speculative work may outlive the call
   if (trial_pending) swap_state(g);                               // undo the speculative step
@@ -1196,7 +1205,8 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
     fprintf(stderr, "  first start -> last end: %lld cycles\n", tmax - tmin);
   }
   if (iterations) *iterations = num_iter;
-  if (any_notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite");
+  g->stats.lm_trials_notpd = n_notpd;
+  if (last_notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite at the last LM trial");
   return PPS_OK;
 }
 
@@ -1348,6 +1358,13 @@ int pps_eval_factor(pps_graph* g, int fid, int mode, double* J, double* r) {
 int pps_analyze(pps_graph* g) {
   if (!g) return PPS_EINVAL;
   if (g->n_live_nodes == 0) return fail(g, PPS_ESTATE, "empty graph");
+  // run_analysis re-assigns the node / factor slots; anything that is newer on the device still lives in the OLD slot layout
+  // and has to come home first (a refresh or a solve followed by an edit, then this call)
+  if (g->dev_ready) {
+    int rc = download_state(g); if (rc != PPS_OK) return rc;
+    rc = download_measurements(g); if (rc != PPS_OK) return rc;
+    g->topo_dirty = true;            // the device arrays no longer match the slot tables: the next solve uploads again
+  }
   return run_analysis(g);
 }
 

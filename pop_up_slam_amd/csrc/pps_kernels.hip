@@ -15,6 +15,8 @@
 //   K4  k_retract<TRIAL> exmap per node (Slam::self_exmap/apply_exmap, Slam.cpp:216-234)
 //       k_chi2           residual-only sweep + chi^2 reduction, last block writes the pinned result record
 //                        (Slam::weighted_errors/chi2, Slam.cpp:254-268)
+#include <cstdlib>
+
 #include "pps_device.h"
 #include "pps_geom.h"
 #include "pps_regtile.h"
@@ -197,12 +199,22 @@ constexpr int kLinBlock = 128;
 // A wave's 64 factor records (N doubles each, contiguous in global memory) are staged through LDS
 // (row stride N+1: conflict-free) and written back as one contiguous 64*N-double stream with 16-byte
 // stores per lane, instead of 64 scattered N*8-byte records per store instruction.
+// second half: the wave's records already sit in LDS (lane l at lds_wave + l * (N + 1))
+template <int N>
+__device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gbase, int n_valid, double* __restrict__ lds_wave);
+
 template <int N>
 __device__ __forceinline__ void store_records_coalesced(const double (&v)[N], double* __restrict__ gbase, int n_valid,
                                                          double* __restrict__ lds_wave) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int k = 0; k < N; k++) lds_wave[lane * (N + 1) + k] = v[k];
+  flush_records_coalesced<N>(gbase, n_valid, lds_wave);
+}
+
+template <int N>
+__device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gbase, int n_valid, double* __restrict__ lds_wave) {
+  const int lane = threadIdx.x & 63;
   __builtin_amdgcn_wave_barrier();
   const int total = n_valid * N;                    // doubles this wave owns (N even -> total even)
 #pragma unroll
@@ -243,26 +255,24 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const doubl
   }
   b -= nb_obs;
   if (b < nb_odo) {
-    if (MODE == 1) {
-      const int i0 = b * kLinBlock + (threadIdx.x & ~63);
-      const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
-      double p1[7], p2[7], ms[6], w[21], out[78];
-      load_pose(pose, d.pose_ld, d.odo_a[i], p1);
-      load_pose(pose, d.pose_ld, d.odo_b[i], p2);
-      load_soa<6>(d.odo_meas, d.n_odo, i, ms);
-      load_soa<21>(d.odo_w, d.n_odo, i, w);
-      lin_odometry<MODE>(p1, p2, ms, w, out);
-      if (i0 < d.n_odo) store_records_coalesced<78>(out, d.J + d.joff_odo + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
-      return;
-    }
-    const int i = b * kLinBlock + threadIdx.x;
-    if (i >= d.n_odo) return;
+    // both Jacobian modes leave through the LDS-staged store: written straight from the lanes, a 624-byte record per lane
+    // turns every store instruction into 64 partial 32-byte sectors (PMC: 265 MB written for 67 MB of records)
+    const int i0 = b * kLinBlock + (threadIdx.x & ~63);
+    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
     double p1[7], p2[7], ms[6], w[21];
     load_pose(pose, d.pose_ld, d.odo_a[i], p1);
     load_pose(pose, d.pose_ld, d.odo_b[i], p2);
     load_soa<6>(d.odo_meas, d.n_odo, i, ms);
     load_soa<21>(d.odo_w, d.n_odo, i, w);
-    lin_odometry<MODE>(p1, p2, ms, w, d.J + d.joff_odo + (size_t)i * 78);
+    if (MODE == 1) {
+      double out[78];
+      lin_odometry<MODE>(p1, p2, ms, w, out);
+      if (i0 < d.n_odo) store_records_coalesced<78>(out, d.J + d.joff_odo + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+    } else {
+      // the central-difference loops stay rolled (24 residual evaluations): the record is built in LDS, not in registers
+      lin_odometry<MODE>(p1, p2, ms, w, lds_wave + (threadIdx.x & 63) * 79);
+      if (i0 < d.n_odo) flush_records_coalesced<78>(d.J + d.joff_odo + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+    }
     return;
   }
   b -= nb_odo;
@@ -488,7 +498,8 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   if (nb == 0) return hipSuccess;
   const double* pose = at_estimate ? d.pose_est : d.pose_lin;
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
-  if (mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors) {
+  // PPS_K1_THREAD_FORM=1 forces the thread-per-factor kernels on small graphs (parity tests of that form)
+  if (mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !getenv("PPS_K1_THREAD_FORM")) {
     const int lb_obs = cdiv(d.n_obs_fixed, kFactorsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
               lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
     hipLaunchKernelGGL(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
@@ -502,7 +513,7 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
     if (nb_rest) hipLaunchKernelGGL((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
   } else {
     if (nb_obs) hipLaunchKernelGGL((k_linearize<0, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
-    if (nb_rest) hipLaunchKernelGGL((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+    if (nb_rest) hipLaunchKernelGGL((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
   }
   return hipGetLastError();
 }
@@ -540,26 +551,21 @@ __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* _
     return;
   }
   b -= nb_obs_per;
-  if (MODE == 1) {
-    const int i0 = b * kLinBlock + (threadIdx.x & ~63);
-    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
-    double p1[7], p2[7], ms[6], w[21], out[78];
-    load_pose(d.pose_lin, d.pose_ld, odo_a[i], p1);
-    load_pose(d.pose_lin, d.pose_ld, odo_b[i], p2);
-    load_soa<6>(odo_meas, d.n_odo, i, ms);
-    load_soa<21>(odo_w, d.n_odo, i, w);
-    lin_odometry<MODE>(p1, p2, ms, w, out);
-    if (i0 < d.n_odo) store_records_coalesced<78>(out, Jr + (size_t)d.n_obs * 30 + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
-    return;
-  }
-  const int i = b * kLinBlock + threadIdx.x;
-  if (i >= d.n_odo) return;
+  const int i0 = b * kLinBlock + (threadIdx.x & ~63);
+  const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
   double p1[7], p2[7], ms[6], w[21];
   load_pose(d.pose_lin, d.pose_ld, odo_a[i], p1);
   load_pose(d.pose_lin, d.pose_ld, odo_b[i], p2);
   load_soa<6>(odo_meas, d.n_odo, i, ms);
   load_soa<21>(odo_w, d.n_odo, i, w);
-  lin_odometry<MODE>(p1, p2, ms, w, Jr + (size_t)d.n_obs * 30 + (size_t)i * 78);
+  if (MODE == 1) {
+    double out[78];
+    lin_odometry<MODE>(p1, p2, ms, w, out);
+    if (i0 < d.n_odo) store_records_coalesced<78>(out, Jr + (size_t)d.n_obs * 30 + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+  } else {
+    lin_odometry<MODE>(p1, p2, ms, w, lds_wave + (threadIdx.x & 63) * 79);
+    if (i0 < d.n_odo) flush_records_coalesced<78>(Jr + (size_t)d.n_obs * 30 + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+  }
 }
 
 hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, int part, hipStream_t st) {
@@ -571,7 +577,7 @@ hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double*
     if (nb_odo && part != 0) hipLaunchKernelGGL((k_sweep_bench<1, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), lds1, st, d, Jbig, nb_obs, nb_odo, replicas);
   } else {
     if (nb_obs && part != 1) hipLaunchKernelGGL((k_sweep_bench<0, 0>), dim3(nb_obs * replicas), dim3(kLinBlock), lds0, st, d, Jbig, nb_obs, nb_odo, replicas);
-    if (nb_odo && part != 0) hipLaunchKernelGGL((k_sweep_bench<0, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), 0, st, d, Jbig, nb_obs, nb_odo, replicas);
+    if (nb_odo && part != 0) hipLaunchKernelGGL((k_sweep_bench<0, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), lds1, st, d, Jbig, nb_obs, nb_odo, replicas);
   }
   return hipGetLastError();
 }
@@ -1148,7 +1154,9 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
     double i0 = 0, i1 = 0, i2 = 0, i3 = 0, l10 = 0, l20 = 0, l30 = 0, l21 = 0, l31 = 0, l32 = 0;
     double x0, x1, x2, x3;
     {
+#ifndef PPS_NO_FMA
 #pragma clang fp contract(fast)     // the serial pivot chain: a - b * c is one operation here
+#endif
       { bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? rsqrt_nr(d00) : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
       if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
       if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
@@ -1229,7 +1237,9 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   __builtin_amdgcn_wave_barrier();
   double tj = 0.0, dinv = 0.0;
   {
+#ifndef PPS_NO_FMA
 #pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
+#endif
     if (lane < p) {
       // y - L_B^T x_b in two interleaved partial sums (half the dependent chain)
       double acc = PL[f * p + lane], acc2 = 0.0;
@@ -1580,7 +1590,7 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
     double a = 0.0, b2 = 0.0;
     for (int k = 0; k < kChiBlock / 64; k++) { a += red2[0][k]; b2 += red2[1][k]; }
     const double npd = __hip_atomic_load(&d.result_dev[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    d.result_dev[0] = a; d.result_dev[1] = b2;
+    d.result_dev[0] = a; d.result_dev[1] = b2; d.result_dev[2] = 0.0;   // the flag belongs to the solve before this record
     out[0] = a; out[1] = b2; out[2] = npd;                 // `out` is pinned host memory: no copy kernel
     // the sequence number goes last, with system-scope release: the host polls it instead of paying a stream sync
     __hip_atomic_store(&out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

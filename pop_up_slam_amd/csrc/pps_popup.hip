@@ -98,27 +98,129 @@ __global__ __launch_bounds__(64) void k_popup_planes(const float* __restrict__ s
   for (int k = 0; k < 4; k++) planes_out[4 * j + k] = pl[k];
 }
 
-// Fused K5 + K6.  grid = (ceil(W / 256), ceil(H / PX)): a thread owns one column of PX consecutive rows.
-// Pixel sets: cv::fillConvexPoly semantics of closed_polygons_homo_pts (pps_raster.h); every workgroup derives the
-// column intervals of its PX rows for every polygon into LDS, a pixel then compares its column with those intervals.
-template <int PX>
-__global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const float* __restrict__ seg2d, int n,
-                                                     const float* __restrict__ polys, const int* __restrict__ poly_off,
-                                                     int nplanes, const unsigned char* __restrict__ bgr,
-                                                     float* __restrict__ planes_out, pps_point* __restrict__ cloud,
-                                                     float* __restrict__ depth, int* __restrict__ plane_id,
-                                                     unsigned int* __restrict__ n_valid) {
-  __shared__ float s_planes[kMaxPlanes + 1][4];
+// Row intervals of every plane polygon, once per frame: closed_polygons_homo_pts / cv::fillConvexPoly (pps_raster.h).
+// One thread per (scaled row, polygon) derives the fill span and the outline runs of that row and merges them into
+// disjoint column runs (usually one).  Layout: row_iv[row][s_off[p] + p + i] (stride nverts + nplanes), row_cnt[row][p],
+// boxes[p] = boundingRect of the truncated polygon.  Rows are in scaled coordinates (image row / step).
+constexpr int kRowMergeCap = 17;    // lists up to this length are merged, longer ones stay raw (still exact)
+
+__global__ __launch_bounds__(256) void k_popup_rows(PopupParams prm, const float* __restrict__ polys, const int* __restrict__ poly_off,
+                                                    int nplanes, unsigned int* __restrict__ row_iv, int* __restrict__ row_cnt,
+                                                    int4* __restrict__ boxes) {
   __shared__ float s_poly[2 * kMaxVerts];
   __shared__ int2 s_q[kMaxVerts];                 // vertices as the integer points fillConvexPoly sees (box coordinates)
   __shared__ RasterLine s_line[kMaxVerts];        // outline edge ending at vertex v
   __shared__ int s_off[kMaxPlanes + 2];
+  __shared__ int4 s_box[kMaxPlanes];
+  __shared__ unsigned int s_scr[256 * kRowMergeCap];
+  const int tid = threadIdx.x;
+  for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
+  __syncthreads();
+  const int nverts = s_off[nplanes];
+  const int S = prm.step;                                       // 2 = downsample_poly
+  for (int i = tid; i < 2 * nverts; i += 256) s_poly[i] = S == 2 ? polys[i] / 2 : polys[i];   // new_polys_close / 2 (:86-87)
+  __syncthreads();
+  // boundingRect of the truncated points (matrix_to_points + boundingRect, popup_plane.cpp:89-91)
+  if (tid < nplanes) {
+    const int v0 = s_off[tid], v1 = s_off[tid + 1];
+    int x0 = 0, y0b = 0, x1 = -1, y1 = -1;
+    for (int v = v0; v < v1; v++) {
+      const int x = (int)s_poly[2 * v], y = (int)s_poly[2 * v + 1];
+      if (v == v0) { x0 = x1 = x; y0b = y1 = y; }
+      x0 = min(x0, x); x1 = max(x1, x); y0b = min(y0b, y); y1 = max(y1, y);
+    }
+    s_box[tid] = make_int4(x0, y0b, x1 - x0 + 1, y1 - y0b + 1);
+    if (blockIdx.x == 0) boxes[tid] = s_box[tid];
+  }
+  __syncthreads();
+  // polygon - box origin in fp32, truncated again (:92-96)
+  for (int v = tid; v < nverts; v += 256) {
+    int p = 0;
+    while (s_off[p + 1] <= v) p++;
+    const int4 bx = s_box[p];
+    s_q[v] = make_int2((int)(s_poly[2 * v] - (float)bx.x), (int)(s_poly[2 * v + 1] - (float)bx.y));
+  }
+  __syncthreads();
+  // outline: the edge that ends at vertex v starts at the previous vertex (the last one for the first)
+  for (int v = tid; v < nverts; v += 256) {
+    int p = 0;
+    while (s_off[p + 1] <= v) p++;
+    const int4 bx = s_box[p];
+    const int u = v > s_off[p] ? v - 1 : s_off[p + 1] - 1;
+    s_line[v] = raster_line(bx.z, bx.w, s_q[u].x, s_q[u].y, s_q[v].x, s_q[v].y);
+  }
+  __syncthreads();
+  const int Ws = (prm.width + S - 1) / S, Hs = (prm.height + S - 1) / S;
+  const int item = blockIdx.x * 256 + tid;
+  if (item >= Hs * nplanes) return;
+  const int row = item / nplanes, p = item - row * nplanes;
+  const int v0 = s_off[p], npts = s_off[p + 1] - v0;
+  const int E = nverts + nplanes;
+  unsigned int* __restrict__ out = row_iv + (size_t)row * E + v0 + p;
+  const int4 bx = s_box[p];
+  const int cy = row - bx.y;
+  int cnt = 0;
+  if (npts > 0 && cy >= 0 && cy < bx.w) {
+    const int n = npts + 1;
+    const bool merge = n <= kRowMergeCap;
+    unsigned int* iv = merge ? s_scr + tid * kRowMergeCap : out;
+    for (int i = 0; i < n; i++) {
+      int lo = 0, hi = -1;
+      const bool hit = i == 0 ? raster_fill_row(s_q + v0, npts, bx.z, bx.w, cy, lo, hi) : raster_line_row(s_line[v0 + i - 1], cy, lo, hi);
+      unsigned int o = 1u;                                         // lo = 1 > hi = 0: empty
+      if (hit) {
+        lo = max(lo, 0) + bx.x; hi = min(hi, bx.z - 1) + bx.x;   // inside the box image, then frame columns (:104-113)
+        lo = max(lo, 0); hi = min(hi, Ws - 1);
+        if (lo <= hi) o = (unsigned int)lo | ((unsigned int)hi << 16);
+      }
+      iv[i] = o;
+    }
+    cnt = n;
+    if (merge) {
+      for (int a = 1; a < n; a++) {                                // insertion sort by lo; empty intervals merge away below
+        const unsigned int key = iv[a];
+        int b = a - 1;
+        while (b >= 0 && (iv[b] & 0xffffu) > (key & 0xffffu)) { iv[b + 1] = iv[b]; b--; }
+        iv[b + 1] = key;
+      }
+      int m = 0;
+      unsigned int cur = 1u;
+      for (int a = 0; a < n; a++) {
+        const unsigned int v = iv[a], lo = v & 0xffffu, hi = v >> 16;
+        if (lo > hi) continue;
+        if (m > 0 && lo <= (cur >> 16) + 1u) { if (hi > (cur >> 16)) cur = (cur & 0xffffu) | (hi << 16); }
+        else { if (m > 0) out[m - 1] = cur; cur = v; m++; }
+      }
+      if (m > 0) out[m - 1] = cur;
+      cnt = m;
+    }
+  }
+  row_cnt[(size_t)row * nplanes + p] = cnt;
+}
+
+// Fused K5 + K6.  grid = (ceil(W / 256), ceil(H / PX)): a thread owns one column of PX consecutive rows and compares its
+// column with the row intervals k_popup_rows derived (loaded into LDS for the PX rows of the workgroup).
+template <int PX>
+__global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const float* __restrict__ seg2d, int n,
+                                                     const int* __restrict__ poly_off, int nplanes,
+                                                     const unsigned int* __restrict__ row_iv, const int* __restrict__ row_cnt,
+                                                     const int4* __restrict__ boxes, const unsigned char* __restrict__ bgr,
+                                                     float* __restrict__ planes_out, pps_point* __restrict__ cloud,
+                                                     float* __restrict__ depth, int* __restrict__ plane_id,
+                                                     unsigned int* __restrict__ n_valid) {
+  __shared__ float s_planes[kMaxPlanes + 1][4];
+  __shared__ int s_off[kMaxPlanes + 2];
   __shared__ int4 s_box[kMaxPlanes];              // boundingRect of the truncated polygon: x, y, width, height
-  __shared__ unsigned int s_iv[(kMaxVerts + kMaxPlanes) * PX];   // per (polygon, row): lo | hi << 16, scaled image columns
+  __shared__ unsigned int s_iv[(kMaxVerts + kMaxPlanes) * PX];   // per row, per polygon: lo | hi << 16, scaled image columns
   __shared__ int s_ivcnt[kMaxPlanes * PX];
   __shared__ float s_ceil[4];
   __shared__ unsigned int s_cnt;
   const int tid = threadIdx.x;
+  const int S = prm.step;
+  const int W = prm.width, H = prm.height;
+  const int y0 = blockIdx.y * PX;
+  for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
+  if (tid < nplanes) s_box[tid] = boxes[tid];
   // ---- K5: plane equations of this frame (every workgroup; block 0 publishes them) ----
   if (tid <= n && tid <= kMaxPlanes) {
     float gs[4], pl[4];
@@ -141,93 +243,16 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
       s_ceil[k] = prm.T[0 * 4 + k] * 0.f + prm.T[1 * 4 + k] * 0.f + prm.T[2 * 4 + k] * -1.f + prm.T[3 * 4 + k] * prm.ceiling_thre;
     s_cnt = 0;
   }
-  for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
   __syncthreads();
-  const int nverts = s_off[nplanes];
-  const int S = prm.step;                                       // 2 = downsample_poly
-  for (int i = tid; i < 2 * nverts; i += 256) s_poly[i] = S == 2 ? polys[i] / 2 : polys[i];   // new_polys_close / 2 (:86-87)
-  __syncthreads();
-  // boundingRect of the truncated points (matrix_to_points + boundingRect, popup_plane.cpp:89-91)
-  if (tid < nplanes) {
-    const int v0 = s_off[tid], v1 = s_off[tid + 1];
-    int x0 = 0, y0b = 0, x1 = -1, y1 = -1;
-    for (int v = v0; v < v1; v++) {
-      const int x = (int)s_poly[2 * v], y = (int)s_poly[2 * v + 1];
-      if (v == v0) { x0 = x1 = x; y0b = y1 = y; }
-      x0 = min(x0, x); x1 = max(x1, x); y0b = min(y0b, y); y1 = max(y1, y);
-    }
-    s_box[tid] = make_int4(x0, y0b, x1 - x0 + 1, y1 - y0b + 1);
+  const int E = s_off[nplanes] + nplanes;                       // entries per row of row_iv
+  // interval lists of this workgroup's rows (rows that are not a multiple of the step have none)
+  for (int i = tid; i < nplanes * PX; i += 256) {
+    const int k = i / nplanes, p = i - k * nplanes, Y = y0 + k;
+    s_ivcnt[k * nplanes + p] = (Y < H && Y % S == 0) ? row_cnt[(size_t)(Y / S) * nplanes + p] : 0;
   }
-  __syncthreads();
-  // polygon - box origin in fp32, truncated again (:92-96)
-  for (int v = tid; v < nverts; v += 256) {
-    int p = 0;
-    while (s_off[p + 1] <= v) p++;
-    const int4 bx = s_box[p];
-    s_q[v] = make_int2((int)(s_poly[2 * v] - (float)bx.x), (int)(s_poly[2 * v + 1] - (float)bx.y));
-  }
-  __syncthreads();
-  // outline: the edge that ends at vertex v starts at the previous vertex (the last one for the first)
-  for (int v = tid; v < nverts; v += 256) {
-    int p = 0;
-    while (s_off[p + 1] <= v) p++;
-    const int4 bx = s_box[p];
-    const int u = v > s_off[p] ? v - 1 : s_off[p + 1] - 1;
-    s_line[v] = raster_line(bx.z, bx.w, s_q[u].x, s_q[u].y, s_q[v].x, s_q[v].y);
-  }
-  __syncthreads();
-  const int W = prm.width, H = prm.height;
-  const int Ws = (W + S - 1) / S;                               // columns a scaled coordinate may take inside the frame
-  const int y0 = blockIdx.y * PX;
-  // one interval per (polygon, row, [fill span | outline edge]); slot 0 of a (polygon, row) list is the fill span
-  const int n_items = (nverts + nplanes) * PX;
-  for (int it = tid; it < n_items; it += 256) {
-    int p = 0;
-    while ((s_off[p + 1] + p + 1) * PX <= it) p++;
-    const int v0 = s_off[p], npts = s_off[p + 1] - v0;
-    const int loc = it - (v0 + p) * PX;
-    const int k = loc / (npts + 1), i = loc - k * (npts + 1);
-    const int4 bx = s_box[p];
-    const int Y = y0 + k;
-    unsigned int out = 1u;                                       // lo = 1 > hi = 0: empty
-    if (npts > 0 && Y < H && Y % S == 0) {
-      const int cy = Y / S - bx.y;
-      if (cy >= 0 && cy < bx.w) {
-        int lo = 0, hi = -1;
-        const bool hit = i == 0 ? raster_fill_row(s_q + v0, npts, bx.z, bx.w, cy, lo, hi) : raster_line_row(s_line[v0 + i - 1], cy, lo, hi);
-        if (hit) {
-          lo = max(lo, 0) + bx.x; hi = min(hi, bx.z - 1) + bx.x;   // inside the box image, then frame columns (:104-113)
-          lo = max(lo, 0); hi = min(hi, Ws - 1);
-          if (lo <= hi) out = (unsigned int)lo | ((unsigned int)hi << 16);
-        }
-      }
-    }
-    s_iv[it] = out;
-  }
-  __syncthreads();
-  // merge the intervals of a (polygon, row) into disjoint runs (usually one); long lists stay as they are
-  for (int it = tid; it < nplanes * PX; it += 256) {
-    const int p = it / PX, k = it - p * PX;
-    const int npts = s_off[p + 1] - s_off[p];
-    unsigned int* iv = s_iv + (s_off[p] + p) * PX + k * (npts + 1);
-    int cnt = npts > 0 ? npts + 1 : 0;
-    if (cnt <= 17) {
-      for (int a = 1; a < cnt; a++) {                              // empty intervals (lo = 1, hi = 0) sort anywhere: they merge away
-        const unsigned int key = iv[a];
-        int b = a - 1;
-        while (b >= 0 && (iv[b] & 0xffffu) > (key & 0xffffu)) { iv[b + 1] = iv[b]; b--; }
-        iv[b + 1] = key;
-      }
-      int m = 0;
-      for (int a = 0; a < cnt; a++) {
-        const unsigned int lo = iv[a] & 0xffffu, hi = iv[a] >> 16;
-        if (lo > hi) continue;
-        if (m > 0 && lo <= (iv[m - 1] >> 16) + 1u) { if (hi > (iv[m - 1] >> 16)) iv[m - 1] = (iv[m - 1] & 0xffffu) | (hi << 16); }
-        else iv[m++] = iv[a];
-      }
-      cnt = m;
-    }
-    s_ivcnt[it] = cnt;
+  for (int i = tid; i < E * PX; i += 256) {
+    const int k = i / E, Y = y0 + k;
+    s_iv[i] = (Y < H && Y % S == 0) ? row_iv[(size_t)(Y / S) * E + (i - k * E)] : 1u;
   }
   __syncthreads();
 
@@ -246,14 +271,13 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
     for (int p = nplanes - 1; p >= 0; p--) {                 // a later plane overwrites an earlier one: scan backwards
       const int4 bx = s_box[p];
       if ((int)xs < bx.x || (int)xs >= bx.x + bx.z) continue;
-      const int npts = s_off[p + 1] - s_off[p];
-      const unsigned int* iv = s_iv + (s_off[p] + p) * PX;
+      const unsigned int* iv = s_iv + s_off[p] + p;
       bool all_set = true;
 #pragma unroll
       for (int k = 0; k < PX; k++) {
         if (pid[k] < 0) {
-          const int cnt = s_ivcnt[p * PX + k];
-          const unsigned int* r = iv + k * (npts + 1);
+          const int cnt = s_ivcnt[k * nplanes + p];
+          const unsigned int* r = iv + k * E;
           bool in = false;
           for (int a = 0; a < cnt; a++) { const unsigned int v = r[a]; in = in || (xs >= (v & 0xffffu) && xs <= (v >> 16)); }
           if (in) pid[k] = p;
@@ -385,6 +409,9 @@ struct pps_popup {
   float* d_seg = nullptr;      // kMaxPlanes x 4
   float* d_polys = nullptr;    // 2*kMaxVerts
   int* d_off = nullptr;        // kMaxPlanes+2
+  unsigned int* d_row_iv = nullptr;   // row intervals of the last run (k_popup_rows): height x (kMaxVerts + kMaxPlanes)
+  int* d_row_cnt = nullptr;           // height x kMaxPlanes
+  int4* d_boxes = nullptr;            // kMaxPlanes
   unsigned int* d_count = nullptr;
   unsigned int* h_count = nullptr;   // pinned
   int last_n = 0;
@@ -439,6 +466,9 @@ int pps_popup_create(int device, int width, int height, const float invK[9], pps
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_polys), sizeof(float) * 2 * kMaxVerts);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_off), sizeof(int) * (kMaxPlanes + 2));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_count), sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_iv), sizeof(unsigned int) * (size_t)height * (kMaxVerts + kMaxPlanes));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_cnt), sizeof(int) * (size_t)height * kMaxPlanes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_boxes), sizeof(int4) * kMaxPlanes);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_count), sizeof(unsigned int), hipHostMallocDefault);
   if (e != hipSuccess) { pps_popup_destroy(p); return PPS_EHIP; }
   *out = p;
@@ -451,6 +481,7 @@ int pps_popup_destroy(pps_popup* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   (void)hipFree(p->d_bgr); (void)hipFree(p->d_cloud); (void)hipFree(p->d_depth); (void)hipFree(p->d_depth_fill); (void)hipFree(p->d_pid);
   (void)hipFree(p->d_planes); (void)hipFree(p->d_seg); (void)hipFree(p->d_polys); (void)hipFree(p->d_off); (void)hipFree(p->d_count);
+  (void)hipFree(p->d_row_iv); (void)hipFree(p->d_row_cnt); (void)hipFree(p->d_boxes);
   if (p->h_count) (void)hipHostFree(p->h_count);
   if (p->ev[0]) (void)hipEventDestroy(p->ev[0]);
   if (p->ev[1]) (void)hipEventDestroy(p->ev[1]);
@@ -494,13 +525,18 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   int pxt = npx >= (1 << 20) ? 8 : 2;
   if (const char* e = getenv("PPS_POPUP_PXT")) pxt = atoi(e) >= 8 ? 8 : 2;
   const dim3 grid((p->width + 255) / 256, (p->height + pxt - 1) / pxt);
+  if (nplanes > 0) {
+    const int hs = (p->height + step - 1) / step;
+    hipLaunchKernelGGL(k_popup_rows, dim3((hs * nplanes + 255) / 256), dim3(256), 0, p->stream, prm, p->d_polys, p->d_off, nplanes,
+                       p->d_row_iv, p->d_row_cnt, p->d_boxes);
+  }
   if (pxt == 8)
-    hipLaunchKernelGGL(k_popup_frame<8>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
-                       p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
+    hipLaunchKernelGGL(k_popup_frame<8>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
+                       p->d_boxes, p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
                        p->want_pid ? p->d_pid : nullptr, p->d_count);
   else
-    hipLaunchKernelGGL(k_popup_frame<2>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes,
-                       p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
+    hipLaunchKernelGGL(k_popup_frame<2>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
+                       p->d_boxes, p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
                        p->want_pid ? p->d_pid : nullptr, p->d_count);
   PHIP(p, hipGetLastError());
   PHIP(p, hipEventRecord(p->ev[1], p->stream));

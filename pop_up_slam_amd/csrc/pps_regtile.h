@@ -15,8 +15,13 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const double t = x * y, hy = 0.5 * y;
+#ifdef PPS_NO_FMA                                      // diagnostic build (make nofma): no contracted operation anywhere
+    const double e = 0.5 - t * hy;
+    y = y + y * e;
+#else
     const double e = __builtin_fma(-t, hy, 0.5);       // 0.5 - 0.5 x y^2
     y = __builtin_fma(y, e, y);
+#endif
   }
   return y;
 }

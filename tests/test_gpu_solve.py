@@ -33,6 +33,23 @@ def test_factor_jacobians_match_oracle(built, mk, mode):
         np.testing.assert_allclose(J, Jo, rtol=0, atol=(2e-8 if mode == P.JAC_NUMERIC else 1e-11))
 
 
+def test_thread_per_factor_sweep_matches_oracle(built, monkeypatch):
+    """graphs above 200 000 factors run K1 as one thread per factor (records staged through LDS and written as one stream);
+    the same kernels forced onto small graphs, every factor type against the oracle"""
+    monkeypatch.setenv("PPS_K1_THREAD_FORM", "1")
+    for mk in (SMALL[2], lambda: synth.corridor(300, 60, seed=4)):
+        spec = mk()
+        g, o, nid, fid, onid, ofid = _pair(spec)
+        for k in range(0, len(fid), max(1, len(fid) // 400)):
+            J, r = g.eval_factor(int(fid[k]), P.JAC_NUMERIC)
+            Jo, ro = o.factor_jacobian(int(ofid[k]), analytic=0)
+            np.testing.assert_allclose(r, ro, rtol=0, atol=2e-11)
+            np.testing.assert_allclose(J, Jo, rtol=0, atol=2e-8)
+        it, ito = g.batch_optimize(), o.batch_optimize()
+        c, co = g.chi2(), o.chi2()
+        assert it == ito and abs(c - co) <= 1e-7 * co
+
+
 @pytest.mark.parametrize("mk", SMALL)
 def test_chi2_matches_oracle(built, mk):
     spec = mk()
@@ -99,28 +116,98 @@ def test_c3_manhattan_rooms_final_chi2(built):
     assert abs(c - co) <= 1e-5 * abs(co), (c, co)
 
 
-def test_c4_independent_seeds(built):
-    """BASELINE config 4 (one C2-size graph per GPU): the per-rank graphs of bench.py, solved one after the
-    other on this GPU, each against the oracle."""
-    import bench
-    # the C4 graphs of bench.py (well-conditioned seeds: 55-79 LM trials): chi2 within the north_star tolerance and the
-    # same trial count.  Seeds 101 / 107 start at chi2_0 = 31 / 67 and wander for hundreds of trials along accept/reject
-    # knife edges that amplify round-off chaotically (the elimination order alone changes the path and where the
-    # relative-decrease test stops it), so only LM's own guarantees are checked there: chi2 never increases, finite.
-    for seed in bench.C4_SEEDS[1:] + [101, 107]:
+def _c4_fixture():
+    import os
+    from helpers import GOLDEN
+    return np.load(os.path.join(GOLDEN, "c4_oracle.npz"))
+
+
+def _canon(v):
+    """plane 4-vectors and pose quaternions are defined up to sign"""
+    v = np.array(v, dtype=np.float64)
+    if v.shape[1] == 4:
+        return v * np.where(v[:, 3:4] < 0, -1.0, 1.0)
+    v[:, 3:] *= np.where(v[:, 6:7] < 0, -1.0, 1.0)
+    return v
+
+
+def _state(g, spec, nid):
+    poses = [g.get_pose(int(a)) for a, t in zip(nid, spec.node_type) if t == synth.NODE_POSE]
+    planes = [g.get_plane(int(a)) for a, t in zip(nid, spec.node_type) if t != synth.NODE_POSE]
+    return _canon(poses), _canon(planes)
+
+
+def _compare_traces(tr, tro, tol_acc=1e-6, tol_rej=1e-3):
+    """same lambda schedule and verdicts; chi2 of accepted trials to tol_acc, of rejected trials (steps at too small a
+    lambda on an ill-conditioned system: their chi2 amplifies round-off) to tol_rej.  Returns the worst accepted-trial error."""
+    assert len(tr) == len(tro), (len(tr), len(tro))
+    worst = 0.0
+    for k, ((lam, chi, acc), (lo, cho, aco)) in enumerate(zip(tr, tro)):
+        assert bool(acc) == bool(aco) and lam == lo, (k, lam, lo, acc, aco, chi, cho)
+        rel = abs(chi - cho) / abs(cho)
+        assert rel <= (tol_acc if acc else tol_rej), (k, acc, chi, cho, rel)
+        if acc:
+            worst = max(worst, rel)
+    return worst
+
+
+def test_c4_survey_seeds_against_the_oracle(built):
+    """BASELINE config 4 on SURVEY's seeds 100-107, every one compared with the oracle (tests/golden/c4_oracle.npz, written by
+    tools/c4_trace_diff.py --write-fixture from the CPU oracle alone).
+
+    Four of the eight graphs (100, 102, 104, 105) are numerically stable: two CPU builds of the oracle (with and without
+    fused multiply-adds) end at the same chi2 to 1e-13.  There the HIP path must reproduce the oracle's LM run trial for
+    trial under the application's stopping rules -- same trial count, same accept/reject sequence, final chi2 within
+    north_star's rel 1e-5 -- and reach the same minimum when both run until LM stalls.
+
+    On the other four (101, 103, 106, 107) the LM run is chaotic: the two CPU builds of the SAME oracle source leave each
+    other after 26-60 trials and end 17 %-134 % apart, so "final chi2 under the default rules" is not a reproducible
+    quantity for any implementation.  The comparison is made where it is well posed: from states along the oracle's own
+    path (after 0 / 60 / 200 trials) both sides run the next 8 LM trials -- same verdicts, chi2 per accepted trial to
+    1e-6, chi2 after the burst to rel 1e-5.  End to end only sanity remains (monotone, finite, in the range the CPU
+    builds span)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import c4_trace_diff as T
+    fx = _c4_fixture()
+    chaotic = set(int(s) for s in fx["chaotic"])
+    assert chaotic == {101, 103, 106, 107}
+    for seed in range(100, 108):
         spec = synth.corridor(seed=seed)
-        g, o, *_ = _pair(spec)
+        tro = [tuple(r) for r in fx[f"s{seed}_trace"]]
+        co, co_fma = float(fx[f"s{seed}_chi2"]), float(fx[f"s{seed}_fma_chi2"])
+        g = P.Graph(); nid, _ = spec.replay(g)
         c0 = g.chi2()
-        it, ito = g.batch_optimize(), o.batch_optimize()
-        c, co = g.chi2(), o.chi2()
-        print("C4 seed %d: gpu chi2 %.12g (%d it) oracle %.12g (%d it) rel %.2e" % (seed, c, it, co, ito, abs(c - co) / co))
-        if seed in (101, 107):
-            assert np.isfinite(c) and c < c0 and 1 <= it <= 500
-            tr = g.trace()
-            acc = [chi for (_lam, chi, ok) in tr if ok]
-            assert all(b <= a for a, b in zip(acc, acc[1:]))
+        assert abs(c0 - float(fx[f"s{seed}_chi2_0"])) <= 1e-11 * c0
+        it = g.batch_optimize(); tr = g.trace(); c = g.chi2()
+        acc = [c0] + [chi for (_l, chi, ok) in tr if ok]
+        assert np.isfinite(c) and all(b <= a for a, b in zip(acc, acc[1:]))
+        if seed not in chaotic:
+            worst = _compare_traces(tr, tro)
+            assert it == len(tro) and abs(c - co) <= 1e-5 * co, (seed, it, len(tro), c, co)
+            g2 = P.Graph(**T.TIGHT); nid2, _ = spec.replay(g2)
+            g2.batch_optimize(); c2 = g2.chi2(); co2 = float(fx[f"s{seed}_tight_chi2"])
+            assert abs(c2 - co2) <= 1e-5 * co2, (seed, c2, co2)
+            poses, planes = _state(g2, spec, nid2)
+            dp = np.max(np.abs(poses - _canon(fx[f"s{seed}_tight_poses"]))); dl = np.max(np.abs(planes - _canon(fx[f"s{seed}_tight_planes"])))
+            assert dp <= 1e-5 and dl <= 1e-5, (seed, dp, dl)
+            print("C4 seed %d (stable): %d trials, chi2 %.12g vs oracle %.12g rel %.1e (worst accepted trial %.1e); at the stalled "
+                  "optimum rel %.1e, state %.1e / %.1e" % (seed, it, c, co, abs(c - co) / co, worst, abs(c2 - co2) / co2, dp, dl))
         else:
-            assert abs(c - co) <= 1e-5 * abs(co) and it == ito, (seed, it, ito, c, co)
+            lo, hi = min(co, co_fma), max(co, co_fma)
+            assert c <= 1.5 * hi and 1 <= it <= 500, (seed, c, co, co_fma)
+            worst_all = 0.0
+            for k in fx["checkpoints"]:
+                gb = P.Graph(max_iterations=int(fx["burst"])); nidb, _ = spec.replay(gb)
+                T.set_state(gb, spec, nidb, fx[f"s{seed}_cp{k}_poses"], fx[f"s{seed}_cp{k}_planes"])
+                cb0 = gb.chi2(); ob0 = float(fx[f"s{seed}_cp{k}_chi2_0"])
+                assert abs(cb0 - ob0) <= 1e-10 * ob0, (seed, k, cb0, ob0)
+                gb.batch_optimize()
+                worst_all = max(worst_all, _compare_traces(gb.trace(), [tuple(r) for r in fx[f"s{seed}_cp{k}_trace"]]))
+                cb, ob = gb.chi2(), float(fx[f"s{seed}_cp{k}_chi2"])
+                assert abs(cb - ob) <= 1e-5 * ob, (seed, k, cb, ob)
+            print("C4 seed %d (chaotic: two CPU builds of the oracle end at %.4g / %.4g): HIP %.4g in %d trials; bursts from the oracle's "
+                  "path agree to %.1e per accepted trial" % (seed, co, co_fma, c, it, worst_all))
 
 
 def test_mid_and_large_graphs(built):

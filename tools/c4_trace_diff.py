@@ -37,10 +37,48 @@ def final_state(g, spec, nid):
     return poses, planes
 
 
+CHECKPOINTS = (0, 60, 200)      # oracle trials after which a chaotic seed's state is stored
+BURST = 8                       # LM trials run from every checkpoint on both sides
+
+
+def _fma_oracle_traces(seeds):
+    """The same oracle sources built with fused multiply-adds (-mfma -ffp-contract=fast): a second, equally legal CPU
+    build.  Where its LM run leaves the plain build's, the final chi2 under the default stopping rules is not a
+    reproducible quantity -- for any implementation.  Runs in a child process (its own copy of the library)."""
+    import shutil, subprocess, tempfile
+    tmp = tempfile.mkdtemp(prefix="pps_fma_")
+    shutil.copytree(os.path.join(ROOT, "oracle"), os.path.join(tmp, "oracle"), ignore=shutil.ignore_patterns("*.so", "__pycache__"))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(tmp, "oracle"),
+                           "CFLAGS=-O3 -DNDEBUG -std=c99 -fPIC -mfma -ffp-contract=fast -fopenmp -D_POSIX_C_SOURCE=200809L"])
+    code = ("import sys, json, numpy as np\n"
+            "from pop_up_slam_amd import synth\n"
+            "from oracle import oracle_py as O\n"
+            "out = {}\n"
+            "for seed in %r:\n"
+            "    o = O.OracleGraph(); synth.corridor(seed=seed).replay(o); o.batch_optimize()\n"
+            "    out[str(seed)] = {'trace': o.trace(), 'chi2': o.chi2()}\n"
+            "print(json.dumps(out))\n" % (list(seeds),))
+    env = dict(os.environ, PYTHONPATH=tmp + os.pathsep + ROOT)
+    res = json.loads(subprocess.check_output([sys.executable, "-c", code], env=env, cwd=tmp).decode().strip().splitlines()[-1])
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def set_state(g, spec, nid, poses, planes):
+    ip = il = 0
+    for a, t in zip(nid, spec.node_type):
+        if t == 0:
+            g.set_pose(int(a), poses[ip]); ip += 1
+        else:
+            g.set_plane(int(a), planes[il]); il += 1
+
+
 def write_fixture(seeds):
     from pop_up_slam_amd import synth
     from oracle import oracle_py as O
     out = {}
+    fma = _fma_oracle_traces(seeds)
+    chaotic = []
     for seed in seeds:
         spec = synth.corridor(seed=seed)
         o = O.OracleGraph(); nid, _ = spec.replay(o)
@@ -49,6 +87,9 @@ def write_fixture(seeds):
         out[f"s{seed}_chi2_0"] = np.float64(c0)
         out[f"s{seed}_trace"] = np.array(o.trace(), dtype=np.float64)           # trials x (lambda, chi2, accepted)
         out[f"s{seed}_chi2"] = np.float64(o.chi2())
+        out[f"s{seed}_fma_trace"] = np.array(fma[str(seed)]["trace"], dtype=np.float64)
+        out[f"s{seed}_fma_chi2"] = np.float64(fma[str(seed)]["chi2"])
+        spread = abs(float(out[f"s{seed}_fma_chi2"]) - float(out[f"s{seed}_chi2"])) / float(out[f"s{seed}_chi2"])
         o2 = O.OracleGraph(**TIGHT); nid2, _ = spec.replay(o2)
         it2 = o2.batch_optimize()
         out[f"s{seed}_tight_trace"] = np.array(o2.trace(), dtype=np.float64)
@@ -56,9 +97,30 @@ def write_fixture(seeds):
         poses, planes = final_state(o2, spec, nid2)
         out[f"s{seed}_tight_poses"] = poses
         out[f"s{seed}_tight_planes"] = planes
-        print(f"seed {seed}: chi2_0 {c0:.6g}; default {it} trials -> {float(out[f's{seed}_chi2']):.12g}; "
+        print(f"seed {seed}: chi2_0 {c0:.6g}; default {it} trials -> {float(out[f's{seed}_chi2']):.12g} "
+              f"(FMA build of the same oracle: {len(fma[str(seed)]['trace'])} trials -> {fma[str(seed)]['chi2']:.12g}, rel {spread:.2e}); "
               f"tight {it2} trials -> {float(out[f's{seed}_tight_chi2']):.12g}", flush=True)
-    np.savez_compressed(FIXTURE, seeds=np.array(seeds), **out)
+        if spread > 1e-5:
+            # two CPU builds of the oracle already disagree end to end: store states along the plain build's path and the
+            # oracle's next BURST trials from each, so that the HIP path can be compared where the comparison is well posed
+            chaotic.append(seed)
+            for k in CHECKPOINTS:
+                ok = O.OracleGraph(max_iterations=k) if k > 0 else O.OracleGraph()
+                nidk, _ = spec.replay(ok)
+                if k > 0:
+                    ok.batch_optimize()
+                cp_poses, cp_planes = final_state(ok, spec, nidk)
+                ob = O.OracleGraph(max_iterations=BURST); nidb, _ = spec.replay(ob)
+                set_state(ob, spec, nidb, cp_poses, cp_planes)
+                cb0 = ob.chi2()
+                ob.batch_optimize()
+                out[f"s{seed}_cp{k}_poses"] = cp_poses; out[f"s{seed}_cp{k}_planes"] = cp_planes
+                out[f"s{seed}_cp{k}_chi2_0"] = np.float64(cb0)
+                out[f"s{seed}_cp{k}_trace"] = np.array(ob.trace(), dtype=np.float64)
+                out[f"s{seed}_cp{k}_chi2"] = np.float64(ob.chi2())
+                print(f"   checkpoint after {k} trials: chi2 {cb0:.9g} -> {float(ob.chi2()):.9g} in {BURST} trials", flush=True)
+    np.savez_compressed(FIXTURE, seeds=np.array(seeds), chaotic=np.array(chaotic, dtype=np.int64),
+                        checkpoints=np.array(CHECKPOINTS), burst=np.int64(BURST), **out)
 
 
 def main():
