@@ -98,6 +98,59 @@ def cpu_baseline(spec, budget_s=12.0, optimised=False, threads=1, min_runs=5, ma
 C4_SEEDS = [42, 135, 110, 143, 225, 154, 169, 185]
 
 
+def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisation, k1_bytes, torch):
+    """G in {1, 8, 64} C4 timing graphs (seeds cycle through C4_SEEDS) solved by pps_multi_optimize from their initial
+    estimates; per graph the chi2 / iteration count must equal the single-handle solve of the same seed."""
+    specs = {sd: synth.corridor(seed=sd) for sd in C4_SEEDS}
+    single = {}
+    for sd, sp in specs.items():
+        g1 = P.Graph(device=device, jacobian_mode=mode); sp.replay(g1)
+        single[sd] = (g1.batch_optimize(), g1.chi2()); g1.close()
+    res = {}
+    for G in (1, 8, 64):
+        gs = []
+        for k in range(G):
+            gk = P.Graph(device=device, jacobian_mode=mode)
+            specs[rank_seed(k)].replay(gk); gk.save_state()
+            gs.append(gk)
+        mm = P.Multi(gs)
+        its, st = mm.optimize()                                          # analysis + upload + first solve: outside the clock
+        same = all((int(its[k]), gs[k].chi2()) == single[rank_seed(k)] for k in range(G))
+        reps = max(2, args.steps // (10 if G >= 64 else 4))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter(); iters = 0
+        for _ in range(reps):
+            for gk in gs:
+                gk.restore_state()
+            its, st = mm.optimize()
+            iters += int(its.sum())
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        mm.set_profiling(1)
+        for gk in gs:
+            gk.restore_state()
+        mm.optimize()
+        ph = mm.phase_times(); mm.set_profiling(0)
+        ent = {"graphs": G, "graphs_per_sec": G * reps / el, "value": iters / el, "unit": "LM iters/s", "rounds": mm.rounds(),
+               "ms_per_batch_solve": 1e3 * el / reps, "bit_identical_to_single_handle": bool(same),
+               "device_seconds_per_phase": {k: ph[k] for k in ("linearize", "assemble", "factor", "backsolve", "trial")},
+               "relinearisations": ph["n_relinearized"], "factorisations": ph["n_solves"]}
+        if ph["factor"] > 0:
+            tf = flops_per_factorisation * ph["n_solves"] / ph["factor"] / 1e12
+            ent["roofline_k3"] = {"bound": "mfma", "kernel": "kb_band_factor", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                                  "us_per_factorisation_amortised": 1e6 * ph["factor"] / max(1, ph["n_solves"])}
+        if ph["linearize"] > 0:
+            gb = k1_bytes * ph["n_relinearized"] / ph["linearize"] / 1e9
+            ent["roofline_k1"] = {"bound": "hbm", "kernel": "kb_linearize_lanes" if mode == P.JAC_NUMERIC else "kb_linearize<1,*>",
+                                  "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None,
+                                  "us_per_graph_amortised": 1e6 * ph["linearize"] / max(1, ph["n_relinearized"])}
+        res[str(G)] = ent
+        mm.close()
+        for gk in gs:
+            gk.close()
+    return res
+
+
 def rank_seed(rank):
     return C4_SEEDS[rank % len(C4_SEEDS)]
 
@@ -354,6 +407,11 @@ def main():
                                                 "seeds": [rank_seed(k) for k in range(n_h)]}
             for gk in hs:
                 gk.close()
+        if world == 1:
+            # pps_multi: G independent C2 graphs per launch (BASELINE config 4 on ONE device; north_star's graphs/sec).  The
+            # headline above stays the single graph BASELINE.json's metric is quoted on.
+            out["multi_graph_one_gpu"] = multi_graph_bench(P, synth, local_rank, mode, args, spec, out["roofline_k3"]["flops_per_factorisation"],
+                                                           bytes_per_launch, torch)
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(spec)
             out["cpu_baseline"] = cb

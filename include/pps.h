@@ -121,6 +121,27 @@ int pps_batch_optimize(pps_graph* g, int* iterations);
 /* Slam::chi2(ESTIMATE) (Slam.cpp:266-268) */
 int pps_chi2(pps_graph* g, double* chi2);
 
+/* ---- many graphs side by side (BASELINE config 4 on one device; north_star reports graphs/sec) ----------------
+ * One C2-size LM solve is a dependency chain that occupies a few dozen of the 256 CUs.  pps_multi runs
+ * Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) on n independent graphs in lockstep: every kernel of an LM
+ * trial is launched once for all graphs, lambda / accept / reject stay per graph (host side, one 32-byte record per
+ * graph and round).  Arithmetic, lambda schedule, iteration count and trace of every graph are exactly those of its own
+ * pps_batch_optimize.  The graphs keep belonging to the caller (same device; they must outlive the pps_multi and must
+ * not be used from another thread during the call); topology edits between calls are picked up.  Graphs with
+ * loop-closure fronts (dense-front kernels) are refused with PPS_ESTATE.
+ *   iterations[n], status[n] (either may be NULL): LM iterations and PPS_OK / PPS_ENOTPD per graph. */
+typedef struct pps_multi pps_multi;
+int pps_multi_create(int n, pps_graph* const* graphs, pps_multi** out);
+int pps_multi_destroy(pps_multi* m);
+const char* pps_multi_last_error(const pps_multi* m);
+int pps_multi_optimize(pps_multi* m, int* iterations, int* status);
+int pps_multi_rounds(const pps_multi* m, int* rounds);    /* lockstep rounds of the last call = the longest LM run + 1 */
+/* level 1: HIP events at the phase boundaries of every round (no host syncs); after the next pps_multi_optimize
+ * sec[5] = device seconds in K1 (Jacobian sweep) | K2 (H blocks) | K3 factor | K3 back-substitution | trial step + chi2,
+ * counts[2] = graphs re-linearised | factorised, summed over the rounds (counts may be NULL) */
+int pps_multi_set_profiling(pps_multi* m, int level);
+int pps_multi_phase_times(const pps_multi* m, double sec[5], long long counts[2]);
+
 /* ---- state access (NodeT::value(), Node.h:130) ---------------------------------------- */
 int pps_num_nodes(const pps_graph* g, int* n);
 int pps_num_factors(const pps_graph* g, int* n);

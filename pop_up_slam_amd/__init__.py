@@ -105,6 +105,7 @@ SYMBOLS = [
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
     "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
+    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times",
 ]
 
 
@@ -168,6 +169,14 @@ def lib():
         L.pps_popup_download.argtypes = [C.c_void_p, _fp, C.c_void_p, _fp, C.POINTER(C.c_int32)]
         L.pps_popup_last_kernel_time.argtypes = [C.c_void_p, _dp]
         L.pps_popup_mask_host.argtypes = [_fp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        L.pps_multi_create.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.pps_multi_destroy.argtypes = [C.c_void_p]
+        L.pps_multi_last_error.argtypes = [C.c_void_p]
+        L.pps_multi_last_error.restype = C.c_char_p
+        L.pps_multi_optimize.argtypes = [C.c_void_p, _ip, _ip]
+        L.pps_multi_rounds.argtypes = [C.c_void_p, _ip]
+        L.pps_multi_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.pps_multi_phase_times.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_longlong)]
         L.pps_popup_fill_depth.argtypes = [C.c_void_p]
         L.pps_popup_plane_info.argtypes = [C.c_void_p, C.c_float, _ip, C.c_int, _fp, _ip]
         L.pps_frames_set_calibration.argtypes = [C.c_void_p, _fp]
@@ -591,6 +600,52 @@ class Popup:
 
     def last_kernel_time(self):
         s = C.c_double(); self._ck(self.L.pps_popup_last_kernel_time(self.h, C.byref(s))); return s.value
+
+
+class Multi:
+    """pps_multi: independent graphs solved side by side, every kernel of an LM trial launched once for all of them"""
+
+    def __init__(self, graphs):
+        self.L = lib()
+        self.graphs = list(graphs)                       # keeps the handles alive
+        arr = (C.c_void_p * len(self.graphs))(*[g.h for g in self.graphs])
+        self.h = C.c_void_p()
+        rc = self.L.pps_multi_create(len(self.graphs), arr, C.byref(self.h))
+        if rc != 0:
+            raise PpsError(rc, "pps_multi_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pps_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def optimize(self, check=True):
+        """-> (iterations per graph, status per graph)"""
+        n = len(self.graphs)
+        it = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+        rc = self.L.pps_multi_optimize(self.h, it.ctypes.data_as(_ip), st.ctypes.data_as(_ip))
+        if rc != 0 and check:
+            raise PpsError(rc, (self.L.pps_multi_last_error(self.h) or b"").decode())
+        return it, st
+
+    def rounds(self):
+        r = C.c_int(); self.L.pps_multi_rounds(self.h, C.byref(r)); return r.value
+
+    def set_profiling(self, level=1):
+        self.L.pps_multi_set_profiling(self.h, level)
+
+    def phase_times(self):
+        """device seconds of the last optimize (profiling on): dict of K1 / K2 / factor / backsolve / trial + relinearisations, solves"""
+        t = np.zeros(5); c = (C.c_longlong * 2)()
+        self.L.pps_multi_phase_times(self.h, t.ctypes.data_as(_dp), c)
+        return {"linearize": t[0], "assemble": t[1], "factor": t[2], "backsolve": t[3], "trial": t[4],
+                "n_relinearized": int(c[0]), "n_solves": int(c[1])}
 
 
 def _flatten_polys(polys):

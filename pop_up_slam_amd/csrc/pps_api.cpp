@@ -1210,6 +1210,312 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   return PPS_OK;
 }
 
+// =========================================================================================
+// pps_multi: G independent graphs solved side by side.  One C2-size solve is a dependency chain that keeps a few dozen
+// of the 256 CUs busy; here every kernel of an LM trial is launched ONCE for all graphs (blockIdx.y = graph) and the
+// graphs advance in lockstep rounds -- a round = [re-linearise the graphs whose last trial was accepted] + factor +
+// solve + trial step + chi2 for every graph still iterating.  Per-graph lambda / accept / reject run on the host from
+// one 32-byte record per graph and round, with exactly the control flow (and the arithmetic) of pps_batch_optimize.
+// =========================================================================================
+struct pps_multi {
+  std::vector<pps_graph*> gs;
+  int device = 0;
+  std::string err;
+  hipStream_t stream = nullptr;
+  DevGraph* d_gs = nullptr; size_t cap_gs = 0;
+  BatchStage* d_stage = nullptr; size_t cap_stage = 0;
+  double* results = nullptr;      // pinned: 8 doubles per graph
+  double seq = 0.0;
+  int rounds = 0; double t_total = 0;
+  // profiling (pps_multi_set_profiling): HIP events at the phase boundaries of every round, resolved after the solve
+  int profiling = 0;
+  std::vector<hipEvent_t> evs; size_t ev_used = 0;
+  double t_phase[5] = {0, 0, 0, 0, 0};     // K1 | K2 | factor | back-substitution | trial step + chi2   [seconds, device]
+  long long n_relin = 0, n_solves = 0;      // graphs re-linearised / factorised, summed over the rounds
+};
+
+static int mfail(pps_multi* m, int code, const std::string& msg) { if (m) m->err = msg; return code; }
+#define MHIP(m, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return mfail(m, PPS_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+int pps_multi_create(int n, pps_graph* const* graphs, pps_multi** out) {
+  if (!out || n < 1 || !graphs) return PPS_EINVAL;
+  for (int i = 0; i < n; i++) {
+    if (!graphs[i]) return PPS_EINVAL;
+    if (graphs[i]->props.device != graphs[0]->props.device) return PPS_EINVAL;
+    for (int j = 0; j < i; j++) if (graphs[j] == graphs[i]) return PPS_EINVAL;
+  }
+  pps_multi* m = new (std::nothrow) pps_multi();
+  if (!m) return PPS_ENOMEM;
+  m->gs.assign(graphs, graphs + n);
+  m->device = graphs[0]->props.device;
+  *out = m;
+  return PPS_OK;
+}
+
+int pps_multi_destroy(pps_multi* m) {
+  if (!m) return PPS_EINVAL;
+  if (m->stream) {
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipStreamDestroy(m->stream);
+  }
+  for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);
+  if (m->d_gs) (void)hipFree(m->d_gs);
+  if (m->d_stage) (void)hipFree(m->d_stage);
+  if (m->results) (void)hipHostFree(m->results);
+  delete m;
+  return PPS_OK;
+}
+
+const char* pps_multi_last_error(const pps_multi* m) { return m ? m->err.c_str() : "null handle"; }
+
+int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
+  if (!m) return PPS_EINVAL;
+  const double t0 = now_s();
+  const int G = (int)m->gs.size();
+  if (hipSetDevice(m->device) != hipSuccess) return mfail(m, PPS_EHIP, "hipSetDevice failed (no HIP device: there is no CPU fallback)");
+  // ---- every graph analysed, uploaded and idle; all of them must take the wave-per-front path ----
+  int mode = m->gs[0]->props.jacobian_mode, max_stages = 0;
+  for (int i = 0; i < G; i++) {
+    pps_graph* g = m->gs[i];
+    reset_solve_stats(g);
+    g->tr_lambda.clear(); g->tr_chi2.clear(); g->tr_acc.clear();
+    int rc = prepare_solve(g);
+    if (rc != PPS_OK) return mfail(m, rc, "graph " + std::to_string(i) + ": " + g->err);
+    if (!g->use_band) return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + " has fronts beyond the wave-per-front kernels (loop closures): solve it through its own handle");
+    if (g->n_live_factors == 0) return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + " has no factors");
+    if (g->props.jacobian_mode != mode) return mfail(m, PPS_EINVAL, "all graphs of a batch share one jacobian_mode");
+    if (g->an.n_stages > 32) return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + ": elimination tree too deep for the batched schedule");
+    MHIP(m, hipStreamSynchronize(g->stream));
+    if (g->stream_b) MHIP(m, hipStreamSynchronize(g->stream_b));
+    max_stages = std::max(max_stages, g->an.n_stages);
+  }
+  if (!m->stream) MHIP(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  if (!m->results) MHIP(m, hipHostMalloc(reinterpret_cast<void**>(&m->results), sizeof(double) * 8 * (size_t)G, hipHostMallocDefault));
+  memset(m->results, 0, sizeof(double) * 8 * (size_t)G);
+  // ---- device tables: the graphs' records and their band schedules ----
+  std::vector<DevGraph> hg(G);
+  std::vector<BatchStage> hs((size_t)std::max(1, max_stages) * G, BatchStage{0, 0});
+  for (int i = 0; i < G; i++) {
+    hg[i] = m->gs[i]->dev;
+    const Analysis& A = m->gs[i]->an;
+    for (int stg = 0; stg < A.n_stages; stg++) hs[(size_t)stg * G + i] = BatchStage{A.stage_grp_off[stg], A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]};
+  }
+  if (m->cap_gs < (size_t)G) { if (m->d_gs) (void)hipFree(m->d_gs); m->d_gs = nullptr; MHIP(m, hipMalloc(reinterpret_cast<void**>(&m->d_gs), sizeof(DevGraph) * (size_t)G)); m->cap_gs = G; }
+  if (m->cap_stage < hs.size()) { if (m->d_stage) (void)hipFree(m->d_stage); m->d_stage = nullptr; MHIP(m, hipMalloc(reinterpret_cast<void**>(&m->d_stage), sizeof(BatchStage) * hs.size())); m->cap_stage = hs.size(); }
+  MHIP(m, hipMemcpy(m->d_gs, hg.data(), sizeof(DevGraph) * (size_t)G, hipMemcpyHostToDevice));
+  MHIP(m, hipMemcpy(m->d_stage, hs.data(), sizeof(BatchStage) * hs.size(), hipMemcpyHostToDevice));
+  // ---- launch geometry per chunk of kBatchMax graphs ----
+  const int n_chunks = (G + kBatchMax - 1) / kBatchMax;
+  std::vector<BatchGeom> geom(n_chunks);
+  const size_t lds_budget = 150 * 1024;
+  for (int c = 0; c < n_chunks; c++) {
+    BatchGeom& q = geom[c];
+    q.n_stages = max_stages;
+    int max_panel[32] = {0};
+    for (int stg = 0; stg < 32; stg++) q.stage_reg_only[stg] = true;
+    for (int i = c * kBatchMax; i < std::min(G, (c + 1) * kBatchMax); i++) {
+      const pps_graph* g = m->gs[i];
+      const DevGraph& d = g->dev;
+      const Analysis& A = g->an;
+      q.lin_blocks = std::max(q.lin_blocks, (d.n_obs_fixed + 7) / 8 + (d.n_odo + 7) / 8 + (d.n_pp + 7) / 8 + (d.n_lp + 7) / 8);
+      q.lin_obs_blocks = std::max(q.lin_obs_blocks, (d.n_obs_fixed + 127) / 128);
+      q.lin_rest_blocks = std::max(q.lin_rest_blocks, (d.n_odo + 127) / 128 + (d.n_pp + 127) / 128 + (d.n_lp + 127) / 128);
+      q.repop_blocks = std::max(q.repop_blocks, (d.n_obs - d.n_obs_fixed + 63) / 64);
+      q.hblocks = std::max(q.hblocks, (d.n_segs + 3) / 4);
+      q.hreduce = std::max(q.hreduce, d.n_mseg);
+      q.retract = std::max(q.retract, (d.n_pose + d.n_plane + 255) / 256);
+      q.chi2 = std::max(q.chi2, d.chi2_blocks);
+      for (int stg = 0; stg < A.n_stages; stg++) {
+        q.stage_groups[stg] = std::max(q.stage_groups[stg], A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
+        q.stage_nw_factor[stg] = std::max(q.stage_nw_factor[stg], g->stage_nw_factor[stg]);
+        q.stage_nw_solve[stg] = std::max(q.stage_nw_solve[stg], g->stage_nw_solve[stg]);
+        q.stage_per_wave_factor[stg] = std::max(q.stage_per_wave_factor[stg], (int)(band_lds_bytes(A.stage_max_front[stg]) / sizeof(double)));
+        max_panel[stg] = std::max(max_panel[stg], g->stage_max_panel[stg]);
+        q.stage_grp_fronts[stg] = std::max(q.stage_grp_fronts[stg], g->stage_max_grp_fronts[stg]);
+        if (A.stage_max_front[stg] + 1 > band_reg_rows() || g->dev.trace) q.stage_reg_only[stg] = false;
+      }
+    }
+    for (int stg = 0; stg < max_stages; stg++) {
+      q.stage_per_wave_solve[stg] = (int)(band_solve_lds_bytes(max_panel[stg]) / sizeof(double));
+      const size_t fw = (size_t)q.stage_per_wave_factor[stg] * sizeof(double), sw = (size_t)q.stage_per_wave_solve[stg] * sizeof(double);
+      const size_t xbytes = (size_t)q.stage_grp_fronts[stg] * band_max_rows() * sizeof(double);
+      if (fw > lds_budget || xbytes + sw > lds_budget) return mfail(m, PPS_ESTATE, "a band group of this batch does not fit the LDS: solve the graphs through their own handles");
+      q.stage_nw_factor[stg] = (int)std::max<size_t>(1, std::min<size_t>(q.stage_nw_factor[stg], lds_budget / fw));
+      q.stage_nw_solve[stg] = (int)std::max<size_t>(1, std::min<size_t>(q.stage_nw_solve[stg], (lds_budget - xbytes) / sw));
+    }
+  }
+  // ---- LM state per graph ----
+  struct LM { double lambda, error, dnorm; int num_iter; bool done, swap, trial_pending, relin, active, last_notpd; int n_notpd; };
+  std::vector<LM> lm(G);
+  for (int i = 0; i < G; i++) lm[i] = LM{m->gs[i]->props.lm_lambda0, 0.0, 0.0, 0, false, false, true, true, true, false, 0};
+  auto make_args = [&](int c) {
+    BatchArgs a{};
+    a.gs = m->d_gs; a.stage_tab = m->d_stage; a.results = m->results; a.n_total = G; a.b0 = c * kBatchMax;
+    a.n = std::min(G, (c + 1) * kBatchMax) - a.b0; a.seq = m->seq;
+    for (int k = 0; k < a.n; k++) {
+      const LM& s = lm[a.b0 + k];
+      a.lambda[k] = s.lambda;
+      a.flags[k] = (unsigned char)((s.active ? BF_ACTIVE : 0) | (s.relin ? BF_RELIN : 0) | (s.swap ? BF_SWAP : 0));
+    }
+    return a;
+  };
+  auto wait_round = [&](int slot) -> int {
+    const double tw = now_s();
+    unsigned spins = 0;
+    for (int i = 0; i < G; i++) {
+      if (!lm[i].active) continue;
+      volatile double* r = m->results + 8 * (size_t)i + 4 * slot;
+      while (r[3] != m->seq) {
+        if ((++spins & 0x3ff) == 0 && now_s() - tw > 2.0) {
+          MHIP(m, hipStreamSynchronize(m->stream));
+          if (r[3] != m->seq) return mfail(m, PPS_EHIP, "result record of graph " + std::to_string(i) + " did not arrive");
+        }
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return PPS_OK;
+  };
+  m->ev_used = 0; m->n_relin = 0; m->n_solves = 0;
+  for (double& t : m->t_phase) t = 0;
+  auto mark = [&]() -> hipEvent_t {          // next event of the pool, recorded on the stream (profiling only)
+    if (!m->profiling) return nullptr;
+    if (m->ev_used == m->evs.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; m->evs.push_back(e); }
+    hipEvent_t e = m->evs[m->ev_used++];
+    (void)hipEventRecord(e, m->stream);
+    return e;
+  };
+  auto next_event = [&]() -> hipEvent_t {    // next event of the pool, recorded by the callee
+    if (!m->profiling) return nullptr;
+    if (m->ev_used == m->evs.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; m->evs.push_back(e); }
+    return m->evs[m->ev_used++];
+  };
+  // one round of one chunk: 6 events e0 | K1 | e1 | K2 | e2 | factor | e3 | solve | e4 | trial | e5
+  auto run_round = [&](const BatchArgs& a, const BatchGeom& q, bool first, bool any_relin) -> int {
+    if (first) MHIP(m, launch_batch_begin(a, q, m->stream));
+    mark();
+    if (any_relin) MHIP(m, launch_batch_linearize(a, q, mode, m->stream));
+    mark();
+    if (any_relin) MHIP(m, launch_batch_hblocks(a, q, m->stream));
+    if (first) MHIP(m, launch_batch_chi2(a, q, 0, m->stream));
+    mark();
+    hipEvent_t ef = next_event();
+    MHIP(m, launch_batch_solve(a, q, m->stream, ef));
+    mark();
+    MHIP(m, launch_batch_trial(a, q, m->stream));
+    mark();
+    return PPS_OK;
+  };
+  // ---- round 0: lin <- est, linearise, chi2 at the linearisation point, first trial ----
+  m->seq += 1.0; m->rounds = 0;
+  for (int c = 0; c < n_chunks; c++) {
+    const BatchArgs a = make_args(c);
+    int rc = run_round(a, geom[c], true, true); if (rc != PPS_OK) return rc;
+  }
+  m->n_relin += G; m->n_solves += G;
+  { int rc = wait_round(1); if (rc != PPS_OK) return rc; }
+  m->rounds++;
+  for (int i = 0; i < G; i++) {
+    pps_graph* g = m->gs[i];
+    const double* r0 = m->results + 8 * (size_t)i;
+    lm[i].error = r0[0]; g->stats.chi2_initial = r0[0];
+    lm[i].dnorm = std::sqrt(r0[5]); lm[i].last_notpd = r0[6] != 0.0; lm[i].n_notpd = lm[i].last_notpd ? 1 : 0;
+    g->stats.n_linearize = 1; g->stats.n_factorize = 1;
+  }
+  // ---- rounds: Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) per graph, in lockstep ----
+  for (;;) {
+    int n_active = 0;
+    for (int i = 0; i < G; i++) {
+      LM& s = lm[i];
+      s.active = false; s.relin = false;
+      if (s.done) continue;
+      pps_graph* g = m->gs[i];
+      const pps_props& prop = g->props;
+      if (!((prop.max_iterations <= 0 || s.num_iter < prop.max_iterations) && s.dnorm > prop.epsilon2 && s.error > prop.epsilon_abs)) { s.done = true; continue; }
+      s.num_iter++;
+      const double error_new = m->results[8 * (size_t)i + 4];
+      const double error_diff = s.error - error_new;
+      const bool accepted = error_diff > 0.;
+      g->tr_lambda.push_back(s.lambda); g->tr_chi2.push_back(error_new); g->tr_acc.push_back(accepted ? 1 : 0);
+      if (accepted) {
+        g->stats.lm_trials_accepted++;
+        if (error_diff < prop.epsilon_rel * s.error) { s.error = error_new; s.trial_pending = false; s.done = true; continue; }   // (:431-434)
+        s.lambda /= prop.lm_lambda_factor;
+        s.error = error_new;
+        s.relin = true;                                              // relinearise around the accepted point (:444)
+        g->stats.n_linearize++;
+      } else {
+        g->stats.lm_trials_rejected++;
+        s.lambda *= prop.lm_lambda_factor;
+        s.swap = !s.swap;                                            // estimate_to_linpoint: restore (:454)
+      }
+      s.active = true;
+      g->stats.n_factorize++;
+      n_active++;
+    }
+    if (n_active == 0) break;
+    m->seq += 1.0;
+    for (int c = 0; c < n_chunks; c++) {
+      const BatchArgs a = make_args(c);
+      bool any = false, any_relin = false;
+      for (int k = 0; k < a.n; k++) { any = any || (a.flags[k] & BF_ACTIVE); any_relin = any_relin || (a.flags[k] & BF_RELIN); }
+      if (!any) continue;
+      for (int k = 0; k < a.n; k++) { m->n_solves += (a.flags[k] & BF_ACTIVE) ? 1 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
+      int rc = run_round(a, geom[c], false, any_relin); if (rc != PPS_OK) return rc;
+    }
+    { int rc = wait_round(1); if (rc != PPS_OK) return rc; }
+    m->rounds++;
+    for (int i = 0; i < G; i++) {
+      if (!lm[i].active) continue;
+      const double* r1 = m->results + 8 * (size_t)i + 4;
+      lm[i].dnorm = std::sqrt(r1[1]);
+      lm[i].last_notpd = r1[2] != 0.0;
+      lm[i].n_notpd += lm[i].last_notpd ? 1 : 0;
+    }
+  }
+  MHIP(m, hipStreamSynchronize(m->stream));
+  for (size_t k = 0; k + 6 <= m->ev_used; k += 6) {          // e0 e1 e2 ef(after factor) e3 e4 in recording order
+    const hipEvent_t* e = &m->evs[k];
+    // recording order inside run_round: mark, mark, mark, next_event (= after factor), mark (after solve), mark (after trial)
+    const int from[5] = {0, 1, 2, 3, 4}, to[5] = {1, 2, 3, 4, 5};
+    for (int ph = 0; ph < 5; ph++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e[from[ph]], e[to[ph]]) == hipSuccess) m->t_phase[ph] += 1e-3 * ms;
+    }
+  }
+  // ---- hand the estimates back to the handles ----
+  int first_bad = PPS_OK;
+  m->t_total = now_s() - t0;
+  for (int i = 0; i < G; i++) {
+    pps_graph* g = m->gs[i];
+    const LM& s = lm[i];
+    // the estimate is the logical `est` copy when the last trial is still pending (it is undone), else the logical `lin`
+    // copy (linpoint_to_estimate, :466); `swap` says whether logical and physical copies are exchanged
+    if (s.swap == s.trial_pending) swap_state(g);
+    g->dev_values_newer = true;
+    g->stats.lm_iterations = s.num_iter; g->stats.chi2_final = s.error; g->stats.lambda_final = s.lambda; g->stats.last_delta_norm = s.dnorm;
+    g->stats.lm_trials_notpd = s.n_notpd; g->stats.t_total = m->t_total;
+    if (iterations) iterations[i] = s.num_iter;
+    const int st_i = s.last_notpd ? PPS_ENOTPD : PPS_OK;
+    if (st_i != PPS_OK) g->err = "normal equations not positive definite at the last LM trial";
+    if (status) status[i] = st_i;
+    if (st_i != PPS_OK && first_bad == PPS_OK) first_bad = st_i;
+  }
+  if (first_bad != PPS_OK) return mfail(m, first_bad, "at least one graph ended on a factorisation that was not positive definite (see status[])");
+  return PPS_OK;
+}
+
+int pps_multi_set_profiling(pps_multi* m, int level) { if (!m) return PPS_EINVAL; m->profiling = level > 0 ? 1 : 0; return PPS_OK; }
+
+int pps_multi_phase_times(const pps_multi* m, double sec[5], long long counts[2]) {
+  if (!m || !sec) return PPS_EINVAL;
+  for (int k = 0; k < 5; k++) sec[k] = m->t_phase[k];
+  if (counts) { counts[0] = m->n_relin; counts[1] = m->n_solves; }
+  return PPS_OK;
+}
+
+int pps_multi_rounds(const pps_multi* m, int* rounds) { if (!m || !rounds) return PPS_EINVAL; *rounds = m->rounds; return PPS_OK; }
+
 int pps_chi2(pps_graph* g, double* chi2) {
   if (!g || !chi2) return PPS_EINVAL;
   int rc = prepare_solve(g);

@@ -92,6 +92,7 @@ hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st);
 int band_max_rows();
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
+int band_reg_rows();                            // fronts up to this many rows (incl. rhs) take the register-resident path
 size_t band_lds_bytes(int max_front);           // LDS bytes one wave needs for the factor kernel
 // est <- lin ; lin <- lin (+) delta          (LM trial: Optimizer.cpp:414-416)
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st);
@@ -115,6 +116,42 @@ hipError_t launch_dense_hpush(const DevGraph& d, int max_el_per_front, double la
 hipError_t launch_dense_factor_level(const DevGraph& d, int level_begin, int level_count, const int* off_asm, int n_asm,
                                      const int* off_pan, int n_pan, const int* off_trl, int n_trl, hipStream_t st);
 hipError_t launch_dense_solve_level(const DevGraph& d, int level_begin, int level_count, int level_max_b, hipStream_t st);
+
+// ---- batched form: G independent graphs per launch (pps_multi_*) ------------------------------------------------
+// Every kernel of an LM trial is launched once for a chunk of up to kBatchMax graphs: blockIdx.y = graph, blockIdx.x =
+// the block index the single-graph kernel would have (blocks past a graph's own count exit).  The graphs' DevGraph
+// records sit in a device array; what changes from trial to trial -- who takes part, lambda, which of the two state
+// copies is the linearisation point -- travels in the kernel arguments.
+constexpr int kBatchMax = 64;
+enum { BF_ACTIVE = 1,      // the graph takes part in this round
+       BF_RELIN = 2,       // ... and is re-linearised first (its last trial was accepted)
+       BF_SWAP = 4 };      // est / lin exchanged (an odd number of rejections since the pointers were last in order)
+struct BatchStage { int grp_begin, grp_count; };
+struct BatchArgs {
+  const DevGraph* gs;          // [n_total]
+  const BatchStage* stage_tab; // [n_stages_max][n_total]
+  double* results;             // pinned host, 8 doubles per graph: [0..3] chi2 at the linearisation point, [4..7] the trial
+  int n_total, b0, n;          // graphs in the batch / first graph of this chunk / graphs in this chunk
+  int pad;
+  double seq;
+  double lambda[kBatchMax];
+  unsigned char flags[kBatchMax];
+};
+// grid extents (maxima over the graphs of the chunk) and LDS needs of one round
+struct BatchGeom {
+  int lin_blocks = 0, lin_obs_blocks = 0, lin_rest_blocks = 0, repop_blocks = 0;
+  int hblocks = 0, hreduce = 0, retract = 0, chi2 = 0;
+  int n_stages = 0;
+  int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
+  int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};
+  bool stage_reg_only[32] = {false};
+};
+hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // lin <- est for every active graph
+hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st);   // K1 of the BF_RELIN graphs
+hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st);               // K2 of the BF_RELIN graphs
+hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st);        // chi2 at lin -> results[8 b + 4 slot]
+hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor = nullptr);   // K3, lambda per graph
+hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // est <- lin, lin <- lin (+) delta, chi2 -> slot 1
 
 // Largest front (scalars incl. rhs row) the LDS path of the factor kernel accepts.
 int lds_front_limit();

@@ -15,6 +15,7 @@
 //   K4  k_retract<TRIAL> exmap per node (Slam::self_exmap/apply_exmap, Slam.cpp:216-234)
 //       k_chi2           residual-only sweep + chi^2 reduction, last block writes the pinned result record
 //                        (Slam::weighted_errors/chi2, Slam.cpp:254-268)
+#include <algorithm>
 #include <cstdlib>
 
 #include "pps_device.h"
@@ -235,12 +236,11 @@ __device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gba
 // PART 0: plane-observation edges (16 KB of staging LDS per wave); PART 1: odometry edges and priors
 // (40 KB per wave in analytic mode) -- separate launches so that the big edge class keeps its occupancy.
 template <int MODE, int PART>
-__global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const double* __restrict__ pose,
-                                                          const double* __restrict__ plane, int nb_obs, int nb_odo,
-                                                          int nb_pp) {
-  extern __shared__ double lin_lds[];
+__device__ __forceinline__ void body_linearize(const DevGraph& d, const double* __restrict__ pose,
+                                               const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx,
+                                               double* __restrict__ lin_lds) {
   double* lds_wave = lin_lds + (size_t)(threadIdx.x >> 6) * 64 * (PART == 0 ? 31 : 79);
-  int b = blockIdx.x + (PART == 0 ? 0 : nb_obs);
+  int b = bx + (PART == 0 ? 0 : nb_obs);
   if (b < nb_obs) {
     const int i0 = b * kLinBlock + (threadIdx.x & ~63);            // first factor of this wave
     const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_obs_fixed - 1);   // clamped: every lane stays active for the staged store
@@ -298,6 +298,14 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const doubl
   }
 }
 
+template <int MODE, int PART>
+__global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const double* __restrict__ pose,
+                                                          const double* __restrict__ plane, int nb_obs, int nb_odo,
+                                                          int nb_pp) {
+  extern __shared__ double lin_lds[];
+  body_linearize<MODE, PART>(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------
@@ -324,14 +332,13 @@ constexpr int kLaneGroup = 32;
 constexpr int kLanesPerBlock = 256;
 constexpr int kFactorsPerBlock = kLanesPerBlock / kLaneGroup;
 
-__global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, const double* __restrict__ pose,
-                                                                    const double* __restrict__ plane, int nb_obs, int nb_odo,
-                                                                    int nb_pp) {
+__device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const double* __restrict__ pose,
+                                                     const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx) {
   const int grp = threadIdx.x / kLaneGroup, gl = threadIdx.x % kLaneGroup;
   const int q = gl >> 1;                       // perturbed column
   const double sgn = (gl & 1) ? -1.0 : 1.0;
   const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
-  int b = blockIdx.x;
+  int b = bx;
   if (b < nb_obs) {
     const int i = b * kFactorsPerBlock + grp;
     if (i >= d.n_obs_fixed) return;
@@ -445,16 +452,22 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
   }
 }
 
+__global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, const double* __restrict__ pose,
+                                                                    const double* __restrict__ plane, int nb_obs, int nb_odo,
+                                                                    int nb_pp) {
+  body_linearize_lanes(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x);
+}
+
 // below this many factors the lane-parallel form wins (latency); above it the thread-per-factor
 // form has the higher throughput (no idle lanes)
 constexpr int kLaneParallelMaxFactors = 200000;
 
 // Pose3d_Plane3d_Factor2 edges (slots [n_obs_fixed, n_obs)): central differences in both Jacobian modes -- the
 // measurement moves with the pose perturbation (the reference differentiates it numerically too).
-__global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double* __restrict__ pose,
-                                                        const double* __restrict__ plane) {
+__device__ __forceinline__ void body_linearize_repop(const DevGraph& d, const double* __restrict__ pose,
+                                                     const double* __restrict__ plane, int bx) {
   const int n2 = d.n_obs - d.n_obs_fixed;
-  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int k = bx * 64 + threadIdx.x;
   if (k >= n2) return;
   const int i = d.n_obs_fixed + k;
   double pz[7], pl[4], ray[6], w[6], e[3], r[3], Jp[18], Jl[9];
@@ -485,6 +498,11 @@ __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double
   for (int q = 0; q < 18; q++) out[q] = Jp[q];
   for (int q = 0; q < 9; q++) out[18 + q] = Jl[q];
   for (int q = 0; q < 3; q++) out[27 + q] = r[q];
+}
+
+__global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double* __restrict__ pose,
+                                                        const double* __restrict__ plane) {
+  body_linearize_repop(d, pose, plane, blockIdx.x);
 }
 
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st) {
@@ -585,8 +603,8 @@ hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double*
 // ------------------------------------------------------------------------------------------
 // K2: one wavefront per H-block segment; lane = block entry, loop over <= seg_len contributions.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) {
-  const int seg = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
+__device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
+  const int seg = uni(bx * 4 + (threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (seg >= d.n_segs) return;
   // one coalesced load of the packed segment record, fields broadcast with v_readlane
@@ -653,9 +671,11 @@ __global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) {
   if (dst >= 0) d.Hf[dst] = acc;                          // final value (single-segment block): also where its front gathers it
 }
 
+__global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) { body_hblocks(d, blockIdx.x); }
+
 // fold the partial sums of multi-segment blocks (the ground plane's diagonal) into their first slot
-__global__ __launch_bounds__(64) void k_hreduce(DevGraph d) {
-  const int blk = d.mseg_blk[blockIdx.x];
+__device__ __forceinline__ void body_hreduce(const DevGraph& d, int bx) {
+  const int blk = d.mseg_blk[bx];
   const int size = d.blk_size[blk], nseg = d.blk_nseg[blk];
   double* __restrict__ h = d.H + d.blk_hoff[blk];
   const int lane = threadIdx.x;
@@ -672,6 +692,8 @@ __global__ __launch_bounds__(64) void k_hreduce(DevGraph d) {
   const int dst = d.blk_dst[d.blk_doff[blk] + lane];
   if (dst >= 0) d.Hf[dst] = v;
 }
+
+__global__ __launch_bounds__(64) void k_hreduce(DevGraph d) { body_hreduce(d, blockIdx.x); }
 
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st) {
   if (d.n_segs == 0) return hipSuccess;
@@ -862,6 +884,7 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
 }
 
 int band_front_limit() { return kBandMaxRows - 1; }
+int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
 size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return (fa * (fa + 1) / 2 + 64 * 5) * sizeof(double); }   // packed triangle + panel buffer
 
@@ -1266,9 +1289,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane + 64 < b) Xs[p + lane + 64] = g1;
 }
 
-__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, int lds_doubles_per_wave) {
-  extern __shared__ double lds[];
-  const int g = grp_begin + blockIdx.x;
+__device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
   double* X = lds + (size_t)nw * lds_doubles_per_wave;          // one local solution vector per front of the group
@@ -1284,13 +1305,16 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, i
   }
 }
 
+__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+}
+
 // REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the fused
 // root solve are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
 template <bool REG_ONLY>
-__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave,
-                                                     int solve_doubles_per_wave) {
-  extern __shared__ double lds[];
-  const int g = grp_begin + blockIdx.x;
+__device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave,
+                                                 int solve_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* F = lds + (size_t)wave * lds_doubles_per_wave;
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
@@ -1324,6 +1348,13 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
       __syncthreads();
     }
   }
+}
+
+template <bool REG_ONLY>
+__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave,
+                                                     int solve_doubles_per_wave) {
+  extern __shared__ double lds[];
+  body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, solve_doubles_per_wave, lds);
 }
 
 static bool g_band_attr_set[64] = {false};   // per device ordinal
@@ -1398,39 +1429,40 @@ hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_
 // ------------------------------------------------------------------------------------------
 // K4: retraction and chi^2
 // ------------------------------------------------------------------------------------------
+// pose_lin / pose_est / plane_lin / plane_est are passed explicitly: the batched form swaps them per graph
 template <bool TRIAL>
-__global__ __launch_bounds__(256) void k_retract(DevGraph d) {
-  __shared__ double red[4];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void body_retract(const DevGraph& d, double* __restrict__ pose_lin, double* __restrict__ pose_est,
+                                             double* __restrict__ plane_lin, double* __restrict__ plane_est, int bx, double* red) {
+  const int i = bx * blockDim.x + threadIdx.x;
   double dn = 0.0;
   if (i < d.n_pose) {
     double p[7], o[7], dl[6];
-    load_pose(d.pose_lin, d.pose_ld, i, p);
+    load_pose(pose_lin, d.pose_ld, i, p);
     const int off = d.pose_voff[i];
 #pragma unroll
     for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
     pose_exmap(p, dl, o);
     if (TRIAL) {
 #pragma unroll
-      for (int k = 0; k < 7; k++) { d.pose_est[(size_t)k * d.pose_ld + i] = p[k]; d.pose_lin[(size_t)k * d.pose_ld + i] = o[k]; }
+      for (int k = 0; k < 7; k++) { pose_est[(size_t)k * d.pose_ld + i] = p[k]; pose_lin[(size_t)k * d.pose_ld + i] = o[k]; }
     } else {
 #pragma unroll
-      for (int k = 0; k < 7; k++) d.pose_est[(size_t)k * d.pose_ld + i] = o[k];
+      for (int k = 0; k < 7; k++) pose_est[(size_t)k * d.pose_ld + i] = o[k];
     }
   } else if (i < d.n_pose + d.n_plane) {
     const int l = i - d.n_pose;
     double p[4], o[4], dl[3];
-    load_plane(d.plane_lin, d.plane_ld, l, p);
+    load_plane(plane_lin, d.plane_ld, l, p);
     const int off = d.plane_voff[l];
 #pragma unroll
     for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
     plane_exmap(p, dl, o);
     if (TRIAL) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) { d.plane_est[(size_t)k * d.plane_ld + l] = p[k]; d.plane_lin[(size_t)k * d.plane_ld + l] = o[k]; }
+      for (int k = 0; k < 4; k++) { plane_est[(size_t)k * d.plane_ld + l] = p[k]; plane_lin[(size_t)k * d.plane_ld + l] = o[k]; }
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) d.plane_est[(size_t)k * d.plane_ld + l] = o[k];
+      for (int k = 0; k < 4; k++) plane_est[(size_t)k * d.plane_ld + l] = o[k];
     }
   }
   // |delta|^2 partial of this block (summed by the last block of the following k_chi2)
@@ -1438,7 +1470,13 @@ __global__ __launch_bounds__(256) void k_retract(DevGraph d) {
   for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
   __syncthreads();
-  if (threadIdx.x == 0) d.dn_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) d.dn_partials[bx] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <bool TRIAL>
+__global__ __launch_bounds__(256) void k_retract(DevGraph d) {
+  __shared__ double red[4];
+  body_retract<TRIAL>(d, d.pose_lin, d.pose_est, d.plane_lin, d.plane_est, blockIdx.x, red);
 }
 
 // out <- base (+) delta, nothing else touched: the speculative LM trial (step computed for lambda * factor on the
@@ -1498,11 +1536,12 @@ hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st) {
 
 constexpr int kChiBlock = 256;
 
-__global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __restrict__ pose,
-                                                    const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
-                                                    int n_dn, double* __restrict__ out, double seq) {
+// bx: block within the graph, nb: blocks of the graph (the one that draws the last ticket reduces)
+__device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __restrict__ pose,
+                                          const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
+                                          int n_dn, double* __restrict__ out, double seq, int bx, int nb) {
   __shared__ double red[kChiBlock / 64];
-  int b = blockIdx.x;
+  int b = bx;
   double s = 0.0;
   if (b < nb_obs) {
     const int i = b * kChiBlock + threadIdx.x;
@@ -1568,18 +1607,18 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int k = 0; k < kChiBlock / 64; k++) t += red[k];
-    d.chi2_partials[blockIdx.x] = t;
+    d.chi2_partials[bx] = t;
     // publish, then take a ticket: the block that draws the last one reduces everything
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = atomicAdd(d.ticket, 1u) == gridDim.x - 1;
+    last = atomicAdd(d.ticket, 1u) == (unsigned int)(nb - 1);
   }
   __syncthreads();
   if (!last) return;
   if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
   double cs = 0.0, dn = 0.0;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += kChiBlock) cs += __hip_atomic_load(&d.chi2_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < nb; i += kChiBlock) cs += __hip_atomic_load(&d.chi2_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int i = threadIdx.x; i < n_dn; i += kChiBlock) dn += __hip_atomic_load(&d.dn_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cs += __shfl_down(cs, o, 64); dn += __shfl_down(dn, o, 64); }
@@ -1596,6 +1635,12 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
     __hip_atomic_store(&out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     *d.ticket = 0u;
   }
+}
+
+__global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __restrict__ pose,
+                                                    const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
+                                                    int n_dn, double* __restrict__ out, double seq) {
+  body_chi2(d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
 }
 
 hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, double seq, hipStream_t st) {
@@ -1620,6 +1665,195 @@ hipError_t launch_chi2_at(const DevGraph& d, const double* pose, const double* p
   const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
   hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
   return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched forms (pps_multi_*): the same bodies, blockIdx.y = graph.  The DevGraph record of the graph is read through
+// the constant address space -- it does not change while a kernel runs -- so that its fields arrive by scalar loads
+// into SGPRs exactly like the by-value kernel argument of the single-graph kernels.
+// ------------------------------------------------------------------------------------------
+// a pointer that came out of memory is generic to the compiler; these all point into HBM (or pinned host memory)
+template <class T>
+__device__ __forceinline__ T* gptr(T* p) {
+  // through an integer, so that the address-space round trip is not folded away: on gfx9 a global address and its generic
+  // form are the same 64 bits
+  return (T*)(T __attribute__((address_space(1)))*)(unsigned long long)p;
+}
+
+__device__ __forceinline__ DevGraph load_graph(const DevGraph* gp) {
+  DevGraph d = *(const DevGraph*)((const DevGraph __attribute__((address_space(4)))*)gp);   // scalar loads; unused fields drop out
+#define PPS_G(f) d.f = gptr(d.f);
+  PPS_G(pose_est) PPS_G(pose_lin) PPS_G(plane_est) PPS_G(plane_lin) PPS_G(pose_voff) PPS_G(plane_voff)
+  PPS_G(obs_pose) PPS_G(obs_plane) PPS_G(obs_meas) PPS_G(obs_w) PPS_G(obs_ray) PPS_G(odo_a) PPS_G(odo_b) PPS_G(odo_meas) PPS_G(odo_w)
+  PPS_G(pp_pose) PPS_G(pp_meas) PPS_G(pp_w) PPS_G(lp_plane) PPS_G(lp_meas) PPS_G(lp_w)
+  PPS_G(J) PPS_G(H) PPS_G(L) PPS_G(U) PPS_G(delta)
+  PPS_G(f_p) PPS_G(f_b) PPS_G(f_poff) PPS_G(f_Loff) PPS_G(f_Uoff) PPS_G(f_bidx_off) PPS_G(bidx) PPS_G(f_child_off) PPS_G(child)
+  PPS_G(f_cmap_off) PPS_G(cmap) PPS_G(level_fronts) PPS_G(f_asm_off) PPS_G(asm_blk) PPS_G(asm_lrow) PPS_G(asm_lcol) PPS_G(asm_el0) PPS_G(asm_fsz)
+  PPS_G(blk_rows) PPS_G(blk_cols) PPS_G(blk_size) PPS_G(blk_nseg) PPS_G(blk_hoff) PPS_G(seg_blk) PPS_G(seg_c0) PPS_G(seg_cnt) PPS_G(seg_hoff)
+  PPS_G(contrib) PPS_G(mseg_blk) PPS_G(f_el_off) PPS_G(el_src) PPS_G(el_tgt) PPS_G(blk_doff) PPS_G(blk_dst) PPS_G(Hf) PPS_G(f_ea_off) PPS_G(ea_tgt)
+  PPS_G(grp_lvl_off) PPS_G(glvl_front_off) PPS_G(glvl_fronts) PPS_G(frec) PPS_G(crec) PPS_G(srec)
+  PPS_G(chi2_partials) PPS_G(dn_partials) PPS_G(ticket) PPS_G(result_dev) PPS_G(trace) PPS_G(gwork)
+#undef PPS_G
+  return d;
+}
+
+#define PPS_BATCH_PROLOGUE(NEED)                                                                             \
+  const int b = blockIdx.y;                                                                                  \
+  const unsigned int fl = a.flags[b];                                                                        \
+  if ((fl & (NEED)) != (NEED)) return;                                                                       \
+  const DevGraph d = load_graph(a.gs + a.b0 + b);                                                            \
+  const bool swp = (fl & BF_SWAP) != 0;                                                                      \
+  double* const pose_lin = swp ? d.pose_est : d.pose_lin;                                                    \
+  double* const pose_est = swp ? d.pose_lin : d.pose_est;                                                    \
+  double* const plane_lin = swp ? d.plane_est : d.plane_lin;                                                 \
+  double* const plane_est = swp ? d.plane_lin : d.plane_est;                                                 \
+  (void)pose_lin; (void)pose_est; (void)plane_lin; (void)plane_est;
+
+__device__ __forceinline__ int dcdiv(int a, int b) { return (a + b - 1) / b; }
+
+// lin <- est (estimate_to_linpoint, Optimizer.cpp:376) for the graphs of the chunk
+__global__ __launch_bounds__(256) void kb_begin(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const int np = 7 * d.pose_ld, nl = 4 * d.plane_ld;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < np + nl; i += gridDim.x * 256) {
+    if (i < np) pose_lin[i] = pose_est[i]; else plane_lin[i - np] = plane_est[i - np];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) d.result_dev[threadIdx.x] = 0.0;
+}
+
+__global__ __launch_bounds__(kLanesPerBlock) void kb_linearize_lanes(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  const int nb_obs = dcdiv(d.n_obs_fixed, kFactorsPerBlock), nb_odo = dcdiv(d.n_odo, kFactorsPerBlock),
+            nb_pp = dcdiv(d.n_pp, kFactorsPerBlock), nb_lp = dcdiv(d.n_lp, kFactorsPerBlock);
+  if ((int)blockIdx.x >= nb_obs + nb_odo + nb_pp + nb_lp) return;
+  body_linearize_lanes(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x);
+}
+
+template <int MODE, int PART>
+__global__ __launch_bounds__(kLinBlock) void kb_linearize(BatchArgs a) {
+  extern __shared__ double lin_lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  const int nb_obs = dcdiv(d.n_obs_fixed, kLinBlock), nb_odo = dcdiv(d.n_odo, kLinBlock), nb_pp = dcdiv(d.n_pp, kLinBlock),
+            nb_lp = dcdiv(d.n_lp, kLinBlock);
+  if ((int)blockIdx.x >= (PART == 0 ? nb_obs : nb_odo + nb_pp + nb_lp)) return;
+  body_linearize<MODE, PART>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);
+}
+
+__global__ __launch_bounds__(64) void kb_linearize_repop(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  if ((int)blockIdx.x * 64 >= d.n_obs - d.n_obs_fixed) return;
+  body_linearize_repop(d, pose_lin, plane_lin, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256, 2) void kb_hblocks(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  if ((int)blockIdx.x * 4 >= d.n_segs) return;
+  body_hblocks(d, blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void kb_hreduce(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  if ((int)blockIdx.x >= d.n_mseg) return;
+  body_hreduce(d, blockIdx.x);
+}
+
+template <bool REG_ONLY>
+__global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
+  if ((int)blockIdx.x >= sg.grp_count) return;
+  body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, 0, lds);
+}
+
+__global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
+  if ((int)blockIdx.x >= sg.grp_count) return;
+  body_band_solve(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+}
+
+__global__ __launch_bounds__(256) void kb_retract_trial(BatchArgs a) {
+  __shared__ double red[4];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  if ((int)blockIdx.x * 256 >= d.n_pose + d.n_plane) return;
+  body_retract<true>(d, pose_lin, pose_est, plane_lin, plane_est, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(kChiBlock) void kb_chi2(BatchArgs a, int slot) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const int nb_obs = dcdiv(d.n_obs, kChiBlock), nb_odo = dcdiv(d.n_odo, kChiBlock), nb_pp = dcdiv(d.n_pp, kChiBlock),
+            nb_lp = dcdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if ((int)blockIdx.x >= nb) return;
+  body_chi2(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256), a.results + 8 * (size_t)(a.b0 + b) + 4 * slot,
+            a.seq, blockIdx.x, nb);
+}
+
+hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  hipLaunchKernelGGL(kb_begin, dim3(std::max(1, std::min(8, g.retract)), a.n), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st) {
+  if (g.repop_blocks > 0) hipLaunchKernelGGL(kb_linearize_repop, dim3(g.repop_blocks, a.n), dim3(64), 0, st, a);
+  if (mode == 0) {
+    if (g.lin_blocks > 0) hipLaunchKernelGGL(kb_linearize_lanes, dim3(g.lin_blocks, a.n), dim3(kLanesPerBlock), 0, st, a);
+  } else {
+    const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
+    if (g.lin_obs_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 0>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 1>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  if (g.hblocks > 0) hipLaunchKernelGGL(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
+  if (g.hreduce > 0) hipLaunchKernelGGL(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st) {
+  if (g.chi2 <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kb_chi2, dim3(g.chi2, a.n), dim3(kChiBlock), 0, st, a, slot);
+  return hipGetLastError();
+}
+
+static bool g_batch_attr_set[64] = {false};
+
+hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!g_batch_attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e != hipSuccess) return e;
+    g_batch_attr_set[dev & 63] = true;
+  }
+  for (int stg = 0; stg < g.n_stages; stg++) {
+    if (g.stage_groups[stg] <= 0) continue;
+    const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
+    const size_t bytes = (size_t)per_wave * nw * sizeof(double);
+    if (g.stage_reg_only[stg])
+      hipLaunchKernelGGL(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    else
+      hipLaunchKernelGGL(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+  }
+  if (after_factor) (void)hipEventRecord(after_factor, st);
+  for (int stg = g.n_stages - 1; stg >= 0; stg--) {
+    if (g.stage_groups[stg] <= 0) continue;
+    const int per_wave = g.stage_per_wave_solve[stg], nw = g.stage_nw_solve[stg];
+    const size_t bytes = ((size_t)per_wave * nw + (size_t)g.stage_grp_fronts[stg] * kBandMaxRows) * sizeof(double);
+    hipLaunchKernelGGL(kb_band_solve, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  if (g.retract > 0) hipLaunchKernelGGL(kb_retract_trial, dim3(g.retract, a.n), dim3(256), 0, st, a);
+  return launch_batch_chi2(a, g, 1, st);
 }
 
 hipError_t launch_clear_status(const DevGraph& d, hipStream_t st) {

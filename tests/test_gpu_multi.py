@@ -1,0 +1,107 @@
+"""GPU: pps_multi (G independent graphs per launch) against the single-handle path and the oracle."""
+import numpy as np
+import pytest
+
+import pop_up_slam_amd as P
+from pop_up_slam_amd import synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(g, spec, nid):
+    return (np.array([g.get_pose(int(a)) for a, t in zip(nid, spec.node_type) if t == synth.NODE_POSE]),
+            np.array([g.get_plane(int(a)) for a, t in zip(nid, spec.node_type) if t != synth.NODE_POSE]))
+
+
+def _build(specs, **props):
+    gs, nids = [], []
+    for sp in specs:
+        g = P.Graph(**props)
+        nid, _ = sp.replay(g)
+        gs.append(g); nids.append(nid)
+    return gs, nids
+
+
+@pytest.mark.parametrize("mode", [P.JAC_NUMERIC, P.JAC_ANALYTIC])
+def test_mixed_batch_is_bit_identical_to_single_handles(built, mode):
+    """graphs of different size, topology and LM length in one batch: per graph the same trace, chi2 and state -- bit for bit --
+    as its own pps_batch_optimize; and the oracle's trial count / chi2 on top"""
+    specs = [synth.small_world(5, 3, seed=1), synth.small_world(20, 6, seed=2), synth.corridor(120, 26, seed=5),
+             synth.small_world(50, 10, seed=3), synth.corridor(300, 60, seed=4), synth.corridor(120, 26, seed=6),
+             synth.corridor(60, 14, seed=7)]
+    singles, nids = _build(specs, jacobian_mode=mode)
+    ref = []
+    for g, sp, nid in zip(singles, specs, nids):
+        it = g.batch_optimize()
+        ref.append((it, g.trace(), g.chi2(), _state(g, sp, nid)))
+    batch, bnids = _build(specs, jacobian_mode=mode)
+    m = P.Multi(batch)
+    its, st = m.optimize()
+    assert np.all(st == 0)
+    assert m.rounds() == max(r[0] for r in ref) + 1
+    for k, (g, sp, nid) in enumerate(zip(batch, specs, bnids)):
+        it, tr, c, (poses, planes) = ref[k]
+        assert its[k] == it and g.trace() == tr, k
+        assert g.chi2() == c, (k, g.chi2(), c)
+        bp, bl = _state(g, sp, nid)
+        np.testing.assert_array_equal(bp, poses); np.testing.assert_array_equal(bl, planes)
+        assert g.stats()["lm_iterations"] == it
+        o = O.OracleGraph(analytic=mode); sp.replay(o)
+        assert o.batch_optimize() == it and abs(o.chi2() - c) <= 1e-7 * c
+
+
+def test_c2_batches(built):
+    """8 C4 graphs (independently seeded C2) in one batch: equal to their single-handle solves; a second call on the solved
+    batch is a no-op LM; edits between calls are picked up"""
+    import bench
+    specs = [synth.corridor(seed=s) for s in bench.C4_SEEDS]
+    singles, _ = _build(specs)
+    ref = [(g.batch_optimize(), g.chi2(), g.trace()) for g in singles]
+    batch, nids = _build(specs)
+    m = P.Multi(batch)
+    its, st = m.optimize()
+    for k, g in enumerate(batch):
+        assert (its[k], g.chi2(), g.trace()) == ref[k], k
+    its2, _ = m.optimize()                       # already at the optimum: the first trial ends every graph
+    assert np.all(its2 <= 3)
+    for k, g in enumerate(batch):
+        assert g.chi2() <= ref[k][1] * (1 + 1e-12)
+    # move a pose of graph 3 and re-solve the whole batch: only that graph has work to do
+    tq = np.array(batch[3].get_pose(int(nids[3][10]))); tq[0] += 0.3
+    batch[3].set_pose(int(nids[3][10]), tq)
+    c_before = batch[3].chi2()
+    its3, _ = m.optimize()
+    assert its3[3] >= 2 and batch[3].chi2() < c_before
+    assert abs(batch[3].chi2() - ref[3][1]) <= 1e-4 * ref[3][1]
+
+
+def test_more_graphs_than_one_chunk(built):
+    """100 graphs = two launches per kernel (chunks of 64); every graph equal to a single-handle solve of the same seed"""
+    seeds = [3 + (k % 10) for k in range(100)]
+    specs = {s: synth.corridor(60, 14, seed=s) for s in set(seeds)}
+    ref = {}
+    for s, sp in specs.items():
+        g = P.Graph(); sp.replay(g)
+        ref[s] = (g.batch_optimize(), g.chi2())
+    batch, _ = _build([specs[s] for s in seeds])
+    its, st = P.Multi(batch).optimize()
+    for k, s in enumerate(seeds):
+        assert (its[k], batch[k].chi2()) == ref[s], (k, s)
+
+
+def test_refusals(built):
+    g1 = P.Graph(); synth.small_world(5, 3, seed=1).replay(g1)
+    g2 = P.Graph(jacobian_mode=P.JAC_ANALYTIC); synth.small_world(5, 3, seed=1).replay(g2)
+    with pytest.raises(P.PpsError):
+        P.Multi([g1, g2]).optimize()             # one jacobian_mode per batch
+    with pytest.raises(P.PpsError):
+        P.Multi([g1, g1])                        # a graph appears once
+    # an unobserved landmark: not positive definite for that graph only, reported per graph
+    g3 = P.Graph(); synth.small_world(6, 3, seed=1).replay(g3); g3.add_plane(np.array([0.0, 1.0, 0.0, -3.0]))
+    g4 = P.Graph(); synth.small_world(5, 3, seed=1).replay(g4)
+    m = P.Multi([g3, g4])
+    its, st = m.optimize(check=False)
+    assert st[0] == 2 and st[1] == 0
+    o = O.OracleGraph(); synth.small_world(5, 3, seed=1).replay(o); o.batch_optimize()
+    assert abs(g4.chi2() - o.chi2()) <= 1e-7 * o.chi2()
