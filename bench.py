@@ -116,6 +116,8 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         mm = P.Multi(gs)
         its, st = mm.optimize()                                          # analysis + upload + first solve: outside the clock
         same = all((int(its[k]), gs[k].chi2()) == single[rank_seed(k)] for k in range(G))
+        same_iters = all(int(its[k]) == single[rank_seed(k)][0] for k in range(G))
+        max_rel = max(abs(gs[k].chi2() - single[rank_seed(k)][1]) / single[rank_seed(k)][1] for k in range(G))
         reps = max(2, args.steps // (10 if G >= 64 else 4))
         torch.cuda.synchronize()
         t1 = time.perf_counter(); iters = 0
@@ -132,7 +134,8 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         mm.optimize()
         ph = mm.phase_times(); mm.set_profiling(0)
         ent = {"graphs": G, "graphs_per_sec": G * reps / el, "value": iters / el, "unit": "LM iters/s", "rounds": mm.rounds(),
-               "ms_per_batch_solve": 1e3 * el / reps, "bit_identical_to_single_handle": bool(same),
+               "ms_per_batch_solve": 1e3 * el / reps, "bit_identical_to_single_handle": bool(same), "same_iteration_counts": bool(same_iters),
+               "max_rel_chi2_diff_vs_single_handle": max_rel,
                "device_seconds_per_phase": {k: ph[k] for k in ("linearize", "assemble", "factor", "backsolve", "trial")},
                "relinearisations": ph["n_relinearized"], "factorisations": ph["n_solves"]}
         if ph["factor"] > 0:

@@ -1306,6 +1306,8 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
   MHIP(m, hipMemcpy(m->d_gs, hg.data(), sizeof(DevGraph) * (size_t)G, hipMemcpyHostToDevice));
   MHIP(m, hipMemcpy(m->d_stage, hs.data(), sizeof(BatchStage) * hs.size(), hipMemcpyHostToDevice));
   // ---- launch geometry per chunk of kBatchMax graphs ----
+  int n_cu = 256;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
   const int n_chunks = (G + kBatchMax - 1) / kBatchMax;
   std::vector<BatchGeom> geom(n_chunks);
   const size_t lds_budget = 150 * 1024;
@@ -1326,6 +1328,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.hreduce = std::max(q.hreduce, d.n_mseg);
       q.retract = std::max(q.retract, (d.n_pose + d.n_plane + 255) / 256);
       q.chi2 = std::max(q.chi2, d.chi2_blocks);
+      q.n_factors_total += (long long)d.n_obs + d.n_odo + d.n_pp + d.n_lp;
       for (int stg = 0; stg < A.n_stages; stg++) {
         q.stage_groups[stg] = std::max(q.stage_groups[stg], A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
         q.stage_nw_factor[stg] = std::max(q.stage_nw_factor[stg], g->stage_nw_factor[stg]);
@@ -1336,6 +1339,9 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
         if (A.stage_max_front[stg] + 1 > band_reg_rows() || g->dev.trace) q.stage_reg_only[stg] = false;
       }
     }
+    // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
+    // hundred thousand factors per launch the thread-per-factor form has the higher throughput
+    q.lin_thread_form = q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES");
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_solve[stg] = (int)(band_solve_lds_bytes(max_panel[stg]) / sizeof(double));
       const size_t fw = (size_t)q.stage_per_wave_factor[stg] * sizeof(double), sw = (size_t)q.stage_per_wave_solve[stg] * sizeof(double);
@@ -1343,6 +1349,21 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
       if (fw > lds_budget || xbytes + sw > lds_budget) return mfail(m, PPS_ESTATE, "a band group of this batch does not fit the LDS: solve the graphs through their own handles");
       q.stage_nw_factor[stg] = (int)std::max<size_t>(1, std::min<size_t>(q.stage_nw_factor[stg], lds_budget / fw));
       q.stage_nw_solve[stg] = (int)std::max<size_t>(1, std::min<size_t>(q.stage_nw_solve[stg], (lds_budget - xbytes) / sw));
+      // Throughput, not latency, is what a batch is for.  A band group is a sub-tree (8 + 4 + 2 + 1 fronts on C2): walked
+      // by 8 waves, half of the wave-slots -- and the LDS they hold -- idle on its upper levels.  When the chunk has more
+      // groups than the device has wave-slots, fewer waves per group keep every slot on a front (2 waves: 94 % instead of
+      // 47 %); the groups of the upper stages stay wide, there the tree depth is the cost.
+      long long total_groups = 0;
+      for (int i = c * kBatchMax; i < std::min(G, (c + 1) * kBatchMax); i++) {
+        const Analysis& A = m->gs[i]->an;
+        if (stg < A.n_stages) total_groups += A.stage_grp_off[stg + 1] - A.stage_grp_off[stg];
+      }
+      if (!getenv("PPS_MULTI_WIDE") && total_groups > 0) {
+        const long long slots_f = (long long)n_cu * std::max<size_t>(1, lds_budget / fw);
+        const long long slots_s = (long long)n_cu * std::max<size_t>(1, (lds_budget - std::min(lds_budget / 2, xbytes)) / sw);
+        q.stage_nw_factor[stg] = (int)std::max<long long>(1, std::min<long long>(q.stage_nw_factor[stg], (slots_f + total_groups - 1) / total_groups));
+        q.stage_nw_solve[stg] = (int)std::max<long long>(1, std::min<long long>(q.stage_nw_solve[stg], (slots_s + total_groups - 1) / total_groups));
+      }
     }
   }
   // ---- LM state per graph ----
@@ -1394,7 +1415,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
   auto run_round = [&](const BatchArgs& a, const BatchGeom& q, bool first, bool any_relin) -> int {
     if (first) MHIP(m, launch_batch_begin(a, q, m->stream));
     mark();
-    if (any_relin) MHIP(m, launch_batch_linearize(a, q, mode, m->stream));
+    if (any_relin) MHIP(m, launch_batch_linearize(a, q, q.lin_thread_form ? mode | 2 : mode, m->stream));
     mark();
     if (any_relin) MHIP(m, launch_batch_hblocks(a, q, m->stream));
     if (first) MHIP(m, launch_batch_chi2(a, q, 0, m->stream));

@@ -141,13 +141,15 @@ struct BatchArgs {
 struct BatchGeom {
   int lin_blocks = 0, lin_obs_blocks = 0, lin_rest_blocks = 0, repop_blocks = 0;
   int hblocks = 0, hreduce = 0, retract = 0, chi2 = 0;
+  long long n_factors_total = 0;
+  bool lin_thread_form = false;   // numeric K1 as one thread per factor (many graphs) instead of 32 lanes per factor
   int n_stages = 0;
   int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
   int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};
   bool stage_reg_only[32] = {false};
 };
 hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // lin <- est for every active graph
-hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st);   // K1 of the BF_RELIN graphs
+hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st);   // K1 of the BF_RELIN graphs (mode | 2: thread-per-factor form)
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st);               // K2 of the BF_RELIN graphs
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st);        // chi2 at lin -> results[8 b + 4 slot]
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor = nullptr);   // K3, lambda per graph

@@ -1798,10 +1798,13 @@ hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_
 
 hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st) {
   if (g.repop_blocks > 0) hipLaunchKernelGGL(kb_linearize_repop, dim3(g.repop_blocks, a.n), dim3(64), 0, st, a);
+  const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   if (mode == 0) {
     if (g.lin_blocks > 0) hipLaunchKernelGGL(kb_linearize_lanes, dim3(g.lin_blocks, a.n), dim3(kLanesPerBlock), 0, st, a);
+  } else if (mode == 2) {          // numeric, one thread per factor
+    if (g.lin_obs_blocks > 0) hipLaunchKernelGGL((kb_linearize<0, 0>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<0, 1>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   } else {
-    const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
     if (g.lin_obs_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 0>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
     if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 1>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   }
