@@ -673,6 +673,81 @@ __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
 
 __global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) { body_hblocks(d, blockIdx.x); }
 
+// Throughput form (many graphs per launch): a wave takes S consecutive segments.  The three dependent round trips of a
+// segment -- record, contribution descriptors, Jacobian slices -- are each issued for all S segments before the first
+// answer is needed; the sums run in the order of body_hblocks (contribution by contribution, k ascending), bit for bit.
+template <int S>
+__device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
+  const int seg0 = uni((bx * 4 + (threadIdx.x >> 6)) * S);
+  const int lane = threadIdx.x & 63;
+  if (seg0 >= d.n_segs) return;
+  int rec[S];
+#pragma unroll
+  for (int q = 0; q < S; q++) rec[q] = (seg0 + q < d.n_segs) ? d.srec[(size_t)(seg0 + q) * 8 + (lane & 7)] : 0;
+  int rows[S], cols[S], size[S], cnt[S], hoff[S], dst[S], ii[S], jj[S];
+  bool act[S], isg[S];
+  int4 mine[S];
+#pragma unroll
+  for (int q = 0; q < S; q++) {
+    rows[q] = __builtin_amdgcn_readlane(rec[q], 0); cols[q] = __builtin_amdgcn_readlane(rec[q], 1); size[q] = __builtin_amdgcn_readlane(rec[q], 2);
+    const int c0 = __builtin_amdgcn_readlane(rec[q], 3);
+    cnt[q] = __builtin_amdgcn_readlane(rec[q], 4); hoff[q] = __builtin_amdgcn_readlane(rec[q], 5);
+    const int doff = __builtin_amdgcn_readlane(rec[q], 6), nsegb = __builtin_amdgcn_readlane(rec[q], 7);
+    mine[q] = make_int4(0, 0, 0, 0);
+    if (lane < cnt[q]) mine[q] = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
+    act[q] = lane < size[q];                                  // size 0 for a segment past the end
+    dst[q] = (act[q] && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
+    const int rc = rows[q] * cols[q];
+    isg[q] = lane >= rc;
+    const int cq = cols[q] > 0 ? cols[q] : 1;
+    ii[q] = isg[q] ? lane - rc : lane / cq;
+    jj[q] = isg[q] ? 0 : lane - (lane / cq) * cq;
+  }
+  const double* __restrict__ J = d.J;
+  double a[S][6], bb[S][6];
+#pragma unroll
+  for (int q = 0; q < S; q++) {                               // first contribution of every segment: all loads in flight together
+    const int jv = __builtin_amdgcn_readlane(mine[q].x, 0), ju = __builtin_amdgcn_readlane(mine[q].y, 0);
+    const int ro = __builtin_amdgcn_readlane(mine[q].z, 0), mm = cnt[q] > 0 ? __builtin_amdgcn_readlane(mine[q].w, 0) : 0;
+    const double* pa = J + jv + ii[q];
+    const double* pb = isg[q] ? J + ro : J + ju + jj[q];
+    const int sb = isg[q] ? 1 : cols[q];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const bool ok = act[q] && k < mm;
+      a[q][k] = ok ? pa[k * rows[q]] : 0.0;
+      bb[q][k] = ok ? pb[k * sb] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < S; q++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc += a[q][k] * bb[q][k];
+    for (int c = 1; c < cnt[q]; c++) {                        // further contributions (diagonal blocks)
+      const int jv = __builtin_amdgcn_readlane(mine[q].x, c), ju = __builtin_amdgcn_readlane(mine[q].y, c);
+      const int ro = __builtin_amdgcn_readlane(mine[q].z, c), mm = __builtin_amdgcn_readlane(mine[q].w, c);
+      const double* pa = J + jv + ii[q];
+      const double* pb = isg[q] ? J + ro : J + ju + jj[q];
+      const int sb = isg[q] ? 1 : cols[q];
+      double a2[6], b2[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const bool ok = act[q] && k < mm;
+        a2[k] = ok ? pa[k * rows[q]] : 0.0;
+        b2[k] = ok ? pb[k * sb] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc += a2[k] * b2[k];
+    }
+    if (act[q]) {
+      if (isg[q]) acc = -acc;                                 // b = -r (isam/Jacobian.h:98)
+      d.H[hoff[q] + lane] = acc;
+      if (dst[q] >= 0) d.Hf[dst[q]] = acc;
+    }
+  }
+}
+
 // fold the partial sums of multi-segment blocks (the ground plane's diagonal) into their first slot
 __device__ __forceinline__ void body_hreduce(const DevGraph& d, int bx) {
   const int blk = d.mseg_blk[bx];
@@ -1751,6 +1826,13 @@ __global__ __launch_bounds__(256, 2) void kb_hblocks(BatchArgs a) {
   body_hblocks(d, blockIdx.x);
 }
 
+constexpr int kHblocksT = 4;      // segments per wave of the throughput form
+__global__ __launch_bounds__(256) void kb_hblocks_t(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  if ((int)blockIdx.x * 4 * kHblocksT >= d.n_segs) return;
+  body_hblocks_t<kHblocksT>(d, blockIdx.x);
+}
+
 __global__ __launch_bounds__(64) void kb_hreduce(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
   if ((int)blockIdx.x >= d.n_mseg) return;
@@ -1812,7 +1894,10 @@ hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mo
 }
 
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
-  if (g.hblocks > 0) hipLaunchKernelGGL(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
+  if (g.hblocks > 0) {
+    if (g.lin_thread_form) hipLaunchKernelGGL(kb_hblocks_t, dim3((g.hblocks + kHblocksT - 1) / kHblocksT, a.n), dim3(256), 0, st, a);   // many graphs: throughput form
+    else hipLaunchKernelGGL(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
+  }
   if (g.hreduce > 0) hipLaunchKernelGGL(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
   return hipGetLastError();
 }
