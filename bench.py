@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--mode", choices=["numeric", "analytic"], default="numeric",
                     help="Jacobian mode of the sweep (numeric = reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-5 frame loop (1000 frames, ~2 s)")
     ap.add_argument("--batched-replicas", type=int, default=0, help="0 = auto (> 256 MB per sweep)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="CI only: gloo backend, no GPU work -- exercises the rank/seed/aggregation plumbing of the N>1 path")
@@ -415,6 +416,23 @@ def main():
             # headline above stays the single graph BASELINE.json's metric is quoted on.
             out["multi_graph_one_gpu"] = multi_graph_bench(P, synth, local_rank, mode, args, spec, out["roofline_k3"]["flops_per_factorisation"],
                                                            bytes_per_launch, torch)
+        if world == 1 and not args.no_c5:
+            # BASELINE config 5: 1000 synthetic 640x480 frames, pop-up (half resolution) fused with the incremental solve
+            from pop_up_slam_amd import pipeline
+            n5 = 1000
+            frames = pipeline.popup_sequence(n5)
+            pl5, g5, pp5, st5 = pipeline.gpu_pipeline(step=2)
+            t1 = time.perf_counter(); lm5 = 0; an5 = up5 = 0.0
+            for fr in frames:
+                it5 = pl5.process(fr)
+                lm5 += max(it5, 0)
+                s5 = g5.stats(); an5 += s5["t_analysis"]; up5 += s5["t_upload"]
+            e5 = time.perf_counter() - t1
+            out["c5_frame_loop"] = {"frames": n5, "frames_per_sec": n5 / e5, "lm_iterations": lm5, "final_chi2": g5.chi2(),
+                                    "host_analysis_ms_per_frame": 1e3 * an5 / n5, "upload_ms_per_frame": 1e3 * up5 / n5,
+                                    "popup_kernel_us_per_frame": 1e6 * st5["popup_kernel_s"] / n5, "points_per_frame": st5["points"] / n5,
+                                    "note": "Python frame loop over the C-ABI (tools/c5_bench.py); the C++ facade loop is tools/c5_bench_cpp.py"}
+            g5.close(); pp5.close()
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(spec)
             out["cpu_baseline"] = cb

@@ -6,8 +6,8 @@
 // Everything numeric runs on the device; per LM trial one 32-byte result record (chi2, |delta|^2,
 // not-PD flag) returns to the host for the accept / reject decision.
 #include <hip/hip_runtime.h>
-#include <malloc.h>
 
+#include <charconv>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -374,9 +374,14 @@ int run_analysis(pps_graph* g) {
       for (int gi = A.stage_grp_off[st]; gi < A.stage_grp_off[st + 1]; gi++)
         mg = std::max(mg, A.glvl_front_off[A.grp_lvl_off[gi + 1]] - A.glvl_front_off[A.grp_lvl_off[gi]]);
       g->stage_max_grp_fronts[st] = mg;
+      // per workgroup: one local solution vector per front of a group + per wave xb and the factor panel.  A group that does
+      // not fit (very wide elimination trees: hundreds of fronts in one band group) takes the graph off the band kernels.
       const size_t xbytes = (size_t)mg * band_max_rows() * sizeof(double);
-      g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, (lds_budget - std::min(lds_budget / 2, xbytes)) / band_solve_lds_bytes(g->stage_max_panel[st])));
+      const size_t per_wave = band_solve_lds_bytes(g->stage_max_panel[st]);
+      if (xbytes + per_wave > lds_budget) { g->use_band = false; g->stage_nw_solve[st] = 1; continue; }
+      g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, (lds_budget - xbytes) / per_wave));
     }
+    // (such a graph then runs on the level-per-launch kernels: its fronts are <= 127 rows by the use_band test above)
   }
   if (!g->use_band && !g->use_dense && g->an.max_front > 4096)
     return fail(g, PPS_ENOMEM, "fronts too wide for this ordering (max front " + std::to_string(g->an.max_front) +
@@ -726,12 +731,12 @@ int do_solve(pps_graph* g, double lambda) {
 
 // Wait for the result record with sequence number `seq`: spin on the pinned word the chi2 kernel writes
 // last (a few microseconds), falling back to a stream sync if it does not show up (launch failure).
-int wait_result(pps_graph* g, volatile double* slot, double seq) {
+int wait_result(pps_graph* g, volatile double* slot, double seq, hipStream_t producer = nullptr) {
   const double t0 = now_s();
   unsigned spins = 0;
   while (slot[3] != seq) {
     if ((++spins & 0x3ff) == 0 && now_s() - t0 > 0.5) {
-      HIP_TRY(g, hipStreamSynchronize(g->stream));
+      HIP_TRY(g, hipStreamSynchronize(producer ? producer : g->stream));
       if (slot[3] != seq) return fail(g, PPS_EHIP, "result record did not arrive");
       break;
     }
@@ -809,22 +814,8 @@ int pps_version(void) { return PPS_VERSION; }
 
 const char* pps_last_error(const pps_graph* g) { return g ? g->err.c_str() : "null handle"; }
 
-// The symbolic analysis of a frame loop re-creates megabytes of index vectors for every new pose.  With glibc's
-// defaults those blocks come from mmap (or are trimmed off the heap again on free), so every analysis pays the page
-// faults anew: 5.5 -> 3.1 ms on a 1000-pose graph.  Keep large blocks on the heap, once per process
-// (PPS_NO_MALLOPT=1 leaves the allocator alone).
-static void tune_allocator_once() {
-  static std::once_flag once;
-  std::call_once(once, [] {
-    if (getenv("PPS_NO_MALLOPT")) return;
-    (void)mallopt(M_MMAP_THRESHOLD, 256 << 20);
-    (void)mallopt(M_TRIM_THRESHOLD, 512 << 20);
-  });
-}
-
 int pps_graph_create(const pps_props* props, pps_graph** out) {
   if (!out) return PPS_EINVAL;
-  tune_allocator_once();
   pps_graph* g = new (std::nothrow) pps_graph();
   if (!g) return PPS_ENOMEM;
   if (props) g->props = *props; else pps_default_props(&g->props);
@@ -1006,6 +997,7 @@ int pps_update(pps_graph* g) {
   if (!g) return PPS_EINVAL;
   const double t0 = now_s();
   reset_solve_stats(g);
+  if (g->n_live_nodes > 0 && g->n_live_factors == 0) return PPS_OK;   // no factor, no step
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
   HIP_TRY(g, launch_clear_status(g->dev, g->stream));
@@ -1029,8 +1021,30 @@ int pps_update(pps_graph* g) {
   return PPS_OK;
 }
 
+static int lm_solve(pps_graph* g, int* iterations);
+
+// A failure in the middle of a solve (a HIP error: lost device, out of memory) leaves est / lin possibly exchanged and
+// speculative work in flight.  Both streams are drained and the device copy is abandoned: the next call uploads again from
+// the host's node values -- the estimate falls back to the last state the host has seen -- instead of reading half-updated
+// buffers.  (PPS_ENOTPD is not such a failure: the solve ran to its end.)
 int pps_batch_optimize(pps_graph* g, int* iterations) {
   if (!g) return PPS_EINVAL;
+  if (g->n_live_nodes > 0 && g->n_live_factors == 0) {          // nothing to optimise: chi2 = 0 ends LM before its first trial
+    reset_solve_stats(g);
+    g->tr_lambda.clear(); g->tr_chi2.clear(); g->tr_acc.clear();
+    if (iterations) *iterations = 0;
+    return PPS_OK;
+  }
+  const int rc = lm_solve(g, iterations);
+  if (rc != PPS_OK && rc != PPS_ENOTPD && g->dev_ready) {
+    (void)hipStreamSynchronize(g->stream);
+    if (g->stream_b) (void)hipStreamSynchronize(g->stream_b);
+    g->topo_dirty = true; g->dev_values_newer = false; g->dev_meas_newer = false;
+  }
+  return rc;
+}
+
+static int lm_solve(pps_graph* g, int* iterations) {
   const double t0 = now_s();
   reset_solve_stats(g);
   g->tr_lambda.clear(); g->tr_chi2.clear(); g->tr_acc.clear();
@@ -1153,7 +1167,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
         if (spec_trial_inflight) {
           // the trial for this lambda has been evaluated as well: rotate its state in (lin <- x (+) delta', est stays x;
           // the buffer of the rejected trial becomes the next spare) and take its verdict from slot2
-          rc = wait_result(g, slot2, g->seq2); if (rc != PPS_OK) return rc;
+          rc = wait_result(g, slot2, g->seq2, g->stream_b); if (rc != PPS_OK) return rc;
           double* const rej_pose = g->dev.pose_est; double* const rej_plane = g->dev.plane_est;   // after swap_state: the rejected x (+) delta
           g->dev.pose_est = g->dev.pose_lin; g->dev.plane_est = g->dev.plane_lin;                   // x
           g->dev.pose_lin = g->spec_pose; g->dev.plane_lin = g->spec_plane;                         // x (+) delta'
@@ -1998,7 +2012,13 @@ int pps_graph_save(pps_graph* g, const char* path, int precision) {
   FILE* f = fopen(path, "wb");
   if (!f) return fail(g, PPS_EINVAL, std::string("graph_save: cannot open ") + path);
   const int prec = precision <= 0 ? 6 : precision;
-  auto num = [&](double v) { fprintf(f, "%.*g", prec, v); };
+  // std::to_chars / from_chars: the format must not follow LC_NUMERIC (a host that called setlocale() with a comma decimal
+  // separator would otherwise write numbers that collide with the ", " and ";" field separators)
+  auto num = [&](double v) {
+    char b[64];
+    const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::general, prec);
+    fwrite(b, 1, (size_t)(r.ptr - b), f);
+  };
   auto pose6 = [&](const double v6[6]) {
     fputc('(', f); num(v6[0]); fputs(", ", f); num(v6[1]); fputs(", ", f); num(v6[2]); fputs("; ", f);
     num(v6[3]); fputs(", ", f); num(v6[4]); fputs(", ", f); num(v6[5]); fputc(')', f);
@@ -2068,7 +2088,14 @@ int pps_graph_load(const char* path, const pps_props* props, pps_graph** out) {
     }
     auto numbers = [](const std::string& t, std::vector<double>& o) {
       const char* p = t.c_str();
-      while (*p) { char* q; double v = strtod(p, &q); if (q == p) { p++; continue; } o.push_back(v); p = q; }
+      const char* end = p + t.size();
+      while (p < end) {
+        if (*p == '+') { p++; continue; }                      // from_chars takes no leading plus
+        double v = 0;
+        const auto r = std::from_chars(p, end, v);
+        if (r.ec != std::errc() || r.ptr == p) { p++; continue; }
+        o.push_back(v); p = r.ptr;
+      }
     };
     numbers(s.substr(po + 1, pc - po - 1), L.meas);
     const size_t bo = s.find('{', pc), bc = s.find('}', pc);

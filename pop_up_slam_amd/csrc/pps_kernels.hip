@@ -16,6 +16,7 @@
 //       k_chi2           residual-only sweep + chi^2 reduction, last block writes the pinned result record
 //                        (Slam::weighted_errors/chi2, Slam.cpp:254-268)
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "pps_device.h"
@@ -875,7 +876,7 @@ __global__ __launch_bounds__(256) void k_front_factor(DevGraph d, int level_begi
   }
 }
 
-static bool g_attr_set[64] = {false};   // per device ordinal
+static std::atomic<bool> g_attr_set[64];   // per device ordinal (idempotent set-up: a race only repeats it)
 
 hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
                                hipStream_t st) {
@@ -1432,7 +1433,7 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, 
   body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, solve_doubles_per_wave, lds);
 }
 
-static bool g_band_attr_set[64] = {false};   // per device ordinal
+static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
 
 hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
                               int fused_solve_panel, int fused_solve_group_fronts) {
@@ -1908,7 +1909,7 @@ hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, h
   return hipGetLastError();
 }
 
-static bool g_batch_attr_set[64] = {false};
+static std::atomic<bool> g_batch_attr_set[64];
 
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor) {
   int dev = 0;

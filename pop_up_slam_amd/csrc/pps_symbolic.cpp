@@ -243,6 +243,68 @@ struct Builder {
 
 }  // namespace
 
+// A fresh analysis in an Analysis that has been used before: every vector keeps its capacity, so a frame loop (one new pose
+// per call, every array a little longer than last time) does not go back to the allocator for megabytes per frame.
+void reset_keep_capacity(Analysis& A) {
+  A.node_pos.clear();
+  A.node_voff.clear();
+  A.order.clear();
+  A.f_p.clear();
+  A.f_b.clear();
+  A.f_poff.clear();
+  A.f_parent.clear();
+  A.f_level.clear();
+  A.f_Loff.clear();
+  A.f_Uoff.clear();
+  A.f_bidx_off.clear();
+  A.bidx.clear();
+  A.f_child_off.clear();
+  A.child.clear();
+  A.f_cmap_off.clear();
+  A.cmap.clear();
+  A.level_off.clear();
+  A.level_fronts.clear();
+  A.f_asm_off.clear();
+  A.asm_blk.clear();
+  A.asm_lrow.clear();
+  A.asm_lcol.clear();
+  A.asm_el0.clear();
+  A.asm_fsz.clear();
+  A.stage_grp_off.clear();
+  A.grp_lvl_off.clear();
+  A.glvl_front_off.clear();
+  A.glvl_fronts.clear();
+  A.stage_max_front.clear();
+  A.stage_max_width.clear();
+  A.blk_doff.clear();
+  A.blk_dst.clear();
+  A.f_el_off.clear();
+  A.el_src.clear();
+  A.el_tgt.clear();
+  A.f_ea_off.clear();
+  A.ea_tgt.clear();
+  A.frec.clear();
+  A.crec.clear();
+  A.srec.clear();
+  A.blk_rows.clear();
+  A.blk_cols.clear();
+  A.blk_size.clear();
+  A.blk_nseg.clear();
+  A.blk_hoff.clear();
+  A.seg_blk.clear();
+  A.seg_c0.clear();
+  A.seg_cnt.clear();
+  A.seg_hoff.clear();
+  A.contrib.clear();
+  A.n_nodes = A.n_scalars = 0;
+  A.n_fronts = A.n_levels = A.max_front = 0;
+  A.el_total = 0; A.L_size = A.U_size = 0;
+  A.n_stages = A.n_groups = A.n_glevels = 0;
+  A.ea_total = 0;
+  A.n_blocks = 0; A.n_segs = 0;
+  A.H_size = 0; A.J_size = 0;
+}
+
 namespace {
 bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
                   Analysis& A, const char** msg, bool general_ordering) {
@@ -250,7 +312,7 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
   *msg = kOk;
   const bool timing = getenv("PPS_ANALYSIS_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
-  A = Analysis();
+  reset_keep_capacity(A);
   const int N = (int)nodes.size();
   A.n_nodes = N;
   if (N == 0) { *msg = "empty graph"; return false; }

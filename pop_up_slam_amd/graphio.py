@@ -102,3 +102,37 @@ def trajectory_from_log(path, max_lines=0):
     """Dead-reckoned trajectory of a log: the initial values the loader assigns (used on the *_groundtruth files,
     whose constraints are noise-free, to recover the true trajectory)."""
     return load_edge3_log(path, max_lines).node_init
+
+
+def replay_saved_graph(path, backend):
+    """Read a file written by Graph.save / Slam::save (Slam.cpp:84-89, Graph.h:120-131; see include/pps.h) into any
+    backend with the add_* surface (the CPU oracle in the tests).  Returns {file node id: backend node id}."""
+    import re
+    nodes, factors = [], []
+    num = r"[-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?|inf|nan)"
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            name = line.split()[0]
+            ids = [int(t) for t in line[len(name):line.index("(")].split()]
+            meas = [float(t) for t in re.findall(num, line[line.index("(") + 1:line.index(")")])]
+            ut = [float(t) for t in re.findall(num, line[line.index("{") + 1:line.index("}")])] if "{" in line else []
+            (nodes if name.endswith("_Node") else factors).append((name, ids, meas, ut))
+    idmap = {}
+    for name, ids, meas, _ in nodes:
+        if name == "Pose3d_Node":
+            idmap[ids[0]] = backend.add_pose(_pose_from_xyzypr(*meas))
+        else:
+            idmap[ids[0]] = backend.add_plane(np.array(meas))
+    for name, ids, meas, ut in factors:
+        if name == "Pose3d_Pose3d_Factor":
+            backend.add_odometry(idmap[ids[0]], idmap[ids[1]], np.array(meas), np.array(ut))
+        elif name == "Pose3d_Plane3d_Factor":
+            backend.add_plane_obs(idmap[ids[0]], idmap[ids[1]], np.array(meas), np.array(ut))
+        elif len(meas) == 6:
+            backend.add_pose_prior(idmap[ids[0]], np.array(meas), np.array(ut))
+        else:
+            backend.add_plane_prior(idmap[ids[0]], np.array(meas), np.array(ut))
+    return idmap

@@ -96,3 +96,44 @@ def test_save_format(tmp_path, built):
             fx = np.array([float(t) for t in x.replace("(", " ").replace(")", " ").replace(";", " ").replace(",", " ").replace("{", " ").replace("}", " ").split()[1:]])
             fy = np.array([float(t) for t in y.replace("(", " ").replace(")", " ").replace(";", " ").replace(",", " ").replace("{", " ").replace("}", " ").split()[1:]])
             np.testing.assert_allclose(fx, fy, atol=1e-14)
+
+
+def test_graph_text_format_ignores_the_numeric_locale(tmp_path):
+    """Slam::save output must not follow LC_NUMERIC: a comma decimal separator would collide with the field separators"""
+    import locale
+    old = locale.setlocale(locale.LC_NUMERIC)
+    try:
+        for name in ("de_DE.UTF-8", "de_DE.utf8", "fr_FR.UTF-8", "de_DE"):
+            try:
+                locale.setlocale(locale.LC_NUMERIC, name)
+                break
+            except locale.Error:
+                continue
+        else:
+            pytest.skip("no comma-decimal locale installed")
+        assert locale.localeconv()["decimal_point"] == ","
+        spec = synth.small_world(5, 3, seed=1)
+        g = P.Graph(); spec.replay(g)
+        path = str(tmp_path / "g.txt")
+        g.save(path, precision=17)
+        text = open(path).read()
+        assert "0," not in text.replace(", ", " ")              # no comma decimals
+        h = P.Graph.load(path)
+        assert h.num_nodes() == g.num_nodes() and h.num_factors() == g.num_factors()
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)
+
+
+def test_saved_graph_replays_into_the_oracle(tmp_path):
+    """graphio.replay_saved_graph: the Slam::save text of a graph rebuilt in another backend has the same chi2"""
+    from oracle import oracle_py as O
+    from pop_up_slam_amd import graphio
+    spec = synth.corridor(60, 14, seed=7)
+    g = P.Graph(); spec.replay(g)
+    o1 = O.OracleGraph(); spec.replay(o1)
+    path = str(tmp_path / "g.txt")
+    g.save(path, precision=17)
+    o2 = O.OracleGraph()
+    idmap = graphio.replay_saved_graph(path, o2)
+    assert len(idmap) == g.num_nodes() and o2.num_factors() == g.num_factors()
+    assert abs(o1.chi2() - o2.chi2()) <= 1e-12 * o1.chi2()
