@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+import pop_up_slam_amd as P
 from oracle import oracle_py as O
 from pop_up_slam_amd import graphio, synth
 
