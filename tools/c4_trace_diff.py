@@ -159,6 +159,16 @@ def main():
         poses, planes = final_state(g2, spec, nid2)
         rec["state_maxabs_tight"] = {"poses": float(np.max(np.abs(poses - fx[f"s{seed}_tight_poses"]))),
                                      "planes": float(np.max(np.abs(planes - fx[f"s{seed}_tight_planes"])))}
+        # bursts from the oracle's checkpoints (chaotic seeds): per-trial relative chi2 error and verdict agreement
+        if f"s{seed}_cp0_trace" in fx.files:
+            rec["bursts"] = {}
+            for k in fx["checkpoints"]:
+                gb = P.Graph(max_iterations=int(fx["burst"])); nidb, _ = spec.replay(gb)
+                set_state(gb, spec, nidb, fx[f"s{seed}_cp{k}_poses"], fx[f"s{seed}_cp{k}_planes"])
+                gb.batch_optimize()
+                trb, trob = gb.trace(), [tuple(r) for r in fx[f"s{seed}_cp{k}_trace"]]
+                rec["bursts"][str(int(k))] = [[int(a[2]), int(b[2]), abs(a[1] - b[1]) / abs(b[1])] for a, b in zip(trb, trob)]
+                gb.close()
         g.close(); g2.close()
         print(json.dumps(rec), flush=True)
 
