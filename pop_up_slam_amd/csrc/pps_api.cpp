@@ -296,6 +296,7 @@ int run_analysis(pps_graph* g) {
     s.a = g->nodes[f.a].compact;
     s.b = f.b >= 0 ? g->nodes[f.b].compact : -1;
     s.joff = (int)(base[f.type] + (int64_t)f.slot * kJSize[f.type]);
+    s.direct_ok = (f.type == F_PLANE_OBS && !f.repop) ? 1 : 0;
     sf.push_back(s);
   }
   if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
@@ -570,6 +571,7 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
   TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec));
+  TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
   if (g->use_dense) { TRY(dev_upload(g, &g->d_dw_asm, g->dw_asm)); TRY(dev_upload(g, &g->d_dw_pan, g->dw_pan)); TRY(dev_upload(g, &g->d_dw_trl, g->dw_trl)); }
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
@@ -1339,6 +1341,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.lin_rest_blocks = std::max(q.lin_rest_blocks, (d.n_odo + 127) / 128 + (d.n_pp + 127) / 128 + (d.n_lp + 127) / 128);
       q.repop_blocks = std::max(q.repop_blocks, (d.n_obs - d.n_obs_fixed + 63) / 64);
       q.hblocks = std::max(q.hblocks, (d.n_segs + 3) / 4);
+      q.hblocks_nd = std::max(q.hblocks_nd, (d.n_nd_segs + 15) / 16);
       q.hreduce = std::max(q.hreduce, d.n_mseg);
       q.retract = std::max(q.retract, (d.n_pose + d.n_plane + 255) / 256);
       q.chi2 = std::max(q.chi2, d.chi2_blocks);
@@ -1355,7 +1358,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
-    q.lin_thread_form = q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES");
+    q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES")) || getenv("PPS_MULTI_THREAD_FORM");
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_solve[stg] = (int)(band_solve_lds_bytes(max_panel[stg]) / sizeof(double));
       const size_t fw = (size_t)q.stage_per_wave_factor[stg] * sizeof(double), sw = (size_t)q.stage_per_wave_solve[stg] * sizeof(double);

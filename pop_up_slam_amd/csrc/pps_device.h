@@ -62,6 +62,8 @@ struct DevGraph {
   int64_t* f_ea_off = nullptr; int* ea_tgt = nullptr;
   int *grp_lvl_off = nullptr, *glvl_front_off = nullptr, *glvl_fronts = nullptr;
   int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
+  int* obs_dir = nullptr;                                   // direct (pose, plane) blocks: 3 ints per plane-observation slot (pps_symbolic.h)
+  int* nd_segs = nullptr; int n_nd_segs = 0;                // H segments that are not direct
   // ---- reductions / status ----
   double* chi2_partials = nullptr;   // one per block of the residual sweep
   int chi2_blocks = 0;
@@ -140,7 +142,7 @@ struct BatchArgs {
 // grid extents (maxima over the graphs of the chunk) and LDS needs of one round
 struct BatchGeom {
   int lin_blocks = 0, lin_obs_blocks = 0, lin_rest_blocks = 0, repop_blocks = 0;
-  int hblocks = 0, hreduce = 0, retract = 0, chi2 = 0;
+  int hblocks = 0, hblocks_nd = 0, hreduce = 0, retract = 0, chi2 = 0;
   long long n_factors_total = 0;
   bool lin_thread_form = false;   // numeric K1 as one thread per factor (many graphs) instead of 32 lanes per factor
   int n_stages = 0;

@@ -236,7 +236,10 @@ __device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gba
 
 // PART 0: plane-observation edges (16 KB of staging LDS per wave); PART 1: odometry edges and priors
 // (40 KB per wave in analytic mode) -- separate launches so that the big edge class keeps its occupancy.
-template <int MODE, int PART>
+// DIRECT (many-graph batches): a plane observation that is the only contribution of its (pose, plane) block writes that H
+// block itself -- the product of its own two Jacobian blocks, summed in the order the H-block kernel uses -- into H and into
+// the front-ordered copy; kb_hblocks_t then skips those segments (60 % of the segments of a C2 graph).
+template <int MODE, int PART, bool DIRECT = false>
 __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* __restrict__ pose,
                                                const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx,
                                                double* __restrict__ lin_lds) {
@@ -251,6 +254,27 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
     load_soa<4>(d.obs_meas, d.n_obs, i, ms);
     load_soa<6>(d.obs_w, d.n_obs, i, w);
     lin_plane_obs<MODE>(pz, pl, ms, w, out);
+    if (DIRECT && b * kLinBlock + (int)threadIdx.x < d.n_obs_fixed) {
+      const int hoff = d.obs_dir[3 * (size_t)i], el0 = d.obs_dir[3 * (size_t)i + 1], rows6 = d.obs_dir[3 * (size_t)i + 2];
+      if (hoff >= 0) {
+        double* __restrict__ h = d.H + hoff;
+        double* __restrict__ hf = d.Hf + el0;
+        // block (v, u), rows = the node eliminated later: entry (i, j) = sum_k Jv[k][i] * Ju[k][j], k = 0, 1, 2
+#pragma unroll
+        for (int e = 0; e < 18; e++) {
+          const int ri = rows6 ? e / 3 : e / 6, cj = rows6 ? e - 3 * (e / 3) : e - 6 * (e / 6);
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const double av = rows6 ? out[k * 6 + ri] : out[18 + k * 3 + ri];
+            const double bv = rows6 ? out[18 + k * 3 + cj] : out[k * 6 + cj];
+            acc += av * bv;
+          }
+          h[e] = acc;
+          if (el0 >= 0) hf[e] = acc;
+        }
+      }
+    }
     if (i0 < d.n_obs_fixed) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs_fixed - i0), lds_wave);
     return;
   }
@@ -679,12 +703,18 @@ __global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) { body_hblocks(d
 // answer is needed; the sums run in the order of body_hblocks (contribution by contribution, k ascending), bit for bit.
 template <int S>
 __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
-  const int seg0 = uni((bx * 4 + (threadIdx.x >> 6)) * S);
+  const int slot0 = uni((bx * 4 + (threadIdx.x >> 6)) * S);        // position in the list of non-direct segments
   const int lane = threadIdx.x & 63;
-  if (seg0 >= d.n_segs) return;
+  if (slot0 >= d.n_nd_segs) return;
   int rec[S];
+  {
+    const int sidx = (lane >> 3) < S && slot0 + (lane >> 3) < d.n_nd_segs ? d.nd_segs[slot0 + (lane >> 3)] : -1;   // lanes 8q..8q+7: segment q
 #pragma unroll
-  for (int q = 0; q < S; q++) rec[q] = (seg0 + q < d.n_segs) ? d.srec[(size_t)(seg0 + q) * 8 + (lane & 7)] : 0;
+    for (int q = 0; q < S; q++) {
+      const int sg = __builtin_amdgcn_readlane(sidx, 8 * q);
+      rec[q] = sg >= 0 ? d.srec[(size_t)sg * 8 + (lane & 7)] : 0;
+    }
+  }
   int rows[S], cols[S], size[S], cnt[S], hoff[S], dst[S], ii[S], jj[S];
   bool act[S], isg[S];
   int4 mine[S];
@@ -1812,7 +1842,7 @@ __global__ __launch_bounds__(kLinBlock) void kb_linearize(BatchArgs a) {
   const int nb_obs = dcdiv(d.n_obs_fixed, kLinBlock), nb_odo = dcdiv(d.n_odo, kLinBlock), nb_pp = dcdiv(d.n_pp, kLinBlock),
             nb_lp = dcdiv(d.n_lp, kLinBlock);
   if ((int)blockIdx.x >= (PART == 0 ? nb_obs : nb_odo + nb_pp + nb_lp)) return;
-  body_linearize<MODE, PART>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);
+  body_linearize<MODE, PART, PART == 0>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);   // pairs with kb_hblocks_t
 }
 
 __global__ __launch_bounds__(64) void kb_linearize_repop(BatchArgs a) {
@@ -1830,7 +1860,7 @@ __global__ __launch_bounds__(256, 2) void kb_hblocks(BatchArgs a) {
 constexpr int kHblocksT = 4;      // segments per wave of the throughput form
 __global__ __launch_bounds__(256) void kb_hblocks_t(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
-  if ((int)blockIdx.x * 4 * kHblocksT >= d.n_segs) return;
+  if ((int)blockIdx.x * 4 * kHblocksT >= d.n_nd_segs) return;
   body_hblocks_t<kHblocksT>(d, blockIdx.x);
 }
 
@@ -1896,7 +1926,7 @@ hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mo
 
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
   if (g.hblocks > 0) {
-    if (g.lin_thread_form) hipLaunchKernelGGL(kb_hblocks_t, dim3((g.hblocks + kHblocksT - 1) / kHblocksT, a.n), dim3(256), 0, st, a);   // many graphs: throughput form
+    if (g.lin_thread_form) hipLaunchKernelGGL(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form, direct blocks done by K1
     else hipLaunchKernelGGL(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
   }
   if (g.hreduce > 0) hipLaunchKernelGGL(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);

@@ -303,6 +303,7 @@ void reset_keep_capacity(Analysis& A) {
   A.ea_total = 0;
   A.n_blocks = 0; A.n_segs = 0;
   A.H_size = 0; A.J_size = 0;
+  A.obs_dir.clear(); A.nd_segs.clear();
 }
 
 namespace {
@@ -606,29 +607,33 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
 
     lap("band schedule");
     // ---- 5. block-sparse H and contribution lists ----
-    struct Ctr { int pv, pu, jv, ju, roff, m; };   // (row position, column position) of the H block, then the J slices
+    struct Ctr { int pv, pu, jv, ju, roff, m, fi; };   // (row position, column position) of the H block, the J slices, the factor
     std::vector<Ctr> ctr;
     ctr.reserve(factors.size() * 3);
     A.J_size = 0;
-    for (const auto& f : factors) {
+    int n_obs_slots = 0;
+    for (size_t fi2 = 0; fi2 < factors.size(); fi2++) {
+      const auto& f = factors[fi2];
+      const int fi = (int)fi2;
+      if (f.type == F_PLANE_OBS) n_obs_slots = std::max(n_obs_slots, f.joff / kJSize[F_PLANE_OBS] + 1);
       const int m = kFDim[f.type];
       const int da = nodes[f.a].dim;
       const int db = f.b >= 0 ? nodes[f.b].dim : 0;
       const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
       A.J_size = std::max<int64_t>(A.J_size, (int64_t)roff + m);
       const int pa = A.node_pos[f.a];
-      ctr.push_back({pa, pa, ja, ja, roff, m});
+      ctr.push_back({pa, pa, ja, ja, roff, m, fi});
       if (f.b >= 0) {
         const int pb = A.node_pos[f.b];
-        ctr.push_back({pb, pb, jb, jb, roff, m});
-        if (pa > pb) ctr.push_back({pa, pb, ja, jb, roff, m});   // rows = later node
-        else         ctr.push_back({pb, pa, jb, ja, roff, m});
+        ctr.push_back({pb, pb, jb, jb, roff, m, fi});
+        if (pa > pb) ctr.push_back({pa, pb, ja, jb, roff, m, fi});   // rows = later node
+        else         ctr.push_back({pb, pa, jb, ja, roff, m, fi});
       }
     }
     // every node needs a diagonal block even when it has no factor (it will then fail as not PD)
     std::vector<char> has_diag(N, 0);
     for (auto& c : ctr) if (c.pv == c.pu) has_diag[c.pv] = 1;
-    for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({p, p, 0, 0, 0, 0});
+    for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({p, p, 0, 0, 0, 0, -1});
     // stable sort by (row position, column position): counting sort on the row, then a stable insertion sort on
     // the column inside each row (rows hold a handful of blocks; the dense nodes' rows fall back to std::stable_sort)
     {
@@ -654,6 +659,7 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     lap("  contributions sorted");
     A.contrib.clear();
     A.contrib.reserve(ctr.size() * 4);
+    A.obs_dir.assign(3 * (size_t)n_obs_slots, -1);
     std::vector<std::vector<int>> asm_of(F);   // block ids per front
     A.H_size = 0;
     for (size_t i = 0; i < ctr.size();) {
@@ -668,6 +674,16 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
       const int blk = A.n_blocks++;
       A.blk_rows.push_back(rows); A.blk_cols.push_back(cols); A.blk_size.push_back(size); A.blk_nseg.push_back(nseg);
       A.blk_hoff.push_back(A.H_size);
+      // a (pose, plane) block fed by exactly one plain plane observation: K1 may write it (see pps_symbolic.h)
+      const bool direct = v != u && cnt == 1 && ctr[i].fi >= 0 && factors[ctr[i].fi].direct_ok;
+      if (direct) {
+        const int slot = factors[ctr[i].fi].joff / kJSize[F_PLANE_OBS];
+        A.obs_dir[3 * (size_t)slot + 0] = (int)A.H_size;
+        A.obs_dir[3 * (size_t)slot + 1] = blk;                          // replaced by the block's Hf offset below
+        A.obs_dir[3 * (size_t)slot + 2] = nodes[v].type == NODE_POSE ? 1 : 0;
+      } else {
+        for (int sgi = 0; sgi < nseg; sgi++) A.nd_segs.push_back(A.n_segs + sgi);
+      }
       for (int sgi = 0; sgi < nseg; sgi++) {
         const int c0 = sgi * prm.seg_len;
         A.seg_blk.push_back(blk);
@@ -701,6 +717,7 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     A.asm_el0.reserve(A.n_blocks); A.asm_fsz.reserve(A.n_blocks);
     A.asm_blk.reserve(A.n_blocks); A.asm_lrow.reserve(A.n_blocks); A.asm_lcol.reserve(A.n_blocks);
     if (A.H_size > 0x3fffffffLL) { *msg = "H too large for int32 gather offsets"; return false; }
+    std::vector<int> blk_el0(A.n_blocks, -1);
     for (int s = 0; s < F; s++) {
       int off = 0;
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
@@ -720,6 +737,7 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
           const int rows = A.blk_rows[blk], cols = A.blk_cols[blk];
           const bool diag = blk_v[blk] == blk_u[blk];
           A.asm_el0.push_back((int)A.el_total);
+          blk_el0[blk] = (int)A.el_total;
           A.asm_fsz.push_back(fsz);
           A.el_total += diag ? rows * (rows + 1) / 2 + rows : rows * cols;
         }
@@ -728,6 +746,8 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
       for (int v : bnd[s]) loc[v] = -1;
     }
+    for (size_t k = 0; k + 2 < A.obs_dir.size(); k += 3)
+      if (A.obs_dir[k] >= 0) A.obs_dir[k + 1] = blk_el0[A.obs_dir[k + 1]];
       lap("H blocks / lists");
       // ---- packed records ----
     {

@@ -25,7 +25,8 @@ constexpr int kJSize[4] = {36 + 6, 36 + 36 + 6, 18 + 9 + 3, 9 + 3};
 constexpr int kFDim[4] = {6, 6, 3, 3};
 
 struct SymNode { int type; int dim; int rank; };        // rank: insertion index among poses (time order), -1 for planes
-struct SymFactor { int type; int a, b; int joff; };       // compact node ids (b = -1 when unary); joff: offset in the J buffer
+struct SymFactor { int type; int a, b; int joff; int direct_ok = 0; };   // compact node ids (b = -1 when unary); joff: offset in the J buffer;
+                                                                       // direct_ok: a plain plane observation (slot = joff / 30) whose pose-plane block K1 may write itself
 
 struct AnalysisParams {
   int leaf_poses = 4;      // a sub-chain with <= leaf_poses poses becomes one leaf front
@@ -110,6 +111,12 @@ struct Analysis {
   std::vector<int> contrib;              // 4 ints per contribution: jv, ju, roff, m
   int64_t H_size = 0;
   int64_t J_size = 0;
+
+  // ---- "direct" blocks: the off-diagonal H block of a (pose, plane) pair that ONE plane observation contributes to is a
+  // product of that factor's own two Jacobian blocks; the thread-per-factor sweep can write it itself (many-graph batches),
+  // and the H-block kernel then only visits the segments listed in nd_segs ----
+  std::vector<int> obs_dir;              // 3 ints per plane-observation slot: H offset (-1 = not direct), Hf offset, 1 if the pose is the row node
+  std::vector<int> nd_segs;              // segments that are not direct
 };
 
 // nodes/factors are the compacted live sets.  Returns false (with msg) on structural problems.

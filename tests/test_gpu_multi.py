@@ -108,3 +108,23 @@ def test_refusals(built):
     assert st[0] == 2 and st[1] == 0
     o = O.OracleGraph(); synth.small_world(5, 3, seed=1).replay(o); o.batch_optimize()
     assert abs(g4.chi2() - o.chi2()) <= 1e-7 * o.chi2()
+
+
+@pytest.mark.parametrize("mode", [P.JAC_NUMERIC, P.JAC_ANALYTIC])
+def test_throughput_forms_are_bit_identical(built, monkeypatch, mode):
+    """large batches switch K1 to one thread per factor (which then writes the single-contribution pose-plane blocks of H itself)
+    and K2 to the 4-segments-per-wave form over the remaining segments; forced onto a small batch here and compared with
+    single handles running the same K1 form with the ordinary K2: every H entry must come out the same, so trace, chi2 and
+    state are equal bit for bit"""
+    monkeypatch.setenv("PPS_K1_THREAD_FORM", "1")
+    specs = [synth.corridor(120, 26, seed=5), synth.small_world(50, 10, seed=3), synth.corridor(300, 60, seed=4),
+             synth.small_world(20, 6, seed=2), synth.corridor(1000, 200, seed=42)]
+    singles, nids = _build(specs, jacobian_mode=mode)
+    ref = [(g.batch_optimize(), g.trace(), g.chi2()) for g in singles]
+    monkeypatch.setenv("PPS_MULTI_THREAD_FORM", "1")
+    batch, _ = _build(specs, jacobian_mode=mode)
+    its, st = P.Multi(batch).optimize()
+    for k, g in enumerate(batch):
+        assert (its[k], g.trace(), g.chi2()) == ref[k], k
+    o = O.OracleGraph(analytic=mode); specs[2].replay(o)
+    assert o.batch_optimize() == ref[2][0] and abs(o.chi2() - ref[2][2]) <= 1e-7 * ref[2][2]
