@@ -261,6 +261,15 @@ int pps_popup_fill_depth(pps_popup* p);
 int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world);
 /* device time of the last pps_popup_run kernel (HIP events), seconds */
 int pps_popup_last_kernel_time(const pps_popup* p, double* sec);
+/* popup_plane::find_2d_3d_closed_polygon_simplemode (libs/popup_plane.cpp:409-500; simple_polygon_mode, popup_plane.h): the
+ * closed 2-D polygon of every wall plane of a frame, from the ground / wall boundary segments pps_edges_select returns
+ * (closed_segs) and the camera pose -- what pps_popup_run takes as `polys`.  walllength_threshold <= 0 (the class default,
+ * popup_plane.h:81); the wall-length cut of :502-546 relies on cv::intersectConvexConvex and is not offered.  Host code (a
+ * handful of fp32 operations per segment).  K / invK: the calibration and its inverse (popup_plane::set_calibration, :72-76).
+ *   verts      (x, y) pairs, cap_verts >= 8 * n;  poly_off[n + 2]: vertex offsets of planes 0 .. n; plane 0 (ground) is empty
+ *   a wall whose vertical lines do not reach the image boundary gets no polygon (:480-481) */
+int pps_popup_polygons_simple(const float K[9], const float invK[9], const float T_wc[16], int width, int height, const float* seg2d, int n,
+                              float* verts, int cap_verts, int* poly_off, int* n_verts);
 /* The polygon -> pixel-set rules of pps_popup_run (closed_polygons_homo_pts / cv::fillConvexPoly, popup_plane.cpp:81-116)
  * evaluated on the host by the same interval code the kernel runs (no device needed; used by the CPU tests):
  * plane_id width*height, -1 = none. */

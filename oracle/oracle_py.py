@@ -93,6 +93,7 @@ def lib():
             ("ora_popup_depth", [ip, C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.c_float, fp], None),
             ("ora_depth_fill_half", [fp, C.c_int, C.c_int, fp], None),
             ("ora_popup_mask", [fp, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip], None),
+            ("ora_popup_polygons_simple", [fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, fp, ip], C.c_int),
             ("ora_fill_convex_poly", [ip, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte)], None),
             ("ora_popup_plane_info", [fp, C.c_int, fp, fp, C.c_float, ip, C.c_int, fp, ip], None),
             ("ora_edge_default_params", [C.c_void_p], None),
@@ -345,6 +346,16 @@ def depth_fill_half(sparse):
     out = np.zeros((h, w), dtype=np.float32)
     lib().ora_depth_fill_half(pa, w, h, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
+
+
+def popup_polygons_simple(seg2d, K, T_wc, width, height):
+    """find_2d_3d_closed_polygon_simplemode (popup_plane.cpp:409-500): list of n + 1 polygons (k_i x 2), plane 0 empty"""
+    seg, ps = _f(seg2d); n = seg.reshape(-1, 4).shape[0]
+    k, pk = _f(K); ik, pik = _f(np.linalg.inv(np.asarray(K, dtype=np.float32).reshape(3, 3)).astype(np.float32)); t, pt = _f(T_wc)
+    verts = np.zeros((8 * max(1, n), 2), dtype=np.float32); off = np.zeros(n + 2, dtype=np.int32)
+    lib().ora_popup_polygons_simple(ps, n, pk, pik, pt, width, height, verts.ctypes.data_as(C.POINTER(C.c_float)),
+                                    off.ctypes.data_as(C.POINTER(C.c_int)))
+    return [verts[off[i]:off[i + 1]].copy() for i in range(n + 1)]
 
 
 def popup_mask(polys, width, height, step=1):

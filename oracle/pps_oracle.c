@@ -1568,6 +1568,99 @@ static float point_dist_lineseg_f(const float b[2], const float e[2], const floa
   return sqrtf((q[0] - p[0]) * (q[0] - p[0]) + (q[1] - p[1]) * (q[1] - p[1]));
 }
 
+/* direction_hit_boundary (libs/matrix_utils.cpp:229-270): where the ray pt + lambda * direc leaves the image.  The
+ * literals 0.0 / 1.0 are doubles there, so lambda is a double quotient rounded to float.  (-1, -1) = no hit. */
+static void direction_hit_boundary(const float pt[2], const float direc[2], int img_width, int img_height, float hit[2]) {
+  float lambd;
+  if (direc[1] < 0) {                                   /* top edge */
+    lambd = (float)((0.0 - pt[1]) / direc[1]);
+    if (lambd >= 0) {
+      const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1];
+      if ((0 <= (int)hx) && ((int)hx <= img_width - 1)) { hit[0] = hx; hit[1] = hy; return; }
+    }
+  }
+  if (direc[1] > 0) {                                   /* bottom edge (nobottom = false) */
+    lambd = (float)((img_height - 1.0 - pt[1]) / direc[1]);
+    if (lambd >= 0) {
+      const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1];
+      if ((0 <= (int)hx) && ((int)hx <= img_width - 1)) { hit[0] = hx; hit[1] = hy; return; }
+    }
+  }
+  if (direc[0] > 0) {                                   /* right edge */
+    lambd = (float)((img_width - 1.0 - pt[0]) / direc[0]);
+    if (lambd >= 0) {
+      const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1];
+      if ((0 <= (int)hy) && ((int)hy <= img_height - 1)) { hit[0] = hx; hit[1] = hy; return; }
+    }
+  }
+  if (direc[0] < 0) {                                   /* left edge */
+    lambd = (float)((0.0 - pt[0]) / direc[0]);
+    if (lambd >= 0) {
+      const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1];
+      if ((0 <= (int)hy) && ((int)hy <= img_height - 1)) { hit[0] = hx; hit[1] = hy; return; }
+    }
+  }
+  hit[0] = -1.f; hit[1] = -1.f;
+}
+
+/* popup_plane::find_2d_3d_closed_polygon_simplemode (libs/popup_plane.cpp:409-500) with walllength_threshold <= 0 (the class
+ * default, popup_plane.h:81; the cut of :502-546 needs cv::intersectConvexConvex and is not restated): one closed 2-D polygon
+ * per wall -- the ground segment, the image-boundary hits of the world-vertical lines through its two end points, and the
+ * image corners between them.  Plane 0 (ground) has no polygon in this mode (:489).
+ * The reference inverts transToWolrd with Eigen's general 4x4 inverse; here the rigid-body inverse [R' | -R' t] is used (same
+ * matrix up to fp32 rounding; Eigen's operation order cannot be restated without Eigen).
+ * verts: (x, y) pairs, at most 8 per wall; off[n + 2]: vertex offsets of planes 0 .. n.  Returns the vertex count. */
+int ora_popup_polygons_simple(const float* seg2d, int n, const float K[9], const float invK[9], const float T[16], int width, int height,
+                              float* verts, int* off) {
+  off[0] = 0; off[1] = 0;                                /* ground: void */
+  if (n <= 0) return 0;
+  float* planes = (float*)malloc(sizeof(float) * 4 * (size_t)(n + 1));
+  float* seg3d = (float*)malloc(sizeof(float) * 6 * (size_t)n);
+  ora_popup_planes_ex(seg2d, n, invK, T, planes, seg3d);   /* ground_seg3d_lines_world (:569-578) */
+  float iT[12];                                          /* rows 0..2 of invT */
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) iT[i * 4 + j] = T[j * 4 + i];
+    iT[i * 4 + 3] = -(T[0 * 4 + i] * T[3] + T[1 * 4 + i] * T[7] + T[2 * 4 + i] * T[11]);
+  }
+  int nv = 0;
+  for (int sg = 0; sg < n; sg++) {
+    float hitb[2][2];
+    for (int e = 0; e < 2; e++) {
+      float img[2][2];
+      for (int c = 0; c < 2; c++) {                      /* the ground point and the point 2 m above it (:419-427) */
+        const float Pw[3] = {seg3d[sg * 6 + 3 * e], seg3d[sg * 6 + 3 * e + 1], seg3d[sg * 6 + 3 * e + 2] + (c ? 2.f : 0.f)};
+        float Ps[3], h[3];
+        for (int i = 0; i < 3; i++) Ps[i] = iT[i * 4 + 0] * Pw[0] + iT[i * 4 + 1] * Pw[1] + iT[i * 4 + 2] * Pw[2] + iT[i * 4 + 3] * 1.f;
+        for (int i = 0; i < 3; i++) h[i] = K[i * 3 + 0] * Ps[0] + K[i * 3 + 1] * Ps[1] + K[i * 3 + 2] * Ps[2];
+        img[c][0] = h[0] / h[2]; img[c][1] = h[1] / h[2];
+      }
+      float dir[2] = {img[1][0] - img[0][0], img[1][1] - img[0][1]};
+      if (dir[1] > 0) { dir[0] = -dir[0]; dir[1] = -dir[1]; }                  /* :428-429 */
+      direction_hit_boundary(seg2d + sg * 4 + 2 * e, dir, width, height, hitb[e]);   /* :436-441 */
+    }
+    const float* p0 = seg2d + sg * 4;
+    const float* p1 = seg2d + sg * 4 + 2;
+    const float* bh = hitb[0];
+    const float* eh = hitb[1];
+    float* v = verts + 2 * (size_t)nv;
+    int k = 0;
+#define PUSH(x, y) do { v[2 * k] = (x); v[2 * k + 1] = (y); k++; } while (0)
+    PUSH(p0[0], p0[1]); PUSH(p1[0], p1[1]);
+    if ((eh[0] != p1[0]) || (eh[1] != p1[1])) PUSH(eh[0], eh[1]);                                  /* :462 */
+    if (0 < bh[0] && bh[0] < width - 1 && eh[0] == width - 1) PUSH((float)(width - 1), 0.f);     /* :464-466 */
+    if (bh[0] == 0 && eh[0] == width - 1) { PUSH((float)(width - 1), 0.f); PUSH(0.f, 0.f); }      /* :467-470 */
+    if (bh[0] == 0 && 0 < eh[0] && eh[0] < width - 1) PUSH(0.f, 0.f);                             /* :471-473 */
+    if ((bh[0] != p0[0]) || (bh[1] != p0[1])) PUSH(bh[0], bh[1]);                                  /* :474 */
+    PUSH(p0[0], p0[1]);                                                                            /* final close (:477) */
+#undef PUSH
+    if ((bh[0] == -1) || (eh[0] == -1)) k = 0;                                                    /* :480-481 */
+    nv += k;
+    off[sg + 2] = nv;
+  }
+  free(planes); free(seg3d);
+  return nv;
+}
+
 /* popup_plane.cpp:616-640 */
 void ora_popup_plane_info(const float* seg2d, int n, const float invK[9], const float T[16], float plane_cam_dist_thre,
                           const int* actual, int n_actual, float* dist_to_cam, int* good) {

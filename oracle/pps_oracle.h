@@ -155,6 +155,10 @@ void ora_popup_plane_info(const float* seg2d, int n, const float invK[9], const 
 /* popup_plane.cpp:913-917: depth map known on the even pixels -> cv::resize 0.5 (INTER_AREA for a factor of exactly 2), x 4,
  * cv::resize 2 (INTER_LINEAR).  w, h even. */
 void ora_depth_fill_half(const float* sparse, int w, int h, float* out);
+/* popup_plane::find_2d_3d_closed_polygon_simplemode (popup_plane.cpp:409-500), walllength_threshold <= 0: closed 2-D polygon
+ * of every wall (plane 0 = ground: none).  verts: up to 8 (x, y) pairs per wall; off[n + 2].  Returns the vertex count. */
+int ora_popup_polygons_simple(const float* seg2d, int n, const float K[9], const float invK[9], const float T_wc[16], int width,
+                              int height, float* verts, int* off);
 /* pps_raster_oracle.c: popup_plane::closed_polygons_homo_pts (popup_plane.cpp:81-116) per polygon -- float -> int
  * truncation, boundingRect, cv::fillConvexPoly (restated from OpenCV's published drawing.cpp), findNonZero -- composed
  * into a plane-id map (later planes overwrite, -1 = none).  step 2 = downsample_poly. */

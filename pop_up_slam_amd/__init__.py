@@ -105,7 +105,7 @@ SYMBOLS = [
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
     "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
-    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times",
+    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times", "pps_popup_polygons_simple",
 ]
 
 
@@ -169,6 +169,7 @@ def lib():
         L.pps_popup_download.argtypes = [C.c_void_p, _fp, C.c_void_p, _fp, C.POINTER(C.c_int32)]
         L.pps_popup_last_kernel_time.argtypes = [C.c_void_p, _dp]
         L.pps_popup_mask_host.argtypes = [_fp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        L.pps_popup_polygons_simple.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _ip, _ip]
         L.pps_multi_create.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.pps_multi_destroy.argtypes = [C.c_void_p]
         L.pps_multi_last_error.argtypes = [C.c_void_p]
@@ -657,6 +658,20 @@ def _flatten_polys(polys):
         if len(p):
             flat[off[i]:off[i + 1]] = np.asarray(p, dtype=np.float32).reshape(-1, 2)
     return flat, off
+
+
+def popup_polygons_simple(seg2d, K, T_wc, width, height):
+    """pps_popup_polygons_simple: list of n + 1 closed wall polygons (k_i x 2 float32; plane 0 = ground: empty)"""
+    seg = np.ascontiguousarray(seg2d, dtype=np.float32).reshape(-1, 4); n = len(seg)
+    k = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+    ik = np.ascontiguousarray(np.linalg.inv(k.reshape(3, 3)).astype(np.float32)).reshape(9)
+    t = np.ascontiguousarray(T_wc, dtype=np.float32).reshape(16)
+    verts = np.zeros((8 * max(1, n), 2), dtype=np.float32); off = np.zeros(n + 2, dtype=np.int32); nv = C.c_int()
+    rc = lib().pps_popup_polygons_simple(k.ctypes.data_as(_fp), ik.ctypes.data_as(_fp), t.ctypes.data_as(_fp), width, height,
+                                         seg.ctypes.data_as(_fp), n, verts.ctypes.data_as(_fp), len(verts), off.ctypes.data_as(_ip), C.byref(nv))
+    if rc != 0:
+        raise PpsError(rc, "pps_popup_polygons_simple")
+    return [verts[off[i]:off[i + 1]].copy() for i in range(n + 1)]
 
 
 def popup_mask_host(polys, width, height, step=1):

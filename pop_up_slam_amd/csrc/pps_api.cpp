@@ -1359,6 +1359,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
     q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES")) || getenv("PPS_MULTI_THREAD_FORM");
+    q.k1_direct = (q.lin_thread_form || mode == PPS_JAC_ANALYTIC) && !getenv("PPS_MULTI_NO_DIRECT");   // the analytic sweep always runs one thread per factor
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_solve[stg] = (int)(band_solve_lds_bytes(max_panel[stg]) / sizeof(double));
       const size_t fw = (size_t)q.stage_per_wave_factor[stg] * sizeof(double), sw = (size_t)q.stage_per_wave_solve[stg] * sizeof(double);

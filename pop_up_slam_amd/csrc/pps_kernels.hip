@@ -25,6 +25,15 @@
 
 namespace pps {
 
+// H = J'J accumulations are written as explicit multiply-adds: three kernels (k_hblocks, the batched kb_hblocks_t and the
+// direct blocks of the thread-per-factor sweep) must produce the same bits for the same block, whatever the compiler would
+// have contracted on its own.  (PPS_NO_FMA: the diagnostic build without any fused operation.)
+#ifdef PPS_NO_FMA
+#define PPS_MAC(acc, a, b) ((acc) + (a) * (b))
+#else
+#define PPS_MAC(acc, a, b) __builtin_fma((a), (b), (acc))
+#endif
+
 // PPS_TRACE=1 instrumentation: lane 0 stamps s_memtime at phase boundaries of a front
 #define PPS_TR(k) do { if (d.trace && lane == 0) d.trace[(size_t)s * 8 + (k)] = clock64(); } while (0)
 
@@ -268,7 +277,7 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
           for (int k = 0; k < 3; k++) {
             const double av = rows6 ? out[k * 6 + ri] : out[18 + k * 3 + ri];
             const double bv = rows6 ? out[18 + k * 3 + cj] : out[k * 6 + cj];
-            acc += av * bv;
+            acc = PPS_MAC(acc, av, bv);
           }
           h[e] = acc;
           if (el0 >= 0) hf[e] = acc;
@@ -672,7 +681,7 @@ __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
 #pragma unroll
     for (int u = 0; u < 2; u++)
 #pragma unroll
-      for (int k = 0; k < 6; k++) acc += a[u][k] * bb[u][k];
+      for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a[u][k], bb[u][k]);
   }
   for (; c < cnt; c++) {                                  // tail, and the single-contribution segments (most pose-plane blocks)
     const int jv = __builtin_amdgcn_readlane(mine.x, c), ju = __builtin_amdgcn_readlane(mine.y, c);
@@ -688,7 +697,7 @@ __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
       bb[k] = ok ? pb[k * sb] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) acc += a[k] * bb[k];
+    for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a[k], bb[k]);
   }
   if (!act) return;
   if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
@@ -754,7 +763,7 @@ __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
   for (int q = 0; q < S; q++) {
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) acc += a[q][k] * bb[q][k];
+    for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a[q][k], bb[q][k]);
     for (int c = 1; c < cnt[q]; c++) {                        // further contributions (diagonal blocks)
       const int jv = __builtin_amdgcn_readlane(mine[q].x, c), ju = __builtin_amdgcn_readlane(mine[q].y, c);
       const int ro = __builtin_amdgcn_readlane(mine[q].z, c), mm = __builtin_amdgcn_readlane(mine[q].w, c);
@@ -769,7 +778,7 @@ __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
         b2[k] = ok ? pb[k * sb] : 0.0;
       }
 #pragma unroll
-      for (int k = 0; k < 6; k++) acc += a2[k] * b2[k];
+      for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a2[k], b2[k]);
     }
     if (act[q]) {
       if (isg[q]) acc = -acc;                                 // b = -r (isam/Jacobian.h:98)
@@ -1835,14 +1844,14 @@ __global__ __launch_bounds__(kLanesPerBlock) void kb_linearize_lanes(BatchArgs a
   body_linearize_lanes(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x);
 }
 
-template <int MODE, int PART>
+template <int MODE, int PART, bool DIRECT>
 __global__ __launch_bounds__(kLinBlock) void kb_linearize(BatchArgs a) {
   extern __shared__ double lin_lds[];
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
   const int nb_obs = dcdiv(d.n_obs_fixed, kLinBlock), nb_odo = dcdiv(d.n_odo, kLinBlock), nb_pp = dcdiv(d.n_pp, kLinBlock),
             nb_lp = dcdiv(d.n_lp, kLinBlock);
   if ((int)blockIdx.x >= (PART == 0 ? nb_obs : nb_odo + nb_pp + nb_lp)) return;
-  body_linearize<MODE, PART, PART == 0>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);   // pairs with kb_hblocks_t
+  body_linearize<MODE, PART, DIRECT>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);   // DIRECT pairs with kb_hblocks_t
 }
 
 __global__ __launch_bounds__(64) void kb_linearize_repop(BatchArgs a) {
@@ -1915,18 +1924,24 @@ hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mo
   if (mode == 0) {
     if (g.lin_blocks > 0) hipLaunchKernelGGL(kb_linearize_lanes, dim3(g.lin_blocks, a.n), dim3(kLanesPerBlock), 0, st, a);
   } else if (mode == 2) {          // numeric, one thread per factor
-    if (g.lin_obs_blocks > 0) hipLaunchKernelGGL((kb_linearize<0, 0>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
-    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<0, 1>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
+    if (g.lin_obs_blocks > 0) {
+      if (g.k1_direct) hipLaunchKernelGGL((kb_linearize<0, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      else hipLaunchKernelGGL((kb_linearize<0, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+    }
+    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<0, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   } else {
-    if (g.lin_obs_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 0>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
-    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 1>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
+    if (g.lin_obs_blocks > 0) {
+      if (g.k1_direct) hipLaunchKernelGGL((kb_linearize<1, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      else hipLaunchKernelGGL((kb_linearize<1, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+    }
+    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
   if (g.hblocks > 0) {
-    if (g.lin_thread_form) hipLaunchKernelGGL(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form, direct blocks done by K1
+    if (g.k1_direct) hipLaunchKernelGGL(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form, direct blocks done by K1
     else hipLaunchKernelGGL(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
   }
   if (g.hreduce > 0) hipLaunchKernelGGL(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);

@@ -30,7 +30,7 @@ constexpr int kMaxPlanes = 64;
 constexpr int kMaxVerts = 512;
 
 // one wall plane from a ground segment; exact operation order of the reference (and of the oracle)
-__device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
+__host__ __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
                                              const float gs[4], float out[4], float* __restrict__ seg3d_world = nullptr,
                                              float* __restrict__ info = nullptr) {
   float Pw[2][3], zs[2];
@@ -81,7 +81,7 @@ __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, cons
   for (int k = 0; k < 4; k++) out[k] = T[0 * 4 + k] * pw[0] + T[1 * 4 + k] * pw[1] + T[2 * 4 + k] * pw[2] + T[3 * 4 + k] * pw[3];
 }
 
-__device__ __forceinline__ void ground_plane_sensor(const float* T, float gs[4]) {
+__host__ __device__ __forceinline__ void ground_plane_sensor(const float* T, float gs[4]) {
 #pragma unroll
   for (int k = 0; k < 4; k++) gs[k] = T[0 * 4 + k] * 0.f + T[1 * 4 + k] * 0.f + T[2 * 4 + k] * -1.f + T[3 * 4 + k] * 0.f;
 }
@@ -636,6 +636,87 @@ int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world) {
   PHIP(p, hipSetDevice(p->device));
   if (p->last_n > 0)
     PHIP(p, hipMemcpy(seg3d_world, p->d_planes + 4 * (kMaxPlanes + 1), sizeof(float) * 6 * (size_t)p->last_n, hipMemcpyDeviceToHost));
+  return PPS_OK;
+}
+
+// popup_plane::find_2d_3d_closed_polygon_simplemode (libs/popup_plane.cpp:409-500) with walllength_threshold <= 0 (the class
+// default, popup_plane.h:81): the closed 2-D polygon of every wall -- ground segment, image-boundary hits of the world-vertical
+// lines through its end points (direction_hit_boundary, libs/matrix_utils.cpp:229-270), image corners in between.  Sequential
+// fp32 work on a handful of segments: host code, like the segment selection of pps_edges_select.  The world ground points come
+// from the same seg_to_plane the kernels run.  (The wall-length cut of :502-546 needs cv::intersectConvexConvex: not offered.)
+namespace {
+void hit_boundary(const float pt[2], const float direc[2], int w, int h, float hit[2]) {
+  float lambd;
+  if (direc[1] < 0) {
+    lambd = (float)((0.0 - pt[1]) / direc[1]);
+    if (lambd >= 0) { const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1]; if ((0 <= (int)hx) && ((int)hx <= w - 1)) { hit[0] = hx; hit[1] = hy; return; } }
+  }
+  if (direc[1] > 0) {
+    lambd = (float)((h - 1.0 - pt[1]) / direc[1]);
+    if (lambd >= 0) { const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1]; if ((0 <= (int)hx) && ((int)hx <= w - 1)) { hit[0] = hx; hit[1] = hy; return; } }
+  }
+  if (direc[0] > 0) {
+    lambd = (float)((w - 1.0 - pt[0]) / direc[0]);
+    if (lambd >= 0) { const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1]; if ((0 <= (int)hy) && ((int)hy <= h - 1)) { hit[0] = hx; hit[1] = hy; return; } }
+  }
+  if (direc[0] < 0) {
+    lambd = (float)((0.0 - pt[0]) / direc[0]);
+    if (lambd >= 0) { const float hx = pt[0] + lambd * direc[0], hy = pt[1] + lambd * direc[1]; if ((0 <= (int)hy) && ((int)hy <= h - 1)) { hit[0] = hx; hit[1] = hy; return; } }
+  }
+  hit[0] = -1.f; hit[1] = -1.f;
+}
+}  // namespace
+
+int pps_popup_polygons_simple(const float K[9], const float invK[9], const float T_wc[16], int width, int height, const float* seg2d, int n,
+                              float* verts, int cap_verts, int* poly_off, int* n_verts) {
+  if (!K || !invK || !T_wc || !poly_off || n < 0 || width <= 0 || height <= 0 || (n > 0 && (!seg2d || !verts))) return PPS_EINVAL;
+  if (cap_verts < 8 * n) return PPS_EINVAL;
+  const float* T = T_wc;
+  poly_off[0] = 0; poly_off[1] = 0;                      // the ground has no polygon in this mode (:489)
+  float gs[4];
+  ground_plane_sensor(T, gs);
+  float iT[12];                                          // rows 0..2 of the rigid inverse of T_wc
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) iT[i * 4 + j] = T[j * 4 + i];
+    iT[i * 4 + 3] = -(T[0 * 4 + i] * T[3] + T[1 * 4 + i] * T[7] + T[2 * 4 + i] * T[11]);
+  }
+  int nv = 0;
+  for (int sg = 0; sg < n; sg++) {
+    float pl[4], s3[6];
+    seg_to_plane(seg2d + 4 * sg, invK, T, gs, pl, s3);   // s3 = ground_seg3d_lines_world row (:569-578)
+    float hitb[2][2];
+    for (int e = 0; e < 2; e++) {
+      float img[2][2];
+      for (int c = 0; c < 2; c++) {                      // the ground point and the point 2 m above it (:419-427)
+        const float Pw[3] = {s3[3 * e], s3[3 * e + 1], s3[3 * e + 2] + (c ? 2.f : 0.f)};
+        float Ps[3], hh[3];
+        for (int i = 0; i < 3; i++) Ps[i] = iT[i * 4 + 0] * Pw[0] + iT[i * 4 + 1] * Pw[1] + iT[i * 4 + 2] * Pw[2] + iT[i * 4 + 3] * 1.f;
+        for (int i = 0; i < 3; i++) hh[i] = K[i * 3 + 0] * Ps[0] + K[i * 3 + 1] * Ps[1] + K[i * 3 + 2] * Ps[2];
+        img[c][0] = hh[0] / hh[2]; img[c][1] = hh[1] / hh[2];
+      }
+      float dir[2] = {img[1][0] - img[0][0], img[1][1] - img[0][1]};
+      if (dir[1] > 0) { dir[0] = -dir[0]; dir[1] = -dir[1]; }
+      hit_boundary(seg2d + 4 * sg + 2 * e, dir, width, height, hitb[e]);
+    }
+    const float* p0 = seg2d + 4 * sg;
+    const float* p1 = p0 + 2;
+    const float* bh = hitb[0];
+    const float* eh = hitb[1];
+    float* v = verts + 2 * (size_t)nv;
+    int k = 0;
+    auto push = [&](float x, float y) { v[2 * k] = x; v[2 * k + 1] = y; k++; };
+    push(p0[0], p0[1]); push(p1[0], p1[1]);
+    if ((eh[0] != p1[0]) || (eh[1] != p1[1])) push(eh[0], eh[1]);
+    if (0 < bh[0] && bh[0] < width - 1 && eh[0] == width - 1) push((float)(width - 1), 0.f);
+    if (bh[0] == 0 && eh[0] == width - 1) { push((float)(width - 1), 0.f); push(0.f, 0.f); }
+    if (bh[0] == 0 && 0 < eh[0] && eh[0] < width - 1) push(0.f, 0.f);
+    if ((bh[0] != p0[0]) || (bh[1] != p0[1])) push(bh[0], bh[1]);
+    push(p0[0], p0[1]);
+    if ((bh[0] == -1) || (eh[0] == -1)) k = 0;
+    nv += k;
+    poly_off[sg + 2] = nv;
+  }
+  if (n_verts) *n_verts = nv;
   return PPS_OK;
 }
 
