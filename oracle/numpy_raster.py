@@ -204,3 +204,121 @@ def make_fixtures():
 
 if __name__ == "__main__":
     make_fixtures()
+
+
+# ---- simple-mode wall polygons (popup_plane::find_2d_3d_closed_polygon_simplemode, popup_plane.cpp:409-500) ---------------
+def _f32(x):
+    return np.float32(x)
+
+
+def hit_boundary(pt, d, w, h):
+    """direction_hit_boundary (matrix_utils.cpp:229-270) in numpy scalars: float32 points, double quotient rounded to float32"""
+    pt = [np.float32(pt[0]), np.float32(pt[1])]; d = [np.float32(d[0]), np.float32(d[1])]
+    def at(lam):
+        return np.float32(pt[0] + lam * d[0]), np.float32(pt[1] + lam * d[1])
+    if d[1] < 0:
+        lam = np.float32((0.0 - float(pt[1])) / float(d[1]))
+        if lam >= 0:
+            hx, hy = at(lam)
+            if 0 <= int(hx) <= w - 1:
+                return hx, hy
+    if d[1] > 0:
+        lam = np.float32((h - 1.0 - float(pt[1])) / float(d[1]))
+        if lam >= 0:
+            hx, hy = at(lam)
+            if 0 <= int(hx) <= w - 1:
+                return hx, hy
+    if d[0] > 0:
+        lam = np.float32((w - 1.0 - float(pt[0])) / float(d[0]))
+        if lam >= 0:
+            hx, hy = at(lam)
+            if 0 <= int(hy) <= h - 1:
+                return hx, hy
+    if d[0] < 0:
+        lam = np.float32((0.0 - float(pt[0])) / float(d[0]))
+        if lam >= 0:
+            hx, hy = at(lam)
+            if 0 <= int(hy) <= h - 1:
+                return hx, hy
+    return np.float32(-1), np.float32(-1)
+
+
+def polygons_simple(seg2d, K, T, width, height):
+    """numpy float32 evaluation of the simple-mode wall polygons; returns a list of n + 1 vertex arrays (plane 0 empty)"""
+    f = np.float32
+    K = np.asarray(K, dtype=f).reshape(3, 3); T = np.asarray(T, dtype=f).reshape(4, 4)
+    invK = np.linalg.inv(K).astype(f)
+    seg2d = np.asarray(seg2d, dtype=f).reshape(-1, 4)
+    gs = [f(f(f(f(T[0, k] * f(0)) + f(T[1, k] * f(0))) + f(T[2, k] * f(-1))) + f(T[3, k] * f(0))) for k in range(4)]
+    iT = np.zeros((3, 4), dtype=f)
+    for i in range(3):
+        for j in range(3):
+            iT[i, j] = T[j, i]
+        iT[i, 3] = -f(f(f(T[0, i] * T[0, 3]) + f(T[1, i] * T[1, 3])) + f(T[2, i] * T[2, 3]))
+    out = [np.zeros((0, 2), dtype=f)]
+    for s in seg2d:
+        hits = []
+        for e in range(2):
+            u, v = s[2 * e], s[2 * e + 1]
+            ray = [f(f(f(invK[i, 0] * u) + f(invK[i, 1] * v)) + f(invK[i, 2] * f(1))) for i in range(3)]
+            frac = f(-gs[3] / f(f(f(gs[0] * ray[0]) + f(gs[1] * ray[1])) + f(gs[2] * ray[2])))
+            Ps = [f(frac * ray[0]), f(frac * ray[1]), f(frac * ray[2]), f(1)]
+            Ph = [f(f(f(f(T[i, 0] * Ps[0]) + f(T[i, 1] * Ps[1])) + f(T[i, 2] * Ps[2])) + f(T[i, 3] * Ps[3])) for i in range(4)]
+            Pw = [f(Ph[0] / Ph[3]), f(Ph[1] / Ph[3]), f(0)]                      # z forced to exact zero (:575-578)
+            img = []
+            for c in range(2):
+                P = [Pw[0], Pw[1], f(Pw[2] + (f(2) if c else f(0)))]
+                S = [f(f(f(f(iT[i, 0] * P[0]) + f(iT[i, 1] * P[1])) + f(iT[i, 2] * P[2])) + f(iT[i, 3] * f(1))) for i in range(3)]
+                hh = [f(f(f(K[i, 0] * S[0]) + f(K[i, 1] * S[1])) + f(K[i, 2] * S[2])) for i in range(3)]
+                img.append((f(hh[0] / hh[2]), f(hh[1] / hh[2])))
+            d = [f(img[1][0] - img[0][0]), f(img[1][1] - img[0][1])]
+            if d[1] > 0:
+                d = [-d[0], -d[1]]
+            hits.append(hit_boundary((u, v), d, width, height))
+        p0, p1, bh, eh = (s[0], s[1]), (s[2], s[3]), hits[0], hits[1]
+        poly = [p0, p1]
+        if eh[0] != p1[0] or eh[1] != p1[1]:
+            poly.append(eh)
+        if 0 < bh[0] < width - 1 and eh[0] == width - 1:
+            poly.append((f(width - 1), f(0)))
+        if bh[0] == 0 and eh[0] == width - 1:
+            poly += [(f(width - 1), f(0)), (f(0), f(0))]
+        if bh[0] == 0 and 0 < eh[0] < width - 1:
+            poly.append((f(0), f(0)))
+        if bh[0] != p0[0] or bh[1] != p0[1]:
+            poly.append(bh)
+        poly.append(p0)
+        if bh[0] == -1 or eh[0] == -1:
+            poly = []
+        out.append(np.array(poly, dtype=f).reshape(-1, 2))
+    return out
+
+
+def make_polygon_fixtures():
+    rng = np.random.default_rng(20260928)
+    K = np.array([[535.4, 0, 320.1], [0, 539.2, 247.6], [0, 0, 1]], dtype=np.float64)       # TUM fr3 (pop_up_wall yaml)
+    cases = []
+    for k in range(40):
+        yaw, pitch, roll = rng.normal(0, 0.4), rng.normal(0, 0.12), rng.normal(0, 0.05)
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+        R0 = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=float)               # camera looks along world +y, image up = world up
+        Rp = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]]); Rr = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        T = np.eye(4); T[:3, :3] = Rz @ R0 @ Rp @ Rr; T[:3, 3] = [rng.normal(0, 0.5), rng.normal(0, 0.5), 1.0 + rng.normal(0, 0.15)]
+        n = int(rng.integers(1, 7))
+        seg = rng.uniform([0, 255, 0, 255], [639, 479, 639, 479], size=(n, 4))
+        if k % 5 == 0:
+            seg[0, 0] = 0.0                 # a segment that starts on the left image border
+        if k % 7 == 0:
+            seg[-1, 2] = 639.0              # ... ends on the right border
+        polys = polygons_simple(seg, K, T, 640, 480)
+        cases.append({"K": K.tolist(), "T": T.astype(np.float32).astype(float).tolist(), "seg2d": seg.astype(np.float32).astype(float).tolist(),
+                      "size": [640, 480], "polys": [p.astype(float).tolist() for p in polys]})
+    path = os.path.join(os.path.dirname(HERE), "tests", "golden", "polygons_simple_cases.json")
+    with open(path, "w") as f:
+        json.dump({"generator": "oracle/numpy_raster.py make_polygon_fixtures", "cases": cases}, f)
+    print("wrote", path, len(cases), "cases;", sum(len(p) > 0 for c in cases for p in c["polys"]), "non-empty polygons")
+
+
+if __name__ == "__main__" and "polygons" in os.sys.argv[1:]:
+    make_polygon_fixtures()

@@ -129,3 +129,45 @@ def test_label_and_lines_to_wall_planes(built, yaw, lateral):
         assert np.array_equal(a, b)
     assert closed.shape == (3, 4)
     E.planes_agree(P.popup_planes(closed, invK, T), P.popup_planes(true_seg, invK, T))
+
+
+def test_label_map_to_cloud_end_to_end(built):
+    """the whole front end on the reference's four sample label maps: label map + lines -> ground edges (pps_edges_select, device)
+    -> simple-mode wall polygons (pps_popup_polygons_simple, host) -> pop-up of every wall pixel (pps_popup_run, device); the
+    same chain through the oracle gives the same segments, polygons, pixel sets, planes and 3-D points, bit for bit"""
+    from pop_up_slam_amd import synth
+    K = synth.K_TUM.astype(np.float32)
+    invK = np.linalg.inv(synth.K_TUM).astype(np.float32)
+    T = synth.T_from_pose(synth.pose_from_Rt(synth.CAM_R0, np.array([0.0, 0.0, 1.0]))).astype(np.float32)
+    n_walls = 0
+    for name, lab in E.reference_labels().items():
+        h, w = lab.shape
+        pre = O.label_preprocess(lab)
+        xy, _, _ = O.ground_contour(pre)
+        lines = E.lines_from_contour(pre, xy)
+        ed = P.Edges(w, h)
+        open_segs, closed, idx = ed.select(lab, lines)
+        want = O.select_ground_edges(lab, lines)
+        for a, b in zip(want, (open_segs, closed, idx)):
+            assert np.array_equal(a, b)
+        if len(closed) == 0:
+            continue
+        polys = P.popup_polygons_simple(closed, K, T, w, h)
+        opolys = O.popup_polygons_simple(closed, K, T, w, h)
+        assert len(polys) == len(closed) + 1
+        for a, b in zip(polys, opolys):
+            np.testing.assert_array_equal(a, b)
+        pp = P.Popup(w, h, invK)
+        nv = pp.run(closed, T, polys, step=1, depth_thre=10.0, ceiling_thre=2.5)
+        planes, cloud, depth, pid = pp.download()
+        np.testing.assert_array_equal(pid, O.popup_mask(opolys, w, h, 1))
+        np.testing.assert_array_equal(planes, O.popup_planes(closed, invK, T))
+        xyz, valid = O.popup_cloud(pid, invK, T, planes, 10.0, 2.5)
+        np.testing.assert_array_equal((cloud["rgba"] >> 24) & 1, valid)
+        v = valid.astype(bool)
+        for k, c in enumerate(("x", "y", "z")):
+            np.testing.assert_array_equal(cloud[c][v], xyz[..., k][v])
+        assert nv == int(valid.sum())
+        n_walls += int(sum(len(p) > 0 for p in polys))
+        print("label %s: %d boundary segments, %d wall polygons, %d of %d pixels popped up" % (name, len(closed), sum(len(p) > 0 for p in polys), nv, w * h))
+    assert n_walls >= 4
