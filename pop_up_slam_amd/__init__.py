@@ -489,7 +489,8 @@ def parse_analysis_dump(buf):
     for name in ("n_stages", "n_groups", "n_glevels"):
         out[name] = int(buf[k]); k += 1
     for name in ("stage_grp_off", "grp_lvl_off", "glvl_front_off", "glvl_fronts", "stage_max_front", "stage_max_width",
-                 "f_el_off", "el_src", "el_tgt", "f_ea_off", "ea_tgt", "blk_doff", "blk_dst", "frec", "crec", "srec"):
+                 "f_el_off", "el_src", "el_tgt", "f_ea_off", "ea_tgt", "blk_doff", "blk_dst", "frec", "crec", "srec",
+                 "pidx", "obs_dir", "nd_segs"):
         out[name] = vec()
     for name in _DUMP_VECTORS[-2:]:
         out[name] = vec()

@@ -65,6 +65,8 @@ struct pps_graph {
   bool dev_values_newer = false;   // device estimate is newer than the host copy
   bool meas_dirty = false;
   bool analyzed = false;
+  int n_analyses = 0;              // analyses so far; with `grown_only` it selects the frame-loop form of the analysis
+  bool grown_only = true;          // nothing has been removed since the last analysis (nodes / factors were only appended)
   Analysis an;
   AnalysisParams aprm;
   std::vector<int> pose_ids, plane_ids;   // slot -> node id
@@ -257,6 +259,19 @@ int ensure_device(pps_graph* g) {
   return PPS_OK;
 }
 
+// Offsets of the four per-type slabs of the J buffer: [plane obs | odometry | pose priors | plane priors].  Every slab is
+// sized for a capacity that grows in powers of two, so that a graph that gains a few factors per frame keeps all of its J
+// offsets -- and with them the whole contribution list of the H-block kernel -- from one frame to the next.
+int64_t j_capacity(int64_t n) { int64_t c = 16; while (c < n) c <<= 1; return c; }
+void j_bases(const pps_graph* g, int64_t base[4], int64_t* total) {
+  const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(),
+                n_obs = g->fslot_ids[F_PLANE_OBS].size(), n_lp = g->fslot_ids[F_PLANE_PRIOR].size();
+  const int64_t joff_obs = 0, joff_odo = j_capacity(n_obs) * 30, joff_pp = joff_odo + j_capacity(n_odo) * 78,
+                joff_lp = joff_pp + j_capacity(n_pp) * 42;
+  base[F_POSE_PRIOR] = joff_pp; base[F_ODOMETRY] = joff_odo; base[F_PLANE_OBS] = joff_obs; base[F_PLANE_PRIOR] = joff_lp;
+  if (total) *total = joff_lp + j_capacity(n_lp) * 12;
+}
+
 // ---- compaction + symbolic analysis (host only) -------------------------------------------
 int run_analysis(pps_graph* g) {
   const double t0 = now_s();
@@ -281,11 +296,9 @@ int run_analysis(pps_graph* g) {
     }
   g->n_obs_fixed = 0;
   for (int id : g->fslot_ids[F_PLANE_OBS]) g->n_obs_fixed += g->factors[id].repop ? 0 : 1;
-  const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(),
-                n_obs = g->fslot_ids[F_PLANE_OBS].size();
-  const int64_t joff_obs = 0, joff_odo = n_obs * 30, joff_pp = joff_odo + n_odo * 78, joff_lp = joff_pp + n_pp * 42;
-  const int64_t base[4] = {joff_pp, joff_odo, joff_obs, joff_lp};
-  if (joff_lp + (int64_t)g->fslot_ids[F_PLANE_PRIOR].size() * 12 > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
+  int64_t base[4], j_total = 0;
+  j_bases(g, base, &j_total);
+  if (j_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
   std::vector<SymFactor> sf;
   sf.reserve(g->factors.size());
   for (size_t i = 0; i < g->factors.size(); i++) {
@@ -310,6 +323,9 @@ int run_analysis(pps_graph* g) {
   g->aprm.seg_len = g->pose_ids.size() >= 4000 ? 32 : 8;
   if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
   if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
+  // a graph that is re-analysed after pure appends is a frame loop: absolute cut positions keep the left part of its tree
+  g->aprm.aligned_cuts = (g->n_analyses > 0 && g->grown_only) ? 1 : 0;
+  if (const char* e = getenv("PPS_ALIGNED_CUTS")) g->aprm.aligned_cuts = atoi(e);
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
   g->aprm.band_rows = band_front_limit();
   if (const char* e = getenv("PPS_ORDERING")) g->aprm.ordering = atoi(e);
@@ -388,6 +404,7 @@ int run_analysis(pps_graph* g) {
     return fail(g, PPS_ENOMEM, "fronts too wide for this ordering (max front " + std::to_string(g->an.max_front) +
                                " scalars): the pose chain is not a good dissection backbone for this graph");
   g->analyzed = true;
+  g->n_analyses++; g->grown_only = true;
   g->stats.n_fronts = g->an.n_fronts; g->stats.n_levels = g->an.n_levels; g->stats.max_front = g->an.max_front;
   g->stats.nnz_L = g->an.L_size;
   g->stats.t_analysis = now_s() - t0;
@@ -499,8 +516,7 @@ int upload_all(pps_graph* g) {
   // factors
   d.n_obs = (int)g->fslot_ids[F_PLANE_OBS].size(); d.n_odo = (int)g->fslot_ids[F_ODOMETRY].size();
   d.n_pp = (int)g->fslot_ids[F_POSE_PRIOR].size(); d.n_lp = (int)g->fslot_ids[F_PLANE_PRIOR].size();
-  d.joff_obs = 0; d.joff_odo = (int64_t)d.n_obs * 30; d.joff_pp = d.joff_odo + (int64_t)d.n_odo * 78;
-  d.joff_lp = d.joff_pp + (int64_t)d.n_pp * 42;
+  { int64_t base[4]; j_bases(g, base, nullptr); d.joff_obs = base[F_PLANE_OBS]; d.joff_odo = base[F_ODOMETRY]; d.joff_pp = base[F_POSE_PRIOR]; d.joff_lp = base[F_PLANE_PRIOR]; }
   auto idx_of = [&](int type, bool second) {
     std::vector<int> v(g->fslot_ids[type].size());
     for (size_t s = 0; s < v.size(); s++) {
@@ -543,7 +559,7 @@ int upload_all(pps_graph* g) {
   HIP_TRY(g, hipMemsetAsync(d.delta, 0, (size_t)std::max(1, A.n_scalars) * 8, g->stream));
   d.n_scalars = A.n_scalars;
   d.n_fronts = A.n_fronts; d.n_levels = A.n_levels; d.max_front = A.max_front; d.n_segs = A.n_segs; d.n_blocks = A.n_blocks;
-  TRY(dev_upload(g, &d.f_p, A.f_p)); TRY(dev_upload(g, &d.f_b, A.f_b)); TRY(dev_upload(g, &d.f_poff, A.f_poff));
+  TRY(dev_upload(g, &d.f_p, A.f_p)); TRY(dev_upload(g, &d.f_b, A.f_b)); TRY(dev_upload(g, &d.f_poff, A.f_poff)); TRY(dev_upload(g, &d.pidx, A.pidx));
   TRY(dev_upload(g, &d.f_Loff, A.f_Loff)); TRY(dev_upload(g, &d.f_Uoff, A.f_Uoff));
   TRY(dev_upload(g, &d.f_bidx_off, A.f_bidx_off)); TRY(dev_upload(g, &d.bidx, A.bidx));
   TRY(dev_upload(g, &d.f_child_off, A.f_child_off)); TRY(dev_upload(g, &d.child, A.child));
@@ -974,6 +990,7 @@ int pps_remove_factor(pps_graph* g, int fid) {
   if (!g) return PPS_EINVAL;
   if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "remove_factor: unknown id");
   g->factors[fid].deleted = true;
+  g->grown_only = false;
   g->n_live_factors--;
   g->dim_measure -= kFDim[g->factors[fid].type];
   g->topo_dirty = true;
@@ -989,6 +1006,7 @@ int pps_remove_node(pps_graph* g, int nid) {
     if (!f.deleted && (f.a == nid || f.b == nid)) pps_remove_factor(g, (int)i);
   }
   g->nodes[nid].deleted = true;
+  g->grown_only = false;
   g->n_live_nodes--;
   g->dim_nodes -= g->nodes[nid].type == NODE_POSE ? 6 : 3;
   g->topo_dirty = true; g->host_values_newer = true;
@@ -1721,8 +1739,7 @@ int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed) 
   // append the compact-id tables the tests need: node id -> compact id, factor id -> joff
   v.push_back((int32_t)g->nodes.size());
   for (const auto& n : g->nodes) v.push_back(n.deleted ? -1 : n.compact);
-  const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(), n_obs = g->fslot_ids[F_PLANE_OBS].size();
-  const int64_t base[4] = {n_obs * 30 + n_odo * 78, n_obs * 30, 0, n_obs * 30 + n_odo * 78 + n_pp * 42};
+  int64_t base[4]; j_bases(g, base, nullptr);
   v.push_back((int32_t)g->factors.size());
   for (const auto& f : g->factors) v.push_back(f.deleted ? -1 : (int32_t)(base[f.type] + (int64_t)f.slot * kJSize[f.type]));
   *needed = (int64_t)v.size();

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void k_dense_solve(DevGraph d, int level_begin
     if (lane == k) t = xk;
     else if (lane < k) t -= A[k * kLdA + lane] * xk;
   }
-  if (lane < p) d.delta[d.f_poff[s] + lane] = t;
+  if (lane < p) d.delta[d.pidx[d.f_poff[s] + lane]] = t;
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -7,7 +7,8 @@
 //   J            AoS per factor [J_a | J_b | r]: plane edge 30, odometry 78, pose prior 42, plane prior 12 doubles.
 //   H            block-sparse J'J (lower triangle in elimination order) as per-segment partial blocks.
 //   L / U        multifrontal factor panels and update matrices, offsets from the symbolic analysis.
-//   delta, g     elimination-ordered vectors (front pivots are contiguous ranges).
+//   delta        one scalar block per node, nodes in creation order (an offset never moves when the graph grows);
+//                a front reaches its pivots through pidx, its boundary through bidx.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,6 +43,7 @@ struct DevGraph {
   // symbolic arrays (device copies of pps::Analysis)
   int n_fronts = 0, n_levels = 0, max_front = 0, n_segs = 0, n_blocks = 0;
   int *f_p = nullptr, *f_b = nullptr, *f_poff = nullptr;
+  int* pidx = nullptr;       // elimination-ordered scalar -> index in delta (pivots of front s: pidx[f_poff[s] .. + f_p[s]))
   int64_t *f_Loff = nullptr, *f_Uoff = nullptr;
   int *f_bidx_off = nullptr, *bidx = nullptr;
   int *f_child_off = nullptr, *child = nullptr;

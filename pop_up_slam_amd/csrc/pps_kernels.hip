@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
       tj = (lane == k) ? xk : tj - lkj * xk;
     }
   }
-  if (lane < p) d.delta[__builtin_amdgcn_readlane(rec, 7) + lane] = tj;
+  if (lane < p) d.delta[d.pidx[__builtin_amdgcn_readlane(rec, 7) + lane]] = tj;
   // own local solution [x_p | x_b] for the children inside this group
   double* __restrict__ Xs = X + (size_t)slot * kBandMaxRows;
   if (lane < p) Xs[lane] = tj;
@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(64) void k_front_solve(DevGraph d, int level_begin)
     if (lane == 0) t[k] = xk;
     __syncthreads();
   }
-  for (int k = lane; k < p; k += 64) d.delta[d.f_poff[s] + k] = t[k];
+  for (int k = lane; k < p; k += 64) d.delta[d.pidx[d.f_poff[s] + k]] = t[k];
 }
 
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st) {
@@ -1802,7 +1802,7 @@ __device__ __forceinline__ DevGraph load_graph(const DevGraph* gp) {
   PPS_G(obs_pose) PPS_G(obs_plane) PPS_G(obs_meas) PPS_G(obs_w) PPS_G(obs_ray) PPS_G(odo_a) PPS_G(odo_b) PPS_G(odo_meas) PPS_G(odo_w)
   PPS_G(pp_pose) PPS_G(pp_meas) PPS_G(pp_w) PPS_G(lp_plane) PPS_G(lp_meas) PPS_G(lp_w)
   PPS_G(J) PPS_G(H) PPS_G(L) PPS_G(U) PPS_G(delta)
-  PPS_G(f_p) PPS_G(f_b) PPS_G(f_poff) PPS_G(f_Loff) PPS_G(f_Uoff) PPS_G(f_bidx_off) PPS_G(bidx) PPS_G(f_child_off) PPS_G(child)
+  PPS_G(f_p) PPS_G(f_b) PPS_G(f_poff) PPS_G(pidx) PPS_G(f_Loff) PPS_G(f_Uoff) PPS_G(f_bidx_off) PPS_G(bidx) PPS_G(f_child_off) PPS_G(child)
   PPS_G(f_cmap_off) PPS_G(cmap) PPS_G(level_fronts) PPS_G(f_asm_off) PPS_G(asm_blk) PPS_G(asm_lrow) PPS_G(asm_lcol) PPS_G(asm_el0) PPS_G(asm_fsz)
   PPS_G(blk_rows) PPS_G(blk_cols) PPS_G(blk_size) PPS_G(blk_nseg) PPS_G(blk_hoff) PPS_G(seg_blk) PPS_G(seg_c0) PPS_G(seg_cnt) PPS_G(seg_hoff)
   PPS_G(contrib) PPS_G(mseg_blk) PPS_G(f_el_off) PPS_G(el_src) PPS_G(el_tgt) PPS_G(blk_doff) PPS_G(blk_dst) PPS_G(Hf) PPS_G(f_ea_off) PPS_G(ea_tgt)

@@ -189,7 +189,20 @@ struct Builder {
     int K = std::max(2, prm.arity);
     while (K > 2 && n < 2 * K + 1) K--;        // too short for that many parts
     std::vector<int> cuts;
-    for (int c = 1; c < K; c++) {
+    if (K == 2 && prm.aligned_cuts) {
+      // Bisection at an ABSOLUTE position: the pose whose rank (insertion index) is the multiple of the largest power of two
+      // inside this sub-chain.  A chain that grows at its end (a SLAM front
+      // end adds one pose per frame) then keeps every sub-tree left of its newest poses -- ordering, fronts and all index
+      // arrays of that part stay what they were, frame after frame (a quantile cut moves with n).
+      const int r_lo = nodes[poses[0]].rank, r_hi = nodes[poses[n - 1]].rank;
+      int c_rank = r_hi;
+      for (int k = 30; k >= 0; k--) { const int c = (r_hi >> k) << k; if (c > r_lo) { c_rank = c; break; } }
+      int centre = (int)(std::lower_bound(poses.begin(), poses.end(), c_rank, [&](int u, int r) { return nodes[u].rank < r; }) - poses.begin());
+      // (no search window here: a cut that leaves its aligned rank makes the child ranges straddle their own aligned cuts
+      // and the tree degenerates -- 12 levels instead of 9 on a 512-pose chain)
+      cuts.push_back(std::min(std::max(centre, 1), n - 2));
+    }
+    for (int c = 1; c < K && !(K == 2 && prm.aligned_cuts); c++) {
       const int centre = (int)((long long)n * c / K);
       const int half = std::max(0, n / (6 * K));
       int lo = std::max(1, centre - half), hi = std::min(n - 2, centre + half);
@@ -303,7 +316,7 @@ void reset_keep_capacity(Analysis& A) {
   A.ea_total = 0;
   A.n_blocks = 0; A.n_segs = 0;
   A.H_size = 0; A.J_size = 0;
-  A.obs_dir.clear(); A.nd_segs.clear();
+  A.obs_dir.clear(); A.nd_segs.clear(); A.pidx.clear();
 }
 
 namespace {
@@ -388,7 +401,9 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     }
     A.node_pos.assign(N, -1);
     A.node_voff.assign(N, -1);
+    { int off = 0; for (int u = 0; u < N; u++) { A.node_voff[u] = off; off += nodes[u].dim; } }   // creation order: append-only
     A.order.clear();
+    A.pidx.clear();
     std::vector<int> f_pos0, f_npiv;
     std::vector<int> tn_last(B.tree.size(), -1);
     int pos = 0, voff = 0;
@@ -408,7 +423,7 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
         for (int u : chunks[k]) {
           if (A.node_pos[u] != -1) { *msg = "internal: node placed twice"; return false; }
           A.node_pos[u] = pos++;
-          A.node_voff[u] = voff;
+          for (int dd = 0; dd < nodes[u].dim; dd++) A.pidx.push_back(A.node_voff[u] + dd);
           voff += nodes[u].dim;
           A.order.push_back(u);
         }
@@ -634,23 +649,26 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     std::vector<char> has_diag(N, 0);
     for (auto& c : ctr) if (c.pv == c.pu) has_diag[c.pv] = 1;
     for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({p, p, 0, 0, 0, 0, -1});
-    // stable sort by (row position, column position): counting sort on the row, then a stable insertion sort on
-    // the column inside each row (rows hold a handful of blocks; the dense nodes' rows fall back to std::stable_sort)
+    // stable sort by (COLUMN position, row position) -- the column is the node eliminated first, i.e. the front that assembles
+    // the block: the blocks of a front are contiguous, and the numbering of everything that belongs to an unchanged part of
+    // the tree does not move when nodes are appended behind it (a row-major order would renumber every block whose row is a
+    // late separator -- the ground plane's thousand blocks -- with every new pose).  Counting sort on the column, then a
+    // stable insertion sort on the row inside each column (a handful of blocks; long columns fall back to std::stable_sort)
     {
-      std::vector<int> row_off(N + 1, 0);
-      for (const auto& c : ctr) row_off[c.pv + 1]++;
-      for (int p = 0; p < N; p++) row_off[p + 1] += row_off[p];
+      std::vector<int> col_off(N + 1, 0);
+      for (const auto& c : ctr) col_off[c.pu + 1]++;
+      for (int p = 0; p < N; p++) col_off[p + 1] += col_off[p];
       std::vector<Ctr> sorted(ctr.size());
-      std::vector<int> fill(row_off.begin(), row_off.end() - 1);
-      for (const auto& c : ctr) sorted[fill[c.pv]++] = c;
+      std::vector<int> fill(col_off.begin(), col_off.end() - 1);
+      for (const auto& c : ctr) sorted[fill[c.pu]++] = c;
       for (int p = 0; p < N; p++) {
-        Ctr* b = sorted.data() + row_off[p];
-        const int n = row_off[p + 1] - row_off[p];
-        if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pu < y.pu; }); continue; }
+        Ctr* b = sorted.data() + col_off[p];
+        const int n = col_off[p + 1] - col_off[p];
+        if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pv < y.pv; }); continue; }
         for (int i = 1; i < n; i++) {
           const Ctr c = b[i];
           int j = i - 1;
-          while (j >= 0 && b[j].pu > c.pu) { b[j + 1] = b[j]; j--; }
+          while (j >= 0 && b[j].pv > c.pv) { b[j + 1] = b[j]; j--; }
           b[j + 1] = c;
         }
       }
@@ -882,6 +900,7 @@ void dump_analysis(const Analysis& a_in, std::vector<int32_t>& out) {
   putv(a.stage_grp_off); putv(a.grp_lvl_off); putv(a.glvl_front_off); putv(a.glvl_fronts); putv(a.stage_max_front); putv(a.stage_max_width);
   putv(a.f_el_off); putv(a.el_src); putv(a.el_tgt); putv64(a.f_ea_off); putv(a.ea_tgt); putv(a.blk_doff); putv(a.blk_dst);
   putv(a.frec); putv(a.crec); putv(a.srec);
+  putv(a.pidx); putv(a.obs_dir); putv(a.nd_segs);
 }
 
 }  // namespace pps

@@ -31,6 +31,9 @@ struct SymFactor { int type; int a, b; int joff; int direct_ok = 0; };   // comp
 struct AnalysisParams {
   int leaf_poses = 4;      // a sub-chain with <= leaf_poses poses becomes one leaf front
   int arity = 2;           // sub-chains per dissection step (2 = bisection; 4 = three cut poses form ONE separator front)
+  int aligned_cuts = 0;    // bisection at absolute (power-of-two aligned) pose ranks instead of the cheapest cut near the middle of
+                           // the sub-chain: the tree of a chain that grows at its end then keeps its left part (frame loops); the
+                           // balanced, cost-driven cuts give the smaller fronts on a graph that is analysed once
   int max_pivots = 48;     // split supernodes with more pivot scalars into a chain
   int seg_len = 32;        // contributions reduced per wave in the H-block kernel
   int band_levels = 3;     // tree levels walked by one workgroup inside one launch ("band")
@@ -44,13 +47,15 @@ struct AnalysisParams {
 struct Analysis {
   int n_nodes = 0, n_scalars = 0;
   std::vector<int> node_pos;    // [n_nodes] elimination position
-  std::vector<int> node_voff;   // [n_nodes] scalar offset in the elimination-ordered delta / g vectors
+  std::vector<int> node_voff;   // [n_nodes] scalar offset of the node in delta: nodes in CREATION order (compact id), so an offset
+                                // never moves when nodes are appended
+  std::vector<int> pidx;        // [n_scalars] elimination-ordered scalar (front s owns f_poff[s] .. + f_p[s]) -> index in delta
   std::vector<int> order;       // [n_nodes] order[pos] = node
 
   // ---- fronts (post-order: children before parents) ----
   int n_fronts = 0, n_levels = 0, max_front = 0;
   std::vector<int> f_p, f_b;        // pivot / boundary scalar counts
-  std::vector<int> f_poff;          // scalar offset of the first pivot (pivots are contiguous)
+  std::vector<int> f_poff;          // elimination-order offset of the first pivot scalar (into pidx)
   std::vector<int> f_parent, f_level;
   std::vector<int64_t> f_Loff;      // offset of the (f+1) x p factor panel (row-major, ld = p)
   std::vector<int64_t> f_Uoff;      // offset of the (b+1) x (b+1) update matrix (row-major, ld = b+1)

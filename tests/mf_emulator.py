@@ -68,7 +68,7 @@ def solve_with_analysis(A, Jbuf, lam):
         bi = A["bidx"][A["f_bidx_off"][s]:A["f_bidx_off"][s + 1]]
         t = y - L[p:p + b, :].T @ delta[bi]
         x = np.linalg.solve(L[:p, :].T, t)
-        delta[A["f_poff"][s]:A["f_poff"][s] + p] = x
+        delta[A["pidx"][A["f_poff"][s]:A["f_poff"][s] + p]] = x
     return delta
 
 
@@ -154,6 +154,6 @@ def solve_with_band_schedule(A, Jbuf, lam):
             xb = xb_ref
         t = L[p + b, :] - L[p:p + b, :].T @ xb
         xp = np.linalg.solve(L[:p, :].T, t)
-        delta[poff:poff + p] = xp
+        delta[A["pidx"][poff:poff + p]] = xp
         xloc[i] = np.concatenate([xp, xb])
     return delta
