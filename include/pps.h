@@ -189,6 +189,10 @@ int pps_eval_factor(pps_graph* g, int fid, int mode /* enum pps_jacobian_mode */
 
 /* Host-side symbolic analysis only (no device needed): runs ordering + front construction. */
 int pps_analyze(pps_graph* g);
+/* Frame loops: a graph that only GROWS between two analyses (nodes / factors appended, every new factor touching a new node)
+ * is analysed incrementally -- the part of the elimination tree left of the new poses, with all of its index arrays, is
+ * kept (csrc/pps_symbolic.h).  fronts_kept of fronts_total of the last analysis were taken over (0 = from scratch). */
+int pps_analysis_reuse(const pps_graph* g, int* fronts_kept, int* fronts_total);
 /* Flat dump of the analysis for host-logic tests.  Call with out == NULL to get the needed length. */
 int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed);
 

@@ -105,7 +105,7 @@ SYMBOLS = [
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
     "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
-    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times", "pps_popup_polygons_simple",
+    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times", "pps_popup_polygons_simple", "pps_analysis_reuse",
 ]
 
 
@@ -450,6 +450,12 @@ class Graph:
         J = np.zeros((m.value, c.value)); r = np.zeros(m.value)
         self._ck(self.L.pps_eval_factor(self.h, fid, mode, J.ctypes.data_as(_dp), r.ctypes.data_as(_dp)))
         return J, r
+
+    def analysis_reuse(self):
+        """(fronts kept from the previous analysis, fronts in total) of the last analysis"""
+        a, b = C.c_int(), C.c_int()
+        self._ck(self.L.pps_analysis_reuse(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def analyze(self):
         self._ck(self.L.pps_analyze(self.h))

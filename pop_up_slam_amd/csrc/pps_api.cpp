@@ -60,7 +60,8 @@ struct pps_graph {
   std::vector<HostNode> nodes;
   std::vector<HostFactor> factors;
   int n_live_nodes = 0, n_live_factors = 0, dim_nodes = 0, dim_measure = 0;
-  bool topo_dirty = true;       // structure changed since the last analysis/upload
+  bool topo_dirty = true;       // structure changed since the last upload
+  bool analysis_stale = true;   // structure changed since the last analysis
   bool host_values_newer = true;   // host node values must be pushed before the next solve
   bool dev_values_newer = false;   // device estimate is newer than the host copy
   bool meas_dirty = false;
@@ -69,6 +70,7 @@ struct pps_graph {
   bool grown_only = true;          // nothing has been removed since the last analysis (nodes / factors were only appended)
   Analysis an;
   AnalysisParams aprm;
+  AnalysisCache* acache = nullptr;   // what the last analysis left for the next one (frame loops)
   std::vector<int> pose_ids, plane_ids;   // slot -> node id
   std::vector<int> fslot_ids[4];          // per type: slot -> factor id
   std::vector<int> level_max_front;
@@ -331,13 +333,17 @@ int run_analysis(pps_graph* g) {
   if (const char* e = getenv("PPS_ORDERING")) g->aprm.ordering = atoi(e);
   const char* msg = "";
   try {
-  if (!analyze(sn, sf, g->aprm, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+  if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "compaction (api)", 1e3 * (now_s() - t0));
+  if (!g->acache) g->acache = analysis_cache_new();
+  if (!analyze(sn, sf, g->aprm, g->an, &msg, getenv("PPS_NO_INCREMENTAL") ? nullptr : g->acache))
+    return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
   // fronts beyond the wave-per-front kernels (loop-closure separators) run in the dense-front form, whose cost is
   // per tree level: split their supernodes into 64-pivot chunks instead of 48 (a quarter fewer levels)
   if (g->an.max_front > band_front_limit() && g->aprm.max_pivots < dense_front_max_pivots() && !getenv("PPS_MAX_PIVOTS")) {
     AnalysisParams wide = g->aprm;
     wide.max_pivots = dense_front_max_pivots();
-    if (!analyze(sn, sf, wide, g->an, &msg)) return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+    if (!analyze(sn, sf, wide, g->an, &msg, getenv("PPS_NO_INCREMENTAL") ? nullptr : g->acache))
+      return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
   }
   } catch (const std::bad_alloc&) {
     g->an = Analysis();
@@ -403,7 +409,8 @@ int run_analysis(pps_graph* g) {
   if (!g->use_band && !g->use_dense && g->an.max_front > 4096)
     return fail(g, PPS_ENOMEM, "fronts too wide for this ordering (max front " + std::to_string(g->an.max_front) +
                                " scalars): the pose chain is not a good dissection backbone for this graph");
-  g->analyzed = true;
+  if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "total incl. api", 1e3 * (now_s() - t0));
+  g->analyzed = true; g->analysis_stale = false;
   g->n_analyses++; g->grown_only = true;
   g->stats.n_fronts = g->an.n_fronts; g->stats.n_levels = g->an.n_levels; g->stats.max_front = g->an.max_front;
   g->stats.nnz_L = g->an.L_size;
@@ -501,7 +508,7 @@ int upload_all(pps_graph* g) {
   g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
   g->frames_dirty = true;
   g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
-  if (!g->analyzed || g->topo_dirty) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
+  if (!g->analyzed || g->analysis_stale) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
@@ -843,6 +850,7 @@ int pps_graph_create(const pps_props* props, pps_graph** out) {
 
 int pps_graph_destroy(pps_graph* g) {
   if (!g) return PPS_EINVAL;
+  if (g->acache) analysis_cache_free(g->acache);
   if (g->dev_ready) {
     (void)hipSetDevice(g->props.device);
     (void)hipStreamSynchronize(g->stream);
@@ -891,7 +899,7 @@ static int add_node(pps_graph* g, int type, const double* v, int nv, int* id) {
   g->nodes.push_back(n);
   g->n_live_nodes++;
   g->dim_nodes += type == NODE_POSE ? 6 : 3;
-  g->topo_dirty = true; g->host_values_newer = true;
+  g->topo_dirty = true; g->analysis_stale = true; g->host_values_newer = true;
   if (id) *id = (int)g->nodes.size() - 1;
   return PPS_OK;
 }
@@ -915,7 +923,7 @@ static int add_factor(pps_graph* g, int type, int a, int b, const double* meas, 
   g->factors.push_back(f);
   g->n_live_factors++;
   g->dim_measure += kFDim[type];
-  g->topo_dirty = true;
+  g->topo_dirty = true; g->analysis_stale = true;
   if (fid) *fid = (int)g->factors.size() - 1;
   return PPS_OK;
 }
@@ -993,7 +1001,7 @@ int pps_remove_factor(pps_graph* g, int fid) {
   g->grown_only = false;
   g->n_live_factors--;
   g->dim_measure -= kFDim[g->factors[fid].type];
-  g->topo_dirty = true;
+  g->topo_dirty = true; g->analysis_stale = true;
   return PPS_OK;
 }
 
@@ -1009,7 +1017,7 @@ int pps_remove_node(pps_graph* g, int nid) {
   g->grown_only = false;
   g->n_live_nodes--;
   g->dim_nodes -= g->nodes[nid].type == NODE_POSE ? 6 : 3;
-  g->topo_dirty = true; g->host_values_newer = true;
+  g->topo_dirty = true; g->analysis_stale = true; g->host_values_newer = true;
   return PPS_OK;
 }
 
@@ -1731,9 +1739,15 @@ int pps_analyze(pps_graph* g) {
   return run_analysis(g);
 }
 
+int pps_analysis_reuse(const pps_graph* g, int* fronts_kept, int* fronts_total) {
+  if (!g) return PPS_EINVAL;
+  analysis_cache_stats(g->acache, fronts_kept, fronts_total);
+  return PPS_OK;
+}
+
 int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed) {
   if (!g || !needed) return PPS_EINVAL;
-  if (!g->analyzed || g->topo_dirty) { int rc = pps_analyze(g); if (rc != PPS_OK) return rc; }
+  if (!g->analyzed || g->analysis_stale) { int rc = pps_analyze(g); if (rc != PPS_OK) return rc; }
   std::vector<int32_t> v;
   dump_analysis(g->an, v);
   // append the compact-id tables the tests need: node id -> compact id, factor id -> joff

@@ -19,11 +19,25 @@ struct TNode {
   std::vector<int> kids;  // tnode ids
 };
 
+// One dissected sub-chain of a previous analysis: the poses [first .. last] (ids; a chain only grows at its end, so first /
+// last / count identify the set), the planes handed down to it, and the block of tree nodes [t0, t1) it produced.
+struct DissectMemo { int first, last, count, t0, t1; std::vector<int> planes; };
+
 struct Builder {
   const std::vector<SymNode>& nodes;
   const std::vector<SymFactor>& factors;
   const AnalysisParams& prm;
   int N;
+  // frame-loop reuse (aligned cuts only): sub-chains of the previous analysis by (first pose, last pose); a sub-chain that
+  // comes back with the same poses and planes is the same sub-tree -- nothing inside it has a new neighbour -- and its
+  // block of tree nodes is copied instead of dissected again
+  const std::vector<TNode>* old_tree = nullptr;
+  const std::vector<DissectMemo>* old_memo = nullptr;
+  const std::vector<int>* old_memo_of_first = nullptr;   // pose id -> first memo index of the sub-chains starting there (-1)
+  const std::vector<int>* old_memo_next = nullptr;       // memo index -> next memo with the same first pose (-1)
+  std::vector<DissectMemo> memo;                         // of THIS run
+  std::vector<char> t_reused;                            // tree node copied from the previous analysis
+  std::vector<int> t_old;                                // ... and which one it was there
   std::vector<int> adj_off, adj;   // CSR, unique neighbours
   std::vector<TNode> tree;
   std::vector<int> lidx;           // scratch: node -> local pose index in the current call
@@ -56,7 +70,7 @@ struct Builder {
   }
   int degree(int u) const { return adj_off[u + 1] - adj_off[u]; }
 
-  int new_tnode() { tree.emplace_back(); return (int)tree.size() - 1; }
+  int new_tnode() { tree.emplace_back(); t_reused.push_back(0); t_old.push_back(-1); return (int)tree.size() - 1; }
 
   // General fill-reducing ordering for graphs the pose chain does not dissect well (pose graphs with many loop
   // closures, 2-D meshes): minimum degree on the node graph (degrees in scalars, lazy heap, adjacency lists merged
@@ -152,10 +166,30 @@ struct Builder {
   // poses: node ids sorted by rank; planes: node ids.  Returns tnode id.
   int dissect(std::vector<int> poses, std::vector<int> planes) {
     const int n = (int)poses.size();
+    if (old_memo && n > 0 && poses[0] < (int)old_memo_of_first->size()) {
+      for (int mi = (*old_memo_of_first)[poses[0]]; mi >= 0; mi = (*old_memo_next)[mi]) {
+        const DissectMemo& m = (*old_memo)[mi];
+        if (m.last != poses[n - 1] || m.count != n || m.planes != planes) continue;
+        // the same sub-chain with the same planes: copy its block of tree nodes
+        const int t0 = (int)tree.size(), delta = t0 - m.t0;
+        for (int q = m.t0; q < m.t1; q++) {
+          tree.push_back((*old_tree)[q]);
+          for (int& k : tree.back().kids) k += delta;
+          t_reused.push_back(1); t_old.push_back(q);
+        }
+        // the memos of the copied block stay valid for the next frame (re-based)
+        for (const DissectMemo& mm : *old_memo)
+          if (mm.t0 >= m.t0 && mm.t1 <= m.t1) { memo.push_back(mm); memo.back().t0 += delta; memo.back().t1 += delta; }
+        return t0;
+      }
+    }
     const int t = new_tnode();
+    const size_t my_memo = memo.size();
+    memo.push_back(DissectMemo{n > 0 ? poses[0] : -1, n > 0 ? poses[n - 1] : -1, n, t, -1, planes});
     if (n <= prm.leaf_poses) {
       for (int pl : planes) tree[t].piv.push_back(pl);
       for (int po : poses) tree[t].piv.push_back(po);
+      memo[my_memo].t1 = (int)tree.size();
       return t;
     }
     for (int i = 0; i < n; i++) lidx[poses[i]] = i;
@@ -250,6 +284,7 @@ struct Builder {
     for (int po : sep_poses) tree[t].piv.push_back(po);
     for (int q = 0; q < nparts; q++)
       if (!pposes[q].empty()) { const int c = dissect(std::move(pposes[q]), std::move(pplanes[q])); tree[t].kids.push_back(c); }
+    memo[my_memo].t1 = (int)tree.size();
     return t;
   }
 };
@@ -319,24 +354,63 @@ void reset_keep_capacity(Analysis& A) {
   A.obs_dir.clear(); A.nd_segs.clear(); A.pidx.clear();
 }
 
+// What an analysis leaves behind for the next analysis of the same, grown graph (see pps_symbolic.h).
+struct AnalysisCache {
+  bool valid = false;
+  std::vector<SymNode> nodes;
+  std::vector<SymFactor> factors;
+  AnalysisParams prm;
+  std::vector<char> dense;
+  std::vector<TNode> tree;
+  std::vector<DissectMemo> memo;
+  std::vector<int> memo_of_first, memo_next;
+  std::vector<int> post;                  // post-order sequence of tree nodes
+  std::vector<int> f_pos0, f_npiv;        // first position / node count of every front
+  std::vector<std::vector<int>> bnd;      // boundary nodes of every front, in elimination order
+  std::vector<int> blk_pu;                // column position of every H block (blocks are sorted by it)
+  int fronts_reused = 0, fronts_total = 0;
+};
+AnalysisCache* analysis_cache_new() { return new AnalysisCache(); }
+void analysis_cache_free(AnalysisCache* c) { delete c; }
+void analysis_cache_stats(const AnalysisCache* c, int* fronts_reused, int* fronts_total) {
+  if (fronts_reused) *fronts_reused = c ? c->fronts_reused : 0;
+  if (fronts_total) *fronts_total = c ? c->fronts_total : 0;
+}
+
 namespace {
-bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
-                  Analysis& A, const char** msg, bool general_ordering) {
+// 1 = done, 0 = error (msg), 2 = the reuse attempt does not apply after all: run again from scratch
+int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
+                 Analysis& A, const char** msg, bool general_ordering, AnalysisCache* C, bool reuse) {
   static const char* kOk = "";
   *msg = kOk;
   const bool timing = getenv("PPS_ANALYSIS_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
-  reset_keep_capacity(A);
   const int N = (int)nodes.size();
-  A.n_nodes = N;
-  if (N == 0) { *msg = "empty graph"; return false; }
+  if (N == 0) { reset_keep_capacity(A); *msg = "empty graph"; return 0; }
   auto lap = [&](const char* what) {
     if (!timing) return;
     const auto t = std::chrono::steady_clock::now();
     fprintf(stderr, "[analysis] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
   };
-  lap("reset");
+  // ---- 0. may the previous result be built upon?  The graph must be the cached one plus appended nodes / factors, every
+  // new factor touching a new node (then nothing left of the new poses has a new neighbour) ----
+  if (reuse) {
+    const size_t N0 = C->nodes.size(), M0 = C->factors.size();
+    bool ok = C->valid && !general_ordering && prm.aligned_cuts && std::max(2, prm.arity) == 2 && N0 <= nodes.size() && M0 <= factors.size() &&
+              C->prm.leaf_poses == prm.leaf_poses && C->prm.max_pivots == prm.max_pivots && C->prm.seg_len == prm.seg_len &&
+              C->prm.band_levels == prm.band_levels && C->prm.band_rows == prm.band_rows && C->prm.aligned_cuts == prm.aligned_cuts &&
+              C->prm.dense_min == prm.dense_min && C->prm.dense_mult == prm.dense_mult && (int)A.f_b.size() == C->fronts_total;
+    for (size_t i = 0; ok && i < N0; i++) ok = nodes[i].type == C->nodes[i].type && nodes[i].dim == C->nodes[i].dim && nodes[i].rank == C->nodes[i].rank;
+    for (size_t i = 0; ok && i < M0; i++)
+      ok = factors[i].type == C->factors[i].type && factors[i].a == C->factors[i].a && factors[i].b == C->factors[i].b &&
+           factors[i].joff == C->factors[i].joff && factors[i].direct_ok == C->factors[i].direct_ok;
+    for (size_t i = M0; ok && i < factors.size(); i++) ok = factors[i].a >= (int)N0 || factors[i].b >= (int)N0;
+    if (!ok) return 2;
+  }
+  if (!reuse) reset_keep_capacity(A);
+  A.n_nodes = N;
+  lap("validate / reset");
   Builder B(nodes, factors, prm);
   B.build_adjacency();
   lap("adjacency");
@@ -351,8 +425,15 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
     else if (nodes[u].type == NODE_POSE) poses.push_back(u);
     else planes.push_back(u);
   }
+  if (reuse) {                                            // the border block must be the one it was
+    for (size_t u = 0; u < C->dense.size(); u++) if (C->dense[u] != B.dense[u]) return 2;
+    for (size_t u = C->dense.size(); u < (size_t)N; u++) if (B.dense[u]) return 2;
+  }
   std::sort(poses.begin(), poses.end(), [&](int a, int b) { return nodes[a].rank < nodes[b].rank; });
   // strip dense nodes from the adjacency the dissection sees
+  std::vector<int> post;
+  std::vector<int> f_pos0, f_npiv;
+  int root = -1;
   {
     std::vector<int> off(N + 1, 0), a2;
     a2.reserve(B.adj.size());
@@ -371,12 +452,13 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
         live.insert(live.end(), planes.begin(), planes.end());
         top = B.mindeg_tree(live);
       } else {
+        if (reuse) { B.old_tree = &C->tree; B.old_memo = &C->memo; B.old_memo_of_first = &C->memo_of_first; B.old_memo_next = &C->memo_next; }
         top = B.dissect(poses, planes);
       }
     }
     B.adj_off.swap(full_off);
     B.adj.swap(full_adj);
-    int root = top;
+    root = top;
     if (!dense_nodes.empty()) {
       root = B.new_tnode();
       // planes first, poses last
@@ -384,439 +466,502 @@ bool analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor
       for (int u : dense_nodes) if (nodes[u].type == NODE_POSE) B.tree[root].piv.push_back(u);
       if (top >= 0) B.tree[root].kids.push_back(top);
     }
-    lap("dissection");
-    // ---- 2./3. post-order over the separator tree; oversized supernodes are emitted as a chain of
-    // fronts (first chunk child-most: it receives the tnode's children) ----
-    std::vector<int> post;
-    post.reserve(B.tree.size());
-    {
-      std::vector<std::pair<int, size_t>> st;
-      st.emplace_back(root, 0);
-      while (!st.empty()) {
-        auto& top2 = st.back();
-        const int t = top2.first;
-        if (top2.second < B.tree[t].kids.size()) { const int c = B.tree[t].kids[top2.second++]; st.emplace_back(c, 0); }
-        else { post.push_back(t); st.pop_back(); }
-      }
+  }
+  lap("dissection");
+  // ---- 2./3. post-order over the separator tree; oversized supernodes are emitted as a chain of
+  // fronts (first chunk child-most: it receives the tnode's children) ----
+  post.reserve(B.tree.size());
+  {
+    std::vector<std::pair<int, size_t>> st;
+    st.emplace_back(root, 0);
+    while (!st.empty()) {
+      auto& top2 = st.back();
+      const int t = top2.first;
+      if (top2.second < B.tree[t].kids.size()) { const int c = B.tree[t].kids[top2.second++]; st.emplace_back(c, 0); }
+      else { post.push_back(t); st.pop_back(); }
     }
-    A.node_pos.assign(N, -1);
-    A.node_voff.assign(N, -1);
-    { int off = 0; for (int u = 0; u < N; u++) { A.node_voff[u] = off; off += nodes[u].dim; } }   // creation order: append-only
-    A.order.clear();
-    A.pidx.clear();
-    std::vector<int> f_pos0, f_npiv;
-    std::vector<int> tn_last(B.tree.size(), -1);
-    int pos = 0, voff = 0;
-    for (int t : post) {
-      const TNode& tn = B.tree[t];
-      std::vector<std::vector<int>> chunks(1);
-      int acc = 0;
-      for (int u : tn.piv) {
-        if (acc + nodes[u].dim > prm.max_pivots && acc > 0) { chunks.emplace_back(); acc = 0; }
-        chunks.back().push_back(u);
-        acc += nodes[u].dim;
-      }
-      for (size_t k = 0; k < chunks.size(); k++) {
-        const int s = (int)A.f_p.size();
-        f_pos0.push_back(pos);
-        A.f_poff.push_back(voff);
-        for (int u : chunks[k]) {
-          if (A.node_pos[u] != -1) { *msg = "internal: node placed twice"; return false; }
-          A.node_pos[u] = pos++;
-          for (int dd = 0; dd < nodes[u].dim; dd++) A.pidx.push_back(A.node_voff[u] + dd);
-          voff += nodes[u].dim;
-          A.order.push_back(u);
-        }
-        f_npiv.push_back(pos - f_pos0[s]);
-        A.f_p.push_back(voff - A.f_poff[s]);
-        A.f_parent.push_back(-1);
-        if (k == 0) { for (int c : tn.kids) A.f_parent[tn_last[c]] = s; }
-        else A.f_parent[s - 1] = s;
-      }
-      tn_last[t] = (int)A.f_p.size() - 1;
+  }
+  // the tree nodes taken over from the previous analysis that also sit at the same place of the post-order: their fronts
+  // keep their numbers, positions and everything indexed by them
+  size_t K0 = 0;
+  if (reuse) while (K0 < post.size() && K0 < C->post.size() && B.t_reused[post[K0]] && B.t_old[post[K0]] == C->post[K0]) K0++;
+  A.node_pos.assign(N, -1);
+  A.node_voff.assign(N, -1);
+  { int off = 0; for (int u = 0; u < N; u++) { A.node_voff[u] = off; off += nodes[u].dim; } }   // creation order: append-only
+  A.order.clear();
+  A.pidx.clear();
+  A.f_p.clear(); A.f_poff.clear(); A.f_parent.clear();
+  std::vector<int> tn_last(B.tree.size(), -1);
+  int pos = 0, voff = 0;
+  int F0 = 0;                                             // fronts kept from the previous analysis
+  for (size_t pi = 0; pi < post.size(); pi++) {
+    const int t = post[pi];
+    const TNode& tn = B.tree[t];
+    std::vector<std::vector<int>> chunks(1);
+    int acc = 0;
+    for (int u : tn.piv) {
+      if (acc + nodes[u].dim > prm.max_pivots && acc > 0) { chunks.emplace_back(); acc = 0; }
+      chunks.back().push_back(u);
+      acc += nodes[u].dim;
     }
-    const int F = (int)A.f_p.size();
-    A.n_fronts = F;
-    A.f_b.assign(F, 0); A.f_level.assign(F, 0);
-    if (pos != N) { *msg = "internal: ordering does not cover all nodes"; return false; }
-    A.n_scalars = voff;
+    for (size_t k = 0; k < chunks.size(); k++) {
+      const int s = (int)A.f_p.size();
+      f_pos0.push_back(pos);
+      A.f_poff.push_back(voff);
+      for (int u : chunks[k]) {
+        if (A.node_pos[u] != -1) { *msg = "internal: node placed twice"; return 0; }
+        A.node_pos[u] = pos++;
+        for (int dd = 0; dd < nodes[u].dim; dd++) A.pidx.push_back(A.node_voff[u] + dd);
+        voff += nodes[u].dim;
+        A.order.push_back(u);
+      }
+      f_npiv.push_back(pos - f_pos0[s]);
+      A.f_p.push_back(voff - A.f_poff[s]);
+      A.f_parent.push_back(-1);
+      if (k == 0) { for (int c : tn.kids) A.f_parent[tn_last[c]] = s; }
+      else A.f_parent[s - 1] = s;
+    }
+    tn_last[t] = (int)A.f_p.size() - 1;
+    if (pi + 1 == K0) F0 = (int)A.f_p.size();
+  }
+  const int F = (int)A.f_p.size();
+  A.n_fronts = F;
+  if (pos != N) { *msg = "internal: ordering does not cover all nodes"; return 0; }
+  A.n_scalars = voff;
+  if (reuse) {
+    if (F0 > (int)C->f_pos0.size() || F0 > (int)A.f_b.size()) return 2;
+    for (int s = 0; s < F0; s++) if (f_pos0[s] != C->f_pos0[s] || f_npiv[s] != C->f_npiv[s]) return 2;
+  }
+  A.f_b.resize(F, 0); A.f_level.assign(F, 0);
 
-    lap("post-order / chains");
-    // ---- 4. boundaries ----
-    std::vector<std::vector<int>> bnd(F);
-    std::vector<std::vector<int>> kids(F);
-    for (int s = 0; s < F; s++) if (A.f_parent[s] >= 0) kids[A.f_parent[s]].push_back(s);
-    auto compute_boundaries = [&]() {
-      std::vector<int> stamp(N, -1);
-      for (int s = 0; s < F; s++) {
-        const int end = f_pos0[s] + f_npiv[s];
-        std::vector<int>& b = bnd[s];
-        b.clear();
-        for (int k = f_pos0[s]; k < end; k++) {
-          const int u = A.order[k];
-          for (int q = B.adj_off[u]; q < B.adj_off[u + 1]; q++) {
-            const int v = B.adj[q];
-            if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
-          }
+  lap("post-order / chains");
+  // ---- 4. boundaries ----
+  std::vector<std::vector<int>> bnd(F);
+  std::vector<std::vector<int>> kids(F);
+  for (int s = 0; s < F; s++) if (A.f_parent[s] >= 0) kids[A.f_parent[s]].push_back(s);
+  for (int s = 0; s < F0; s++) {
+    bnd[s].swap(C->bnd[s]);
+    // The boundary nodes of a kept front lie in later fronts, kept or redone; they must still come in the order they had
+    // (a plane that moved to another separator of the redone spine changes the local layout of the fronts it bounds):
+    // the kept part ends at the first front for which that no longer holds.
+    bool same = true;
+    for (size_t k = 0; same && k + 1 < bnd[s].size(); k++) same = A.node_pos[bnd[s][k]] < A.node_pos[bnd[s][k + 1]];
+    for (size_t k = 0; same && k < bnd[s].size(); k++) same = A.node_pos[bnd[s][k]] >= f_pos0[s] + f_npiv[s];
+    if (!same) { F0 = s; break; }
+  }
+  if (reuse) C->valid = false;                            // its boundary lists are gone: from here on a failure means "from scratch"
+  const int P0 = F0 < F ? f_pos0[F0] : N;                 // positions below P0 belong to kept fronts
+  auto compute_boundaries = [&](int s_begin) {
+    std::vector<int> stamp(N, -1);
+    for (int s = s_begin; s < F; s++) {
+      const int end = f_pos0[s] + f_npiv[s];
+      std::vector<int>& b = bnd[s];
+      b.clear();
+      for (int k = f_pos0[s]; k < end; k++) {
+        const int u = A.order[k];
+        for (int q = B.adj_off[u]; q < B.adj_off[u + 1]; q++) {
+          const int v = B.adj[q];
+          if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
         }
-        for (int c : kids[s])
-          for (int v : bnd[c])
-            if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
-        std::sort(b.begin(), b.end(), [&](int x, int y) { return A.node_pos[x] < A.node_pos[y]; });
       }
-    };
-    compute_boundaries();
-    // verify the separator property: every boundary node of s is a pivot of an ancestor of s,
-    // and every boundary node of a child is inside the parent's front.
-    std::vector<int> node_front(N);
-    for (int s = 0; s < F; s++)
-      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) node_front[A.order[k]] = s;
-    bool valid = true;
-    {
-      std::vector<int> anc_stamp(F, -1);
-      for (int s = 0; s < F && valid; s++) {
-        for (int x = A.f_parent[s]; x >= 0; x = A.f_parent[x]) anc_stamp[x] = s;
-        for (int v : bnd[s]) if (anc_stamp[node_front[v]] != s) { valid = false; break; }
-      }
+      for (int c : kids[s])
+        for (int v : bnd[c])
+          if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
+      std::sort(b.begin(), b.end(), [&](int x, int y) { return A.node_pos[x] < A.node_pos[y]; });
     }
-    if (!valid) {
-      // fall back to a chain: every later front is an ancestor, which is always a valid assembly tree
-      for (int s = 0; s < F; s++) { A.f_parent[s] = (s + 1 < F) ? s + 1 : -1; kids[s].clear(); }
-      for (int s = 0; s + 1 < F; s++) kids[s + 1].push_back(s);
-      compute_boundaries();
+  };
+  compute_boundaries(F0);
+  // verify the separator property: every boundary node of s is a pivot of an ancestor of s,
+  // and every boundary node of a child is inside the parent's front.
+  std::vector<int> node_front(N);
+  for (int s = 0; s < F; s++)
+    for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) node_front[A.order[k]] = s;
+  bool valid = true;
+  {
+    std::vector<int> anc_stamp(F, -1);
+    for (int s = F0; s < F && valid; s++) {
+      for (int x = A.f_parent[s]; x >= 0; x = A.f_parent[x]) anc_stamp[x] = s;
+      for (int v : bnd[s]) if (anc_stamp[node_front[v]] != s) { valid = false; break; }
     }
-    // levels
-    A.n_levels = 0;
-    for (int s = 0; s < F; s++) {
-      int lv = 0;
-      for (int c : kids[s]) lv = std::max(lv, A.f_level[c] + 1);
-      A.f_level[s] = lv;
-      A.n_levels = std::max(A.n_levels, lv + 1);
+  }
+  if (!valid) {
+    if (reuse) return 2;
+    // fall back to a chain: every later front is an ancestor, which is always a valid assembly tree
+    for (int s = 0; s < F; s++) { A.f_parent[s] = (s + 1 < F) ? s + 1 : -1; kids[s].clear(); }
+    for (int s = 0; s + 1 < F; s++) kids[s + 1].push_back(s);
+    compute_boundaries(0);
+  }
+  // levels
+  A.n_levels = 0;
+  for (int s = 0; s < F; s++) {
+    int lv = 0;
+    for (int c : kids[s]) lv = std::max(lv, A.f_level[c] + 1);
+    A.f_level[s] = lv;
+    A.n_levels = std::max(A.n_levels, lv + 1);
+  }
+  A.level_off.assign(A.n_levels + 1, 0);
+  for (int s = 0; s < F; s++) A.level_off[A.f_level[s] + 1]++;
+  for (int l = 0; l < A.n_levels; l++) A.level_off[l + 1] += A.level_off[l];
+  A.level_fronts.resize(F);
+  {
+    std::vector<int> w(A.level_off.begin(), A.level_off.end() - 1);
+    for (int s = 0; s < F; s++) A.level_fronts[w[A.f_level[s]]++] = s;
+  }
+  lap("boundaries");
+  // ---- band schedule ----
+  {
+    const int Bn = std::max(1, prm.band_levels);
+    A.n_stages = (A.n_levels + Bn - 1) / Bn;
+    std::vector<int> grp(F, -1), ll(F, 0);
+    std::vector<int> grp_stage;
+    for (int s = F - 1; s >= 0; s--) {       // parents before children (post-order reversed)
+      const int par = A.f_parent[s];
+      const int band = A.f_level[s] / Bn;
+      if (par < 0 || A.f_level[par] / Bn != band) { grp[s] = (int)grp_stage.size(); grp_stage.push_back(band); }
+      else grp[s] = grp[par];
     }
-    A.level_off.assign(A.n_levels + 1, 0);
-    for (int s = 0; s < F; s++) A.level_off[A.f_level[s] + 1]++;
-    for (int l = 0; l < A.n_levels; l++) A.level_off[l + 1] += A.level_off[l];
-    A.level_fronts.resize(F);
-    {
-      std::vector<int> w(A.level_off.begin(), A.level_off.end() - 1);
-      for (int s = 0; s < F; s++) A.level_fronts[w[A.f_level[s]]++] = s;
+    for (int s = 0; s < F; s++) {             // children before parents
+      int l = 0;
+      for (int c : kids[s]) if (grp[c] == grp[s]) l = std::max(l, ll[c] + 1);
+      ll[s] = l;
     }
-    lap("boundaries");
-    // ---- band schedule ----
-    {
-      const int Bn = std::max(1, prm.band_levels);
-      A.n_stages = (A.n_levels + Bn - 1) / Bn;
-      std::vector<int> grp(F, -1), ll(F, 0);
-      std::vector<int> grp_stage;
-      for (int s = F - 1; s >= 0; s--) {       // parents before children (post-order reversed)
-        const int par = A.f_parent[s];
-        const int band = A.f_level[s] / Bn;
-        if (par < 0 || A.f_level[par] / Bn != band) { grp[s] = (int)grp_stage.size(); grp_stage.push_back(band); }
-        else grp[s] = grp[par];
-      }
-      for (int s = 0; s < F; s++) {             // children before parents
-        int l = 0;
-        for (int c : kids[s]) if (grp[c] == grp[s]) l = std::max(l, ll[c] + 1);
-        ll[s] = l;
-      }
-      const int G = (int)grp_stage.size();
-      // order groups by stage
-      std::vector<int> gorder(G), gnew(G);
-      std::iota(gorder.begin(), gorder.end(), 0);
-      std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return grp_stage[a] < grp_stage[b]; });
-      for (int i = 0; i < G; i++) gnew[gorder[i]] = i;
-      A.n_groups = G;
-      A.stage_grp_off.assign(A.n_stages + 1, 0);
-      for (int g2 = 0; g2 < G; g2++) A.stage_grp_off[grp_stage[g2] + 1]++;
-      for (int st = 0; st < A.n_stages; st++) A.stage_grp_off[st + 1] += A.stage_grp_off[st];
-      std::vector<int> g_nl(G, 0);
-      for (int s = 0; s < F; s++) g_nl[gnew[grp[s]]] = std::max(g_nl[gnew[grp[s]]], ll[s] + 1);
-      A.grp_lvl_off.assign(G + 1, 0);
-      for (int g2 = 0; g2 < G; g2++) A.grp_lvl_off[g2 + 1] = A.grp_lvl_off[g2] + g_nl[g2];
-      A.n_glevels = A.grp_lvl_off[G];
-      A.glvl_front_off.assign(A.n_glevels + 1, 0);
-      for (int s = 0; s < F; s++) A.glvl_front_off[A.grp_lvl_off[gnew[grp[s]]] + ll[s] + 1]++;
-      for (int i = 0; i < A.n_glevels; i++) A.glvl_front_off[i + 1] += A.glvl_front_off[i];
-      A.glvl_fronts.assign(F, 0);
-      std::vector<int> w(A.glvl_front_off.begin(), A.glvl_front_off.end() - 1);
-      for (int s = 0; s < F; s++) A.glvl_fronts[w[A.grp_lvl_off[gnew[grp[s]]] + ll[s]]++] = s;
-      A.stage_max_front.assign(A.n_stages, 0);
-      A.stage_max_width.assign(A.n_stages, 0);
-      for (int s = 0; s < F; s++) {
-        const int st = A.f_level[s] / Bn;
-        A.stage_max_front[st] = std::max(A.stage_max_front[st], 0);
-      }
-      for (int g2 = 0; g2 < G; g2++) {
-        int st = 0;
-        while (g2 >= A.stage_grp_off[st + 1]) st++;
-        for (int l = A.grp_lvl_off[g2]; l < A.grp_lvl_off[g2 + 1]; l++)
-          A.stage_max_width[st] = std::max(A.stage_max_width[st], A.glvl_front_off[l + 1] - A.glvl_front_off[l]);
-      }
+    const int G = (int)grp_stage.size();
+    // order groups by stage
+    std::vector<int> gorder(G), gnew(G);
+    std::iota(gorder.begin(), gorder.end(), 0);
+    std::stable_sort(gorder.begin(), gorder.end(), [&](int a2, int b2) { return grp_stage[a2] < grp_stage[b2]; });
+    for (int i = 0; i < G; i++) gnew[gorder[i]] = i;
+    A.n_groups = G;
+    A.stage_grp_off.assign(A.n_stages + 1, 0);
+    for (int g2 = 0; g2 < G; g2++) A.stage_grp_off[grp_stage[g2] + 1]++;
+    for (int st = 0; st < A.n_stages; st++) A.stage_grp_off[st + 1] += A.stage_grp_off[st];
+    std::vector<int> g_nl(G, 0);
+    for (int s = 0; s < F; s++) g_nl[gnew[grp[s]]] = std::max(g_nl[gnew[grp[s]]], ll[s] + 1);
+    A.grp_lvl_off.assign(G + 1, 0);
+    for (int g2 = 0; g2 < G; g2++) A.grp_lvl_off[g2 + 1] = A.grp_lvl_off[g2] + g_nl[g2];
+    A.n_glevels = A.grp_lvl_off[G];
+    A.glvl_front_off.assign(A.n_glevels + 1, 0);
+    for (int s = 0; s < F; s++) A.glvl_front_off[A.grp_lvl_off[gnew[grp[s]]] + ll[s] + 1]++;
+    for (int i = 0; i < A.n_glevels; i++) A.glvl_front_off[i + 1] += A.glvl_front_off[i];
+    A.glvl_fronts.assign(F, 0);
+    std::vector<int> w(A.glvl_front_off.begin(), A.glvl_front_off.end() - 1);
+    for (int s = 0; s < F; s++) A.glvl_fronts[w[A.grp_lvl_off[gnew[grp[s]]] + ll[s]]++] = s;
+    A.stage_max_front.assign(A.n_stages, 0);
+    A.stage_max_width.assign(A.n_stages, 0);
+    for (int g2 = 0; g2 < G; g2++) {
+      int st = 0;
+      while (g2 >= A.stage_grp_off[st + 1]) st++;
+      for (int l = A.grp_lvl_off[g2]; l < A.grp_lvl_off[g2 + 1]; l++)
+        A.stage_max_width[st] = std::max(A.stage_max_width[st], A.glvl_front_off[l + 1] - A.glvl_front_off[l]);
     }
-    // children CSR
-    A.f_child_off.assign(F + 1, 0);
-    for (int s = 0; s < F; s++) A.f_child_off[s + 1] = A.f_child_off[s] + (int)kids[s].size();
-    A.child.clear();
-    for (int s = 0; s < F; s++) for (int c : kids[s]) A.child.push_back(c);
-    // boundary scalar indices, sizes, storage
-    A.f_bidx_off.assign(F + 1, 0);
-    A.bidx.clear();
-    A.max_front = 0;
-    A.f_Loff.assign(F, 0); A.f_Uoff.assign(F, 0);
-    A.L_size = 0; A.U_size = 0;
-    for (int s = 0; s < F; s++) {
-      int b = 0;
-      for (int v : bnd[s]) { for (int d = 0; d < nodes[v].dim; d++) A.bidx.push_back(A.node_voff[v] + d); b += nodes[v].dim; }
-      A.f_b[s] = b;
-      A.f_bidx_off[s + 1] = (int)A.bidx.size();
-      const int f = A.f_p[s] + b;
-      A.max_front = std::max(A.max_front, f);
-      A.f_Loff[s] = A.L_size; A.L_size += (int64_t)(f + 1) * A.f_p[s];
-      A.f_Uoff[s] = A.U_size; A.U_size += (int64_t)(b + 1) * (b + 1);
-    }
-    for (int s = 0; s < F; s++) {
-      const int st = A.f_level[s] / std::max(1, prm.band_levels);
-      A.stage_max_front[st] = std::max(A.stage_max_front[st], A.f_p[s] + A.f_b[s]);
-    }
-    // child -> parent scatter maps
-    A.f_cmap_off.assign(F + 1, 0);
-    A.cmap.clear();
-    std::vector<int> loc(N, -1);
-    // process per parent so that loc[] is filled once per front
-    std::vector<std::vector<int>> cm(F);
-    for (int s = 0; s < F; s++) {
+  }
+  // children CSR
+  A.f_child_off.assign(F + 1, 0);
+  for (int s = 0; s < F; s++) A.f_child_off[s + 1] = A.f_child_off[s] + (int)kids[s].size();
+  A.child.clear();
+  for (int s = 0; s < F; s++) for (int c : kids[s]) A.child.push_back(c);
+  // boundary scalar indices, sizes, storage: the kept fronts keep theirs (every offset is cumulative in front order)
+  const int bidx0 = F0 > 0 ? A.f_bidx_off[F0] : 0;
+  A.L_size = F0 > 0 ? (F0 < (int)A.f_Loff.size() ? A.f_Loff[F0] : A.L_size) : 0;
+  A.U_size = F0 > 0 ? (F0 < (int)A.f_Uoff.size() ? A.f_Uoff[F0] : A.U_size) : 0;
+  A.f_bidx_off.resize(F + 1, 0);
+  A.bidx.resize(bidx0);
+  A.f_Loff.resize(F, 0); A.f_Uoff.resize(F, 0);
+  if (F0 == 0) A.f_bidx_off[0] = 0;
+  for (int s = F0; s < F; s++) {
+    int b = 0;
+    for (int v : bnd[s]) { for (int d = 0; d < nodes[v].dim; d++) A.bidx.push_back(A.node_voff[v] + d); b += nodes[v].dim; }
+    A.f_b[s] = b;
+    A.f_bidx_off[s + 1] = (int)A.bidx.size();
+    const int f = A.f_p[s] + b;
+    A.f_Loff[s] = A.L_size; A.L_size += (int64_t)(f + 1) * A.f_p[s];
+    A.f_Uoff[s] = A.U_size; A.U_size += (int64_t)(b + 1) * (b + 1);
+  }
+  A.max_front = 0;
+  for (int s = 0; s < F; s++) {
+    A.max_front = std::max(A.max_front, A.f_p[s] + A.f_b[s]);
+    const int st = A.f_level[s] / std::max(1, prm.band_levels);
+    A.stage_max_front[st] = std::max(A.stage_max_front[st], A.f_p[s] + A.f_b[s]);
+  }
+  // child -> parent scatter maps: a kept front whose parent is kept as well keeps its map; the children of redone fronts
+  // (kept or not) get theirs from the parent's new layout -- same length, written in place
+  std::vector<int> loc(N, -1);
+  {
+    std::vector<int> cm_off(F + 1, 0);
+    for (int s = 0; s < F; s++) cm_off[s + 1] = cm_off[s] + (A.f_parent[s] >= 0 ? A.f_b[s] + 1 : 0);
+    if (F0 > 0) for (int s = 0; s <= F0; s++) if (cm_off[s] != A.f_cmap_off[s]) return 2;
+    A.f_cmap_off = cm_off;
+    A.cmap.resize(cm_off[F]);
+    for (int s = F0; s < F; s++) {
       int off = 0;
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
       for (int v : bnd[s]) { loc[v] = off; off += nodes[v].dim; }
       const int rhs_row = off;   // == f
       for (int c : kids[s]) {
+        int* out = A.cmap.data() + cm_off[c];
         for (int v : bnd[c]) {
-          if (loc[v] < 0) { *msg = "internal: child boundary not inside parent front"; return false; }
-          for (int d = 0; d < nodes[v].dim; d++) cm[c].push_back(loc[v] + d);
+          if (loc[v] < 0) { *msg = "internal: child boundary not inside parent front"; return 0; }
+          for (int d = 0; d < nodes[v].dim; d++) *out++ = loc[v] + d;
         }
-        cm[c].push_back(rhs_row);
+        *out++ = rhs_row;
+        if (out != A.cmap.data() + cm_off[c + 1]) { *msg = "internal: child map length"; return 0; }
       }
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
       for (int v : bnd[s]) loc[v] = -1;
     }
-    // packed update matrix of c -> packed index in the parent front
-    // (only the wave-per-front kernels read these lists; a graph with wider fronts runs in the dense-front form, which
-    // pulls through cmap -- its (b+1)^2/2 entries per front would be gigabytes for loop-closure separators)
-    A.f_ea_off.assign(F + 1, 0);
-    A.ea_tgt.clear();
-    // Only the offsets are computed here: the lists themselves (sum of (b+1)(b+2)/2 entries, ~0.3 M for a
-    // 1000-pose graph) are expanded from cmap on the device (k_expand_ea) -- or by expand_ea_tgt() for the dump.
-    A.ea_total = 0;
-    if (A.max_front <= prm.band_rows) {
-      for (int s = 0; s < F; s++) {
-        A.f_ea_off[s] = A.ea_total;
-        A.ea_total += (int64_t)(cm[s].size() * (cm[s].size() + 1) / 2);    // cm[root] is empty
-      }
-      A.f_ea_off[F] = A.ea_total;
-    }
+  }
+  // packed update matrix of c -> packed index in the parent front
+  // (only the wave-per-front kernels read these lists; a graph with wider fronts runs in the dense-front form, which
+  // pulls through cmap -- its (b+1)^2/2 entries per front would be gigabytes for loop-closure separators)
+  A.f_ea_off.assign(F + 1, 0);
+  A.ea_tgt.clear();
+  // Only the offsets are computed here: the lists themselves (sum of (b+1)(b+2)/2 entries, ~0.3 M for a
+  // 1000-pose graph) are expanded from cmap on the device (k_expand_ea) -- or by expand_ea_tgt() for the dump.
+  A.ea_total = 0;
+  if (A.max_front <= prm.band_rows) {
     for (int s = 0; s < F; s++) {
-      A.f_cmap_off[s] = (int)A.cmap.size();
-      A.cmap.insert(A.cmap.end(), cm[s].begin(), cm[s].end());
+      A.f_ea_off[s] = A.ea_total;
+      const int64_t len = A.f_cmap_off[s + 1] - A.f_cmap_off[s];             // the root has no map
+      A.ea_total += len * (len + 1) / 2;
     }
-    A.f_cmap_off[F] = (int)A.cmap.size();
+    A.f_ea_off[F] = A.ea_total;
+  }
 
-    lap("band schedule");
-    // ---- 5. block-sparse H and contribution lists ----
-    struct Ctr { int pv, pu, jv, ju, roff, m, fi; };   // (row position, column position) of the H block, the J slices, the factor
-    std::vector<Ctr> ctr;
-    ctr.reserve(factors.size() * 3);
-    A.J_size = 0;
-    int n_obs_slots = 0;
-    for (size_t fi2 = 0; fi2 < factors.size(); fi2++) {
-      const auto& f = factors[fi2];
-      const int fi = (int)fi2;
-      if (f.type == F_PLANE_OBS) n_obs_slots = std::max(n_obs_slots, f.joff / kJSize[F_PLANE_OBS] + 1);
-      const int m = kFDim[f.type];
-      const int da = nodes[f.a].dim;
-      const int db = f.b >= 0 ? nodes[f.b].dim : 0;
-      const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
-      A.J_size = std::max<int64_t>(A.J_size, (int64_t)roff + m);
-      const int pa = A.node_pos[f.a];
-      ctr.push_back({pa, pa, ja, ja, roff, m, fi});
-      if (f.b >= 0) {
-        const int pb = A.node_pos[f.b];
-        ctr.push_back({pb, pb, jb, jb, roff, m, fi});
-        if (pa > pb) ctr.push_back({pa, pb, ja, jb, roff, m, fi});   // rows = later node
-        else         ctr.push_back({pb, pa, jb, ja, roff, m, fi});
-      }
+  lap("band schedule");
+  // ---- 5. block-sparse H and contribution lists ----
+  // Blocks are numbered by (column position, row position); the blocks whose column is a kept position, with their
+  // segments and contribution lists, are the ones of the previous analysis.
+  struct Ctr { int pv, pu, jv, ju, roff, m, fi; };   // (row position, column position) of the H block, the J slices, the factor
+  int B0 = 0;                                          // blocks kept
+  if (F0 > 0) B0 = (int)(std::lower_bound(C->blk_pu.begin(), C->blk_pu.end(), P0) - C->blk_pu.begin());
+  const int S0 = B0 > 0 ? (B0 < (int)A.blk_hoff.size() ? (int)(std::lower_bound(A.seg_blk.begin(), A.seg_blk.end(), B0) - A.seg_blk.begin()) : (int)A.seg_blk.size()) : 0;
+  const int C0 = S0 > 0 ? (S0 < (int)A.seg_c0.size() ? A.seg_c0[S0] : (int)(A.contrib.size() / 4)) : 0;
+  const int64_t H0 = B0 > 0 ? (B0 < (int)A.blk_hoff.size() ? A.blk_hoff[B0] : A.H_size) : 0;
+  std::vector<Ctr> ctr;
+  ctr.reserve(factors.size() * 3);
+  A.J_size = 0;
+  int n_obs_slots = 0;
+  for (size_t fi2 = 0; fi2 < factors.size(); fi2++) {
+    const auto& f = factors[fi2];
+    const int fi = (int)fi2;
+    if (f.type == F_PLANE_OBS) n_obs_slots = std::max(n_obs_slots, f.joff / kJSize[F_PLANE_OBS] + 1);
+    const int m = kFDim[f.type];
+    const int da = nodes[f.a].dim;
+    const int db = f.b >= 0 ? nodes[f.b].dim : 0;
+    const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
+    A.J_size = std::max<int64_t>(A.J_size, (int64_t)roff + m);
+    const int pa = A.node_pos[f.a];
+    if (pa >= P0) ctr.push_back({pa, pa, ja, ja, roff, m, fi});
+    if (f.b >= 0) {
+      const int pb = A.node_pos[f.b];
+      if (pb >= P0) ctr.push_back({pb, pb, jb, jb, roff, m, fi});
+      if (pa > pb) { if (pb >= P0) ctr.push_back({pa, pb, ja, jb, roff, m, fi}); }   // rows = later node
+      else         { if (pa >= P0) ctr.push_back({pb, pa, jb, ja, roff, m, fi}); }
     }
-    // every node needs a diagonal block even when it has no factor (it will then fail as not PD)
+  }
+  // every node needs a diagonal block even when it has no factor (it will then fail as not PD)
+  {
     std::vector<char> has_diag(N, 0);
     for (auto& c : ctr) if (c.pv == c.pu) has_diag[c.pv] = 1;
-    for (int p = 0; p < N; p++) if (!has_diag[p]) ctr.push_back({p, p, 0, 0, 0, 0, -1});
-    // stable sort by (COLUMN position, row position) -- the column is the node eliminated first, i.e. the front that assembles
-    // the block: the blocks of a front are contiguous, and the numbering of everything that belongs to an unchanged part of
-    // the tree does not move when nodes are appended behind it (a row-major order would renumber every block whose row is a
-    // late separator -- the ground plane's thousand blocks -- with every new pose).  Counting sort on the column, then a
-    // stable insertion sort on the row inside each column (a handful of blocks; long columns fall back to std::stable_sort)
-    {
-      std::vector<int> col_off(N + 1, 0);
-      for (const auto& c : ctr) col_off[c.pu + 1]++;
-      for (int p = 0; p < N; p++) col_off[p + 1] += col_off[p];
-      std::vector<Ctr> sorted(ctr.size());
-      std::vector<int> fill(col_off.begin(), col_off.end() - 1);
-      for (const auto& c : ctr) sorted[fill[c.pu]++] = c;
-      for (int p = 0; p < N; p++) {
-        Ctr* b = sorted.data() + col_off[p];
-        const int n = col_off[p + 1] - col_off[p];
-        if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pv < y.pv; }); continue; }
-        for (int i = 1; i < n; i++) {
-          const Ctr c = b[i];
-          int j = i - 1;
-          while (j >= 0 && b[j].pv > c.pv) { b[j + 1] = b[j]; j--; }
-          b[j + 1] = c;
-        }
+    for (int p2 = P0; p2 < N; p2++) if (!has_diag[p2]) ctr.push_back({p2, p2, 0, 0, 0, 0, -1});
+  }
+  // stable sort by (COLUMN position, row position) -- the column is the node eliminated first, i.e. the front that assembles
+  // the block: the blocks of a front are contiguous, and the numbering of everything that belongs to an unchanged part of
+  // the tree does not move when nodes are appended behind it (a row-major order would renumber every block whose row is a
+  // late separator -- the ground plane's thousand blocks -- with every new pose).  Counting sort on the column, then a
+  // stable insertion sort on the row inside each column (a handful of blocks; long columns fall back to std::stable_sort)
+  {
+    const int NC = N - P0;
+    std::vector<int> col_off(NC + 1, 0);
+    for (const auto& c : ctr) col_off[c.pu - P0 + 1]++;
+    for (int p2 = 0; p2 < NC; p2++) col_off[p2 + 1] += col_off[p2];
+    std::vector<Ctr> sorted(ctr.size());
+    std::vector<int> fill(col_off.begin(), col_off.end() - 1);
+    for (const auto& c : ctr) sorted[fill[c.pu - P0]++] = c;
+    for (int p2 = 0; p2 < NC; p2++) {
+      Ctr* b = sorted.data() + col_off[p2];
+      const int n = col_off[p2 + 1] - col_off[p2];
+      if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pv < y.pv; }); continue; }
+      for (int i = 1; i < n; i++) {
+        const Ctr c = b[i];
+        int j = i - 1;
+        while (j >= 0 && b[j].pv > c.pv) { b[j + 1] = b[j]; j--; }
+        b[j + 1] = c;
       }
-      ctr.swap(sorted);
     }
-    lap("  contributions sorted");
-    A.contrib.clear();
-    A.contrib.reserve(ctr.size() * 4);
-    A.obs_dir.assign(3 * (size_t)n_obs_slots, -1);
-    std::vector<std::vector<int>> asm_of(F);   // block ids per front
-    A.H_size = 0;
-    for (size_t i = 0; i < ctr.size();) {
-      size_t j = i;
-      while (j < ctr.size() && ctr[j].pv == ctr[i].pv && ctr[j].pu == ctr[i].pu) j++;
-      const int pv = ctr[i].pv, pu = ctr[i].pu;
-      const int v = A.order[pv], u = A.order[pu];
-      const int rows = nodes[v].dim, cols = nodes[u].dim;
-      const int size = rows * cols + (v == u ? rows : 0);
-      const int cnt = (int)(j - i);
-      const int nseg = std::max(1, (cnt + prm.seg_len - 1) / prm.seg_len);
-      const int blk = A.n_blocks++;
-      A.blk_rows.push_back(rows); A.blk_cols.push_back(cols); A.blk_size.push_back(size); A.blk_nseg.push_back(nseg);
-      A.blk_hoff.push_back(A.H_size);
-      // a (pose, plane) block fed by exactly one plain plane observation: K1 may write it (see pps_symbolic.h)
-      const bool direct = v != u && cnt == 1 && ctr[i].fi >= 0 && factors[ctr[i].fi].direct_ok;
-      if (direct) {
-        const int slot = factors[ctr[i].fi].joff / kJSize[F_PLANE_OBS];
-        A.obs_dir[3 * (size_t)slot + 0] = (int)A.H_size;
-        A.obs_dir[3 * (size_t)slot + 1] = blk;                          // replaced by the block's Hf offset below
-        A.obs_dir[3 * (size_t)slot + 2] = nodes[v].type == NODE_POSE ? 1 : 0;
-      } else {
-        for (int sgi = 0; sgi < nseg; sgi++) A.nd_segs.push_back(A.n_segs + sgi);
-      }
-      for (int sgi = 0; sgi < nseg; sgi++) {
-        const int c0 = sgi * prm.seg_len;
-        A.seg_blk.push_back(blk);
-        A.seg_c0.push_back((int)(A.contrib.size() / 4));
-        int k = 0;
-        for (; k < prm.seg_len && c0 + k < cnt; k++) {
-          const Ctr& c = ctr[i + c0 + k];
-          if (c.m == 0) continue;   // placeholder for a factor-less node
-          A.contrib.push_back(c.jv); A.contrib.push_back(c.ju); A.contrib.push_back(c.roff); A.contrib.push_back(c.m);
-        }
-        A.seg_cnt.push_back((int)(A.contrib.size() / 4) - A.seg_c0.back());
-        A.seg_hoff.push_back(A.H_size);
-        A.H_size += size;
-        A.n_segs++;
-      }
-      asm_of[node_front[u]].push_back(blk);
-      // remember (v,u) for the local offsets below
-      A.asm_lrow.push_back(v); A.asm_lcol.push_back(u);   // temporarily indexed by block id
-      i = j;
+    ctr.swap(sorted);
+  }
+  lap("  contributions sorted");
+  A.contrib.resize((size_t)C0 * 4);
+  A.contrib.reserve((size_t)C0 * 4 + ctr.size() * 4);
+  A.obs_dir.resize(3 * (size_t)n_obs_slots, -1);
+  // an observation whose (pose, plane) block is redone starts as "not direct"
+  for (const auto& c : ctr)
+    if (c.pv != c.pu && c.fi >= 0 && factors[c.fi].direct_ok) A.obs_dir[3 * (size_t)(factors[c.fi].joff / kJSize[F_PLANE_OBS])] = -1;
+  { size_t k = 0; while (k < A.nd_segs.size() && A.nd_segs[k] < S0) k++; A.nd_segs.resize(k); }
+  A.blk_rows.resize(B0); A.blk_cols.resize(B0); A.blk_size.resize(B0); A.blk_nseg.resize(B0); A.blk_hoff.resize(B0);
+  A.seg_blk.resize(S0); A.seg_c0.resize(S0); A.seg_cnt.resize(S0); A.seg_hoff.resize(S0);
+  A.n_blocks = B0; A.n_segs = S0; A.H_size = H0;
+  std::vector<int> blk_pu;                             // column position per block (kept part from the cache)
+  if (B0 > 0) blk_pu.assign(C->blk_pu.begin(), C->blk_pu.begin() + B0);
+  std::vector<std::vector<int>> asm_of(F);             // block ids per (redone) front
+  std::vector<int> blk_v, blk_u;                       // row / column node of the redone blocks (index blk - B0)
+  std::vector<int> blk_is_direct_slot;                 // redone block -> observation slot when direct, else -1
+  for (size_t i = 0; i < ctr.size();) {
+    size_t j = i;
+    while (j < ctr.size() && ctr[j].pv == ctr[i].pv && ctr[j].pu == ctr[i].pu) j++;
+    const int pv = ctr[i].pv, pu = ctr[i].pu;
+    const int v = A.order[pv], u = A.order[pu];
+    const int rows = nodes[v].dim, cols = nodes[u].dim;
+    const int size = rows * cols + (v == u ? rows : 0);
+    const int cnt = (int)(j - i);
+    const int nseg = std::max(1, (cnt + prm.seg_len - 1) / prm.seg_len);
+    const int blk = A.n_blocks++;
+    A.blk_rows.push_back(rows); A.blk_cols.push_back(cols); A.blk_size.push_back(size); A.blk_nseg.push_back(nseg);
+    A.blk_hoff.push_back(A.H_size);
+    blk_pu.push_back(pu);
+    // a (pose, plane) block fed by exactly one plain plane observation: K1 may write it (see pps_symbolic.h)
+    const bool direct = v != u && cnt == 1 && ctr[i].fi >= 0 && factors[ctr[i].fi].direct_ok;
+    if (direct) {
+      const int slot = factors[ctr[i].fi].joff / kJSize[F_PLANE_OBS];
+      A.obs_dir[3 * (size_t)slot + 0] = (int)A.H_size;
+      A.obs_dir[3 * (size_t)slot + 1] = -1;                           // the block's Hf offset: set below
+      A.obs_dir[3 * (size_t)slot + 2] = nodes[v].type == NODE_POSE ? 1 : 0;
+      blk_is_direct_slot.push_back(slot);
+    } else {
+      for (int sgi = 0; sgi < nseg; sgi++) A.nd_segs.push_back(A.n_segs + sgi);
+      blk_is_direct_slot.push_back(-1);
     }
-    lap("  blocks / segments");
-    // per-front assembly lists with local offsets
-    std::vector<int> blk_v(A.asm_lrow), blk_u(A.asm_lcol);
-    A.asm_blk.clear(); A.asm_lrow.clear(); A.asm_lcol.clear();
-    A.f_asm_off.assign(F + 1, 0);
-    A.f_el_off.assign(1, 0); A.el_tgt.clear(); A.el_total = 0; A.asm_el0.clear(); A.asm_fsz.clear();
-    A.f_el_off.reserve(F + 1);
-    A.blk_doff.assign(A.n_blocks + 1, 0);
-    for (int bk = 0; bk < A.n_blocks; bk++) A.blk_doff[bk + 1] = A.blk_doff[bk] + A.blk_size[bk];
-    A.blk_dst.clear();
-    A.asm_el0.reserve(A.n_blocks); A.asm_fsz.reserve(A.n_blocks);
-    A.asm_blk.reserve(A.n_blocks); A.asm_lrow.reserve(A.n_blocks); A.asm_lcol.reserve(A.n_blocks);
-    if (A.H_size > 0x3fffffffLL) { *msg = "H too large for int32 gather offsets"; return false; }
-    std::vector<int> blk_el0(A.n_blocks, -1);
-    for (int s = 0; s < F; s++) {
-      int off = 0;
-      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
-      for (int v : bnd[s]) { loc[v] = off; off += nodes[v].dim; }
-      for (int blk : asm_of[s]) {
-        const int v = blk_v[blk], u = blk_u[blk];
-        if (loc[v] < 0 || loc[u] < 0) { *msg = "internal: H block outside its front"; return false; }
-        A.asm_blk.push_back(blk); A.asm_lrow.push_back(loc[v]); A.asm_lcol.push_back(loc[u]);
+    for (int sgi = 0; sgi < nseg; sgi++) {
+      const int c0 = sgi * prm.seg_len;
+      A.seg_blk.push_back(blk);
+      A.seg_c0.push_back((int)(A.contrib.size() / 4));
+      int k = 0;
+      for (; k < prm.seg_len && c0 + k < cnt; k++) {
+        const Ctr& c = ctr[i + c0 + k];
+        if (c.m == 0) continue;   // placeholder for a factor-less node
+        A.contrib.push_back(c.jv); A.contrib.push_back(c.ju); A.contrib.push_back(c.roff); A.contrib.push_back(c.m);
       }
-      A.f_asm_off[s + 1] = (int)A.asm_blk.size();
+      A.seg_cnt.push_back((int)(A.contrib.size() / 4) - A.seg_c0.back());
+      A.seg_hoff.push_back(A.H_size);
+      A.H_size += size;
+      A.n_segs++;
+    }
+    asm_of[node_front[u]].push_back(blk);
+    blk_v.push_back(v); blk_u.push_back(u);
+    i = j;
+  }
+  lap("  blocks / segments");
+  // per-front assembly lists with local offsets
+  const int asm0 = F0 > 0 ? A.f_asm_off[F0] : 0;
+  A.el_total = F0 > 0 ? A.f_el_off[F0] : 0;
+  A.f_asm_off.resize(F + 1, 0); A.f_el_off.resize(F + 1, 0);
+  if (F0 == 0) { A.f_asm_off[0] = 0; A.f_el_off[0] = 0; }
+  A.asm_blk.resize(asm0); A.asm_lrow.resize(asm0); A.asm_lcol.resize(asm0); A.asm_el0.resize(asm0); A.asm_fsz.resize(asm0);
+  A.el_tgt.clear();
+  A.blk_doff.resize(A.n_blocks + 1, 0);
+  if (B0 == 0) A.blk_doff[0] = 0;
+  for (int bk = B0; bk < A.n_blocks; bk++) A.blk_doff[bk + 1] = A.blk_doff[bk] + A.blk_size[bk];
+  A.blk_dst.clear();
+  if (A.H_size > 0x3fffffffLL) { *msg = "H too large for int32 gather offsets"; return 0; }
+  for (int s = F0; s < F; s++) {
+    int off = 0;
+    for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
+    for (int v : bnd[s]) { loc[v] = off; off += nodes[v].dim; }
+    const int fsz = A.f_p[s] + A.f_b[s];
+    for (int blk : asm_of[s]) {
+      const int v = blk_v[blk - B0], u = blk_u[blk - B0];
+      if (loc[v] < 0 || loc[u] < 0) { *msg = "internal: H block outside its front"; return 0; }
+      A.asm_blk.push_back(blk); A.asm_lrow.push_back(loc[v]); A.asm_lcol.push_back(loc[u]);
       // flat element list of the front (lower triangle of diagonal blocks, full off-diagonal blocks, g entries): only
       // where each assembled block starts is recorded here; el_tgt / blk_dst are expanded from that on the device
       // (k_expand_el) or by expand_el_lists() for the dump
-      {
-        const int fsz = A.f_p[s] + A.f_b[s];
-        for (int blk : asm_of[s]) {
-          const int rows = A.blk_rows[blk], cols = A.blk_cols[blk];
-          const bool diag = blk_v[blk] == blk_u[blk];
-          A.asm_el0.push_back((int)A.el_total);
-          blk_el0[blk] = (int)A.el_total;
-          A.asm_fsz.push_back(fsz);
-          A.el_total += diag ? rows * (rows + 1) / 2 + rows : rows * cols;
-        }
-        A.f_el_off.push_back((int)A.el_total);
-      }
-      for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
-      for (int v : bnd[s]) loc[v] = -1;
+      const int rows = A.blk_rows[blk], cols = A.blk_cols[blk];
+      const bool diag = v == u;
+      A.asm_el0.push_back((int)A.el_total);
+      if (blk_is_direct_slot[blk - B0] >= 0) A.obs_dir[3 * (size_t)blk_is_direct_slot[blk - B0] + 1] = (int)A.el_total;
+      A.asm_fsz.push_back(fsz);
+      A.el_total += diag ? rows * (rows + 1) / 2 + rows : rows * cols;
     }
-    for (size_t k = 0; k + 2 < A.obs_dir.size(); k += 3)
-      if (A.obs_dir[k] >= 0) A.obs_dir[k + 1] = blk_el0[A.obs_dir[k + 1]];
-      lap("H blocks / lists");
-      // ---- packed records ----
-    {
-      A.frec.assign((size_t)F * 16, 0);
-      A.crec.clear();
-      std::vector<int> pos_of(F, -1);
-      for (int i = 0; i < F; i++) pos_of[A.glvl_fronts[i]] = i;
-      for (int i = 0; i < F; i++) {
-        const int s2 = A.glvl_fronts[i];
-        int* r = &A.frec[(size_t)i * 16];
-        r[0] = s2; r[1] = A.f_p[s2]; r[2] = A.f_b[s2]; r[3] = A.f_el_off[s2]; r[4] = A.f_el_off[s2 + 1];
-        r[5] = (int)(A.crec.size() / 8); r[6] = A.f_child_off[s2 + 1] - A.f_child_off[s2];
-        r[7] = A.f_poff[s2]; r[8] = A.f_bidx_off[s2];
-        r[9] = (int)(A.f_Loff[s2] & 0xffffffffLL); r[10] = (int)(A.f_Loff[s2] >> 32);
-        r[11] = (int)(A.f_Uoff[s2] & 0xffffffffLL); r[12] = (int)(A.f_Uoff[s2] >> 32);
-        r[13] = (A.f_b[s2] + 1) * (A.f_b[s2] + 2) / 2;
-        // solve hand-down: a front whose parent sits in the same group reads its boundary values from the parent's
-        // local solution vector (LDS) through cmap instead of gathering them from delta
-        r[14] = -1;
-        r[15] = A.f_cmap_off[s2];
-        {
-          const int par = A.f_parent[s2];
-          const int Bn2 = std::max(1, prm.band_levels);
-          if (par >= 0 && A.f_level[par] / Bn2 == A.f_level[s2] / Bn2) {
-            // slot = position inside the group (groups are contiguous in glvl_fronts: first position of the group's
-            // first local level)
-            const int ip = pos_of[par];
-            const int l = (int)(std::upper_bound(A.glvl_front_off.begin(), A.glvl_front_off.end(), ip) - A.glvl_front_off.begin()) - 1;
-            const int g2 = (int)(std::upper_bound(A.grp_lvl_off.begin(), A.grp_lvl_off.end(), l) - A.grp_lvl_off.begin()) - 1;
-            r[14] = ip - A.glvl_front_off[A.grp_lvl_off[g2]];
-          }
-        }
-        for (int ci = A.f_child_off[s2]; ci < A.f_child_off[s2 + 1]; ci++) {
-          const int c = A.child[ci];
-          const int bc1 = A.f_b[c] + 1;
-          int cr[8] = {bc1 * (bc1 + 1) / 2, (int)(A.f_Uoff[c] & 0xffffffffLL), (int)(A.f_Uoff[c] >> 32),
-                       (int)(A.f_ea_off[c] & 0xffffffffLL), (int)(A.f_ea_off[c] >> 32), c, 0, 0};
-          A.crec.insert(A.crec.end(), cr, cr + 8);
-        }
-      }
-      A.srec.assign((size_t)A.n_segs * 8, 0);
-      for (int sg = 0; sg < A.n_segs; sg++) {
-        const int bk = A.seg_blk[sg];
-        int* r = &A.srec[(size_t)sg * 8];
-        r[0] = A.blk_rows[bk]; r[1] = A.blk_cols[bk]; r[2] = A.blk_size[bk]; r[3] = A.seg_c0[sg]; r[4] = A.seg_cnt[sg];
-        r[5] = (int)A.seg_hoff[sg]; r[6] = A.blk_doff[bk]; r[7] = A.blk_nseg[bk];
-      }
-      lap("packed records");
-    }
+    A.f_asm_off[s + 1] = (int)A.asm_blk.size();
+    A.f_el_off[s + 1] = (int)A.el_total;
+    for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) loc[A.order[k]] = -1;
+    for (int v : bnd[s]) loc[v] = -1;
   }
-  return true;
+  lap("H blocks / lists");
+  // ---- packed records ----
+  {
+    A.frec.assign((size_t)F * 16, 0);
+    A.crec.clear();
+    std::vector<int> pos_of(F, -1);
+    for (int i = 0; i < F; i++) pos_of[A.glvl_fronts[i]] = i;
+    for (int i = 0; i < F; i++) {
+      const int s2 = A.glvl_fronts[i];
+      int* r = &A.frec[(size_t)i * 16];
+      r[0] = s2; r[1] = A.f_p[s2]; r[2] = A.f_b[s2]; r[3] = A.f_el_off[s2]; r[4] = A.f_el_off[s2 + 1];
+      r[5] = (int)(A.crec.size() / 8); r[6] = A.f_child_off[s2 + 1] - A.f_child_off[s2];
+      r[7] = A.f_poff[s2]; r[8] = A.f_bidx_off[s2];
+      r[9] = (int)(A.f_Loff[s2] & 0xffffffffLL); r[10] = (int)(A.f_Loff[s2] >> 32);
+      r[11] = (int)(A.f_Uoff[s2] & 0xffffffffLL); r[12] = (int)(A.f_Uoff[s2] >> 32);
+      r[13] = (A.f_b[s2] + 1) * (A.f_b[s2] + 2) / 2;
+      // solve hand-down: a front whose parent sits in the same group reads its boundary values from the parent's
+      // local solution vector (LDS) through cmap instead of gathering them from delta
+      r[14] = -1;
+      r[15] = A.f_cmap_off[s2];
+      {
+        const int par = A.f_parent[s2];
+        const int Bn2 = std::max(1, prm.band_levels);
+        if (par >= 0 && A.f_level[par] / Bn2 == A.f_level[s2] / Bn2) {
+          // slot = position inside the group (groups are contiguous in glvl_fronts: first position of the group's
+          // first local level)
+          const int ip = pos_of[par];
+          const int l = (int)(std::upper_bound(A.glvl_front_off.begin(), A.glvl_front_off.end(), ip) - A.glvl_front_off.begin()) - 1;
+          const int g2 = (int)(std::upper_bound(A.grp_lvl_off.begin(), A.grp_lvl_off.end(), l) - A.grp_lvl_off.begin()) - 1;
+          r[14] = ip - A.glvl_front_off[A.grp_lvl_off[g2]];
+        }
+      }
+      for (int ci = A.f_child_off[s2]; ci < A.f_child_off[s2 + 1]; ci++) {
+        const int c = A.child[ci];
+        const int bc1 = A.f_b[c] + 1;
+        int cr[8] = {bc1 * (bc1 + 1) / 2, (int)(A.f_Uoff[c] & 0xffffffffLL), (int)(A.f_Uoff[c] >> 32),
+                     (int)(A.f_ea_off[c] & 0xffffffffLL), (int)(A.f_ea_off[c] >> 32), c, 0, 0};
+        A.crec.insert(A.crec.end(), cr, cr + 8);
+      }
+    }
+    A.srec.resize((size_t)A.n_segs * 8, 0);
+    for (int sg = S0; sg < A.n_segs; sg++) {
+      const int bk = A.seg_blk[sg];
+      int* r = &A.srec[(size_t)sg * 8];
+      r[0] = A.blk_rows[bk]; r[1] = A.blk_cols[bk]; r[2] = A.blk_size[bk]; r[3] = A.seg_c0[sg]; r[4] = A.seg_cnt[sg];
+      r[5] = (int)A.seg_hoff[sg]; r[6] = A.blk_doff[bk]; r[7] = A.blk_nseg[bk];
+    }
+    lap("packed records");
+  }
+  // ---- what the next analysis of this graph may build upon ----
+  if (C && !general_ordering) {
+    C->nodes = nodes; C->factors = factors; C->prm = prm;
+    C->dense = B.dense;
+    C->tree.swap(B.tree);
+    C->memo.swap(B.memo);
+    C->memo_of_first.assign(N, -1);
+    C->memo_next.assign(C->memo.size(), -1);
+    for (int mi = (int)C->memo.size() - 1; mi >= 0; mi--) {
+      const int fp = C->memo[mi].first;
+      if (fp < 0) continue;
+      C->memo_next[mi] = C->memo_of_first[fp];
+      C->memo_of_first[fp] = mi;
+    }
+    C->post.swap(post);
+    C->f_pos0.swap(f_pos0); C->f_npiv.swap(f_npiv);
+    C->bnd.swap(bnd);
+    C->blk_pu.swap(blk_pu);
+    C->fronts_reused = F0; C->fronts_total = F;
+    C->valid = valid;                                    // (a chain fall-back is not something to build upon)
+  } else if (C) {
+    C->valid = false;
+  }
+  lap("cache");
+  return 1;
 }
 
 double factor_flops(const Analysis& A) {
@@ -830,12 +975,21 @@ double factor_flops(const Analysis& A) {
 // when it leaves fronts beyond the wave-per-front kernels (pose graphs with many loop closures, 2-D meshes) the
 // general minimum-degree ordering is analysed as well and the cheaper factorisation (flops) wins.
 bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
-             Analysis& A, const char** msg) {
-  if (!analyze_with(nodes, factors, prm, A, msg, prm.ordering == 1)) return false;
+             Analysis& A, const char** msg, AnalysisCache* cache) {
+  int rc = 2;
+  if (cache && cache->valid && prm.ordering != 1 && prm.aligned_cuts) rc = analyze_with(nodes, factors, prm, A, msg, false, cache, true);
+  if (rc == 2) {
+    if (cache) cache->valid = false;
+    rc = analyze_with(nodes, factors, prm, A, msg, prm.ordering == 1, cache, false);
+  }
+  if (rc != 1) { if (cache) cache->valid = false; return false; }
   if (prm.ordering == 0 && A.max_front > prm.band_rows) {
     Analysis G;
     const char* m2 = "";
-    if (analyze_with(nodes, factors, prm, G, &m2, true) && factor_flops(G) < factor_flops(A)) A = std::move(G);
+    if (analyze_with(nodes, factors, prm, G, &m2, true, nullptr, false) == 1 && factor_flops(G) < factor_flops(A)) {
+      A = std::move(G);
+      if (cache) cache->valid = false;
+    }
   }
   return true;
 }

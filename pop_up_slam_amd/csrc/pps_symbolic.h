@@ -124,9 +124,20 @@ struct Analysis {
   std::vector<int> nd_segs;              // segments that are not direct
 };
 
+// What one analysis leaves behind for the next one of the same, grown graph (frame loops; opaque).
+struct AnalysisCache;
+AnalysisCache* analysis_cache_new();
+void analysis_cache_free(AnalysisCache* c);
+// fronts / tree nodes the last analysis with this cache took over from the one before (0 = it started from scratch)
+void analysis_cache_stats(const AnalysisCache* c, int* fronts_reused, int* fronts_total);
+
 // nodes/factors are the compacted live sets.  Returns false (with msg) on structural problems.
+// cache (may be NULL): when the graph is the previous one plus appended nodes / factors (every new factor touches a new
+// node) and prm.aligned_cuts is set, the part of the elimination tree left of the new poses -- with its fronts, boundaries,
+// H blocks and all index arrays of `out`, which must still hold the previous result -- is kept and only the rest is redone.
+// The result is identical, array for array, to an analysis from scratch.
 bool analyze(const std::vector<SymNode>& nodes, const std::vector<SymFactor>& factors, const AnalysisParams& prm,
-             Analysis& out, const char** msg);
+             Analysis& out, const char** msg, AnalysisCache* cache = nullptr);
 
 // ea_tgt from cmap / f_ea_off on the host (what k_expand_ea does on the device)
 void expand_ea_tgt(Analysis& a);

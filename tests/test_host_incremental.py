@@ -1,0 +1,88 @@
+"""CPU: the frame-loop form of the symbolic analysis.  A graph that only grows (one pose per frame, its odometry edge, its plane
+observations, now and then a new landmark) is re-analysed incrementally: the part of the elimination tree left of the new
+poses is kept with all of its index arrays.  The result must be the analysis from scratch -- every exported array equal --
+and must solve the normal equations (numpy multifrontal emulation of both kernel families)."""
+import numpy as np
+import pytest
+
+import pop_up_slam_amd as P
+from pop_up_slam_amd import pipeline, synth
+from mf_emulator import solve_with_analysis, solve_with_band_schedule
+
+I6 = synth._ut_diag([1.0] * 6)
+I3 = synth._ut_diag([1.0] * 3)
+
+
+def _grow(g, st, fr):
+    p = g.add_pose(fr.true_pose)
+    if st["prev"] is None:
+        g.add_pose_prior(p, np.zeros(6), I6)
+    else:
+        g.add_odometry(st["prev"], p, np.zeros(6), I6)
+    st["prev"] = p
+    for key in ["g"] + list(fr.ids):
+        if key not in st["lm"]:
+            st["lm"][key] = g.add_plane(np.array([0, 1.0, 0, -1.0]))
+            if key == "g":
+                g.add_plane_prior(st["lm"][key], np.array([0, 0, 1.0, 0]), I3)
+        g.add_plane_obs(p, st["lm"][key], np.array([0, 1.0, 0, -1.0]), I3)
+
+
+def test_incremental_analysis_equals_analysis_from_scratch(built, monkeypatch):
+    n = 260
+    frames = pipeline.popup_sequence(n, seed=5)
+    gi, gf = P.Graph(), P.Graph()
+    si, sf = {"prev": None, "lm": {}}, {"prev": None, "lm": {}}
+    kept = []
+    for k, fr in enumerate(frames):
+        _grow(gi, si, fr); _grow(gf, sf, fr)
+        gi.analyze()
+        kept.append(gi.analysis_reuse())
+        monkeypatch.setenv("PPS_NO_INCREMENTAL", "1")
+        gf.analyze()
+        monkeypatch.delenv("PPS_NO_INCREMENTAL")
+        assert gf.analysis_reuse()[0] == 0
+        if k % 5 == 0 or k >= n - 3:
+            a, b = gi.analysis_dump(), gf.analysis_dump()
+            assert a.keys() == b.keys()
+            for key in b:
+                np.testing.assert_array_equal(np.atleast_1d(a[key]), np.atleast_1d(b[key]), err_msg=f"frame {k}: {key}")
+    kept = np.array(kept)
+    assert (kept[100:, 0] > 0).mean() > 0.9                     # nearly every frame builds on the previous one ...
+    assert (kept[100:, 0] / kept[100:, 1]).mean() > 0.8          # ... and keeps most of its fronts
+
+
+def test_incremental_analysis_solves_the_normal_equations(built):
+    """the arrays an incremental analysis leaves behind, replayed by the numpy emulation of the level and the band kernels"""
+    from test_host_analysis import _dense_and_jbuf
+    spec = synth.corridor(90, 20, seed=11)
+    # replay the spec frame by frame: nodes and factors in creation order, an analysis after every pose
+    g = P.Graph()
+    nid = {}
+    done = 0
+    order = np.argsort(spec.meta["factor_after_node"], kind="stable") if "factor_after_node" in spec.meta else np.arange(len(spec.f_type))
+    fa = spec.meta["factor_after_node"]
+    fi = 0
+    for i in range(len(spec.node_type)):
+        nid[i] = g.add_pose(spec.node_init[i, :7]) if spec.node_type[i] == synth.NODE_POSE else g.add_plane(spec.node_init[i, :4])
+        while fi < len(order) and fa[order[fi]] <= i:
+            k = order[fi]; t = spec.f_type[k]; a, b = spec.f_nodes[k]
+            if t == synth.F_POSE_PRIOR: g.add_pose_prior(nid[a], spec.f_meas[k, :6], spec.f_sqrtinf[k, :21])
+            elif t == synth.F_ODOMETRY: g.add_odometry(nid[a], nid[b], spec.f_meas[k, :6], spec.f_sqrtinf[k, :21])
+            elif t == synth.F_PLANE_OBS: g.add_plane_obs(nid[a], nid[b], spec.f_meas[k, :4], spec.f_sqrtinf[k, :6])
+            else: g.add_plane_prior(nid[a], spec.f_meas[k, :4], spec.f_sqrtinf[k, :6])
+            fi += 1
+        if spec.node_type[i] == synth.NODE_POSE and fi > 0:
+            g.analyze()
+    assert fi == len(order)
+    g.analyze()
+    A = g.analysis_dump()
+    for lam in (0.0, 1e-3):
+        dref, Jbuf, starts, dims = _dense_and_jbuf(spec, A, lam)
+        for solver in (solve_with_analysis, solve_with_band_schedule):
+            d = solver(A, Jbuf, lam)
+            dm = np.zeros_like(dref)
+            for i in range(len(dims)):
+                c = A["node_compact"][i]
+                dm[starts[i]:starts[i] + dims[i]] = d[A["node_voff"][c]:A["node_voff"][c] + dims[i]]
+            assert np.abs(dm - dref).max() <= 1e-9 * np.abs(dref).max(), solver.__name__
