@@ -95,6 +95,19 @@ struct pps_graph {
   char* stage = nullptr;            // pinned host mirror of `up` (one H2D copy per upload, at link rate)
   size_t stage_cap = 0;
   size_t stage_lo = 0, stage_hi = 0;   // dirty range of the mirror
+  // Frame loops re-upload a topology that is the previous one plus a little: every array of the upload arena keeps its
+  // place from one upload to the next (a slot with spare capacity per dev_upload call, in call order), the pinned mirror
+  // knows what the device holds, and only the bytes that differ are sent -- gathered into one patch buffer, one copy, one
+  // scatter kernel (dozens of small copies would cost more than they carry).
+  struct UpSlot { size_t off, cap; };
+  std::vector<UpSlot> up_slots;
+  size_t up_cursor = 0, up_high = 0;
+  bool up_unknown = true;              // the arena was (re)allocated: the mirror says nothing about the device
+  struct UpPatch { size_t off, len; };
+  std::vector<UpPatch> up_patches;
+  char* patch_host = nullptr; size_t patch_cap = 0;    // pinned: [table | data]
+  char* patch_dev = nullptr; size_t patch_dev_cap = 0;
+  size_t up_bytes_sent = 0, up_bytes_total = 0;        // of the last flush (stats)
   double* host_result = nullptr;   // pinned, 12 doubles: chi2 at the linearisation point | trial | speculative trial
   double seq = 0.0;                // sequence number the chi2 kernel publishes last (host polls it)
   // speculative solve of the LM reject branch (lambda * factor) on a second stream, into a second set of L/U/delta
@@ -160,18 +173,21 @@ void free_device(pps_graph* g) {
   g->allocs.clear();
   // arenas are kept; grow them when the last layout spilled into fallback allocations
   for (pps_graph::Arena* a : {&g->up, &g->scr}) {
-    const size_t want = a->off + a->spill;
+    const size_t want = (a == &g->up ? std::max(a->off, g->up_high) : a->off) + a->spill;
     if (a->spill > 0 || a->base == nullptr) {
       if (a->base) (void)hipFree(a->base);
       a->cap = std::max<size_t>(size_t(1) << 20, 2 * want);
       if (hipMalloc(reinterpret_cast<void**>(&a->base), a->cap) != hipSuccess) { a->base = nullptr; a->cap = 0; }
+      if (a == &g->up) { g->up_slots.clear(); g->up_high = 0; g->up_unknown = true; }
     }
     a->off = 0; a->spill = 0;
   }
+  g->up_cursor = 0; g->up_patches.clear();
   if (g->stage_cap < g->up.cap) {
     if (g->stage) (void)hipHostFree(g->stage);
     g->stage = nullptr; g->stage_cap = 0;
     if (hipHostMalloc(reinterpret_cast<void**>(&g->stage), g->up.cap, hipHostMallocDefault) == hipSuccess) g->stage_cap = g->up.cap;
+    g->up_unknown = true;
   }
   g->stage_lo = g->stage_hi = 0;
   g->dev = DevGraph();
@@ -181,6 +197,10 @@ void release_arenas(pps_graph* g) {
   for (pps_graph::Arena* a : {&g->up, &g->scr}) { if (a->base) (void)hipFree(a->base); a->base = nullptr; a->cap = a->off = a->spill = 0; }
   if (g->stage) (void)hipHostFree(g->stage);
   g->stage = nullptr; g->stage_cap = 0;
+  if (g->patch_host) (void)hipHostFree(g->patch_host);
+  if (g->patch_dev) (void)hipFree(g->patch_dev);
+  g->patch_host = g->patch_dev = nullptr; g->patch_cap = g->patch_dev_cap = 0;
+  g->up_slots.clear(); g->up_high = 0; g->up_unknown = true;
 }
 
 template <class T>
@@ -202,27 +222,102 @@ int arena_alloc(pps_graph* g, pps_graph::Arena& a, T** out, size_t count) {
 template <class T>
 int dev_alloc(pps_graph* g, T** out, size_t count) { return arena_alloc(g, g->scr, out, count); }
 
+// The k-th upload of a layout goes where the k-th upload of the previous layout went, as long as it fits the slot.
 template <class T>
 int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
-  int rc = arena_alloc(g, g->up, out, v.size());
-  if (rc != PPS_OK) return rc;
-  if (v.empty()) return PPS_OK;
-  char* p = reinterpret_cast<char*>(*out);
-  if (g->stage && g->up.base && p >= g->up.base && p < g->up.base + g->up.cap) {      // staged: goes out with the next flush
-    const size_t o = (size_t)(p - g->up.base);
-    memcpy(g->stage + o, v.data(), v.size() * sizeof(T));
-    if (g->stage_hi == g->stage_lo) { g->stage_lo = o; g->stage_hi = o + v.size() * sizeof(T); }
-    else { g->stage_lo = std::min(g->stage_lo, o); g->stage_hi = std::max(g->stage_hi, o + v.size() * sizeof(T)); }
-  } else {
-    HIP_TRY(g, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = nullptr;
+  pps_graph::Arena& a = g->up;
+  const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(T);
+  const size_t k = g->up_cursor++;
+  size_t o = 0;
+  bool placed = false;
+  if (a.base && g->stage) {
+    if (k < g->up_slots.size() && bytes <= g->up_slots[k].cap) { o = g->up_slots[k].off; placed = true; }
+    else {
+      const size_t cap = (std::max<size_t>(256, bytes + bytes / 2) + 255) & ~size_t(255);
+      o = (g->up_high + 255) & ~size_t(255);
+      if (o + cap <= a.cap) {
+        if (k < g->up_slots.size()) g->up_slots[k] = pps_graph::UpSlot{o, cap}; else g->up_slots.push_back(pps_graph::UpSlot{o, cap});
+        g->up_high = o + cap;
+        placed = true;
+      }
+    }
   }
+  if (!placed) {                                     // arena exhausted (it is re-sized at the next upload): a plain allocation
+    a.spill += bytes + bytes / 2 + 512;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return hip_fail(g, e, "hipMalloc");
+    g->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    if (!v.empty()) HIP_TRY(g, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PPS_OK;
+  }
+  *out = reinterpret_cast<T*>(a.base + o);
+  a.off = std::max(a.off, o + bytes);
+  if (v.empty()) return PPS_OK;
+  const size_t n = v.size() * sizeof(T);
+  const char* src = reinterpret_cast<const char*>(v.data());
+  char* mir = g->stage + o;
+  g->up_bytes_total += n;
+  if (g->up_unknown) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n}); return PPS_OK; }
+  // first and last 64-byte chunk that differs from what the device holds
+  size_t lo = 0, hi = n;
+  while (lo + 64 <= hi && memcmp(mir + lo, src + lo, 64) == 0) lo += 64;
+  if (lo + 64 > hi && memcmp(mir + lo, src + lo, hi - lo) == 0) return PPS_OK;      // identical
+  while (hi >= lo + 64 && memcmp(mir + hi - 64, src + hi - 64, 64) == 0) hi -= 64;
+  lo &= ~size_t(15);
+  memcpy(mir + lo, src + lo, hi - lo);
+  g->up_patches.push_back(pps_graph::UpPatch{o + lo, hi - lo});
   return PPS_OK;
 }
 
-// send the staged part of the upload arena in one copy
+// send what differs: everything in one copy when the device content is unknown or most of it changed, else the patches
 int flush_uploads(pps_graph* g) {
-  if (g->stage_hi > g->stage_lo)
-    HIP_TRY(g, hipMemcpy(g->up.base + g->stage_lo, g->stage + g->stage_lo, g->stage_hi - g->stage_lo, hipMemcpyHostToDevice));
+  size_t sent = 0;
+  for (const auto& pt : g->up_patches) sent += pt.len;
+  g->up_bytes_sent = sent;
+  if (g->up_patches.empty()) { g->up_bytes_total = 0; return PPS_OK; }
+  const bool bulk = g->up_unknown || g->up_patches.size() <= 2 || sent * 2 > g->up_high || getenv("PPS_NO_PATCH_UPLOAD");
+  if (bulk) {
+    size_t lo = g->up_patches[0].off, hi = lo;
+    for (const auto& pt : g->up_patches) { lo = std::min(lo, pt.off); hi = std::max(hi, pt.off + pt.len); }
+    if (g->up_unknown) { lo = 0; hi = std::max(hi, g->up_high); hi = std::min(hi, g->stage_cap); }
+    HIP_TRY(g, hipMemcpyAsync(g->up.base + lo, g->stage + lo, hi - lo, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    g->up_bytes_sent = hi - lo;
+  } else {
+    // [table: 4 x int64 per patch | data, 16-byte aligned pieces] -> one copy -> scatter kernel
+    const size_t np = g->up_patches.size();
+    size_t need = np * 32;
+    std::vector<size_t> src_off(np);
+    for (size_t i = 0; i < np; i++) { need = (need + 15) & ~size_t(15); src_off[i] = need; need += (g->up_patches[i].len + 15) & ~size_t(15); }
+    if (need > g->patch_cap) {
+      if (g->patch_host) (void)hipHostFree(g->patch_host);
+      g->patch_host = nullptr; g->patch_cap = 0;
+      const size_t cap = std::max<size_t>(1 << 16, 2 * need);
+      HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->patch_host), cap, hipHostMallocDefault));
+      g->patch_cap = cap;
+    }
+    if (need > g->patch_dev_cap) {
+      if (g->patch_dev) (void)hipFree(g->patch_dev);
+      g->patch_dev = nullptr; g->patch_dev_cap = 0;
+      const size_t cap = std::max<size_t>(1 << 16, 2 * need);
+      HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->patch_dev), cap));
+      g->patch_dev_cap = cap;
+    }
+    long long* tab = reinterpret_cast<long long*>(g->patch_host);
+    for (size_t i = 0; i < np; i++) {
+      const auto& pt = g->up_patches[i];
+      tab[4 * i + 0] = (long long)pt.off; tab[4 * i + 1] = (long long)src_off[i]; tab[4 * i + 2] = (long long)((pt.len + 15) & ~size_t(15)); tab[4 * i + 3] = 0;
+      memcpy(g->patch_host + src_off[i], g->stage + pt.off, (pt.len + 15) & ~size_t(15));    // the mirror already holds the new bytes
+    }
+    HIP_TRY(g, hipMemcpyAsync(g->patch_dev, g->patch_host, need, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, launch_scatter_patches(g->patch_dev, (int)np, g->up.base, g->stream));
+    HIP_TRY(g, hipStreamSynchronize(g->stream));       // the patch buffer is re-used by the next flush
+  }
+  g->up_unknown = false;
+  g->up_patches.clear();
   g->stage_lo = g->stage_hi = 0;
   return PPS_OK;
 }

@@ -160,6 +160,9 @@ hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, h
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor = nullptr);   // K3, lambda per graph
 hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // est <- lin, lin <- lin (+) delta, chi2 -> slot 1
 
+// patch upload: table of (dst offset, src offset, bytes [multiple of 16], -) int64 quadruples at the head of `patch`
+hipError_t launch_scatter_patches(const char* patch, int n_patches, char* arena, hipStream_t st);
+
 // Largest front (scalars incl. rhs row) the LDS path of the factor kernel accepts.
 int lds_front_limit();
 

@@ -1990,6 +1990,21 @@ hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_
   return launch_batch_chi2(a, g, 1, st);
 }
 
+// patch upload of a re-uploaded topology (pps_api.cpp: flush_uploads): piece i of the patch buffer -> its place in the arena
+__global__ __launch_bounds__(256) void k_scatter_patches(const char* __restrict__ patch, char* __restrict__ arena) {
+  const long long* tab = reinterpret_cast<const long long*>(patch) + 4 * (size_t)blockIdx.x;
+  const long long dst = tab[0], src = tab[1], len = tab[2];
+  const int4* s4 = reinterpret_cast<const int4*>(patch + src);
+  int4* d4 = reinterpret_cast<int4*>(arena + dst);
+  for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len / 16; i += (long long)gridDim.y * 256) d4[i] = s4[i];
+}
+
+hipError_t launch_scatter_patches(const char* patch, int n_patches, char* arena, hipStream_t st) {
+  if (n_patches <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scatter_patches, dim3(n_patches, 8), dim3(256), 0, st, patch, arena);
+  return hipGetLastError();
+}
+
 hipError_t launch_clear_status(const DevGraph& d, hipStream_t st) {
   return hipMemsetAsync(d.result_dev, 0, 4 * sizeof(double), st);
 }
