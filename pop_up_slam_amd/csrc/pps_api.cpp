@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 
@@ -68,6 +69,7 @@ struct pps_graph {
   bool analyzed = false;
   int n_analyses = 0;              // analyses so far; with `grown_only` it selects the frame-loop form of the analysis
   bool grown_only = true;          // nothing has been removed since the last analysis (nodes / factors were only appended)
+  bool grown_only_upload = false;  // ... since the last upload (false until there has been one)
   Analysis an;
   AnalysisParams aprm;
   AnalysisCache* acache = nullptr;   // what the last analysis left for the next one (frame loops)
@@ -103,6 +105,10 @@ struct pps_graph {
   std::vector<UpSlot> up_slots;
   size_t up_cursor = 0, up_high = 0;
   bool up_unknown = true;              // the arena was (re)allocated: the mirror says nothing about the device
+  bool up_unknown_meas = false;        // ... only about the measurement arrays (written behind the mirror's back)
+  size_t slot_obs_meas = (size_t)-1;   // which upload slot holds obs_meas
+  std::vector<int> pk_i[2]; std::vector<double> pk_d[2];   // packing scratch of upload_all (kept: no allocation per frame)
+  std::unordered_map<std::string, double> up_laps;         // PPS_UPLOAD_TIMING=1: seconds per phase of upload_all, summed; printed at destroy
   struct UpPatch { size_t off, len; };
   std::vector<UpPatch> up_patches;
   char* patch_host = nullptr; size_t patch_cap = 0;    // pinned: [table | data]
@@ -222,9 +228,36 @@ int arena_alloc(pps_graph* g, pps_graph::Arena& a, T** out, size_t count) {
 template <class T>
 int dev_alloc(pps_graph* g, T** out, size_t count) { return arena_alloc(g, g->scr, out, count); }
 
+// bytes [0, n) of `src` against the mirror at offset o: record (and copy into the mirror) the range that differs
+void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force) {
+  if (n == 0) return;
+  char* mir = g->stage + o;
+  g->up_bytes_total += n;
+  if (g->up_unknown || force) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n}); return; }
+  // first and last 64-byte chunk that differs from what the device holds
+  size_t lo = 0, hi = n;
+  while (lo + 64 <= hi && memcmp(mir + lo, src + lo, 64) == 0) lo += 64;
+  if (lo + 64 > hi && memcmp(mir + lo, src + lo, hi - lo) == 0) return;      // identical
+  while (hi >= lo + 64 && memcmp(mir + hi - 64, src + hi - 64, 64) == 0) hi -= 64;
+  lo &= ~size_t(15);
+  memcpy(mir + lo, src + lo, hi - lo);
+  g->up_patches.push_back(pps_graph::UpPatch{o + lo, hi - lo});
+}
+
 // The k-th upload of a layout goes where the k-th upload of the previous layout went, as long as it fits the slot.
+// rows > 0: an SoA array of `rows` rows with leading dimension ld of which the first `used` entries per row are live -- the
+// rows are compared one by one (appending a factor touches the end of every row, not the array from end to end).
 template <class T>
-int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
+int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force);
+template <class T>
+int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) { return dev_upload_impl(g, out, v, 0, 0, 0, false); }
+template <class T>
+int dev_upload_rows(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force) {
+  return dev_upload_impl(g, out, v, rows, ld, used, force);
+}
+
+template <class T>
+int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force) {
   *out = nullptr;
   pps_graph::Arena& a = g->up;
   const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(T);
@@ -256,19 +289,9 @@ int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) {
   *out = reinterpret_cast<T*>(a.base + o);
   a.off = std::max(a.off, o + bytes);
   if (v.empty()) return PPS_OK;
-  const size_t n = v.size() * sizeof(T);
   const char* src = reinterpret_cast<const char*>(v.data());
-  char* mir = g->stage + o;
-  g->up_bytes_total += n;
-  if (g->up_unknown) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n}); return PPS_OK; }
-  // first and last 64-byte chunk that differs from what the device holds
-  size_t lo = 0, hi = n;
-  while (lo + 64 <= hi && memcmp(mir + lo, src + lo, 64) == 0) lo += 64;
-  if (lo + 64 > hi && memcmp(mir + lo, src + lo, hi - lo) == 0) return PPS_OK;      // identical
-  while (hi >= lo + 64 && memcmp(mir + hi - 64, src + hi - 64, 64) == 0) hi -= 64;
-  lo &= ~size_t(15);
-  memcpy(mir + lo, src + lo, hi - lo);
-  g->up_patches.push_back(pps_graph::UpPatch{o + lo, hi - lo});
+  if (rows == 0 || g->up_unknown) { up_diff(g, o, src, v.size() * sizeof(T), force); return PPS_OK; }
+  for (size_t r = 0; r < rows; r++) up_diff(g, o + r * ld * sizeof(T), src + r * ld * sizeof(T), used * sizeof(T), force);
   return PPS_OK;
 }
 
@@ -546,16 +569,17 @@ int upload_state(pps_graph* g) {
   return PPS_OK;
 }
 
+// SoA with leading dimension ld (>= count): value k of slot s at [k * ld + s]
 template <int K>
-void pack_soa(const pps_graph* g, int type, const double HostFactor::*dummy, bool weights, std::vector<double>& out) {
+void pack_soa(const pps_graph* g, int type, const double HostFactor::*dummy, bool weights, std::vector<double>& out, size_t ld) {
   (void)dummy;
   const std::vector<int>& ids = g->fslot_ids[type];
   const size_t n = ids.size();
-  out.assign((size_t)K * n, 0.0);
+  out.assign((size_t)K * ld, 0.0);
   for (size_t s = 0; s < n; s++) {
     const HostFactor& f = g->factors[ids[s]];
     const double* src = weights ? f.w : f.meas;
-    for (int k = 0; k < K; k++) out[(size_t)k * n + s] = src[k];
+    for (int k = 0; k < K; k++) out[(size_t)k * ld + s] = src[k];
   }
 }
 
@@ -564,13 +588,13 @@ int download_measurements(pps_graph* g) {
   if (!g->dev_meas_newer) return PPS_OK;
   HIP_TRY(g, hipSetDevice(g->props.device));
   const DevGraph& d = g->dev;
-  const size_t n = g->fslot_ids[F_PLANE_OBS].size();
-  std::vector<double> m((size_t)4 * n);
+  const size_t n = g->fslot_ids[F_PLANE_OBS].size(), ld = (size_t)d.obs_ld;
+  std::vector<double> m((size_t)4 * ld);
   if (n) HIP_TRY(g, hipMemcpyAsync(m.data(), d.obs_meas, m.size() * 8, hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(g, hipStreamSynchronize(g->stream));
-  for (size_t s2 = 0; s2 < n; s2++) {
+  for (size_t s2 = 0; s2 < n && s2 < (size_t)d.n_obs; s2++) {
     HostFactor& f = g->factors[g->fslot_ids[F_PLANE_OBS][s2]];
-    for (int k = 0; k < 4; k++) f.meas[k] = m[(size_t)k * n + s2];
+    for (int k = 0; k < 4; k++) f.meas[k] = m[(size_t)k * ld + s2];
   }
   g->dev_meas_newer = false;
   return PPS_OK;
@@ -579,11 +603,13 @@ int download_measurements(pps_graph* g) {
 int upload_measurements(pps_graph* g) {
   DevGraph& d = g->dev;
   std::vector<double> m;
-  pack_soa<4>(g, F_PLANE_OBS, nullptr, false, m);
-  if (!m.empty()) HIP_TRY(g, hipMemcpyAsync(d.obs_meas, m.data(), m.size() * 8, hipMemcpyHostToDevice, g->stream));
+  pack_soa<4>(g, F_PLANE_OBS, nullptr, false, m, (size_t)d.obs_ld);
+  if (d.n_obs) HIP_TRY(g, hipMemcpyAsync(d.obs_meas, m.data(), m.size() * 8, hipMemcpyHostToDevice, g->stream));
   std::vector<double> m2;
-  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, m2);
-  if (!m2.empty()) HIP_TRY(g, hipMemcpyAsync(d.lp_meas, m2.data(), m2.size() * 8, hipMemcpyHostToDevice, g->stream));
+  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, m2, (size_t)d.lp_ld);
+  if (d.n_lp) HIP_TRY(g, hipMemcpyAsync(d.lp_meas, m2.data(), m2.size() * 8, hipMemcpyHostToDevice, g->stream));
+  // (the upload mirror no longer describes these arrays: the next topology upload sends them whole)
+  g->up_unknown_meas = true;
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->meas_dirty = false;
   return PPS_OK;
@@ -591,19 +617,36 @@ int upload_measurements(pps_graph* g) {
 
 int upload_all(pps_graph* g) {
   const double t0 = now_s();
+  const bool tm = getenv("PPS_UPLOAD_TIMING") != nullptr;
+  double tl = t0;
+  auto lap = [&](const char* what) { if (!tm) return; const double t = now_s(); g->up_laps[what] += t - tl; tl = t; };
   int rc = ensure_device(g);
   if (rc != PPS_OK) return rc;
   if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
-  if (g->dev_meas_newer) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
+  // Refreshed measurements may stay on the device across an upload that only appends (see the obs_meas upload below): same
+  // arena, same slot with room for the new rows, same leading dimension, no re-popping edges (their slots sit behind the
+  // fixed ones and would move).
+  bool keep_meas = false;
+  if (g->dev_meas_newer) {
+    size_t n_obs_new = 0, n_lp_new = 0; bool any_repop = false;
+    for (const HostFactor& f : g->factors) if (!f.deleted) { n_obs_new += f.type == F_PLANE_OBS; n_lp_new += f.type == F_PLANE_PRIOR; any_repop = any_repop || (f.type == F_PLANE_OBS && f.repop); }
+    keep_meas = g->grown_only_upload && !g->up_unknown && !g->up_unknown_meas && g->up.spill == 0 && !any_repop && g->dev.n_obs == g->dev.n_obs_fixed &&
+                j_capacity((int64_t)n_obs_new) == g->dev.obs_ld && j_capacity((int64_t)n_lp_new) == g->dev.lp_ld && g->slot_obs_meas < g->up_slots.size() &&
+                !getenv("PPS_NO_KEEP_MEAS");
+    if (!keep_meas) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
+  }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   if (g->stream_b) HIP_TRY(g, hipStreamSynchronize(g->stream_b));
+  lap("1 state/meas download + syncs");
   free_device(g);
   g->spec_L = g->spec_U = g->spec_delta = nullptr; g->spec_result = nullptr;
   g->spec_pose = g->spec_plane = g->spec_chi2_partials = g->spec_dn_partials = nullptr; g->spec_ticket = nullptr;
   g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
   g->frames_dirty = true;
   g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
+  lap("2 free_device");
   if (!g->analyzed || g->analysis_stale) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
+  lap("3 analysis");
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
@@ -628,9 +671,28 @@ int upload_all(pps_graph* g) {
     return v;
   };
   std::vector<double> tmp;
-  TRY(dev_upload(g, &d.obs_pose, idx_of(F_PLANE_OBS, false))); TRY(dev_upload(g, &d.obs_plane, idx_of(F_PLANE_OBS, true)));
-  pack_soa<4>(g, F_PLANE_OBS, nullptr, false, tmp); TRY(dev_upload(g, &d.obs_meas, tmp));
-  pack_soa<6>(g, F_PLANE_OBS, nullptr, true, tmp); TRY(dev_upload(g, &d.obs_w, tmp));
+  d.obs_ld = (int)j_capacity(d.n_obs); d.odo_ld = (int)j_capacity(d.n_odo); d.pp_ld = (int)j_capacity(d.n_pp); d.lp_ld = (int)j_capacity(d.n_lp);
+  {
+    // one pass over the plane observations (a HostFactor is 300 bytes: four passes were four times the memory traffic)
+    const std::vector<int>& ids = g->fslot_ids[F_PLANE_OBS];
+    const size_t n = ids.size(), ld = (size_t)d.obs_ld;
+    std::vector<int>& ia = g->pk_i[0]; std::vector<int>& ib = g->pk_i[1];
+    std::vector<double>& pm = g->pk_d[0]; std::vector<double>& pw = g->pk_d[1];
+    ia.resize(n); ib.resize(n); pm.assign(4 * ld, 0.0); pw.assign(6 * ld, 0.0);
+    for (size_t s2 = 0; s2 < n; s2++) {
+      const HostFactor& f = g->factors[ids[s2]];
+      ia[s2] = g->nodes[f.a].slot; ib[s2] = g->nodes[f.b].slot;
+      for (int k = 0; k < 4; k++) pm[(size_t)k * ld + s2] = f.meas[k];
+      for (int k = 0; k < 6; k++) pw[(size_t)k * ld + s2] = f.w[k];
+    }
+    TRY(dev_upload(g, &d.obs_pose, ia)); TRY(dev_upload(g, &d.obs_plane, ib));
+    // Measurements that a device-side refresh has rewritten (pps_refresh_measurements) stay where they are when this upload
+    // only appends: the host packs its (older) copies, the mirror holds the same bytes, so nothing is sent for them and the
+    // device keeps the refreshed values; only the new observations travel.  dev_meas_newer stays set.
+    g->slot_obs_meas = g->up_cursor;
+    TRY(dev_upload_rows(g, &d.obs_meas, pm, 4, ld, n, g->up_unknown_meas));
+    TRY(dev_upload_rows(g, &d.obs_w, pw, 6, ld, n, false));
+  }
   d.n_obs_fixed = g->n_obs_fixed;
   {
     const std::vector<int>& ids = g->fslot_ids[F_PLANE_OBS];
@@ -642,15 +704,30 @@ int upload_all(pps_graph* g) {
       TRY(dev_upload(g, &d.obs_ray, tmp));
     }
   }
-  TRY(dev_upload(g, &d.odo_a, idx_of(F_ODOMETRY, false))); TRY(dev_upload(g, &d.odo_b, idx_of(F_ODOMETRY, true)));
-  pack_soa<6>(g, F_ODOMETRY, nullptr, false, tmp); TRY(dev_upload(g, &d.odo_meas, tmp));
-  pack_soa<21>(g, F_ODOMETRY, nullptr, true, tmp); TRY(dev_upload(g, &d.odo_w, tmp));
+  {
+    const std::vector<int>& ids = g->fslot_ids[F_ODOMETRY];
+    const size_t n = ids.size(), ld = (size_t)d.odo_ld;
+    std::vector<int>& ia = g->pk_i[0]; std::vector<int>& ib = g->pk_i[1];
+    std::vector<double>& pm = g->pk_d[0]; std::vector<double>& pw = g->pk_d[1];
+    ia.resize(n); ib.resize(n); pm.assign(6 * ld, 0.0); pw.assign(21 * ld, 0.0);
+    for (size_t s2 = 0; s2 < n; s2++) {
+      const HostFactor& f = g->factors[ids[s2]];
+      ia[s2] = g->nodes[f.a].slot; ib[s2] = g->nodes[f.b].slot;
+      for (int k = 0; k < 6; k++) pm[(size_t)k * ld + s2] = f.meas[k];
+      for (int k = 0; k < 21; k++) pw[(size_t)k * ld + s2] = f.w[k];
+    }
+    TRY(dev_upload(g, &d.odo_a, ia)); TRY(dev_upload(g, &d.odo_b, ib));
+    TRY(dev_upload_rows(g, &d.odo_meas, pm, 6, ld, n, false));
+    TRY(dev_upload_rows(g, &d.odo_w, pw, 21, ld, n, false));
+  }
   TRY(dev_upload(g, &d.pp_pose, idx_of(F_POSE_PRIOR, false)));
-  pack_soa<6>(g, F_POSE_PRIOR, nullptr, false, tmp); TRY(dev_upload(g, &d.pp_meas, tmp));
-  pack_soa<21>(g, F_POSE_PRIOR, nullptr, true, tmp); TRY(dev_upload(g, &d.pp_w, tmp));
+  pack_soa<6>(g, F_POSE_PRIOR, nullptr, false, tmp, (size_t)d.pp_ld); TRY(dev_upload_rows(g, &d.pp_meas, tmp, 6, (size_t)d.pp_ld, (size_t)d.n_pp, false));
+  pack_soa<21>(g, F_POSE_PRIOR, nullptr, true, tmp, (size_t)d.pp_ld); TRY(dev_upload_rows(g, &d.pp_w, tmp, 21, (size_t)d.pp_ld, (size_t)d.n_pp, false));
   TRY(dev_upload(g, &d.lp_plane, idx_of(F_PLANE_PRIOR, false)));
-  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, tmp); TRY(dev_upload(g, &d.lp_meas, tmp));
-  pack_soa<6>(g, F_PLANE_PRIOR, nullptr, true, tmp); TRY(dev_upload(g, &d.lp_w, tmp));
+  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, tmp, (size_t)d.lp_ld); TRY(dev_upload_rows(g, &d.lp_meas, tmp, 4, (size_t)d.lp_ld, (size_t)d.n_lp, g->up_unknown_meas));
+  pack_soa<6>(g, F_PLANE_PRIOR, nullptr, true, tmp, (size_t)d.lp_ld); TRY(dev_upload_rows(g, &d.lp_w, tmp, 6, (size_t)d.lp_ld, (size_t)d.n_lp, false));
+  g->up_unknown_meas = false;
+  lap("4 factor packing + diff");
   // linear system storage
   TRY(dev_alloc(g, &d.J, (size_t)A.J_size)); TRY(dev_alloc(g, &d.H, (size_t)A.H_size));
   TRY(dev_alloc(g, &d.L, (size_t)A.L_size)); TRY(dev_alloc(g, &d.U, (size_t)A.U_size));
@@ -712,14 +789,19 @@ int upload_all(pps_graph* g) {
     TRY(dev_alloc(g, &d.gwork, (size_t)d.gwork_stride * std::max(1, widest)));
   }
 #undef TRY
+  lap("5 index arrays + diff");
   rc = flush_uploads(g); if (rc != PPS_OK) return rc;
+  lap("6 flush");
   if (A.ea_total > 0) HIP_TRY(g, launch_expand_ea(d, A.n_fronts, g->stream));
   HIP_TRY(g, hipMemsetAsync(d.blk_dst, 0xff, sizeof(int) * (size_t)std::max(1, A.blk_doff[A.n_blocks]), g->stream));
   HIP_TRY(g, launch_expand_el(d, (int)A.asm_blk.size(), g->stream));
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->topo_dirty = false;
   g->meas_dirty = false;
+  g->grown_only_upload = true;
+  lap("7 expand kernels + sync");
   rc = upload_state(g);
+  lap("8 upload_state");
   g->stats.t_upload = now_s() - t0 - g->stats.t_analysis;
   return rc;
 }
@@ -945,6 +1027,11 @@ int pps_graph_create(const pps_props* props, pps_graph** out) {
 
 int pps_graph_destroy(pps_graph* g) {
   if (!g) return PPS_EINVAL;
+  if (!g->up_laps.empty()) {
+    std::vector<std::pair<std::string, double>> v(g->up_laps.begin(), g->up_laps.end());
+    std::sort(v.begin(), v.end());
+    for (auto& kv : v) fprintf(stderr, "[upload] %-34s %9.3f ms total\n", kv.first.c_str(), 1e3 * kv.second);
+  }
   if (g->acache) analysis_cache_free(g->acache);
   if (g->dev_ready) {
     (void)hipSetDevice(g->props.device);
@@ -1093,7 +1180,7 @@ int pps_remove_factor(pps_graph* g, int fid) {
   if (!g) return PPS_EINVAL;
   if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "remove_factor: unknown id");
   g->factors[fid].deleted = true;
-  g->grown_only = false;
+  g->grown_only = false; g->grown_only_upload = false;
   g->n_live_factors--;
   g->dim_measure -= kFDim[g->factors[fid].type];
   g->topo_dirty = true; g->analysis_stale = true;
@@ -1109,7 +1196,7 @@ int pps_remove_node(pps_graph* g, int nid) {
     if (!f.deleted && (f.a == nid || f.b == nid)) pps_remove_factor(g, (int)i);
   }
   g->nodes[nid].deleted = true;
-  g->grown_only = false;
+  g->grown_only = false; g->grown_only_upload = false;
   g->n_live_nodes--;
   g->dim_nodes -= g->nodes[nid].type == NODE_POSE ? 6 : 3;
   g->topo_dirty = true; g->analysis_stale = true; g->host_values_newer = true;
@@ -1899,9 +1986,9 @@ int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec
   auto cleanup = [&]() { (void)hipStreamSynchronize(g->stream); for (void* p : tmp) (void)hipFree(p); };
 #define BT(x) do { rc = (x); if (rc != PPS_OK) { cleanup(); return rc; } } while (0)
   BT(rep(&d.obs_pose, (size_t)d.n_obs)); BT(rep(&d.obs_plane, (size_t)d.n_obs));
-  BT(rep(&d.obs_meas, (size_t)4 * d.n_obs)); BT(rep(&d.obs_w, (size_t)6 * d.n_obs));
+  BT(rep(&d.obs_meas, (size_t)4 * d.obs_ld)); BT(rep(&d.obs_w, (size_t)6 * d.obs_ld));
   BT(rep(&d.odo_a, (size_t)d.n_odo)); BT(rep(&d.odo_b, (size_t)d.n_odo));
-  BT(rep(&d.odo_meas, (size_t)6 * d.n_odo)); BT(rep(&d.odo_w, (size_t)21 * d.n_odo));
+  BT(rep(&d.odo_meas, (size_t)6 * d.odo_ld)); BT(rep(&d.odo_w, (size_t)21 * d.odo_ld));
 #undef BT
   const size_t slab = (size_t)d.n_obs * 30 + (size_t)d.n_odo * 78;
   double* Jbig = nullptr;
@@ -1992,7 +2079,7 @@ int pps_refresh_measurements(pps_graph* g) {
   a.frame_pose_slot = g->d_frame_pose_slot; a.frame_seg_off = g->d_frame_seg_off; a.seg2d = g->d_fr_seg;
   memcpy(a.invK, g->frames_invK, sizeof a.invK);
   a.pose_est = g->dev.pose_est; a.pose_ld = g->dev.pose_ld;
-  a.obs_meas = g->dev.obs_meas; a.n_obs = g->dev.n_obs;
+  a.obs_meas = g->dev.obs_meas; a.n_obs = g->dev.n_obs; a.obs_ld = g->dev.obs_ld;
   HIP_TRY(g, launch_refresh_measurements(a, g->stream));
   g->dev_meas_newer = true;
   return PPS_OK;

@@ -23,8 +23,10 @@ struct DevGraph {
   double *pose_est = nullptr, *pose_lin = nullptr;
   double *plane_est = nullptr, *plane_lin = nullptr;
   int *pose_voff = nullptr, *plane_voff = nullptr;   // scalar offset of each node in delta
-  // ---- factors (SoA, leading dimension = count) ----
+  // ---- factors (SoA: value k of factor i at [k * ld + i]; the leading dimensions are capacities that grow in powers of two, so
+  // a factor keeps its place when others are appended) ----
   int n_obs = 0, n_odo = 0, n_pp = 0, n_lp = 0;
+  int obs_ld = 0, odo_ld = 0, pp_ld = 0, lp_ld = 0;
   int *obs_pose = nullptr, *obs_plane = nullptr; double *obs_meas = nullptr, *obs_w = nullptr;
   // plane edges [n_obs_fixed, n_obs) re-pop their measurement from two ground-edge rays at every evaluation
   // (Pose3d_Plane3d_Factor2); obs_ray is SoA [6][n_obs - n_obs_fixed]

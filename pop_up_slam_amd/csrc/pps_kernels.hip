@@ -260,8 +260,8 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
     double pz[7], pl[4], ms[4], w[6], out[30];
     load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
     load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
-    load_soa<4>(d.obs_meas, d.n_obs, i, ms);
-    load_soa<6>(d.obs_w, d.n_obs, i, w);
+    load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
+    load_soa<6>(d.obs_w, d.obs_ld, i, w);
     lin_plane_obs<MODE>(pz, pl, ms, w, out);
     if (DIRECT && b * kLinBlock + (int)threadIdx.x < d.n_obs_fixed) {
       const int hoff = d.obs_dir[3 * (size_t)i], el0 = d.obs_dir[3 * (size_t)i + 1], rows6 = d.obs_dir[3 * (size_t)i + 2];
@@ -296,8 +296,8 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
     double p1[7], p2[7], ms[6], w[21];
     load_pose(pose, d.pose_ld, d.odo_a[i], p1);
     load_pose(pose, d.pose_ld, d.odo_b[i], p2);
-    load_soa<6>(d.odo_meas, d.n_odo, i, ms);
-    load_soa<21>(d.odo_w, d.n_odo, i, w);
+    load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
+    load_soa<21>(d.odo_w, d.odo_ld, i, w);
     if (MODE == 1) {
       double out[78];
       lin_odometry<MODE>(p1, p2, ms, w, out);
@@ -315,8 +315,8 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
     if (i >= d.n_pp) return;
     double pz[7], ms[6], w[21];
     load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
-    load_soa<6>(d.pp_meas, d.n_pp, i, ms);
-    load_soa<21>(d.pp_w, d.n_pp, i, w);
+    load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
+    load_soa<21>(d.pp_w, d.pp_ld, i, w);
     lin_pose_prior<MODE>(pz, ms, w, d.J + d.joff_pp + (size_t)i * 42);
     return;
   }
@@ -326,8 +326,8 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
     if (i >= d.n_lp) return;
     double pl[4], ms[4], w[6];
     load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
-    load_soa<4>(d.lp_meas, d.n_lp, i, ms);
-    load_soa<6>(d.lp_w, d.n_lp, i, w);
+    load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
+    load_soa<6>(d.lp_w, d.lp_ld, i, w);
     lin_plane_prior<MODE>(pl, ms, w, d.J + d.joff_lp + (size_t)i * 12);
   }
 }
@@ -379,8 +379,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     double pz[7], pl[4], ms[4], w[6], e[3], y[3];
     load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
     load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
-    load_soa<4>(d.obs_meas, d.n_obs, i, ms);
-    load_soa<6>(d.obs_w, d.n_obs, i, w);
+    load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
+    load_soa<6>(d.obs_w, d.obs_ld, i, w);
     {
       // every lane takes the same path: a perturbation that does not apply is the zero step, which is the
       // exact identity for a pose; the plane keeps its stored value unless it is the perturbed node
@@ -413,8 +413,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     double p1[7], p2[7], ms[6], w[21], e[6], y[6];
     load_pose(pose, d.pose_ld, d.odo_a[i], p1);
     load_pose(pose, d.pose_ld, d.odo_b[i], p2);
-    load_soa<6>(d.odo_meas, d.n_odo, i, ms);
-    load_soa<21>(d.odo_w, d.n_odo, i, w);
+    load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
+    load_soa<21>(d.odo_w, d.odo_ld, i, w);
     {
       double pa[7], pb[7];
       perturb6(p1, q, sgn, pa);                       // out-of-range q: zero step == identity
@@ -441,8 +441,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     if (i >= d.n_pp) return;
     double pz[7], ms[6], w[21], e[6], y[6];
     load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
-    load_soa<6>(d.pp_meas, d.n_pp, i, ms);
-    load_soa<21>(d.pp_w, d.n_pp, i, w);
+    load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
+    load_soa<21>(d.pp_w, d.pp_ld, i, w);
     { double pp[7]; perturb6(pz, q, sgn, pp); res_pose_prior(pp, ms, e); }
     whiten<6>(w, e, y);
     double* __restrict__ out = d.J + d.joff_pp + (size_t)i * 42;
@@ -463,8 +463,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     if (i >= d.n_lp) return;
     double pl[4], ms[4], w[6], e[3], y[3];
     load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
-    load_soa<4>(d.lp_meas, d.n_lp, i, ms);
-    load_soa<6>(d.lp_w, d.n_lp, i, w);
+    load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
+    load_soa<6>(d.lp_w, d.lp_ld, i, w);
     {
       double lp[4];
       perturb3(pl, q, sgn, lp);
@@ -508,7 +508,7 @@ __device__ __forceinline__ void body_linearize_repop(const DevGraph& d, const do
   load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
   load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
   load_soa<6>(d.obs_ray, n2, k, ray);
-  load_soa<6>(d.obs_w, d.n_obs, i, w);
+  load_soa<6>(d.obs_w, d.obs_ld, i, w);
   res_plane_obs2(pz, pl, ray, e);
   whiten<3>(w, e, r);
   const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
@@ -580,12 +580,12 @@ __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* _
   const size_t slab = (size_t)d.n_obs * 30 + (size_t)d.n_odo * 78;
   double* Jr = Jbig + (size_t)rep * slab;
   // replicas read shifted copies of the edge arrays so that no two replicas share cache lines
-  const double* obs_meas = d.obs_meas + (size_t)rep * 4 * d.n_obs;
-  const double* obs_w = d.obs_w + (size_t)rep * 6 * d.n_obs;
+  const double* obs_meas = d.obs_meas + (size_t)rep * 4 * d.obs_ld;
+  const double* obs_w = d.obs_w + (size_t)rep * 6 * d.obs_ld;
   const int* obs_pose = d.obs_pose + (size_t)rep * d.n_obs;
   const int* obs_plane = d.obs_plane + (size_t)rep * d.n_obs;
-  const double* odo_meas = d.odo_meas + (size_t)rep * 6 * d.n_odo;
-  const double* odo_w = d.odo_w + (size_t)rep * 21 * d.n_odo;
+  const double* odo_meas = d.odo_meas + (size_t)rep * 6 * d.odo_ld;
+  const double* odo_w = d.odo_w + (size_t)rep * 21 * d.odo_ld;
   const int* odo_a = d.odo_a + (size_t)rep * d.n_odo;
   const int* odo_b = d.odo_b + (size_t)rep * d.n_odo;
   extern __shared__ double lin_lds[];
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* _
     double pz[7], pl[4], ms[4], w[6], out[30];
     load_pose(d.pose_lin, d.pose_ld, obs_pose[i], pz);
     load_plane(d.plane_lin, d.plane_ld, obs_plane[i], pl);
-    load_soa<4>(obs_meas, d.n_obs, i, ms);
-    load_soa<6>(obs_w, d.n_obs, i, w);
+    load_soa<4>(obs_meas, d.obs_ld, i, ms);
+    load_soa<6>(obs_w, d.obs_ld, i, w);
     lin_plane_obs<MODE>(pz, pl, ms, w, out);
     if (i0 < d.n_obs) store_records_coalesced<30>(out, Jr + (size_t)i0 * 30, min(64, d.n_obs - i0), lds_wave);
     return;
@@ -608,8 +608,8 @@ __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* _
   double p1[7], p2[7], ms[6], w[21];
   load_pose(d.pose_lin, d.pose_ld, odo_a[i], p1);
   load_pose(d.pose_lin, d.pose_ld, odo_b[i], p2);
-  load_soa<6>(odo_meas, d.n_odo, i, ms);
-  load_soa<21>(odo_w, d.n_odo, i, w);
+  load_soa<6>(odo_meas, d.odo_ld, i, ms);
+  load_soa<21>(odo_w, d.odo_ld, i, w);
   if (MODE == 1) {
     double out[78];
     lin_odometry<MODE>(p1, p2, ms, w, out);
@@ -1664,13 +1664,13 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
       double pz[7], pl[4], ms[4], w[6], e[3], r[3];
       load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
       load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
-      if (i < d.n_obs_fixed) load_soa<4>(d.obs_meas, d.n_obs, i, ms);
+      if (i < d.n_obs_fixed) load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
       else {                                  // Pose3d_Plane3d_Factor2: re-pop the measurement at this pose
         double ray[6];
         load_soa<6>(d.obs_ray, d.n_obs - d.n_obs_fixed, i - d.n_obs_fixed, ray);
         repop_wall_plane(pz, ray, ms);
       }
-      load_soa<6>(d.obs_w, d.n_obs, i, w);
+      load_soa<6>(d.obs_w, d.obs_ld, i, w);
       res_plane_obs(pz, pl, ms, e);
       whiten<3>(w, e, r);
       s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -1681,8 +1681,8 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
       double p1[7], p2[7], ms[6], w[21], e[6], r[6];
       load_pose(pose, d.pose_ld, d.odo_a[i], p1);
       load_pose(pose, d.pose_ld, d.odo_b[i], p2);
-      load_soa<6>(d.odo_meas, d.n_odo, i, ms);
-      load_soa<21>(d.odo_w, d.n_odo, i, w);
+      load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
+      load_soa<21>(d.odo_w, d.odo_ld, i, w);
       res_odometry(p1, p2, ms, e);
       whiten<6>(w, e, r);
 #pragma unroll
@@ -1693,8 +1693,8 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
     if (i < d.n_pp) {
       double pz[7], ms[6], w[21], e[6], r[6];
       load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
-      load_soa<6>(d.pp_meas, d.n_pp, i, ms);
-      load_soa<21>(d.pp_w, d.n_pp, i, w);
+      load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
+      load_soa<21>(d.pp_w, d.pp_ld, i, w);
       res_pose_prior(pz, ms, e);
       whiten<6>(w, e, r);
 #pragma unroll
@@ -1706,8 +1706,8 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
     if (i < d.n_lp) {
       double pl[4], ms[4], w[6], e[3], r[3];
       load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
-      load_soa<4>(d.lp_meas, d.n_lp, i, ms);
-      load_soa<6>(d.lp_w, d.n_lp, i, w);
+      load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
+      load_soa<6>(d.lp_w, d.lp_ld, i, w);
       res_plane_prior(pl, ms, e);
       whiten<3>(w, e, r);
       s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_refresh_measurements(RefreshArgs a) {
   // creation, main_3d.cpp:434-435) and lose the graph.  Keep the previous measurement instead.
   if (!(nrm > 0.0) || !(nrm < 1e300)) return;
 #pragma unroll
-  for (int k = 0; k < 4; k++) a.obs_meas[(size_t)k * a.n_obs + slot] = v[k] / nrm;
+  for (int k = 0; k < 4; k++) a.obs_meas[(size_t)k * a.obs_ld + slot] = v[k] / nrm;
 }
 
 hipError_t launch_refresh_measurements(const RefreshArgs& a, hipStream_t st) {

@@ -22,7 +22,7 @@ struct RefreshArgs {
   const float* seg2d;           // all segments, 4 floats each
   float invK[9];
   const double* pose_est; int pose_ld;
-  double* obs_meas; int n_obs;
+  double* obs_meas; int n_obs, obs_ld;
 };
 
 hipError_t launch_refresh_measurements(const RefreshArgs& a, hipStream_t st);
