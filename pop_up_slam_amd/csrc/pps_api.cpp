@@ -107,7 +107,14 @@ struct pps_graph {
   bool up_unknown = true;              // the arena was (re)allocated: the mirror says nothing about the device
   bool up_unknown_meas = false;        // ... only about the measurement arrays (written behind the mirror's back)
   size_t slot_obs_meas = (size_t)-1;   // which upload slot holds obs_meas
-  std::vector<int> pk_i[2]; std::vector<double> pk_d[2];   // packing scratch of upload_all (kept: no allocation per frame)
+  // packed factor arrays of the last upload: an upload that only appends fills in the new slots instead of packing every
+  // factor again (pk_n = slots that are current; pk_meas_ok: the measurement rows still match the host factors)
+  std::vector<int> pk_obs_a, pk_obs_b, pk_odo_a, pk_odo_b, pk_obs_ids, pk_odo_ids;
+  std::vector<double> pk_obs_m, pk_obs_w, pk_odo_m, pk_odo_w;
+  size_t pk_n_obs = 0, pk_n_odo = 0, pk_ld_obs = 0, pk_ld_odo = 0;
+  bool pk_meas_ok = false;
+  bool up_inflight = false;      // upload_all left copies from the pinned buffers in flight on `stream`
+  double* state_pin = nullptr; size_t state_pin_cap = 0;     // pinned staging of upload_state / download_state
   std::unordered_map<std::string, double> up_laps;         // PPS_UPLOAD_TIMING=1: seconds per phase of upload_all, summed; printed at destroy
   struct UpPatch { size_t off, len; };
   std::vector<UpPatch> up_patches;
@@ -204,6 +211,8 @@ void release_arenas(pps_graph* g) {
   if (g->stage) (void)hipHostFree(g->stage);
   g->stage = nullptr; g->stage_cap = 0;
   if (g->patch_host) (void)hipHostFree(g->patch_host);
+  if (g->state_pin) (void)hipHostFree(g->state_pin);
+  g->state_pin = nullptr; g->state_pin_cap = 0;
   if (g->patch_dev) (void)hipFree(g->patch_dev);
   g->patch_host = g->patch_dev = nullptr; g->patch_cap = g->patch_dev_cap = 0;
   g->up_slots.clear(); g->up_high = 0; g->up_unknown = true;
@@ -234,10 +243,13 @@ void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force) {
   char* mir = g->stage + o;
   g->up_bytes_total += n;
   if (g->up_unknown || force) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n}); return; }
-  // first and last 64-byte chunk that differs from what the device holds
+  // first and last 64-byte chunk that differs from what the device holds (4 KB strides first: most arrays of a frame loop
+  // are unchanged from end to end, or up to a short tail)
   size_t lo = 0, hi = n;
+  while (lo + 4096 <= hi && memcmp(mir + lo, src + lo, 4096) == 0) lo += 4096;
   while (lo + 64 <= hi && memcmp(mir + lo, src + lo, 64) == 0) lo += 64;
   if (lo + 64 > hi && memcmp(mir + lo, src + lo, hi - lo) == 0) return;      // identical
+  while (hi >= lo + 4096 && memcmp(mir + hi - 4096, src + hi - 4096, 4096) == 0) hi -= 4096;
   while (hi >= lo + 64 && memcmp(mir + hi - 64, src + hi - 64, 64) == 0) hi -= 64;
   lo &= ~size_t(15);
   memcpy(mir + lo, src + lo, hi - lo);
@@ -307,7 +319,6 @@ int flush_uploads(pps_graph* g) {
     for (const auto& pt : g->up_patches) { lo = std::min(lo, pt.off); hi = std::max(hi, pt.off + pt.len); }
     if (g->up_unknown) { lo = 0; hi = std::max(hi, g->up_high); hi = std::min(hi, g->stage_cap); }
     HIP_TRY(g, hipMemcpyAsync(g->up.base + lo, g->stage + lo, hi - lo, hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(g, hipStreamSynchronize(g->stream));
     g->up_bytes_sent = hi - lo;
   } else {
     // [table: 4 x int64 per patch | data, 16-byte aligned pieces] -> one copy -> scatter kernel
@@ -337,7 +348,7 @@ int flush_uploads(pps_graph* g) {
     }
     HIP_TRY(g, hipMemcpyAsync(g->patch_dev, g->patch_host, need, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(g, launch_scatter_patches(g->patch_dev, (int)np, g->up.base, g->stream));
-    HIP_TRY(g, hipStreamSynchronize(g->stream));       // the patch buffer is re-used by the next flush
+    // (the mirror and the patch buffer are written again by the next upload_all, which begins and ends with a stream sync)
   }
   g->up_unknown = false;
   g->up_patches.clear();
@@ -536,14 +547,30 @@ int run_analysis(pps_graph* g) {
   return PPS_OK;
 }
 
+// pinned staging for the estimate (pose rows, then plane rows): copies to and from pageable memory are staged by the runtime
+// and cost a synchronisation each
+int state_pin_reserve(pps_graph* g, size_t doubles) {
+  if (doubles <= g->state_pin_cap) return PPS_OK;
+  if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }
+  if (g->state_pin) (void)hipHostFree(g->state_pin);
+  g->state_pin = nullptr; g->state_pin_cap = 0;
+  const size_t cap = std::max<size_t>(4096, 2 * doubles);
+  HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->state_pin), cap * sizeof(double), hipHostMallocDefault));
+  g->state_pin_cap = cap;
+  return PPS_OK;
+}
+
 // pull the device estimate back into the host node table
 int download_state(pps_graph* g) {
   if (!g->dev_values_newer) return PPS_OK;
   HIP_TRY(g, hipSetDevice(g->props.device));
   const DevGraph& d = g->dev;
-  std::vector<double> bp((size_t)7 * d.pose_ld), bl((size_t)4 * d.plane_ld);
-  if (d.n_pose) HIP_TRY(g, hipMemcpyAsync(bp.data(), d.pose_est, bp.size() * 8, hipMemcpyDeviceToHost, g->stream));
-  if (d.n_plane) HIP_TRY(g, hipMemcpyAsync(bl.data(), d.plane_est, bl.size() * 8, hipMemcpyDeviceToHost, g->stream));
+  const size_t np = (size_t)7 * d.pose_ld, nl = (size_t)4 * d.plane_ld;
+  int rc = state_pin_reserve(g, np + nl);
+  if (rc != PPS_OK) return rc;
+  double* bp = g->state_pin; double* bl = g->state_pin + np;
+  if (d.n_pose) HIP_TRY(g, hipMemcpyAsync(bp, d.pose_est, np * 8, hipMemcpyDeviceToHost, g->stream));
+  if (d.n_plane) HIP_TRY(g, hipMemcpyAsync(bl, d.plane_est, nl * 8, hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) g->nodes[g->pose_ids[s]].v[k] = bp[(size_t)k * d.pose_ld + s];
   for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) g->nodes[g->plane_ids[s]].v[k] = bl[(size_t)k * d.plane_ld + s];
@@ -551,20 +578,27 @@ int download_state(pps_graph* g) {
   return PPS_OK;
 }
 
-int upload_state(pps_graph* g) {
+int upload_state(pps_graph* g, bool sync = true) {
   DevGraph& d = g->dev;
-  std::vector<double> bp((size_t)7 * d.pose_ld, 0.0), bl((size_t)4 * d.plane_ld, 0.0);
+  if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }   // the staging buffer is still being read
+  const size_t np = (size_t)7 * d.pose_ld, nl = (size_t)4 * d.plane_ld;
+  int rc = state_pin_reserve(g, np + nl);
+  if (rc != PPS_OK) return rc;
+  double* bp = g->state_pin; double* bl = g->state_pin + np;
+  for (int k = 0; k < 7; k++) for (int s = d.n_pose; s < d.pose_ld; s++) bp[(size_t)k * d.pose_ld + s] = 0.0;
+  for (int k = 0; k < 4; k++) for (int s = d.n_plane; s < d.plane_ld; s++) bl[(size_t)k * d.plane_ld + s] = 0.0;
   for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) bp[(size_t)k * d.pose_ld + s] = g->nodes[g->pose_ids[s]].v[k];
   for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) bl[(size_t)k * d.plane_ld + s] = g->nodes[g->plane_ids[s]].v[k];
   if (d.n_pose) {
-    HIP_TRY(g, hipMemcpyAsync(d.pose_est, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(g, hipMemcpyAsync(d.pose_lin, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(d.pose_est, bp, np * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(d.pose_lin, d.pose_est, np * 8, hipMemcpyDeviceToDevice, g->stream));
   }
   if (d.n_plane) {
-    HIP_TRY(g, hipMemcpyAsync(d.plane_est, bl.data(), bl.size() * 8, hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(g, hipMemcpyAsync(d.plane_lin, bl.data(), bl.size() * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(d.plane_est, bl, nl * 8, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, hipMemcpyAsync(d.plane_lin, d.plane_est, nl * 8, hipMemcpyDeviceToDevice, g->stream));
   }
-  HIP_TRY(g, hipStreamSynchronize(g->stream));   // staging vectors die at scope exit
+  if (sync) HIP_TRY(g, hipStreamSynchronize(g->stream));
+  else g->up_inflight = true;
   g->host_values_newer = false;
   return PPS_OK;
 }
@@ -597,6 +631,7 @@ int download_measurements(pps_graph* g) {
     for (int k = 0; k < 4; k++) f.meas[k] = m[(size_t)k * ld + s2];
   }
   g->dev_meas_newer = false;
+  g->pk_meas_ok = false;
   return PPS_OK;
 }
 
@@ -617,6 +652,7 @@ int upload_measurements(pps_graph* g) {
 
 int upload_all(pps_graph* g) {
   const double t0 = now_s();
+  const bool was_grown_only = g->grown_only_upload;
   const bool tm = getenv("PPS_UPLOAD_TIMING") != nullptr;
   double tl = t0;
   auto lap = [&](const char* what) { if (!tm) return; const double t = now_s(); g->up_laps[what] += t - tl; tl = t; };
@@ -636,6 +672,7 @@ int upload_all(pps_graph* g) {
     if (!keep_meas) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
   }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
+  g->up_inflight = false;
   if (g->stream_b) HIP_TRY(g, hipStreamSynchronize(g->stream_b));
   lap("1 state/meas download + syncs");
   free_device(g);
@@ -671,20 +708,29 @@ int upload_all(pps_graph* g) {
     return v;
   };
   std::vector<double> tmp;
+  // the previous upload's packed arrays are still right for the old factors when nothing was removed since (slots only append)
+  const bool incr_pack = was_grown_only && !getenv("PPS_NO_INCR_PACK");
   d.obs_ld = (int)j_capacity(d.n_obs); d.odo_ld = (int)j_capacity(d.n_odo); d.pp_ld = (int)j_capacity(d.n_pp); d.lp_ld = (int)j_capacity(d.n_lp);
   {
-    // one pass over the plane observations (a HostFactor is 300 bytes: four passes were four times the memory traffic)
+    // one pass over the plane observations (a HostFactor is 300 bytes: four passes were four times the memory traffic), and
+    // only over the new ones when the graph has just grown
     const std::vector<int>& ids = g->fslot_ids[F_PLANE_OBS];
     const size_t n = ids.size(), ld = (size_t)d.obs_ld;
-    std::vector<int>& ia = g->pk_i[0]; std::vector<int>& ib = g->pk_i[1];
-    std::vector<double>& pm = g->pk_d[0]; std::vector<double>& pw = g->pk_d[1];
-    ia.resize(n); ib.resize(n); pm.assign(4 * ld, 0.0); pw.assign(6 * ld, 0.0);
-    for (size_t s2 = 0; s2 < n; s2++) {
+    std::vector<int>& ia = g->pk_obs_a; std::vector<int>& ib = g->pk_obs_b;
+    std::vector<double>& pm = g->pk_obs_m; std::vector<double>& pw = g->pk_obs_w;
+    size_t s_begin = 0;
+    if (incr_pack && g->pk_ld_obs == ld && g->pk_n_obs <= n && pm.size() == 4 * ld && g->pk_obs_ids.size() == g->pk_n_obs &&
+        std::equal(g->pk_obs_ids.begin(), g->pk_obs_ids.end(), ids.begin())) s_begin = g->pk_n_obs;   // (re-popping edges sit behind the fixed ones: their slots move)
+    ia.resize(n); ib.resize(n); pm.resize(4 * ld); pw.resize(6 * ld);
+    for (size_t s2 = s_begin; s2 < n; s2++) {
       const HostFactor& f = g->factors[ids[s2]];
       ia[s2] = g->nodes[f.a].slot; ib[s2] = g->nodes[f.b].slot;
       for (int k = 0; k < 4; k++) pm[(size_t)k * ld + s2] = f.meas[k];
       for (int k = 0; k < 6; k++) pw[(size_t)k * ld + s2] = f.w[k];
     }
+    if (s_begin > 0 && !g->pk_meas_ok)                                 // the host's measurements changed: those rows again
+      for (size_t s2 = 0; s2 < s_begin; s2++) { const HostFactor& f = g->factors[ids[s2]]; for (int k = 0; k < 4; k++) pm[(size_t)k * ld + s2] = f.meas[k]; }
+    g->pk_n_obs = n; g->pk_ld_obs = ld; g->pk_obs_ids.resize(s_begin); g->pk_obs_ids.insert(g->pk_obs_ids.end(), ids.begin() + (std::ptrdiff_t)s_begin, ids.end());
     TRY(dev_upload(g, &d.obs_pose, ia)); TRY(dev_upload(g, &d.obs_plane, ib));
     // Measurements that a device-side refresh has rewritten (pps_refresh_measurements) stay where they are when this upload
     // only appends: the host packs its (older) copies, the mirror holds the same bytes, so nothing is sent for them and the
@@ -707,15 +753,19 @@ int upload_all(pps_graph* g) {
   {
     const std::vector<int>& ids = g->fslot_ids[F_ODOMETRY];
     const size_t n = ids.size(), ld = (size_t)d.odo_ld;
-    std::vector<int>& ia = g->pk_i[0]; std::vector<int>& ib = g->pk_i[1];
-    std::vector<double>& pm = g->pk_d[0]; std::vector<double>& pw = g->pk_d[1];
-    ia.resize(n); ib.resize(n); pm.assign(6 * ld, 0.0); pw.assign(21 * ld, 0.0);
-    for (size_t s2 = 0; s2 < n; s2++) {
+    std::vector<int>& ia = g->pk_odo_a; std::vector<int>& ib = g->pk_odo_b;
+    std::vector<double>& pm = g->pk_odo_m; std::vector<double>& pw = g->pk_odo_w;
+    size_t s_begin = 0;
+    if (incr_pack && g->pk_ld_odo == ld && g->pk_n_odo <= n && pm.size() == 6 * ld && g->pk_odo_ids.size() == g->pk_n_odo &&
+        std::equal(g->pk_odo_ids.begin(), g->pk_odo_ids.end(), ids.begin())) s_begin = g->pk_n_odo;
+    ia.resize(n); ib.resize(n); pm.resize(6 * ld); pw.resize(21 * ld);
+    for (size_t s2 = s_begin; s2 < n; s2++) {
       const HostFactor& f = g->factors[ids[s2]];
       ia[s2] = g->nodes[f.a].slot; ib[s2] = g->nodes[f.b].slot;
       for (int k = 0; k < 6; k++) pm[(size_t)k * ld + s2] = f.meas[k];
       for (int k = 0; k < 21; k++) pw[(size_t)k * ld + s2] = f.w[k];
     }
+    g->pk_n_odo = n; g->pk_ld_odo = ld; g->pk_odo_ids.resize(s_begin); g->pk_odo_ids.insert(g->pk_odo_ids.end(), ids.begin() + (std::ptrdiff_t)s_begin, ids.end());
     TRY(dev_upload(g, &d.odo_a, ia)); TRY(dev_upload(g, &d.odo_b, ib));
     TRY(dev_upload_rows(g, &d.odo_meas, pm, 6, ld, n, false));
     TRY(dev_upload_rows(g, &d.odo_w, pw, 21, ld, n, false));
@@ -727,6 +777,7 @@ int upload_all(pps_graph* g) {
   pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, tmp, (size_t)d.lp_ld); TRY(dev_upload_rows(g, &d.lp_meas, tmp, 4, (size_t)d.lp_ld, (size_t)d.n_lp, g->up_unknown_meas));
   pack_soa<6>(g, F_PLANE_PRIOR, nullptr, true, tmp, (size_t)d.lp_ld); TRY(dev_upload_rows(g, &d.lp_w, tmp, 6, (size_t)d.lp_ld, (size_t)d.n_lp, false));
   g->up_unknown_meas = false;
+  g->pk_meas_ok = true;
   lap("4 factor packing + diff");
   // linear system storage
   TRY(dev_alloc(g, &d.J, (size_t)A.J_size)); TRY(dev_alloc(g, &d.H, (size_t)A.H_size));
@@ -772,12 +823,12 @@ int upload_all(pps_graph* g) {
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &d.result_dev, 4)); TRY(dev_alloc(g, &g->spec_result, 4));
   TRY(dev_alloc(g, &d.dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
-  HIP_TRY(g, hipMemset(d.dn_partials, 0, ((size_t)(d.n_pose + d.n_plane + 255) / 256 + 1) * 8));
-  TRY(dev_alloc(g, &d.ticket, 1)); HIP_TRY(g, hipMemset(d.ticket, 0, 4));
+  HIP_TRY(g, hipMemsetAsync(d.dn_partials, 0, ((size_t)(d.n_pose + d.n_plane + 255) / 256 + 1) * 8, g->stream));
+  TRY(dev_alloc(g, &d.ticket, 1)); HIP_TRY(g, hipMemsetAsync(d.ticket, 0, 4, g->stream));
   TRY(dev_alloc(g, &g->spec_pose, (size_t)7 * d.pose_ld + 1)); TRY(dev_alloc(g, &g->spec_plane, (size_t)4 * d.plane_ld + 1));
   TRY(dev_alloc(g, &g->spec_chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &g->spec_dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
-  TRY(dev_alloc(g, &g->spec_ticket, 1)); HIP_TRY(g, hipMemset(g->spec_ticket, 0, 4));
+  TRY(dev_alloc(g, &g->spec_ticket, 1)); HIP_TRY(g, hipMemsetAsync(g->spec_ticket, 0, 4, g->stream));
   if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
   // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
   if (!g->use_band && !g->use_dense && A.max_front > lds_front_limit()) {
@@ -795,12 +846,13 @@ int upload_all(pps_graph* g) {
   if (A.ea_total > 0) HIP_TRY(g, launch_expand_ea(d, A.n_fronts, g->stream));
   HIP_TRY(g, hipMemsetAsync(d.blk_dst, 0xff, sizeof(int) * (size_t)std::max(1, A.blk_doff[A.n_blocks]), g->stream));
   HIP_TRY(g, launch_expand_el(d, (int)A.asm_blk.size(), g->stream));
-  HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->topo_dirty = false;
   g->meas_dirty = false;
   g->grown_only_upload = true;
   lap("7 expand kernels + sync");
-  rc = upload_state(g);
+  // no sync: the solve that follows runs on the same stream (and ends with one); whatever writes the pinned buffers
+  // again checks up_inflight or follows upload_all's opening sync
+  rc = upload_state(g, false);
   lap("8 upload_state");
   g->stats.t_upload = now_s() - t0 - g->stats.t_analysis;
   return rc;
@@ -1172,7 +1224,7 @@ int pps_set_measurements(pps_graph* g, int n, const int* fids, const double* mea
     }
     normalize4(f.meas);
   }
-  g->meas_dirty = true;
+  g->meas_dirty = true; g->pk_meas_ok = false;
   return PPS_OK;
 }
 
