@@ -1306,12 +1306,116 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
   return rc;
 }
 
+// Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) with both candidate steps of a linearisation in the same launches.
+// A rejected trial only changes lambda (same J, same H), so every solve factors H for lambda AND for lambda * factor
+// (blockIdx.y of the band kernels, second L / U / delta set), applies both steps to two spare copies of the state and reduces
+// both chi2 values into two pinned records.  One stream, no events: 10 launches per linearisation instead of 21 on two streams.
+// The host walks the reference's lambda schedule over the records: an accepted step rotates its copy in as the new
+// linearisation point, a first rejection finds the next trial's verdict already on the host.  Arithmetic, lambda schedule and
+// LM trace are exactly those of the one-step-at-a-time loop below.
+static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
+  const pps_props& prop = g->props;
+  const Analysis& A = g->an;
+  HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+  HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));
+  int num_iter = 0;
+  double lambda = prop.lm_lambda0;
+  double* slot0 = g->host_result;                                   // chi2 at the linearisation point
+  double* slot[2] = {g->host_result + 4, g->host_result + 8};       // trial for lambda / for lambda * factor
+  DevGraph& d = g->dev;
+  // three state copies: x = the linearisation point (d.pose_lin), t[0] / t[1] = x (+) delta for the two damping values
+  double *t_pose[2] = {d.pose_est, g->spec_pose}, *t_plane[2] = {d.plane_est, g->spec_plane};
+  int rc = copy_state(g, true); if (rc != PPS_OK) return rc;       // estimate_to_linpoint (Optimizer.cpp:376): est is dead from here on
+  double seqs[2] = {0, 0};
+  auto enqueue_dual = [&](double lam) -> int {
+    DualAlt alt{g->spec_L, g->spec_U, g->spec_delta, g->spec_result, g->spec_chi2_partials, g->spec_dn_partials, g->spec_ticket,
+                lam * prop.lm_lambda_factor};
+    for (int st = 0; st < A.n_stages; st++)
+      HIP_TRY(g, launch_band_factor_dual(d, alt, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
+                                         A.stage_max_front[st], lam, g->stream));
+    for (int st = A.n_stages - 1; st >= 0; st--)
+      HIP_TRY(g, launch_band_solve(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
+                                   g->stage_max_panel[st], g->stage_max_grp_fronts[st], g->stream, &alt));
+    g->stats.n_factorize += 2;
+    g->seq += 1.0; seqs[0] = g->seq;
+    g->seq2 += 1.0; seqs[1] = g->seq2;
+    HIP_TRY(g, launch_trial_dual(d, alt, d.pose_lin, d.plane_lin, t_pose[0], t_plane[0], t_pose[1], t_plane[1], slot[0], seqs[0], slot[1], seqs[1],
+                                 g->stream));
+    return PPS_OK;
+  };
+  rc = do_linearize(g); if (rc != PPS_OK) return rc;               // jacobian() (:379)
+  g->seq += 1.0;
+  const double seq0 = g->seq;
+  HIP_TRY(g, launch_chi2(d, false, slot0, seq0, g->stream));       // r = weighted_errors(LINPOINT); error = |r|^2 (:382-385)
+  rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;
+  rc = wait_result(g, slot0, seq0); if (rc != PPS_OK) return rc;
+  rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
+  double error = slot0[0];
+  g->stats.chi2_initial = error;
+  int cur = 0;                           // which of the two trials the loop is looking at
+  bool have_next = true;                 // trial 1 of the last launch is the step for the next lambda after a rejection
+  double dnorm = std::sqrt(slot[0][1]);
+  bool last_notpd = slot[0][2] != 0.0;
+  int n_notpd = last_notpd ? 1 : 0;
+  bool trial_taken = false;              // the loop ended on an accepted, converged step: the estimate is that trial
+  while ((prop.max_iterations <= 0 || num_iter < prop.max_iterations) && dnorm > prop.epsilon2 && error > prop.epsilon_abs) {
+    num_iter++;
+    const double error_new = slot[cur][0];
+    const double error_diff = error - error_new;
+    const bool accepted = error_diff > 0.;
+    g->tr_lambda.push_back(lambda); g->tr_chi2.push_back(error_new); g->tr_acc.push_back(accepted ? 1 : 0);
+    if (prop.verbose) fprintf(stderr, "LM Iteration %d: (lambda=%g) %s %.12g\n", num_iter, lambda, accepted ? "residual:" : "rejected", error_new);
+    if (accepted) {
+      g->stats.lm_trials_accepted++;
+      if (error_diff < prop.epsilon_rel * error) { error = error_new; trial_taken = true; break; }   // (:431-434)
+      lambda /= prop.lm_lambda_factor;
+      error = error_new;
+      // the accepted copy becomes the linearisation point; the old one is the spare now
+      std::swap(d.pose_lin, t_pose[cur]); std::swap(d.plane_lin, t_plane[cur]);
+      rc = do_linearize(g); if (rc != PPS_OK) return rc;           // relinearise (:444)
+      rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;      // (:458)
+      cur = 0; have_next = true;
+      rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
+    } else {
+      g->stats.lm_trials_rejected++;
+      lambda *= prop.lm_lambda_factor;                             // estimate_to_linpoint (:454): x was never overwritten
+      if (have_next) {                                             // computed alongside: nothing to launch
+        cur = 1; have_next = false;
+        rc = wait_result(g, slot[1], seqs[1]); if (rc != PPS_OK) return rc;
+      } else {
+        rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;    // (:458), same J and H
+        cur = 0; have_next = true;
+        rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
+      }
+    }
+    dnorm = std::sqrt(slot[cur][1]);
+    last_notpd = slot[cur][2] != 0.0;
+    n_notpd += last_notpd ? 1 : 0;
+  }
+  // linpoint_to_estimate (:466): the estimate is the accepted trial, or the linearisation point when the pending step is dropped
+  if (trial_taken) { std::swap(d.pose_lin, t_pose[cur]); std::swap(d.plane_lin, t_plane[cur]); }
+  d.pose_est = d.pose_lin; d.plane_est = d.plane_lin;
+  d.pose_lin = t_pose[0]; d.plane_lin = t_plane[0];
+  g->spec_pose = t_pose[1]; g->spec_plane = t_plane[1];
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  g->dev_values_newer = true;
+  resolve_k1_events(g);
+  g->stats.lm_iterations = num_iter;
+  g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
+  g->stats.lm_trials_notpd = n_notpd;
+  g->stats.t_total = now_s() - t0;
+  if (iterations) *iterations = num_iter;
+  if (last_notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite at the last LM trial");
+  return PPS_OK;
+}
+
 static int lm_solve(pps_graph* g, int* iterations) {
   const double t0 = now_s();
   reset_solve_stats(g);
   g->tr_lambda.clear(); g->tr_chi2.clear(); g->tr_acc.clear();
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
+  if (g->spec_enabled && g->use_band && g->profiling < 2 && !g->dev.trace && !getenv("PPS_NO_DUAL")) return lm_solve_dual(g, iterations, t0);
   const pps_props& prop = g->props;
   HIP_TRY(g, launch_clear_status(g->dev, g->stream));
   HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));

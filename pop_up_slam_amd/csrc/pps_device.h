@@ -87,9 +87,24 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);
 // wave-per-front band kernels: one workgroup per group of the stage, `nwaves` fronts in flight per workgroup
 // fused_solve_panel > 0: the back-substitution of the same groups follows inside the launch (used for the root stage)
+// Two damping values of one linearisation in the same launches (blockIdx.y = 0 / 1): the second factorisation has its own
+// L / U / delta, not-PD flag and reduction scratch, everything else (J, H, the index arrays) is shared.  A rejected LM trial only
+// changes lambda, so the step for lambda * factor is computed next to the step for lambda (Optimizer.cpp:448-458).
+struct DualAlt {
+  double *L, *U, *delta, *result_dev, *chi2_partials, *dn_partials;
+  unsigned int* ticket;
+  double lambda;
+};
 hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
                               int fused_solve_panel = 0, int fused_solve_group_fronts = 0);
-hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st);
+hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
+                             const DualAlt* alt = nullptr);
+hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
+                                   hipStream_t st);
+// both trials of a dual solve: out_k <- base (+) delta_k, chi2 and |delta|^2 of each into its own result record
+hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
+                             double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
+                             double seq1, hipStream_t st);
 // ea_tgt (packed update matrix of a front -> packed index in its parent) expanded from cmap / f_cmap_off / f_ea_off
 hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st);
 // el_tgt / blk_dst (H block element <-> front-ordered H <-> packed front index) expanded from the per-block records;

@@ -1420,8 +1420,9 @@ __device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int ld
   }
 }
 
-__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, int grp_begin, int lds_doubles_per_wave) {
+__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int grp_begin, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
   body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
@@ -1466,17 +1467,16 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
 }
 
 template <bool REG_ONLY>
-__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, int grp_begin, double lambda, int lds_doubles_per_wave,
+__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave,
                                                      int solve_doubles_per_wave) {
   extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
   body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, solve_doubles_per_wave, lds);
 }
 
 static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
 
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
-                              int fused_solve_panel, int fused_solve_group_fronts) {
-  if (grp_count == 0) return hipSuccess;
+static hipError_t ensure_band_attrs() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!g_band_attr_set[dev & 63]) {
@@ -1486,6 +1486,13 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
   }
+  return hipSuccess;
+}
+
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
+                              int fused_solve_panel, int fused_solve_group_fronts) {
+  if (grp_count == 0) return hipSuccess;
+  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
   size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   int solve_per_wave = 0;
@@ -1494,20 +1501,35 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
   }
   if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
-    hipLaunchKernelGGL(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, 0);
+    hipLaunchKernelGGL(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
   else
-    hipLaunchKernelGGL(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, lambda, per_wave, solve_per_wave);
+    hipLaunchKernelGGL(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, solve_per_wave);
+  return hipGetLastError();
+}
+
+hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
+                                   hipStream_t st) {
+  if (grp_count == 0) return hipSuccess;
+  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
+  const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
+  const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
+  if (max_front + 1 <= kRegRows && d.trace == nullptr)
+    hipLaunchKernelGGL(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+  else
+    hipLaunchKernelGGL(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
   return hipGetLastError();
 }
 
 size_t band_solve_lds_bytes(int max_panel) { return (size_t)(kBandMaxRows + max_panel) * sizeof(double); }   // xb + the factor panel
 
-hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st) {
+hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
+                             const DualAlt* alt) {
   if (grp_count == 0) return hipSuccess;
   // per wave: xb + the largest factor panel of the stage; per workgroup: one local solution vector per front of a group
   const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
-  hipLaunchKernelGGL(k_band_solve, dim3(grp_count), dim3(64 * nwaves),
-                     ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double), st, d, grp_begin, per_wave);
+  hipLaunchKernelGGL(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves),
+                     ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double), st, d, alt ? *alt : DualAlt{}, grp_begin,
+                     per_wave);
   return hipGetLastError();
 }
 
@@ -1596,9 +1618,11 @@ __global__ __launch_bounds__(256) void k_retract(DevGraph d) {
 
 // out <- base (+) delta, nothing else touched: the speculative LM trial (step computed for lambda * factor on the
 // second stream) is applied to a third copy of the state; |delta|^2 partials go to d.dn_partials
-__global__ __launch_bounds__(256) void k_retract_to(DevGraph d, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
-                                                    double* __restrict__ out_pose, double* __restrict__ out_plane) {
+__global__ __launch_bounds__(256) void k_retract_to(DevGraph d, DualAlt alt, const double* __restrict__ base_pose,
+                                                    const double* __restrict__ base_plane, double* __restrict__ out_pose,
+                                                    double* __restrict__ out_plane, double* __restrict__ out_pose1, double* __restrict__ out_plane1) {
   __shared__ double red[4];
+  if (blockIdx.y) { d.delta = alt.delta; d.dn_partials = alt.dn_partials; out_pose = out_pose1; out_plane = out_plane1; }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double dn = 0.0;
   if (i < d.n_pose) {
@@ -1632,7 +1656,7 @@ hipError_t launch_retract_to(const DevGraph& d, const double* base_pose, const d
                              hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_retract_to, dim3(cdiv(n, 256)), dim3(256), 0, st, d, base_pose, base_plane, out_pose, out_plane);
+  hipLaunchKernelGGL(k_retract_to, dim3(cdiv(n, 256)), dim3(256), 0, st, d, DualAlt{}, base_pose, base_plane, out_pose, out_plane, nullptr, nullptr);
   return hipGetLastError();
 }
 
@@ -1756,6 +1780,31 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
                                                     const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
                                                     int n_dn, double* __restrict__ out, double seq) {
   body_chi2(d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(kChiBlock) void k_chi2_dual(DevGraph d, DualAlt alt, const double* __restrict__ pose, const double* __restrict__ plane,
+                                                         const double* __restrict__ pose1, const double* __restrict__ plane1, int nb_obs,
+                                                         int nb_odo, int nb_pp, int n_dn, double* __restrict__ out, double seq,
+                                                         double* __restrict__ out1, double seq1) {
+  if (blockIdx.y) {
+    d.chi2_partials = alt.chi2_partials; d.dn_partials = alt.dn_partials; d.ticket = alt.ticket; d.result_dev = alt.result_dev;
+    pose = pose1; plane = plane1; out = out1; seq = seq1;
+  }
+  body_chi2(d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
+}
+
+hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
+                             double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
+                             double seq1, hipStream_t st) {
+  const int n = d.n_pose + d.n_plane;
+  if (n > 0)
+    hipLaunchKernelGGL(k_retract_to, dim3(cdiv(n, 256), 2), dim3(256), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1);
+  const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock), nb_lp = cdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if (nb == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_chi2_dual, dim3(nb, 2), dim3(kChiBlock), 0, st, d, alt, out_pose0, out_plane0, out_pose1, out_plane1, nb_obs, nb_odo, nb_pp,
+                     cdiv(n, 256), host_result0, seq0, host_result1, seq1);
+  return hipGetLastError();
 }
 
 hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, double seq, hipStream_t st) {
