@@ -137,6 +137,7 @@ struct pps_graph {
   int snap_version = -1, upload_version = 0;
   int profiling = 0;               // 0 off, 1 = K1 event pairs without host syncs, 2 = every phase (adds syncs)
   hipEvent_t ev[2] = {nullptr, nullptr};
+  std::vector<char> k1_skip;          // per K1 event pair: not a linearisation that ran
   std::vector<hipEvent_t> k1_events;   // pairs (start, stop) recorded around the sweep
   int k1_used = 0;
   // registered frames (pps_frames_add): 2-D ground segments that re-derive edge measurements on the device
@@ -882,19 +883,22 @@ struct PhaseTimer {
 };
 
 // linearise at `lin` (K1) and reduce the H blocks (K2)
-int do_linearize(pps_graph* g) {
+// guard: the launches are speculative (dual LM loop) -- the caller counts them once it knows they ran
+int do_linearize(pps_graph* g, const LinGuard* guard = nullptr) {
   if (g->profiling == 1) {
     if (g->k1_used + 2 > (int)g->k1_events.size()) {
       for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->k1_events.push_back(e); }
     }
+    g->k1_skip.resize(g->k1_events.size() / 2, 0);
+    g->k1_skip[g->k1_used / 2] = 0;
     HIP_TRY(g, hipEventRecord(g->k1_events[g->k1_used], g->stream));
-    HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream));
+    HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream, guard));
     HIP_TRY(g, hipEventRecord(g->k1_events[g->k1_used + 1], g->stream));
     g->k1_used += 2;
   } else
-  { PhaseTimer t(g, &g->stats.t_linearize); HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream)); }
-  { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream)); }
-  g->stats.n_linearize++;
+  { PhaseTimer t(g, &g->stats.t_linearize); HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream, guard)); }
+  { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream, guard)); }
+  if (!guard) g->stats.n_linearize++;
   return PPS_OK;
 }
 
@@ -1033,6 +1037,7 @@ int read_result(pps_graph* g, bool at_estimate, double* chi2, double* dnorm, boo
 void resolve_k1_events(pps_graph* g) {
   for (int k = 0; k + 1 < g->k1_used; k += 2) {
     float ms = 0;
+    if ((size_t)(k / 2) < g->k1_skip.size() && g->k1_skip[k / 2]) continue;       // a speculative K1 that left at its guard
     if (hipEventElapsedTime(&ms, g->k1_events[k], g->k1_events[k + 1]) == hipSuccess) g->stats.t_linearize += 1e-3 * ms;
   }
   g->k1_used = 0;
@@ -1347,11 +1352,24 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   g->seq += 1.0;
   const double seq0 = g->seq;
   HIP_TRY(g, launch_chi2(d, false, slot0, seq0, g->stream));       // r = weighted_errors(LINPOINT); error = |r|^2 (:382-385)
+  // Accept-branch speculation: the relinearisation that follows an accepted step is queued behind the trials before their
+  // verdict is known; its kernels apply the accept test themselves (LinGuard) and pick the accepted copy, so the device does
+  // not idle for the host round trip between chi2 and K1.
+  const bool spec_lin = !getenv("PPS_NO_SPEC_LIN");
+  int spec_pair = -1;                    // K1 event pair of the queued speculative linearisation
+  auto enqueue_spec_lin = [&](double err) -> int {
+    if (!spec_lin) return PPS_OK;
+    LinGuard gd{{d.result_dev, g->spec_result}, {t_pose[0], t_pose[1]}, {t_plane[0], t_plane[1]}, err, 1, 0};
+    spec_pair = g->profiling == 1 ? g->k1_used / 2 : -1;
+    return do_linearize(g, &gd);
+  };
+  auto drop_spec_lin = [&]() { if (spec_pair >= 0 && (size_t)spec_pair < g->k1_skip.size()) g->k1_skip[spec_pair] = 1; spec_pair = -1; };
   rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;
   rc = wait_result(g, slot0, seq0); if (rc != PPS_OK) return rc;
-  rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
   double error = slot0[0];
   g->stats.chi2_initial = error;
+  rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;
+  rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
   int cur = 0;                           // which of the two trials the loop is looking at
   bool have_next = true;                 // trial 1 of the last launch is the step for the next lambda after a rejection
   double dnorm = std::sqrt(slot[0][1]);
@@ -1372,8 +1390,10 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
       error = error_new;
       // the accepted copy becomes the linearisation point; the old one is the spare now
       std::swap(d.pose_lin, t_pose[cur]); std::swap(d.plane_lin, t_plane[cur]);
-      rc = do_linearize(g); if (rc != PPS_OK) return rc;           // relinearise (:444)
+      if (spec_lin) { g->stats.n_linearize++; spec_pair = -1; }    // relinearise (:444): queued already, at this very copy
+      else { rc = do_linearize(g); if (rc != PPS_OK) return rc; }
       rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;      // (:458)
+      rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;
       cur = 0; have_next = true;
       rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
     } else {
@@ -1383,7 +1403,9 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
         cur = 1; have_next = false;
         rc = wait_result(g, slot[1], seqs[1]); if (rc != PPS_OK) return rc;
       } else {
+        drop_spec_lin();                                           // both trials rejected: its kernels left J and H alone
         rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;    // (:458), same J and H
+        rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;
         cur = 0; have_next = true;
         rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
       }
@@ -1393,6 +1415,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
     n_notpd += last_notpd ? 1 : 0;
   }
   // linpoint_to_estimate (:466): the estimate is the accepted trial, or the linearisation point when the pending step is dropped
+  drop_spec_lin();                       // (a linearisation queued behind the last trials is not one the solve asked for)
   if (trial_taken) { std::swap(d.pose_lin, t_pose[cur]); std::swap(d.plane_lin, t_plane[cur]); }
   d.pose_est = d.pose_lin; d.plane_est = d.plane_lin;
   d.pose_lin = t_pose[0]; d.plane_lin = t_plane[0];

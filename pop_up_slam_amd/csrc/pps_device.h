@@ -79,9 +79,20 @@ struct DevGraph {
   int64_t gwork_stride = 0;
 };
 
+// Accept-branch speculation of the dual LM loop: K1 / K2 are queued right behind the two trials, before the host has seen
+// their chi2.  The kernels repeat the host's accept test (Optimizer.cpp:425-428: error - error_new > 0, trial 0 first) on the
+// device records and linearise at the accepted copy of the state -- or leave J and H alone when both trials were rejected.
+struct LinGuard {
+  const double* chi[2];      // result_dev of trial 0 / 1 ([0] = chi2 after the step)
+  const double* pose[2];
+  const double* plane[2];
+  double error;              // chi2 at the linearisation point the trials started from
+  int on, pad;
+};
+
 // All launchers enqueue on `st` and return the HIP error of the launch.
-hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st);
-hipError_t launch_hblocks(const DevGraph& d, hipStream_t st);
+hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard = nullptr);
+hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard = nullptr);
 hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
                                hipStream_t st);
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);

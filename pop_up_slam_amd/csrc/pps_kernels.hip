@@ -332,11 +332,25 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
   }
 }
 
+// LinGuard (pps_device.h): which state does a speculatively queued K1 linearise at?  false = neither trial was accepted
+__device__ __forceinline__ bool lin_guard(const LinGuard& gd, const double* __restrict__& pose, const double* __restrict__& plane) {
+  if (!gd.on) return true;
+  const double c0 = *gd.chi[0], c1 = *gd.chi[1];
+  if (gd.error - c0 > 0.) { pose = gd.pose[0]; plane = gd.plane[0]; return true; }
+  if (gd.error - c1 > 0.) { pose = gd.pose[1]; plane = gd.plane[1]; return true; }
+  return false;
+}
+__device__ __forceinline__ bool lin_guard(const LinGuard& gd) {
+  if (!gd.on) return true;
+  return gd.error - *gd.chi[0] > 0. || gd.error - *gd.chi[1] > 0.;
+}
+
 template <int MODE, int PART>
 __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const double* __restrict__ pose,
                                                           const double* __restrict__ plane, int nb_obs, int nb_odo,
-                                                          int nb_pp) {
+                                                          int nb_pp, LinGuard gd) {
   extern __shared__ double lin_lds[];
+  if (!lin_guard(gd, pose, plane)) return;
   body_linearize<MODE, PART>(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);
 }
 
@@ -488,7 +502,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
 
 __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, const double* __restrict__ pose,
                                                                     const double* __restrict__ plane, int nb_obs, int nb_odo,
-                                                                    int nb_pp) {
+                                                                    int nb_pp, LinGuard gd) {
+  if (!lin_guard(gd, pose, plane)) return;
   body_linearize_lanes(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x);
 }
 
@@ -535,14 +550,16 @@ __device__ __forceinline__ void body_linearize_repop(const DevGraph& d, const do
 }
 
 __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double* __restrict__ pose,
-                                                        const double* __restrict__ plane) {
+                                                        const double* __restrict__ plane, LinGuard gd) {
+  if (!lin_guard(gd, pose, plane)) return;
   body_linearize_repop(d, pose, plane, blockIdx.x);
 }
 
-hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st) {
+hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard) {
+  const LinGuard gd = guard ? *guard : LinGuard{};
   if (d.n_obs > d.n_obs_fixed) {
     hipLaunchKernelGGL(k_linearize_repop, dim3(cdiv(d.n_obs - d.n_obs_fixed, 64)), dim3(64), 0, st, d,
-                       at_estimate ? d.pose_est : d.pose_lin, at_estimate ? d.plane_est : d.plane_lin);
+                       at_estimate ? d.pose_est : d.pose_lin, at_estimate ? d.plane_est : d.plane_lin, gd);
   }
   const int nb_obs = cdiv(d.n_obs_fixed, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock), nb_pp = cdiv(d.n_pp, kLinBlock),
             nb_lp = cdiv(d.n_lp, kLinBlock);
@@ -555,17 +572,17 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
     const int lb_obs = cdiv(d.n_obs_fixed, kFactorsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
               lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
     hipLaunchKernelGGL(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
-                       lb_obs, lb_odo, lb_pp);
+                       lb_obs, lb_odo, lb_pp, gd);
     return hipGetLastError();
   }
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   const int nb_rest = nb - nb_obs;
   if (mode == 1) {
-    if (nb_obs) hipLaunchKernelGGL((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
-    if (nb_rest) hipLaunchKernelGGL((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+    if (nb_obs) hipLaunchKernelGGL((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_rest) hipLaunchKernelGGL((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
   } else {
-    if (nb_obs) hipLaunchKernelGGL((k_linearize<0, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
-    if (nb_rest) hipLaunchKernelGGL((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp);
+    if (nb_obs) hipLaunchKernelGGL((k_linearize<0, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_rest) hipLaunchKernelGGL((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
   }
   return hipGetLastError();
 }
@@ -705,7 +722,7 @@ __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
   if (dst >= 0) d.Hf[dst] = acc;                          // final value (single-segment block): also where its front gathers it
 }
 
-__global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d) { body_hblocks(d, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hblocks(d, blockIdx.x); }
 
 // Throughput form (many graphs per launch): a wave takes S consecutive segments.  The three dependent round trips of a
 // segment -- record, contribution descriptors, Jacobian slices -- are each issued for all S segments before the first
@@ -808,12 +825,13 @@ __device__ __forceinline__ void body_hreduce(const DevGraph& d, int bx) {
   if (dst >= 0) d.Hf[dst] = v;
 }
 
-__global__ __launch_bounds__(64) void k_hreduce(DevGraph d) { body_hreduce(d, blockIdx.x); }
+__global__ __launch_bounds__(64) void k_hreduce(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hreduce(d, blockIdx.x); }
 
-hipError_t launch_hblocks(const DevGraph& d, hipStream_t st) {
+hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard) {
   if (d.n_segs == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_hblocks, dim3(cdiv(d.n_segs, 4)), dim3(256), 0, st, d);
-  if (d.n_mseg > 0) hipLaunchKernelGGL(k_hreduce, dim3(d.n_mseg), dim3(64), 0, st, d);
+  const LinGuard gd = guard ? *guard : LinGuard{};
+  hipLaunchKernelGGL(k_hblocks, dim3(cdiv(d.n_segs, 4)), dim3(256), 0, st, d, gd);
+  if (d.n_mseg > 0) hipLaunchKernelGGL(k_hreduce, dim3(d.n_mseg), dim3(64), 0, st, d, gd);
   return hipGetLastError();
 }
 
