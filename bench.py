@@ -300,7 +300,7 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "note": "K1 of the C2 graph on the solver's stream: 400 back-to-back launches between two HIP events "
                             "(rocprofv3 of this command reports 8.4-9.1 us for these launches and ~11.4 us for the launches "
-                            "inside the solves, where the speculation stream is active and the state has just been rewritten: "
+                            "inside the solves, where the state has just been rewritten: "
                             "its mean over both kinds is ~10.8 us, profiles/r1_v8_kernel_stats_c2.txt; an event pair around "
                             "every single launch of one extra solve, in_solve_event_pairs, also measures the event handling "
                             "itself). One C2 "
@@ -346,6 +346,9 @@ def main():
                        "graphs_per_sec": world * solves / elapsed},
             "final_chi2": chi2, "chi2_initial": st["chi2_initial"],
             "fronts": st["n_fronts"], "levels": st["n_levels"], "max_front": st["max_front"],
+            # kernel launches of one LM solve (pps_stats.n_launches): the dual loop issues both damping values of a
+            # linearisation in the same launches on one stream (round 1: 21 launches per accepted + rejected pair on two streams)
+            "launches_per_lm_iteration": st["n_launches"] / max(1, st["lm_iterations"]), "launches_per_solve": st["n_launches"],
             "roofline": roofline, "roofline_batched": roofline_batched,
         }
         if world == 1:

@@ -174,6 +174,7 @@ typedef struct pps_stats {
   int    n_linearize, n_factorize;         /* launches of the sweep / factorizations        */
   int    lm_trials_notpd;                  /* LM trials whose factorisation hit a non-positive pivot (the step is then
                                               rejected like any other bad step; PPS_ENOTPD only if the last trial did) */
+  int    n_launches;                       /* kernel launches of the last solve call (all streams)                    */
 } pps_stats;
 int pps_get_stats(const pps_graph* g, pps_stats* out);
 /* LM trace of the last batch_optimize: per trial (lambda, chi2_new, accepted); returns count via n */

@@ -45,7 +45,7 @@ class PpsStats(C.Structure):
         ("t_total", C.c_double), ("t_analysis", C.c_double), ("t_upload", C.c_double),
         ("t_linearize", C.c_double), ("t_assemble", C.c_double), ("t_factor", C.c_double),
         ("t_backsolve", C.c_double), ("t_retract_chi2", C.c_double),
-        ("n_linearize", C.c_int), ("n_factorize", C.c_int), ("lm_trials_notpd", C.c_int),
+        ("n_linearize", C.c_int), ("n_factorize", C.c_int), ("lm_trials_notpd", C.c_int), ("n_launches", C.c_int),
     ]
 
     def asdict(self):

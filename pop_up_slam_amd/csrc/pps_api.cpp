@@ -137,6 +137,7 @@ struct pps_graph {
   int snap_version = -1, upload_version = 0;
   int profiling = 0;               // 0 off, 1 = K1 event pairs without host syncs, 2 = every phase (adds syncs)
   hipEvent_t ev[2] = {nullptr, nullptr};
+  unsigned long long launches0 = 0;   // launch_count() at the start of the solve call
   std::vector<char> k1_skip;          // per K1 event pair: not a linearisation that ran
   std::vector<hipEvent_t> k1_events;   // pairs (start, stop) recorded around the sweep
   int k1_used = 0;
@@ -1049,6 +1050,8 @@ void reset_solve_stats(pps_graph* g) {
   s.n_linearize = s.n_factorize = 0;
   s.lm_iterations = s.lm_trials_accepted = s.lm_trials_rejected = s.lm_trials_notpd = 0;
   s.t_analysis = s.t_upload = 0;
+  s.n_launches = 0;
+  g->launches0 = launch_count();
 }
 
 }  // namespace
@@ -1279,12 +1282,12 @@ int pps_update(pps_graph* g) {
     // the step is garbage: put the estimate back (lin still holds it) instead of handing NaNs to the caller
     rc = copy_state(g, false); if (rc != PPS_OK) return rc;
     HIP_TRY(g, hipStreamSynchronize(g->stream));
-    g->stats.t_total = now_s() - t0;
+    g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
     return fail(g, PPS_ENOTPD, "normal equations not positive definite");
   }
   g->dev_values_newer = true;
   g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
-  g->stats.t_total = now_s() - t0;
+  g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
   return PPS_OK;
 }
 
@@ -1426,7 +1429,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
   g->stats.lm_trials_notpd = n_notpd;
-  g->stats.t_total = now_s() - t0;
+  g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
   if (iterations) *iterations = num_iter;
   if (last_notpd) return fail(g, PPS_ENOTPD, "normal equations not positive definite at the last LM trial");
   return PPS_OK;
@@ -1587,7 +1590,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
   resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
-  g->stats.t_total = now_s() - t0;
+  g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
   if (g->dev.trace) {
     const Analysis& A = g->an;
     std::vector<long long> tr((size_t)A.n_fronts * 8);

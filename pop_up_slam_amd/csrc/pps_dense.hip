@@ -351,23 +351,23 @@ int dense_front_max_pivots() { return kMaxPiv; }
 hipError_t launch_dense_hpush(const DevGraph& d, int max_el_per_front, double lambda, hipStream_t st) {
   if (d.n_fronts == 0) return hipSuccess;
   const int gx = std::max(1, std::min(64, cdiv(max_el_per_front, 256)));
-  hipLaunchKernelGGL(k_dense_hpush, dim3(gx, d.n_fronts), dim3(256), 0, st, d, lambda);
+  PPS_LAUNCH(k_dense_hpush, dim3(gx, d.n_fronts), dim3(256), 0, st, d, lambda);
   return hipGetLastError();
 }
 
 hipError_t launch_dense_factor_level(const DevGraph& d, int level_begin, int level_count, const int* off_asm, int n_asm,
                                      const int* off_pan, int n_pan, const int* off_trl, int n_trl, hipStream_t st) {
   if (level_count == 0) return hipSuccess;
-  if (n_asm) hipLaunchKernelGGL(k_dense_assemble, dim3(n_asm), dim3(256), 0, st, d, level_begin, off_asm, level_count);
-  if (n_pan) hipLaunchKernelGGL(k_dense_panel, dim3(n_pan), dim3(256), 0, st, d, level_begin, off_pan, level_count);
-  if (n_trl) hipLaunchKernelGGL(k_dense_trailing, dim3(n_trl), dim3(256), (size_t)2 * 64 * (kMaxPiv + 1) * sizeof(double), st, d,
+  if (n_asm) PPS_LAUNCH(k_dense_assemble, dim3(n_asm), dim3(256), 0, st, d, level_begin, off_asm, level_count);
+  if (n_pan) PPS_LAUNCH(k_dense_panel, dim3(n_pan), dim3(256), 0, st, d, level_begin, off_pan, level_count);
+  if (n_trl) PPS_LAUNCH(k_dense_trailing, dim3(n_trl), dim3(256), (size_t)2 * 64 * (kMaxPiv + 1) * sizeof(double), st, d,
                                 level_begin, off_trl, level_count);
   return hipGetLastError();
 }
 
 hipError_t launch_dense_solve_level(const DevGraph& d, int level_begin, int level_count, int level_max_b, hipStream_t st) {
   if (level_count == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_dense_solve, dim3(level_count), dim3(256), (size_t)std::max(1, level_max_b) * sizeof(double), st, d, level_begin);
+  PPS_LAUNCH(k_dense_solve, dim3(level_count), dim3(256), (size_t)std::max(1, level_max_b) * sizeof(double), st, d, level_begin);
   return hipGetLastError();
 }
 

@@ -90,6 +90,11 @@ struct LinGuard {
   int on, pad;
 };
 
+// kernel launches issued by the calling host thread (pps_stats::n_launches is the difference over a solve call)
+unsigned long long launch_count();
+void count_launch();
+#define PPS_LAUNCH(...) do { ::pps::count_launch(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 // All launchers enqueue on `st` and return the HIP error of the launch.
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard = nullptr);
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard = nullptr);

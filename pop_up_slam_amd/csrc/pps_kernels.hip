@@ -356,6 +356,10 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const doubl
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+static thread_local unsigned long long t_launches = 0;
+unsigned long long launch_count() { return t_launches; }
+void count_launch() { ++t_launches; }
+
 // ------------------------------------------------------------------------------------------
 // K1, lane-parallel central differences (the reference's numericalDiff, one evaluation per lane):
 // 32 lanes per factor = 2 factors per wavefront.  Lane 2q evaluates the residual at x (+) eps e_q,
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard) {
   const LinGuard gd = guard ? *guard : LinGuard{};
   if (d.n_obs > d.n_obs_fixed) {
-    hipLaunchKernelGGL(k_linearize_repop, dim3(cdiv(d.n_obs - d.n_obs_fixed, 64)), dim3(64), 0, st, d,
+    PPS_LAUNCH(k_linearize_repop, dim3(cdiv(d.n_obs - d.n_obs_fixed, 64)), dim3(64), 0, st, d,
                        at_estimate ? d.pose_est : d.pose_lin, at_estimate ? d.plane_est : d.plane_lin, gd);
   }
   const int nb_obs = cdiv(d.n_obs_fixed, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock), nb_pp = cdiv(d.n_pp, kLinBlock),
@@ -571,18 +575,18 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   if (mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !getenv("PPS_K1_THREAD_FORM")) {
     const int lb_obs = cdiv(d.n_obs_fixed, kFactorsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
               lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
-    hipLaunchKernelGGL(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
+    PPS_LAUNCH(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
                        lb_obs, lb_odo, lb_pp, gd);
     return hipGetLastError();
   }
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   const int nb_rest = nb - nb_obs;
   if (mode == 1) {
-    if (nb_obs) hipLaunchKernelGGL((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
-    if (nb_rest) hipLaunchKernelGGL((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_obs) PPS_LAUNCH((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_rest) PPS_LAUNCH((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
   } else {
-    if (nb_obs) hipLaunchKernelGGL((k_linearize<0, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
-    if (nb_rest) hipLaunchKernelGGL((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_obs) PPS_LAUNCH((k_linearize<0, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_rest) PPS_LAUNCH((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
   }
   return hipGetLastError();
 }
@@ -642,11 +646,11 @@ hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double*
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   if (nb_obs + nb_odo == 0) return hipSuccess;
   if (mode == 1) {
-    if (nb_obs && part != 1) hipLaunchKernelGGL((k_sweep_bench<1, 0>), dim3(nb_obs * replicas), dim3(kLinBlock), lds0, st, d, Jbig, nb_obs, nb_odo, replicas);
-    if (nb_odo && part != 0) hipLaunchKernelGGL((k_sweep_bench<1, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), lds1, st, d, Jbig, nb_obs, nb_odo, replicas);
+    if (nb_obs && part != 1) PPS_LAUNCH((k_sweep_bench<1, 0>), dim3(nb_obs * replicas), dim3(kLinBlock), lds0, st, d, Jbig, nb_obs, nb_odo, replicas);
+    if (nb_odo && part != 0) PPS_LAUNCH((k_sweep_bench<1, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), lds1, st, d, Jbig, nb_obs, nb_odo, replicas);
   } else {
-    if (nb_obs && part != 1) hipLaunchKernelGGL((k_sweep_bench<0, 0>), dim3(nb_obs * replicas), dim3(kLinBlock), lds0, st, d, Jbig, nb_obs, nb_odo, replicas);
-    if (nb_odo && part != 0) hipLaunchKernelGGL((k_sweep_bench<0, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), lds1, st, d, Jbig, nb_obs, nb_odo, replicas);
+    if (nb_obs && part != 1) PPS_LAUNCH((k_sweep_bench<0, 0>), dim3(nb_obs * replicas), dim3(kLinBlock), lds0, st, d, Jbig, nb_obs, nb_odo, replicas);
+    if (nb_odo && part != 0) PPS_LAUNCH((k_sweep_bench<0, 1>), dim3(nb_odo * replicas), dim3(kLinBlock), lds1, st, d, Jbig, nb_obs, nb_odo, replicas);
   }
   return hipGetLastError();
 }
@@ -830,8 +834,8 @@ __global__ __launch_bounds__(64) void k_hreduce(DevGraph d, LinGuard gd) { if (!
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard) {
   if (d.n_segs == 0) return hipSuccess;
   const LinGuard gd = guard ? *guard : LinGuard{};
-  hipLaunchKernelGGL(k_hblocks, dim3(cdiv(d.n_segs, 4)), dim3(256), 0, st, d, gd);
-  if (d.n_mseg > 0) hipLaunchKernelGGL(k_hreduce, dim3(d.n_mseg), dim3(64), 0, st, d, gd);
+  PPS_LAUNCH(k_hblocks, dim3(cdiv(d.n_segs, 4)), dim3(256), 0, st, d, gd);
+  if (d.n_mseg > 0) PPS_LAUNCH(k_hreduce, dim3(d.n_mseg), dim3(64), 0, st, d, gd);
   return hipGetLastError();
 }
 
@@ -949,9 +953,9 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
       if (e != hipSuccess) return e;
       g_attr_set[dev & 63] = true;
     }
-    hipLaunchKernelGGL(k_front_factor<true>, dim3(level_count), dim3(256), bytes, st, d, level_begin, lambda);
+    PPS_LAUNCH(k_front_factor<true>, dim3(level_count), dim3(256), bytes, st, d, level_begin, lambda);
   } else {
-    hipLaunchKernelGGL(k_front_factor<false>, dim3(level_count), dim3(256), 0, st, d, level_begin, lambda);
+    PPS_LAUNCH(k_front_factor<false>, dim3(level_count), dim3(256), 0, st, d, level_begin, lambda);
   }
   return hipGetLastError();
 }
@@ -1006,13 +1010,13 @@ __global__ __launch_bounds__(256) void k_expand_el(DevGraph d, int n_asm) {
 
 hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st) {
   if (n_asm <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_expand_el, dim3((n_asm + 255) / 256), dim3(256), 0, st, d, n_asm);
+  PPS_LAUNCH(k_expand_el, dim3((n_asm + 255) / 256), dim3(256), 0, st, d, n_asm);
   return hipGetLastError();
 }
 
 hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
   if (n_fronts <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_expand_ea, dim3(n_fronts), dim3(64), 0, st, d);
+  PPS_LAUNCH(k_expand_ea, dim3(n_fronts), dim3(64), 0, st, d);
   return hipGetLastError();
 }
 
@@ -1519,9 +1523,9 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
   }
   if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
-    hipLaunchKernelGGL(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
+    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
   else
-    hipLaunchKernelGGL(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, solve_per_wave);
+    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, solve_per_wave);
   return hipGetLastError();
 }
 
@@ -1532,9 +1536,9 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
   const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   if (max_front + 1 <= kRegRows && d.trace == nullptr)
-    hipLaunchKernelGGL(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
   else
-    hipLaunchKernelGGL(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
   return hipGetLastError();
 }
 
@@ -1545,7 +1549,7 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
   if (grp_count == 0) return hipSuccess;
   // per wave: xb + the largest factor panel of the stage; per workgroup: one local solution vector per front of a group
   const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
-  hipLaunchKernelGGL(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves),
+  PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves),
                      ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double), st, d, alt ? *alt : DualAlt{}, grp_begin,
                      per_wave);
   return hipGetLastError();
@@ -1577,7 +1581,7 @@ __global__ __launch_bounds__(64) void k_front_solve(DevGraph d, int level_begin)
 
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st) {
   if (level_count == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_front_solve, dim3(level_count), dim3(64), 0, st, d, level_begin);
+  PPS_LAUNCH(k_front_solve, dim3(level_count), dim3(64), 0, st, d, level_begin);
   return hipGetLastError();
 }
 
@@ -1674,20 +1678,20 @@ hipError_t launch_retract_to(const DevGraph& d, const double* base_pose, const d
                              hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_retract_to, dim3(cdiv(n, 256)), dim3(256), 0, st, d, DualAlt{}, base_pose, base_plane, out_pose, out_plane, nullptr, nullptr);
+  PPS_LAUNCH(k_retract_to, dim3(cdiv(n, 256)), dim3(256), 0, st, d, DualAlt{}, base_pose, base_plane, out_pose, out_plane, nullptr, nullptr);
   return hipGetLastError();
 }
 
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_retract<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, d);
+  PPS_LAUNCH(k_retract<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, d);
   return hipGetLastError();
 }
 hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_retract<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, d);
+  PPS_LAUNCH(k_retract<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, d);
   return hipGetLastError();
 }
 
@@ -1816,11 +1820,11 @@ hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double
                              double seq1, hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
   if (n > 0)
-    hipLaunchKernelGGL(k_retract_to, dim3(cdiv(n, 256), 2), dim3(256), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1);
+    PPS_LAUNCH(k_retract_to, dim3(cdiv(n, 256), 2), dim3(256), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1);
   const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock), nb_lp = cdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if (nb == 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_chi2_dual, dim3(nb, 2), dim3(kChiBlock), 0, st, d, alt, out_pose0, out_plane0, out_pose1, out_plane1, nb_obs, nb_odo, nb_pp,
+  PPS_LAUNCH(k_chi2_dual, dim3(nb, 2), dim3(kChiBlock), 0, st, d, alt, out_pose0, out_plane0, out_pose1, out_plane1, nb_obs, nb_odo, nb_pp,
                      cdiv(n, 256), host_result0, seq0, host_result1, seq1);
   return hipGetLastError();
 }
@@ -1833,7 +1837,7 @@ hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result,
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
   if (nb == 0) return hipErrorInvalidValue;
   const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
-  hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
+  PPS_LAUNCH(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
   return hipGetLastError();
 }
 
@@ -1845,7 +1849,7 @@ hipError_t launch_chi2_at(const DevGraph& d, const double* pose, const double* p
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if (nb == 0) return hipErrorInvalidValue;
   const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
-  hipLaunchKernelGGL(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
+  PPS_LAUNCH(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
   return hipGetLastError();
 }
 
@@ -1981,43 +1985,43 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2(BatchArgs a, int slot) {
 }
 
 hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
-  hipLaunchKernelGGL(kb_begin, dim3(std::max(1, std::min(8, g.retract)), a.n), dim3(256), 0, st, a);
+  PPS_LAUNCH(kb_begin, dim3(std::max(1, std::min(8, g.retract)), a.n), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st) {
-  if (g.repop_blocks > 0) hipLaunchKernelGGL(kb_linearize_repop, dim3(g.repop_blocks, a.n), dim3(64), 0, st, a);
+  if (g.repop_blocks > 0) PPS_LAUNCH(kb_linearize_repop, dim3(g.repop_blocks, a.n), dim3(64), 0, st, a);
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   if (mode == 0) {
-    if (g.lin_blocks > 0) hipLaunchKernelGGL(kb_linearize_lanes, dim3(g.lin_blocks, a.n), dim3(kLanesPerBlock), 0, st, a);
+    if (g.lin_blocks > 0) PPS_LAUNCH(kb_linearize_lanes, dim3(g.lin_blocks, a.n), dim3(kLanesPerBlock), 0, st, a);
   } else if (mode == 2) {          // numeric, one thread per factor
     if (g.lin_obs_blocks > 0) {
-      if (g.k1_direct) hipLaunchKernelGGL((kb_linearize<0, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
-      else hipLaunchKernelGGL((kb_linearize<0, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      if (g.k1_direct) PPS_LAUNCH((kb_linearize<0, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      else PPS_LAUNCH((kb_linearize<0, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
     }
-    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<0, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
+    if (g.lin_rest_blocks > 0) PPS_LAUNCH((kb_linearize<0, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   } else {
     if (g.lin_obs_blocks > 0) {
-      if (g.k1_direct) hipLaunchKernelGGL((kb_linearize<1, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
-      else hipLaunchKernelGGL((kb_linearize<1, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      if (g.k1_direct) PPS_LAUNCH((kb_linearize<1, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      else PPS_LAUNCH((kb_linearize<1, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
     }
-    if (g.lin_rest_blocks > 0) hipLaunchKernelGGL((kb_linearize<1, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
+    if (g.lin_rest_blocks > 0) PPS_LAUNCH((kb_linearize<1, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
   if (g.hblocks > 0) {
-    if (g.k1_direct) hipLaunchKernelGGL(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form, direct blocks done by K1
-    else hipLaunchKernelGGL(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
+    if (g.k1_direct) PPS_LAUNCH(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form, direct blocks done by K1
+    else PPS_LAUNCH(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
   }
-  if (g.hreduce > 0) hipLaunchKernelGGL(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
+  if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st) {
   if (g.chi2 <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kb_chi2, dim3(g.chi2, a.n), dim3(kChiBlock), 0, st, a, slot);
+  PPS_LAUNCH(kb_chi2, dim3(g.chi2, a.n), dim3(kChiBlock), 0, st, a, slot);
   return hipGetLastError();
 }
 
@@ -2038,22 +2042,22 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
     const size_t bytes = (size_t)per_wave * nw * sizeof(double);
     if (g.stage_reg_only[stg])
-      hipLaunchKernelGGL(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+      PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else
-      hipLaunchKernelGGL(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+      PPS_LAUNCH(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
   }
   if (after_factor) (void)hipEventRecord(after_factor, st);
   for (int stg = g.n_stages - 1; stg >= 0; stg--) {
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_solve[stg], nw = g.stage_nw_solve[stg];
     const size_t bytes = ((size_t)per_wave * nw + (size_t)g.stage_grp_fronts[stg] * kBandMaxRows) * sizeof(double);
-    hipLaunchKernelGGL(kb_band_solve, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    PPS_LAUNCH(kb_band_solve, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
-  if (g.retract > 0) hipLaunchKernelGGL(kb_retract_trial, dim3(g.retract, a.n), dim3(256), 0, st, a);
+  if (g.retract > 0) PPS_LAUNCH(kb_retract_trial, dim3(g.retract, a.n), dim3(256), 0, st, a);
   return launch_batch_chi2(a, g, 1, st);
 }
 
@@ -2068,7 +2072,7 @@ __global__ __launch_bounds__(256) void k_scatter_patches(const char* __restrict_
 
 hipError_t launch_scatter_patches(const char* patch, int n_patches, char* arena, hipStream_t st) {
   if (n_patches <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_scatter_patches, dim3(n_patches, 8), dim3(256), 0, st, patch, arena);
+  PPS_LAUNCH(k_scatter_patches, dim3(n_patches, 8), dim3(256), 0, st, patch, arena);
   return hipGetLastError();
 }
 
