@@ -68,6 +68,9 @@ struct pps_graph {
   bool meas_dirty = false;
   bool analyzed = false;
   int n_analyses = 0;              // analyses so far; with `grown_only` it selects the frame-loop form of the analysis
+  // compacted node / factor tables of the last analysis (run_analysis appends to them while the graph only grows)
+  std::vector<SymNode> sym_nodes; std::vector<SymFactor> sym_factors;
+  size_t cmp_nodes = 0, cmp_factors = 0; int64_t cmp_base[4] = {0, 0, 0, 0}; bool cmp_valid = false, cmp_has_repop = false;
   bool grown_only = true;          // nothing has been removed since the last analysis (nodes / factors were only appended)
   bool grown_only_upload = false;  // ... since the last upload (false until there has been one)
   Analysis an;
@@ -408,9 +411,50 @@ void j_bases(const pps_graph* g, int64_t base[4], int64_t* total) {
 // ---- compaction + symbolic analysis (host only) -------------------------------------------
 int run_analysis(pps_graph* g) {
   const double t0 = now_s();
+  std::vector<SymNode>& sn = g->sym_nodes;
+  std::vector<SymFactor>& sf = g->sym_factors;
+  // A graph that only grew since the last analysis (the frame loop) appends to the compacted tables instead of walking
+  // every node and factor again; re-popping edges are ordered behind the fixed ones, which moves slots: they take the full path.
+  bool append = g->cmp_valid && g->grown_only && g->n_analyses > 0 && !g->cmp_has_repop && g->cmp_nodes <= g->nodes.size() &&
+                g->cmp_factors <= g->factors.size() && !getenv("PPS_NO_INCR_COMPACT");
+  for (size_t i = g->cmp_factors; append && i < g->factors.size(); i++)
+    append = !g->factors[i].deleted && !(g->factors[i].type == F_PLANE_OBS && g->factors[i].repop);
+  for (size_t i = g->cmp_nodes; append && i < g->nodes.size(); i++) append = !g->nodes[i].deleted;
+  if (append) {
+    for (size_t i = g->cmp_nodes; i < g->nodes.size(); i++) {
+      HostNode& n = g->nodes[i];
+      n.compact = (int)sn.size();
+      if (n.type == NODE_POSE) { n.slot = (int)g->pose_ids.size(); g->pose_ids.push_back((int)i); sn.push_back({NODE_POSE, 6, n.slot}); }
+      else { n.slot = (int)g->plane_ids.size(); g->plane_ids.push_back((int)i); sn.push_back({NODE_PLANE, 3, -1}); }
+    }
+    for (size_t i = g->cmp_factors; i < g->factors.size(); i++) {
+      HostFactor& f = g->factors[i];
+      f.slot = (int)g->fslot_ids[f.type].size();
+      g->fslot_ids[f.type].push_back((int)i);
+    }
+    g->n_obs_fixed = (int)g->fslot_ids[F_PLANE_OBS].size();
+    int64_t base[4], j_total = 0;
+    j_bases(g, base, &j_total);
+    if (j_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
+    if (memcmp(base, g->cmp_base, sizeof(base)) != 0) {          // a J slab outgrew its capacity: every offset moves
+      int cnt[4] = {0, 0, 0, 0};
+      for (SymFactor& q : sf) q.joff = (int)(base[q.type] + (int64_t)(cnt[q.type]++) * kJSize[q.type]);
+      memcpy(g->cmp_base, base, sizeof(base));
+    }
+    for (size_t i = g->cmp_factors; i < g->factors.size(); i++) {
+      const HostFactor& f = g->factors[i];
+      SymFactor q;
+      q.type = f.type;
+      q.a = g->nodes[f.a].compact;
+      q.b = f.b >= 0 ? g->nodes[f.b].compact : -1;
+      q.joff = (int)(base[f.type] + (int64_t)f.slot * kJSize[f.type]);
+      q.direct_ok = f.type == F_PLANE_OBS ? 1 : 0;
+      sf.push_back(q);
+    }
+  } else {
   g->pose_ids.clear(); g->plane_ids.clear();
   for (int t = 0; t < 4; t++) g->fslot_ids[t].clear();
-  std::vector<SymNode> sn;
+  sn.clear(); sf.clear();
   for (size_t i = 0; i < g->nodes.size(); i++) {
     HostNode& n = g->nodes[i];
     if (n.deleted) { n.compact = n.slot = -1; continue; }
@@ -419,11 +463,13 @@ int run_analysis(pps_graph* g) {
     else { n.slot = (int)g->plane_ids.size(); g->plane_ids.push_back((int)i); sn.push_back({NODE_PLANE, 3, -1}); }
   }
   // plane observations with a fixed measurement first, the re-popping ones (Factor2) behind them
+  g->cmp_has_repop = false;
   for (int pass = 0; pass < 2; pass++)
     for (size_t i = 0; i < g->factors.size(); i++) {
       HostFactor& f = g->factors[i];
       if (f.deleted) { f.slot = -1; continue; }
       if ((f.type == F_PLANE_OBS && f.repop) != (pass == 1)) continue;
+      if (pass == 1) g->cmp_has_repop = true;
       f.slot = (int)g->fslot_ids[f.type].size();
       g->fslot_ids[f.type].push_back((int)i);
     }
@@ -432,11 +478,12 @@ int run_analysis(pps_graph* g) {
   int64_t base[4], j_total = 0;
   j_bases(g, base, &j_total);
   if (j_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
-  std::vector<SymFactor> sf;
+  memcpy(g->cmp_base, base, sizeof(base));
   sf.reserve(g->factors.size());
+  bool any_deleted = false;
   for (size_t i = 0; i < g->factors.size(); i++) {
     const HostFactor& f = g->factors[i];
-    if (f.deleted) continue;
+    if (f.deleted) { any_deleted = true; continue; }
     SymFactor s;
     s.type = f.type;
     s.a = g->nodes[f.a].compact;
@@ -445,6 +492,10 @@ int run_analysis(pps_graph* g) {
     s.direct_ok = (f.type == F_PLANE_OBS && !f.repop) ? 1 : 0;
     sf.push_back(s);
   }
+  // the append path relies on: table index == host index order with nothing skipped
+  g->cmp_valid = !any_deleted && sn.size() == g->nodes.size();
+  }
+  g->cmp_nodes = g->nodes.size(); g->cmp_factors = g->factors.size();
   if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
   if (const char* e = getenv("PPS_MAX_PIVOTS")) g->aprm.max_pivots = atoi(e);
   // band depth: 4 levels per launch when the solve is latency bound (C2: 512 fronts; 113.3 vs 115.0 us per LM iteration

@@ -31,8 +31,8 @@ struct Builder {
   // frame-loop reuse (aligned cuts only): sub-chains of the previous analysis by (first pose, last pose); a sub-chain that
   // comes back with the same poses and planes is the same sub-tree -- nothing inside it has a new neighbour -- and its
   // block of tree nodes is copied instead of dissected again
-  const std::vector<TNode>* old_tree = nullptr;
-  const std::vector<DissectMemo>* old_memo = nullptr;
+  std::vector<TNode>* old_tree = nullptr;        // (not const: reused tree nodes and memos are MOVED out, the cache is rebuilt at the end)
+  std::vector<DissectMemo>* old_memo = nullptr;
   const std::vector<int>* old_memo_of_first = nullptr;   // pose id -> first memo index of the sub-chains starting there (-1)
   const std::vector<int>* old_memo_next = nullptr;       // memo index -> next memo with the same first pose (-1)
   std::vector<DissectMemo> memo;                         // of THIS run
@@ -49,11 +49,12 @@ struct Builder {
   void build_adjacency() {
     // CSR of the undirected node graph, neighbours sorted and unique: counting sort on the first end point, small
     // sorts inside each row
-    std::vector<int> cnt(N + 1, 0);
+    static thread_local std::vector<int> cnt, raw, fill;    // scratch that keeps its capacity from call to call (frame loops)
+    cnt.assign(N + 1, 0);
     for (const auto& f : factors)
       if (f.b >= 0 && f.a != f.b) { cnt[f.a + 1]++; cnt[f.b + 1]++; }
     for (int i = 0; i < N; i++) cnt[i + 1] += cnt[i];
-    std::vector<int> raw(cnt[N]), fill(cnt.begin(), cnt.end() - 1);
+    raw.resize(cnt[N]); fill.assign(cnt.begin(), cnt.end() - 1);
     for (const auto& f : factors)
       if (f.b >= 0 && f.a != f.b) { raw[fill[f.a]++] = f.b; raw[fill[f.b]++] = f.a; }
     adj_off.assign(N + 1, 0);
@@ -62,7 +63,7 @@ struct Builder {
     for (int u = 0; u < N; u++) {
       int* b = raw.data() + cnt[u];
       int* e = raw.data() + cnt[u + 1];
-      std::sort(b, e);
+      if (!std::is_sorted(b, e)) std::sort(b, e);      // factors arrive in time order: a landmark's observers already are
       e = std::unique(b, e);
       adj.insert(adj.end(), b, e);
       adj_off[u + 1] = (int)adj.size();
@@ -171,15 +172,20 @@ struct Builder {
         const DissectMemo& m = (*old_memo)[mi];
         if (m.last != poses[n - 1] || m.count != n || m.planes != planes) continue;
         // the same sub-chain with the same planes: copy its block of tree nodes
-        const int t0 = (int)tree.size(), delta = t0 - m.t0;
-        for (int q = m.t0; q < m.t1; q++) {
-          tree.push_back((*old_tree)[q]);
+        const int t0 = (int)tree.size(), delta = t0 - m.t0, m_t0 = m.t0, m_t1 = m.t1;
+        for (int q = m_t0; q < m_t1; q++) {
+          tree.push_back(std::move((*old_tree)[q]));
           for (int& k : tree.back().kids) k += delta;
           t_reused.push_back(1); t_old.push_back(q);
         }
-        // the memos of the copied block stay valid for the next frame (re-based)
-        for (const DissectMemo& mm : *old_memo)
-          if (mm.t0 >= m.t0 && mm.t1 <= m.t1) { memo.push_back(mm); memo.back().t0 += delta; memo.back().t1 += delta; }
+        // the memos of the copied block stay valid for the next frame (re-based): memos are pushed in pre-order, so the
+        // block's own are the run that starts at this one
+        for (size_t k = (size_t)mi; k < old_memo->size(); k++) {
+          DissectMemo& mm = (*old_memo)[k];
+          if (mm.t0 < m_t0 || mm.t1 > m_t1) break;
+          memo.push_back(std::move(mm)); memo.back().t0 += delta; memo.back().t1 += delta;
+          mm.t0 = mm.t1 = -1; mm.count = -1;           // moved from: never matches again
+        }
         return t0;
       }
     }
@@ -442,8 +448,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
         if (!B.dense[B.adj[q]] && !B.dense[u]) a2.push_back(B.adj[q]);
       off[u + 1] = (int)a2.size();
     }
-    std::vector<int> full_off = B.adj_off, full_adj = B.adj;
-    B.adj_off.swap(off);
+    B.adj_off.swap(off);           // (off / a2 hold the full adjacency until the swap back below)
     B.adj.swap(a2);
     int top = -1;
     if (!poses.empty() || !planes.empty()) {
@@ -452,12 +457,13 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
         live.insert(live.end(), planes.begin(), planes.end());
         top = B.mindeg_tree(live);
       } else {
-        if (reuse) { B.old_tree = &C->tree; B.old_memo = &C->memo; B.old_memo_of_first = &C->memo_of_first; B.old_memo_next = &C->memo_next; }
+        if (reuse) { C->valid = false;   // its tree and memos are moved from; set again when this analysis has succeeded
+          B.old_tree = &C->tree; B.old_memo = &C->memo; B.old_memo_of_first = &C->memo_of_first; B.old_memo_next = &C->memo_next; }
         top = B.dissect(poses, planes);
       }
     }
-    B.adj_off.swap(full_off);
-    B.adj.swap(full_adj);
+    B.adj_off.swap(off);
+    B.adj.swap(a2);
     root = top;
     if (!dense_nodes.empty()) {
       root = B.new_tnode();
