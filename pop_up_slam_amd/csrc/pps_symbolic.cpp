@@ -229,7 +229,8 @@ struct Builder {
     int K = std::max(2, prm.arity);
     while (K > 2 && n < 2 * K + 1) K--;        // too short for that many parts
     std::vector<int> cuts;
-    if (K == 2 && prm.aligned_cuts) {
+    const bool aligned = K == 2 && prm.aligned_cuts;
+    if (aligned) {
       // Bisection at an ABSOLUTE position: the pose whose rank (insertion index) is the multiple of the largest power of two
       // inside this sub-chain.  A chain that grows at its end (a SLAM front
       // end adds one pose per frame) then keeps every sub-tree left of its newest poses -- ordering, fronts and all index
@@ -242,7 +243,7 @@ struct Builder {
       // and the tree degenerates -- 12 levels instead of 9 on a 512-pose chain)
       cuts.push_back(std::min(std::max(centre, 1), n - 2));
     }
-    for (int c = 1; c < K && !(K == 2 && prm.aligned_cuts); c++) {
+    for (int c = 1; c < K && !aligned; c++) {
       const int centre = (int)((long long)n * c / K);
       const int half = std::max(0, n / (6 * K));
       int lo = std::max(1, centre - half), hi = std::min(n - 2, centre + half);

@@ -219,6 +219,26 @@ def test_c4_survey_seeds_against_the_oracle(built):
                   "path: first 5 trials agree to %.1e (accepted) / %.1e (rejected), all 8 verdicts equal; after trial 8: %.1e" % (seed, co, co_fma, c, it, worst_all, worst_rej, worst_end))
 
 
+@pytest.mark.parametrize("mk", [lambda: synth.corridor(600, 100, obs_per_pose=8, seed=5), lambda: synth.corridor(400, 40, obs_per_pose=10, seed=5)],
+                         ids=["600p-8obs", "400p-10obs"])
+def test_fronts_of_65_to_80_rows(built, mk):
+    """Walls observed from many poses give separators beyond the 64 rows of the register-resident fronts (the aligned-cut trees
+    of frame loops do the same): such a stage runs the full band kernel, where those fronts take the LDS-tile path next to
+    register-resident neighbours.  Against the oracle trial for trial."""
+    spec = mk()
+    g, o, *_ = _pair(spec)
+    g.analyze()
+    A = g.analysis_dump()
+    rows = A["f_p"] + A["f_b"] + 1
+    assert ((rows > 64) & (rows <= 80)).sum() >= 4 and rows.max() <= 80
+    it, ito = g.batch_optimize(), o.batch_optimize()
+    c, co = g.chi2(), o.chi2()
+    assert it == ito and abs(c - co) <= 1e-7 * abs(co), (it, ito, c, co)
+    tr, tro = g.trace(), o.trace()
+    assert [a for _, _, a in tr] == [a for _, _, a in tro]
+    np.testing.assert_allclose([x for _, x, _ in tr], [x for _, x, _ in tro], rtol=1e-6)
+
+
 def test_mid_and_large_graphs(built):
     """5 000 poses against the oracle (dead reckoning drifts over this length: the first LM trials are all rejected --
     on both sides, trial for trial); then 50 000 poses / 250 000 plane edges (50x C2, minutes for the oracle) through
