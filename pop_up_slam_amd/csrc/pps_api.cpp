@@ -116,6 +116,7 @@ struct pps_graph {
   std::vector<double> pk_obs_m, pk_obs_w, pk_odo_m, pk_odo_w;
   size_t pk_n_obs = 0, pk_n_odo = 0, pk_ld_obs = 0, pk_ld_odo = 0;
   bool pk_meas_ok = false;
+  bool lin_is_est = false;       // upload_state has just filled est AND lin: the estimate_to_linpoint copy of the next solve is a no-op
   bool up_inflight = false;      // upload_all left copies from the pinned buffers in flight on `stream`
   double* state_pin = nullptr; size_t state_pin_cap = 0;     // pinned staging of upload_state / download_state
   std::unordered_map<std::string, double> up_laps;         // PPS_UPLOAD_TIMING=1: seconds per phase of upload_all, summed; printed at destroy
@@ -622,8 +623,7 @@ int download_state(pps_graph* g) {
   int rc = state_pin_reserve(g, np + nl);
   if (rc != PPS_OK) return rc;
   double* bp = g->state_pin; double* bl = g->state_pin + np;
-  if (d.n_pose) HIP_TRY(g, hipMemcpyAsync(bp, d.pose_est, np * 8, hipMemcpyDeviceToHost, g->stream));
-  if (d.n_plane) HIP_TRY(g, hipMemcpyAsync(bl, d.plane_est, nl * 8, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(g, hipMemcpyAsync(bp, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToHost, g->stream));   // [poses | planes], one block
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) g->nodes[g->pose_ids[s]].v[k] = bp[(size_t)k * d.pose_ld + s];
   for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) g->nodes[g->plane_ids[s]].v[k] = bl[(size_t)k * d.plane_ld + s];
@@ -642,14 +642,9 @@ int upload_state(pps_graph* g, bool sync = true) {
   for (int k = 0; k < 4; k++) for (int s = d.n_plane; s < d.plane_ld; s++) bl[(size_t)k * d.plane_ld + s] = 0.0;
   for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) bp[(size_t)k * d.pose_ld + s] = g->nodes[g->pose_ids[s]].v[k];
   for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) bl[(size_t)k * d.plane_ld + s] = g->nodes[g->plane_ids[s]].v[k];
-  if (d.n_pose) {
-    HIP_TRY(g, hipMemcpyAsync(d.pose_est, bp, np * 8, hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(g, hipMemcpyAsync(d.pose_lin, d.pose_est, np * 8, hipMemcpyDeviceToDevice, g->stream));
-  }
-  if (d.n_plane) {
-    HIP_TRY(g, hipMemcpyAsync(d.plane_est, bl, nl * 8, hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(g, hipMemcpyAsync(d.plane_lin, d.plane_est, nl * 8, hipMemcpyDeviceToDevice, g->stream));
-  }
+  HIP_TRY(g, hipMemcpyAsync(d.pose_est, bp, (np + nl) * 8, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(g, hipMemcpyAsync(d.pose_lin, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToDevice, g->stream));
+  g->lin_is_est = true;
   if (sync) HIP_TRY(g, hipStreamSynchronize(g->stream));
   else g->up_inflight = true;
   g->host_values_newer = false;
@@ -742,8 +737,11 @@ int upload_all(pps_graph* g) {
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
   d.pose_ld = std::max(1, (d.n_pose + 63) / 64 * 64); d.plane_ld = std::max(1, (d.n_plane + 63) / 64 * 64);
 #define TRY(x) do { rc = (x); if (rc != PPS_OK) return rc; } while (0)
-  TRY(dev_alloc(g, &d.pose_est, (size_t)7 * d.pose_ld)); TRY(dev_alloc(g, &d.pose_lin, (size_t)7 * d.pose_ld));
-  TRY(dev_alloc(g, &d.plane_est, (size_t)4 * d.plane_ld)); TRY(dev_alloc(g, &d.plane_lin, (size_t)4 * d.plane_ld));
+  // every copy of the state is one block [poses | planes]: one transfer moves it (copies rotate by pointer pairs, so a
+  // plane array always sits behind its pose array)
+  const size_t state_doubles = (size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld;
+  TRY(dev_alloc(g, &d.pose_est, state_doubles)); d.plane_est = d.pose_est + (size_t)7 * d.pose_ld;
+  TRY(dev_alloc(g, &d.pose_lin, state_doubles)); d.plane_lin = d.pose_lin + (size_t)7 * d.pose_ld;
   std::vector<int> pv(d.n_pose), lv(d.n_plane);
   for (int s = 0; s < d.n_pose; s++) pv[s] = A.node_voff[g->nodes[g->pose_ids[s]].compact];
   for (int s = 0; s < d.n_plane; s++) lv[s] = A.node_voff[g->nodes[g->plane_ids[s]].compact];
@@ -875,13 +873,19 @@ int upload_all(pps_graph* g) {
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &d.result_dev, 4)); TRY(dev_alloc(g, &g->spec_result, 4));
-  TRY(dev_alloc(g, &d.dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
-  HIP_TRY(g, hipMemsetAsync(d.dn_partials, 0, ((size_t)(d.n_pose + d.n_plane + 255) / 256 + 1) * 8, g->stream));
-  TRY(dev_alloc(g, &d.ticket, 1)); HIP_TRY(g, hipMemsetAsync(d.ticket, 0, 4, g->stream));
-  TRY(dev_alloc(g, &g->spec_pose, (size_t)7 * d.pose_ld + 1)); TRY(dev_alloc(g, &g->spec_plane, (size_t)4 * d.plane_ld + 1));
+  {
+    // one zeroed block: [dn_partials | ticket | spec ticket]
+    const size_t n_dn = (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1;
+    double* zb = nullptr;
+    TRY(dev_alloc(g, &zb, n_dn + 2));
+    HIP_TRY(g, hipMemsetAsync(zb, 0, (n_dn + 2) * 8, g->stream));
+    d.dn_partials = zb;
+    d.ticket = reinterpret_cast<unsigned int*>(zb + n_dn);
+    g->spec_ticket = reinterpret_cast<unsigned int*>(zb + n_dn + 1);
+  }
+  TRY(dev_alloc(g, &g->spec_pose, state_doubles + 1)); g->spec_plane = g->spec_pose + (size_t)7 * d.pose_ld;
   TRY(dev_alloc(g, &g->spec_chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &g->spec_dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
-  TRY(dev_alloc(g, &g->spec_ticket, 1)); HIP_TRY(g, hipMemsetAsync(g->spec_ticket, 0, 4, g->stream));
   if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
   // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
   if (!g->use_band && !g->use_dense && A.max_front > lds_front_limit()) {
@@ -1065,9 +1069,9 @@ void swap_state(pps_graph* g) {
 int copy_state(pps_graph* g, bool est_to_lin) {
   const DevGraph& d = g->dev;
   double *ps = est_to_lin ? d.pose_est : d.pose_lin, *pd = est_to_lin ? d.pose_lin : d.pose_est;
-  double *ls = est_to_lin ? d.plane_est : d.plane_lin, *ld = est_to_lin ? d.plane_lin : d.plane_est;
-  if (d.n_pose) HIP_TRY(g, hipMemcpyAsync(pd, ps, (size_t)7 * d.pose_ld * 8, hipMemcpyDeviceToDevice, g->stream));
-  if (d.n_plane) HIP_TRY(g, hipMemcpyAsync(ld, ls, (size_t)4 * d.plane_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  if (est_to_lin && g->lin_is_est) { g->lin_is_est = false; return PPS_OK; }       // upload_state has just written both copies
+  g->lin_is_est = false;
+  HIP_TRY(g, hipMemcpyAsync(pd, ps, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
   return PPS_OK;
 }
 
@@ -1336,7 +1340,7 @@ int pps_update(pps_graph* g) {
     g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
     return fail(g, PPS_ENOTPD, "normal equations not positive definite");
   }
-  g->dev_values_newer = true;
+  g->dev_values_newer = true; g->lin_is_est = false;
   g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
   g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
   return PPS_OK;
@@ -1475,7 +1479,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   d.pose_lin = t_pose[0]; d.plane_lin = t_plane[0];
   g->spec_pose = t_pose[1]; g->spec_plane = t_plane[1];
   HIP_TRY(g, hipStreamSynchronize(g->stream));
-  g->dev_values_newer = true;
+  g->dev_values_newer = true; g->lin_is_est = false;
   resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
@@ -1637,7 +1641,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
   if (trial_pending) swap_state(g);                               // undo the speculative step
   swap_state(g);                                                  // linpoint_to_estimate (:466)
   HIP_TRY(g, hipStreamSynchronize(g->stream));
-  g->dev_values_newer = true;
+  g->dev_values_newer = true; g->lin_is_est = false;
   resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
@@ -1972,7 +1976,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
     // the estimate is the logical `est` copy when the last trial is still pending (it is undone), else the logical `lin`
     // copy (linpoint_to_estimate, :466); `swap` says whether logical and physical copies are exchanged
     if (s.swap == s.trial_pending) swap_state(g);
-    g->dev_values_newer = true;
+    g->dev_values_newer = true; g->lin_is_est = false;
     g->stats.lm_iterations = s.num_iter; g->stats.chi2_final = s.error; g->stats.lambda_final = s.lambda; g->stats.last_delta_norm = s.dnorm;
     g->stats.lm_trials_notpd = s.n_notpd; g->stats.t_total = m->t_total;
     if (iterations) iterations[i] = s.num_iter;
@@ -2065,12 +2069,11 @@ int pps_save_state(pps_graph* g) {
   const DevGraph& d = g->dev;
   if (!g->snap_pose || g->snap_version != g->upload_version) {
     // (re)allocate with the current leading dimensions; owned by the allocation list of this upload
-    rc = dev_alloc(g, &g->snap_pose, (size_t)7 * d.pose_ld); if (rc != PPS_OK) return rc;
-    rc = dev_alloc(g, &g->snap_plane, (size_t)4 * d.plane_ld); if (rc != PPS_OK) return rc;
+    rc = dev_alloc(g, &g->snap_pose, (size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld); if (rc != PPS_OK) return rc;
+    g->snap_plane = g->snap_pose + (size_t)7 * d.pose_ld;
     g->snap_version = g->upload_version;
   }
-  HIP_TRY(g, hipMemcpyAsync(g->snap_pose, d.pose_est, (size_t)7 * d.pose_ld * 8, hipMemcpyDeviceToDevice, g->stream));
-  HIP_TRY(g, hipMemcpyAsync(g->snap_plane, d.plane_est, (size_t)4 * d.plane_ld * 8, hipMemcpyDeviceToDevice, g->stream));
+  HIP_TRY(g, hipMemcpyAsync(g->snap_pose, d.pose_est, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
   return PPS_OK;
 }
 
@@ -2079,9 +2082,9 @@ int pps_restore_state(pps_graph* g) {
   if (!g->snap_pose || g->snap_version != g->upload_version || g->topo_dirty) return fail(g, PPS_ESTATE, "no snapshot for the current topology");
   if (g->host_values_newer) return fail(g, PPS_ESTATE, "host values were modified after the snapshot");
   const DevGraph& d = g->dev;
-  HIP_TRY(g, hipMemcpyAsync(d.pose_est, g->snap_pose, (size_t)7 * d.pose_ld * 8, hipMemcpyDeviceToDevice, g->stream));
-  HIP_TRY(g, hipMemcpyAsync(d.plane_est, g->snap_plane, (size_t)4 * d.plane_ld * 8, hipMemcpyDeviceToDevice, g->stream));
-  g->dev_values_newer = true;
+  HIP_TRY(g, hipMemcpyAsync(d.pose_est, g->snap_pose, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
+  g->lin_is_est = false;
+  g->dev_values_newer = true; g->lin_is_est = false;
   return PPS_OK;
 }
 
