@@ -735,6 +735,7 @@ int upload_all(pps_graph* g) {
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
+  d.no_strip = getenv("PPS_NO_STRIP") ? 1 : 0;
   d.pose_ld = std::max(1, (d.n_pose + 63) / 64 * 64); d.plane_ld = std::max(1, (d.n_plane + 63) / 64 * 64);
 #define TRY(x) do { rc = (x); if (rc != PPS_OK) return rc; } while (0)
   // every copy of the state is one block [poses | planes]: one transfer moves it (copies rotate by pointer pairs, so a
@@ -1661,6 +1662,17 @@ static int lm_solve(pps_graph* g, int* iterations) {
     fprintf(stderr, "PPS_TRACE mean cycles per front: zero %.0f gather %.0f extend-add %.0f eliminate %.0f store %.0f\n",
             acc[0] / A.n_fronts, acc[1] / A.n_fronts, acc[2] / A.n_fronts, acc[3] / A.n_fronts, acc[4] / A.n_fronts);
     for (int l = 0; l < A.n_levels; l++) fprintf(stderr, "  level %d: %d fronts, mean total %.0f cycles\n", l, lvl_n[l], lvl_tot[l] / std::max(1, lvl_n[l]));
+    {
+      double w[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nw2 = 0;
+      for (int s2 = 0; s2 < A.n_fronts; s2++) {
+        if (A.f_p[s2] + A.f_b[s2] + 1 <= 64) continue;
+        nw2++;
+        for (int k = 0; k < 5; k++) w[k] += (double)(tr[(size_t)s2 * 8 + k + 1] - tr[(size_t)s2 * 8 + k]);
+        w[5] += (double)tr[(size_t)s2 * 8 + 6]; w[6] += (double)tr[(size_t)s2 * 8 + 7];
+      }
+      if (nw2) fprintf(stderr, "  fronts beyond 64 rows (%d): zero %.0f gather %.0f extend-add %.0f eliminate %.0f (panel %.0f trailing %.0f) store %.0f cycles\n", nw2,
+                       w[0] / nw2, w[1] / nw2, w[2] / nw2, w[3] / nw2, w[5] / nw2, w[6] / nw2, w[4] / nw2);
+    }
     long long tmin = tr[0], tmax = tr[5];
     for (int s2 = 0; s2 < A.n_fronts; s2++) { tmin = std::min(tmin, tr[(size_t)s2 * 8]); tmax = std::max(tmax, tr[(size_t)s2 * 8 + 5]); }
     fprintf(stderr, "  first start -> last end: %lld cycles\n", tmax - tmin);

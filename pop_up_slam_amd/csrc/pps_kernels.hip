@@ -1023,7 +1023,7 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
 int band_front_limit() { return kBandMaxRows - 1; }
 int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
-size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return (fa * (fa + 1) / 2 + 64 * 5) * sizeof(double); }   // packed triangle + panel buffer
+size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return (fa * (fa + 1) / 2 + kRegRowsMax * kPStride) * sizeof(double); }   // packed triangle + panel buffer
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 
@@ -1229,6 +1229,10 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   const int l16 = lane & 15, lq = lane >> 4;
   const int f = p + b, fa = f + 1;
   const int ntri = tri(fa);
+  // Fronts of 65 .. 80 rows (full kernel only): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary
+  // rows, the pivots are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried
+  // along panel by panel: triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
+  const bool strip = TR && fa > kRegRows;
   if (TR) PPS_TR(0);
   const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
@@ -1303,6 +1307,12 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       case 2: if (NT > 2) reg_extract_panel<(NT > 2 ? 2 : 1), NT>(c, P, c0, lane); break;
       default: if (NT > 3) reg_extract_panel<(NT > 3 ? 3 : NT - 1), NT>(c, P, c0, lane); break;
     }
+    const int row2 = kRegRows + (lane & 15);                   // the strip row of this lane (lanes 0 .. 15)
+    const bool has2 = TR && strip && lane < 16 && row2 < fa;
+    if (has2) {
+#pragma unroll
+      for (int m = 0; m < 4; m++) P[row2 * kPStride + m] = F[tri(row2) + K + m];   // (K + m < 64 <= row2: inside the row)
+    }
     __builtin_amdgcn_wave_barrier();
     // ---- panel: lane = row ----
     double r0 = P[lane * kPStride + 0], r1 = P[lane * kPStride + 1], r2 = P[lane * kPStride + 2], r3 = P[lane * kPStride + 3];
@@ -1335,7 +1345,58 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       if (nb > 2 && lane >= K + 2) lrow[2] = x2;
       if (nb > 3 && lane >= K + 3) lrow[3] = x3;
     }
+    if (TR && strip) {
+      const double q0 = P[row2 * kPStride + 0], q1 = P[row2 * kPStride + 1], q2 = P[row2 * kPStride + 2], q3 = P[row2 * kPStride + 3];
+      double y0, y1, y2, y3;
+      {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)
+#endif
+        y0 = q0 * i0;
+        y1 = (q1 - y0 * l10) * i1;
+        y2 = (q2 - y0 * l20 - y1 * l21) * i2;
+        y3 = (q3 - y0 * l30 - y1 * l31 - y2 * l32) * i3;
+      }
+      if (has2) {
+        P[row2 * kPStride + 0] = y0; P[row2 * kPStride + 1] = y1; P[row2 * kPStride + 2] = y2; P[row2 * kPStride + 3] = y3;
+        double* __restrict__ lrow = Lp + (size_t)row2 * p + K;
+        lrow[0] = y0;
+        if (nb > 1) lrow[1] = y1;
+        if (nb > 2) lrow[2] = y2;
+        if (nb > 3) lrow[3] = y3;
+      }
+    }
     __builtin_amdgcn_wave_barrier();
+    if (TR && strip) {
+      // F[r][c] -= sum_k L[r][k] L[c][k] for the strip rows r and the live columns c >= K + nb: the strip is tile row 4 of the
+      // front; its five 16x16 tiles are loaded from the LDS triangle, updated with one MFMA each and written back (only the
+      // entries that exist: c <= r < fa).  Tile columns left of the panel are finished and skipped.
+      const int cmin = K + nb;
+      const bool kvalid = lq < nb;
+      const double a4r = P[(kRegRows + l16) * kPStride + lq];
+      const double a4 = kvalid ? -a4r : 0.0;
+#pragma unroll 1                                    // one tile at a time: eight registers next to the ten resident tiles
+      for (int tj = cmin >> 4; tj < 5; tj++) {
+        const double br = P[(16 * tj + l16) * kPStride + lq];
+        const double bj = kvalid ? br : 0.0;
+        const int col = 16 * tj + l16;
+        double4_t t;
+        bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = kRegRows + lq + 4 * r;
+          ok[r] = row < fa && col <= row && col >= cmin;
+          const double x = F[ok[r] ? tri(row) + col : 0];
+          t[r] = ok[r] ? x : 0.0;
+        }
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, bj, t, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = kRegRows + lq + 4 * r;
+          if (ok[r]) F[tri(row) + col] = t[r];
+        }
+      }
+    }
     const long long tk1 = (TR && d.trace) ? clock64() : 0;
     switch (tjK) {
       case 0: reg_trailing<0, NT>(c, P, nb, lane, (K + 4) >> 4); break;
@@ -1359,6 +1420,10 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
         const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
         if (row < fa && col <= row && col >= p) Us[tri(row - p) + col - p] = c[tile_id(ti, tj)][r];
       }
+  if (TR && strip) {
+    for (int r = kRegRows; r < fa; r++)
+      for (int col = p + lane; col <= r; col += 64) Us[tri(r - p) + col - p] = F[tri(r) + col];
+  }
   if (TR) PPS_TR(5);
 }
 
@@ -1462,10 +1527,12 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      if (REG_ONLY && fa <= 32) wave_front_factor_reg<2, false>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
-      else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3, false>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
-      else if (REG_ONLY) wave_front_factor_reg<4, false>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
-      else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, F + lds_doubles_per_wave - kRegRows * kPStride);
+      double* const Pn = F + lds_doubles_per_wave - kRegRowsMax * kPStride;
+      if (REG_ONLY && fa <= 32) wave_front_factor_reg<2, false>(d, rec, lambda, F, Pn);
+      else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3, false>(d, rec, lambda, F, Pn);
+      else if (REG_ONLY) wave_front_factor_reg<4, false>(d, rec, lambda, F, Pn);
+      else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);   // 65 .. 80 rows: register tiles + LDS strip
+      else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);
       else wave_front_factor(d, s, lambda, F);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)

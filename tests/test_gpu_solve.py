@@ -221,10 +221,10 @@ def test_c4_survey_seeds_against_the_oracle(built):
 
 @pytest.mark.parametrize("mk", [lambda: synth.corridor(600, 100, obs_per_pose=8, seed=5), lambda: synth.corridor(400, 40, obs_per_pose=10, seed=5)],
                          ids=["600p-8obs", "400p-10obs"])
-def test_fronts_of_65_to_80_rows(built, mk):
+def test_fronts_of_65_to_80_rows(built, mk, monkeypatch):
     """Walls observed from many poses give separators beyond the 64 rows of the register-resident fronts (the aligned-cut trees
-    of frame loops do the same): such a stage runs the full band kernel, where those fronts take the LDS-tile path next to
-    register-resident neighbours.  Against the oracle trial for trial."""
+    of frame loops do the same): their first 64 rows are register tiles as usual, rows 64 .. 79 ride along as a strip of the LDS
+    triangle.  Against the oracle trial for trial, and against the LDS-tile path of the same fronts (PPS_NO_STRIP=1)."""
     spec = mk()
     g, o, *_ = _pair(spec)
     g.analyze()
@@ -237,6 +237,12 @@ def test_fronts_of_65_to_80_rows(built, mk):
     tr, tro = g.trace(), o.trace()
     assert [a for _, _, a in tr] == [a for _, _, a in tro]
     np.testing.assert_allclose([x for _, x, _ in tr], [x for _, x, _ in tro], rtol=1e-6)
+    monkeypatch.setenv("PPS_NO_STRIP", "1")
+    h = P.Graph(); spec.replay(h)
+    ith = h.batch_optimize()
+    assert ith == it and abs(h.chi2() - c) <= 1e-9 * abs(c)
+    np.testing.assert_allclose([x for _, x, _ in h.trace()], [x for _, x, _ in tr], rtol=1e-8)
+    h.close()
 
 
 def test_mid_and_large_graphs(built):
