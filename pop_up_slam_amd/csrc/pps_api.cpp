@@ -1697,7 +1697,8 @@ struct pps_multi {
   hipStream_t stream = nullptr;
   DevGraph* d_gs = nullptr; size_t cap_gs = 0;
   BatchStage* d_stage = nullptr; size_t cap_stage = 0;
-  double* results = nullptr;      // pinned: 8 doubles per graph
+  BatchAlt* d_alt = nullptr; size_t cap_alt = 0;          // dual-lambda form: second factorisation + the three state copies per graph
+  double* results = nullptr; size_t cap_results = 0;      // pinned: 12 doubles per graph (8 used by the single-lambda form)
   double seq = 0.0;
   int rounds = 0; double t_total = 0;
   // profiling (pps_multi_set_profiling): HIP events at the phase boundaries of every round, resolved after the solve
@@ -1735,6 +1736,7 @@ int pps_multi_destroy(pps_multi* m) {
   for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);
   if (m->d_gs) (void)hipFree(m->d_gs);
   if (m->d_stage) (void)hipFree(m->d_stage);
+  if (m->d_alt) (void)hipFree(m->d_alt);
   if (m->results) (void)hipHostFree(m->results);
   delete m;
   return PPS_OK;
@@ -1763,9 +1765,18 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
     if (g->stream_b) MHIP(m, hipStreamSynchronize(g->stream_b));
     max_stages = std::max(max_stages, g->an.n_stages);
   }
+  // both damping values of a linearisation in the same launches (lm_solve_dual's scheme), when every handle has its second
+  // factor / state set
+  bool dual = !getenv("PPS_MULTI_NO_DUAL");
+  for (int i = 0; i < G && dual; i++) dual = m->gs[i]->spec_L && m->gs[i]->spec_U && m->gs[i]->spec_delta && m->gs[i]->spec_pose && m->gs[i]->spec_result;
   if (!m->stream) MHIP(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-  if (!m->results) MHIP(m, hipHostMalloc(reinterpret_cast<void**>(&m->results), sizeof(double) * 8 * (size_t)G, hipHostMallocDefault));
-  memset(m->results, 0, sizeof(double) * 8 * (size_t)G);
+  if (m->cap_results < (size_t)G) {
+    if (m->results) (void)hipHostFree(m->results);
+    m->results = nullptr; m->cap_results = 0;
+    MHIP(m, hipHostMalloc(reinterpret_cast<void**>(&m->results), sizeof(double) * 12 * (size_t)G, hipHostMallocDefault));
+    m->cap_results = G;
+  }
+  memset(m->results, 0, sizeof(double) * 12 * (size_t)G);
   // ---- device tables: the graphs' records and their band schedules ----
   std::vector<DevGraph> hg(G);
   std::vector<BatchStage> hs((size_t)std::max(1, max_stages) * G, BatchStage{0, 0});
@@ -1831,7 +1842,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
       long long total_groups = 0;
       for (int i = c * kBatchMax; i < std::min(G, (c + 1) * kBatchMax); i++) {
         const Analysis& A = m->gs[i]->an;
-        if (stg < A.n_stages) total_groups += A.stage_grp_off[stg + 1] - A.stage_grp_off[stg];
+        if (stg < A.n_stages) total_groups += (dual ? 2 : 1) * (A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
       }
       if (!getenv("PPS_MULTI_WIDE") && total_groups > 0) {
         const long long slots_f = (long long)n_cu * std::max<size_t>(1, lds_budget / fw);
@@ -1840,6 +1851,186 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
         q.stage_nw_solve[stg] = (int)std::max<long long>(1, std::min<long long>(q.stage_nw_solve[stg], (slots_s + total_groups - 1) / total_groups));
       }
     }
+  }
+  // ---- dual-lambda form: every graph walks lm_solve_dual's scheme, in lockstep rounds of one linearisation each ----
+  if (dual) {
+    std::vector<BatchAlt> ha(G);
+    for (int i = 0; i < G; i++) {
+      pps_graph* g = m->gs[i];
+      ha[i] = BatchAlt{g->spec_L, g->spec_U, g->spec_delta, g->spec_result, g->spec_chi2_partials, g->spec_dn_partials, g->spec_ticket,
+                       {g->dev.pose_est, g->dev.pose_lin, g->spec_pose}, {g->dev.plane_est, g->dev.plane_lin, g->spec_plane}};
+    }
+    if (m->cap_alt < (size_t)G) { if (m->d_alt) (void)hipFree(m->d_alt); m->d_alt = nullptr; MHIP(m, hipMalloc(reinterpret_cast<void**>(&m->d_alt), sizeof(BatchAlt) * (size_t)G)); m->cap_alt = G; }
+    MHIP(m, hipMemcpy(m->d_alt, ha.data(), sizeof(BatchAlt) * (size_t)G, hipMemcpyHostToDevice));
+    struct LMD { double lambda, error, dnorm; int num_iter, cur, xsel; bool done, have_next, relin, active, last_notpd, trial_taken; int n_notpd; };
+    std::vector<LMD> lm(G);
+    for (int i = 0; i < G; i++) lm[i] = LMD{m->gs[i]->props.lm_lambda0, 0.0, 0.0, 0, 0, 0, false, true, true, true, false, false, 0};
+    auto make_args = [&](int c) {
+      BatchArgs a{};
+      a.gs = m->d_gs; a.stage_tab = m->d_stage; a.results = m->results; a.n_total = G; a.b0 = c * kBatchMax;
+      a.n = std::min(G, (c + 1) * kBatchMax) - a.b0; a.seq = m->seq;
+      a.alt = m->d_alt; a.rstride = 12;
+      for (int k = 0; k < a.n; k++) {
+        const LMD& q = lm[a.b0 + k];
+        a.lambda[k] = q.lambda; a.lambda2[k] = q.lambda * m->gs[a.b0 + k]->props.lm_lambda_factor;
+        a.xsel[k] = (unsigned char)q.xsel;
+        a.flags[k] = (unsigned char)((q.active ? BF_ACTIVE : 0) | (q.relin ? BF_RELIN : 0));
+      }
+      return a;
+    };
+    auto wait_round = [&]() -> int {
+      const double tw = now_s();
+      unsigned spins = 0;
+      for (int i = 0; i < G; i++) {
+        if (!lm[i].active) continue;
+        for (int slot = 1; slot <= 2; slot++) {
+          volatile double* r = m->results + 12 * (size_t)i + 4 * slot;
+          while (r[3] != m->seq) {
+            if ((++spins & 0x3ff) == 0 && now_s() - tw > 2.0) {
+              MHIP(m, hipStreamSynchronize(m->stream));
+              if (r[3] != m->seq) return mfail(m, PPS_EHIP, "result record of graph " + std::to_string(i) + " did not arrive");
+            }
+          }
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return PPS_OK;
+    };
+    m->ev_used = 0; m->n_relin = 0; m->n_solves = 0;
+    for (double& t : m->t_phase) t = 0;
+    auto mark = [&]() {
+      if (!m->profiling) return;
+      if (m->ev_used == m->evs.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; m->evs.push_back(e); }
+      (void)hipEventRecord(m->evs[m->ev_used++], m->stream);
+    };
+    auto next_event = [&]() -> hipEvent_t {
+      if (!m->profiling) return nullptr;
+      if (m->ev_used == m->evs.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; m->evs.push_back(e); }
+      return m->evs[m->ev_used++];
+    };
+    // one round of one chunk: e0 | K1 | e1 | K2 (+ chi2 at x) | e2 | factor x 2 | e3 | solve x 2 | e4 | both trials | e5
+    auto run_round = [&](const BatchArgs& a, const BatchGeom& q, bool first, bool any_relin) -> int {
+      if (first) MHIP(m, launch_batch_begin_dual(a, q, m->stream));
+      mark();
+      if (any_relin) MHIP(m, launch_batch_linearize(a, q, q.lin_thread_form ? mode | 2 : mode, m->stream));
+      mark();
+      if (any_relin) MHIP(m, launch_batch_hblocks(a, q, m->stream));
+      if (first) MHIP(m, launch_batch_chi2(a, q, 0, m->stream));
+      mark();
+      hipEvent_t ef = next_event();
+      MHIP(m, launch_batch_solve(a, q, m->stream, ef));
+      mark();
+      MHIP(m, launch_batch_trial_dual(a, q, m->stream));
+      mark();
+      return PPS_OK;
+    };
+    // the part of lm_solve_dual's loop that needs no launch: consume the verdicts that are on the host.  Returns with the
+    // graph done, or active (and possibly relin) for the next round.
+    auto advance = [&](int i) {
+      LMD& q = lm[i];
+      pps_graph* g = m->gs[i];
+      const pps_props& prop = g->props;
+      q.active = false; q.relin = false;
+      for (;;) {
+        if (!((prop.max_iterations <= 0 || q.num_iter < prop.max_iterations) && q.dnorm > prop.epsilon2 && q.error > prop.epsilon_abs)) { q.done = true; return; }
+        q.num_iter++;
+        const double* rec = m->results + 12 * (size_t)i + 4 * (1 + q.cur);
+        const double error_new = rec[0];
+        const double error_diff = q.error - error_new;
+        const bool accepted = error_diff > 0.;
+        g->tr_lambda.push_back(q.lambda); g->tr_chi2.push_back(error_new); g->tr_acc.push_back(accepted ? 1 : 0);
+        if (accepted) {
+          g->stats.lm_trials_accepted++;
+          if (error_diff < prop.epsilon_rel * q.error) { q.error = error_new; q.trial_taken = true; q.done = true; return; }   // (:431-434)
+          q.lambda /= prop.lm_lambda_factor;
+          q.error = error_new;
+          q.xsel = (q.xsel + 1 + q.cur) % 3;                           // the accepted copy is the linearisation point now
+          q.relin = true; q.active = true; q.cur = 0; q.have_next = true;
+          g->stats.n_linearize++; g->stats.n_factorize += 2;
+          return;
+        }
+        g->stats.lm_trials_rejected++;
+        q.lambda *= prop.lm_lambda_factor;
+        if (q.have_next) {                                             // the step for this lambda was computed alongside
+          q.cur = 1; q.have_next = false;
+          const double* rb = m->results + 12 * (size_t)i + 8;
+          q.dnorm = std::sqrt(rb[1]); q.last_notpd = rb[2] != 0.0; q.n_notpd += q.last_notpd ? 1 : 0;
+          continue;
+        }
+        q.active = true; q.cur = 0; q.have_next = true;               // both rejected: same J and H, two more damping values
+        g->stats.n_factorize += 2;
+        return;
+      }
+    };
+    m->seq += 1.0; m->rounds = 0;
+    for (int c = 0; c < n_chunks; c++) {
+      const BatchArgs a = make_args(c);
+      int rc = run_round(a, geom[c], true, true); if (rc != PPS_OK) return rc;
+    }
+    m->n_relin += G; m->n_solves += 2 * (long long)G;
+    { int rc = wait_round(); if (rc != PPS_OK) return rc; }
+    m->rounds++;
+    for (int i = 0; i < G; i++) {
+      pps_graph* g = m->gs[i];
+      const double* r0 = m->results + 12 * (size_t)i;
+      lm[i].error = r0[0]; g->stats.chi2_initial = r0[0];
+      lm[i].dnorm = std::sqrt(r0[5]); lm[i].last_notpd = r0[6] != 0.0; lm[i].n_notpd = lm[i].last_notpd ? 1 : 0;
+      g->stats.n_linearize = 1; g->stats.n_factorize = 2;
+    }
+    for (;;) {
+      int n_active = 0;
+      for (int i = 0; i < G; i++) { if (!lm[i].done) advance(i); else { lm[i].active = false; lm[i].relin = false; } n_active += lm[i].active ? 1 : 0; }
+      if (n_active == 0) break;
+      m->seq += 1.0;
+      for (int c = 0; c < n_chunks; c++) {
+        const BatchArgs a = make_args(c);
+        bool any = false, any_relin = false;
+        for (int k = 0; k < a.n; k++) { any = any || (a.flags[k] & BF_ACTIVE); any_relin = any_relin || (a.flags[k] & BF_RELIN); }
+        if (!any) continue;
+        for (int k = 0; k < a.n; k++) { m->n_solves += (a.flags[k] & BF_ACTIVE) ? 2 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
+        int rc = run_round(a, geom[c], false, any_relin); if (rc != PPS_OK) return rc;
+      }
+      { int rc = wait_round(); if (rc != PPS_OK) return rc; }
+      m->rounds++;
+      for (int i = 0; i < G; i++) {
+        if (!lm[i].active) continue;
+        const double* r1 = m->results + 12 * (size_t)i + 4;
+        lm[i].dnorm = std::sqrt(r1[1]);
+        lm[i].last_notpd = r1[2] != 0.0;
+        lm[i].n_notpd += lm[i].last_notpd ? 1 : 0;
+      }
+    }
+    MHIP(m, hipStreamSynchronize(m->stream));
+    for (size_t k = 0; k + 6 <= m->ev_used; k += 6) {
+      const hipEvent_t* e = &m->evs[k];
+      for (int ph = 0; ph < 5; ph++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e[ph], e[ph + 1]) == hipSuccess) m->t_phase[ph] += 1e-3 * ms;
+      }
+    }
+    int first_bad = PPS_OK;
+    m->t_total = now_s() - t0;
+    for (int i = 0; i < G; i++) {
+      pps_graph* g = m->gs[i];
+      const LMD& q = lm[i];
+      // linpoint_to_estimate (:466): the accepted, converged trial -- or the linearisation point when the pending step is dropped
+      const int fin = q.trial_taken ? (q.xsel + 1 + q.cur) % 3 : q.xsel;
+      double* const sp[3] = {ha[i].pose[0], ha[i].pose[1], ha[i].pose[2]};
+      double* const sl[3] = {ha[i].plane[0], ha[i].plane[1], ha[i].plane[2]};
+      g->dev.pose_est = sp[fin]; g->dev.plane_est = sl[fin];
+      g->dev.pose_lin = sp[(fin + 1) % 3]; g->dev.plane_lin = sl[(fin + 1) % 3];
+      g->spec_pose = sp[(fin + 2) % 3]; g->spec_plane = sl[(fin + 2) % 3];
+      g->dev_values_newer = true; g->lin_is_est = false;
+      g->stats.lm_iterations = q.num_iter; g->stats.chi2_final = q.error; g->stats.lambda_final = q.lambda; g->stats.last_delta_norm = q.dnorm;
+      g->stats.lm_trials_notpd = q.n_notpd; g->stats.t_total = m->t_total;
+      if (iterations) iterations[i] = q.num_iter;
+      const int st_i = q.last_notpd ? PPS_ENOTPD : PPS_OK;
+      if (st_i != PPS_OK) g->err = "normal equations not positive definite at the last LM trial";
+      if (status) status[i] = st_i;
+      if (st_i != PPS_OK && first_bad == PPS_OK) first_bad = st_i;
+    }
+    if (first_bad != PPS_OK) return mfail(m, first_bad, "at least one graph ended on a factorisation that was not positive definite (see status[])");
+    return PPS_OK;
   }
   // ---- LM state per graph ----
   struct LM { double lambda, error, dnorm; int num_iter; bool done, swap, trial_pending, relin, active, last_notpd; int n_notpd; };

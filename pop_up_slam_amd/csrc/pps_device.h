@@ -165,6 +165,15 @@ enum { BF_ACTIVE = 1,      // the graph takes part in this round
        BF_RELIN = 2,       // ... and is re-linearised first (its last trial was accepted)
        BF_SWAP = 4 };      // est / lin exchanged (an odd number of rejections since the pointers were last in order)
 struct BatchStage { int grp_begin, grp_count; };
+// Dual-lambda form of a batch (the lm_solve_dual scheme per graph): what the second factorisation of a graph writes, and the
+// three copies of its state.  x = state[xsel] is the linearisation point, state[(xsel + 1) % 3] / [(xsel + 2) % 3] receive
+// x (+) delta for lambda / lambda2; an accepted trial only changes xsel.
+struct BatchAlt {
+  double *L, *U, *delta, *result_dev, *chi2_partials, *dn_partials;
+  unsigned int* ticket;
+  double* pose[3];
+  double* plane[3];
+};
 struct BatchArgs {
   const DevGraph* gs;          // [n_total]
   const BatchStage* stage_tab; // [n_stages_max][n_total]
@@ -174,6 +183,12 @@ struct BatchArgs {
   double seq;
   double lambda[kBatchMax];
   unsigned char flags[kBatchMax];
+  // dual form (alt != nullptr): grid z = 0 / 1 of the solve and trial kernels = lambda / lambda2, 12 result doubles per graph
+  // ([0..3] chi2 at x, [4..7] trial for lambda, [8..11] trial for lambda2)
+  const BatchAlt* alt;
+  int rstride, pad2;
+  double lambda2[kBatchMax];
+  unsigned char xsel[kBatchMax];
 };
 // grid extents (maxima over the graphs of the chunk) and LDS needs of one round
 struct BatchGeom {
@@ -193,6 +208,8 @@ hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStrea
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st);        // chi2 at lin -> results[8 b + 4 slot]
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor = nullptr);   // K3, lambda per graph
 hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // est <- lin, lin <- lin (+) delta, chi2 -> slot 1
+hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // not-PD flags of both factorisations cleared
+hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // state[..] <- x (+) delta_z, chi2 -> slots 1 / 2
 
 // patch upload: table of (dst offset, src offset, bytes [multiple of 16], -) int64 quadruples at the head of `patch`
 hipError_t launch_scatter_patches(const char* patch, int n_patches, char* arena, hipStream_t st);

@@ -1950,16 +1950,32 @@ __device__ __forceinline__ DevGraph load_graph(const DevGraph* gp) {
   return d;
 }
 
+__device__ __forceinline__ BatchAlt load_alt(const BatchAlt* ap) {
+  BatchAlt t = *(const BatchAlt*)((const BatchAlt __attribute__((address_space(4)))*)ap);
+  t.L = gptr(t.L); t.U = gptr(t.U); t.delta = gptr(t.delta); t.result_dev = gptr(t.result_dev);
+  t.chi2_partials = gptr(t.chi2_partials); t.dn_partials = gptr(t.dn_partials); t.ticket = gptr(t.ticket);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { t.pose[k] = gptr(t.pose[k]); t.plane[k] = gptr(t.plane[k]); }
+  return t;
+}
+__device__ __forceinline__ double* sel3(double* const (&p)[3], int k) { return k == 0 ? p[0] : (k == 1 ? p[1] : p[2]); }
+
+// single-lambda form: est / lin exchanged by BF_SWAP.  Dual form (a.alt): the linearisation point is state[xsel] -- it takes the
+// place of `lin` for K1 and chi2 -- and nothing is ever written over it.
 #define PPS_BATCH_PROLOGUE(NEED)                                                                             \
   const int b = blockIdx.y;                                                                                  \
   const unsigned int fl = a.flags[b];                                                                        \
   if ((fl & (NEED)) != (NEED)) return;                                                                       \
   const DevGraph d = load_graph(a.gs + a.b0 + b);                                                            \
   const bool swp = (fl & BF_SWAP) != 0;                                                                      \
-  double* const pose_lin = swp ? d.pose_est : d.pose_lin;                                                    \
-  double* const pose_est = swp ? d.pose_lin : d.pose_est;                                                    \
-  double* const plane_lin = swp ? d.plane_est : d.plane_lin;                                                 \
-  double* const plane_est = swp ? d.plane_lin : d.plane_est;                                                 \
+  double* pose_lin = swp ? d.pose_est : d.pose_lin;                                                          \
+  double* pose_est = swp ? d.pose_lin : d.pose_est;                                                          \
+  double* plane_lin = swp ? d.plane_est : d.plane_lin;                                                       \
+  double* plane_est = swp ? d.plane_lin : d.plane_est;                                                       \
+  if (a.alt) {                                                                                               \
+    const BatchAlt al_ = load_alt(a.alt + a.b0 + b);                                                         \
+    pose_lin = sel3(al_.pose, a.xsel[b]); plane_lin = sel3(al_.plane, a.xsel[b]);                            \
+  }                                                                                                          \
   (void)pose_lin; (void)pose_est; (void)plane_lin; (void)plane_est;
 
 __device__ __forceinline__ int dcdiv(int a, int b) { return (a + b - 1) / b; }
@@ -2023,6 +2039,13 @@ __global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, in
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
   if ((int)blockIdx.x >= sg.grp_count) return;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
+    body_band_factor<REG_ONLY>(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, 0, lds);
+    return;
+  }
   body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, 0, lds);
 }
 
@@ -2031,6 +2054,13 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
   if ((int)blockIdx.x >= sg.grp_count) return;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
+    body_band_solve(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+    return;
+  }
   body_band_solve(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
@@ -2047,8 +2077,8 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2(BatchArgs a, int slot) {
             nb_lp = dcdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if ((int)blockIdx.x >= nb) return;
-  body_chi2(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256), a.results + 8 * (size_t)(a.b0 + b) + 4 * slot,
-            a.seq, blockIdx.x, nb);
+  body_chi2(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+            a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot, a.seq, blockIdx.x, nb);
 }
 
 hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
@@ -2109,16 +2139,16 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
     const size_t bytes = (size_t)per_wave * nw * sizeof(double);
     if (g.stage_reg_only[stg])
-      PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+      PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else
-      PPS_LAUNCH(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+      PPS_LAUNCH(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
   }
   if (after_factor) (void)hipEventRecord(after_factor, st);
   for (int stg = g.n_stages - 1; stg >= 0; stg--) {
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_solve[stg], nw = g.stage_nw_solve[stg];
     const size_t bytes = ((size_t)per_wave * nw + (size_t)g.stage_grp_fronts[stg] * kBandMaxRows) * sizeof(double);
-    PPS_LAUNCH(kb_band_solve, dim3(g.stage_groups[stg], a.n), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    PPS_LAUNCH(kb_band_solve, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
   }
   return hipGetLastError();
 }
@@ -2126,6 +2156,84 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
 hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
   if (g.retract > 0) PPS_LAUNCH(kb_retract_trial, dim3(g.retract, a.n), dim3(256), 0, st, a);
   return launch_batch_chi2(a, g, 1, st);
+}
+
+// ---- dual-lambda batch (BatchAlt): both trials of a graph in one launch, grid z = 0 / 1 ----
+__global__ __launch_bounds__(64) void kb_begin_dual(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchAlt al = load_alt(a.alt + a.b0 + b);
+  if (threadIdx.x < 4) { d.result_dev[threadIdx.x] = 0.0; al.result_dev[threadIdx.x] = 0.0; }
+}
+
+__device__ __forceinline__ void body_retract_to(const DevGraph& d, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
+                                                double* __restrict__ out_pose, double* __restrict__ out_plane, int bx, double* red) {
+  const int i = bx * blockDim.x + threadIdx.x;
+  double dn = 0.0;
+  if (i < d.n_pose) {
+    double p[7], o[7], dl[6];
+    load_pose(base_pose, d.pose_ld, i, p);
+    const int off = d.pose_voff[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    pose_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 7; k++) out_pose[(size_t)k * d.pose_ld + i] = o[k];
+  } else if (i < d.n_pose + d.n_plane) {
+    const int l = i - d.n_pose;
+    double p[4], o[4], dl[3];
+    load_plane(base_plane, d.plane_ld, l, p);
+    const int off = d.plane_voff[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    plane_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out_plane[(size_t)k * d.plane_ld + l] = o[k];
+  }
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
+  __syncthreads();
+  if (threadIdx.x == 0) d.dn_partials[bx] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void kb_retract_dual(BatchArgs a) {
+  __shared__ double red[4];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  if ((int)blockIdx.x * 256 >= d.n_pose + d.n_plane) return;
+  const BatchAlt al = load_alt(a.alt + a.b0 + b);
+  const int xs = a.xsel[b], z = blockIdx.z;
+  const int ts = (xs + 1 + z) % 3;
+  DevGraph d2 = d;
+  if (z) { d2.delta = al.delta; d2.dn_partials = al.dn_partials; }
+  body_retract_to(d2, pose_lin, plane_lin, sel3(al.pose, ts), sel3(al.plane, ts), blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(kChiBlock) void kb_chi2_dual(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const int nb_obs = dcdiv(d.n_obs, kChiBlock), nb_odo = dcdiv(d.n_odo, kChiBlock), nb_pp = dcdiv(d.n_pp, kChiBlock),
+            nb_lp = dcdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if ((int)blockIdx.x >= nb) return;
+  const BatchAlt al = load_alt(a.alt + a.b0 + b);
+  const int xs = a.xsel[b], z = blockIdx.z;
+  const int ts = (xs + 1 + z) % 3;
+  DevGraph d2 = d;
+  if (z) { d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.ticket = al.ticket; d2.result_dev = al.result_dev; }
+  body_chi2(d2, sel3(al.pose, ts), sel3(al.plane, ts), nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+            a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
+}
+
+hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  (void)g;
+  PPS_LAUNCH(kb_begin_dual, dim3(1, a.n), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  if (g.chi2 <= 0) return hipErrorInvalidValue;
+  if (g.retract > 0) PPS_LAUNCH(kb_retract_dual, dim3(g.retract, a.n, 2), dim3(256), 0, st, a);
+  PPS_LAUNCH(kb_chi2_dual, dim3(g.chi2, a.n, 2), dim3(kChiBlock), 0, st, a);
+  return hipGetLastError();
 }
 
 // patch upload of a re-uploaded topology (pps_api.cpp: flush_uploads): piece i of the patch buffer -> its place in the arena

@@ -39,7 +39,9 @@ def test_mixed_batch_is_bit_identical_to_single_handles(built, mode):
     m = P.Multi(batch)
     its, st = m.optimize()
     assert np.all(st == 0)
-    assert m.rounds() in (max(r[0] for r in ref), max(r[0] for r in ref) + 1)   # the longest LM run (+ its pending trial)
+    # a round holds one linearisation's two damping values: at most one round per LM trial of the longest run (+ its pending
+    # trial), about half as many in LM's accept / reject zig-zag
+    assert 1 <= m.rounds() <= max(r[0] for r in ref) + 1
     for k, (g, sp, nid) in enumerate(zip(batch, specs, bnids)):
         it, tr, c, (poses, planes) = ref[k]
         assert its[k] == it and g.trace() == tr, k
