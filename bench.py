@@ -204,6 +204,9 @@ def main():
                     help="Jacobian mode of the sweep (numeric = reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-5 frame loop (1000 frames, ~2 s)")
+    ap.add_argument("--no-concurrent", action="store_true",
+                    help="skip the 8-host-thread section (rocprofv3 --kernel-trace of ROCm 7.2 crashes inside hipLaunchKernel when several "
+                         "host threads launch at once; the profile in profiles/ is taken with this flag)")
     ap.add_argument("--batched-replicas", type=int, default=0, help="0 = auto (> 256 MB per sweep)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="CI only: gloo backend, no GPU work -- exercises the rank/seed/aggregation plumbing of the N>1 path")
@@ -389,7 +392,7 @@ def main():
             # + one host thread each, no shared state) overlap.  Reported next to the headline, which stays the
             # one-graph-per-GPU configuration BASELINE.json names.
             import threading
-            n_h = 8
+            n_h = 0 if args.no_concurrent else 8
             hs = []
             for k in range(n_h):
                 gk = P.Graph(device=local_rank, jacobian_mode=mode)
