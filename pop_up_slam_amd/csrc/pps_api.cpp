@@ -280,7 +280,7 @@ int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows,
   pps_graph::Arena& a = g->up;
   const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(T);
   const size_t k = g->up_cursor++;
-  size_t o = 0;
+  size_t o = 0, fresh_cap = 0;
   bool placed = false;
   if (a.base && g->stage) {
     if (k < g->up_slots.size() && bytes <= g->up_slots[k].cap) { o = g->up_slots[k].off; placed = true; }
@@ -291,6 +291,7 @@ int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows,
         if (k < g->up_slots.size()) g->up_slots[k] = pps_graph::UpSlot{o, cap}; else g->up_slots.push_back(pps_graph::UpSlot{o, cap});
         g->up_high = o + cap;
         placed = true;
+        fresh_cap = cap;
       }
     }
   }
@@ -306,6 +307,17 @@ int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows,
   }
   *out = reinterpret_cast<T*>(a.base + o);
   a.off = std::max(a.off, o + bytes);
+  if (fresh_cap) {
+    // A slot that has just been created (or moved behind the others because it outgrew its place) lies in a part of the arena
+    // the mirror says nothing about: neither side has ever been written there, and a diff against it may find the new bytes
+    // "already there" (zeros against a fresh pinned page, say) and leave the device with whatever it held.  Define the whole
+    // slot -- capacity, not just what is used today: later uploads grow into it -- and send it once.
+    memset(g->stage + o, 0, fresh_cap);
+    if (!v.empty()) memcpy(g->stage + o, v.data(), v.size() * sizeof(T));
+    g->up_bytes_total += fresh_cap;
+    g->up_patches.push_back(pps_graph::UpPatch{o, fresh_cap});
+    return PPS_OK;
+  }
   if (v.empty()) return PPS_OK;
   const char* src = reinterpret_cast<const char*>(v.data());
   if (rows == 0 || g->up_unknown) { up_diff(g, o, src, v.size() * sizeof(T), force); return PPS_OK; }
@@ -315,6 +327,8 @@ int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows,
 
 // send what differs: everything in one copy when the device content is unknown or most of it changed, else the patches
 int flush_uploads(pps_graph* g) {
+  // callers: upload_all (after its opening stream sync) and the frame tables of pps_refresh_measurements (which settles
+  // up_inflight first) -- the pinned mirror and the patch buffer are never rewritten under a copy that still reads them
   size_t sent = 0;
   for (const auto& pt : g->up_patches) sent += pt.len;
   g->up_bytes_sent = sent;
@@ -359,6 +373,27 @@ int flush_uploads(pps_graph* g) {
   g->up_unknown = false;
   g->up_patches.clear();
   g->stage_lo = g->stage_hi = 0;
+  return PPS_OK;
+}
+
+// PPS_DEBUG_VERIFY_UPLOAD=1: after a flush, the arena on the device must equal the pinned mirror (except the observation
+// measurements, which kernels refresh behind the mirror's back) -- PPS_ESTATE if not.  tests/test_gpu_pipeline.py runs a frame
+// loop under it.
+int verify_uploads(pps_graph* g, const char* where) {
+  if (!getenv("PPS_DEBUG_VERIFY_UPLOAD") || g->up_high == 0 || g->up.spill) return PPS_OK;
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  std::vector<char> dev(g->up_high);
+  HIP_TRY(g, hipMemcpy(dev.data(), g->up.base, g->up_high, hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < g->up_slots.size() && k < g->up_cursor; k++) {
+    if (k == g->slot_obs_meas) continue;
+    const size_t o = g->up_slots[k].off, n = std::min(g->up_slots[k].cap, g->up_high - std::min(g->up_high, o));
+    if (o >= g->up_high) continue;
+    if (memcmp(dev.data() + o, g->stage + o, n) != 0) {
+      size_t b = 0; while (b < n && dev[o + b] == g->stage[o + b]) b++;
+      return fail(g, PPS_ESTATE, std::string("upload verification (") + where + "): slot " + std::to_string(k) + " (offset " + std::to_string(o) + ", capacity " +
+                                     std::to_string(g->up_slots[k].cap) + ") differs from the mirror at byte " + std::to_string(b));
+    }
+  }
   return PPS_OK;
 }
 
@@ -900,6 +935,7 @@ int upload_all(pps_graph* g) {
 #undef TRY
   lap("5 index arrays + diff");
   rc = flush_uploads(g); if (rc != PPS_OK) return rc;
+  rc = verify_uploads(g, "upload_all"); if (rc != PPS_OK) return rc;
   lap("6 flush");
   if (A.ea_total > 0) HIP_TRY(g, launch_expand_ea(d, A.n_fronts, g->stream));
   HIP_TRY(g, hipMemsetAsync(d.blk_dst, 0xff, sizeof(int) * (size_t)std::max(1, A.blk_doff[A.n_blocks]), g->stream));
@@ -2502,7 +2538,9 @@ int pps_refresh_measurements(pps_graph* g) {
       if (slot[i] >= 0 && g->nodes[g->fr_pose[g->fr_item_frame[i]]].deleted) slot[i] = -1;
     }
     for (size_t f = 0; f < pslot.size(); f++) pslot[f] = g->nodes[g->fr_pose[f]].deleted ? 0 : g->nodes[g->fr_pose[f]].slot;
-    // tables live in the allocation list of the current upload; older copies are simply abandoned until then
+    // tables live in the allocation list of the current upload; older copies are simply abandoned until then.  (The topology
+    // upload may still be copying out of the pinned mirror and the patch buffer this is about to write.)
+    if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }
     rc = dev_upload(g, &g->d_item_frame, g->fr_item_frame); if (rc != PPS_OK) return rc;
     rc = dev_upload(g, &g->d_item_plane, g->fr_item_plane); if (rc != PPS_OK) return rc;
     rc = dev_upload(g, &g->d_item_slot, slot); if (rc != PPS_OK) return rc;
@@ -2510,6 +2548,8 @@ int pps_refresh_measurements(pps_graph* g) {
     rc = dev_upload(g, &g->d_frame_seg_off, g->fr_seg_off); if (rc != PPS_OK) return rc;
     rc = dev_upload(g, &g->d_fr_seg, g->fr_seg); if (rc != PPS_OK) return rc;
     rc = flush_uploads(g); if (rc != PPS_OK) return rc;
+    rc = verify_uploads(g, "frames"); if (rc != PPS_OK) return rc;
+    g->up_inflight = true;                                  // (whoever writes the mirror next waits for this copy)
     g->frames_dirty = false;
   }
   RefreshArgs a{};

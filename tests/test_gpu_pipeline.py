@@ -89,3 +89,16 @@ def test_config5_at_size_1000_frames(built, tmp_path):
           "%d points popped up" % (n, wall, n / wall, lm_calls, g.chi2(), rms, stats["points"]))
     assert rms < 1.0                                   # dead reckoning alone drifts further; the wall landmarks hold the lateral error
     assert stats["points"] > n * 20000
+
+
+def test_difference_uploads_leave_the_device_equal_to_the_mirror(built, monkeypatch):
+    """Frame loops upload only what changed against a pinned mirror of the upload arena (patch buffer + scatter kernel).  With
+    PPS_DEBUG_VERIFY_UPLOAD=1 the library reads the arena back after every flush and fails the call if a byte differs -- in
+    particular in slots that were created or moved since the last upload, where the mirror used to say nothing about the device."""
+    monkeypatch.setenv("PPS_DEBUG_VERIFY_UPLOAD", "1")
+    frames = pipeline.popup_sequence(150, seed=11)
+    for repop in (False, True):
+        pl, g, pp, stats = pipeline.gpu_pipeline(step=2, repop=repop)
+        for fr in frames:
+            pl.process(fr)
+        assert np.isfinite(g.chi2())
