@@ -116,6 +116,8 @@ struct pps_graph {
   std::vector<double> pk_obs_m, pk_obs_w, pk_odo_m, pk_odo_w;
   size_t pk_n_obs = 0, pk_n_odo = 0, pk_ld_obs = 0, pk_ld_odo = 0;
   bool pk_meas_ok = false;
+  bool stream_b_used = false;    // work was queued on the second stream since it was last synchronised (one-step LM loop only)
+  bool status_clean = false;     // result_dev / spec_result are zero: upload_all zeroed them, or the last solve's chi2 kernels consumed the flags
   bool lin_is_est = false;       // upload_state has just filled est AND lin: the estimate_to_linpoint copy of the next solve is a no-op
   bool up_inflight = false;      // upload_all left copies from the pinned buffers in flight on `stream`
   double* state_pin = nullptr; size_t state_pin_cap = 0;     // pinned staging of upload_state / download_state
@@ -756,7 +758,7 @@ int upload_all(pps_graph* g) {
   }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->up_inflight = false;
-  if (g->stream_b) HIP_TRY(g, hipStreamSynchronize(g->stream_b));
+  if (g->stream_b && g->stream_b_used) { HIP_TRY(g, hipStreamSynchronize(g->stream_b)); g->stream_b_used = false; }
   lap("1 state/meas download + syncs");
   free_device(g);
   g->spec_L = g->spec_U = g->spec_delta = nullptr; g->spec_result = nullptr;
@@ -908,16 +910,18 @@ int upload_all(pps_graph* g) {
   if (g->use_dense) { TRY(dev_upload(g, &g->d_dw_asm, g->dw_asm)); TRY(dev_upload(g, &g->d_dw_pan, g->dw_pan)); TRY(dev_upload(g, &g->d_dw_trl, g->dw_trl)); }
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
-  TRY(dev_alloc(g, &d.result_dev, 4)); TRY(dev_alloc(g, &g->spec_result, 4));
+
   {
-    // one zeroed block: [dn_partials | ticket | spec ticket]
+    // one zeroed block: [dn_partials | ticket | spec ticket | result record | the second factorisation's result record]
     const size_t n_dn = (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1;
     double* zb = nullptr;
-    TRY(dev_alloc(g, &zb, n_dn + 2));
-    HIP_TRY(g, hipMemsetAsync(zb, 0, (n_dn + 2) * 8, g->stream));
+    TRY(dev_alloc(g, &zb, n_dn + 2 + 8));
+    HIP_TRY(g, hipMemsetAsync(zb, 0, (n_dn + 2 + 8) * 8, g->stream));
     d.dn_partials = zb;
     d.ticket = reinterpret_cast<unsigned int*>(zb + n_dn);
     g->spec_ticket = reinterpret_cast<unsigned int*>(zb + n_dn + 1);
+    d.result_dev = zb + n_dn + 2; g->spec_result = zb + n_dn + 6;
+    g->status_clean = true;
   }
   TRY(dev_alloc(g, &g->spec_pose, state_doubles + 1)); g->spec_plane = g->spec_pose + (size_t)7 * d.pose_ld;
   TRY(dev_alloc(g, &g->spec_chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
@@ -1362,7 +1366,8 @@ int pps_update(pps_graph* g) {
   if (g->n_live_nodes > 0 && g->n_live_factors == 0) return PPS_OK;   // no factor, no step
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
-  HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+  if (!g->status_clean) HIP_TRY(g, launch_clear_status(g->dev, g->stream));   // (else: zero since the upload / the last chi2 kernel)
+  g->status_clean = false;
   rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:116)
   rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:119)
   rc = do_solve(g, 0.0); if (rc != PPS_OK) return rc;             // compute_gauss_newton_step, lambda = 0 (:122)
@@ -1378,6 +1383,7 @@ int pps_update(pps_graph* g) {
     return fail(g, PPS_ENOTPD, "normal equations not positive definite");
   }
   g->dev_values_newer = true; g->lin_is_est = false;
+  g->status_clean = true;                                         // the chi2 kernel took the flag with it
   g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
   g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
   return PPS_OK;
@@ -1416,8 +1422,11 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
 static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   const pps_props& prop = g->props;
   const Analysis& A = g->an;
-  HIP_TRY(g, launch_clear_status(g->dev, g->stream));
-  HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));
+  if (!g->status_clean) {          // (else: both records are zero since the upload, or the last solve's chi2 kernels took the flags)
+    HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+    HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));
+  }
+  g->status_clean = false;
   int num_iter = 0;
   double lambda = prop.lm_lambda0;
   double* slot0 = g->host_result;                                   // chi2 at the linearisation point
@@ -1517,6 +1526,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   g->spec_pose = t_pose[1]; g->spec_plane = t_plane[1];
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->dev_values_newer = true; g->lin_is_est = false;
+  g->status_clean = true;                // every dual solve was followed by both chi2 kernels
   resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
@@ -1537,6 +1547,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
   const pps_props& prop = g->props;
   HIP_TRY(g, launch_clear_status(g->dev, g->stream));
   HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));
+  g->status_clean = false;              // (a speculative factorisation whose trial was never evaluated leaves its flag behind)
   int num_iter = 0;
   double lambda = prop.lm_lambda0;
   double* slot0 = g->host_result;       // chi2 at the linearisation point
@@ -1578,6 +1589,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
     DevGraph dv = g->dev;
     dv.L = g->spec_L; dv.U = g->spec_U; dv.delta = g->spec_delta; dv.result_dev = g->spec_result;   // its own not-PD flag
     HIP_TRY(g, hipStreamWaitEvent(g->stream_b, g->ev_h_ready, 0));
+    g->stream_b_used = true;
     int r = do_solve_on(g, dv, lam, g->stream_b); if (r != PPS_OK) return r;
     HIP_TRY(g, hipEventRecord(g->ev_spec_done, g->stream_b));
     spec_inflight = true; spec_lambda = lam;
@@ -1799,6 +1811,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
     if (g->an.n_stages > 32) return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + ": elimination tree too deep for the batched schedule");
     MHIP(m, hipStreamSynchronize(g->stream));
     if (g->stream_b) MHIP(m, hipStreamSynchronize(g->stream_b));
+    g->status_clean = false;
     max_stages = std::max(max_stages, g->an.n_stages);
   }
   // both damping values of a linearisation in the same launches (lm_solve_dual's scheme), when every handle has its second

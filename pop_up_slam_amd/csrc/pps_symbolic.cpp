@@ -202,14 +202,28 @@ struct Builder {
     // observer span of every plane inside this sub-chain
     std::vector<int> pmin(planes.size(), n), pmax(planes.size(), -1);
     std::vector<int> diff(n + 1, 0);
+    // A landmark's observers are sorted by node id, which grows with the pose rank: inside this sub-chain they are one run of
+    // the row, and its two ends are the span (two binary searches instead of a walk over every observer -- the ground-level
+    // chains of a frame loop are walked once per frame).  Anything unexpected falls back to the walk.
+    const bool ids_sorted = std::is_sorted(poses.begin(), poses.end());
     for (size_t k = 0; k < planes.size(); k++) {
       const int pl = planes[k];
-      for (int q = adj_off[pl]; q < adj_off[pl + 1]; q++) {
-        const int li = lidx[adj[q]];
-        if (li < 0) continue;
-        pmin[k] = std::min(pmin[k], li);
-        pmax[k] = std::max(pmax[k], li);
+      const int* a0 = adj.data() + adj_off[pl];
+      const int* a1 = adj.data() + adj_off[pl + 1];
+      bool done = false;
+      if (ids_sorted) {
+        const int* f = std::lower_bound(a0, a1, poses[0]);
+        const int* l = std::upper_bound(f, a1, poses[n - 1]);
+        if (f == l) done = true;                                  // not seen from this sub-chain
+        else if (lidx[*f] >= 0 && lidx[*(l - 1)] >= 0) { pmin[k] = lidx[*f]; pmax[k] = lidx[*(l - 1)]; done = true; }
       }
+      if (!done)
+        for (const int* q = a0; q < a1; q++) {
+          const int li = lidx[*q];
+          if (li < 0) continue;
+          pmin[k] = std::min(pmin[k], li);
+          pmax[k] = std::max(pmax[k], li);
+        }
       if (pmax[k] - pmin[k] >= 2) { diff[pmin[k] + 1] += 3; diff[pmax[k]] -= 3; }  // spans m for pmin < m < pmax
     }
     // pose-pose edges that are not between chain neighbours
@@ -273,8 +287,15 @@ struct Builder {
       if (part[i] < 0) sep_poses.push_back(poses[i]);
       else pposes[part[i]].push_back(poses[i]);
     }
+    const bool one_cut = cuts.size() == 1 && cross.empty();     // parts = [0, cut) and (cut, n): the spans above decide
     for (size_t k = 0; k < planes.size(); k++) {
       const int pl = planes[k];
+      if (one_cut) {
+        const bool left = pmin[k] < cuts[0], right = pmax[k] > cuts[0];
+        if (left == right) sep_planes.push_back(pl);             // spans the cut, or attached to the cut pose (or ancestors) only
+        else pplanes[left ? 0 : 1].push_back(pl);
+        continue;
+      }
       // which parts still hold an observer once the separator poses are gone?
       int seen = -1; bool multi = false;
       for (int q = adj_off[pl]; q < adj_off[pl + 1]; q++) {
