@@ -1221,7 +1221,7 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
 // ------------------------------------------------------------------------------------------
 // TR: in-kernel phase trace (PPS_TRACE=1) compiled in
-template <int NT, bool TR>
+template <int NT, bool TR, bool STRIP = false>
 __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
                                                       double* __restrict__ P) {
   const int lane = threadIdx.x & 63;
@@ -1232,7 +1232,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   // Fronts of 65 .. 80 rows (full kernel only): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary
   // rows, the pivots are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried
   // along panel by panel: triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
-  const bool strip = TR && fa > kRegRows;
+  const bool strip = STRIP && fa > kRegRows;
   if (TR) PPS_TR(0);
   const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
@@ -1308,7 +1308,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       default: if (NT > 3) reg_extract_panel<(NT > 3 ? 3 : NT - 1), NT>(c, P, c0, lane); break;
     }
     const int row2 = kRegRows + (lane & 15);                   // the strip row of this lane (lanes 0 .. 15)
-    const bool has2 = TR && strip && lane < 16 && row2 < fa;
+    const bool has2 = STRIP && strip && lane < 16 && row2 < fa;
     if (has2) {
 #pragma unroll
       for (int m = 0; m < 4; m++) P[row2 * kPStride + m] = F[tri(row2) + K + m];   // (K + m < 64 <= row2: inside the row)
@@ -1345,7 +1345,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       if (nb > 2 && lane >= K + 2) lrow[2] = x2;
       if (nb > 3 && lane >= K + 3) lrow[3] = x3;
     }
-    if (TR && strip) {
+    if (STRIP && strip) {
       const double q0 = P[row2 * kPStride + 0], q1 = P[row2 * kPStride + 1], q2 = P[row2 * kPStride + 2], q3 = P[row2 * kPStride + 3];
       double y0, y1, y2, y3;
       {
@@ -1367,7 +1367,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (TR && strip) {
+    if (STRIP && strip) {
       // F[r][c] -= sum_k L[r][k] L[c][k] for the strip rows r and the live columns c >= K + nb: the strip is tile row 4 of the
       // front; its five 16x16 tiles are loaded from the LDS triangle, updated with one MFMA each and written back (only the
       // entries that exist: c <= r < fa).  Tile columns left of the panel are finished and skipped.
@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
         const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
         if (row < fa && col <= row && col >= p) Us[tri(row - p) + col - p] = c[tile_id(ti, tj)][r];
       }
-  if (TR && strip) {
+  if (STRIP && strip) {
     for (int r = kRegRows; r < fa; r++)
       for (int col = p + lane; col <= r; col += 64) Us[tri(r - p) + col - p] = F[tri(r) + col];
   }
@@ -1515,7 +1515,9 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int
 
 // REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the fused
 // root solve are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
-template <bool REG_ONLY>
+// REG_STRIP (with REG_ONLY): the stage also holds fronts of 65 .. 80 rows -- ten register tiles + the LDS strip -- and still
+// nothing that needs the LDS-tile path, the trace or the fused root solve (frame-loop trees, C3)
+template <bool REG_ONLY, bool REG_STRIP = false>
 __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave,
                                                  int solve_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -1530,8 +1532,9 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       double* const Pn = F + lds_doubles_per_wave - kRegRowsMax * kPStride;
       if (REG_ONLY && fa <= 32) wave_front_factor_reg<2, false>(d, rec, lambda, F, Pn);
       else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3, false>(d, rec, lambda, F, Pn);
-      else if (REG_ONLY) wave_front_factor_reg<4, false>(d, rec, lambda, F, Pn);
-      else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);   // 65 .. 80 rows: register tiles + LDS strip
+      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, false>(d, rec, lambda, F, Pn);
+      else if (REG_ONLY) wave_front_factor_reg<4, false, true>(d, rec, lambda, F, Pn);                   // 65 .. 80 rows: register tiles + LDS strip
+      else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true, true>(d, rec, lambda, F, Pn);
       else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);
       else wave_front_factor(d, s, lambda, F);
     }
@@ -1563,6 +1566,12 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, in
   body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, solve_doubles_per_wave, lds);
 }
 
+__global__ __launch_bounds__(512) void k_band_factor_strip(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
+  body_band_factor<true, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, 0, lds);
+}
+
 static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
 
 static hipError_t ensure_band_attrs() {
@@ -1572,6 +1581,7 @@ static hipError_t ensure_band_attrs() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_strip), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
   }
@@ -1591,6 +1601,8 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
   }
   if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
+  else if (max_front + 1 <= kRegRowsMax && solve_per_wave == 0 && d.trace == nullptr && !d.no_strip)
+    PPS_LAUNCH(k_band_factor_strip, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
   else
     PPS_LAUNCH(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, solve_per_wave);
   return hipGetLastError();
@@ -1604,6 +1616,8 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   if (max_front + 1 <= kRegRows && d.trace == nullptr)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
+    PPS_LAUNCH(k_band_factor_strip, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else
     PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
   return hipGetLastError();
