@@ -871,11 +871,8 @@ int upload_all(pps_graph* g) {
   // linear system storage
   TRY(dev_alloc(g, &d.J, (size_t)A.J_size)); TRY(dev_alloc(g, &d.H, (size_t)A.H_size));
   TRY(dev_alloc(g, &d.L, (size_t)A.L_size)); TRY(dev_alloc(g, &d.U, (size_t)A.U_size));
-  TRY(dev_alloc(g, &d.delta, (size_t)A.n_scalars));
   TRY(dev_alloc(g, &g->spec_L, (size_t)A.L_size)); TRY(dev_alloc(g, &g->spec_U, (size_t)A.U_size));
-  TRY(dev_alloc(g, &g->spec_delta, (size_t)A.n_scalars));
-  HIP_TRY(g, hipMemsetAsync(g->spec_delta, 0, (size_t)std::max(1, A.n_scalars) * 8, g->stream));
-  HIP_TRY(g, hipMemsetAsync(d.delta, 0, (size_t)std::max(1, A.n_scalars) * 8, g->stream));
+  const size_t delta_doubles = (size_t)std::max(1, A.n_scalars);   // (delta and the second delta sit in the zeroed block below)
   d.n_scalars = A.n_scalars;
   d.n_fronts = A.n_fronts; d.n_levels = A.n_levels; d.max_front = A.max_front; d.n_segs = A.n_segs; d.n_blocks = A.n_blocks;
   TRY(dev_upload(g, &d.f_p, A.f_p)); TRY(dev_upload(g, &d.f_b, A.f_b)); TRY(dev_upload(g, &d.f_poff, A.f_poff)); TRY(dev_upload(g, &d.pidx, A.pidx));
@@ -912,11 +909,13 @@ int upload_all(pps_graph* g) {
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
 
   {
-    // one zeroed block: [dn_partials | ticket | spec ticket | result record | the second factorisation's result record]
+    // one zeroed block: [dn_partials | ticket | spec ticket | result record | the second factorisation's result record |
+    // delta | the second delta]
     const size_t n_dn = (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1;
     double* zb = nullptr;
-    TRY(dev_alloc(g, &zb, n_dn + 2 + 8));
-    HIP_TRY(g, hipMemsetAsync(zb, 0, (n_dn + 2 + 8) * 8, g->stream));
+    TRY(dev_alloc(g, &zb, n_dn + 2 + 8 + 2 * delta_doubles));
+    HIP_TRY(g, hipMemsetAsync(zb, 0, (n_dn + 2 + 8 + 2 * delta_doubles) * 8, g->stream));
+    d.delta = zb + n_dn + 10; g->spec_delta = d.delta + delta_doubles;
     d.dn_partials = zb;
     d.ticket = reinterpret_cast<unsigned int*>(zb + n_dn);
     g->spec_ticket = reinterpret_cast<unsigned int*>(zb + n_dn + 1);

@@ -28,6 +28,8 @@ namespace pps {
 
 constexpr int kMaxPlanes = 64;
 constexpr int kMaxVerts = 512;
+constexpr size_t kInSegOff = 512, kInPolyOff = kInSegOff + sizeof(float) * 4 * kMaxPlanes, kInBytes = kInPolyOff + sizeof(float) * 2 * kMaxVerts;
+static_assert(sizeof(int) * (kMaxPlanes + 2) <= kInSegOff, "poly_off does not fit its part of the input block");
 
 // one wall plane from a ground segment; exact operation order of the reference (and of the oracle)
 __host__ __device__ __forceinline__ void seg_to_plane(const float* __restrict__ seg, const float* invK, const float* T,
@@ -409,6 +411,8 @@ struct pps_popup {
   float* d_seg = nullptr;      // kMaxPlanes x 4
   float* d_polys = nullptr;    // 2*kMaxVerts
   int* d_off = nullptr;        // kMaxPlanes+2
+  char* d_in = nullptr;        // the block d_off / d_seg / d_polys point into
+  char* h_in = nullptr;        // pinned staging of the same layout
   unsigned int* d_row_iv = nullptr;   // row intervals of the last run (k_popup_rows): height x (kMaxVerts + kMaxPlanes)
   int* d_row_cnt = nullptr;           // height x kMaxPlanes
   int4* d_boxes = nullptr;            // kMaxPlanes
@@ -462,9 +466,14 @@ int pps_popup_create(int device, int width, int height, const float invK[9], pps
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_depth), npx * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_pid), npx * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * (4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * kMaxPlanes));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_seg), sizeof(float) * 4 * kMaxPlanes);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_polys), sizeof(float) * 2 * kMaxVerts);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_off), sizeof(int) * (kMaxPlanes + 2));
+  // per-frame inputs in one block (one transfer per frame): [poly_off | seg2d | polygons]
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_in), kInBytes);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_in), kInBytes, hipHostMallocDefault);
+  if (e == hipSuccess) {
+    p->d_off = reinterpret_cast<int*>(p->d_in);
+    p->d_seg = reinterpret_cast<float*>(p->d_in + kInSegOff);
+    p->d_polys = reinterpret_cast<float*>(p->d_in + kInPolyOff);
+  }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_count), sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_iv), sizeof(unsigned int) * (size_t)height * (kMaxVerts + kMaxPlanes));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_cnt), sizeof(int) * (size_t)height * kMaxPlanes);
@@ -480,7 +489,7 @@ int pps_popup_destroy(pps_popup* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   (void)hipFree(p->d_bgr); (void)hipFree(p->d_cloud); (void)hipFree(p->d_depth); (void)hipFree(p->d_depth_fill); (void)hipFree(p->d_pid);
-  (void)hipFree(p->d_planes); (void)hipFree(p->d_seg); (void)hipFree(p->d_polys); (void)hipFree(p->d_off); (void)hipFree(p->d_count);
+  (void)hipFree(p->d_planes); (void)hipFree(p->d_in); if (p->h_in) (void)hipHostFree(p->h_in); (void)hipFree(p->d_count);
   (void)hipFree(p->d_row_iv); (void)hipFree(p->d_row_cnt); (void)hipFree(p->d_boxes);
   if (p->h_count) (void)hipHostFree(p->h_count);
   if (p->ev[0]) (void)hipEventDestroy(p->ev[0]);
@@ -515,9 +524,12 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   memcpy(prm.T, T_wc, sizeof prm.T);
   prm.width = p->width; prm.height = p->height; prm.step = step;
   prm.depth_thre = depth_thre; prm.ceiling_thre = ceiling_thre;
-  if (n > 0) PHIP(p, hipMemcpyAsync(p->d_seg, seg2d, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, p->stream));
-  if (poly_off[nplanes] > 0) PHIP(p, hipMemcpyAsync(p->d_polys, polys, sizeof(float) * 2 * (size_t)poly_off[nplanes], hipMemcpyHostToDevice, p->stream));
-  PHIP(p, hipMemcpyAsync(p->d_off, poly_off, sizeof(int) * (size_t)(nplanes + 1), hipMemcpyHostToDevice, p->stream));
+  // (the previous run ended with a stream sync: the pinned block is free)
+  memcpy(p->h_in, poly_off, sizeof(int) * (size_t)(nplanes + 1));
+  if (n > 0) memcpy(p->h_in + kInSegOff, seg2d, sizeof(float) * 4 * (size_t)n);
+  const size_t poly_bytes = sizeof(float) * 2 * (size_t)poly_off[nplanes];
+  if (poly_bytes > 0) memcpy(p->h_in + kInPolyOff, polys, poly_bytes);
+  PHIP(p, hipMemcpyAsync(p->d_in, p->h_in, kInPolyOff + poly_bytes, hipMemcpyHostToDevice, p->stream));
   PHIP(p, hipMemsetAsync(p->d_count, 0, sizeof(unsigned int), p->stream));
   const int npx = p->width * p->height;
   PHIP(p, hipEventRecord(p->ev[0], p->stream));
