@@ -245,6 +245,32 @@ def test_fronts_of_65_to_80_rows(built, mk, monkeypatch):
     h.close()
 
 
+def test_lm_loop_forms_are_bit_identical(built, monkeypatch):
+    """The LM loop as shipped -- both damping values of a linearisation in the same launches, the next linearisation queued
+    behind the trials with the accept test repeated on the device -- against the same loop without the queued linearisation
+    (PPS_NO_SPEC_LIN=1) and the one-step-at-a-time loop with its speculation stream (PPS_NO_DUAL=1): same trials, same chi2,
+    same state, bit for bit; and it needs about half the launches."""
+    spec = synth.corridor(300, 60, seed=4)
+    runs = []
+    for env in (None, "PPS_NO_SPEC_LIN", "PPS_NO_DUAL"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        g = P.Graph(); nid, _ = spec.replay(g)
+        it = g.batch_optimize()
+        st = g.stats()
+        runs.append((it, g.trace(), g.chi2(), _state(g, spec, nid), st["n_launches"], st["n_linearize"], st["n_factorize"]))
+        g.close()
+        if env:
+            monkeypatch.delenv(env)
+    it0, tr0, c0, (p0, l0), launches0, nlin0, _ = runs[0]
+    assert it0 >= 10
+    for it, tr, c, (p, l), _, nlin, _ in runs[1:]:
+        assert it == it0 and tr == tr0 and c == c0
+        np.testing.assert_array_equal(p, p0); np.testing.assert_array_equal(l, l0)
+        assert nlin == nlin0
+    assert launches0 / it0 < 8.0 and runs[2][4] > 1.4 * launches0
+
+
 def test_mid_and_large_graphs(built):
     """5 000 poses against the oracle (dead reckoning drifts over this length: the first LM trials are all rejected --
     on both sides, trial for trial); then 50 000 poses / 250 000 plane edges (50x C2, minutes for the oracle) through
