@@ -335,13 +335,18 @@ int flush_uploads(pps_graph* g) {
   for (const auto& pt : g->up_patches) sent += pt.len;
   g->up_bytes_sent = sent;
   if (g->up_patches.empty()) { g->up_bytes_total = 0; return PPS_OK; }
-  const bool bulk = g->up_unknown || g->up_patches.size() <= 2 || sent * 2 > g->up_high || getenv("PPS_NO_PATCH_UPLOAD");
-  if (bulk) {
-    size_t lo = g->up_patches[0].off, hi = lo;
-    for (const auto& pt : g->up_patches) { lo = std::min(lo, pt.off); hi = std::max(hi, pt.off + pt.len); }
-    if (g->up_unknown) { lo = 0; hi = std::max(hi, g->up_high); hi = std::min(hi, g->stage_cap); }
+  // One copy of the whole arena only when the device content is unknown.  Otherwise nothing but the changed pieces may be
+  // written: the span between two pieces can hold what kernels have refreshed behind the mirror's back (the observation
+  // measurements that stay on the device) -- a copy "from the first to the last change" would put stale values over them.
+  if (g->up_unknown) {
+    size_t lo = 0, hi = 0;
+    for (const auto& pt : g->up_patches) hi = std::max(hi, pt.off + pt.len);
+    hi = std::max(hi, g->up_high); hi = std::min(hi, g->stage_cap);
     HIP_TRY(g, hipMemcpyAsync(g->up.base + lo, g->stage + lo, hi - lo, hipMemcpyHostToDevice, g->stream));
     g->up_bytes_sent = hi - lo;
+  } else if (g->up_patches.size() <= 3 || getenv("PPS_NO_PATCH_UPLOAD")) {
+    for (const auto& pt : g->up_patches)        // a few pieces: straight from the pinned mirror
+      HIP_TRY(g, hipMemcpyAsync(g->up.base + pt.off, g->stage + pt.off, pt.len, hipMemcpyHostToDevice, g->stream));
   } else {
     // [table: 4 x int64 per patch | data, 16-byte aligned pieces] -> one copy -> scatter kernel
     const size_t np = g->up_patches.size();

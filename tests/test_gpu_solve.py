@@ -268,7 +268,9 @@ def test_lm_loop_forms_are_bit_identical(built, monkeypatch):
         assert it == it0 and tr == tr0 and c == c0
         np.testing.assert_array_equal(p, p0); np.testing.assert_array_equal(l, l0)
         assert nlin == nlin0
-    assert launches0 / it0 < 8.0 and runs[2][4] > 1.4 * launches0
+    import os
+    if not os.environ.get("PPS_NO_DUAL"):                      # (the whole suite is also run with that switch set)
+        assert launches0 / it0 < 8.0 and runs[2][4] > 1.4 * launches0
 
 
 def test_mid_and_large_graphs(built):
