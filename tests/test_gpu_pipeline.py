@@ -102,3 +102,35 @@ def test_difference_uploads_leave_the_device_equal_to_the_mirror(built, monkeypa
         for fr in frames:
             pl.process(fr)
         assert np.isfinite(g.chi2())
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_frame_loop_with_random_read_only_calls(built, seed):
+    """The frame loop keeps a good deal of state between calls (which copy of the estimate is current, whether the device or the
+    host holds the newer values / measurements, what the upload mirror says, ...).  Calls that must not change anything --
+    chi2, getters, save + restore, a re-analysis, statistics, one factor's Jacobian -- are thrown in at random between the
+    frames; the loop must still follow the oracle frame by frame."""
+    rng = np.random.default_rng(100 + seed)
+    frames = pipeline.popup_sequence(70, seed=20 + seed)
+    pl, g, pp, stats = pipeline.gpu_pipeline(step=2)
+    ol, og = _oracle_pipeline()
+    for fr in frames:
+        it, ito = pl.process(fr), ol.process(fr)
+        assert it == ito
+        for _ in range(int(rng.integers(0, 4))):
+            k = int(rng.integers(0, 8))
+            if k == 0: g.chi2()
+            elif k == 1: g.get_pose(pl.pose_nodes[int(rng.integers(0, len(pl.pose_nodes)))])
+            elif k == 2: g.save_state(); g.restore_state()
+            elif k == 3: g.analyze()
+            elif k == 4: g.stats(); g.trace()
+            elif k == 5: g.get_poses(pl.pose_nodes)
+            elif k == 6:
+                fs = pl.frames[int(rng.integers(0, len(pl.frames)))][2]
+                if len(fs): g.eval_factor(int(fs[0]))
+            else: g.analysis_dump()
+        c, co = g.chi2(), og.chi2()
+        # (chi2 of the first frames is ~1e-5: there a different elimination order alone moves it by 1e-10)
+        assert abs(c - co) <= 1e-5 * max(co, 1e-4), (seed, pl.k, c, co)
+    for a, b in zip(pl.pose_nodes, ol.pose_nodes):
+        np.testing.assert_allclose(g.get_pose(a)[:3], og.get_pose(b)[:3], atol=1e-6)
