@@ -439,6 +439,15 @@ def main():
                                     "popup_kernel_us_per_frame": 1e6 * st5["popup_kernel_s"] / n5, "points_per_frame": st5["points"] / n5,
                                     "note": "Python frame loop over the C-ABI (tools/c5_bench.py); the C++ facade loop is tools/c5_bench_cpp.py"}
             g5.close(); pp5.close()
+            # the same 1000 frames with the host loop in C++ over include/pps_isam.hpp (what a maintainer's Mapper_mono runs):
+            # tools/c5_bench_cpp.py writes the drive as a binary script, builds tools/cpp/c5_replay.cpp with g++ and runs it
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c5_bench_cpp.py")], capture_output=True, text=True, timeout=240)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+                out["c5_frame_loop_cpp_host"] = json.loads(line)
+            except Exception as e:      # no compiler on the box, ...: the Python-loop figure above stands
+                out["c5_frame_loop_cpp_host"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(spec)
             out["cpu_baseline"] = cb
