@@ -553,6 +553,9 @@ int run_analysis(pps_graph* g) {
   // a graph that is re-analysed after pure appends is a frame loop: absolute cut positions keep the left part of its tree
   g->aprm.aligned_cuts = (g->n_analyses > 0 && g->grown_only) ? 1 : 0;
   if (const char* e = getenv("PPS_ALIGNED_CUTS")) g->aprm.aligned_cuts = atoi(e);
+  // ... and its aligned cuts leave a few fronts of 65 .. 80 rows, whose 25 KB triangles let 5 waves share a CU's LDS, not 8:
+  // groups of 4 leaves (3 levels per launch) keep every front of a level on its own wave (C5: 1 580 vs 1 500 frames/s)
+  if (g->aprm.aligned_cuts && g->pose_ids.size() < 4000 && !getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = 3;
   if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
   g->aprm.band_rows = band_front_limit();
   if (const char* e = getenv("PPS_ORDERING")) g->aprm.ordering = atoi(e);
