@@ -620,7 +620,7 @@ int run_analysis(pps_graph* g) {
     if (const char* e = getenv("PPS_BAND_WAVES")) max_waves = std::max(1, std::min(8, atoi(e)));
     for (int st = 0; st < A.n_stages; st++) {
       const int want = std::max(1, std::min(max_waves, A.stage_max_width[st]));
-      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st])));
+      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st], A.stage_max_front[st] + 1 <= band_reg_rows() && !getenv("PPS_TRACE"))));
       int mg = 1;
       for (int gi = A.stage_grp_off[st]; gi < A.stage_grp_off[st + 1]; gi++)
         mg = std::max(mg, A.glvl_front_off[A.grp_lvl_off[gi + 1]] - A.glvl_front_off[A.grp_lvl_off[gi]]);
@@ -1874,7 +1874,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
         q.stage_groups[stg] = std::max(q.stage_groups[stg], A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
         q.stage_nw_factor[stg] = std::max(q.stage_nw_factor[stg], g->stage_nw_factor[stg]);
         q.stage_nw_solve[stg] = std::max(q.stage_nw_solve[stg], g->stage_nw_solve[stg]);
-        q.stage_per_wave_factor[stg] = std::max(q.stage_per_wave_factor[stg], (int)(band_lds_bytes(A.stage_max_front[stg]) / sizeof(double)));
+        q.stage_per_wave_factor[stg] = std::max(q.stage_per_wave_factor[stg], A.stage_max_front[stg]);   // (max front for now: sized below)
         max_panel[stg] = std::max(max_panel[stg], g->stage_max_panel[stg]);
         q.stage_grp_fronts[stg] = std::max(q.stage_grp_fronts[stg], g->stage_max_grp_fronts[stg]);
         if (A.stage_max_front[stg] + 1 > band_reg_rows() || g->dev.trace) q.stage_reg_only[stg] = false;
@@ -1885,6 +1885,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
     q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES")) || getenv("PPS_MULTI_THREAD_FORM");
     q.k1_direct = (q.lin_thread_form || mode == PPS_JAC_ANALYTIC) && !getenv("PPS_MULTI_NO_DIRECT");   // the analytic sweep always runs one thread per factor
     for (int stg = 0; stg < max_stages; stg++) {
+      q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));
       q.stage_per_wave_solve[stg] = (int)(band_solve_lds_bytes(max_panel[stg]) / sizeof(double));
       const size_t fw = (size_t)q.stage_per_wave_factor[stg] * sizeof(double), sw = (size_t)q.stage_per_wave_solve[stg] * sizeof(double);
       const size_t xbytes = (size_t)q.stage_grp_fronts[stg] * band_max_rows() * sizeof(double);

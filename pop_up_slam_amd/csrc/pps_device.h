@@ -131,7 +131,7 @@ int band_max_rows();
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
 int band_reg_rows();                            // fronts up to this many rows (incl. rhs) take the register-resident path
-size_t band_lds_bytes(int max_front);           // LDS bytes one wave needs for the factor kernel
+size_t band_lds_bytes(int max_front, bool reg_only_kernel = false);   // LDS bytes one wave needs for the factor kernel
 // est <- lin ; lin <- lin (+) delta          (LM trial: Optimizer.cpp:414-416)
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st);
 // est <- lin (+) delta                        (GN step: Optimizer.cpp:183)

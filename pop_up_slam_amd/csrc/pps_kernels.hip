@@ -1023,7 +1023,10 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
 int band_front_limit() { return kBandMaxRows - 1; }
 int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
-size_t band_lds_bytes(int max_front) { const size_t fa = (size_t)max_front + 1; return (fa * (fa + 1) / 2 + kRegRowsMax * kPStride) * sizeof(double); }   // packed triangle + panel buffer
+size_t band_lds_bytes(int max_front, bool reg_only_kernel) {       // (the register-only kernels keep a 64-row panel buffer, the others 80 rows: strip)
+  const size_t fa = (size_t)max_front + 1;
+  return (fa * (fa + 1) / 2 + (reg_only_kernel ? kRegRows : kRegRowsMax) * kPStride) * sizeof(double);
+}   // packed triangle + panel buffer
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 
@@ -1529,7 +1532,7 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      double* const Pn = F + lds_doubles_per_wave - kRegRowsMax * kPStride;
+      double* const Pn = F + lds_doubles_per_wave - ((REG_ONLY && !REG_STRIP) ? kRegRows : kRegRowsMax) * kPStride;
       if (REG_ONLY && fa <= 32) wave_front_factor_reg<2, false>(d, rec, lambda, F, Pn);
       else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3, false>(d, rec, lambda, F, Pn);
       else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, false>(d, rec, lambda, F, Pn);
@@ -1592,7 +1595,8 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
                               int fused_solve_panel, int fused_solve_group_fronts) {
   if (grp_count == 0) return hipSuccess;
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
-  const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
+  const bool reg_only = max_front + 1 <= kRegRows && fused_solve_panel <= 0 && d.trace == nullptr;
+  const int per_wave = (int)(band_lds_bytes(max_front, reg_only) / sizeof(double));
   size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   int solve_per_wave = 0;
   if (fused_solve_panel > 0) {       // the stage's back-substitution runs in the same launch (root stage)
@@ -1612,7 +1616,7 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
                                    hipStream_t st) {
   if (grp_count == 0) return hipSuccess;
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
-  const int per_wave = (int)(band_lds_bytes(max_front) / sizeof(double));
+  const int per_wave = (int)(band_lds_bytes(max_front, max_front + 1 <= kRegRows && d.trace == nullptr) / sizeof(double));
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   if (max_front + 1 <= kRegRows && d.trace == nullptr)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
