@@ -38,9 +38,9 @@ def test_incremental_analysis_equals_analysis_from_scratch(built, monkeypatch):
         _grow(gi, si, fr); _grow(gf, sf, fr)
         gi.analyze()
         kept.append(gi.analysis_reuse())
-        monkeypatch.setenv("PPS_NO_INCREMENTAL", "1")
+        monkeypatch.setenv("PPS_NO_INCREMENTAL", "1"); monkeypatch.setenv("PPS_NO_INCR_COMPACT", "1")   # tables rebuilt, analysis from scratch
         gf.analyze()
-        monkeypatch.delenv("PPS_NO_INCREMENTAL")
+        monkeypatch.delenv("PPS_NO_INCREMENTAL"); monkeypatch.delenv("PPS_NO_INCR_COMPACT")
         assert gf.analysis_reuse()[0] == 0
         if k % 5 == 0 or k >= n - 3:
             a, b = gi.analysis_dump(), gf.analysis_dump()
