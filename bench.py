@@ -99,7 +99,7 @@ C4_SEEDS = [42, 135, 110, 143, 225, 154, 169, 185]
 
 
 def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisation, k1_bytes, torch):
-    """G in {1, 8, 64} C4 timing graphs (seeds cycle through C4_SEEDS) solved by pps_multi_optimize from their initial
+    """G in {1, 8, 64, 128} C4 timing graphs (seeds cycle through C4_SEEDS) solved by pps_multi_optimize from their initial
     estimates; per graph the chi2 / iteration count must equal the single-handle solve of the same seed."""
     specs = {sd: synth.corridor(seed=sd) for sd in C4_SEEDS}
     single = {}
@@ -107,7 +107,7 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         g1 = P.Graph(device=device, jacobian_mode=mode); sp.replay(g1)
         single[sd] = (g1.batch_optimize(), g1.chi2()); g1.close()
     res = {}
-    for G in (1, 8, 64):
+    for G in tuple(int(x) for x in os.environ.get("PPS_BENCH_MULTI_G", "1,8,64,128").split(",")):
         gs = []
         for k in range(G):
             gk = P.Graph(device=device, jacobian_mode=mode)

@@ -160,7 +160,7 @@ hipError_t launch_dense_solve_level(const DevGraph& d, int level_begin, int leve
 // the block index the single-graph kernel would have (blocks past a graph's own count exit).  The graphs' DevGraph
 // records sit in a device array; what changes from trial to trial -- who takes part, lambda, which of the two state
 // copies is the linearisation point -- travels in the kernel arguments.
-constexpr int kBatchMax = 64;
+constexpr int kBatchMax = 128;
 enum { BF_ACTIVE = 1,      // the graph takes part in this round
        BF_RELIN = 2,       // ... and is re-linearised first (its last trial was accepted)
        BF_SWAP = 4 };      // est / lin exchanged (an odd number of rejections since the pointers were last in order)

@@ -82,8 +82,8 @@ def test_c2_batches(built):
 
 
 def test_more_graphs_than_one_chunk(built):
-    """100 graphs = two launches per kernel (chunks of 64); every graph equal to a single-handle solve of the same seed"""
-    seeds = [3 + (k % 10) for k in range(100)]
+    """200 graphs = two launches per kernel (chunks of 128); every graph equal to a single-handle solve of the same seed"""
+    seeds = [3 + (k % 10) for k in range(200)]
     specs = {s: synth.corridor(60, 14, seed=s) for s in set(seeds)}
     ref = {}
     for s, sp in specs.items():
