@@ -110,6 +110,7 @@ struct pps_graph {
   bool up_unknown = true;              // the arena was (re)allocated: the mirror says nothing about the device
   bool up_unknown_meas = false;        // ... only about the measurement arrays (written behind the mirror's back)
   size_t slot_obs_meas = (size_t)-1;   // which upload slot holds obs_meas
+  size_t slot_lp_meas = (size_t)-1;    // ... and lp_meas (pps_set_measurement writes both arrays behind the mirror's back)
   // packed factor arrays of the last upload: an upload that only appends fills in the new slots instead of packing every
   // factor again (pk_n = slots that are current; pk_meas_ok: the measurement rows still match the host factors)
   std::vector<int> pk_obs_a, pk_obs_b, pk_odo_a, pk_odo_b, pk_obs_ids, pk_odo_ids;
@@ -392,7 +393,7 @@ int verify_uploads(pps_graph* g, const char* where) {
   std::vector<char> dev(g->up_high);
   HIP_TRY(g, hipMemcpy(dev.data(), g->up.base, g->up_high, hipMemcpyDeviceToHost));
   for (size_t k = 0; k < g->up_slots.size() && k < g->up_cursor; k++) {
-    if (k == g->slot_obs_meas) continue;
+    if (k == g->slot_obs_meas || k == g->slot_lp_meas) continue;
     const size_t o = g->up_slots[k].off, n = std::min(g->up_slots[k].cap, g->up_high - std::min(g->up_high, o));
     if (o >= g->up_high) continue;
     if (memcmp(dev.data() + o, g->stage + o, n) != 0) {
@@ -871,7 +872,7 @@ int upload_all(pps_graph* g) {
   pack_soa<6>(g, F_POSE_PRIOR, nullptr, false, tmp, (size_t)d.pp_ld); TRY(dev_upload_rows(g, &d.pp_meas, tmp, 6, (size_t)d.pp_ld, (size_t)d.n_pp, false));
   pack_soa<21>(g, F_POSE_PRIOR, nullptr, true, tmp, (size_t)d.pp_ld); TRY(dev_upload_rows(g, &d.pp_w, tmp, 21, (size_t)d.pp_ld, (size_t)d.n_pp, false));
   TRY(dev_upload(g, &d.lp_plane, idx_of(F_PLANE_PRIOR, false)));
-  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, tmp, (size_t)d.lp_ld); TRY(dev_upload_rows(g, &d.lp_meas, tmp, 4, (size_t)d.lp_ld, (size_t)d.n_lp, g->up_unknown_meas));
+  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, tmp, (size_t)d.lp_ld); g->slot_lp_meas = g->up_cursor; TRY(dev_upload_rows(g, &d.lp_meas, tmp, 4, (size_t)d.lp_ld, (size_t)d.n_lp, g->up_unknown_meas));
   pack_soa<6>(g, F_PLANE_PRIOR, nullptr, true, tmp, (size_t)d.lp_ld); TRY(dev_upload_rows(g, &d.lp_w, tmp, 6, (size_t)d.lp_ld, (size_t)d.n_lp, false));
   g->up_unknown_meas = false;
   g->pk_meas_ok = true;
