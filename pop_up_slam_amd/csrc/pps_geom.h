@@ -9,6 +9,7 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define PPS_HD __host__ __device__ __forceinline__
 #else
 #define PPS_HD inline

@@ -1,0 +1,464 @@
+// pps_k1_body.h -- K1, the per-edge residual + Jacobian sweep (device bodies).
+//   reference: Slam::jacobian_partial (isamlib/Slam.cpp:395-432) + numericalDiff (numericalDiff.cpp:41-87)
+// Three forms share these bodies: one thread per factor (analytic mode, large batches), 32 lanes per factor with one central-
+// difference evaluation per lane (numeric mode, the reference's arithmetic), and the re-popping Factor2 edges.
+#pragma once
+#include "pps_geom.h"
+#include "pps_kcommon.h"
+
+namespace pps {
+
+template <int MODE>
+__device__ __forceinline__ void lin_plane_obs(const double pz[7], const double pl[4], const double ms[4],
+                                              const double w[6], double* __restrict__ out) {
+  double Jp[18], Jl[9], r[3];
+  if (MODE == 1) {
+    double e[3];
+    jac_plane_obs(pz, pl, ms, e, Jp, Jl);
+    whiten<3>(w, e, r);
+    whiten_rows<3, 6>(w, Jp);
+    whiten_rows<3, 3>(w, Jl);
+  } else {
+    double e[3];
+    res_plane_obs(pz, pl, ms, e);
+    whiten<3>(w, e, r);
+    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double d[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[3], ym[3];
+      d[j] = kNumDiffEps;
+      pose_exmap(pz, d, pp); res_plane_obs(pp, pl, ms, e); whiten<3>(w, e, yp);
+      d[j] = -kNumDiffEps;
+      pose_exmap(pz, d, pp); res_plane_obs(pp, pl, ms, e); whiten<3>(w, e, ym);
+#pragma unroll
+      for (int i = 0; i < 3; i++) Jp[i * 6 + j] = (yp[i] - ym[i]) * inv2e;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double d[3] = {0, 0, 0}, pp[4], yp[3], ym[3];
+      d[j] = kNumDiffEps;
+      plane_exmap(pl, d, pp); res_plane_obs(pz, pp, ms, e); whiten<3>(w, e, yp);
+      d[j] = -kNumDiffEps;
+      plane_exmap(pl, d, pp); res_plane_obs(pz, pp, ms, e); whiten<3>(w, e, ym);
+#pragma unroll
+      for (int i = 0; i < 3; i++) Jl[i * 3 + j] = (yp[i] - ym[i]) * inv2e;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 18; k++) out[k] = Jp[k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) out[18 + k] = Jl[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[27 + k] = r[k];
+}
+
+template <int MODE>
+__device__ __forceinline__ void lin_odometry(const double p1[7], const double p2[7], const double ms[6],
+                                             const double* w, double* __restrict__ out) {
+  double e[6], r[6];
+  if (MODE == 1) {
+    double J1[36], J2[36];
+    jac_odometry(p1, p2, ms, e, J1, J2);
+    whiten<6>(w, e, r);
+    whiten_rows<6, 6>(w, J1);
+    whiten_rows<6, 6>(w, J2);
+#pragma unroll
+    for (int k = 0; k < 36; k++) out[k] = J1[k];
+#pragma unroll
+    for (int k = 0; k < 36; k++) out[36 + k] = J2[k];
+  } else {
+    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+    for (int n = 0; n < 2; n++) {
+      for (int j = 0; j < 6; j++) {
+        double d[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[6], ym[6];
+        d[j] = kNumDiffEps;
+        pose_exmap(n == 0 ? p1 : p2, d, pp);
+        if (n == 0) res_odometry(pp, p2, ms, e); else res_odometry(p1, pp, ms, e);
+        whiten<6>(w, e, yp);
+        d[j] = -kNumDiffEps;
+        pose_exmap(n == 0 ? p1 : p2, d, pp);
+        if (n == 0) res_odometry(pp, p2, ms, e); else res_odometry(p1, pp, ms, e);
+        whiten<6>(w, e, ym);
+#pragma unroll
+        for (int i = 0; i < 6; i++) out[n * 36 + i * 6 + j] = (yp[i] - ym[i]) * inv2e;
+      }
+    }
+    res_odometry(p1, p2, ms, e);
+    whiten<6>(w, e, r);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) out[72 + k] = r[k];
+}
+
+template <int MODE>
+__device__ __forceinline__ void lin_pose_prior(const double pz[7], const double ms[6], const double* w,
+                                               double* __restrict__ out) {
+  double e[6], r[6];
+  if (MODE == 1) {
+    double J[36];
+    jac_pose_prior(pz, ms, e, J);
+    whiten<6>(w, e, r);
+    whiten_rows<6, 6>(w, J);
+#pragma unroll
+    for (int k = 0; k < 36; k++) out[k] = J[k];
+  } else {
+    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+    for (int j = 0; j < 6; j++) {
+      double d[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[6], ym[6];
+      d[j] = kNumDiffEps;
+      pose_exmap(pz, d, pp); res_pose_prior(pp, ms, e); whiten<6>(w, e, yp);
+      d[j] = -kNumDiffEps;
+      pose_exmap(pz, d, pp); res_pose_prior(pp, ms, e); whiten<6>(w, e, ym);
+#pragma unroll
+      for (int i = 0; i < 6; i++) out[i * 6 + j] = (yp[i] - ym[i]) * inv2e;
+    }
+    res_pose_prior(pz, ms, e);
+    whiten<6>(w, e, r);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) out[36 + k] = r[k];
+}
+
+template <int MODE>
+__device__ __forceinline__ void lin_plane_prior(const double pl[4], const double ms[4], const double w[6],
+                                                double* __restrict__ out) {
+  double e[3], r[3], Jl[9];
+  if (MODE == 1) {
+    jac_plane_prior(pl, ms, e, Jl);
+    whiten<3>(w, e, r);
+    whiten_rows<3, 3>(w, Jl);
+  } else {
+    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double d[3] = {0, 0, 0}, pp[4], yp[3], ym[3];
+      d[j] = kNumDiffEps;
+      plane_exmap(pl, d, pp); res_plane_prior(pp, ms, e); whiten<3>(w, e, yp);
+      d[j] = -kNumDiffEps;
+      plane_exmap(pl, d, pp); res_plane_prior(pp, ms, e); whiten<3>(w, e, ym);
+#pragma unroll
+      for (int i = 0; i < 3; i++) Jl[i * 3 + j] = (yp[i] - ym[i]) * inv2e;
+    }
+    res_plane_prior(pl, ms, e);
+    whiten<3>(w, e, r);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) out[k] = Jl[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[9 + k] = r[k];
+}
+
+constexpr int kLinBlock = 128;
+
+// A wave's 64 factor records (N doubles each, contiguous in global memory) are staged through LDS
+// (row stride N+1: conflict-free) and written back as one contiguous 64*N-double stream with 16-byte
+// stores per lane, instead of 64 scattered N*8-byte records per store instruction.
+// second half: the wave's records already sit in LDS (lane l at lds_wave + l * (N + 1))
+template <int N>
+__device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gbase, int n_valid, double* __restrict__ lds_wave);
+
+template <int N>
+__device__ __forceinline__ void store_records_coalesced(const double (&v)[N], double* __restrict__ gbase, int n_valid,
+                                                         double* __restrict__ lds_wave) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < N; k++) lds_wave[lane * (N + 1) + k] = v[k];
+  flush_records_coalesced<N>(gbase, n_valid, lds_wave);
+}
+
+template <int N>
+__device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gbase, int n_valid, double* __restrict__ lds_wave) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+  const int total = n_valid * N;                    // doubles this wave owns (N even -> total even)
+#pragma unroll
+  for (int k = 0; k < (N + 1) / 2; k++) {
+    const int idx = 2 * (lane + 64 * k);
+    if (idx < total) {
+      const int r0 = idx / N, c0 = idx - r0 * N;
+      const int r1 = (idx + 1) / N, c1 = idx + 1 - r1 * N;
+      double2 o;
+      o.x = lds_wave[r0 * (N + 1) + c0];
+      o.y = lds_wave[r1 * (N + 1) + c1];
+      *reinterpret_cast<double2*>(gbase + idx) = o;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// PART 0: plane-observation edges (16 KB of staging LDS per wave); PART 1: odometry edges and priors
+// (40 KB per wave in analytic mode) -- separate launches so that the big edge class keeps its occupancy.
+// DIRECT (many-graph batches): a plane observation that is the only contribution of its (pose, plane) block writes that H
+// block itself -- the product of its own two Jacobian blocks, summed in the order the H-block kernel uses -- into H and into
+// the front-ordered copy; kb_hblocks_t then skips those segments (60 % of the segments of a C2 graph).
+template <int MODE, int PART, bool DIRECT = false>
+__device__ __forceinline__ void body_linearize(const DevGraph& d, const double* __restrict__ pose,
+                                               const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx,
+                                               double* __restrict__ lin_lds) {
+  double* lds_wave = lin_lds + (size_t)(threadIdx.x >> 6) * 64 * (PART == 0 ? 31 : 79);
+  int b = bx + (PART == 0 ? 0 : nb_obs);
+  if (b < nb_obs) {
+    const int i0 = b * kLinBlock + (threadIdx.x & ~63);            // first factor of this wave
+    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_obs_fixed - 1);   // clamped: every lane stays active for the staged store
+    double pz[7], pl[4], ms[4], w[6], out[30];
+    load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
+    load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+    load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
+    load_soa<6>(d.obs_w, d.obs_ld, i, w);
+    lin_plane_obs<MODE>(pz, pl, ms, w, out);
+    if (DIRECT && b * kLinBlock + (int)threadIdx.x < d.n_obs_fixed) {
+      const int hoff = d.obs_dir[3 * (size_t)i], el0 = d.obs_dir[3 * (size_t)i + 1], rows6 = d.obs_dir[3 * (size_t)i + 2];
+      if (hoff >= 0) {
+        double* __restrict__ h = d.H + hoff;
+        double* __restrict__ hf = d.Hf + el0;
+        // block (v, u), rows = the node eliminated later: entry (i, j) = sum_k Jv[k][i] * Ju[k][j], k = 0, 1, 2
+#pragma unroll
+        for (int e = 0; e < 18; e++) {
+          const int ri = rows6 ? e / 3 : e / 6, cj = rows6 ? e - 3 * (e / 3) : e - 6 * (e / 6);
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const double av = rows6 ? out[k * 6 + ri] : out[18 + k * 3 + ri];
+            const double bv = rows6 ? out[18 + k * 3 + cj] : out[k * 6 + cj];
+            acc = PPS_MAC(acc, av, bv);
+          }
+          h[e] = acc;
+          if (el0 >= 0) hf[e] = acc;
+        }
+      }
+    }
+    if (i0 < d.n_obs_fixed) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs_fixed - i0), lds_wave);
+    return;
+  }
+  b -= nb_obs;
+  if (b < nb_odo) {
+    // both Jacobian modes leave through the LDS-staged store: written straight from the lanes, a 624-byte record per lane
+    // turns every store instruction into 64 partial 32-byte sectors (PMC: 265 MB written for 67 MB of records)
+    const int i0 = b * kLinBlock + (threadIdx.x & ~63);
+    const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
+    double p1[7], p2[7], ms[6], w[21];
+    load_pose(pose, d.pose_ld, d.odo_a[i], p1);
+    load_pose(pose, d.pose_ld, d.odo_b[i], p2);
+    load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
+    load_soa<21>(d.odo_w, d.odo_ld, i, w);
+    if (MODE == 1) {
+      double out[78];
+      lin_odometry<MODE>(p1, p2, ms, w, out);
+      if (i0 < d.n_odo) store_records_coalesced<78>(out, d.J + d.joff_odo + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+    } else {
+      // the central-difference loops stay rolled (24 residual evaluations): the record is built in LDS, not in registers
+      lin_odometry<MODE>(p1, p2, ms, w, lds_wave + (threadIdx.x & 63) * 79);
+      if (i0 < d.n_odo) flush_records_coalesced<78>(d.J + d.joff_odo + (size_t)i0 * 78, min(64, d.n_odo - i0), lds_wave);
+    }
+    return;
+  }
+  b -= nb_odo;
+  if (b < nb_pp) {
+    const int i = b * kLinBlock + threadIdx.x;
+    if (i >= d.n_pp) return;
+    double pz[7], ms[6], w[21];
+    load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
+    load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
+    load_soa<21>(d.pp_w, d.pp_ld, i, w);
+    lin_pose_prior<MODE>(pz, ms, w, d.J + d.joff_pp + (size_t)i * 42);
+    return;
+  }
+  b -= nb_pp;
+  {
+    const int i = b * kLinBlock + threadIdx.x;
+    if (i >= d.n_lp) return;
+    double pl[4], ms[4], w[6];
+    load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
+    load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
+    load_soa<6>(d.lp_w, d.lp_ld, i, w);
+    lin_plane_prior<MODE>(pl, ms, w, d.J + d.joff_lp + (size_t)i * 12);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1, lane-parallel central differences (the reference's numericalDiff, one evaluation per lane):
+// 32 lanes per factor = 2 factors per wavefront.  Lane 2q evaluates the residual at x (+) eps e_q,
+// lane 2q+1 at x (-) eps e_q, lane 2*ncols the nominal residual; a lane pair differences through
+// one DPP-style shuffle and lane 2q stores column q.  All lanes of a group read the same edge record
+// (a broadcast load), state is gathered by index from the SoA arrays.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void perturb6(const double p[7], int q, double sgn, double o[7]) {
+  double dl[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) dl[k] = (k == q) ? sgn * kNumDiffEps : 0.0;
+  pose_exmap(p, dl, o);
+}
+__device__ __forceinline__ void perturb3(const double p[4], int q, double sgn, double o[4]) {
+  double dl[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) dl[k] = (k == q) ? sgn * kNumDiffEps : 0.0;
+  plane_exmap(p, dl, o);
+}
+
+constexpr int kLaneGroup = 32;
+constexpr int kLanesPerBlock = 256;
+constexpr int kFactorsPerBlock = kLanesPerBlock / kLaneGroup;
+
+__device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const double* __restrict__ pose,
+                                                     const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx) {
+  const int grp = threadIdx.x / kLaneGroup, gl = threadIdx.x % kLaneGroup;
+  const int q = gl >> 1;                       // perturbed column
+  const double sgn = (gl & 1) ? -1.0 : 1.0;
+  const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+  int b = bx;
+  if (b < nb_obs) {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_obs_fixed) return;
+    double pz[7], pl[4], ms[4], w[6], e[3], y[3];
+    load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
+    load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+    load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
+    load_soa<6>(d.obs_w, d.obs_ld, i, w);
+    {
+      // every lane takes the same path: a perturbation that does not apply is the zero step, which is the
+      // exact identity for a pose; the plane keeps its stored value unless it is the perturbed node
+      double pp[7], lp[4];
+      perturb6(pz, q, sgn, pp);                       // q >= 6: zero delta -> pp == pz bit for bit
+      perturb3(pl, q - 6, sgn, lp);
+      const bool pert_plane = q >= 6 && q < 9;
+#pragma unroll
+      for (int k = 0; k < 4; k++) lp[k] = pert_plane ? lp[k] : pl[k];
+      res_plane_obs(pp, lp, ms, e);
+    }
+    whiten<3>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 6) out[r * 6 + q] = dcol;
+        else if (q < 9) out[18 + r * 3 + (q - 6)] = dcol;
+        else if (gl == 18) out[27 + r] = y[r];
+      }
+    }
+    return;
+  }
+  b -= nb_obs;
+  if (b < nb_odo) {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_odo) return;
+    double p1[7], p2[7], ms[6], w[21], e[6], y[6];
+    load_pose(pose, d.pose_ld, d.odo_a[i], p1);
+    load_pose(pose, d.pose_ld, d.odo_b[i], p2);
+    load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
+    load_soa<21>(d.odo_w, d.odo_ld, i, w);
+    {
+      double pa[7], pb[7];
+      perturb6(p1, q, sgn, pa);                       // out-of-range q: zero step == identity
+      perturb6(p2, q - 6, sgn, pb);
+      res_odometry(pa, pb, ms, e);
+    }
+    whiten<6>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_odo + (size_t)i * 78;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 6) out[r * 6 + q] = dcol;
+        else if (q < 12) out[36 + r * 6 + (q - 6)] = dcol;
+        else if (gl == 24) out[72 + r] = y[r];
+      }
+    }
+    return;
+  }
+  b -= nb_odo;
+  if (b < nb_pp) {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_pp) return;
+    double pz[7], ms[6], w[21], e[6], y[6];
+    load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
+    load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
+    load_soa<21>(d.pp_w, d.pp_ld, i, w);
+    { double pp[7]; perturb6(pz, q, sgn, pp); res_pose_prior(pp, ms, e); }
+    whiten<6>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_pp + (size_t)i * 42;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 6) out[r * 6 + q] = dcol;
+        else if (gl == 12) out[36 + r] = y[r];
+      }
+    }
+    return;
+  }
+  b -= nb_pp;
+  {
+    const int i = b * kFactorsPerBlock + grp;
+    if (i >= d.n_lp) return;
+    double pl[4], ms[4], w[6], e[3], y[3];
+    load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
+    load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
+    load_soa<6>(d.lp_w, d.lp_ld, i, w);
+    {
+      double lp[4];
+      perturb3(pl, q, sgn, lp);
+#pragma unroll
+      for (int k = 0; k < 4; k++) lp[k] = q < 3 ? lp[k] : pl[k];
+      res_plane_prior(lp, ms, e);
+    }
+    whiten<3>(w, e, y);
+    double* __restrict__ out = d.J + d.joff_lp + (size_t)i * 12;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double other = __shfl_xor(y[r], 1, 64);
+      if (!(gl & 1)) {
+        const double dcol = (y[r] - other) * inv2e;
+        if (q < 3) out[r * 3 + q] = dcol;
+        else if (gl == 6) out[9 + r] = y[r];
+      }
+    }
+  }
+}
+
+// below this many factors the lane-parallel form wins (latency); above it the thread-per-factor
+// form has the higher throughput (no idle lanes)
+constexpr int kLaneParallelMaxFactors = 200000;
+
+// Pose3d_Plane3d_Factor2 edges (slots [n_obs_fixed, n_obs)): central differences in both Jacobian modes -- the
+// measurement moves with the pose perturbation (the reference differentiates it numerically too).
+__device__ __forceinline__ void body_linearize_repop(const DevGraph& d, const double* __restrict__ pose,
+                                                     const double* __restrict__ plane, int bx) {
+  const int n2 = d.n_obs - d.n_obs_fixed;
+  const int k = bx * 64 + threadIdx.x;
+  if (k >= n2) return;
+  const int i = d.n_obs_fixed + k;
+  double pz[7], pl[4], ray[6], w[6], e[3], r[3], Jp[18], Jl[9];
+  load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
+  load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+  load_soa<6>(d.obs_ray, n2, k, ray);
+  load_soa<6>(d.obs_w, d.obs_ld, i, w);
+  res_plane_obs2(pz, pl, ray, e);
+  whiten<3>(w, e, r);
+  const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
+  for (int j = 0; j < 6; j++) {
+    double dl[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[3], ym[3];
+    dl[j] = kNumDiffEps;
+    pose_exmap(pz, dl, pp); res_plane_obs2(pp, pl, ray, e); whiten<3>(w, e, yp);
+    dl[j] = -kNumDiffEps;
+    pose_exmap(pz, dl, pp); res_plane_obs2(pp, pl, ray, e); whiten<3>(w, e, ym);
+    for (int q = 0; q < 3; q++) Jp[q * 6 + j] = (yp[q] - ym[q]) * inv2e;
+  }
+  for (int j = 0; j < 3; j++) {
+    double dl[3] = {0, 0, 0}, pp[4], yp[3], ym[3];
+    dl[j] = kNumDiffEps;
+    plane_exmap(pl, dl, pp); res_plane_obs2(pz, pp, ray, e); whiten<3>(w, e, yp);
+    dl[j] = -kNumDiffEps;
+    plane_exmap(pl, dl, pp); res_plane_obs2(pz, pp, ray, e); whiten<3>(w, e, ym);
+    for (int q = 0; q < 3; q++) Jl[q * 3 + j] = (yp[q] - ym[q]) * inv2e;
+  }
+  double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
+  for (int q = 0; q < 18; q++) out[q] = Jp[q];
+  for (int q = 0; q < 9; q++) out[18 + q] = Jl[q];
+  for (int q = 0; q < 3; q++) out[27 + q] = r[q];
+}
+
+}  // namespace pps

@@ -1,0 +1,913 @@
+// pps_k3.hip -- K3: multifrontal Cholesky (cholmod_factorize / cholmod_solve, isamlib/Cholesky.cpp:100-128).
+//   k_band_factor / k_band_solve   one wavefront per front, a workgroup walks a sub-tree of a band of tree levels; fronts
+//                                  <= 64 rows live in registers as 16x16 fp64 MFMA tiles (pps_regtile.h), 65 .. 80 rows keep a
+//                                  strip in LDS, up to 128 rows in LDS tiles
+//   k_front_factor / k_front_solve level-per-launch fallback (one workgroup per front) when neither the band kernels nor the
+//                                  dense-front kernels (pps_dense.hip) apply
+//   k_expand_ea / k_expand_el      index lists of a topology expanded in HBM
+#include <algorithm>
+#include <atomic>
+
+#include "pps_kcommon.h"
+#include "pps_regtile.h"
+
+namespace pps {
+
+// PPS_TRACE=1 instrumentation: lane 0 stamps s_memtime at phase boundaries of a front
+#define PPS_TR(k) do { if (d.trace && lane == 0) d.trace[(size_t)s * 8 + (k)] = clock64(); } while (0)
+
+// ------------------------------------------------------------------------------------------
+// K3: multifrontal partial Cholesky.  One 256-thread workgroup per front; the (f+1)x(f+1) front
+// (last row = right-hand side) lives in LDS (row-major, odd leading dimension), or in a global
+// workspace when it does not fit.  Steps: gather original H blocks (damped diagonal,
+// Cholesky.cpp:94-97) -> extend-add children update matrices -> right-looking elimination of the
+// p pivot columns -> store factor panel and update matrix.
+// ------------------------------------------------------------------------------------------
+constexpr int kLdsLimitBytes = 160 * 1024 - 1024;
+
+int lds_front_limit() {
+  int fa = 1;
+  while ((size_t)(fa + 1) * ((fa + 1) | 1) * 8 <= (size_t)kLdsLimitBytes) fa++;
+  return fa - 1;   // largest f with (f+1) rows
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_front_factor(DevGraph d, int level_begin, double lambda) {
+  extern __shared__ double lds[];
+  const int s = d.level_fronts[level_begin + blockIdx.x];
+  const int p = d.f_p[s], b = d.f_b[s];
+  const int f = p + b, fa = f + 1, ld = fa | 1;
+  double* F = USE_LDS ? lds : d.gwork + (size_t)blockIdx.x * d.gwork_stride;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < fa * ld; i += nt) F[i] = 0.0;
+  __syncthreads();
+  // ---- original entries: one wave per block, lane per entry ----
+  {
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int a0 = d.f_asm_off[s], a1 = d.f_asm_off[s + 1];
+    for (int a = a0 + wave; a < a1; a += nw) {
+      const int blk = d.asm_blk[a], lrow = d.asm_lrow[a], lcol = d.asm_lcol[a];
+      const int rows = d.blk_rows[blk], cols = d.blk_cols[blk], size = d.blk_size[blk];
+      const double* __restrict__ h = d.H + d.blk_hoff[blk];
+      const int rc = rows * cols;
+      const bool diag = size > rc;
+      if (lane < size) {
+        double v = h[lane];   // k_hreduce has folded multi-segment blocks into their first slot
+        if (lane < rc) {
+          const int i = lane / cols, j = lane % cols;
+          if (!diag || i >= j) {
+            if (diag && i == j) v *= (1.0 + lambda);
+            F[(lrow + i) * ld + lcol + j] += v;
+          }
+        } else {
+          F[f * ld + lcol + (lane - rc)] += v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- extend-add of the children's update matrices ----
+  for (int ci = d.f_child_off[s]; ci < d.f_child_off[s + 1]; ci++) {
+    const int c = d.child[ci];
+    const int bc1 = d.f_b[c] + 1;
+    const double* __restrict__ Uc = d.U + d.f_Uoff[c];
+    const int* __restrict__ cm = d.cmap + d.f_cmap_off[c];
+    for (int idx = tid; idx < bc1 * bc1; idx += nt) {
+      const int i = idx / bc1, j = idx - i * bc1;
+      if (j <= i) F[cm[i] * ld + cm[j]] += Uc[idx];
+    }
+    __syncthreads();
+  }
+  // ---- eliminate the p pivot columns (right-looking) ----
+  const int tx = tid & 15, ty = tid >> 4;
+  for (int k = 0; k < p; k++) {
+    const double dkk = F[k * ld + k];
+    double dinv;
+    if (!(dkk > 0.0)) {
+      if (tid == 0) d.result_dev[2] = 1.0;   // not positive definite
+      dinv = 0.0;
+    } else {
+      dinv = 1.0 / sqrt(dkk);
+    }
+    for (int i = k + 1 + tid; i < fa; i += nt) F[i * ld + k] *= dinv;
+    __syncthreads();
+    for (int i = k + 1 + ty; i < fa; i += 16) {
+      const double lik = F[i * ld + k];
+      for (int j = k + 1 + tx; j <= i; j += 16) F[i * ld + j] -= lik * F[j * ld + k];
+    }
+    __syncthreads();   // column k+1 (diagonal included) is final before the next iteration reads it
+  }
+  // ---- store the factor panel ((f+1) x p, row-major) and the update matrix ((b+1) x (b+1)) ----
+  double* __restrict__ Lp = d.L + d.f_Loff[s];
+  for (int idx = tid; idx < fa * p; idx += nt) {
+    const int i = idx / p, j = idx - i * p;
+    double v = 0.0;
+    if (i == j) { const double x = F[j * ld + j]; v = x > 0.0 ? sqrt(x) : 1.0; }
+    else if (i > j) v = F[i * ld + j];
+    Lp[idx] = v;
+  }
+  double* __restrict__ Us = d.U + d.f_Uoff[s];
+  const int b1 = b + 1;
+  for (int idx = tid; idx < b1 * b1; idx += nt) {
+    const int i = idx / b1, j = idx - i * b1;
+    Us[idx] = (j <= i) ? F[(p + i) * ld + p + j] : 0.0;
+  }
+}
+
+static std::atomic<bool> g_attr_set[64];   // per device ordinal (idempotent set-up: a race only repeats it)
+
+hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
+                               hipStream_t st) {
+  if (level_count == 0) return hipSuccess;
+  const int fa = level_max_front + 1;
+  const size_t bytes = (size_t)fa * (fa | 1) * 8;
+  if (bytes <= (size_t)kLdsLimitBytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!g_attr_set[dev & 63]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_factor<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+      if (e != hipSuccess) return e;
+      g_attr_set[dev & 63] = true;
+    }
+    PPS_LAUNCH(k_front_factor<true>, dim3(level_count), dim3(256), bytes, st, d, level_begin, lambda);
+  } else {
+    PPS_LAUNCH(k_front_factor<false>, dim3(level_count), dim3(256), 0, st, d, level_begin, lambda);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K3, wave-per-front form.  The tree levels are cut into bands; inside a band every connected
+// sub-tree ("group") is walked by one workgroup: wave w takes fronts w, w+nw, ... of the current
+// local level, a workgroup barrier separates the levels, update matrices travel through global
+// memory (same CU, workgroup-scope visibility).  A front is a packed lower triangle in LDS
+// (index(i,j) = i(i+1)/2 + j, last row = right-hand side); lane i owns row i (and i+64), so the
+// elimination needs no barrier at all: column k is scaled, written back and re-read as LDS
+// broadcasts by the same wave, in program order.
+// ------------------------------------------------------------------------------------------
+constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
+
+// One workgroup per front: row i of its (b+1)-row packed update matrix goes to row cmap[i] of the parent.
+__global__ __launch_bounds__(64) void k_expand_ea(DevGraph d) {
+  const int s = blockIdx.x;
+  const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
+  const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
+  int* __restrict__ out = d.ea_tgt + d.f_ea_off[s];
+  const int n = len * (len + 1) / 2;
+  int i = 0;                                  // row of entry e: tri(i) <= e < tri(i+1)
+  for (int e = threadIdx.x; e < n; e += 64) {
+    while ((i + 1) * (i + 2) / 2 <= e) i++;
+    const int j = e - i * (i + 1) / 2;
+    out[e] = m[i] * (m[i] + 1) / 2 + m[j];
+  }
+}
+
+// One thread per assembled H block: its elements in the order the front gathers them (lower triangle of a diagonal
+// block, a full off-diagonal block, then the gradient entries of a diagonal block).
+__global__ __launch_bounds__(256) void k_expand_el(DevGraph d, int n_asm) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_asm) return;
+  const int blk = d.asm_blk[a], rows = d.blk_rows[blk], cols = d.blk_cols[blk];
+  const int lrow = d.asm_lrow[a], lcol = d.asm_lcol[a];
+  const bool diag = d.blk_size[blk] != rows * cols;
+  int* __restrict__ dst = d.blk_dst + d.blk_doff[blk];
+  int e = d.asm_el0[a];
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) {
+      if (diag && j > i) continue;
+      dst[i * cols + j] = e;
+      d.el_tgt[e++] = (((lrow + i) * (lrow + i + 1)) / 2 + lcol + j) | ((diag && i == j) ? (1 << 30) : 0);
+    }
+  if (diag) {
+    const int fsz = d.asm_fsz[a];
+    for (int i = 0; i < rows; i++) { dst[rows * cols + i] = e; d.el_tgt[e++] = (fsz * (fsz + 1)) / 2 + lcol + i; }
+  }
+}
+
+hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st) {
+  if (n_asm <= 0) return hipSuccess;
+  PPS_LAUNCH(k_expand_el, dim3((n_asm + 255) / 256), dim3(256), 0, st, d, n_asm);
+  return hipGetLastError();
+}
+
+hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
+  if (n_fronts <= 0) return hipSuccess;
+  PPS_LAUNCH(k_expand_ea, dim3(n_fronts), dim3(64), 0, st, d);
+  return hipGetLastError();
+}
+
+int band_front_limit() { return kBandMaxRows - 1; }
+int band_reg_rows() { return kRegRows; }
+int band_max_rows() { return kBandMaxRows; }
+size_t band_lds_bytes(int max_front, bool reg_only_kernel) {       // (the register-only kernels keep a 64-row panel buffer, the others 80 rows: strip)
+  const size_t fa = (size_t)max_front + 1;
+  return (fa * (fa + 1) / 2 + (reg_only_kernel ? kRegRows : kRegRowsMax) * kPStride) * sizeof(double);
+}   // packed triangle + panel buffer
+
+__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+
+// One row of 16x16 tiles (I, J = o, o+16, ..., I) of the trailing lower triangle gets its rank-nb
+// update C -= P_I P_J^T: all LDS reads are issued unconditionally from clamped (always valid)
+// addresses and masked by selects afterwards, so the NT tiles' loads overlap; then NT back-to-back
+// v_mfma_f64_16x16x4_f64; then the masked stores.
+template <int NT>
+__device__ __forceinline__ void trailing_tile_row(double* __restrict__ F, int fa, int o, int I, int K, int nb, int lane) {
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int kk = K + lq;                                   // this lane's k index of the MFMA operands
+  const bool kvalid = lq < nb;
+  const int ar = I + l16;
+  const bool aok = kvalid && ar < fa;
+  const double araw = F[aok ? tri(ar) + kk : 0];
+  const double av = aok ? -araw : 0.0;
+  int crt[4]; bool rok[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { const int cr = I + lq + 4 * r; rok[r] = cr < fa; crt[r] = rok[r] ? tri(cr) : 0; }   // D layout: row (l/16)+4r, col l%16
+  double bv[NT];
+  double4_t c[NT];
+  bool cok[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int br = o + 16 * t + l16;
+    const bool bok = kvalid && br < fa;
+    const double braw = F[bok ? tri(br) + kk : 0];
+    bv[t] = bok ? braw : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      cok[t][r] = rok[r] && br <= I + lq + 4 * r;
+      const double craw = F[cok[t][r] ? crt[r] + br : 0];
+      c[t][r] = cok[t][r] ? craw : 0.0;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], c[t], 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int cc = o + 16 * t + l16;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (cok[t][r]) F[crt[r] + cc] = c[t][r];
+  }
+}
+
+__device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, double lambda, double* __restrict__ F) {
+  const int lane = threadIdx.x & 63;
+  const int s = uni(s_in);
+  const int p = uni(d.f_p[s]), b = uni(d.f_b[s]);
+  const int f = p + b, fa = f + 1;
+  const int ntri = tri(fa);
+  PPS_TR(0);
+  for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  PPS_TR(1);
+  // ---- original entries: Hf is in gather order, so value and target index are two independent
+  // coalesced streams; 8 elements per lane are fetched before the first LDS update ----
+  {
+    const int e0 = uni(d.f_el_off[s]), e1 = uni(d.f_el_off[s + 1]);
+    const double damp = 1.0 + lambda;
+    const int* __restrict__ tgp = d.el_tgt;
+    const double* __restrict__ hf = d.Hf;
+    for (int e = e0 + lane; e < e1; e += 64 * 8) {
+      int tg[8]; double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < e1 ? tgp[x] : -1; v[u] = x < e1 ? hf[x] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];   // Cholesky.cpp:94-97
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  PPS_TR(2);
+  // ---- extend-add of the children's packed update matrices (same batching) ----
+  const int ci0 = uni(d.f_child_off[s]), ci1 = uni(d.f_child_off[s + 1]);
+  for (int ci = ci0; ci < ci1; ci++) {
+    const int c = uni(d.child[ci]);
+    const int bc1 = uni(d.f_b[c]) + 1;
+    const int n = tri(bc1);
+    const double* __restrict__ Uc = d.U + uni64(d.f_Uoff[c]);
+    const int* __restrict__ tgc = d.ea_tgt + uni64(d.f_ea_off[c]);
+    for (int e = lane; e < n; e += 64 * 8) {
+      int tg[8]; double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < n ? tgc[x] : -1; v[u] = x < n ? Uc[x] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tg[u] >= 0) F[tg[u]] += v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  PPS_TR(3);
+  // ---- eliminate the p pivot columns, four at a time ----
+  // Panel: lane i holds rows i and i+64 of the 4 panel columns in registers; the 4x4 diagonal block is
+  // broadcast with v_readlane, so the panel factorisation never waits on LDS.  Trailing update: the
+  // rank-4 update C -= P_I * P_J^T of every 16x16 tile of the remaining lower triangle is ONE
+  // v_mfma_f64_16x16x4_f64 (A = -P_I, B = P_J^T), operands gathered from the packed triangle in LDS.
+  const int r0 = lane, r1 = lane + 64;
+  const int t0 = tri(r0), t1 = tri(r1);
+  long long cyc_panel = 0, cyc_trail = 0;
+  for (int K = 0; K < p; K += 4) {
+    const long long tk0 = d.trace ? clock64() : 0;
+    double a0[4], a1[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int c = K + m;
+      const bool v0 = c < p && r0 >= c && r0 < fa, v1 = c < p && r1 >= c && r1 < fa;
+      const double x0 = F[v0 ? t0 + c : 0], x1 = F[v1 ? t1 + c : 0];
+      a0[m] = v0 ? x0 : 0.0;
+      a1[m] = v1 ? x1 : 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int c = K + m;
+      if (c < p) {                                         // wave-uniform
+        const double dmm = (c < 64) ? readlane_d(a0[m], c) : readlane_d(a1[m], c - 64);
+        double dinv = 0.0;
+        if (dmm > 0.0) dinv = rsqrt_nr(dmm);
+        else if (lane == 0) d.result_dev[2] = 1.0;         // not positive definite
+        if (r0 >= c) a0[m] *= dinv;                        // the diagonal becomes sqrt(dmm)
+        if (r1 >= c) a1[m] *= dinv;
+#pragma unroll
+        for (int n = m + 1; n < 4; n++) {
+          const int cn = K + n;
+          if (cn < p) {
+            const double lnm = (cn < 64) ? readlane_d(a0[m], cn) : readlane_d(a1[m], cn - 64);
+            if (r0 >= cn) a0[n] -= a0[m] * lnm;
+            if (r1 >= cn) a1[n] -= a1[m] * lnm;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int c = K + m;
+      if (c < p) {
+        if (r0 >= c && r0 < fa) F[t0 + c] = a0[m];
+        if (r1 >= c && r1 < fa) F[t1 + c] = a1[m];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long long tk1 = d.trace ? clock64() : 0;
+    const int o = K + 4 < p ? K + 4 : p;                   // first trailing column
+    const int nb = o - K;                                  // panel width (1..4)
+    for (int I = o; I < fa; I += 16) {
+      const int nt = ((I - o) >> 4) + 1;                   // tiles (I, J <= I) of this tile row, wave-uniform
+      switch (nt) {
+        case 1: trailing_tile_row<1>(F, fa, o, I, K, nb, lane); break;
+        case 2: trailing_tile_row<2>(F, fa, o, I, K, nb, lane); break;
+        case 3: trailing_tile_row<3>(F, fa, o, I, K, nb, lane); break;
+        case 4: trailing_tile_row<4>(F, fa, o, I, K, nb, lane); break;
+        case 5: trailing_tile_row<5>(F, fa, o, I, K, nb, lane); break;
+        case 6: trailing_tile_row<6>(F, fa, o, I, K, nb, lane); break;
+        case 7: trailing_tile_row<7>(F, fa, o, I, K, nb, lane); break;
+        default: trailing_tile_row<8>(F, fa, o, I, K, nb, lane); break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
+  }
+  PPS_TR(4);
+  if (d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
+  // ---- factor panel (f+1) x p row-major (diagonal = sqrt) and packed update matrix ----
+  double* __restrict__ Lp = d.L + uni64(d.f_Loff[s]);
+  if (lane < p) {                                          // p <= 64: lane = column
+    for (int i0 = 0; i0 < fa; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; v[u] = F[(i < fa && lane <= i) ? tri(i) + lane : 0]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; if (i < fa && lane <= i) Lp[(size_t)i * p + lane] = v[u]; }
+    }
+  }
+  double* __restrict__ Us = d.U + uni64(d.f_Uoff[s]);
+  for (int i0 = p; i0 < fa; i0 += 8) {
+    for (int j = p + lane; j < fa; j += 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; v[u] = F[(i < fa && j <= i) ? tri(i) + j : 0]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u; if (i < fa && j <= i) Us[tri(i - p) + j - p] = v[u]; }
+    }
+  }
+  PPS_TR(5);
+}
+
+// ------------------------------------------------------------------------------------------
+// Register-resident variant for fronts of <= 64 rows (all of C2, most of C3).  After assembly in LDS
+// the whole front lives in the lanes' registers as the ten 16x16 tiles of the lower triangle, each in
+// the MFMA accumulator layout (lane l, reg r <-> row (l/16)+4r, col l%16), so a rank-4 update of a
+// tile is a single register-to-register v_mfma_f64_16x16x4_f64.  Per 4-column block only the panel
+// moves through LDS: tile columns K..K+3 -> P[row][4] -> one lane per row solves its row against the
+// 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
+// P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
+// ------------------------------------------------------------------------------------------
+// TR: in-kernel phase trace (PPS_TRACE=1) compiled in
+template <int NT, bool TR, bool STRIP = false>
+__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
+                                                      double* __restrict__ P) {
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readlane(rec, 0), p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int f = p + b, fa = f + 1;
+  const int ntri = tri(fa);
+  // Fronts of 65 .. 80 rows (full kernel only): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary
+  // rows, the pivots are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried
+  // along panel by panel: triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
+  const bool strip = STRIP && fa > kRegRows;
+  if (TR) PPS_TR(0);
+  const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
+  const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
+  const double damp = 1.0 + lambda;
+  const int* __restrict__ tgp = d.el_tgt;
+  const double* __restrict__ hf = d.Hf;
+  // first gather batch and the child records are requested before the LDS triangle is cleared, so the
+  // clearing hides under their latency
+  int tg0[8]; double v0[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) { const int x = e0 + lane + 64 * u; tg0[u] = x < e1 ? tgp[x] : -1; v0[u] = x < e1 ? hf[x] : 0.0; }
+  const int crv0 = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;
+  for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  if (TR) PPS_TR(1);
+#pragma unroll
+  for (int u = 0; u < 8; u++)
+    if (tg0[u] >= 0) F[tg0[u] & 0x3fffffff] += (tg0[u] & (1 << 30)) ? v0[u] * damp : v0[u];   // Cholesky.cpp:94-97
+  for (int e = e0 + lane + 64 * 8; e < e1; e += 64 * 8) {
+    int tg[8]; double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < e1 ? tgp[x] : -1; v[u] = x < e1 ? hf[x] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (TR) PPS_TR(2);
+  for (int cb = 0; cb < nch; cb += 8) {
+   // child records of up to 8 children in one coalesced load (the first batch was requested above)
+   const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);
+   for (int cj = 0; cj < 8 && cb + cj < nch; cj++) {
+    const int n = __builtin_amdgcn_readlane(crv, 8 * cj);
+    const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
+    const long long eo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 4) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 3);
+    const double* __restrict__ Uc = d.U + uo;
+    const int* __restrict__ tgc = d.ea_tgt + eo;
+    for (int e = lane; e < n; e += 64 * 8) {
+      int tg[8]; double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < n ? tgc[x] : -1; v[u] = x < n ? Uc[x] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tg[u] >= 0) F[tg[u]] += v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+   }
+  }
+  if (TR) PPS_TR(3);
+  // ---- packed triangle -> register tiles ----
+  double4_t c[NT * (NT + 1) / 2];
+#pragma unroll
+  for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+    for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
+        const bool ok = row < fa && col <= row;
+        const double x = F[ok ? tri(row) + col : 0];
+        c[tile_id(ti, tj)][r] = ok ? x : 0.0;
+      }
+  double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
+  long long cyc_panel = 0, cyc_trail = 0;
+  for (int K = 0; K < p; K += 4) {
+    const long long tk0 = (TR && d.trace) ? clock64() : 0;
+    const int nb = p - K < 4 ? p - K : 4;
+    const int tjK = K >> 4, c0 = K & 15;
+    switch (tjK) {
+      case 0: reg_extract_panel<0, NT>(c, P, c0, lane); break;
+      case 1: reg_extract_panel<1, NT>(c, P, c0, lane); break;
+      case 2: if (NT > 2) reg_extract_panel<(NT > 2 ? 2 : 1), NT>(c, P, c0, lane); break;
+      default: if (NT > 3) reg_extract_panel<(NT > 3 ? 3 : NT - 1), NT>(c, P, c0, lane); break;
+    }
+    const int row2 = kRegRows + (lane & 15);                   // the strip row of this lane (lanes 0 .. 15)
+    const bool has2 = STRIP && strip && lane < 16 && row2 < fa;
+    if (has2) {
+#pragma unroll
+      for (int m = 0; m < 4; m++) P[row2 * kPStride + m] = F[tri(row2) + K + m];   // (K + m < 64 <= row2: inside the row)
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- panel: lane = row ----
+    double r0 = P[lane * kPStride + 0], r1 = P[lane * kPStride + 1], r2 = P[lane * kPStride + 2], r3 = P[lane * kPStride + 3];
+    const double d00 = readlane_d(r0, K);
+    const double d10 = readlane_d(r0, K + 1), d11 = readlane_d(r1, K + 1);
+    const double d20 = readlane_d(r0, K + 2), d21 = readlane_d(r1, K + 2), d22 = readlane_d(r2, K + 2);
+    const double d30 = readlane_d(r0, K + 3), d31 = readlane_d(r1, K + 3), d32 = readlane_d(r2, K + 3), d33 = readlane_d(r3, K + 3);
+    bool bad = false;
+    double i0 = 0, i1 = 0, i2 = 0, i3 = 0, l10 = 0, l20 = 0, l30 = 0, l21 = 0, l31 = 0, l32 = 0;
+    double x0, x1, x2, x3;
+    {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)     // the serial pivot chain: a - b * c is one operation here
+#endif
+      { bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? rsqrt_nr(d00) : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
+      if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
+      if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
+      if (nb > 3) { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; bad |= !(t > 0.0); i3 = t > 0.0 ? rsqrt_nr(t) : 0.0; }
+      x0 = r0 * i0;
+      x1 = (r1 - x0 * l10) * i1;
+      x2 = (r2 - x0 * l20 - x1 * l21) * i2;
+      x3 = (r3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+    }
+    if (bad && lane == 0) d.result_dev[2] = 1.0;           // not positive definite
+    P[lane * kPStride + 0] = x0; P[lane * kPStride + 1] = x1; P[lane * kPStride + 2] = x2; P[lane * kPStride + 3] = x3;
+    if (lane < fa) {
+      double* __restrict__ lrow = Lp + (size_t)lane * p + K;
+      if (lane >= K) lrow[0] = x0;
+      if (nb > 1 && lane >= K + 1) lrow[1] = x1;
+      if (nb > 2 && lane >= K + 2) lrow[2] = x2;
+      if (nb > 3 && lane >= K + 3) lrow[3] = x3;
+    }
+    if (STRIP && strip) {
+      const double q0 = P[row2 * kPStride + 0], q1 = P[row2 * kPStride + 1], q2 = P[row2 * kPStride + 2], q3 = P[row2 * kPStride + 3];
+      double y0, y1, y2, y3;
+      {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)
+#endif
+        y0 = q0 * i0;
+        y1 = (q1 - y0 * l10) * i1;
+        y2 = (q2 - y0 * l20 - y1 * l21) * i2;
+        y3 = (q3 - y0 * l30 - y1 * l31 - y2 * l32) * i3;
+      }
+      if (has2) {
+        P[row2 * kPStride + 0] = y0; P[row2 * kPStride + 1] = y1; P[row2 * kPStride + 2] = y2; P[row2 * kPStride + 3] = y3;
+        double* __restrict__ lrow = Lp + (size_t)row2 * p + K;
+        lrow[0] = y0;
+        if (nb > 1) lrow[1] = y1;
+        if (nb > 2) lrow[2] = y2;
+        if (nb > 3) lrow[3] = y3;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (STRIP && strip) {
+      // F[r][c] -= sum_k L[r][k] L[c][k] for the strip rows r and the live columns c >= K + nb: the strip is tile row 4 of the
+      // front; its five 16x16 tiles are loaded from the LDS triangle, updated with one MFMA each and written back (only the
+      // entries that exist: c <= r < fa).  Tile columns left of the panel are finished and skipped.
+      const int cmin = K + nb;
+      const bool kvalid = lq < nb;
+      const double a4r = P[(kRegRows + l16) * kPStride + lq];
+      const double a4 = kvalid ? -a4r : 0.0;
+#pragma unroll 1                                    // one tile at a time: eight registers next to the ten resident tiles
+      for (int tj = cmin >> 4; tj < 5; tj++) {
+        const double br = P[(16 * tj + l16) * kPStride + lq];
+        const double bj = kvalid ? br : 0.0;
+        const int col = 16 * tj + l16;
+        double4_t t;
+        bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = kRegRows + lq + 4 * r;
+          ok[r] = row < fa && col <= row && col >= cmin;
+          const double x = F[ok[r] ? tri(row) + col : 0];
+          t[r] = ok[r] ? x : 0.0;
+        }
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, bj, t, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = kRegRows + lq + 4 * r;
+          if (ok[r]) F[tri(row) + col] = t[r];
+        }
+      }
+    }
+    const long long tk1 = (TR && d.trace) ? clock64() : 0;
+    switch (tjK) {
+      case 0: reg_trailing<0, NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 1: reg_trailing<1, NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      case 2: if (NT > 2) reg_trailing<(NT > 2 ? 2 : 1), NT>(c, P, nb, lane, (K + 4) >> 4); break;
+      default: if (NT > 3) reg_trailing<(NT > 3 ? 3 : NT - 1), NT>(c, P, nb, lane, (K + 4) >> 4); break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (TR && d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
+  }
+  if (TR) PPS_TR(4);
+  if (TR && d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
+  // ---- update matrix: live part of the tiles -> packed global ----
+  double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
+#pragma unroll
+  for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+    for (int tj = 0; tj <= ti; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
+        if (row < fa && col <= row && col >= p) Us[tri(row - p) + col - p] = c[tile_id(ti, tj)][r];
+      }
+  if (STRIP && strip) {
+    for (int r = kRegRows; r < fa; r++)
+      for (int col = p + lane; col <= r; col += 64) Us[tri(r - p) + col - p] = F[tri(r) + col];
+  }
+  if (TR) PPS_TR(5);
+}
+
+
+// x_p = L_A^-T (y - L_B^T x_b) for one front, one wave (p <= 64).  The factor panel ((f+1) x p, contiguous) is
+// copied to LDS in batches of 16 independent coalesced loads per lane -- two round trips for a C2 front instead of one
+// per 8 rows -- and everything after that reads LDS; the back-substitution chain runs in registers (lane j holds
+// t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + the panel.
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
+  const int lane = threadIdx.x & 63;
+  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
+  const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
+  const int pslot = __builtin_amdgcn_readlane(rec, 14);
+  // boundary values: from the parent's local solution vector in LDS (through cmap) when the parent was solved by this
+  // workgroup, else gathered from delta.  The index load does not depend on the parent and is issued first.
+  const int* __restrict__ ix = pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8);
+  double* xb = W;
+  double* PL = W + kBandMaxRows;
+  const int ix0 = lane < b ? ix[lane] : 0, ix1 = lane + 64 < b ? ix[lane + 64] : 0;
+  double g0 = 0.0, g1 = 0.0;
+  if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }          // clamped index 0 when out of range: harmless
+  const int n = (f + 1) * p;
+  for (int e0 = 0; e0 < n; e0 += 64 * 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; v[u] = Lp[e < n ? e : n - 1]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; if (e < n) PL[e] = v[u]; }
+  }
+  if (pslot >= 0) {
+    const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows;
+    g0 = Xp[ix0]; g1 = Xp[ix1];
+  }
+  if (lane < b) xb[lane] = g0;
+  if (lane + 64 < b) xb[lane + 64] = g1;
+  __builtin_amdgcn_wave_barrier();
+  double tj = 0.0, dinv = 0.0;
+  {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
+#endif
+    if (lane < p) {
+      // y - L_B^T x_b in two interleaved partial sums (half the dependent chain)
+      double acc = PL[f * p + lane], acc2 = 0.0;
+      const double* __restrict__ lb = PL + p * p + lane;
+      int i = 0;
+#pragma unroll 2
+      for (; i + 2 <= b; i += 2) { acc -= lb[i * p] * xb[i]; acc2 -= lb[(i + 1) * p] * xb[i + 1]; }
+      if (i < b) acc -= lb[i * p] * xb[i];
+      tj = acc + acc2;
+      dinv = 1.0 / PL[lane * p + lane];
+    }
+#pragma unroll 4
+    for (int k = p - 1; k >= 0; k--) {
+      const double lkj = (lane < k) ? PL[k * p + lane] : 0.0;      // independent of the chain
+      const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
+      tj = (lane == k) ? xk : tj - lkj * xk;
+    }
+  }
+  if (lane < p) d.delta[d.pidx[__builtin_amdgcn_readlane(rec, 7) + lane]] = tj;
+  // own local solution [x_p | x_b] for the children inside this group
+  double* __restrict__ Xs = X + (size_t)slot * kBandMaxRows;
+  if (lane < p) Xs[lane] = tj;
+  if (lane < b) Xs[p + lane] = g0;
+  if (lane + 64 < b) Xs[p + lane + 64] = g1;
+}
+
+__device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds) {
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* W = lds + (size_t)wave * lds_doubles_per_wave;
+  double* X = lds + (size_t)nw * lds_doubles_per_wave;          // one local solution vector per front of the group
+  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
+  const int g0 = d.glvl_front_off[l0];
+  for (int l = l1 - 1; l >= l0; l--) {
+    const int i1 = d.glvl_front_off[l + 1];
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+      wave_front_solve(d, rec, W, X, i - g0);
+    }
+    __syncthreads();   // delta of this local level is visible to the children
+  }
+}
+
+__global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int grp_begin, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
+  body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+}
+
+// REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the fused
+// root solve are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
+// REG_STRIP (with REG_ONLY): the stage also holds fronts of 65 .. 80 rows -- ten register tiles + the LDS strip -- and still
+// nothing that needs the LDS-tile path, the trace or the fused root solve (frame-loop trees, C3)
+template <bool REG_ONLY, bool REG_STRIP = false>
+__device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave,
+                                                 int solve_doubles_per_wave, double* __restrict__ lds) {
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* F = lds + (size_t)wave * lds_doubles_per_wave;
+  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
+  for (int l = l0; l < l1; l++) {
+    const int i1 = d.glvl_front_off[l + 1];
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
+      const int s = __builtin_amdgcn_readlane(rec, 0);
+      const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
+      double* const Pn = F + lds_doubles_per_wave - ((REG_ONLY && !REG_STRIP) ? kRegRows : kRegRowsMax) * kPStride;
+      if (REG_ONLY && fa <= 32) wave_front_factor_reg<2, false>(d, rec, lambda, F, Pn);
+      else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3, false>(d, rec, lambda, F, Pn);
+      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, false>(d, rec, lambda, F, Pn);
+      else if (REG_ONLY) wave_front_factor_reg<4, false, true>(d, rec, lambda, F, Pn);                   // 65 .. 80 rows: register tiles + LDS strip
+      else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true, true>(d, rec, lambda, F, Pn);
+      else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);
+      else wave_front_factor(d, s, lambda, F);
+    }
+    __syncthreads();   // children of the next local level are complete and visible (same CU)
+  }
+  if (REG_ONLY) return;
+  // root stage: the back-substitution of the same group follows at once (one launch less per solve); the factor's
+  // LDS is dead by now and is re-partitioned for the solve
+  if (solve_doubles_per_wave > 0) {
+    double* W = lds + (size_t)wave * solve_doubles_per_wave;
+    double* X = lds + (size_t)nw * solve_doubles_per_wave;
+    const int g0 = d.glvl_front_off[l0];
+    for (int l = l1 - 1; l >= l0; l--) {
+      const int i1 = d.glvl_front_off[l + 1];
+      for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+        const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+        wave_front_solve(d, rec, W, X, i - g0);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool REG_ONLY>
+__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave,
+                                                     int solve_doubles_per_wave) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
+  body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, solve_doubles_per_wave, lds);
+}
+
+__global__ __launch_bounds__(512) void k_band_factor_strip(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
+  body_band_factor<true, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, 0, lds);
+}
+
+static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
+
+static hipError_t ensure_band_attrs() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!g_band_attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_strip), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e != hipSuccess) return e;
+    g_band_attr_set[dev & 63] = true;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
+                              int fused_solve_panel, int fused_solve_group_fronts) {
+  if (grp_count == 0) return hipSuccess;
+  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
+  const bool reg_only = max_front + 1 <= kRegRows && fused_solve_panel <= 0 && d.trace == nullptr;
+  const int per_wave = (int)(band_lds_bytes(max_front, reg_only) / sizeof(double));
+  size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
+  int solve_per_wave = 0;
+  if (fused_solve_panel > 0) {       // the stage's back-substitution runs in the same launch (root stage)
+    solve_per_wave = (int)(band_solve_lds_bytes(fused_solve_panel) / sizeof(double));
+    bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
+  }
+  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
+    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
+  else if (max_front + 1 <= kRegRowsMax && solve_per_wave == 0 && d.trace == nullptr && !d.no_strip)
+    PPS_LAUNCH(k_band_factor_strip, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
+  else
+    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, solve_per_wave);
+  return hipGetLastError();
+}
+
+hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
+                                   hipStream_t st) {
+  if (grp_count == 0) return hipSuccess;
+  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
+  const int per_wave = (int)(band_lds_bytes(max_front, max_front + 1 <= kRegRows && d.trace == nullptr) / sizeof(double));
+  const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
+  if (max_front + 1 <= kRegRows && d.trace == nullptr)
+    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
+    PPS_LAUNCH(k_band_factor_strip, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+  else
+    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+  return hipGetLastError();
+}
+
+size_t band_solve_lds_bytes(int max_panel) { return (size_t)(kBandMaxRows + max_panel) * sizeof(double); }   // xb + the factor panel
+
+hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
+                             const DualAlt* alt) {
+  if (grp_count == 0) return hipSuccess;
+  // per wave: xb + the largest factor panel of the stage; per workgroup: one local solution vector per front of a group
+  const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
+  PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves),
+                     ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double), st, d, alt ? *alt : DualAlt{}, grp_begin,
+                     per_wave);
+  return hipGetLastError();
+}
+
+// Back-substitution for one level (parents already solved): x_p = L_A^-T (y - L_B^T x_b).
+__global__ __launch_bounds__(64) void k_front_solve(DevGraph d, int level_begin) {
+  __shared__ double t[256];
+  const int s = d.level_fronts[level_begin + blockIdx.x];
+  const int p = d.f_p[s], b = d.f_b[s], f = p + b;
+  const double* __restrict__ Lp = d.L + d.f_Loff[s];
+  const int* __restrict__ bi = d.bidx + d.f_bidx_off[s];
+  const int lane = threadIdx.x;
+  for (int k = lane; k < p; k += 64) {
+    double acc = Lp[(size_t)f * p + k];                      // y_k (forward-solved rhs row)
+    for (int i = 0; i < b; i++) acc -= Lp[(size_t)(p + i) * p + k] * d.delta[bi[i]];
+    t[k] = acc;
+  }
+  __syncthreads();
+  for (int k = p - 1; k >= 0; k--) {
+    const double xk = t[k] / Lp[(size_t)k * p + k];
+    __syncthreads();
+    for (int j = lane; j < k; j += 64) t[j] -= Lp[(size_t)k * p + j] * xk;
+    if (lane == 0) t[k] = xk;
+    __syncthreads();
+  }
+  for (int k = lane; k < p; k += 64) d.delta[d.pidx[d.f_poff[s] + k]] = t[k];
+}
+
+hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st) {
+  if (level_count == 0) return hipSuccess;
+  PPS_LAUNCH(k_front_solve, dim3(level_count), dim3(64), 0, st, d, level_begin);
+  return hipGetLastError();
+}
+
+// ---- batched forms ----
+template <bool REG_ONLY>
+__global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
+  if ((int)blockIdx.x >= sg.grp_count) return;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
+    body_band_factor<REG_ONLY>(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, 0, lds);
+    return;
+  }
+  body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, 0, lds);
+}
+
+__global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
+  if ((int)blockIdx.x >= sg.grp_count) return;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
+    body_band_solve(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+    return;
+  }
+  body_band_solve(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+}
+
+static std::atomic<bool> g_batch_attr_set[64];
+
+hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!g_batch_attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e != hipSuccess) return e;
+    g_batch_attr_set[dev & 63] = true;
+  }
+  for (int stg = 0; stg < g.n_stages; stg++) {
+    if (g.stage_groups[stg] <= 0) continue;
+    const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
+    const size_t bytes = (size_t)per_wave * nw * sizeof(double);
+    if (g.stage_reg_only[stg])
+      PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    else
+      PPS_LAUNCH(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+  }
+  if (after_factor) (void)hipEventRecord(after_factor, st);
+  for (int stg = g.n_stages - 1; stg >= 0; stg--) {
+    if (g.stage_groups[stg] <= 0) continue;
+    const int per_wave = g.stage_per_wave_solve[stg], nw = g.stage_nw_solve[stg];
+    const size_t bytes = ((size_t)per_wave * nw + (size_t)g.stage_grp_fronts[stg] * kBandMaxRows) * sizeof(double);
+    PPS_LAUNCH(kb_band_solve, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace pps

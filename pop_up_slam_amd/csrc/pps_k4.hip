@@ -1,0 +1,419 @@
+// pps_k4.hip -- K4: retraction (Slam::self_exmap / apply_exmap, Slam.cpp:216-234) and the chi^2 sweep whose last block
+// writes the pinned result record (Slam::weighted_errors / chi2, Slam.cpp:254-268); patch scatter of the difference upload.
+#include <algorithm>
+
+#include "pps_geom.h"
+#include "pps_kcommon.h"
+
+namespace pps {
+
+// ------------------------------------------------------------------------------------------
+// K4: retraction and chi^2
+// ------------------------------------------------------------------------------------------
+// pose_lin / pose_est / plane_lin / plane_est are passed explicitly: the batched form swaps them per graph
+template <bool TRIAL>
+__device__ __forceinline__ void body_retract(const DevGraph& d, double* __restrict__ pose_lin, double* __restrict__ pose_est,
+                                             double* __restrict__ plane_lin, double* __restrict__ plane_est, int bx, double* red) {
+  const int i = bx * blockDim.x + threadIdx.x;
+  double dn = 0.0;
+  if (i < d.n_pose) {
+    double p[7], o[7], dl[6];
+    load_pose(pose_lin, d.pose_ld, i, p);
+    const int off = d.pose_voff[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    pose_exmap(p, dl, o);
+    if (TRIAL) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) { pose_est[(size_t)k * d.pose_ld + i] = p[k]; pose_lin[(size_t)k * d.pose_ld + i] = o[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 7; k++) pose_est[(size_t)k * d.pose_ld + i] = o[k];
+    }
+  } else if (i < d.n_pose + d.n_plane) {
+    const int l = i - d.n_pose;
+    double p[4], o[4], dl[3];
+    load_plane(plane_lin, d.plane_ld, l, p);
+    const int off = d.plane_voff[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    plane_exmap(p, dl, o);
+    if (TRIAL) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { plane_est[(size_t)k * d.plane_ld + l] = p[k]; plane_lin[(size_t)k * d.plane_ld + l] = o[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) plane_est[(size_t)k * d.plane_ld + l] = o[k];
+    }
+  }
+  // |delta|^2 partial of this block (summed by the last block of the following k_chi2)
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
+  __syncthreads();
+  if (threadIdx.x == 0) d.dn_partials[bx] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <bool TRIAL>
+__global__ __launch_bounds__(256) void k_retract(DevGraph d) {
+  __shared__ double red[4];
+  body_retract<TRIAL>(d, d.pose_lin, d.pose_est, d.plane_lin, d.plane_est, blockIdx.x, red);
+}
+
+// out <- base (+) delta, nothing else touched: the speculative LM trial (step computed for lambda * factor on the
+// second stream) is applied to a third copy of the state; |delta|^2 partials go to d.dn_partials
+__global__ __launch_bounds__(256) void k_retract_to(DevGraph d, DualAlt alt, const double* __restrict__ base_pose,
+                                                    const double* __restrict__ base_plane, double* __restrict__ out_pose,
+                                                    double* __restrict__ out_plane, double* __restrict__ out_pose1, double* __restrict__ out_plane1) {
+  __shared__ double red[4];
+  if (blockIdx.y) { d.delta = alt.delta; d.dn_partials = alt.dn_partials; out_pose = out_pose1; out_plane = out_plane1; }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double dn = 0.0;
+  if (i < d.n_pose) {
+    double p[7], o[7], dl[6];
+    load_pose(base_pose, d.pose_ld, i, p);
+    const int off = d.pose_voff[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    pose_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 7; k++) out_pose[(size_t)k * d.pose_ld + i] = o[k];
+  } else if (i < d.n_pose + d.n_plane) {
+    const int l = i - d.n_pose;
+    double p[4], o[4], dl[3];
+    load_plane(base_plane, d.plane_ld, l, p);
+    const int off = d.plane_voff[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    plane_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out_plane[(size_t)k * d.plane_ld + l] = o[k];
+  }
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
+  __syncthreads();
+  if (threadIdx.x == 0) d.dn_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+hipError_t launch_retract_to(const DevGraph& d, const double* base_pose, const double* base_plane, double* out_pose, double* out_plane,
+                             hipStream_t st) {
+  const int n = d.n_pose + d.n_plane;
+  if (n == 0) return hipSuccess;
+  PPS_LAUNCH(k_retract_to, dim3(cdiv(n, 256)), dim3(256), 0, st, d, DualAlt{}, base_pose, base_plane, out_pose, out_plane, nullptr, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st) {
+  const int n = d.n_pose + d.n_plane;
+  if (n == 0) return hipSuccess;
+  PPS_LAUNCH(k_retract<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, d);
+  return hipGetLastError();
+}
+hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st) {
+  const int n = d.n_pose + d.n_plane;
+  if (n == 0) return hipSuccess;
+  PPS_LAUNCH(k_retract<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, d);
+  return hipGetLastError();
+}
+
+constexpr int kChiBlock = 256;
+
+// bx: block within the graph, nb: blocks of the graph (the one that draws the last ticket reduces)
+__device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __restrict__ pose,
+                                          const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
+                                          int n_dn, double* __restrict__ out, double seq, int bx, int nb) {
+  __shared__ double red[kChiBlock / 64];
+  int b = bx;
+  double s = 0.0;
+  if (b < nb_obs) {
+    const int i = b * kChiBlock + threadIdx.x;
+    if (i < d.n_obs) {
+      double pz[7], pl[4], ms[4], w[6], e[3], r[3];
+      load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
+      load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+      if (i < d.n_obs_fixed) load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
+      else {                                  // Pose3d_Plane3d_Factor2: re-pop the measurement at this pose
+        double ray[6];
+        load_soa<6>(d.obs_ray, d.n_obs - d.n_obs_fixed, i - d.n_obs_fixed, ray);
+        repop_wall_plane(pz, ray, ms);
+      }
+      load_soa<6>(d.obs_w, d.obs_ld, i, w);
+      res_plane_obs(pz, pl, ms, e);
+      whiten<3>(w, e, r);
+      s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    }
+  } else if ((b -= nb_obs) < nb_odo) {
+    const int i = b * kChiBlock + threadIdx.x;
+    if (i < d.n_odo) {
+      double p1[7], p2[7], ms[6], w[21], e[6], r[6];
+      load_pose(pose, d.pose_ld, d.odo_a[i], p1);
+      load_pose(pose, d.pose_ld, d.odo_b[i], p2);
+      load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
+      load_soa<21>(d.odo_w, d.odo_ld, i, w);
+      res_odometry(p1, p2, ms, e);
+      whiten<6>(w, e, r);
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += r[k] * r[k];
+    }
+  } else if ((b -= nb_odo) < nb_pp) {
+    const int i = b * kChiBlock + threadIdx.x;
+    if (i < d.n_pp) {
+      double pz[7], ms[6], w[21], e[6], r[6];
+      load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
+      load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
+      load_soa<21>(d.pp_w, d.pp_ld, i, w);
+      res_pose_prior(pz, ms, e);
+      whiten<6>(w, e, r);
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += r[k] * r[k];
+    }
+  } else {
+    b -= nb_pp;
+    const int i = b * kChiBlock + threadIdx.x;
+    if (i < d.n_lp) {
+      double pl[4], ms[4], w[6], e[3], r[3];
+      load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
+      load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
+      load_soa<6>(d.lp_w, d.lp_ld, i, w);
+      res_plane_prior(pl, ms, e);
+      whiten<3>(w, e, r);
+      s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    }
+  }
+  // wave reduction (64 lanes), then across the 4 waves
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kChiBlock / 64; k++) t += red[k];
+    d.chi2_partials[bx] = t;
+    // publish, then take a ticket: the block that draws the last one reduces everything
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicAdd(d.ticket, 1u) == (unsigned int)(nb - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  double cs = 0.0, dn = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kChiBlock) cs += __hip_atomic_load(&d.chi2_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < n_dn; i += kChiBlock) dn += __hip_atomic_load(&d.dn_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cs += __shfl_down(cs, o, 64); dn += __shfl_down(dn, o, 64); }
+  __shared__ double red2[2][kChiBlock / 64];
+  if ((threadIdx.x & 63) == 0) { red2[0][threadIdx.x >> 6] = cs; red2[1][threadIdx.x >> 6] = dn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b2 = 0.0;
+    for (int k = 0; k < kChiBlock / 64; k++) { a += red2[0][k]; b2 += red2[1][k]; }
+    const double npd = __hip_atomic_load(&d.result_dev[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d.result_dev[0] = a; d.result_dev[1] = b2; d.result_dev[2] = 0.0;   // the flag belongs to the solve before this record
+    out[0] = a; out[1] = b2; out[2] = npd;                 // `out` is pinned host memory: no copy kernel
+    // the sequence number goes last, with system-scope release: the host polls it instead of paying a stream sync
+    __hip_atomic_store(&out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    *d.ticket = 0u;
+  }
+}
+
+__global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __restrict__ pose,
+                                                    const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
+                                                    int n_dn, double* __restrict__ out, double seq) {
+  body_chi2(d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(kChiBlock) void k_chi2_dual(DevGraph d, DualAlt alt, const double* __restrict__ pose, const double* __restrict__ plane,
+                                                         const double* __restrict__ pose1, const double* __restrict__ plane1, int nb_obs,
+                                                         int nb_odo, int nb_pp, int n_dn, double* __restrict__ out, double seq,
+                                                         double* __restrict__ out1, double seq1) {
+  if (blockIdx.y) {
+    d.chi2_partials = alt.chi2_partials; d.dn_partials = alt.dn_partials; d.ticket = alt.ticket; d.result_dev = alt.result_dev;
+    pose = pose1; plane = plane1; out = out1; seq = seq1;
+  }
+  body_chi2(d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
+}
+
+hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
+                             double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
+                             double seq1, hipStream_t st) {
+  const int n = d.n_pose + d.n_plane;
+  if (n > 0)
+    PPS_LAUNCH(k_retract_to, dim3(cdiv(n, 256), 2), dim3(256), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1);
+  const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock), nb_lp = cdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if (nb == 0) return hipErrorInvalidValue;
+  PPS_LAUNCH(k_chi2_dual, dim3(nb, 2), dim3(kChiBlock), 0, st, d, alt, out_pose0, out_plane0, out_pose1, out_plane1, nb_obs, nb_odo, nb_pp,
+                     cdiv(n, 256), host_result0, seq0, host_result1, seq1);
+  return hipGetLastError();
+}
+
+hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, double seq, hipStream_t st) {
+  const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock),
+            nb_lp = cdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  const double* pose = at_estimate ? d.pose_est : d.pose_lin;
+  const double* plane = at_estimate ? d.plane_est : d.plane_lin;
+  if (nb == 0) return hipErrorInvalidValue;
+  const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
+  PPS_LAUNCH(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
+  return hipGetLastError();
+}
+
+// chi2 at an explicit state (d.chi2_partials / d.ticket / d.dn_partials are the caller's: a second reduction may run
+// concurrently on another stream with its own set)
+hipError_t launch_chi2_at(const DevGraph& d, const double* pose, const double* plane, double* host_result, double seq, hipStream_t st) {
+  const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock),
+            nb_lp = cdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if (nb == 0) return hipErrorInvalidValue;
+  const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
+  PPS_LAUNCH(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
+  return hipGetLastError();
+}
+
+// ---- batched forms ----
+// lin <- est (estimate_to_linpoint, Optimizer.cpp:376) for the graphs of the chunk
+__global__ __launch_bounds__(256) void kb_begin(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const int np = 7 * d.pose_ld, nl = 4 * d.plane_ld;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < np + nl; i += gridDim.x * 256) {
+    if (i < np) pose_lin[i] = pose_est[i]; else plane_lin[i - np] = plane_est[i - np];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) d.result_dev[threadIdx.x] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void kb_retract_trial(BatchArgs a) {
+  __shared__ double red[4];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  if ((int)blockIdx.x * 256 >= d.n_pose + d.n_plane) return;
+  body_retract<true>(d, pose_lin, pose_est, plane_lin, plane_est, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(kChiBlock) void kb_chi2(BatchArgs a, int slot) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const int nb_obs = dcdiv(d.n_obs, kChiBlock), nb_odo = dcdiv(d.n_odo, kChiBlock), nb_pp = dcdiv(d.n_pp, kChiBlock),
+            nb_lp = dcdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if ((int)blockIdx.x >= nb) return;
+  body_chi2(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+            a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot, a.seq, blockIdx.x, nb);
+}
+
+hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  PPS_LAUNCH(kb_begin, dim3(std::max(1, std::min(8, g.retract)), a.n), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st) {
+  if (g.chi2 <= 0) return hipErrorInvalidValue;
+  PPS_LAUNCH(kb_chi2, dim3(g.chi2, a.n), dim3(kChiBlock), 0, st, a, slot);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  if (g.retract > 0) PPS_LAUNCH(kb_retract_trial, dim3(g.retract, a.n), dim3(256), 0, st, a);
+  return launch_batch_chi2(a, g, 1, st);
+}
+
+// ---- dual-lambda batch (BatchAlt): both trials of a graph in one launch, grid z = 0 / 1 ----
+__global__ __launch_bounds__(64) void kb_begin_dual(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchAlt al = load_alt(a.alt + a.b0 + b);
+  if (threadIdx.x < 4) { d.result_dev[threadIdx.x] = 0.0; al.result_dev[threadIdx.x] = 0.0; }
+}
+
+__device__ __forceinline__ void body_retract_to(const DevGraph& d, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
+                                                double* __restrict__ out_pose, double* __restrict__ out_plane, int bx, double* red) {
+  const int i = bx * blockDim.x + threadIdx.x;
+  double dn = 0.0;
+  if (i < d.n_pose) {
+    double p[7], o[7], dl[6];
+    load_pose(base_pose, d.pose_ld, i, p);
+    const int off = d.pose_voff[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    pose_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 7; k++) out_pose[(size_t)k * d.pose_ld + i] = o[k];
+  } else if (i < d.n_pose + d.n_plane) {
+    const int l = i - d.n_pose;
+    double p[4], o[4], dl[3];
+    load_plane(base_plane, d.plane_ld, l, p);
+    const int off = d.plane_voff[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    plane_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out_plane[(size_t)k * d.plane_ld + l] = o[k];
+  }
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
+  __syncthreads();
+  if (threadIdx.x == 0) d.dn_partials[bx] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void kb_retract_dual(BatchArgs a) {
+  __shared__ double red[4];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  if ((int)blockIdx.x * 256 >= d.n_pose + d.n_plane) return;
+  const BatchAlt al = load_alt(a.alt + a.b0 + b);
+  const int xs = a.xsel[b], z = blockIdx.z;
+  const int ts = (xs + 1 + z) % 3;
+  DevGraph d2 = d;
+  if (z) { d2.delta = al.delta; d2.dn_partials = al.dn_partials; }
+  body_retract_to(d2, pose_lin, plane_lin, sel3(al.pose, ts), sel3(al.plane, ts), blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(kChiBlock) void kb_chi2_dual(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const int nb_obs = dcdiv(d.n_obs, kChiBlock), nb_odo = dcdiv(d.n_odo, kChiBlock), nb_pp = dcdiv(d.n_pp, kChiBlock),
+            nb_lp = dcdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if ((int)blockIdx.x >= nb) return;
+  const BatchAlt al = load_alt(a.alt + a.b0 + b);
+  const int xs = a.xsel[b], z = blockIdx.z;
+  const int ts = (xs + 1 + z) % 3;
+  DevGraph d2 = d;
+  if (z) { d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.ticket = al.ticket; d2.result_dev = al.result_dev; }
+  body_chi2(d2, sel3(al.pose, ts), sel3(al.plane, ts), nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+            a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
+}
+
+hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  (void)g;
+  PPS_LAUNCH(kb_begin_dual, dim3(1, a.n), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
+  if (g.chi2 <= 0) return hipErrorInvalidValue;
+  if (g.retract > 0) PPS_LAUNCH(kb_retract_dual, dim3(g.retract, a.n, 2), dim3(256), 0, st, a);
+  PPS_LAUNCH(kb_chi2_dual, dim3(g.chi2, a.n, 2), dim3(kChiBlock), 0, st, a);
+  return hipGetLastError();
+}
+
+// patch upload of a re-uploaded topology (pps_api.cpp: flush_uploads): piece i of the patch buffer -> its place in the arena
+__global__ __launch_bounds__(256) void k_scatter_patches(const char* __restrict__ patch, char* __restrict__ arena) {
+  const long long* tab = reinterpret_cast<const long long*>(patch) + 4 * (size_t)blockIdx.x;
+  const long long dst = tab[0], src = tab[1], len = tab[2];
+  const int4* s4 = reinterpret_cast<const int4*>(patch + src);
+  int4* d4 = reinterpret_cast<int4*>(arena + dst);
+  for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len / 16; i += (long long)gridDim.y * 256) d4[i] = s4[i];
+}
+
+hipError_t launch_scatter_patches(const char* patch, int n_patches, char* arena, hipStream_t st) {
+  if (n_patches <= 0) return hipSuccess;
+  PPS_LAUNCH(k_scatter_patches, dim3(n_patches, 8), dim3(256), 0, st, patch, arena);
+  return hipGetLastError();
+}
+
+hipError_t launch_clear_status(const DevGraph& d, hipStream_t st) {
+  return hipMemsetAsync(d.result_dev, 0, 4 * sizeof(double), st);
+}
+
+}  // namespace pps

@@ -36,7 +36,7 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
 
 constexpr int kPStride = 5;                       // doubles per panel row: conflict-free operand gathers
 constexpr int kRegRows = 64;                      // rows held as register tiles (one lane per row in the panel step)
-constexpr int kRegRowsMax = 80;                   // ... plus up to 16 boundary rows kept as a strip of the LDS triangle (pps_kernels.hip)
+constexpr int kRegRowsMax = 80;                   // ... plus up to 16 boundary rows kept as a strip of the LDS triangle (pps_k3.hip)
 
 __device__ __forceinline__ constexpr int tile_id(int ti, int tj) { return ti * (ti + 1) / 2 + tj; }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel register / spill / LDS / code-size table of the gfx950 code objects (no GPU needed).
 
-  python tools/kernel_resources.py [pps_kernels.hip ...] [--filter REGEX] [--flags "..."]
+  python tools/kernel_resources.py [pps_k3.hip ...] [--filter REGEX] [--flags "..."]
 
 Compiles every given .hip file of pop_up_slam_amd/csrc device-only (the Makefile's flags), unbundles the gfx950 ELF and
 reads the AMDGPU metadata notes.  waves/SIMD = floor(512 / (vgpr_count rounded up to 8)) -- vgpr_count is the unified total, AGPRs included --, capped at 8 (MI355X_MICROARCH.md).
@@ -16,7 +16,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pop_up_slam_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-SOLVER = {"pps_kernels.hip", "pps_dense.hip", "pps_band.hip", "pps_linhess.hip"}
+SOLVER = {"pps_k1.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip", "pps_dense.hip"}
 
 
 def resources(src, extra):
@@ -60,7 +60,7 @@ def demangle(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("files", nargs="*", default=["pps_kernels.hip"])
+    ap.add_argument("files", nargs="*", default=["pps_k1.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip"])
     ap.add_argument("--filter", default="")
     ap.add_argument("--flags", default="")
     a = ap.parse_args()
