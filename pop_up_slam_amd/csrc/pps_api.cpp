@@ -1876,6 +1876,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
         q.stage_nw_factor[stg] = std::max(q.stage_nw_factor[stg], g->stage_nw_factor[stg]);
         q.stage_nw_solve[stg] = std::max(q.stage_nw_solve[stg], g->stage_nw_solve[stg]);
         q.stage_per_wave_factor[stg] = std::max(q.stage_per_wave_factor[stg], A.stage_max_front[stg]);   // (max front for now: sized below)
+        q.stage_max_front[stg] = std::max(q.stage_max_front[stg], A.stage_max_front[stg]);
         max_panel[stg] = std::max(max_panel[stg], g->stage_max_panel[stg]);
         q.stage_grp_fronts[stg] = std::max(q.stage_grp_fronts[stg], g->stage_max_grp_fronts[stg]);
         if (A.stage_max_front[stg] + 1 > band_reg_rows() || g->dev.trace) q.stage_reg_only[stg] = false;

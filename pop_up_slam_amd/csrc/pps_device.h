@@ -201,6 +201,7 @@ struct BatchGeom {
   int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
   int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};
   bool stage_reg_only[32] = {false};
+  int stage_max_front[32] = {0};    // largest front (scalars, without the rhs row) of the stage over the chunk's graphs
 };
 hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // lin <- est for every active graph
 hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st);   // K1 of the BF_RELIN graphs (mode | 2: thread-per-factor form)

@@ -7,6 +7,7 @@
 //   k_expand_ea / k_expand_el      index lists of a topology expanded in HBM
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "pps_kcommon.h"
 #include "pps_regtile.h"
@@ -400,68 +401,125 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
 // P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
 // ------------------------------------------------------------------------------------------
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NT, bool TR, bool STRIP, class AfterLoad, class BeforeStore>
+__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P, AfterLoad after_load,
+                                                    BeforeStore before_store);
+// ---- assembly of a front's packed triangle in LDS, in pieces (one wave) ----
+// Eight scatter-add items per lane in flight: (target index, value) pairs of the front-ordered H, or of a child's packed update
+// matrix.  Issued as 16 independent coalesced loads, applied as LDS read-modify-writes (targets are unique inside one source).
+template <int N> struct ElBatch { int tg[N]; double v[N]; };
+template <int N>
+__device__ __forceinline__ void el_issue(const int* __restrict__ tgp, const double* __restrict__ val, int e, int e1, int lane, ElBatch<N>& q) {
+#pragma unroll
+  for (int u = 0; u < N; u++) { const int x = e + lane + 64 * u; q.tg[u] = x < e1 ? tgp[x] : -1; q.v[u] = x < e1 ? val[x] : 0.0; }
+}
+template <bool ORIG, int N>     // ORIG: entries of H (bit 30 of the target = diagonal element, damped: Cholesky.cpp:94-97)
+__device__ __forceinline__ void el_apply(const ElBatch<N>& q, double damp, double* __restrict__ F) {
+#pragma unroll
+  for (int u = 0; u < N; u++)
+    if (q.tg[u] >= 0) {
+      if (ORIG) F[q.tg[u] & 0x3fffffff] += (q.tg[u] & (1 << 30)) ? q.v[u] * damp : q.v[u];
+      else F[q.tg[u]] += q.v[u];
+    }
+}
+// what a front needs before its children are complete: first batch of its original entries and its child records (requested),
+// the cleared triangle, the original entries added.  issue -> [anything] -> finish.  NPRE items per lane are requested ahead:
+// 8 when nothing else is live, 4 (256 entries: every separator front of a corridor graph) next to the register tiles of the
+// front being eliminated.
+template <int NPRE> struct FrontPre { ElBatch<NPRE> q; int crv; };
+template <int NPRE>
+__device__ __forceinline__ void front_pre_issue(const DevGraph& d, int rec, int lane, FrontPre<NPRE>& o) {
+  const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
+  const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
+  el_issue(d.el_tgt, d.Hf, e0, e1, lane, o.q);
+  o.crv = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;      // records of up to 8 children in one coalesced load
+}
+__device__ __forceinline__ void front_clear(int rec, int lane, double* __restrict__ F) {
+  const int ntri = tri(__builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1);
+  for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+}
+template <int NPRE>
+__device__ __forceinline__ void front_pre_finish(const DevGraph& d, int rec, int lane, const FrontPre<NPRE>& o, double damp, double* __restrict__ F) {
+  const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
+  el_apply<true>(o.q, damp, F);
+  for (int e = e0 + 64 * NPRE; e < e1; e += 64 * 8) { ElBatch<8> q; el_issue(d.el_tgt, d.Hf, e, e1, lane, q); el_apply<true>(q, damp, F); }
+  __builtin_amdgcn_wave_barrier();
+}
+// extend-add of the children's packed update matrices.  PAIR: the first batches of the first two children are requested
+// together (one memory round trip for a front with two children instead of two)
+template <bool PAIR>
+__device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int crv0, int lane, double* __restrict__ F) {
+  const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
+  for (int cb = 0; cb < nch; cb += 8) {
+    const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);
+    auto child = [&](int cj, int& n, const double* __restrict__& Uc, const int* __restrict__& tgc) {
+      n = __builtin_amdgcn_readlane(crv, 8 * cj);
+      const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
+      const long long eo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 4) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 3);
+      Uc = d.U + uo; tgc = d.ea_tgt + eo;
+    };
+    int cj = 0;
+    if (PAIR && cb + 1 < nch) {
+      int n0, n1; const double *U0, *U1; const int *t0, *t1;
+      child(0, n0, U0, t0); child(1, n1, U1, t1);
+      ElBatch<8> a, b2;
+      el_issue(t0, U0, 0, n0, lane, a); el_issue(t1, U1, 0, n1, lane, b2);
+      el_apply<false>(a, 0.0, F);
+      for (int e = 64 * 8; e < n0; e += 64 * 8) { ElBatch<8> q; el_issue(t0, U0, e, n0, lane, q); el_apply<false>(q, 0.0, F); }
+      __builtin_amdgcn_wave_barrier();
+      el_apply<false>(b2, 0.0, F);
+      for (int e = 64 * 8; e < n1; e += 64 * 8) { ElBatch<8> q; el_issue(t1, U1, e, n1, lane, q); el_apply<false>(q, 0.0, F); }
+      __builtin_amdgcn_wave_barrier();
+      cj = 2;
+    }
+    for (; cj < 8 && cb + cj < nch; cj++) {
+      int n; const double* Uc; const int* tgc;
+      child(cj, n, Uc, tgc);
+      for (int e = 0; e < n; e += 64 * 8) { ElBatch<8> q; el_issue(tgc, Uc, e, n, lane, q); el_apply<false>(q, 0.0, F); }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// One front from start to end (the strip / trace / LDS-tile kernels; the register-only stages run body_band_factor_pipe below).
 // TR: in-kernel phase trace (PPS_TRACE=1) compiled in
+// Fronts of 65 .. 80 rows (STRIP): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary rows, the pivots
+// are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried along panel by panel:
+// triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
 template <int NT, bool TR, bool STRIP = false>
 __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
                                                       double* __restrict__ P) {
   const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readlane(rec, 0);
+  (void)s;
+  if (TR) PPS_TR(0);
+  // the first gather batch and the child records are requested before the LDS triangle is cleared, so the clearing hides
+  // under their latency
+  FrontPre<8> pre;
+  front_pre_issue(d, rec, lane, pre);
+  front_clear(rec, lane, F);
+  if (TR) PPS_TR(1);
+  front_pre_finish(d, rec, lane, pre, 1.0 + lambda, F);
+  if (TR) PPS_TR(2);
+  front_extend_add<false>(d, rec, pre.crv, lane, F);
+  if (TR) PPS_TR(3);
+  front_reg_eliminate<NT, TR, STRIP>(d, rec, F, P, NoHook(), NoHook());
+}
+
+// Second half of a register-resident front: the assembled packed triangle in F -> register tiles -> panels -> factor panel and
+// update matrix in HBM.  after_load runs once the tiles are in registers (F is dead from then on unless STRIP), before_store
+// after the last panel: the pipelined band kernel pre-assembles the wave's NEXT front there, under the latency of the panels.
+template <int NT, bool TR, bool STRIP, class AfterLoad, class BeforeStore>
+__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P,
+                                                    AfterLoad after_load, BeforeStore before_store) {
+  const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0), p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
   const int l16 = lane & 15, lq = lane >> 4;
   const int f = p + b, fa = f + 1;
-  const int ntri = tri(fa);
-  // Fronts of 65 .. 80 rows (full kernel only): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary
-  // rows, the pivots are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried
-  // along panel by panel: triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
   const bool strip = STRIP && fa > kRegRows;
-  if (TR) PPS_TR(0);
-  const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
-  const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
-  const double damp = 1.0 + lambda;
-  const int* __restrict__ tgp = d.el_tgt;
-  const double* __restrict__ hf = d.Hf;
-  // first gather batch and the child records are requested before the LDS triangle is cleared, so the
-  // clearing hides under their latency
-  int tg0[8]; double v0[8];
-#pragma unroll
-  for (int u = 0; u < 8; u++) { const int x = e0 + lane + 64 * u; tg0[u] = x < e1 ? tgp[x] : -1; v0[u] = x < e1 ? hf[x] : 0.0; }
-  const int crv0 = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;
-  for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
-  __builtin_amdgcn_wave_barrier();
-  if (TR) PPS_TR(1);
-#pragma unroll
-  for (int u = 0; u < 8; u++)
-    if (tg0[u] >= 0) F[tg0[u] & 0x3fffffff] += (tg0[u] & (1 << 30)) ? v0[u] * damp : v0[u];   // Cholesky.cpp:94-97
-  for (int e = e0 + lane + 64 * 8; e < e1; e += 64 * 8) {
-    int tg[8]; double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < e1 ? tgp[x] : -1; v[u] = x < e1 ? hf[x] : 0.0; }
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (tg[u] >= 0) F[tg[u] & 0x3fffffff] += (tg[u] & (1 << 30)) ? v[u] * damp : v[u];
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (TR) PPS_TR(2);
-  for (int cb = 0; cb < nch; cb += 8) {
-   // child records of up to 8 children in one coalesced load (the first batch was requested above)
-   const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);
-   for (int cj = 0; cj < 8 && cb + cj < nch; cj++) {
-    const int n = __builtin_amdgcn_readlane(crv, 8 * cj);
-    const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
-    const long long eo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 4) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 3);
-    const double* __restrict__ Uc = d.U + uo;
-    const int* __restrict__ tgc = d.ea_tgt + eo;
-    for (int e = lane; e < n; e += 64 * 8) {
-      int tg[8]; double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { const int x = e + 64 * u; tg[u] = x < n ? tgc[x] : -1; v[u] = x < n ? Uc[x] : 0.0; }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (tg[u] >= 0) F[tg[u]] += v[u];
-    }
-    __builtin_amdgcn_wave_barrier();
-   }
-  }
-  if (TR) PPS_TR(3);
+  (void)s;
   // ---- packed triangle -> register tiles ----
   double4_t c[NT * (NT + 1) / 2];
 #pragma unroll
@@ -475,6 +533,8 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
         const double x = F[ok ? tri(row) + col : 0];
         c[tile_id(ti, tj)][r] = ok ? x : 0.0;
       }
+  __builtin_amdgcn_wave_barrier();
+  after_load();
   double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   long long cyc_panel = 0, cyc_trail = 0;
   for (int K = 0; K < p; K += 4) {
@@ -589,6 +649,7 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   }
   if (TR) PPS_TR(4);
   if (TR && d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
+  before_store();
   // ---- update matrix: live part of the tiles -> packed global ----
   double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
 #pragma unroll
@@ -612,21 +673,38 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
 // copied to LDS in batches of 16 independent coalesced loads per lane -- two round trips for a C2 front instead of one
 // per 8 rows -- and everything after that reads LDS; the back-substitution chain runs in registers (lane j holds
 // t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + the panel.
-__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
-  const int lane = threadIdx.x & 63;
+// What does not depend on the parent's solution -- the first 1024 panel entries and the boundary index list -- is requested
+// ahead (solve_issue) and consumed by wave_front_solve; `mid` runs between the last memory access of the front and its
+// arithmetic: the band kernel requests the wave's NEXT front there, so those loads travel under the back-substitution.
+struct SolvePre { double v[16]; int ix0, ix1; };
+__device__ __forceinline__ void solve_issue(const DevGraph& d, int rec, int lane, SolvePre& q) {
   const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
   const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   const int pslot = __builtin_amdgcn_readlane(rec, 14);
   // boundary values: from the parent's local solution vector in LDS (through cmap) when the parent was solved by this
-  // workgroup, else gathered from delta.  The index load does not depend on the parent and is issued first.
+  // workgroup, else gathered from delta
   const int* __restrict__ ix = pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8);
+  q.ix0 = lane < b ? ix[lane] : 0; q.ix1 = lane + 64 < b ? ix[lane + 64] : 0;
+  const int n = (f + 1) * p;
+#pragma unroll
+  for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; q.v[u] = Lp[e < n ? e : n - 1]; }
+}
+
+template <class Mid>
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, SolvePre& q, double* __restrict__ W, double* __restrict__ X, int slot, Mid mid) {
+  const int lane = threadIdx.x & 63;
+  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
+  const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
+  const int pslot = __builtin_amdgcn_readlane(rec, 14);
   double* xb = W;
   double* PL = W + kBandMaxRows;
-  const int ix0 = lane < b ? ix[lane] : 0, ix1 = lane + 64 < b ? ix[lane + 64] : 0;
+  const int ix0 = q.ix0, ix1 = q.ix1;
   double g0 = 0.0, g1 = 0.0;
   if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }          // clamped index 0 when out of range: harmless
   const int n = (f + 1) * p;
-  for (int e0 = 0; e0 < n; e0 += 64 * 16) {
+#pragma unroll
+  for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; if (e < n) PL[e] = q.v[u]; }
+  for (int e0 = 64 * 16; e0 < n; e0 += 64 * 16) {
     double v[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; v[u] = Lp[e < n ? e : n - 1]; }
@@ -640,6 +718,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane < b) xb[lane] = g0;
   if (lane + 64 < b) xb[lane + 64] = g1;
   __builtin_amdgcn_wave_barrier();
+  mid();                                                             // (may overwrite q)
   double tj = 0.0, dinv = 0.0;
   {
 #ifndef PPS_NO_FMA
@@ -670,27 +749,115 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane < b) Xs[p + lane] = g0;
   if (lane + 64 < b) Xs[p + lane + 64] = g1;
 }
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
+  SolvePre q;
+  solve_issue(d, rec, threadIdx.x & 63, q);
+  wave_front_solve(d, rec, q, W, X, slot, NoHook());
+}
 
+// A wave's fronts inside a group: fronts wave, wave + nw, ... of every local level.  (level, index) of the next one at or
+// after local level l in walking direction DIR (+1: factorisation, leaves first; -1: back-substitution); level == lend: none.
+template <int DIR>
+__device__ __forceinline__ void wave_next_front(const DevGraph& d, int wave, int lbeg, int lend, int& l, int& i) {
+  while (l != lend && i >= d.glvl_front_off[l + 1]) { l += DIR; i = l != lend ? d.glvl_front_off[l] + wave : 0; }
+  (void)lbeg;
+}
+
+// PIPE: the loads of a wave's next front are in flight while it back-substitutes the current one
+template <bool PIPE>
 __device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds) {
-  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
   double* X = lds + (size_t)nw * lds_doubles_per_wave;          // one local solution vector per front of the group
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
   const int g0 = d.glvl_front_off[l0];
+  if (!PIPE) {
+    for (int l = l1 - 1; l >= l0; l--) {
+      const int i1 = d.glvl_front_off[l + 1];
+      for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+        const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+        wave_front_solve(d, rec, W, X, i - g0);
+      }
+      __syncthreads();   // delta of this local level is visible to the children
+    }
+    return;
+  }
+  const int lend = l0 - 1;
+  int cl = l1 - 1, ci = d.glvl_front_off[cl] + wave;
+  wave_next_front<-1>(d, wave, l1 - 1, lend, cl, ci);
+  int rec = cl != lend ? d.frec[(size_t)ci * 16 + (lane & 15)] : 0;
+  SolvePre q;
+  if (cl != lend) solve_issue(d, rec, lane, q);
   for (int l = l1 - 1; l >= l0; l--) {
-    const int i1 = d.glvl_front_off[l + 1];
-    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
-      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
-      wave_front_solve(d, rec, W, X, i - g0);
+    while (cl == l) {
+      int nl = l, ni = ci + nw;
+      wave_next_front<-1>(d, wave, l1 - 1, lend, nl, ni);
+      const bool has_next = nl != lend;
+      const int rec_n = has_next ? d.frec[(size_t)ni * 16 + (lane & 15)] : 0;
+      wave_front_solve(d, rec, q, W, X, ci - g0, [&]() { if (has_next) solve_issue(d, rec_n, lane, q); });
+      rec = rec_n; cl = nl; ci = ni;
     }
     __syncthreads();   // delta of this local level is visible to the children
   }
 }
 
+template <bool PIPE>
 __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int grp_begin, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
-  body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+  body_band_solve<PIPE>(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// Register-only stages (every front <= 64 rows: all of C2, most stages of C3), software-pipelined per wave.  While a front
+// is being eliminated in registers its LDS triangle is dead, so the wave uses the latency of the panel steps to prepare its
+// NEXT front: record and child records requested, triangle cleared, original H entries gathered and added.  After the
+// workgroup barrier that says the children are complete only the extend-add (one memory round trip: both children at once),
+// the tile load, the panels and the stores are left on the critical path of a tree level.
+// NTMAX tile rows cover the stage's largest front; fronts that fit NTMAX - 1 take that instantiation (a 48-row front moves
+// and updates 6 tiles, not 10).  Same arithmetic, same order of every sum as wave_front_factor_reg.
+// ------------------------------------------------------------------------------------------
+template <int NTMAX, bool TWO>
+__device__ __forceinline__ void body_band_factor_pipe(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+  double* F = lds + (size_t)wave * lds_doubles_per_wave;
+  double* const Pn = F + lds_doubles_per_wave - kRegRows * kPStride;
+  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
+  const double damp = 1.0 + lambda;
+  int cl = l0, ci = d.glvl_front_off[l0] + wave;
+  wave_next_front<1>(d, wave, l0, l1, cl, ci);
+  int rec = cl != l1 ? d.frec[(size_t)ci * 16 + (lane & 15)] : 0;          // packed front record, one coalesced load
+  FrontPre<4> pre;
+  pre.crv = 0;
+  if (cl != l1) {                                                          // the wave's first front: nothing to hide behind
+    front_pre_issue(d, rec, lane, pre);
+    front_clear(rec, lane, F);
+    front_pre_finish(d, rec, lane, pre, damp, F);
+  }
+  for (int l = l0; l < l1; l++) {
+    while (cl == l) {
+      int nl = l, ni = ci + nw;
+      wave_next_front<1>(d, wave, l0, l1, nl, ni);
+      const bool has_next = nl != l1;
+      const int rec_n = has_next ? d.frec[(size_t)ni * 16 + (lane & 15)] : 0;
+      // F holds the original entries of the front; its children completed before the last barrier
+      front_extend_add<true>(d, rec, pre.crv, lane, F);
+      auto after_load = [&]() { if (has_next) { front_pre_issue(d, rec_n, lane, pre); front_clear(rec_n, lane, F); } };
+      auto before_store = [&]() { if (has_next) front_pre_finish(d, rec_n, lane, pre, damp, F); };
+      const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
+      if (NTMAX > 2 && TWO && fa <= 16 * (NTMAX - 1)) front_reg_eliminate<(NTMAX > 2 ? NTMAX - 1 : 2), false, false>(d, rec, F, Pn, after_load, before_store);
+      else front_reg_eliminate<NTMAX, false, false>(d, rec, F, Pn, after_load, before_store);
+      rec = rec_n; cl = nl; ci = ni;
+    }
+    __syncthreads();   // children of the next local level are complete and visible (same CU)
+  }
+}
+
+template <int NTMAX, bool TWO>
+__global__ __launch_bounds__(512) void k_band_factor_pipe(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
+  body_band_factor_pipe<NTMAX, TWO>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
 // REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the fused
@@ -754,14 +921,40 @@ __global__ __launch_bounds__(512) void k_band_factor_strip(DevGraph d, DualAlt a
 
 static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
 
+// A/B switches of the pipelined forms (measurement only)
+static bool pipe_factor_on() { return getenv("PPS_NO_PIPE_FACTOR") == nullptr; }
+static bool pipe_solve_on() { return getenv("PPS_NO_PIPE_SOLVE") == nullptr; }
+
+// register-only stage: the pipelined kernel whose tile rows cover the stage's largest front
+static bool pipe_two_on() { return getenv("PPS_PIPE_TWO") != nullptr; }       // A/B: fronts that fit NTMAX - 1 tile rows take their own instantiation
+template <bool TWO>
+static void launch_pipe_t(const DevGraph& d, const DualAlt& alt, int ny, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
+                          size_t bytes, int per_wave, hipStream_t st) {
+  const int fa = max_front + 1;
+  if (fa <= 32) PPS_LAUNCH((k_band_factor_pipe<2, false>), dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+  else if (fa <= 48) PPS_LAUNCH((k_band_factor_pipe<3, TWO>), dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+  else PPS_LAUNCH((k_band_factor_pipe<4, TWO>), dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+}
+static void launch_pipe(const DevGraph& d, const DualAlt& alt, int ny, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
+                        size_t bytes, int per_wave, hipStream_t st) {
+  if (pipe_two_on()) launch_pipe_t<true>(d, alt, ny, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
+  else launch_pipe_t<false>(d, alt, ny, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
+}
+
 static hipError_t ensure_band_attrs() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!g_band_attr_set[dev & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_strip), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
   }
@@ -780,7 +973,9 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     solve_per_wave = (int)(band_solve_lds_bytes(fused_solve_panel) / sizeof(double));
     bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
   }
-  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
+  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr && pipe_factor_on())
+    launch_pipe(d, DualAlt{}, 1, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
+  else if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
   else if (max_front + 1 <= kRegRowsMax && solve_per_wave == 0 && d.trace == nullptr && !d.no_strip)
     PPS_LAUNCH(k_band_factor_strip, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
@@ -795,7 +990,9 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const int per_wave = (int)(band_lds_bytes(max_front, max_front + 1 <= kRegRows && d.trace == nullptr) / sizeof(double));
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
-  if (max_front + 1 <= kRegRows && d.trace == nullptr)
+  if (max_front + 1 <= kRegRows && d.trace == nullptr && pipe_factor_on())
+    launch_pipe(d, alt, 2, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
+  else if (max_front + 1 <= kRegRows && d.trace == nullptr)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
     PPS_LAUNCH(k_band_factor_strip, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
@@ -811,9 +1008,10 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
   if (grp_count == 0) return hipSuccess;
   // per wave: xb + the largest factor panel of the stage; per workgroup: one local solution vector per front of a group
   const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
-  PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves),
-                     ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double), st, d, alt ? *alt : DualAlt{}, grp_begin,
-                     per_wave);
+  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
+  const size_t bytes = ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
+  if (pipe_solve_on()) PPS_LAUNCH(k_band_solve<true>, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
+  else PPS_LAUNCH(k_band_solve<false>, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
   return hipGetLastError();
 }
 
@@ -864,6 +1062,24 @@ __global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, in
   body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, 0, lds);
 }
 
+// register-only stage of a batch: the pipelined body (body_band_factor_pipe)
+template <int NTMAX, bool TWO>
+__global__ __launch_bounds__(512) void kb_band_factor_pipe(BatchArgs a, int stage, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
+  if ((int)blockIdx.x >= sg.grp_count) return;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
+    body_band_factor_pipe<NTMAX, TWO>(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, lds);
+    return;
+  }
+  body_band_factor_pipe<NTMAX, TWO>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, lds);
+}
+
+template <bool PIPE>
 __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
@@ -873,10 +1089,10 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
     DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
-    body_band_solve(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+    body_band_solve<PIPE>(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
     return;
   }
-  body_band_solve(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+  body_band_solve<PIPE>(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
 static std::atomic<bool> g_batch_attr_set[64];
@@ -887,7 +1103,11 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
   if (!g_batch_attr_set[dev & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor_pipe<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor_pipe<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor_pipe<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_batch_attr_set[dev & 63] = true;
   }
@@ -895,7 +1115,13 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
     const size_t bytes = (size_t)per_wave * nw * sizeof(double);
-    if (g.stage_reg_only[stg])
+    const dim3 grid(g.stage_groups[stg], a.n, a.alt ? 2 : 1);
+    if (g.stage_reg_only[stg] && pipe_factor_on()) {
+      const int fa = g.stage_max_front[stg] + 1;
+      if (fa <= 32) PPS_LAUNCH((kb_band_factor_pipe<2, false>), grid, dim3(64 * nw), bytes, st, a, stg, per_wave);
+      else if (fa <= 48) PPS_LAUNCH((kb_band_factor_pipe<3, false>), grid, dim3(64 * nw), bytes, st, a, stg, per_wave);
+      else PPS_LAUNCH((kb_band_factor_pipe<4, false>), grid, dim3(64 * nw), bytes, st, a, stg, per_wave);
+    } else if (g.stage_reg_only[stg])
       PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else
       PPS_LAUNCH(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
@@ -905,7 +1131,8 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_solve[stg], nw = g.stage_nw_solve[stg];
     const size_t bytes = ((size_t)per_wave * nw + (size_t)g.stage_grp_fronts[stg] * kBandMaxRows) * sizeof(double);
-    PPS_LAUNCH(kb_band_solve, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    if (pipe_solve_on()) PPS_LAUNCH(kb_band_solve<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    else PPS_LAUNCH(kb_band_solve<false>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
   }
   return hipGetLastError();
 }
