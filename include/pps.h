@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PPS_VERSION 100
+#define PPS_VERSION 300   /* round.minor: bump whenever a struct of this header changes layout (pps_stats grew in 200) */
 
 typedef struct pps_graph pps_graph;
 

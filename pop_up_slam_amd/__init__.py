@@ -25,6 +25,9 @@ _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 
 
+PPS_VERSION = 300      # include/pps.h: the struct layouts mirrored below
+
+
 class PpsProps(C.Structure):
     _fields_ = [
         ("epsilon2", C.c_double), ("epsilon_abs", C.c_double), ("epsilon_rel", C.c_double),
@@ -118,6 +121,11 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or make -C pop_up_slam_amd/csrc).  There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
+        # the struct mirrors below (PpsProps, PpsStats, ...) are written by hand against ONE layout of include/pps.h: a stale
+        # library -- or another one selected through PPS_LIB -- would write past the end of a Python struct, or into a shorter one
+        L.pps_version.restype = C.c_int
+        if L.pps_version() != PPS_VERSION:
+            raise ImportError(f"{LIB_PATH} reports PPS_VERSION {L.pps_version()}, this binding mirrors {PPS_VERSION}: rebuild the library")
         L.pps_last_error.restype = C.c_char_p
         L.pps_last_error.argtypes = [C.c_void_p]
         L.pps_default_props.argtypes = [C.POINTER(PpsProps)]

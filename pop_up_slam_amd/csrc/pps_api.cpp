@@ -123,7 +123,7 @@ struct pps_graph {
   bool up_inflight = false;      // upload_all left copies from the pinned buffers in flight on `stream`
   double* state_pin = nullptr; size_t state_pin_cap = 0;     // pinned staging of upload_state / download_state
   std::unordered_map<std::string, double> up_laps;         // PPS_UPLOAD_TIMING=1: seconds per phase of upload_all, summed; printed at destroy
-  struct UpPatch { size_t off, len; };
+  struct UpPatch { size_t off, len; bool exact8 = false; };   // exact8: 8-byte granularity, nothing around the piece may be written
   std::vector<UpPatch> up_patches;
   char* patch_host = nullptr; size_t patch_cap = 0;    // pinned: [table | data]
   char* patch_dev = nullptr; size_t patch_dev_cap = 0;
@@ -251,7 +251,7 @@ void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force) {
   if (n == 0) return;
   char* mir = g->stage + o;
   g->up_bytes_total += n;
-  if (g->up_unknown || force) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n}); return; }
+  if (g->up_unknown || force) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n, false}); return; }
   // first and last 64-byte chunk that differs from what the device holds (4 KB strides first: most arrays of a frame loop
   // are unchanged from end to end, or up to a short tail)
   size_t lo = 0, hi = n;
@@ -262,23 +262,28 @@ void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force) {
   while (hi >= lo + 64 && memcmp(mir + hi - 64, src + hi - 64, 64) == 0) hi -= 64;
   lo &= ~size_t(15);
   memcpy(mir + lo, src + lo, hi - lo);
-  g->up_patches.push_back(pps_graph::UpPatch{o + lo, hi - lo});
+  g->up_patches.push_back(pps_graph::UpPatch{o + lo, hi - lo, false});
 }
 
 // The k-th upload of a layout goes where the k-th upload of the previous layout went, as long as it fits the slot.
 // rows > 0: an SoA array of `rows` rows with leading dimension ld of which the first `used` entries per row are live -- the
 // rows are compared one by one (appending a factor touches the end of every row, not the array from end to end).
+// exact_from (rows of 8-byte values only): entries [0, exact_from) of every row are newer on the device than anywhere on the
+// host (measurements refreshed by k_refresh_measurements) -- exactly the entries [exact_from, used) are sent, byte for byte,
+// and nothing around them (a piece rounded to the 64-byte compare stride or to the 16-byte copy unit would put the mirror's
+// stale values over up to seven refreshed neighbours)
+constexpr size_t kNoExact = (size_t)-1;
 template <class T>
-int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force);
+int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from);
 template <class T>
-int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) { return dev_upload_impl(g, out, v, 0, 0, 0, false); }
+int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) { return dev_upload_impl(g, out, v, 0, 0, 0, false, kNoExact); }
 template <class T>
-int dev_upload_rows(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force) {
-  return dev_upload_impl(g, out, v, rows, ld, used, force);
+int dev_upload_rows(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from = kNoExact) {
+  return dev_upload_impl(g, out, v, rows, ld, used, force, exact_from);
 }
 
 template <class T>
-int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force) {
+int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from) {
   *out = nullptr;
   pps_graph::Arena& a = g->up;
   const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(T);
@@ -318,12 +323,21 @@ int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows,
     memset(g->stage + o, 0, fresh_cap);
     if (!v.empty()) memcpy(g->stage + o, v.data(), v.size() * sizeof(T));
     g->up_bytes_total += fresh_cap;
-    g->up_patches.push_back(pps_graph::UpPatch{o, fresh_cap});
+    g->up_patches.push_back(pps_graph::UpPatch{o, fresh_cap, false});
     return PPS_OK;
   }
   if (v.empty()) return PPS_OK;
   const char* src = reinterpret_cast<const char*>(v.data());
   if (rows == 0 || g->up_unknown) { up_diff(g, o, src, v.size() * sizeof(T), force); return PPS_OK; }
+  if (exact_from != kNoExact && !force && sizeof(T) == 8) {
+    for (size_t r = 0; r < rows; r++) {
+      const size_t ro = r * ld * sizeof(T);
+      memcpy(g->stage + o + ro, src + ro, used * sizeof(T));          // the mirror keeps the host's view of the row
+      g->up_bytes_total += used * sizeof(T);
+      if (used > exact_from) g->up_patches.push_back(pps_graph::UpPatch{o + ro + exact_from * sizeof(T), (used - exact_from) * sizeof(T), true});
+    }
+    return PPS_OK;
+  }
   for (size_t r = 0; r < rows; r++) up_diff(g, o + r * ld * sizeof(T), src + r * ld * sizeof(T), used * sizeof(T), force);
   return PPS_OK;
 }
@@ -353,7 +367,8 @@ int flush_uploads(pps_graph* g) {
     const size_t np = g->up_patches.size();
     size_t need = np * 32;
     std::vector<size_t> src_off(np);
-    for (size_t i = 0; i < np; i++) { need = (need + 15) & ~size_t(15); src_off[i] = need; need += (g->up_patches[i].len + 15) & ~size_t(15); }
+    auto plen = [&](size_t i) { const auto& pt = g->up_patches[i]; return pt.exact8 ? pt.len : ((pt.len + 15) & ~size_t(15)); };   // (exact pieces are multiples of 8)
+    for (size_t i = 0; i < np; i++) { need = (need + 15) & ~size_t(15); src_off[i] = need; need += plen(i); }
     if (need > g->patch_cap) {
       if (g->patch_host) (void)hipHostFree(g->patch_host);
       g->patch_host = nullptr; g->patch_cap = 0;
@@ -371,8 +386,8 @@ int flush_uploads(pps_graph* g) {
     long long* tab = reinterpret_cast<long long*>(g->patch_host);
     for (size_t i = 0; i < np; i++) {
       const auto& pt = g->up_patches[i];
-      tab[4 * i + 0] = (long long)pt.off; tab[4 * i + 1] = (long long)src_off[i]; tab[4 * i + 2] = (long long)((pt.len + 15) & ~size_t(15)); tab[4 * i + 3] = 0;
-      memcpy(g->patch_host + src_off[i], g->stage + pt.off, (pt.len + 15) & ~size_t(15));    // the mirror already holds the new bytes
+      tab[4 * i + 0] = (long long)pt.off; tab[4 * i + 1] = (long long)src_off[i]; tab[4 * i + 2] = (long long)plen(i); tab[4 * i + 3] = pt.exact8 ? 1 : 0;
+      memcpy(g->patch_host + src_off[i], g->stage + pt.off, plen(i));    // the mirror already holds the new bytes
     }
     HIP_TRY(g, hipMemcpyAsync(g->patch_dev, g->patch_host, need, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(g, launch_scatter_patches(g->patch_dev, (int)np, g->up.base, g->stream));
@@ -757,6 +772,7 @@ int upload_all(pps_graph* g) {
   // arena, same slot with room for the new rows, same leading dimension, no re-popping edges (their slots sit behind the
   // fixed ones and would move).
   bool keep_meas = false;
+  const size_t n_obs_on_device = (size_t)g->dev.n_obs;         // (free_device below resets g->dev)
   if (g->dev_meas_newer) {
     size_t n_obs_new = 0, n_lp_new = 0; bool any_repop = false;
     for (const HostFactor& f : g->factors) if (!f.deleted) { n_obs_new += f.type == F_PLANE_OBS; n_lp_new += f.type == F_PLANE_PRIOR; any_repop = any_repop || (f.type == F_PLANE_OBS && f.repop); }
@@ -834,7 +850,7 @@ int upload_all(pps_graph* g) {
     // only appends: the host packs its (older) copies, the mirror holds the same bytes, so nothing is sent for them and the
     // device keeps the refreshed values; only the new observations travel.  dev_meas_newer stays set.
     g->slot_obs_meas = g->up_cursor;
-    TRY(dev_upload_rows(g, &d.obs_meas, pm, 4, ld, n, g->up_unknown_meas));
+    TRY(dev_upload_rows(g, &d.obs_meas, pm, 4, ld, n, g->up_unknown_meas, keep_meas ? std::min(n, n_obs_on_device) : kNoExact));
     TRY(dev_upload_rows(g, &d.obs_w, pw, 6, ld, n, false));
   }
   d.n_obs_fixed = g->n_obs_fixed;
@@ -1374,7 +1390,12 @@ int pps_update(pps_graph* g) {
   if (g->n_live_nodes > 0 && g->n_live_factors == 0) return PPS_OK;   // no factor, no step
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
-  if (!g->status_clean) HIP_TRY(g, launch_clear_status(g->dev, g->stream));   // (else: zero since the upload / the last chi2 kernel)
+  if (!g->status_clean) {                                              // (else: zero since the upload / the last chi2 kernel)
+    HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+    // the flag stands for BOTH records: a one-step LM solve may have left a not-PD flag of a speculative factorisation that
+    // was never evaluated in the second one, and this call sets status_clean again at its end
+    if (g->spec_result) HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));
+  }
   g->status_clean = false;
   rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:116)
   rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:119)
@@ -1399,6 +1420,17 @@ int pps_update(pps_graph* g) {
 
 static int lm_solve(pps_graph* g, int* iterations);
 
+// the device copy of a handle is given up after a failed solve: streams drained, nothing on the device is trusted any more --
+// the next upload sends the whole arena (up_unknown: the mirror says nothing about the device, measurements included) and the
+// estimate falls back to the host's node values
+static void abandon_device_copy(pps_graph* g) {
+  if (!g->dev_ready) return;
+  (void)hipStreamSynchronize(g->stream);
+  if (g->stream_b) (void)hipStreamSynchronize(g->stream_b);
+  g->topo_dirty = true; g->dev_values_newer = false; g->dev_meas_newer = false;
+  g->up_unknown = true; g->up_unknown_meas = true; g->pk_meas_ok = false; g->status_clean = false;
+}
+
 // A failure in the middle of a solve (a HIP error: lost device, out of memory) leaves est / lin possibly exchanged and
 // speculative work in flight.  Both streams are drained and the device copy is abandoned: the next call uploads again from
 // the host's node values -- the estimate falls back to the last state the host has seen -- instead of reading half-updated
@@ -1412,11 +1444,7 @@ int pps_batch_optimize(pps_graph* g, int* iterations) {
     return PPS_OK;
   }
   const int rc = lm_solve(g, iterations);
-  if (rc != PPS_OK && rc != PPS_ENOTPD && g->dev_ready) {
-    (void)hipStreamSynchronize(g->stream);
-    if (g->stream_b) (void)hipStreamSynchronize(g->stream_b);
-    g->topo_dirty = true; g->dev_values_newer = false; g->dev_meas_newer = false;
-  }
+  if (rc != PPS_OK && rc != PPS_ENOTPD) abandon_device_copy(g);
   return rc;
 }
 
@@ -1719,6 +1747,25 @@ static int lm_solve(pps_graph* g, int* iterations) {
             acc[0] / A.n_fronts, acc[1] / A.n_fronts, acc[2] / A.n_fronts, acc[3] / A.n_fronts, acc[4] / A.n_fronts);
     for (int l = 0; l < A.n_levels; l++) fprintf(stderr, "  level %d: %d fronts, mean total %.0f cycles\n", l, lvl_n[l], lvl_tot[l] / std::max(1, lvl_n[l]));
     {
+      // per level: the phases, and how long a front's start lies behind the end of its last child (barrier, launch boundary,
+      // record load) -- the part of a tree level that no phase accounts for
+      std::vector<long long> last_child_end(A.n_fronts, 0);
+      for (int s2 = 0; s2 < A.n_fronts; s2++) if (A.f_parent[s2] >= 0) last_child_end[A.f_parent[s2]] = std::max(last_child_end[A.f_parent[s2]], tr[(size_t)s2 * 8 + 5]);
+      for (int l = 0; l < A.n_levels; l++) {
+        double ph[7] = {0, 0, 0, 0, 0, 0, 0}, gap = 0; int n = 0, ng = 0;
+        for (int s2 = 0; s2 < A.n_fronts; s2++) {
+          if (A.f_level[s2] != l) continue;
+          n++;
+          for (int k = 0; k < 5; k++) ph[k] += (double)(tr[(size_t)s2 * 8 + k + 1] - tr[(size_t)s2 * 8 + k]);
+          ph[5] += (double)tr[(size_t)s2 * 8 + 6]; ph[6] += (double)tr[(size_t)s2 * 8 + 7];
+          if (last_child_end[s2] > 0) { gap += (double)(tr[(size_t)s2 * 8] - last_child_end[s2]); ng++; }
+        }
+        if (!n) continue;
+        fprintf(stderr, "  level %d: zero %.0f gather %.0f extend-add %.0f eliminate %.0f (panel %.0f trailing %.0f) store %.0f | start after last child's end %.0f\n", l,
+                ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[5] / n, ph[6] / n, ph[4] / n, ng ? gap / ng : 0.0);
+      }
+    }
+    {
       double w[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nw2 = 0;
       for (int s2 = 0; s2 < A.n_fronts; s2++) {
         if (A.f_p[s2] + A.f_b[s2] + 1 <= 64) continue;
@@ -1800,8 +1847,19 @@ int pps_multi_destroy(pps_multi* m) {
 
 const char* pps_multi_last_error(const pps_multi* m) { return m ? m->err.c_str() : "null handle"; }
 
+static int multi_optimize(pps_multi* m, int* iterations, int* status);
+
 int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
   if (!m) return PPS_EINVAL;
+  const int rc = multi_optimize(m, iterations, status);
+  if (rc != PPS_OK && rc != PPS_ENOTPD && rc != PPS_EINVAL && rc != PPS_ESTATE) {       // a HIP failure in the middle of the rounds: as a failed single solve
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (pps_graph* g : m->gs) abandon_device_copy(g);
+  }
+  return rc;
+}
+
+static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   const double t0 = now_s();
   const int G = (int)m->gs.size();
   if (hipSetDevice(m->device) != hipSuccess) return mfail(m, PPS_EHIP, "hipSetDevice failed (no HIP device: there is no CPU fallback)");

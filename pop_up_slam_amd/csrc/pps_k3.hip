@@ -203,10 +203,12 @@ int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
 size_t band_lds_bytes(int max_front, bool reg_only_kernel) {       // (the register-only kernels keep a 64-row panel buffer, the others 80 rows: strip)
   const size_t fa = (size_t)max_front + 1;
-  return (fa * (fa + 1) / 2 + (reg_only_kernel ? kRegRows : kRegRowsMax) * kPStride) * sizeof(double);
-}   // packed triangle + panel buffer
+  return (fa * (fa + 1) / 2 + 1 + (reg_only_kernel ? kRegRows : kRegRowsMax) * kPStride) * sizeof(double);
+}   // packed triangle + one spare double (where masked-off lanes of a scatter-add land: P[-1]) + panel buffer
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+// the same for 0 <= i < 4096 with the full-rate 24-bit multiplier (per-lane index arithmetic of the register-tile code)
+__device__ __forceinline__ int tri24(int i) { return __mul24(i, i + 1) >> 1; }
 
 // One row of 16x16 tiles (I, J = o, o+16, ..., I) of the trailing lower triangle gets its rank-nb
 // update C -= P_I P_J^T: all LDS reads are issued unconditionally from clamped (always valid)
@@ -401,27 +403,37 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
 // P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
 // ------------------------------------------------------------------------------------------
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int NT, bool TR, bool STRIP, class AfterLoad, class BeforeStore>
-__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P, AfterLoad after_load,
-                                                    BeforeStore before_store);
+template <int NT, bool TR, bool STRIP>
+__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P);
 // ---- assembly of a front's packed triangle in LDS, in pieces (one wave) ----
 // Eight scatter-add items per lane in flight: (target index, value) pairs of the front-ordered H, or of a child's packed update
 // matrix.  Issued as 16 independent coalesced loads, applied as LDS read-modify-writes (targets are unique inside one source).
 template <int N> struct ElBatch { int tg[N]; double v[N]; };
+// loads are issued unconditionally from clamped (always valid) addresses and masked by selects afterwards: predicated loads
+// become one exec-masked basic block each and serialise
 template <int N>
 __device__ __forceinline__ void el_issue(const int* __restrict__ tgp, const double* __restrict__ val, int e, int e1, int lane, ElBatch<N>& q) {
+  const int last = e1 > 0 ? e1 - 1 : 0;
 #pragma unroll
-  for (int u = 0; u < N; u++) { const int x = e + lane + 64 * u; q.tg[u] = x < e1 ? tgp[x] : -1; q.v[u] = x < e1 ? val[x] : 0.0; }
+  for (int u = 0; u < N; u++) {
+    const int x = e + lane + 64 * u, xc = x < e1 ? x : last;
+    const int t = tgp[xc]; const double v = val[xc];
+    q.tg[u] = x < e1 ? t : -1; q.v[u] = x < e1 ? v : 0.0;
+  }
 }
+// The N read-modify-writes of a batch as N reads, N adds, N writes -- one LDS round trip instead of N dependent ones.  Valid
+// because the targets of one source (the original entries of a front; one child's update matrix) are pairwise distinct;
+// items past the end go to the spare double `tr` with a zero increment, so that nothing is predicated.
 template <bool ORIG, int N>     // ORIG: entries of H (bit 30 of the target = diagonal element, damped: Cholesky.cpp:94-97)
-__device__ __forceinline__ void el_apply(const ElBatch<N>& q, double damp, double* __restrict__ F) {
+__device__ __forceinline__ void el_apply(const ElBatch<N>& q, double damp, double* __restrict__ F, int tr) {
+  int t[N]; double old[N];
 #pragma unroll
-  for (int u = 0; u < N; u++)
-    if (q.tg[u] >= 0) {
-      if (ORIG) F[q.tg[u] & 0x3fffffff] += (q.tg[u] & (1 << 30)) ? q.v[u] * damp : q.v[u];
-      else F[q.tg[u]] += q.v[u];
-    }
+  for (int u = 0; u < N; u++) { t[u] = q.tg[u] >= 0 ? (ORIG ? (q.tg[u] & 0x3fffffff) : q.tg[u]) : tr; old[u] = F[t[u]]; }
+#pragma unroll
+  for (int u = 0; u < N; u++) {
+    const double inc = (ORIG && (q.tg[u] & (1 << 30))) ? q.v[u] * damp : q.v[u];      // (tg = -1: v = 0)
+    F[t[u]] = old[u] + inc;
+  }
 }
 // what a front needs before its children are complete: first batch of its original entries and its child records (requested),
 // the cleared triangle, the original entries added.  issue -> [anything] -> finish.  NPRE items per lane are requested ahead:
@@ -441,19 +453,18 @@ __device__ __forceinline__ void front_clear(int rec, int lane, double* __restric
   __builtin_amdgcn_wave_barrier();
 }
 template <int NPRE>
-__device__ __forceinline__ void front_pre_finish(const DevGraph& d, int rec, int lane, const FrontPre<NPRE>& o, double damp, double* __restrict__ F) {
+__device__ __forceinline__ void front_pre_finish(const DevGraph& d, int rec, int lane, const FrontPre<NPRE>& o, double damp, double* __restrict__ F, int tr) {
   const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
-  el_apply<true>(o.q, damp, F);
-  for (int e = e0 + 64 * NPRE; e < e1; e += 64 * 8) { ElBatch<8> q; el_issue(d.el_tgt, d.Hf, e, e1, lane, q); el_apply<true>(q, damp, F); }
+  el_apply<true>(o.q, damp, F, tr);
+  for (int e = e0 + 64 * NPRE; e < e1; e += 64 * 8) { ElBatch<8> q; el_issue(d.el_tgt, d.Hf, e, e1, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<true>(q, damp, F, tr); }
   __builtin_amdgcn_wave_barrier();
 }
-// extend-add of the children's packed update matrices.  PAIR: the first batches of the first two children are requested
-// together (one memory round trip for a front with two children instead of two)
-template <bool PAIR>
-__device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int crv0, int lane, double* __restrict__ F) {
+// extend-add of the children's packed update matrices, child by child, one batch of 512 entries in flight (more loads in
+// flight -- both children at once, two batches per child -- measured SLOWER on MI355X: DESIGN.md section 8)
+__device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int crv0, int lane, double* __restrict__ F, int tr) {
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
   for (int cb = 0; cb < nch; cb += 8) {
-    const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);
+    const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);      // (more than 8 children: rare)
     auto child = [&](int cj, int& n, const double* __restrict__& Uc, const int* __restrict__& tgc) {
       n = __builtin_amdgcn_readlane(crv, 8 * cj);
       const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
@@ -461,29 +472,16 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
       Uc = d.U + uo; tgc = d.ea_tgt + eo;
     };
     int cj = 0;
-    if (PAIR && cb + 1 < nch) {
-      int n0, n1; const double *U0, *U1; const int *t0, *t1;
-      child(0, n0, U0, t0); child(1, n1, U1, t1);
-      ElBatch<8> a, b2;
-      el_issue(t0, U0, 0, n0, lane, a); el_issue(t1, U1, 0, n1, lane, b2);
-      el_apply<false>(a, 0.0, F);
-      for (int e = 64 * 8; e < n0; e += 64 * 8) { ElBatch<8> q; el_issue(t0, U0, e, n0, lane, q); el_apply<false>(q, 0.0, F); }
-      __builtin_amdgcn_wave_barrier();
-      el_apply<false>(b2, 0.0, F);
-      for (int e = 64 * 8; e < n1; e += 64 * 8) { ElBatch<8> q; el_issue(t1, U1, e, n1, lane, q); el_apply<false>(q, 0.0, F); }
-      __builtin_amdgcn_wave_barrier();
-      cj = 2;
-    }
     for (; cj < 8 && cb + cj < nch; cj++) {
       int n; const double* Uc; const int* tgc;
       child(cj, n, Uc, tgc);
-      for (int e = 0; e < n; e += 64 * 8) { ElBatch<8> q; el_issue(tgc, Uc, e, n, lane, q); el_apply<false>(q, 0.0, F); }
+      for (int e = 0; e < n; e += 64 * 8) { ElBatch<8> q; el_issue(tgc, Uc, e, n, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<false>(q, 0.0, F, tr); }
       __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-// One front from start to end (the strip / trace / LDS-tile kernels; the register-only stages run body_band_factor_pipe below).
+// One front from start to end.
 // TR: in-kernel phase trace (PPS_TRACE=1) compiled in
 // Fronts of 65 .. 80 rows (STRIP): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary rows, the pivots
 // are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried along panel by panel:
@@ -501,24 +499,27 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   front_pre_issue(d, rec, lane, pre);
   front_clear(rec, lane, F);
   if (TR) PPS_TR(1);
-  front_pre_finish(d, rec, lane, pre, 1.0 + lambda, F);
+  const int tr = (int)(P - F) - 1;                         // the spare double in front of the panel buffer
+  front_pre_finish(d, rec, lane, pre, 1.0 + lambda, F, tr);
   if (TR) PPS_TR(2);
-  front_extend_add<false>(d, rec, pre.crv, lane, F);
+  front_extend_add(d, rec, pre.crv, lane, F, tr);
   if (TR) PPS_TR(3);
-  front_reg_eliminate<NT, TR, STRIP>(d, rec, F, P, NoHook(), NoHook());
+  front_reg_eliminate<NT, TR, STRIP>(d, rec, F, P);
 }
 
 // Second half of a register-resident front: the assembled packed triangle in F -> register tiles -> panels -> factor panel and
-// update matrix in HBM.  after_load runs once the tiles are in registers (F is dead from then on unless STRIP), before_store
-// after the last panel: the pipelined band kernel pre-assembles the wave's NEXT front there, under the latency of the panels.
-template <int NT, bool TR, bool STRIP, class AfterLoad, class BeforeStore>
-__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P,
-                                                    AfterLoad after_load, BeforeStore before_store) {
+// update matrix in HBM.
+template <int NT, bool TR, bool STRIP>
+__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P) {
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0), p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
   const int l16 = lane & 15, lq = lane >> 4;
   const int f = p + b, fa = f + 1;
   const bool strip = STRIP && fa > kRegRows;
+  // The right-hand side rides along as row f of the front.  Without a strip it is kept as a VECTOR (lane = column) next to
+  // the tiles instead of inside them: a front of 48 rows + rhs then needs three tile rows, not four (6 MFMA per panel instead of
+  // 10, 24 tile registers to load and store instead of 40) -- every separator front of a C2 tree.  mr = rows held in the tiles.
+  const int mr = STRIP ? fa : f;
   (void)s;
   // ---- packed triangle -> register tiles ----
   double4_t c[NT * (NT + 1) / 2];
@@ -529,12 +530,13 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
-        const bool ok = row < fa && col <= row;
-        const double x = F[ok ? tri(row) + col : 0];
+        const bool ok = row < mr && col <= row;
+        const double x = F[ok ? tri24(row) + col : 0];
         c[tile_id(ti, tj)][r] = ok ? x : 0.0;
       }
+  double y = 0.0;                                              // (lane f: the rhs . rhs corner, which nothing reads)
+  if (!STRIP) { const double t = F[lane <= f ? tri24(f) + lane : 0]; y = lane < f ? t : 0.0; }
   __builtin_amdgcn_wave_barrier();
-  after_load();
   double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   long long cyc_panel = 0, cyc_trail = 0;
   for (int K = 0; K < p; K += 4) {
@@ -578,12 +580,31 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
     }
     if (bad && lane == 0) d.result_dev[2] = 1.0;           // not positive definite
     P[lane * kPStride + 0] = x0; P[lane * kPStride + 1] = x1; P[lane * kPStride + 2] = x2; P[lane * kPStride + 3] = x3;
-    if (lane < fa) {
-      double* __restrict__ lrow = Lp + (size_t)lane * p + K;
-      if (lane >= K) lrow[0] = x0;
-      if (nb > 1 && lane >= K + 1) lrow[1] = x1;
-      if (nb > 2 && lane >= K + 2) lrow[2] = x2;
-      if (nb > 3 && lane >= K + 3) lrow[3] = x3;
+    if (!STRIP) {
+      // the rhs row through the same triangular solve (its four panel entries sit in lanes K .. K+3 of y), then its rank-nb
+      // update: y_j -= sum_m L[f][K+m] L[j][K+m], lane j holding row j's panel entries x0 .. x3 already
+      const double q0 = readlane_d(y, K), q1 = readlane_d(y, K + 1), q2 = readlane_d(y, K + 2), q3 = readlane_d(y, K + 3);
+      double y0, y1, y2, y3;
+      {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)
+#endif
+        y0 = q0 * i0;
+        y1 = (q1 - y0 * l10) * i1;
+        y2 = (q2 - y0 * l20 - y1 * l21) * i2;
+        y3 = (q3 - y0 * l30 - y1 * l31 - y2 * l32) * i3;
+        y = y - x0 * y0 - x1 * y1 - x2 * y2 - x3 * y3;
+      }
+      if (lane < nb) Lp[(unsigned)(__mul24(f, p) + K + lane)] = lane == 0 ? y0 : (lane == 1 ? y1 : (lane == 2 ? y2 : y3));
+    }
+    if (lane < mr) {
+      // rows above the diagonal get whatever their lanes computed: (row, col > row) of a factor panel is never read
+      // (wave_front_solve, k_front_solve), and one exec-masked block with uniform branches replaces four masked ones
+      double* __restrict__ lrow = Lp + (unsigned)(__mul24(lane, p) + K);
+      lrow[0] = x0;
+      if (nb > 1) lrow[1] = x1;
+      if (nb > 2) lrow[2] = x2;
+      if (nb > 3) lrow[3] = x3;
     }
     if (STRIP && strip) {
       const double q0 = P[row2 * kPStride + 0], q1 = P[row2 * kPStride + 1], q2 = P[row2 * kPStride + 2], q3 = P[row2 * kPStride + 3];
@@ -649,22 +670,35 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
   }
   if (TR) PPS_TR(4);
   if (TR && d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
-  before_store();
   // ---- update matrix: live part of the tiles -> packed global ----
+  // Every store is issued by all lanes: an entry that does not exist (row >= fa, col > row, col < p) goes to the last double of
+  // the front's (b+1) x (b+1) slab, which the packed triangle never reaches -- no exec-masked block per store, the sixteen row
+  // bases are computed once, and whole tiles left of the pivots or below the front are skipped by wave-uniform branches.
   double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
+  const unsigned trash_u = (unsigned)(__mul24(b + 1, b + 1) - 1);
 #pragma unroll
-  for (int ti = 0; ti < NT; ti++)
+  for (int ti = 0; ti < NT; ti++) {
+    if (16 * ti >= mr) continue;                             // (wave-uniform)
+    int rbase[4]; bool rok[4];
 #pragma unroll
-    for (int tj = 0; tj <= ti; tj++)
+    for (int r = 0; r < 4; r++) { const int row = 16 * ti + lq + 4 * r; rok[r] = row < mr; rbase[r] = tri24(row - p) - p; }
+#pragma unroll
+    for (int tj = 0; tj <= ti; tj++) {
+      if (16 * tj + 15 < p) continue;                        // (wave-uniform)
+      const int col = 16 * tj + l16;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
-        if (row < fa && col <= row && col >= p) Us[tri(row - p) + col - p] = c[tile_id(ti, tj)][r];
+        const int row = 16 * ti + lq + 4 * r;
+        const bool ok = rok[r] && col <= row && col >= p;
+        Us[ok ? (unsigned)(rbase[r] + col) : trash_u] = c[tile_id(ti, tj)][r];
       }
+    }
+  }
   if (STRIP && strip) {
     for (int r = kRegRows; r < fa; r++)
       for (int col = p + lane; col <= r; col += 64) Us[tri(r - p) + col - p] = F[tri(r) + col];
   }
+  if (!STRIP) Us[(lane >= p && lane <= f) ? (unsigned)(tri24(b) + lane - p) : trash_u] = lane < f ? y : 0.0;      // the rhs row of the update matrix
   if (TR) PPS_TR(5);
 }
 
@@ -673,43 +707,27 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
 // copied to LDS in batches of 16 independent coalesced loads per lane -- two round trips for a C2 front instead of one
 // per 8 rows -- and everything after that reads LDS; the back-substitution chain runs in registers (lane j holds
 // t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + the panel.
-// What does not depend on the parent's solution -- the first 1024 panel entries and the boundary index list -- is requested
-// ahead (solve_issue) and consumed by wave_front_solve; `mid` runs between the last memory access of the front and its
-// arithmetic: the band kernel requests the wave's NEXT front there, so those loads travel under the back-substitution.
-struct SolvePre { double v[16]; int ix0, ix1; };
-__device__ __forceinline__ void solve_issue(const DevGraph& d, int rec, int lane, SolvePre& q) {
-  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
-  const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
-  const int pslot = __builtin_amdgcn_readlane(rec, 14);
-  // boundary values: from the parent's local solution vector in LDS (through cmap) when the parent was solved by this
-  // workgroup, else gathered from delta
-  const int* __restrict__ ix = pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8);
-  q.ix0 = lane < b ? ix[lane] : 0; q.ix1 = lane + 64 < b ? ix[lane + 64] : 0;
-  const int n = (f + 1) * p;
-#pragma unroll
-  for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; q.v[u] = Lp[e < n ? e : n - 1]; }
-}
-
-template <class Mid>
-__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, SolvePre& q, double* __restrict__ W, double* __restrict__ X, int slot, Mid mid) {
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
   const int lane = threadIdx.x & 63;
   const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
   const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   const int pslot = __builtin_amdgcn_readlane(rec, 14);
+  // boundary values: from the parent's local solution vector in LDS (through cmap) when the parent was solved by this
+  // workgroup, else gathered from delta.  The index load does not depend on the parent and is issued first.
+  const int* __restrict__ ix = pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8);
   double* xb = W;
   double* PL = W + kBandMaxRows;
-  const int ix0 = q.ix0, ix1 = q.ix1;
+  const int ix0 = lane < b ? ix[lane] : 0, ix1 = lane + 64 < b ? ix[lane + 64] : 0;
   double g0 = 0.0, g1 = 0.0;
   if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }          // clamped index 0 when out of range: harmless
   const int n = (f + 1) * p;
-#pragma unroll
-  for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; if (e < n) PL[e] = q.v[u]; }
-  for (int e0 = 64 * 16; e0 < n; e0 += 64 * 16) {
+  // (entries past the end of the panel land in xb[127], which no front uses: b <= 126 -- unpredicated LDS writes)
+  for (int e0 = 0; e0 < n; e0 += 64 * 16) {
     double v[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; v[u] = Lp[e < n ? e : n - 1]; }
 #pragma unroll
-    for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; if (e < n) PL[e] = v[u]; }
+    for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; PL[e < n ? e : -1] = v[u]; }
   }
   if (pslot >= 0) {
     const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows;
@@ -718,7 +736,6 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, Sol
   if (lane < b) xb[lane] = g0;
   if (lane + 64 < b) xb[lane + 64] = g1;
   __builtin_amdgcn_wave_barrier();
-  mid();                                                             // (may overwrite q)
   double tj = 0.0, dinv = 0.0;
   {
 #ifndef PPS_NO_FMA
@@ -749,122 +766,33 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, Sol
   if (lane < b) Xs[p + lane] = g0;
   if (lane + 64 < b) Xs[p + lane + 64] = g1;
 }
-__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
-  SolvePre q;
-  solve_issue(d, rec, threadIdx.x & 63, q);
-  wave_front_solve(d, rec, q, W, X, slot, NoHook());
-}
-
-// A wave's fronts inside a group: fronts wave, wave + nw, ... of every local level.  (level, index) of the next one at or
-// after local level l in walking direction DIR (+1: factorisation, leaves first; -1: back-substitution); level == lend: none.
-template <int DIR>
-__device__ __forceinline__ void wave_next_front(const DevGraph& d, int wave, int lbeg, int lend, int& l, int& i) {
-  while (l != lend && i >= d.glvl_front_off[l + 1]) { l += DIR; i = l != lend ? d.glvl_front_off[l] + wave : 0; }
-  (void)lbeg;
-}
-
-// PIPE: the loads of a wave's next front are in flight while it back-substitutes the current one
-template <bool PIPE>
 __device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds) {
-  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
   double* X = lds + (size_t)nw * lds_doubles_per_wave;          // one local solution vector per front of the group
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
   const int g0 = d.glvl_front_off[l0];
-  if (!PIPE) {
-    for (int l = l1 - 1; l >= l0; l--) {
-      const int i1 = d.glvl_front_off[l + 1];
-      for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
-        const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
-        wave_front_solve(d, rec, W, X, i - g0);
-      }
-      __syncthreads();   // delta of this local level is visible to the children
-    }
-    return;
-  }
-  const int lend = l0 - 1;
-  int cl = l1 - 1, ci = d.glvl_front_off[cl] + wave;
-  wave_next_front<-1>(d, wave, l1 - 1, lend, cl, ci);
-  int rec = cl != lend ? d.frec[(size_t)ci * 16 + (lane & 15)] : 0;
-  SolvePre q;
-  if (cl != lend) solve_issue(d, rec, lane, q);
   for (int l = l1 - 1; l >= l0; l--) {
-    while (cl == l) {
-      int nl = l, ni = ci + nw;
-      wave_next_front<-1>(d, wave, l1 - 1, lend, nl, ni);
-      const bool has_next = nl != lend;
-      const int rec_n = has_next ? d.frec[(size_t)ni * 16 + (lane & 15)] : 0;
-      wave_front_solve(d, rec, q, W, X, ci - g0, [&]() { if (has_next) solve_issue(d, rec_n, lane, q); });
-      rec = rec_n; cl = nl; ci = ni;
+    const int i1 = d.glvl_front_off[l + 1];
+    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+      wave_front_solve(d, rec, W, X, i - g0);
     }
     __syncthreads();   // delta of this local level is visible to the children
   }
 }
 
-template <bool PIPE>
 __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int grp_begin, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
-  body_band_solve<PIPE>(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
-}
-
-// ------------------------------------------------------------------------------------------
-// Register-only stages (every front <= 64 rows: all of C2, most stages of C3), software-pipelined per wave.  While a front
-// is being eliminated in registers its LDS triangle is dead, so the wave uses the latency of the panel steps to prepare its
-// NEXT front: record and child records requested, triangle cleared, original H entries gathered and added.  After the
-// workgroup barrier that says the children are complete only the extend-add (one memory round trip: both children at once),
-// the tile load, the panels and the stores are left on the critical path of a tree level.
-// NTMAX tile rows cover the stage's largest front; fronts that fit NTMAX - 1 take that instantiation (a 48-row front moves
-// and updates 6 tiles, not 10).  Same arithmetic, same order of every sum as wave_front_factor_reg.
-// ------------------------------------------------------------------------------------------
-template <int NTMAX, bool TWO>
-__device__ __forceinline__ void body_band_factor_pipe(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
-  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
-  double* F = lds + (size_t)wave * lds_doubles_per_wave;
-  double* const Pn = F + lds_doubles_per_wave - kRegRows * kPStride;
-  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
-  const double damp = 1.0 + lambda;
-  int cl = l0, ci = d.glvl_front_off[l0] + wave;
-  wave_next_front<1>(d, wave, l0, l1, cl, ci);
-  int rec = cl != l1 ? d.frec[(size_t)ci * 16 + (lane & 15)] : 0;          // packed front record, one coalesced load
-  FrontPre<4> pre;
-  pre.crv = 0;
-  if (cl != l1) {                                                          // the wave's first front: nothing to hide behind
-    front_pre_issue(d, rec, lane, pre);
-    front_clear(rec, lane, F);
-    front_pre_finish(d, rec, lane, pre, damp, F);
-  }
-  for (int l = l0; l < l1; l++) {
-    while (cl == l) {
-      int nl = l, ni = ci + nw;
-      wave_next_front<1>(d, wave, l0, l1, nl, ni);
-      const bool has_next = nl != l1;
-      const int rec_n = has_next ? d.frec[(size_t)ni * 16 + (lane & 15)] : 0;
-      // F holds the original entries of the front; its children completed before the last barrier
-      front_extend_add<true>(d, rec, pre.crv, lane, F);
-      auto after_load = [&]() { if (has_next) { front_pre_issue(d, rec_n, lane, pre); front_clear(rec_n, lane, F); } };
-      auto before_store = [&]() { if (has_next) front_pre_finish(d, rec_n, lane, pre, damp, F); };
-      const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      if (NTMAX > 2 && TWO && fa <= 16 * (NTMAX - 1)) front_reg_eliminate<(NTMAX > 2 ? NTMAX - 1 : 2), false, false>(d, rec, F, Pn, after_load, before_store);
-      else front_reg_eliminate<NTMAX, false, false>(d, rec, F, Pn, after_load, before_store);
-      rec = rec_n; cl = nl; ci = ni;
-    }
-    __syncthreads();   // children of the next local level are complete and visible (same CU)
-  }
-}
-
-template <int NTMAX, bool TWO>
-__global__ __launch_bounds__(512) void k_band_factor_pipe(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
-  extern __shared__ double lds[];
-  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
-  body_band_factor_pipe<NTMAX, TWO>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
+  body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
 // REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the fused
 // root solve are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
 // REG_STRIP (with REG_ONLY): the stage also holds fronts of 65 .. 80 rows -- ten register tiles + the LDS strip -- and still
 // nothing that needs the LDS-tile path, the trace or the fused root solve (frame-loop trees, C3)
-template <bool REG_ONLY, bool REG_STRIP = false>
+template <bool REG_ONLY, bool REG_STRIP = false, bool TR = false>
 __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave,
                                                  int solve_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -877,9 +805,9 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
       double* const Pn = F + lds_doubles_per_wave - ((REG_ONLY && !REG_STRIP) ? kRegRows : kRegRowsMax) * kPStride;
-      if (REG_ONLY && fa <= 32) wave_front_factor_reg<2, false>(d, rec, lambda, F, Pn);
-      else if (REG_ONLY && fa <= 48) wave_front_factor_reg<3, false>(d, rec, lambda, F, Pn);
-      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, false>(d, rec, lambda, F, Pn);
+      if (REG_ONLY && fa <= 33) wave_front_factor_reg<2, TR>(d, rec, lambda, F, Pn);                    // (without a strip the rhs row is a vector next to the tiles)
+      else if (REG_ONLY && fa <= 49) wave_front_factor_reg<3, TR>(d, rec, lambda, F, Pn);
+      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, TR>(d, rec, lambda, F, Pn);
       else if (REG_ONLY) wave_front_factor_reg<4, false, true>(d, rec, lambda, F, Pn);                   // 65 .. 80 rows: register tiles + LDS strip
       else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true, true>(d, rec, lambda, F, Pn);
       else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);
@@ -913,6 +841,12 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, in
   body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, solve_doubles_per_wave, lds);
 }
 
+// PPS_TRACE=1 PPS_TRACE_LEAN=1: the phase trace compiled into the register-only (one front at a time) kernel
+__global__ __launch_bounds__(512) void k_band_factor_lean_trace(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  body_band_factor<true, false, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, 0, lds);
+}
+
 __global__ __launch_bounds__(512) void k_band_factor_strip(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
@@ -921,40 +855,15 @@ __global__ __launch_bounds__(512) void k_band_factor_strip(DevGraph d, DualAlt a
 
 static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
 
-// A/B switches of the pipelined forms (measurement only)
-static bool pipe_factor_on() { return getenv("PPS_NO_PIPE_FACTOR") == nullptr; }
-static bool pipe_solve_on() { return getenv("PPS_NO_PIPE_SOLVE") == nullptr; }
-
-// register-only stage: the pipelined kernel whose tile rows cover the stage's largest front
-static bool pipe_two_on() { return getenv("PPS_PIPE_TWO") != nullptr; }       // A/B: fronts that fit NTMAX - 1 tile rows take their own instantiation
-template <bool TWO>
-static void launch_pipe_t(const DevGraph& d, const DualAlt& alt, int ny, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                          size_t bytes, int per_wave, hipStream_t st) {
-  const int fa = max_front + 1;
-  if (fa <= 32) PPS_LAUNCH((k_band_factor_pipe<2, false>), dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
-  else if (fa <= 48) PPS_LAUNCH((k_band_factor_pipe<3, TWO>), dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
-  else PPS_LAUNCH((k_band_factor_pipe<4, TWO>), dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
-}
-static void launch_pipe(const DevGraph& d, const DualAlt& alt, int ny, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                        size_t bytes, int per_wave, hipStream_t st) {
-  if (pipe_two_on()) launch_pipe_t<true>(d, alt, ny, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
-  else launch_pipe_t<false>(d, alt, ny, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
-}
-
 static hipError_t ensure_band_attrs() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!g_band_attr_set[dev & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_strip), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pipe<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_lean_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
   }
@@ -973,9 +882,12 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     solve_per_wave = (int)(band_solve_lds_bytes(fused_solve_panel) / sizeof(double));
     bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
   }
-  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr && pipe_factor_on())
-    launch_pipe(d, DualAlt{}, 1, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
-  else if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
+  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace != nullptr && getenv("PPS_TRACE_LEAN")) {      // phase trace of the register-only kernel
+    const int pw = (int)(band_lds_bytes(max_front, true) / sizeof(double));
+    PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count), dim3(64 * nwaves), (size_t)pw * nwaves * sizeof(double), st, d, DualAlt{}, grp_begin, lambda, pw);
+    return hipGetLastError();
+  }
+  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
   else if (max_front + 1 <= kRegRowsMax && solve_per_wave == 0 && d.trace == nullptr && !d.no_strip)
     PPS_LAUNCH(k_band_factor_strip, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
@@ -990,9 +902,7 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const int per_wave = (int)(band_lds_bytes(max_front, max_front + 1 <= kRegRows && d.trace == nullptr) / sizeof(double));
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
-  if (max_front + 1 <= kRegRows && d.trace == nullptr && pipe_factor_on())
-    launch_pipe(d, alt, 2, grp_begin, grp_count, nwaves, max_front, lambda, bytes, per_wave, st);
-  else if (max_front + 1 <= kRegRows && d.trace == nullptr)
+  if (max_front + 1 <= kRegRows && d.trace == nullptr)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
     PPS_LAUNCH(k_band_factor_strip, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
@@ -1010,8 +920,7 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
   const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const size_t bytes = ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
-  if (pipe_solve_on()) PPS_LAUNCH(k_band_solve<true>, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
-  else PPS_LAUNCH(k_band_solve<false>, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
+  PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
   return hipGetLastError();
 }
 
@@ -1062,24 +971,6 @@ __global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, in
   body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, 0, lds);
 }
 
-// register-only stage of a batch: the pipelined body (body_band_factor_pipe)
-template <int NTMAX, bool TWO>
-__global__ __launch_bounds__(512) void kb_band_factor_pipe(BatchArgs a, int stage, int lds_doubles_per_wave) {
-  extern __shared__ double lds[];
-  PPS_BATCH_PROLOGUE(BF_ACTIVE)
-  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
-  if ((int)blockIdx.x >= sg.grp_count) return;
-  if (blockIdx.z) {
-    const BatchAlt al = load_alt(a.alt + a.b0 + b);
-    DevGraph d2 = d;
-    d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
-    body_band_factor_pipe<NTMAX, TWO>(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, lds);
-    return;
-  }
-  body_band_factor_pipe<NTMAX, TWO>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, lds);
-}
-
-template <bool PIPE>
 __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
@@ -1089,10 +980,10 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
     DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
-    body_band_solve<PIPE>(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+    body_band_solve(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
     return;
   }
-  body_band_solve<PIPE>(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+  body_band_solve(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
 static std::atomic<bool> g_batch_attr_set[64];
@@ -1103,11 +994,7 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
   if (!g_batch_attr_set[dev & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor_pipe<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor_pipe<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor_pipe<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_batch_attr_set[dev & 63] = true;
   }
@@ -1115,13 +1002,7 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
     const size_t bytes = (size_t)per_wave * nw * sizeof(double);
-    const dim3 grid(g.stage_groups[stg], a.n, a.alt ? 2 : 1);
-    if (g.stage_reg_only[stg] && pipe_factor_on()) {
-      const int fa = g.stage_max_front[stg] + 1;
-      if (fa <= 32) PPS_LAUNCH((kb_band_factor_pipe<2, false>), grid, dim3(64 * nw), bytes, st, a, stg, per_wave);
-      else if (fa <= 48) PPS_LAUNCH((kb_band_factor_pipe<3, false>), grid, dim3(64 * nw), bytes, st, a, stg, per_wave);
-      else PPS_LAUNCH((kb_band_factor_pipe<4, false>), grid, dim3(64 * nw), bytes, st, a, stg, per_wave);
-    } else if (g.stage_reg_only[stg])
+    if (g.stage_reg_only[stg])
       PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else
       PPS_LAUNCH(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
@@ -1131,8 +1012,7 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_solve[stg], nw = g.stage_nw_solve[stg];
     const size_t bytes = ((size_t)per_wave * nw + (size_t)g.stage_grp_fronts[stg] * kBandMaxRows) * sizeof(double);
-    if (pipe_solve_on()) PPS_LAUNCH(kb_band_solve<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
-    else PPS_LAUNCH(kb_band_solve<false>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    PPS_LAUNCH(kb_band_solve, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
   }
   return hipGetLastError();
 }

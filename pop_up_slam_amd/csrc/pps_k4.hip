@@ -401,6 +401,12 @@ hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipSt
 __global__ __launch_bounds__(256) void k_scatter_patches(const char* __restrict__ patch, char* __restrict__ arena) {
   const long long* tab = reinterpret_cast<const long long*>(patch) + 4 * (size_t)blockIdx.x;
   const long long dst = tab[0], src = tab[1], len = tab[2];
+  if (tab[3]) {                  // an exact piece: 8-byte units (refreshed measurements sit right next to it)
+    const long long* s8 = reinterpret_cast<const long long*>(patch + src);
+    long long* d8 = reinterpret_cast<long long*>(arena + dst);
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len / 8; i += (long long)gridDim.y * 256) d8[i] = s8[i];
+    return;
+  }
   const int4* s4 = reinterpret_cast<const int4*>(patch + src);
   int4* d4 = reinterpret_cast<int4*>(arena + dst);
   for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len / 16; i += (long long)gridDim.y * 256) d4[i] = s4[i];
