@@ -4,7 +4,8 @@
 namespace pps {
 
 // ------------------------------------------------------------------------------------------
-// K2: one wavefront per H-block segment; lane = block entry, loop over <= seg_len contributions.
+// K2, latency form (one graph): one wavefront per H-block segment; lane = block entry, loop over <= seg_len contributions,
+// every lane fetching its own scalars (two contributions' loads in flight).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
   const int seg = uni(bx * 4 + (threadIdx.x >> 6));
@@ -76,84 +77,92 @@ __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
 
 __global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hblocks(d, blockIdx.x); }
 
-// Throughput form (many graphs per launch): a wave takes S consecutive segments.  The three dependent round trips of a
-// segment -- record, contribution descriptors, Jacobian slices -- are each issued for all S segments before the first
-// answer is needed; the sums run in the order of body_hblocks (contribution by contribution, k ascending), bit for bit.
+// ------------------------------------------------------------------------------------------
+// K2, throughput form (many graphs per launch).  The Jacobian slices of a segment's contributions are staged in LDS first --
+// three coalesced loads per contribution (the row node's block, the column node's block, the residual), a chunk of eight
+// contributions in flight at once -- and the products read LDS.  In the latency form every J element is fetched a dozen times
+// over by different lanes, which makes a large batch bound by the texture-address path (kb_hblocks_t: 21.0 -> 14.9 ms per
+// G = 128 batch solve); on a single graph the extra LDS round trip costs more than it saves (C3: 87.6 -> 96.9 us), so the
+// latency form stays there.  Sums run contribution by contribution, k ascending, as explicit multiply-adds: same bits.
+// ------------------------------------------------------------------------------------------
+constexpr int kH2Slots = 8;          // contributions staged per chunk
+constexpr int kH2Stride = 80;        // doubles per slot: [row block <= 36 | column block <= 36 | residual <= 6 | pad]
+constexpr int kH2WaveDoubles = kH2Slots * kH2Stride;
+
+__device__ __forceinline__ void wave_hblock_segment(const DevGraph& d, int seg, double* __restrict__ S) {
+  const int lane = threadIdx.x & 63;
+  // one coalesced load of the packed segment record, fields broadcast with v_readlane
+  const int rec = d.srec[(size_t)seg * 8 + (lane & 7)];
+  const int rows = __builtin_amdgcn_readlane(rec, 0), cols = __builtin_amdgcn_readlane(rec, 1), size = __builtin_amdgcn_readlane(rec, 2);
+  const int c0 = __builtin_amdgcn_readlane(rec, 3), cnt = __builtin_amdgcn_readlane(rec, 4);
+  const int hoff = __builtin_amdgcn_readlane(rec, 5), doff = __builtin_amdgcn_readlane(rec, 6), nsegb = __builtin_amdgcn_readlane(rec, 7);
+  // one contribution descriptor per lane, fetched in a single coalesced load (cnt <= 64)
+  int4 mine = make_int4(0, 0, 0, 0);
+  if (lane < cnt) mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
+  const int rc = rows * cols;
+  const bool act = lane < size;
+  // where the finished entry goes in front-gather order: does not depend on the values, so the load is issued now
+  const int dst = (act && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
+  const bool is_g = lane >= rc;
+  const int cdiv_ = cols > 0 ? cols : 1;
+  const int i = is_g ? lane - rc : lane / cdiv_;
+  const int j = is_g ? 0 : lane - (lane / cdiv_) * cdiv_;
+  const double* __restrict__ J = d.J;
+  double acc = 0.0;
+  for (int cb = 0; cb < cnt; cb += kH2Slots) {
+    const int nc = cnt - cb < kH2Slots ? cnt - cb : kH2Slots;
+    // All loads of the chunk are issued before the first LDS write (a rolled loop would wait for every contribution's data
+    // before requesting the next one's).  Lanes past a slice repeat its last element and slots past the chunk repeat its last
+    // contribution -- the same value to the same LDS word, or to a slot nobody reads -- so nothing is predicated (skipping the
+    // unused slots by wave-uniform branches measured slower: 18.1 against 14.9 ms of K2 per G = 128 batch solve).
+    double xv[kH2Slots], xu[kH2Slots], xr[kH2Slots];
+    int lv[kH2Slots], lu[kH2Slots], lr[kH2Slots];
+#pragma unroll
+    for (int u = 0; u < kH2Slots; u++) {
+      const int cu = cb + (u < nc ? u : nc - 1);
+      const int jv = __builtin_amdgcn_readlane(mine.x, cu), ju = __builtin_amdgcn_readlane(mine.y, cu);
+      const int ro = __builtin_amdgcn_readlane(mine.z, cu), m = __builtin_amdgcn_readlane(mine.w, cu);
+      const int nv = m * rows - 1, nu = m * cols - 1, nr = m - 1;
+      lv[u] = lane < nv ? lane : nv; lu[u] = lane < nu ? lane : nu; lr[u] = lane < nr ? lane : nr;
+      xv[u] = J[jv + lv[u]]; xu[u] = J[ju + lu[u]]; xr[u] = J[ro + lr[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kH2Slots; u++) {
+      double* __restrict__ slot = S + u * kH2Stride;
+      slot[lv[u]] = xv[u]; slot[36 + lu[u]] = xu[u]; slot[72 + lr[u]] = xr[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int u = 0; u < nc; u++) {
+      const int m = __builtin_amdgcn_readlane(mine.w, cb + u);
+      const double* __restrict__ slot = S + u * kH2Stride;
+      const double* __restrict__ pa = slot + i;
+      const double* __restrict__ pb = is_g ? slot + 72 : slot + 36 + j;
+      const int sb = is_g ? 1 : cols;
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc = PPS_MAC(acc, pa[k * rows], pb[k * sb]);
+      if (m > 3) {
+#pragma unroll
+        for (int k = 3; k < 6; k++) acc = PPS_MAC(acc, pa[k * rows], pb[k * sb]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!act) return;
+  if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
+  d.H[hoff + lane] = acc;
+  if (dst >= 0) d.Hf[dst] = acc;                          // final value (single-segment block): also where its front gathers it
+}
+
+// Throughput form (many graphs per launch): a wave takes S consecutive segments of the list of non-direct segments (the
+// single-observation pose-plane blocks are written by K1 itself in that mode).
 template <int S>
 __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
-  const int slot0 = uni((bx * 4 + (threadIdx.x >> 6)) * S);        // position in the list of non-direct segments
-  const int lane = threadIdx.x & 63;
-  if (slot0 >= d.n_nd_segs) return;
-  int rec[S];
-  {
-    const int sidx = (lane >> 3) < S && slot0 + (lane >> 3) < d.n_nd_segs ? d.nd_segs[slot0 + (lane >> 3)] : -1;   // lanes 8q..8q+7: segment q
-#pragma unroll
-    for (int q = 0; q < S; q++) {
-      const int sg = __builtin_amdgcn_readlane(sidx, 8 * q);
-      rec[q] = sg >= 0 ? d.srec[(size_t)sg * 8 + (lane & 7)] : 0;
-    }
-  }
-  int rows[S], cols[S], size[S], cnt[S], hoff[S], dst[S], ii[S], jj[S];
-  bool act[S], isg[S];
-  int4 mine[S];
-#pragma unroll
+  __shared__ double h2_lds[4 * kH2WaveDoubles];
+  const int wave = uni(threadIdx.x >> 6);
+  const int slot0 = uni((bx * 4 + wave) * S);        // position in the list of non-direct segments
   for (int q = 0; q < S; q++) {
-    rows[q] = __builtin_amdgcn_readlane(rec[q], 0); cols[q] = __builtin_amdgcn_readlane(rec[q], 1); size[q] = __builtin_amdgcn_readlane(rec[q], 2);
-    const int c0 = __builtin_amdgcn_readlane(rec[q], 3);
-    cnt[q] = __builtin_amdgcn_readlane(rec[q], 4); hoff[q] = __builtin_amdgcn_readlane(rec[q], 5);
-    const int doff = __builtin_amdgcn_readlane(rec[q], 6), nsegb = __builtin_amdgcn_readlane(rec[q], 7);
-    mine[q] = make_int4(0, 0, 0, 0);
-    if (lane < cnt[q]) mine[q] = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
-    act[q] = lane < size[q];                                  // size 0 for a segment past the end
-    dst[q] = (act[q] && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
-    const int rc = rows[q] * cols[q];
-    isg[q] = lane >= rc;
-    const int cq = cols[q] > 0 ? cols[q] : 1;
-    ii[q] = isg[q] ? lane - rc : lane / cq;
-    jj[q] = isg[q] ? 0 : lane - (lane / cq) * cq;
-  }
-  const double* __restrict__ J = d.J;
-  double a[S][6], bb[S][6];
-#pragma unroll
-  for (int q = 0; q < S; q++) {                               // first contribution of every segment: all loads in flight together
-    const int jv = __builtin_amdgcn_readlane(mine[q].x, 0), ju = __builtin_amdgcn_readlane(mine[q].y, 0);
-    const int ro = __builtin_amdgcn_readlane(mine[q].z, 0), mm = cnt[q] > 0 ? __builtin_amdgcn_readlane(mine[q].w, 0) : 0;
-    const double* pa = J + jv + ii[q];
-    const double* pb = isg[q] ? J + ro : J + ju + jj[q];
-    const int sb = isg[q] ? 1 : cols[q];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const bool ok = act[q] && k < mm;
-      a[q][k] = ok ? pa[k * rows[q]] : 0.0;
-      bb[q][k] = ok ? pb[k * sb] : 0.0;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a[q][k], bb[q][k]);
-    for (int c = 1; c < cnt[q]; c++) {                        // further contributions (diagonal blocks)
-      const int jv = __builtin_amdgcn_readlane(mine[q].x, c), ju = __builtin_amdgcn_readlane(mine[q].y, c);
-      const int ro = __builtin_amdgcn_readlane(mine[q].z, c), mm = __builtin_amdgcn_readlane(mine[q].w, c);
-      const double* pa = J + jv + ii[q];
-      const double* pb = isg[q] ? J + ro : J + ju + jj[q];
-      const int sb = isg[q] ? 1 : cols[q];
-      double a2[6], b2[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const bool ok = act[q] && k < mm;
-        a2[k] = ok ? pa[k * rows[q]] : 0.0;
-        b2[k] = ok ? pb[k * sb] : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a2[k], b2[k]);
-    }
-    if (act[q]) {
-      if (isg[q]) acc = -acc;                                 // b = -r (isam/Jacobian.h:98)
-      d.H[hoff[q] + lane] = acc;
-      if (dst[q] >= 0) d.Hf[dst[q]] = acc;
-    }
+    if (slot0 + q >= d.n_nd_segs) return;
+    wave_hblock_segment(d, uni(d.nd_segs[slot0 + q]), h2_lds + wave * kH2WaveDoubles);
   }
 }
 
