@@ -929,6 +929,7 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
   TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec));
   TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
+  TRY(dev_upload(g, &d.cls_off, A.cls_off)); TRY(dev_upload(g, &d.cls_fronts, A.cls_fronts));
   if (g->use_dense) { TRY(dev_upload(g, &g->d_dw_asm, g->dw_asm)); TRY(dev_upload(g, &g->d_dw_pan, g->dw_pan)); TRY(dev_upload(g, &g->d_dw_trl, g->dw_trl)); }
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
   TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
@@ -1915,6 +1916,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     q.n_stages = max_stages;
     int max_panel[32] = {0};
     for (int stg = 0; stg < 32; stg++) q.stage_reg_only[stg] = true;
+    bool level_ok = true;
     for (int i = c * kBatchMax; i < std::min(G, (c + 1) * kBatchMax); i++) {
       const pps_graph* g = m->gs[i];
       const DevGraph& d = g->dev;
@@ -1929,6 +1931,12 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.retract = std::max(q.retract, (d.n_pose + d.n_plane + 255) / 256);
       q.chi2 = std::max(q.chi2, d.chi2_blocks);
       q.n_factors_total += (long long)d.n_obs + d.n_odo + d.n_pp + d.n_lp;
+      q.n_levels = std::max(q.n_levels, A.n_levels);
+      if (A.n_levels > 64 || A.max_front + 1 > band_reg_rows() || g->dev.trace) level_ok = false;
+      for (int l = 0; l < A.n_levels && l < 64; l++) {
+        for (int c2 = 0; c2 < 3; c2++) q.lvl_cls_blocks[l][c2] = std::max(q.lvl_cls_blocks[l][c2], (A.cls_off[3 * l + c2 + 1] - A.cls_off[3 * l + c2] + 3) / 4);
+        q.lvl_blocks[l] = std::max(q.lvl_blocks[l], (A.cls_off[3 * l + 3] - A.cls_off[3 * l] + 3) / 4);
+      }
       for (int stg = 0; stg < A.n_stages; stg++) {
         q.stage_groups[stg] = std::max(q.stage_groups[stg], A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
         q.stage_nw_factor[stg] = std::max(q.stage_nw_factor[stg], g->stage_nw_factor[stg]);
@@ -1944,6 +1952,9 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
     q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES")) || getenv("PPS_MULTI_THREAD_FORM");
     q.k1_direct = (q.lin_thread_form || mode == PPS_JAC_ANALYTIC) && !getenv("PPS_MULTI_NO_DIRECT");   // the analytic sweep always runs one thread per factor
+    // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
+    q.level_form = level_ok && q.n_factors_total > 200000 && !getenv("PPS_MULTI_BANDS");
+    { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));
       q.stage_per_wave_solve[stg] = (int)(band_solve_lds_bytes(max_panel[stg]) / sizeof(double));

@@ -68,6 +68,7 @@ struct DevGraph {
   int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
   int* obs_dir = nullptr;                                   // direct (pose, plane) blocks: 3 ints per plane-observation slot (pps_symbolic.h)
   int* nd_segs = nullptr; int n_nd_segs = 0;                // H segments that are not direct
+  int *cls_off = nullptr, *cls_fronts = nullptr;             // level-per-launch lists (pps_symbolic.h)
   // ---- reductions / status ----
   double* chi2_partials = nullptr;   // one per block of the residual sweep
   int chi2_blocks = 0;
@@ -201,6 +202,13 @@ struct BatchGeom {
   int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
   int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};
   bool stage_reg_only[32] = {false};
+  // level-per-launch form (large chunks whose fronts all take the register path): one launch per tree level and size class,
+  // every front on its own wave, no groups -- more waves per SIMD on the small classes than the band kernels can hold
+  bool level_form = false;
+  int n_levels = 0;
+  int lvl_cls_blocks[64][3] = {{0}};    // workgroups (4 fronts each) per level and class: maximum over the chunk's graphs
+  int lvl_blocks[64] = {0};             // ... per level, all classes (back-substitution)
+  int solve_per_wave_all = 0;           // LDS doubles per wave of the level solve (largest panel of the chunk)
   int stage_max_front[32] = {0};    // largest front (scalars, without the rhs row) of the stage over the chunk's graphs
 };
 hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // lin <- est for every active graph

@@ -707,11 +707,14 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
 // copied to LDS in batches of 16 independent coalesced loads per lane -- two round trips for a C2 front instead of one
 // per 8 rows -- and everything after that reads LDS; the back-substitution chain runs in registers (lane j holds
 // t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + the panel.
+// GROUP: the front belongs to a band group (boundary values may come from the parent's local solution in LDS, the own solution
+// is left there for the children); false: level-per-launch form, everything through delta
+template <bool GROUP = true>
 __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
   const int lane = threadIdx.x & 63;
   const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
   const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
-  const int pslot = __builtin_amdgcn_readlane(rec, 14);
+  const int pslot = GROUP ? __builtin_amdgcn_readlane(rec, 14) : -1;
   // boundary values: from the parent's local solution vector in LDS (through cmap) when the parent was solved by this
   // workgroup, else gathered from delta.  The index load does not depend on the parent and is issued first.
   const int* __restrict__ ix = pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8);
@@ -760,6 +763,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     }
   }
   if (lane < p) d.delta[d.pidx[__builtin_amdgcn_readlane(rec, 7) + lane]] = tj;
+  if (!GROUP) return;
   // own local solution [x_p | x_b] for the children inside this group
   double* __restrict__ Xs = X + (size_t)slot * kBandMaxRows;
   if (lane < p) Xs[lane] = tj;
@@ -986,6 +990,57 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
   body_band_solve(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
+// ---- level-per-launch form of a batch (BatchGeom::level_form) ----
+// One launch per tree level and size class; a workgroup is four independent fronts (no group, no barrier), the kernel of a
+// class holds exactly its tile rows: 86 / 118 VGPRs for fronts of <= 32 / <= 48 rows against the 256 of the band kernel that
+// carries all three, so 5 / 3 waves share a SIMD instead of 2 (the 12 KB triangle of a 48-row front is what stops at 3).
+#define PPS_LEVEL_FACTOR_KERNEL(NAME, NT, WAVES)                                                                      \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(BatchArgs a, int level,   \
+                                                                                                int lds_doubles_per_wave) { \
+    extern __shared__ double lds[];                                                                                  \
+    PPS_BATCH_PROLOGUE(BF_ACTIVE)                                                                                    \
+    if (level >= d.n_levels) return;                                                                                 \
+    const int wave = uni(threadIdx.x >> 6);                                                                          \
+    const int k = d.cls_off[3 * level + (NT - 2)] + (int)blockIdx.x * 4 + wave;                                     \
+    if (k >= d.cls_off[3 * level + (NT - 2) + 1]) return;                                                           \
+    const int rec = d.frec[(size_t)d.cls_fronts[k] * 16 + (threadIdx.x & 15)];                                      \
+    double* F = lds + (size_t)wave * lds_doubles_per_wave;                                                           \
+    double* const Pn = F + lds_doubles_per_wave - kRegRows * kPStride;                                               \
+    if (blockIdx.z) {                                                                                                \
+      const BatchAlt al = load_alt(a.alt + a.b0 + b);                                                                \
+      DevGraph d2 = d;                                                                                               \
+      d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;                                  \
+      wave_front_factor_reg<NT, false>(d2, rec, a.lambda2[b], F, Pn);                                                \
+      return;                                                                                                        \
+    }                                                                                                                \
+    wave_front_factor_reg<NT, false>(d, rec, a.lambda[b], F, Pn);                                                    \
+  }
+PPS_LEVEL_FACTOR_KERNEL(kb_level_factor2, 2, 5)
+PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, 3)
+PPS_LEVEL_FACTOR_KERNEL(kb_level_factor4, 4, 2)
+#undef PPS_LEVEL_FACTOR_KERNEL
+
+__global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  if (level >= d.n_levels) return;
+  const int wave = uni(threadIdx.x >> 6);
+  const int k = d.cls_off[3 * level] + (int)blockIdx.x * 4 + wave;
+  if (k >= d.cls_off[3 * level + 3]) return;
+  const int rec = d.frec[(size_t)d.cls_fronts[k] * 16 + (threadIdx.x & 15)];
+  double* W = lds + (size_t)wave * lds_doubles_per_wave;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
+    wave_front_solve<false>(d2, rec, W, nullptr, 0);
+    return;
+  }
+  wave_front_solve<false>(d, rec, W, nullptr, 0);
+}
+
+static int level_lds_doubles(int nt) { return (int)(band_lds_bytes(16 * nt, true) / sizeof(double)); }   // fronts of <= 16 nt rows (+ rhs)
+
 static std::atomic<bool> g_batch_attr_set[64];
 
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor) {
@@ -995,8 +1050,24 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_level_factor2), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_level_factor3), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_level_factor4), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_level_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_batch_attr_set[dev & 63] = true;
+  }
+  if (g.level_form) {
+    const int nz = a.alt ? 2 : 1;
+    for (int l = 0; l < g.n_levels; l++) {
+      if (g.lvl_cls_blocks[l][0] > 0) { const int pw = level_lds_doubles(2); PPS_LAUNCH(kb_level_factor2, dim3(g.lvl_cls_blocks[l][0], a.n, nz), dim3(256), (size_t)pw * 4 * sizeof(double), st, a, l, pw); }
+      if (g.lvl_cls_blocks[l][1] > 0) { const int pw = level_lds_doubles(3); PPS_LAUNCH(kb_level_factor3, dim3(g.lvl_cls_blocks[l][1], a.n, nz), dim3(256), (size_t)pw * 4 * sizeof(double), st, a, l, pw); }
+      if (g.lvl_cls_blocks[l][2] > 0) { const int pw = level_lds_doubles(4); PPS_LAUNCH(kb_level_factor4, dim3(g.lvl_cls_blocks[l][2], a.n, nz), dim3(256), (size_t)pw * 4 * sizeof(double), st, a, l, pw); }
+    }
+    if (after_factor) (void)hipEventRecord(after_factor, st);
+    for (int l = g.n_levels - 1; l >= 0; l--)
+      if (g.lvl_blocks[l] > 0) PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)g.solve_per_wave_all * 4 * sizeof(double), st, a, l, g.solve_per_wave_all);
+    return hipGetLastError();
   }
   for (int stg = 0; stg < g.n_stages; stg++) {
     if (g.stage_groups[stg] <= 0) continue;

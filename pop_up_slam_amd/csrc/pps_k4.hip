@@ -1,6 +1,7 @@
 // pps_k4.hip -- K4: retraction (Slam::self_exmap / apply_exmap, Slam.cpp:216-234) and the chi^2 sweep whose last block
 // writes the pinned result record (Slam::weighted_errors / chi2, Slam.cpp:254-268); patch scatter of the difference upload.
 #include <algorithm>
+#include <cstdlib>
 
 #include "pps_geom.h"
 #include "pps_kcommon.h"
@@ -119,7 +120,29 @@ hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st) {
 
 constexpr int kChiBlock = 256;
 
-// bx: block within the graph, nb: blocks of the graph (the one that draws the last ticket reduces)
+// sum of the nb block partials and of the n_dn |delta|^2 partials -> the 32-byte result record (one 256-thread block)
+__device__ __forceinline__ void chi2_finish(const DevGraph& d, int nb, int n_dn, double* __restrict__ out, double seq) {
+  double cs = 0.0, dn = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kChiBlock) cs += __hip_atomic_load(&d.chi2_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < n_dn; i += kChiBlock) dn += __hip_atomic_load(&d.dn_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cs += __shfl_down(cs, o, 64); dn += __shfl_down(dn, o, 64); }
+  __shared__ double red2[2][kChiBlock / 64];
+  if ((threadIdx.x & 63) == 0) { red2[0][threadIdx.x >> 6] = cs; red2[1][threadIdx.x >> 6] = dn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b2 = 0.0;
+    for (int k = 0; k < kChiBlock / 64; k++) { a += red2[0][k]; b2 += red2[1][k]; }
+    const double npd = __hip_atomic_load(&d.result_dev[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d.result_dev[0] = a; d.result_dev[1] = b2; d.result_dev[2] = 0.0;   // the flag belongs to the solve before this record
+    out[0] = a; out[1] = b2; out[2] = npd;                 // `out` is pinned host memory: no copy kernel
+    // the sequence number goes last, with system-scope release: the host polls it instead of paying a stream sync
+    __hip_atomic_store(&out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// bx: block within the graph, nb: blocks of the graph (TICKET: the one that draws the last ticket reduces)
+template <bool TICKET = true>
 __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __restrict__ pose,
                                           const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
                                           int n_dn, double* __restrict__ out, double seq, int bx, int nb) {
@@ -186,12 +209,17 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
+  if (!TICKET) {                                          // a batch: the partials are summed by kb_chi2_finish, a kernel boundary later
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < kChiBlock / 64; k++) t += red[k]; d.chi2_partials[bx] = t; }
+    return;
+  }
   __shared__ bool last;
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int k = 0; k < kChiBlock / 64; k++) t += red[k];
     d.chi2_partials[bx] = t;
-    // publish, then take a ticket: the block that draws the last one reduces everything
+    // publish, then take a ticket: the block that draws the last one reduces everything.  (An agent-scope release writes the
+    // XCD's L2 back on this chip -- microseconds; fine for the few dozen blocks of one graph, not for the thousands of a batch.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     last = atomicAdd(d.ticket, 1u) == (unsigned int)(nb - 1);
@@ -200,24 +228,8 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
   if (!last) return;
   if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
-  double cs = 0.0, dn = 0.0;
-  for (int i = threadIdx.x; i < nb; i += kChiBlock) cs += __hip_atomic_load(&d.chi2_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = threadIdx.x; i < n_dn; i += kChiBlock) dn += __hip_atomic_load(&d.dn_partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { cs += __shfl_down(cs, o, 64); dn += __shfl_down(dn, o, 64); }
-  __shared__ double red2[2][kChiBlock / 64];
-  if ((threadIdx.x & 63) == 0) { red2[0][threadIdx.x >> 6] = cs; red2[1][threadIdx.x >> 6] = dn; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0, b2 = 0.0;
-    for (int k = 0; k < kChiBlock / 64; k++) { a += red2[0][k]; b2 += red2[1][k]; }
-    const double npd = __hip_atomic_load(&d.result_dev[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    d.result_dev[0] = a; d.result_dev[1] = b2; d.result_dev[2] = 0.0;   // the flag belongs to the solve before this record
-    out[0] = a; out[1] = b2; out[2] = npd;                 // `out` is pinned host memory: no copy kernel
-    // the sequence number goes last, with system-scope release: the host polls it instead of paying a stream sync
-    __hip_atomic_store(&out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    *d.ticket = 0u;
-  }
+  chi2_finish(d, nb, n_dn, out, seq);
+  if (threadIdx.x == 0) *d.ticket = 0u;
 }
 
 __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __restrict__ pose,
@@ -299,8 +311,22 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2(BatchArgs a, int slot) {
             nb_lp = dcdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if ((int)blockIdx.x >= nb) return;
-  body_chi2(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
-            a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot, a.seq, blockIdx.x, nb);
+  body_chi2<false>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+                   a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot, a.seq, blockIdx.x, nb);
+}
+
+// the result records of a batch: one block per graph (and per trial: grid z) sums the partials of the sweep before it
+__global__ __launch_bounds__(kChiBlock) void kb_chi2_finish(BatchArgs a, int slot, int dual) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const int nb = dcdiv(d.n_obs, kChiBlock) + dcdiv(d.n_odo, kChiBlock) + dcdiv(d.n_pp, kChiBlock) + dcdiv(d.n_lp, kChiBlock);
+  const int n_dn = dcdiv(d.n_pose + d.n_plane, 256);
+  if (!dual) { chi2_finish(d, nb, n_dn, a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot, a.seq); return; }
+  DevGraph d2 = d;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.result_dev = al.result_dev;
+  }
+  chi2_finish(d2, nb, n_dn, a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + blockIdx.z), a.seq);
 }
 
 hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
@@ -311,6 +337,7 @@ hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st) {
   if (g.chi2 <= 0) return hipErrorInvalidValue;
   PPS_LAUNCH(kb_chi2, dim3(g.chi2, a.n), dim3(kChiBlock), 0, st, a, slot);
+  PPS_LAUNCH(kb_chi2_finish, dim3(1, a.n), dim3(kChiBlock), 0, st, a, slot, 0);
   return hipGetLastError();
 }
 
@@ -380,8 +407,8 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2_dual(BatchArgs a) {
   const int ts = (xs + 1 + z) % 3;
   DevGraph d2 = d;
   if (z) { d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.ticket = al.ticket; d2.result_dev = al.result_dev; }
-  body_chi2(d2, sel3(al.pose, ts), sel3(al.plane, ts), nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
-            a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
+  body_chi2<false>(d2, sel3(al.pose, ts), sel3(al.plane, ts), nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+                   a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
 }
 
 hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
@@ -394,6 +421,7 @@ hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipSt
   if (g.chi2 <= 0) return hipErrorInvalidValue;
   if (g.retract > 0) PPS_LAUNCH(kb_retract_dual, dim3(g.retract, a.n, 2), dim3(256), 0, st, a);
   PPS_LAUNCH(kb_chi2_dual, dim3(g.chi2, a.n, 2), dim3(kChiBlock), 0, st, a);
+  PPS_LAUNCH(kb_chi2_finish, dim3(1, a.n, 2), dim3(kChiBlock), 0, st, a, 0, 1);
   return hipGetLastError();
 }
 

@@ -956,6 +956,15 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
         A.crec.insert(A.crec.end(), cr, cr + 8);
       }
     }
+    {
+      A.cls_off.assign((size_t)A.n_levels * 3 + 1, 0);
+      A.cls_fronts.assign(F, 0);
+      auto cls_of = [&](int s2) { const int f = A.f_p[s2] + A.f_b[s2]; return f <= 32 ? 0 : (f <= 48 ? 1 : 2); };
+      for (int i = 0; i < F; i++) { const int s2 = A.glvl_fronts[i]; A.cls_off[(size_t)A.f_level[s2] * 3 + cls_of(s2) + 1]++; }
+      for (size_t k = 0; k + 1 < A.cls_off.size(); k++) A.cls_off[k + 1] += A.cls_off[k];
+      std::vector<int> w(A.cls_off.begin(), A.cls_off.end() - 1);
+      for (int i = 0; i < F; i++) { const int s2 = A.glvl_fronts[i]; A.cls_fronts[w[(size_t)A.f_level[s2] * 3 + cls_of(s2)]++] = i; }
+    }
     A.srec.resize((size_t)A.n_segs * 8, 0);
     for (int sg = S0; sg < A.n_segs; sg++) {
       const int bk = A.seg_blk[sg];

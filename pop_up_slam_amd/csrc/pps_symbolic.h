@@ -104,6 +104,10 @@ struct Analysis {
   // srec: 8 ints per H segment: 0 rows, 1 cols, 2 size, 3 c0, 4 cnt, 5 hoff (segment slot), 6 blk_doff, 7 nseg of the block
   std::vector<int> frec, crec, srec;
 
+  // ---- level-per-launch form (many-graph batches): positions in frec of the fronts of tree level l with size class c --
+  // 0: p + b <= 32, 1: <= 48, 2: larger -- at cls_fronts[cls_off[3 l + c] .. cls_off[3 l + c + 1]) ----
+  std::vector<int> cls_off, cls_fronts;
+
   // ---- block-sparse H = J'J (lower triangle in elimination order) ----
   int n_blocks = 0;
   std::vector<int> blk_rows, blk_cols;   // dims (rows = later node, cols = earlier node); diagonal blocks carry g appended
