@@ -34,6 +34,36 @@ B_ODO_EDGE = 840     # 216 B read + 624 B written per odometry edge
 HBM_PEAK_GBS = 8000.0
 
 
+K1_SOURCES = ("pps_k1.hip", "pps_k1_body.h", "pps_geom.h")
+
+
+def k1_source_hash():
+    """hash of the sources that define the K1 kernels: a PMC record (profiles/r*_pmc_k1_sweep.json) is only quoted by a build
+    of exactly these sources"""
+    import hashlib
+    h = hashlib.sha1()
+    for name in K1_SOURCES:
+        with open(os.path.join(ROOT, "pop_up_slam_amd", "csrc", name), "rb") as f:
+            h.update(name.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """the newest PMC record of the batched K1 sweep whose source hash equals this tree's; ({}, reason) when there is none"""
+    import glob
+    want = k1_source_hash()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k1_sweep.json")), reverse=True)
+    for path in files:
+        try:
+            with open(path) as f:
+                js = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if js.get("k1_source_hash") == want:
+            return js, os.path.basename(path)
+    return {}, "no PMC record in profiles/ was taken on these K1 sources (hash %s): traffic not quoted" % want
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -204,6 +234,7 @@ def main():
                     help="Jacobian mode of the sweep (numeric = reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-5 frame loop (1000 frames, ~2 s)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the config-3 graph (10 000 poses)")
     ap.add_argument("--no-concurrent", action="store_true",
                     help="skip the 8-host-thread section (rocprofv3 --kernel-trace of ROCm 7.2 crashes inside hipLaunchKernel when several "
                          "host threads launch at once; the profile in profiles/ is taken with this flag)")
@@ -312,12 +343,8 @@ def main():
         # batched variant: replicate the edge arrays until one sweep moves > 256 MB; the plane-edge launch
         # (5 of every 6 factors) is the dominant kernel, the odometry launch is reported next to it
         reps = args.batched_replicas or int(np.ceil(300e6 / bytes_per_launch))
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_k1_sweep.json")) as f:
-                pmc = json.load(f).get("v2", {})
-        except OSError:
-            pass
+        pmc_js, pmc_src = load_pmc()
+        pmc = pmc_js.get("kernels", {})
         roofline_batched = {}
         for mname, mcode in (("analytic", P.JAC_ANALYTIC), ("numeric", P.JAC_NUMERIC)):
             (sec_all, sec_pl, sec_od), npl, nod = g.bench_sweep(mcode, reps, 10)
@@ -326,13 +353,14 @@ def main():
                                                ("odometry", sec_od, nod * B_ODO_EDGE, "k_sweep_bench<%d,1>" % mcode)):
                 rec = pmc.get(f"{mname}_{part}")
                 traffic = None
-                if rec and reps == 108:      # PMC passes were taken at 108 replicas (profiles/r1_pmc_k1_sweep.json)
+                if rec and reps == pmc_js.get("replicas") and "hbm_bytes_corrected" in rec:   # same replica count as the PMC passes
                     traffic = rec["hbm_bytes_corrected"]
                 ent[part] = {"bound": "hbm", "achieved": nbytes / sec_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": nbytes / sec_k / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                              "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec_k * 1e6}
             ent["both_launches_us"] = sec_all * 1e6
             ent["replicas"], ent["n_plane_edges"], ent["n_odometry_edges"] = reps, npl, nod
+            ent["traffic_source"] = pmc_src
             roofline_batched[mname] = ent
         out = {
             "metric": "graph-solve iters/sec + final chi2, 1k-pose/5k-edge plane graph",
@@ -346,7 +374,7 @@ def main():
                                    "short, balanced LM runs; parity on SURVEY's seeds 100-107 is a test, not a bench line), one "
                                    "step = all eight solved once, rank r starting at graph r, no collective" % C4_SEEDS),
                        "jacobian_mode": args.mode, "lm_solves_per_step": len(graphs), "lm_iterations_per_solve": iters / solves,
-                       "graphs_per_sec": world * solves / elapsed},
+                       "graphs_per_sec": world * solves / elapsed, "total_lm_iterations": total_iters, "total_lm_solves": world * solves},
             "final_chi2": chi2, "chi2_initial": st["chi2_initial"],
             "fronts": st["n_fronts"], "levels": st["n_levels"], "max_front": st["max_front"],
             # kernel launches of one LM solve (pps_stats.n_launches): the dual loop issues both damping values of a
@@ -422,6 +450,34 @@ def main():
             # headline above stays the single graph BASELINE.json's metric is quoted on.
             out["multi_graph_one_gpu"] = multi_graph_bench(P, synth, local_rank, mode, args, spec, out["roofline_k3"]["flops_per_factorisation"],
                                                            bytes_per_launch, torch)
+        if world == 1 and not args.no_c3:
+            # BASELINE config 3: 10 000 poses / 2 000 planes / 60 000 plane edges (one 31.9 MB Jacobian sweep per linearisation)
+            spec3 = synth.manhattan_rooms()
+            g3 = P.Graph(device=local_rank, jacobian_mode=mode)
+            spec3.replay(g3); g3.save_state()
+            it3 = g3.batch_optimize()
+            c3_chi2 = g3.chi2()
+            walls = []
+            for _ in range(5):
+                g3.restore_state()
+                t1 = time.perf_counter(); it3 = g3.batch_optimize(); walls.append(time.perf_counter() - t1)
+            w3 = float(np.median(walls))
+            g3.restore_state(); g3.set_profiling(2); g3.batch_optimize(); s3 = g3.stats(); g3.set_profiling(0)
+            cnt3 = spec3.counts()
+            bytes3 = cnt3[synth.F_PLANE_OBS] * B_PLANE_EDGE + cnt3[synth.F_ODOMETRY] * B_ODO_EDGE
+            g3.restore_state()
+            k1_3 = g3.time_linearize(mode, 100)
+            nf3, nl3 = max(1, s3["n_factorize"]), max(1, s3["n_linearize"])
+            out["c3"] = {"workload": "C3 synthetic Manhattan rooms: %d poses, %d planes, %d plane edges, %d odometry edges (BASELINE.json configs[2])"
+                                     % (spec3.n_poses, spec3.n_planes, cnt3[synth.F_PLANE_OBS], cnt3[synth.F_ODOMETRY]),
+                         "lm_iterations": it3, "value": it3 / w3, "unit": "LM iters/s", "us_per_lm_iteration": 1e6 * w3 / max(1, it3),
+                         "final_chi2": c3_chi2, "fronts": s3["n_fronts"], "levels": s3["n_levels"], "max_front": s3["max_front"],
+                         "phase_us_per_call": {"k1": 1e6 * s3["t_linearize"] / nl3, "k2": 1e6 * s3["t_assemble"] / nl3, "factor": 1e6 * s3["t_factor"] / nf3,
+                                               "backsolve": 1e6 * s3["t_backsolve"] / nf3, "trial": 1e6 * s3["t_retract_chi2"] / nf3},
+                         "roofline_k1": {"bound": "hbm", "kernel": "k_linearize_lanes" if mode == P.JAC_NUMERIC else "k_linearize<1,*>",
+                                         "achieved": bytes3 / k1_3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes3 / k1_3 / 1e9 / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_launch": bytes3, "avg_launch_us": 1e6 * k1_3, "launches": 100, "traffic": None}}
+            g3.close()
         if world == 1 and not args.no_c5:
             # BASELINE config 5: 1000 synthetic 640x480 frames, pop-up (half resolution) fused with the incremental solve
             from pop_up_slam_amd import pipeline
@@ -460,6 +516,15 @@ def main():
             out["cpu_baseline_optimised_mt"] = cbm
             out["speedup_vs_cpu_baseline_optimised_mt"] = out["value"] / cbm["value"]
             out["chi2_rel_err_vs_cpu"] = abs(chi2 - cb["final_chi2"]) / abs(cb["final_chi2"])
+            if "c3" in out:
+                # the CPU oracle on C3 (one solve, ~10 s: part of this leg's budget): chi2 parity and the CPU rate at that size
+                from oracle import oracle_py as O
+                o3 = O.OracleGraph(); synth.manhattan_rooms().replay(o3)
+                t1 = time.perf_counter(); ito3 = o3.batch_optimize(); eo3 = time.perf_counter() - t1
+                co3 = o3.chi2()
+                out["c3"]["cpu_oracle"] = {"lm_iterations": ito3, "value": ito3 / eo3, "unit": "LM iters/s", "seconds": eo3, "final_chi2": co3, "cores": 1, "kind": "port"}
+                out["c3"]["chi2_rel_err_vs_cpu"] = abs(out["c3"]["final_chi2"] - co3) / abs(co3)
+                out["c3"]["speedup_vs_cpu_oracle"] = out["c3"]["value"] / (ito3 / eo3)
             if "other_mode" in out:
                 out["other_mode"]["chi2_rel_err_vs_cpu"] = abs(out["other_mode"]["final_chi2"] - cb["final_chi2"]) / abs(cb["final_chi2"])
         print(json.dumps(out))

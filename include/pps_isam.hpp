@@ -307,6 +307,37 @@ protected:
   }
 };
 
+// src/isam_plane3d.h:314-424: a plane observation whose measurement is re-popped from the two ground-edge rays at every
+// evaluation (get_wall_plane_equation, src/isam_plane3d.cpp:13-55) -- the variant Mapping.cpp:515-521 keeps next to the plain
+// factor.  As in the reference precompute_edge_ray() must be called before the factor is added; not for the ground plane.
+class Pose3d_Plane3d_Factor2 : public Factor {
+  Pose3d_Node* _pose; Plane3d_Node* _plane; Plane3d _measure;
+  double _ray[6] = {0, 0, 0, 0, 0, 0}; bool _have_ray = false;
+public:
+  Pose3d_Plane3d_Factor2(Pose3d_Node* pose, Plane3d_Node* plane, const Plane3d& measure, const Noise& noise, bool relative = false)
+      : _pose(pose), _plane(plane), _measure(measure) {
+    if (relative) throw std::runtime_error("Pose3d_Plane3d_Factor2: relative parameterisation is not used by the mapper (Mapping.cpp:21)");
+    _ut = noise.sqrtinf_ut();
+  }
+  void initialize() {
+    if (!_pose->initialized()) throw std::runtime_error("Plane3d: Pose3d_Plane3d_Factor requires pose to be initialized");
+    if (!_plane->initialized()) _plane->init(_measure.transform_from(_pose->value().oTw()));
+  }
+  // invK: row-major 3x3 (fp32, as the reference's Eigen::Matrix3f), ground_seg2d_line: (u0, v0, u1, v1) of the ONE ground edge
+  void precompute_edge_ray(const float invK[9], const float ground_seg2d_line[4]) {
+    if (pps_edge_ray(invK, ground_seg2d_line, _ray) != PPS_OK) throw std::runtime_error("Pose3d_Plane3d_Factor2: precompute_edge_ray");
+    _have_ray = true;
+  }
+  const Plane3d& measurement() const { return _measure; }
+  const double* edge_ray() const { return _ray; }
+protected:
+  void push(pps_graph* g) {
+    if (!_have_ray) throw std::runtime_error("Pose3d_Plane3d_Factor2: precompute_edge_ray() before add_factor() (isam_plane3d.h:359)");
+    const Vector4d m = _measure.vector();
+    detail::check(pps_add_plane_obs2(g, _pose->backend_id(), _plane->backend_id(), m.data(), _ray, _ut.data(), &_id), g, "pps_add_plane_obs2");
+  }
+};
+
 class Plane3d_Factor : public Factor {          // src/isam_plane3d.h:428-474
   Plane3d_Node* _plane; Plane3d _measure;
 public:

@@ -1953,7 +1953,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES")) || getenv("PPS_MULTI_THREAD_FORM");
     q.k1_direct = (q.lin_thread_form || mode == PPS_JAC_ANALYTIC) && !getenv("PPS_MULTI_NO_DIRECT");   // the analytic sweep always runs one thread per factor
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
-    q.level_form = level_ok && q.n_factors_total > 200000 && !getenv("PPS_MULTI_BANDS");
+    q.level_form = level_ok && ((q.n_factors_total > 200000 && !getenv("PPS_MULTI_BANDS")) || getenv("PPS_MULTI_LEVELS"));   // (PPS_MULTI_LEVELS: forced onto small batches by the parity test)
     { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));

@@ -37,7 +37,10 @@ int main(int argc, char** argv) {
     std::map<int, Plane3d_Node*> all_landmarks;
     std::string tok;
     int nframes = 0;
-    in >> tok >> nframes;
+    float inv_calib[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    in >> tok;
+    if (tok == "INVK") { for (float& v : inv_calib) in >> v; in >> tok; }      // optional: K^-1 for OBS2 lines
+    in >> nframes;
     for (int k = 0; k < nframes; k++) {
       double tq[7]; int fk, nobs;
       in >> tok >> fk;
@@ -55,12 +58,14 @@ int main(int argc, char** argv) {
         _slam.add_factor(new Pose3d_Pose3d_Factor(all_frames.back(), poseNode, temp_pose, poseCov));   // :477-478
       }
       all_frames.push_back(poseNode);
-      struct Obs { int key, ground; double dist; Vector4d m; };
+      struct Obs { int key, ground; double dist; Vector4d m; bool repop; float seg[4]; };
       std::vector<Obs> obs(nobs);
       std::vector<int> fresh;
       for (auto& o : obs) {
         in >> tok >> o.key >> o.ground >> o.dist;
         for (double& v : o.m) in >> v;
+        o.repop = tok == "OBS2";                                  // the observation re-pops its measurement from its ground edge
+        if (o.repop) for (float& v : o.seg) in >> v;
         if (!all_landmarks.count(o.key)) {                        // new plane node (:482-490)
           Plane3d_Node* planeNode = new Plane3d_Node();
           _slam.add_node(planeNode);
@@ -81,7 +86,13 @@ int main(int argc, char** argv) {
         const double s = (d - 1) * plane_sigma_dist_mul + 5;
         const double var[3] = {s * s, s * s, s * s};
         Covariance planeCov_new = Covariance::diagonal(var, 3);
-        _slam.add_factor(new Pose3d_Plane3d_Factor(poseNode, planeNode, measure, planeCov_new, false));   // :513,523
+        if (o.repop) {                                            // the variant of :515-521: pop the plane up from its line in every evaluation
+          Pose3d_Plane3d_Factor2* fac = new Pose3d_Plane3d_Factor2(poseNode, planeNode, measure, planeCov_new, false);
+          fac->precompute_edge_ray(inv_calib, o.seg);
+          _slam.add_factor(fac);
+        } else {
+          _slam.add_factor(new Pose3d_Plane3d_Factor(poseNode, planeNode, measure, planeCov_new, false));   // :513,523
+        }
       }
       int iterations = -1;
       if (k % 5 == 0) iterations = _slam.batch_optimization();    // :551-554

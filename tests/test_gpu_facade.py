@@ -71,6 +71,73 @@ def _replay_oracle(frames, analytic=0):
     return chis, np.array([g.get_pose(p) for p in poses])
 
 
+def test_factor2_through_cpp_facade(built, tmp_path):
+    """isam::Pose3d_Plane3d_Factor2 of the facade (precompute_edge_ray + add_factor, the variant of Mapping.cpp:515-521): wall
+    observations alternate between the stored-measurement factor and the re-popping one; chi2 per frame and the final poses
+    against the CPU oracle driven the same way."""
+    from pop_up_slam_amd import pipeline
+    from tests.assoc_helpers import INVK
+    exe = tmp_path / "mapper_replay"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "mapper_replay.cpp"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "pop_up_slam_amd"), "-lpps",
+                           "-Wl,-rpath," + os.path.join(ROOT, "pop_up_slam_amd")])
+    frames = pipeline.popup_sequence(16, seed=5)
+    keys = {}
+    script = tmp_path / "script2.txt"
+    g = O.OracleGraph()
+    pose_ut = synth._ut_diag([0.5] * 6)
+    poses, land, ref_chis, n2 = [], {}, [], 0
+    with open(script, "w") as f:
+        f.write("INVK " + " ".join(repr(float(v)) for v in np.asarray(INVK, dtype=np.float32).ravel()) + f"\nNFRAMES {len(frames)}\n")
+        for k, fr in enumerate(frames):
+            odo = fr.true_pose if k == 0 else fr.odo
+            est = np.array([0, 0, 0, 0, 0, 0, 1.0]) if not poses else O.pose_oplus(g.get_pose(poses[-1]), odo)
+            T32 = synth.T_from_pose(fr.true_pose).astype(np.float32)
+            planes = O.popup_planes(fr.seg2d, INVK, T32).astype(np.float64)
+            obs = []
+            for j, key in enumerate(["g"] + list(fr.ids)):
+                m = planes[j] / np.linalg.norm(planes[j])
+                kid = keys.setdefault(key, len(keys))
+                seg = fr.seg2d[j - 1] if (j > 0 and (j + k) % 2 == 0) else None
+                obs.append((kid, 1 if key == "g" else 0, float(fr.dist[j]), m, seg))
+            f.write(f"FRAME {k} " + " ".join(repr(float(v)) for v in odo) + f" {len(obs)}\n")
+            for kid, ground, dist, m, seg in obs:
+                line = f"{'OBS2' if seg is not None else 'OBS'} {kid} {ground} {dist!r} " + " ".join(repr(float(v)) for v in m)
+                if seg is not None:
+                    line += " " + " ".join(repr(float(v)) for v in seg)
+                f.write(line + "\n")
+            # the oracle, driven like Mapper_mono::processFrame (the same steps as mapper_replay.cpp)
+            if not poses:
+                p = g.add_pose(odo); g.add_pose_prior(p, O.pose_vector(odo), pose_ut)
+            else:
+                p = g.add_pose(est); g.add_odometry(poses[-1], p, O.pose_vector(odo), pose_ut)
+            poses.append(p)
+            for kid, ground, dist, m, seg in obs:
+                if kid not in land:
+                    land[kid] = g.add_plane(O.plane_transform_from(m, est))
+                    if ground:
+                        g.add_plane_prior(land[kid], synth.GROUND, synth._ut_diag([20.0] * 3))
+                ut = synth._ut_diag([1.0 / synth.plane_sigma(dist)] * 3)
+                if seg is not None:
+                    g.add_plane_obs2(p, land[kid], m, O.edge_ray(INVK, seg), ut); n2 += 1
+                else:
+                    g.add_plane_obs(p, land[kid], m, ut)
+            if k % 5 == 0:
+                g.batch_optimize()
+            else:
+                g.update()
+            ref_chis.append(g.chi2())
+    assert n2 >= 10
+    out = subprocess.run([str(exe), str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    chis = [float(l.split()[3]) for l in out.stdout.splitlines() if l.startswith("FRAME")]
+    got = np.array([[float(v) for v in l.split()[2:]] for l in out.stdout.splitlines() if l.startswith("POSE")])
+    np.testing.assert_allclose(chis, ref_chis, rtol=1e-5, atol=1e-12)       # north_star tolerance
+    for a, b in zip(got, np.array([g.get_pose(p) for p in poses])):
+        np.testing.assert_allclose(a[:3], b[:3], atol=1e-6)
+
+
 @pytest.mark.parametrize("analytic", [0, 1])
 def test_mapper_style_replay_through_cpp_facade(built, tmp_path, analytic):
     exe = tmp_path / "mapper_replay"

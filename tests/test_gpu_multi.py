@@ -115,7 +115,7 @@ def test_refusals(built):
 @pytest.mark.parametrize("mode", [P.JAC_NUMERIC, P.JAC_ANALYTIC])
 def test_throughput_forms_are_bit_identical(built, monkeypatch, mode):
     """large batches switch K1 to one thread per factor (which then writes the single-contribution pose-plane blocks of H itself)
-    and K2 to the 4-segments-per-wave form over the remaining segments; forced onto a small batch here and compared with
+    and K2 to the LDS-staged 4-segments-per-wave form over the remaining segments, K3 to the level-per-launch kernels; forced onto a small batch here and compared with
     single handles running the same K1 form with the ordinary K2: every H entry must come out the same, so trace, chi2 and
     state are equal bit for bit"""
     monkeypatch.setenv("PPS_K1_THREAD_FORM", "1")
@@ -124,9 +124,41 @@ def test_throughput_forms_are_bit_identical(built, monkeypatch, mode):
     singles, nids = _build(specs, jacobian_mode=mode)
     ref = [(g.batch_optimize(), g.trace(), g.chi2()) for g in singles]
     monkeypatch.setenv("PPS_MULTI_THREAD_FORM", "1")
+    monkeypatch.setenv("PPS_MULTI_LEVELS", "1")       # ... and K3 to the level-per-launch form (one launch per tree level and size class)
     batch, _ = _build(specs, jacobian_mode=mode)
     its, st = P.Multi(batch).optimize()
     for k, g in enumerate(batch):
         assert (its[k], g.trace(), g.chi2()) == ref[k], k
     o = O.OracleGraph(analytic=mode); specs[2].replay(o)
     assert o.batch_optimize() == ref[2][0] and abs(o.chi2() - ref[2][2]) <= 1e-7 * ref[2][2]
+
+
+@pytest.mark.gpu
+def test_two_bench_ranks_on_one_gpu(built):
+    """The N > 1 path of bench.py on hardware without a second GPU: two ranks under torch.distributed.run, both on device 0
+    (PPS_BENCH_SHARED_GPU=1, gloo for the barrier and the MAX / SUM reductions).  Every rank solves the eight C4 timing graphs
+    once per step, starting at graph `rank`: equal work per rank, the chi2 of the C2 graph, the whole-job iteration count."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-c5", "--no-c3"]
+    env = dict(os.environ, PPS_BENCH_SHARED_GPU="1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                     # only rank 0 prints
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["scaling"] == "weak" and js["steps"] == 2
+    cfg = js["config"]
+    assert cfg["lm_solves_per_step"] == 8 and cfg["total_lm_solves"] == 2 * 2 * 8
+    # every rank walks the same eight graphs: the whole job is twice what rank 0 did, and rank 0 did 2 steps x the eight solves
+    single = {}
+    sys.path.insert(0, root)
+    import bench
+    for sd in bench.C4_SEEDS:
+        g = P.Graph(); synth.corridor(seed=sd).replay(g); single[sd] = g.batch_optimize()
+    assert cfg["total_lm_iterations"] == 2 * 2 * sum(single.values())
+    assert abs(js["final_chi2"] - 0.02349329375) <= 1e-9            # rank 0's first graph is the C2 graph (seed 42)
+    assert js["value"] > 0 and js["vs_baseline"] is None

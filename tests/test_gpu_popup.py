@@ -113,6 +113,7 @@ def test_refresh_measurements_feeds_the_graph(built):
         for j, ln in enumerate([ground] + walls):
             fids.append(g.add_plane_obs(pid, ln, [0.0, 0.0, -1.0, 0.5], ident))   # dummy measurement, overwritten below
         if k == 3:
+            skipped_fid = fids[2]
             fids[2] = -1      # a skipped plane keeps its measurement
         g.frames_add(pid, seg, fids)
         frames.append((pid, seg, fids))
@@ -129,7 +130,7 @@ def test_refresh_measurements_feeds_the_graph(built):
             np.testing.assert_allclose(g.get_measurement(fid), ref[j], rtol=0, atol=1e-15)
     # the skipped one is untouched (normalised dummy)
     d = np.array([0.0, 0.0, -1.0, 0.5]); d /= np.linalg.norm(d)
-    np.testing.assert_allclose(g.get_measurement(frames[3][2][1]), g.get_measurement(frames[3][2][1]))
+    np.testing.assert_allclose(g.get_measurement(skipped_fid), d, rtol=0, atol=1e-15)
     # measurements now consistent with the planes -> chi2 of the plane edges is tiny after refresh
     chi = g.chi2()
     assert np.isfinite(chi)
@@ -140,6 +141,54 @@ def test_refresh_measurements_feeds_the_graph(built):
     # a later refresh overwrites it again
     g.refresh_measurements()
     assert abs(g.get_measurement(frames[0][2][0])[3]) > 1e-3
+
+
+def test_refreshed_measurements_survive_an_appending_upload(built):
+    """Measurements refreshed on the device stay there across a topology upload that only appends; the new observations are
+    sent as exact pieces.  20 old observations (20 % 8 != 0): a piece rounded down to the 64-byte compare stride or up to the
+    16-byte copy unit would put the mirror's stale values over refreshed neighbours."""
+    rng = np.random.default_rng(11)
+    g = P.Graph()
+    g.frames_set_calibration(INVK)
+    ident = synth._ut_diag([1.0] * 3)
+    ground = g.add_plane(synth.GROUND)
+    walls = [g.add_plane(synth._wall((-1, 0), (-1.5, 0))), g.add_plane(synth._wall((0, 1), (0, 8.0))),
+             g.add_plane(synth._wall((1, 0), (1.5, 0)))]
+    g.add_plane_prior(ground, synth.GROUND, synth._ut_diag([20.0] * 3))
+    dummy = np.array([0.0, 0.0, -1.0, 0.5]); dummy /= np.linalg.norm(dummy)
+    frames, prev = [], None
+
+    def add_frame(k):
+        nonlocal prev
+        tq = _pose(yaw=rng.normal(0, 0.05), pitch=rng.normal(0, 0.02), x=rng.normal(0, 0.05), y=0.2 * k)
+        pid = g.add_pose(tq)
+        if prev is None:
+            g.add_pose_prior(pid, synth.pose_vector(tq), synth._ut_diag([0.5] * 6))
+        else:
+            g.add_odometry(prev[0], pid, synth.pose_vector(synth.pose_ominus(tq, prev[1])), synth._ut_diag([0.5] * 6))
+        seg, polys, T = synth.corridor_frame(tq)
+        fids = [g.add_plane_obs(pid, ln, [0.0, 0.0, -1.0, 0.5], ident) for ln in [ground] + walls]
+        g.frames_add(pid, seg, fids)
+        frames.append((pid, seg, fids))
+        prev = (pid, tq)
+
+    for k in range(5):
+        add_frame(k)                              # 20 plane observations
+    g.update()                                    # first topology upload
+    g.refresh_measurements()                      # device-side only: the host still holds the dummies
+    expected = {}
+    for pid, seg, fids in frames:
+        T32 = synth.T_from_pose(g.get_pose(pid)).astype(np.float32)
+        ref = O.popup_planes(seg, INVK, T32).astype(np.float64)
+        ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+        for j, fid in enumerate(fids):
+            expected[fid] = ref[j]
+    add_frame(5)                                  # appends 4 observations: 24 in all, same capacity
+    g.chi2()                                      # second topology upload (appending: the refreshed rows stay on the device)
+    for fid, ref in expected.items():
+        np.testing.assert_allclose(g.get_measurement(fid), ref, rtol=0, atol=1e-15)
+    for fid in frames[5][2]:
+        np.testing.assert_allclose(g.get_measurement(fid), dummy, rtol=0, atol=1e-15)
 
 
 def test_plane_info_matches_oracle(built):
