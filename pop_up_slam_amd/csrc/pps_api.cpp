@@ -117,7 +117,6 @@ struct pps_graph {
   std::vector<double> pk_obs_m, pk_obs_w, pk_odo_m, pk_odo_w;
   size_t pk_n_obs = 0, pk_n_odo = 0, pk_ld_obs = 0, pk_ld_odo = 0;
   bool pk_meas_ok = false;
-  bool stream_b_used = false;    // work was queued on the second stream since it was last synchronised (one-step LM loop only)
   bool status_clean = false;     // result_dev / spec_result are zero: upload_all zeroed them, or the last solve's chi2 kernels consumed the flags
   bool lin_is_est = false;       // upload_state has just filled est AND lin: the estimate_to_linpoint copy of the next solve is a no-op
   bool up_inflight = false;      // upload_all left copies from the pinned buffers in flight on `stream`
@@ -130,16 +129,13 @@ struct pps_graph {
   size_t up_bytes_sent = 0, up_bytes_total = 0;        // of the last flush (stats)
   double* host_result = nullptr;   // pinned, 12 doubles: chi2 at the linearisation point | trial | speculative trial
   double seq = 0.0;                // sequence number the chi2 kernel publishes last (host polls it)
-  // speculative solve of the LM reject branch (lambda * factor) on a second stream, into a second set of L/U/delta
-  hipStream_t stream_b = nullptr;
-  hipEvent_t ev_h_ready = nullptr, ev_spec_done = nullptr, ev_retracted = nullptr, ev_spec_trial_done = nullptr;
-  // speculative trial: the step for lambda * factor applied to a third state copy and its chi2, on the second stream
+  // the second damping value of a dual solve (lambda * factor): its own L / U / delta, a third copy of the state, its own
+  // reduction scratch and result record
   double *spec_pose = nullptr, *spec_plane = nullptr, *spec_chi2_partials = nullptr, *spec_dn_partials = nullptr;
   unsigned int* spec_ticket = nullptr;
   double seq2 = 0.0;
   double *spec_L = nullptr, *spec_U = nullptr, *spec_delta = nullptr;
   double* spec_result = nullptr;   // result_dev of the speculative set: its own not-PD flag
-  bool spec_enabled = true;
   double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
   int snap_version = -1, upload_version = 0;
   int profiling = 0;               // 0 off, 1 = K1 event pairs without host syncs, 2 = every phase (adds syncs)
@@ -423,33 +419,10 @@ int verify_uploads(pps_graph* g, const char* where) {
 int ensure_device(pps_graph* g) {
   if (g->dev_ready) return PPS_OK;
   HIP_TRY(g, hipSetDevice(g->props.device));
-  {
-    // The main and the speculative solve each keep a few dozen workgroups busy; give the two streams
-    // disjoint halves of the CUs so that they do not share SIMDs / LDS (opt-in: PPS_CU_MASK=1).
-    hipDeviceProp_t prop;
-    HIP_TRY(g, hipGetDeviceProperties(&prop, g->props.device));
-    const int ncu = prop.multiProcessorCount;
-    const char* e = getenv("PPS_CU_MASK");
-    const bool masked = (e && atoi(e) != 0) && ncu >= 64 && ncu % 64 == 0;   // measured: no gain on MI355X (143.7 vs 138.9 us/iter), off by default
-    if (masked) {
-      const int words = ncu / 32;
-      std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
-      for (int w = 0; w < words; w++) (w < words / 2 ? ma : mb)[w] = 0xffffffffu;
-      HIP_TRY(g, hipExtStreamCreateWithCUMask(&g->stream, (uint32_t)words, ma.data()));
-      HIP_TRY(g, hipExtStreamCreateWithCUMask(&g->stream_b, (uint32_t)words, mb.data()));
-    } else {
-      HIP_TRY(g, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-      HIP_TRY(g, hipStreamCreateWithFlags(&g->stream_b, hipStreamNonBlocking));
-    }
-  }
+  HIP_TRY(g, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
   HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->host_result), 12 * sizeof(double), hipHostMallocDefault));
   HIP_TRY(g, hipEventCreate(&g->ev[0]));
   HIP_TRY(g, hipEventCreate(&g->ev[1]));
-  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_h_ready, hipEventDisableTiming));
-  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_spec_done, hipEventDisableTiming));
-  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_retracted, hipEventDisableTiming));
-  HIP_TRY(g, hipEventCreateWithFlags(&g->ev_spec_trial_done, hipEventDisableTiming));
-  g->spec_enabled = !getenv("PPS_NO_SPEC");
   g->dev_ready = true;
   return PPS_OK;
 }
@@ -783,7 +756,6 @@ int upload_all(pps_graph* g) {
   }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->up_inflight = false;
-  if (g->stream_b && g->stream_b_used) { HIP_TRY(g, hipStreamSynchronize(g->stream_b)); g->stream_b_used = false; }
   lap("1 state/meas download + syncs");
   free_device(g);
   g->spec_L = g->spec_U = g->spec_delta = nullptr; g->spec_result = nullptr;
@@ -1223,15 +1195,10 @@ int pps_graph_destroy(pps_graph* g) {
     if (g->ev[0]) (void)hipEventDestroy(g->ev[0]);
     if (g->ev[1]) (void)hipEventDestroy(g->ev[1]);
     for (hipEvent_t e : g->k1_events) (void)hipEventDestroy(e);
-    if (g->stream_b) { (void)hipStreamSynchronize(g->stream_b); (void)hipStreamDestroy(g->stream_b); }
     if (g->d_lms) (void)hipFree(g->d_lms);
     if (g->d_queries) (void)hipFree(g->d_queries);
     if (g->d_results) (void)hipFree(g->d_results);
     if (g->d_lm_planes) (void)hipFree(g->d_lm_planes);
-    if (g->ev_h_ready) (void)hipEventDestroy(g->ev_h_ready);
-    if (g->ev_spec_done) (void)hipEventDestroy(g->ev_spec_done);
-    if (g->ev_retracted) (void)hipEventDestroy(g->ev_retracted);
-    if (g->ev_spec_trial_done) (void)hipEventDestroy(g->ev_spec_trial_done);
     (void)hipStreamDestroy(g->stream);
   }
   delete g;
@@ -1427,7 +1394,6 @@ static int lm_solve(pps_graph* g, int* iterations);
 static void abandon_device_copy(pps_graph* g) {
   if (!g->dev_ready) return;
   (void)hipStreamSynchronize(g->stream);
-  if (g->stream_b) (void)hipStreamSynchronize(g->stream_b);
   g->topo_dirty = true; g->dev_values_newer = false; g->dev_meas_newer = false;
   g->up_unknown = true; g->up_unknown_meas = true; g->pk_meas_ok = false; g->status_clean = false;
 }
@@ -1580,81 +1546,34 @@ static int lm_solve(pps_graph* g, int* iterations) {
   g->tr_lambda.clear(); g->tr_chi2.clear(); g->tr_acc.clear();
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
-  if (g->spec_enabled && g->use_band && g->profiling < 2 && !g->dev.trace && !getenv("PPS_NO_DUAL")) return lm_solve_dual(g, iterations, t0);
+  if (g->use_band && g->profiling < 2 && !g->dev.trace && !getenv("PPS_NO_DUAL")) return lm_solve_dual(g, iterations, t0);      // (PPS_NO_DUAL: the loop-forms parity test)
   const pps_props& prop = g->props;
-  HIP_TRY(g, launch_clear_status(g->dev, g->stream));
-  HIP_TRY(g, hipMemsetAsync(g->spec_result, 0, 4 * sizeof(double), g->stream));
-  g->status_clean = false;              // (a speculative factorisation whose trial was never evaluated leaves its flag behind)
+  if (!g->status_clean) HIP_TRY(g, launch_clear_status(g->dev, g->stream));
+  g->status_clean = false;
   int num_iter = 0;
   double lambda = prop.lm_lambda0;
   double* slot0 = g->host_result;       // chi2 at the linearisation point
-  double* slot1 = g->host_result + 4;   // speculative trial: |delta|^2 of the step and chi2 after it
-  double* slot2 = g->host_result + 8;   // the same for the step computed with lambda * factor on the second stream
-  // One stream, one host sync per LM trial.  After every solve the trial step is applied
-  // speculatively (est <- lin, lin <- lin (+) delta) and its chi2 is reduced, so a single result
-  // record carries everything the loop condition and the accept test need; if the loop ends on
-  // |delta| <= eps2 the speculative step is undone (lin <- est).
-  bool spec_trial_pending = false;      // kernels of a speculative trial may still be in flight on the second stream
-  bool spec_trial_inflight = false;     // ... and their result (slot2) belongs to the step in spec_delta
-  auto enqueue_trial_only = [&]() -> int {
-    PhaseTimer t(g, &g->stats.t_retract_chi2);
-    if (spec_trial_pending) {          // the second stream's retraction read this state: let it finish first (it long has)
-      HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_trial_done, 0));
-      spec_trial_pending = false;
-    }
-    HIP_TRY(g, launch_retract_trial(g->dev, g->stream));                       // linpoint_to_estimate + self_exmap (:414-416)
-    HIP_TRY(g, hipEventRecord(g->ev_retracted, g->stream));                    // est now holds the pre-trial point
-    g->seq += 1.0;
-    HIP_TRY(g, launch_chi2(g->dev, false, slot1, g->seq, g->stream));          // weighted_errors(LINPOINT) (:417)
-    return PPS_OK;
-  };
+  double* slot1 = g->host_result + 4;   // the trial: |delta|^2 of the step and chi2 after it
+  // One stream, one result record per LM trial.  After every solve the trial step is applied at once (est <- lin,
+  // lin <- lin (+) delta) and its chi2 is reduced, so a single record carries everything the loop condition and the accept
+  // test need; a rejected trial is undone by exchanging the two copies (pointers), and if the loop ends on |delta| <= eps2
+  // the pending step is undone the same way.  This is the reference's loop one step at a time: the form the profiling levels,
+  // the phase trace and the graphs beyond the band kernels (dense fronts, level-per-launch fallback) run; band graphs take
+  // lm_solve_dual.
   auto enqueue_trial = [&](double lam) -> int {
     int r = do_solve(g, lam); if (r != PPS_OK) return r;                       // compute_gauss_newton_step (:395,458)
-    return enqueue_trial_only();
-  };
-  // Reject-branch speculation: a rejected trial only changes lambda (same J, same H), so right after
-  // every relinearisation the step for lambda * factor is factored and solved on a second stream, into a
-  // second L/U/delta set, while the main solve runs.  The first rejection after an accepted step then
-  // costs one retraction + chi2 instead of a factorisation; arithmetic and lambda schedule are exactly
-  // the reference's.  (One level deep only: a second consecutive rejection solves on the main stream.)
-  const bool spec = g->spec_enabled && g->use_band && g->profiling < 2;
-  const bool spec_trial_enabled = spec && !getenv("PPS_NO_SPEC_TRIAL");
-  bool spec_inflight = false;
-  double spec_lambda = 0.0;
-  auto launch_spec = [&](double lam) -> int {
-    if (!spec) return PPS_OK;
-    DevGraph dv = g->dev;
-    dv.L = g->spec_L; dv.U = g->spec_U; dv.delta = g->spec_delta; dv.result_dev = g->spec_result;   // its own not-PD flag
-    HIP_TRY(g, hipStreamWaitEvent(g->stream_b, g->ev_h_ready, 0));
-    g->stream_b_used = true;
-    int r = do_solve_on(g, dv, lam, g->stream_b); if (r != PPS_OK) return r;
-    HIP_TRY(g, hipEventRecord(g->ev_spec_done, g->stream_b));
-    spec_inflight = true; spec_lambda = lam;
-    g->stats.n_factorize++;
-    // ... and the trial itself: once the main stream has retracted (est = pre-trial point x), x (+) delta' goes into
-    // the third state copy and its chi2 into slot2, so that a rejection of the main trial finds the next trial's
-    // verdict already on the host -- no launch, no round trip.  Same kernels' arithmetic as the main trial.
-    if (spec_trial_enabled) {
-      DevGraph dt = g->dev;
-      dt.delta = g->spec_delta; dt.chi2_partials = g->spec_chi2_partials; dt.dn_partials = g->spec_dn_partials; dt.ticket = g->spec_ticket;
-      dt.result_dev = g->spec_result;
-      HIP_TRY(g, hipStreamWaitEvent(g->stream_b, g->ev_retracted, 0));
-      HIP_TRY(g, launch_retract_to(dt, g->dev.pose_est, g->dev.plane_est, g->spec_pose, g->spec_plane, g->stream_b));
-      g->seq2 += 1.0;
-      HIP_TRY(g, launch_chi2_at(dt, g->spec_pose, g->spec_plane, slot2, g->seq2, g->stream_b));
-      HIP_TRY(g, hipEventRecord(g->ev_spec_trial_done, g->stream_b));
-      spec_trial_inflight = true; spec_trial_pending = true;
-    }
+    PhaseTimer t(g, &g->stats.t_retract_chi2);
+    HIP_TRY(g, launch_retract_trial(g->dev, g->stream));                       // linpoint_to_estimate + self_exmap (:414-416)
+    g->seq += 1.0;
+    HIP_TRY(g, launch_chi2_trial(g->dev, slot1, g->seq, g->stream));           // weighted_errors(LINPOINT) (:417)
     return PPS_OK;
   };
   rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:376)
   rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:379)
-  if (spec) HIP_TRY(g, hipEventRecord(g->ev_h_ready, g->stream));
   g->seq += 1.0;
   const double seq0 = g->seq;
   HIP_TRY(g, launch_chi2(g->dev, false, slot0, seq0, g->stream)); // r = weighted_errors(LINPOINT); error = |r|^2 (:382-385)
-  rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;        // the critical path goes to the queue first ...
-  rc = launch_spec(lambda * prop.lm_lambda_factor); if (rc != PPS_OK) return rc;   // ... the speculation second
+  rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;
   rc = wait_result(g, slot0, seq0); if (rc != PPS_OK) return rc;
   rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc;
   double error = slot0[0];
@@ -1666,7 +1585,6 @@ static int lm_solve(pps_graph* g, int* iterations) {
   bool last_notpd = slot1[2] != 0.0;
   int n_notpd = last_notpd ? 1 : 0;
   bool trial_pending = true;
-  bool have_result = false;
   while ((prop.max_iterations <= 0 || num_iter < prop.max_iterations) && dnorm > prop.epsilon2 && error > prop.epsilon_abs) {
     num_iter++;
     const double error_new = slot1[0];
@@ -1679,55 +1597,23 @@ static int lm_solve(pps_graph* g, int* iterations) {
       if (error_diff < prop.epsilon_rel * error) { error = error_new; trial_pending = false; break; }   // (:431-434)
       lambda /= prop.lm_lambda_factor;
       error = error_new;
-      // relinearise around the accepted point (:444); K2 overwrites H, which an unfinished speculative
-      // solve would still be reading (it started together with the main solve, so this never blocks)
-      if (spec_inflight) HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
-      spec_inflight = false; spec_trial_inflight = false;
-      rc = do_linearize(g); if (rc != PPS_OK) return rc;
-      if (spec) HIP_TRY(g, hipEventRecord(g->ev_h_ready, g->stream));
-      rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;    // (:458)
-      rc = launch_spec(lambda * prop.lm_lambda_factor); if (rc != PPS_OK) return rc;
+      rc = do_linearize(g); if (rc != PPS_OK) return rc;          // relinearise around the accepted point (:444)
     } else {
       g->stats.lm_trials_rejected++;
       lambda *= prop.lm_lambda_factor;
       swap_state(g);                                              // estimate_to_linpoint: restore (:454)
-      if (spec_inflight && spec_lambda == lambda) {
-        // the step for this lambda has been computed alongside the previous solve: adopt its buffers
-        HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
-        std::swap(g->dev.L, g->spec_L); std::swap(g->dev.U, g->spec_U); std::swap(g->dev.delta, g->spec_delta);
-        std::swap(g->dev.result_dev, g->spec_result);
-        spec_inflight = false;
-        if (spec_trial_inflight) {
-          // the trial for this lambda has been evaluated as well: rotate its state in (lin <- x (+) delta', est stays x;
-          // the buffer of the rejected trial becomes the next spare) and take its verdict from slot2
-          rc = wait_result(g, slot2, g->seq2, g->stream_b); if (rc != PPS_OK) return rc;
-          double* const rej_pose = g->dev.pose_est; double* const rej_plane = g->dev.plane_est;   // after swap_state: the rejected x (+) delta
-          g->dev.pose_est = g->dev.pose_lin; g->dev.plane_est = g->dev.plane_lin;                   // x
-          g->dev.pose_lin = g->spec_pose; g->dev.plane_lin = g->spec_plane;                         // x (+) delta'
-          g->spec_pose = rej_pose; g->spec_plane = rej_plane;
-          slot1[0] = slot2[0]; slot1[1] = slot2[1]; slot1[2] = slot2[2];
-          spec_trial_inflight = false;
-          have_result = true;
-        } else {
-          rc = enqueue_trial_only(); if (rc != PPS_OK) return rc;
-        }
-      } else {
-        if (spec_inflight) HIP_TRY(g, hipStreamWaitEvent(g->stream, g->ev_spec_done, 0));
-        spec_inflight = false; spec_trial_inflight = false;
-        rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;  // (:458)
-      }
     }
-    if (!have_result) { rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc; }
-    have_result = false;
+    rc = enqueue_trial(lambda); if (rc != PPS_OK) return rc;      // (:458)
+    rc = wait_result(g, slot1, g->seq); if (rc != PPS_OK) return rc;
     dnorm = std::sqrt(slot1[1]);
     last_notpd = slot1[2] != 0.0;
     n_notpd += last_notpd ? 1 : 0;
   }
-  if (spec) HIP_TRY(g, hipStreamSynchronize(g->stream_b));       // no speculative work may outlive the call
-  if (trial_pending) swap_state(g);                               // undo the speculative step
+  if (trial_pending) swap_state(g);                               // undo the pending step
   swap_state(g);                                                  // linpoint_to_estimate (:466)
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->dev_values_newer = true; g->lin_is_est = false;
+  g->status_clean = true;                                         // every solve was followed by its chi2 kernel
   resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;
   g->stats.chi2_final = error; g->stats.lambda_final = lambda; g->stats.last_delta_norm = dnorm;
@@ -1877,7 +1763,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     if (g->props.jacobian_mode != mode) return mfail(m, PPS_EINVAL, "all graphs of a batch share one jacobian_mode");
     if (g->an.n_stages > 32) return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + ": elimination tree too deep for the batched schedule");
     MHIP(m, hipStreamSynchronize(g->stream));
-    if (g->stream_b) MHIP(m, hipStreamSynchronize(g->stream_b));
     g->status_clean = false;
     max_stages = std::max(max_stages, g->an.n_stages);
   }

@@ -141,10 +141,8 @@ hipError_t launch_retract_apply(const DevGraph& d, hipStream_t st);
 // retraction), not-PD flag} straight into `host_result` (pinned host memory)
 hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result, double seq, hipStream_t st);
 hipError_t launch_clear_status(const DevGraph& d, hipStream_t st);
-// speculative LM trial: out <- base (+) d.delta (partials to d.dn_partials), chi2 at an explicit state
-hipError_t launch_retract_to(const DevGraph& d, const double* base_pose, const double* base_plane, double* out_pose, double* out_plane,
-                             hipStream_t st);
-hipError_t launch_chi2_at(const DevGraph& d, const double* pose, const double* plane, double* host_result, double seq, hipStream_t st);
+// chi2 of the one-step loop's trial, after launch_retract_trial: evaluated at est (+) delta on the spot (pps_k4.hip)
+hipError_t launch_chi2_trial(const DevGraph& d, double* host_result, double seq, hipStream_t st);
 
 // dense-front form (pps_dense.hip): fronts of hundreds of rows, every step spread over many workgroups.
 // L must be zeroed before launch_dense_hpush; levels run leaves -> root (factor) and root -> leaves (solve).

@@ -15,6 +15,15 @@
 #define PPS_HD inline
 #endif
 
+// The retraction (exmap) of a node must give the same bits wherever it is inlined -- the fused trial kernel evaluates chi2 at
+// x (+) delta computed on the fly while another block writes the same x (+) delta to memory for the next linearisation -- so
+// these few functions are compiled without multiply-add contraction whatever the translation unit's -ffp-contract says.
+#if defined(__clang__)
+#define PPS_FP_EXACT _Pragma("clang fp contract(off)")
+#else
+#define PPS_FP_EXACT
+#endif
+
 namespace pps {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -30,6 +39,7 @@ PPS_HD double standard_rad(double t) {
 
 // Eigen quaternion product a*b
 PPS_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
+  PPS_FP_EXACT
   const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
   const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
   o[0] = aw * bx + ax * bw + ay * bz - az * by;
@@ -100,21 +110,26 @@ PPS_HD void quat_to_euler(const double q[4], double ypr[3]) {
 
 // Rot3d::delta3_to_quat  (isam/Rot3d.h:126-136)
 PPS_HD void rot_exp(const double d[3], double q[4]) {
+  PPS_FP_EXACT
   const double theta = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double sn, cs;
+  sincos(0.5 * theta, &sn, &cs);        // (one call: whether the compiler would pair a sin with a cos depends on the inlining context)
   double S;
   if (theta < 0.0001) S = 0.5 + theta * theta / 48.;
-  else S = sin(0.5 * theta) / theta;
-  q[3] = cos(0.5 * theta);
+  else S = sn / theta;
+  q[3] = cs;
   q[0] = S * d[0]; q[1] = S * d[1]; q[2] = S * d[2];
 }
 
 // boost::math::sinc_pi as used by Plane3d::delta3_to_quat (src/isam_plane3d.h:89)
-PPS_HD double sinc_pi(double x) {
+// (sin_x = sin(x), evaluated by the caller together with the cosine)
+PPS_HD double sinc_pi(double x, double sin_x) {
+  PPS_FP_EXACT
   const double eps = 2.220446049250313e-16;
   const double t2 = 1.4901161193847656e-08;   // sqrt(eps)
   const double tn = 1.220703125e-04;          // eps^(1/4)
   const double ax = fabs(x);
-  if (ax >= tn) return sin(x) / x;
+  if (ax >= tn) return sin_x / x;
   double r = 1.0;
   if (ax >= eps) {
     const double x2 = x * x;
@@ -126,19 +141,24 @@ PPS_HD double sinc_pi(double x) {
 
 // Plane3d::delta3_to_quat  (src/isam_plane3d.h:78-93)
 PPS_HD void plane_exp(const double d[3], double q[4]) {
+  PPS_FP_EXACT
   const double theta = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  const double S = 0.5 * sinc_pi(0.5 * theta);
-  q[3] = cos(0.5 * theta);
+  double sn, cs;
+  sincos(0.5 * theta, &sn, &cs);
+  const double S = 0.5 * sinc_pi(0.5 * theta, sn);
+  q[3] = cs;
   q[0] = S * d[0]; q[1] = S * d[1]; q[2] = S * d[2];
 }
 
 PPS_HD void normalize4(double v[4]) {
+  PPS_FP_EXACT
   const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
   v[0] /= n; v[1] /= n; v[2] /= n; v[3] /= n;
 }
 
 // Pose3d::exmap  (isam/Pose3d.h:131-136): t += d[0:3] ; q <- q * Exp(d[3:6])
 PPS_HD void pose_exmap(const double p[7], const double d[6], double o[7]) {
+  PPS_FP_EXACT
   double dq[4], q[4];
   rot_exp(d + 3, dq);
   quat_mul(p + 3, dq, q);
@@ -148,6 +168,7 @@ PPS_HD void pose_exmap(const double p[7], const double d[6], double o[7]) {
 
 // Plane3d::exmap_3dof  (src/isam_plane3d.h:101-127), plane_type == -1
 PPS_HD void plane_exmap(const double pl[4], const double d[3], double o[4]) {
+  PPS_FP_EXACT
   double dq[4];
   plane_exp(d, dq);
   quat_mul(dq, pl, o);

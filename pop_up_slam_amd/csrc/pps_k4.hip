@@ -61,50 +61,6 @@ __global__ __launch_bounds__(256) void k_retract(DevGraph d) {
   body_retract<TRIAL>(d, d.pose_lin, d.pose_est, d.plane_lin, d.plane_est, blockIdx.x, red);
 }
 
-// out <- base (+) delta, nothing else touched: the speculative LM trial (step computed for lambda * factor on the
-// second stream) is applied to a third copy of the state; |delta|^2 partials go to d.dn_partials
-__global__ __launch_bounds__(256) void k_retract_to(DevGraph d, DualAlt alt, const double* __restrict__ base_pose,
-                                                    const double* __restrict__ base_plane, double* __restrict__ out_pose,
-                                                    double* __restrict__ out_plane, double* __restrict__ out_pose1, double* __restrict__ out_plane1) {
-  __shared__ double red[4];
-  if (blockIdx.y) { d.delta = alt.delta; d.dn_partials = alt.dn_partials; out_pose = out_pose1; out_plane = out_plane1; }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double dn = 0.0;
-  if (i < d.n_pose) {
-    double p[7], o[7], dl[6];
-    load_pose(base_pose, d.pose_ld, i, p);
-    const int off = d.pose_voff[i];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
-    pose_exmap(p, dl, o);
-#pragma unroll
-    for (int k = 0; k < 7; k++) out_pose[(size_t)k * d.pose_ld + i] = o[k];
-  } else if (i < d.n_pose + d.n_plane) {
-    const int l = i - d.n_pose;
-    double p[4], o[4], dl[3];
-    load_plane(base_plane, d.plane_ld, l, p);
-    const int off = d.plane_voff[l];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
-    plane_exmap(p, dl, o);
-#pragma unroll
-    for (int k = 0; k < 4; k++) out_plane[(size_t)k * d.plane_ld + l] = o[k];
-  }
-#pragma unroll
-  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
-  __syncthreads();
-  if (threadIdx.x == 0) d.dn_partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-hipError_t launch_retract_to(const DevGraph& d, const double* base_pose, const double* base_plane, double* out_pose, double* out_plane,
-                             hipStream_t st) {
-  const int n = d.n_pose + d.n_plane;
-  if (n == 0) return hipSuccess;
-  PPS_LAUNCH(k_retract_to, dim3(cdiv(n, 256)), dim3(256), 0, st, d, DualAlt{}, base_pose, base_plane, out_pose, out_plane, nullptr, nullptr);
-  return hipGetLastError();
-}
-
 hipError_t launch_retract_trial(const DevGraph& d, hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
   if (n == 0) return hipSuccess;
@@ -141,11 +97,36 @@ __device__ __forceinline__ void chi2_finish(const DevGraph& d, int nb, int n_dn,
   }
 }
 
+// The state a residual is evaluated at: the stored copy, or (APPLY) base (+) delta computed on the spot -- the fused trial kernel
+// evaluates chi2 at x (+) delta without waiting for the retraction to be written (pose_exmap / plane_exmap are compiled without
+// contraction, pps_geom.h: the same bits as the stored copy).
+template <bool APPLY>
+__device__ __forceinline__ void fetch_pose(const DevGraph& d, const double* __restrict__ pose, int idx, double o[7]) {
+  if (!APPLY) { load_pose(pose, d.pose_ld, idx, o); return; }
+  double p[7], dl[6];
+  load_pose(pose, d.pose_ld, idx, p);
+  const int off = d.pose_voff[idx];
+#pragma unroll
+  for (int k = 0; k < 6; k++) dl[k] = d.delta[off + k];
+  pose_exmap(p, dl, o);
+}
+template <bool APPLY>
+__device__ __forceinline__ void fetch_plane(const DevGraph& d, const double* __restrict__ plane, int idx, double o[4]) {
+  if (!APPLY) { load_plane(plane, d.plane_ld, idx, o); return; }
+  double p[4], dl[3];
+  load_plane(plane, d.plane_ld, idx, p);
+  const int off = d.plane_voff[idx];
+#pragma unroll
+  for (int k = 0; k < 3; k++) dl[k] = d.delta[off + k];
+  plane_exmap(p, dl, o);
+}
+
 // bx: block within the graph, nb: blocks of the graph (TICKET: the one that draws the last ticket reduces)
-template <bool TICKET = true>
+// TOTAL > 0 (fused trial): the ticket counts TOTAL blocks -- the chi2 blocks and the retraction blocks of the same launch
+template <bool TICKET = true, bool APPLY = false>
 __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __restrict__ pose,
                                           const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp,
-                                          int n_dn, double* __restrict__ out, double seq, int bx, int nb) {
+                                          int n_dn, double* __restrict__ out, double seq, int bx, int nb, int total_blocks = 0) {
   __shared__ double red[kChiBlock / 64];
   int b = bx;
   double s = 0.0;
@@ -153,8 +134,8 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
     const int i = b * kChiBlock + threadIdx.x;
     if (i < d.n_obs) {
       double pz[7], pl[4], ms[4], w[6], e[3], r[3];
-      load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
-      load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+      fetch_pose<APPLY>(d, pose, d.obs_pose[i], pz);
+      fetch_plane<APPLY>(d, plane, d.obs_plane[i], pl);
       if (i < d.n_obs_fixed) load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
       else {                                  // Pose3d_Plane3d_Factor2: re-pop the measurement at this pose
         double ray[6];
@@ -170,8 +151,8 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
     const int i = b * kChiBlock + threadIdx.x;
     if (i < d.n_odo) {
       double p1[7], p2[7], ms[6], w[21], e[6], r[6];
-      load_pose(pose, d.pose_ld, d.odo_a[i], p1);
-      load_pose(pose, d.pose_ld, d.odo_b[i], p2);
+      fetch_pose<APPLY>(d, pose, d.odo_a[i], p1);
+      fetch_pose<APPLY>(d, pose, d.odo_b[i], p2);
       load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
       load_soa<21>(d.odo_w, d.odo_ld, i, w);
       res_odometry(p1, p2, ms, e);
@@ -183,7 +164,7 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
     const int i = b * kChiBlock + threadIdx.x;
     if (i < d.n_pp) {
       double pz[7], ms[6], w[21], e[6], r[6];
-      load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
+      fetch_pose<APPLY>(d, pose, d.pp_pose[i], pz);
       load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
       load_soa<21>(d.pp_w, d.pp_ld, i, w);
       res_pose_prior(pz, ms, e);
@@ -196,7 +177,7 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
     const int i = b * kChiBlock + threadIdx.x;
     if (i < d.n_lp) {
       double pl[4], ms[4], w[6], e[3], r[3];
-      load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
+      fetch_plane<APPLY>(d, plane, d.lp_plane[i], pl);
       load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
       load_soa<6>(d.lp_w, d.lp_ld, i, w);
       res_plane_prior(pl, ms, e);
@@ -222,7 +203,7 @@ __device__ __forceinline__ void body_chi2(const DevGraph& d, const double* __res
     // XCD's L2 back on this chip -- microseconds; fine for the few dozen blocks of one graph, not for the thousands of a batch.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = atomicAdd(d.ticket, 1u) == (unsigned int)(nb - 1);
+    last = atomicAdd(d.ticket, 1u) == (unsigned int)((total_blocks > 0 ? total_blocks : nb) - 1);
   }
   __syncthreads();
   if (!last) return;
@@ -238,28 +219,81 @@ __global__ __launch_bounds__(kChiBlock) void k_chi2(DevGraph d, const double* __
   body_chi2(d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
 }
 
-__global__ __launch_bounds__(kChiBlock) void k_chi2_dual(DevGraph d, DualAlt alt, const double* __restrict__ pose, const double* __restrict__ plane,
-                                                         const double* __restrict__ pose1, const double* __restrict__ plane1, int nb_obs,
-                                                         int nb_odo, int nb_pp, int n_dn, double* __restrict__ out, double seq,
-                                                         double* __restrict__ out1, double seq1) {
-  if (blockIdx.y) {
-    d.chi2_partials = alt.chi2_partials; d.dn_partials = alt.dn_partials; d.ticket = alt.ticket; d.result_dev = alt.result_dev;
-    pose = pose1; plane = plane1; out = out1; seq = seq1;
+// out <- base (+) delta for one block of nodes; the block's |delta|^2 partial goes to d.dn_partials[bx]
+__device__ __forceinline__ void body_retract_to(const DevGraph& d, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
+                                                double* __restrict__ out_pose, double* __restrict__ out_plane, int bx, double* red) {
+  const int i = bx * blockDim.x + threadIdx.x;
+  double dn = 0.0;
+  if (i < d.n_pose) {
+    double p[7], o[7], dl[6];
+    load_pose(base_pose, d.pose_ld, i, p);
+    const int off = d.pose_voff[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    pose_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 7; k++) out_pose[(size_t)k * d.pose_ld + i] = o[k];
+  } else if (i < d.n_pose + d.n_plane) {
+    const int l = i - d.n_pose;
+    double p[4], o[4], dl[3];
+    load_plane(base_plane, d.plane_ld, l, p);
+    const int off = d.plane_voff[l];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
+    plane_exmap(p, dl, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out_plane[(size_t)k * d.plane_ld + l] = o[k];
   }
-  body_chi2(d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
+  __syncthreads();
+  if (threadIdx.x == 0) d.dn_partials[bx] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Both trials of a dual solve in ONE launch (grid y = trial): blocks [0, nb_ret) write out_k <- base (+) delta_k and their
+// |delta|^2 partials, the others reduce chi2 at base (+) delta_k computed on the fly -- they do not wait for the retraction,
+// which only the next linearisation reads.  All of them take a ticket; the last one writes the result record.
+__global__ __launch_bounds__(kChiBlock) void k_trial_dual(DevGraph d, DualAlt alt, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
+                                                          double* __restrict__ out_pose, double* __restrict__ out_plane, double* __restrict__ out_pose1,
+                                                          double* __restrict__ out_plane1, int nb_ret, int nb_obs, int nb_odo, int nb_pp, int nb_chi,
+                                                          double* __restrict__ out, double seq, double* __restrict__ out1, double seq1) {
+  if (blockIdx.y) {
+    d.delta = alt.delta; d.chi2_partials = alt.chi2_partials; d.dn_partials = alt.dn_partials; d.ticket = alt.ticket; d.result_dev = alt.result_dev;
+    out_pose = out_pose1; out_plane = out_plane1; out = out1; seq = seq1;
+  }
+  const int total = nb_ret + nb_chi;
+  if ((int)blockIdx.x >= nb_ret) {
+    body_chi2<true, true>(d, base_pose, base_plane, nb_obs, nb_odo, nb_pp, nb_ret, out, seq, (int)blockIdx.x - nb_ret, nb_chi, total);
+    return;
+  }
+  __shared__ double red[4];
+  body_retract_to(d, base_pose, base_plane, out_pose, out_plane, blockIdx.x, red);
+  // the same publish / ticket protocol as a chi2 block (body_retract_to has written this block's |delta|^2 partial)
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicAdd(d.ticket, 1u) == (unsigned int)(total - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  chi2_finish(d, nb_chi, nb_ret, out, seq);
+  if (threadIdx.x == 0) *d.ticket = 0u;
 }
 
 hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
                              double seq1, hipStream_t st) {
   const int n = d.n_pose + d.n_plane;
-  if (n > 0)
-    PPS_LAUNCH(k_retract_to, dim3(cdiv(n, 256), 2), dim3(256), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1);
   const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock), nb_lp = cdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
-  if (nb == 0) return hipErrorInvalidValue;
-  PPS_LAUNCH(k_chi2_dual, dim3(nb, 2), dim3(kChiBlock), 0, st, d, alt, out_pose0, out_plane0, out_pose1, out_plane1, nb_obs, nb_odo, nb_pp,
-                     cdiv(n, 256), host_result0, seq0, host_result1, seq1);
+  if (nb == 0 || n == 0) return hipErrorInvalidValue;
+  const int nb_ret = cdiv(n, 256);
+  PPS_LAUNCH(k_trial_dual, dim3(nb_ret + nb, 2), dim3(kChiBlock), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1, nb_ret,
+             nb_obs, nb_odo, nb_pp, nb, host_result0, seq0, host_result1, seq1);
   return hipGetLastError();
 }
 
@@ -275,15 +309,19 @@ hipError_t launch_chi2(const DevGraph& d, bool at_estimate, double* host_result,
   return hipGetLastError();
 }
 
-// chi2 at an explicit state (d.chi2_partials / d.ticket / d.dn_partials are the caller's: a second reduction may run
-// concurrently on another stream with its own set)
-hipError_t launch_chi2_at(const DevGraph& d, const double* pose, const double* plane, double* host_result, double seq, hipStream_t st) {
+// chi2 of the trial of the one-step loop: after launch_retract_trial est holds the point x the step started from and lin its
+// result; the residuals are evaluated at est (+) delta computed on the spot -- the same arithmetic, in the same kernel body, as
+// the fused trial of the dual loop and the batch, so that every form of the LM loop reports the same bits
+__global__ __launch_bounds__(kChiBlock) void k_chi2_trial(DevGraph d, int nb_obs, int nb_odo, int nb_pp, int n_dn, double* __restrict__ out, double seq) {
+  body_chi2<true, true>(d, d.pose_est, d.plane_est, nb_obs, nb_odo, nb_pp, n_dn, out, seq, blockIdx.x, gridDim.x);
+}
+
+hipError_t launch_chi2_trial(const DevGraph& d, double* host_result, double seq, hipStream_t st) {
   const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock),
             nb_lp = cdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if (nb == 0) return hipErrorInvalidValue;
-  const int n_dn = cdiv(d.n_pose + d.n_plane, 256);
-  PPS_LAUNCH(k_chi2, dim3(nb), dim3(kChiBlock), 0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, n_dn, host_result, seq);
+  PPS_LAUNCH(k_chi2_trial, dim3(nb), dim3(kChiBlock), 0, st, d, nb_obs, nb_odo, nb_pp, cdiv(d.n_pose + d.n_plane, 256), host_result, seq);
   return hipGetLastError();
 }
 
@@ -311,8 +349,10 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2(BatchArgs a, int slot) {
             nb_lp = dcdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if ((int)blockIdx.x >= nb) return;
-  body_chi2<false>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
-                   a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot, a.seq, blockIdx.x, nb);
+  double* const out = a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot;
+  // slot 1: the trial of a one-lambda round -- kb_retract_trial has left x in est; chi2 at est (+) delta on the spot (k_chi2_trial)
+  if (slot == 1) body_chi2<false, true>(d, pose_est, plane_est, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256), out, a.seq, blockIdx.x, nb);
+  else body_chi2<false>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256), out, a.seq, blockIdx.x, nb);
 }
 
 // the result records of a batch: one block per graph (and per trial: grid z) sums the partials of the sweep before it
@@ -353,37 +393,6 @@ __global__ __launch_bounds__(64) void kb_begin_dual(BatchArgs a) {
   if (threadIdx.x < 4) { d.result_dev[threadIdx.x] = 0.0; al.result_dev[threadIdx.x] = 0.0; }
 }
 
-__device__ __forceinline__ void body_retract_to(const DevGraph& d, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
-                                                double* __restrict__ out_pose, double* __restrict__ out_plane, int bx, double* red) {
-  const int i = bx * blockDim.x + threadIdx.x;
-  double dn = 0.0;
-  if (i < d.n_pose) {
-    double p[7], o[7], dl[6];
-    load_pose(base_pose, d.pose_ld, i, p);
-    const int off = d.pose_voff[i];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
-    pose_exmap(p, dl, o);
-#pragma unroll
-    for (int k = 0; k < 7; k++) out_pose[(size_t)k * d.pose_ld + i] = o[k];
-  } else if (i < d.n_pose + d.n_plane) {
-    const int l = i - d.n_pose;
-    double p[4], o[4], dl[3];
-    load_plane(base_plane, d.plane_ld, l, p);
-    const int off = d.plane_voff[l];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { dl[k] = d.delta[off + k]; dn += dl[k] * dl[k]; }
-    plane_exmap(p, dl, o);
-#pragma unroll
-    for (int k = 0; k < 4; k++) out_plane[(size_t)k * d.plane_ld + l] = o[k];
-  }
-#pragma unroll
-  for (int o2 = 32; o2 > 0; o2 >>= 1) dn += __shfl_down(dn, o2, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dn;
-  __syncthreads();
-  if (threadIdx.x == 0) d.dn_partials[bx] = red[0] + red[1] + red[2] + red[3];
-}
-
 __global__ __launch_bounds__(256) void kb_retract_dual(BatchArgs a) {
   __shared__ double red[4];
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
@@ -405,10 +414,12 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2_dual(BatchArgs a) {
   const BatchAlt al = load_alt(a.alt + a.b0 + b);
   const int xs = a.xsel[b], z = blockIdx.z;
   const int ts = (xs + 1 + z) % 3;
+  (void)ts;
   DevGraph d2 = d;
-  if (z) { d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.ticket = al.ticket; d2.result_dev = al.result_dev; }
-  body_chi2<false>(d2, sel3(al.pose, ts), sel3(al.plane, ts), nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
-                   a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
+  if (z) { d2.delta = al.delta; d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.ticket = al.ticket; d2.result_dev = al.result_dev; }
+  // chi2 at x (+) delta_z computed on the spot, like k_trial_dual (the stored copy kb_retract_dual writes is for the next K1)
+  body_chi2<false, true>(d2, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+                         a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
 }
 
 hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {

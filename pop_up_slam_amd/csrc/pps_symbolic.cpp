@@ -488,11 +488,25 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     B.adj.swap(a2);
     root = top;
     if (!dense_nodes.empty()) {
-      root = B.new_tnode();
       // planes first, poses last
-      for (int u : dense_nodes) if (nodes[u].type == NODE_PLANE) B.tree[root].piv.push_back(u);
-      for (int u : dense_nodes) if (nodes[u].type == NODE_POSE) B.tree[root].piv.push_back(u);
-      if (top >= 0) B.tree[root].kids.push_back(top);
+      std::vector<int> border;
+      for (int u : dense_nodes) if (nodes[u].type == NODE_PLANE) border.push_back(u);
+      for (int u : dense_nodes) if (nodes[u].type == NODE_POSE) border.push_back(u);
+      // A small border block (the ground plane: 3 scalars) joins the top separator of the dissection as its last pivots instead
+      // of forming a front of its own: that front's boundary is the border block anyway, so the merged front has the same rows
+      // and the tree loses a level -- one front latency less on the critical path of every factorisation and back-substitution.
+      int top_dim = 0, border_dim = 0;
+      if (top >= 0) for (int u : B.tree[top].piv) top_dim += nodes[u].dim;
+      for (int u : border) border_dim += nodes[u].dim;
+      if (top >= 0 && !general_ordering && top_dim + border_dim <= prm.max_pivots) {
+        std::vector<int>& tp = B.tree[top].piv;
+        const bool already = tp.size() >= border.size() && std::equal(border.begin(), border.end(), tp.end() - (std::ptrdiff_t)border.size());   // (a top taken over from the previous analysis)
+        if (!already) tp.insert(tp.end(), border.begin(), border.end());
+      } else {
+        root = B.new_tnode();
+        B.tree[root].piv = border;
+        if (top >= 0) B.tree[root].kids.push_back(top);
+      }
     }
   }
   lap("dissection");

@@ -1,5 +1,4 @@
 import sys, os
-os.environ.setdefault("PPS_NO_SPEC", "1")   # the speculative solve on the second stream writes the same trace slots
 os.environ.setdefault("PPS_TRACE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pop_up_slam_amd as P
