@@ -539,6 +539,7 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
   __builtin_amdgcn_wave_barrier();
   double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   long long cyc_panel = 0, cyc_trail = 0;
+  bool bad = false;                                            // a pivot that is not positive: reported once, after the last panel
   for (int K = 0; K < p; K += 4) {
     const long long tk0 = (TR && d.trace) ? clock64() : 0;
     const int nb = p - K < 4 ? p - K : 4;
@@ -562,23 +563,24 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
     const double d10 = readlane_d(r0, K + 1), d11 = readlane_d(r1, K + 1);
     const double d20 = readlane_d(r0, K + 2), d21 = readlane_d(r1, K + 2), d22 = readlane_d(r2, K + 2);
     const double d30 = readlane_d(r0, K + 3), d31 = readlane_d(r1, K + 3), d32 = readlane_d(r2, K + 3), d33 = readlane_d(r3, K + 3);
-    bool bad = false;
     double i0 = 0, i1 = 0, i2 = 0, i3 = 0, l10 = 0, l20 = 0, l30 = 0, l21 = 0, l31 = 0, l32 = 0;
     double x0, x1, x2, x3;
     {
 #ifndef PPS_NO_FMA
 #pragma clang fp contract(fast)     // the serial pivot chain: a - b * c is one operation here
 #endif
-      { bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? rsqrt_nr(d00) : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
-      if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
-      if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
-      if (nb > 3) { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; bad |= !(t > 0.0); i3 = t > 0.0 ? rsqrt_nr(t) : 0.0; }
+      // (the reciprocal square root is evaluated unconditionally -- NaN for a pivot that is not positive -- and selected away:
+      // a branch per pivot would split the serial chain into basic blocks; a panel narrower than four columns, the last one of a
+      // front, zeroes the factors of the columns it does not have the same way)
+      { const double q = rsqrt_nr(d00); bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? q : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
+      { const double t = d11 - l10 * l10; const double q = rsqrt_nr(t); const bool on = nb > 1; bad |= on && !(t > 0.0); i1 = (on && t > 0.0) ? q : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
+      { const double t = d22 - l20 * l20 - l21 * l21; const double q = rsqrt_nr(t); const bool on = nb > 2; bad |= on && !(t > 0.0); i2 = (on && t > 0.0) ? q : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
+      { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; const double q = rsqrt_nr(t); const bool on = nb > 3; bad |= on && !(t > 0.0); i3 = (on && t > 0.0) ? q : 0.0; }
       x0 = r0 * i0;
       x1 = (r1 - x0 * l10) * i1;
       x2 = (r2 - x0 * l20 - x1 * l21) * i2;
       x3 = (r3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
     }
-    if (bad && lane == 0) d.result_dev[2] = 1.0;           // not positive definite
     P[lane * kPStride + 0] = x0; P[lane * kPStride + 1] = x1; P[lane * kPStride + 2] = x2; P[lane * kPStride + 3] = x3;
     if (!STRIP) {
       // the rhs row through the same triangular solve (its four panel entries sit in lanes K .. K+3 of y), then its rank-nb
@@ -668,6 +670,7 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
     __builtin_amdgcn_wave_barrier();
     if (TR && d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
   }
+  if (bad && lane == 0) d.result_dev[2] = 1.0;             // not positive definite
   if (TR) PPS_TR(4);
   if (TR && d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
   // ---- update matrix: live part of the tiles -> packed global ----
