@@ -106,105 +106,131 @@ __global__ __launch_bounds__(64) void k_popup_planes(const float* __restrict__ s
 // boxes[p] = boundingRect of the truncated polygon.  Rows are in scaled coordinates (image row / step).
 constexpr int kRowMergeCap = 17;    // lists up to this length are merged, longer ones stay raw (still exact)
 
-__global__ __launch_bounds__(256) void k_popup_rows(PopupParams prm, const float* __restrict__ polys, const int* __restrict__ poly_off,
-                                                    int nplanes, unsigned int* __restrict__ row_iv, int* __restrict__ row_cnt,
-                                                    int4* __restrict__ boxes) {
-  __shared__ float s_poly[2 * kMaxVerts];
-  __shared__ int2 s_q[kMaxVerts];                 // vertices as the integer points fillConvexPoly sees (box coordinates)
-  __shared__ RasterLine s_line[kMaxVerts];        // outline edge ending at vertex v
-  __shared__ int s_off[kMaxPlanes + 2];
-  __shared__ int4 s_box[kMaxPlanes];
-  __shared__ unsigned int s_scr[256 * kRowMergeCap];
+// LDS of the polygon set-up: the polygons as fillConvexPoly sees them
+struct PolySetup {
+  float poly[2 * kMaxVerts];
+  int2 q[kMaxVerts];                  // vertices as the integer points fillConvexPoly sees (box coordinates)
+  RasterLine line[kMaxVerts];         // outline edge ending at vertex v
+  int off[kMaxPlanes + 2];
+  int4 box[kMaxPlanes];               // boundingRect of the truncated polygon: x, y, width, height (scaled coordinates)
+};
+
+// every thread of a 256-thread workgroup calls this; ends with a barrier
+__device__ __forceinline__ void popup_poly_setup(const PopupParams& prm, const float* __restrict__ polys, const int* __restrict__ poly_off, int nplanes,
+                                                 PolySetup& L) {
   const int tid = threadIdx.x;
-  for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
+  for (int i = tid; i <= nplanes; i += 256) L.off[i] = poly_off[i];
   __syncthreads();
-  const int nverts = s_off[nplanes];
+  const int nverts = L.off[nplanes];
   const int S = prm.step;                                       // 2 = downsample_poly
-  for (int i = tid; i < 2 * nverts; i += 256) s_poly[i] = S == 2 ? polys[i] / 2 : polys[i];   // new_polys_close / 2 (:86-87)
+  for (int i = tid; i < 2 * nverts; i += 256) L.poly[i] = S == 2 ? polys[i] / 2 : polys[i];   // new_polys_close / 2 (:86-87)
   __syncthreads();
   // boundingRect of the truncated points (matrix_to_points + boundingRect, popup_plane.cpp:89-91)
   if (tid < nplanes) {
-    const int v0 = s_off[tid], v1 = s_off[tid + 1];
+    const int v0 = L.off[tid], v1 = L.off[tid + 1];
     int x0 = 0, y0b = 0, x1 = -1, y1 = -1;
     for (int v = v0; v < v1; v++) {
-      const int x = (int)s_poly[2 * v], y = (int)s_poly[2 * v + 1];
+      const int x = (int)L.poly[2 * v], y = (int)L.poly[2 * v + 1];
       if (v == v0) { x0 = x1 = x; y0b = y1 = y; }
       x0 = min(x0, x); x1 = max(x1, x); y0b = min(y0b, y); y1 = max(y1, y);
     }
-    s_box[tid] = make_int4(x0, y0b, x1 - x0 + 1, y1 - y0b + 1);
-    if (blockIdx.x == 0) boxes[tid] = s_box[tid];
+    L.box[tid] = make_int4(x0, y0b, x1 - x0 + 1, y1 - y0b + 1);
   }
   __syncthreads();
   // polygon - box origin in fp32, truncated again (:92-96)
   for (int v = tid; v < nverts; v += 256) {
     int p = 0;
-    while (s_off[p + 1] <= v) p++;
-    const int4 bx = s_box[p];
-    s_q[v] = make_int2((int)(s_poly[2 * v] - (float)bx.x), (int)(s_poly[2 * v + 1] - (float)bx.y));
+    while (L.off[p + 1] <= v) p++;
+    const int4 bx = L.box[p];
+    L.q[v] = make_int2((int)(L.poly[2 * v] - (float)bx.x), (int)(L.poly[2 * v + 1] - (float)bx.y));
   }
   __syncthreads();
   // outline: the edge that ends at vertex v starts at the previous vertex (the last one for the first)
   for (int v = tid; v < nverts; v += 256) {
     int p = 0;
-    while (s_off[p + 1] <= v) p++;
-    const int4 bx = s_box[p];
-    const int u = v > s_off[p] ? v - 1 : s_off[p + 1] - 1;
-    s_line[v] = raster_line(bx.z, bx.w, s_q[u].x, s_q[u].y, s_q[v].x, s_q[v].y);
+    while (L.off[p + 1] <= v) p++;
+    const int4 bx = L.box[p];
+    const int u = v > L.off[p] ? v - 1 : L.off[p + 1] - 1;
+    L.line[v] = raster_line(bx.z, bx.w, L.q[u].x, L.q[u].y, L.q[v].x, L.q[v].y);
   }
   __syncthreads();
+}
+
+// sub-interval i of polygon p in scaled row `row` (i = 0: the fill span, i >= 1: outline edge i - 1), as lo | hi << 16 in frame
+// columns; 1u (lo = 1 > hi = 0) = empty
+__device__ __forceinline__ unsigned int popup_raw_interval(const PolySetup& L, int row, int p, int i, int Ws) {
+  const int v0 = L.off[p], npts = L.off[p + 1] - v0;
+  const int4 bx = L.box[p];
+  const int cy = row - bx.y;
+  if (!(npts > 0 && cy >= 0 && cy < bx.w)) return 1u;
+  int lo = 0, hi = -1;
+  const bool hit = i == 0 ? raster_fill_row(L.q + v0, npts, bx.z, bx.w, cy, lo, hi) : raster_line_row(L.line[v0 + i - 1], cy, lo, hi);
+  if (!hit) return 1u;
+  lo = max(lo, 0) + bx.x; hi = min(hi, bx.z - 1) + bx.x;       // inside the box image, then frame columns (:104-113)
+  lo = max(lo, 0); hi = min(hi, Ws - 1);
+  return lo <= hi ? ((unsigned int)lo | ((unsigned int)hi << 16)) : 1u;
+}
+
+// n raw sub-intervals in iv (thread-private scratch, n <= kRowMergeCap) -> disjoint column runs in out; returns their number
+__device__ __forceinline__ int popup_merge_intervals(unsigned int* __restrict__ iv, int n, unsigned int* __restrict__ out) {
+  for (int a = 1; a < n; a++) {                                // insertion sort by lo; empty intervals merge away below
+    const unsigned int key = iv[a];
+    int b = a - 1;
+    while (b >= 0 && (iv[b] & 0xffffu) > (key & 0xffffu)) { iv[b + 1] = iv[b]; b--; }
+    iv[b + 1] = key;
+  }
+  int m = 0;
+  unsigned int cur = 1u;
+  for (int a = 0; a < n; a++) {
+    const unsigned int v = iv[a], lo = v & 0xffffu, hi = v >> 16;
+    if (lo > hi) continue;
+    if (m > 0 && lo <= (cur >> 16) + 1u) { if (hi > (cur >> 16)) cur = (cur & 0xffffu) | (hi << 16); }
+    else { if (m > 0) out[m - 1] = cur; cur = v; m++; }
+  }
+  if (m > 0) out[m - 1] = cur;
+  return m;
+}
+
+// disjoint column runs of polygon p in scaled row `row` -> out[0 .. return value); scr: kRowMergeCap words of this thread
+__device__ __forceinline__ int popup_row_item(const PolySetup& L, int row, int p, int Ws, unsigned int* __restrict__ scr, unsigned int* __restrict__ out) {
+  const int v0 = L.off[p], npts = L.off[p + 1] - v0;
+  const int4 bx = L.box[p];
+  const int cy = row - bx.y;
+  if (!(npts > 0 && cy >= 0 && cy < bx.w)) return 0;
+  const int n = npts + 1;
+  const bool merge = n <= kRowMergeCap;
+  unsigned int* iv = merge ? scr : out;
+  for (int i = 0; i < n; i++) iv[i] = popup_raw_interval(L, row, p, i, Ws);
+  return merge ? popup_merge_intervals(iv, n, out) : n;
+}
+
+__global__ __launch_bounds__(256) void k_popup_rows(PopupParams prm, const float* __restrict__ polys, const int* __restrict__ poly_off,
+                                                    int nplanes, unsigned int* __restrict__ row_iv, int* __restrict__ row_cnt,
+                                                    int4* __restrict__ boxes) {
+  __shared__ PolySetup L;
+  __shared__ unsigned int s_scr[256 * kRowMergeCap];
+  const int tid = threadIdx.x;
+  popup_poly_setup(prm, polys, poly_off, nplanes, L);
+  if (blockIdx.x == 0 && tid < nplanes) boxes[tid] = L.box[tid];
+  const int nverts = L.off[nplanes];
+  const int S = prm.step;
   const int Ws = (prm.width + S - 1) / S, Hs = (prm.height + S - 1) / S;
   const int item = blockIdx.x * 256 + tid;
   if (item >= Hs * nplanes) return;
   const int row = item / nplanes, p = item - row * nplanes;
-  const int v0 = s_off[p], npts = s_off[p + 1] - v0;
   const int E = nverts + nplanes;
-  unsigned int* __restrict__ out = row_iv + (size_t)row * E + v0 + p;
-  const int4 bx = s_box[p];
-  const int cy = row - bx.y;
-  int cnt = 0;
-  if (npts > 0 && cy >= 0 && cy < bx.w) {
-    const int n = npts + 1;
-    const bool merge = n <= kRowMergeCap;
-    unsigned int* iv = merge ? s_scr + tid * kRowMergeCap : out;
-    for (int i = 0; i < n; i++) {
-      int lo = 0, hi = -1;
-      const bool hit = i == 0 ? raster_fill_row(s_q + v0, npts, bx.z, bx.w, cy, lo, hi) : raster_line_row(s_line[v0 + i - 1], cy, lo, hi);
-      unsigned int o = 1u;                                         // lo = 1 > hi = 0: empty
-      if (hit) {
-        lo = max(lo, 0) + bx.x; hi = min(hi, bx.z - 1) + bx.x;   // inside the box image, then frame columns (:104-113)
-        lo = max(lo, 0); hi = min(hi, Ws - 1);
-        if (lo <= hi) o = (unsigned int)lo | ((unsigned int)hi << 16);
-      }
-      iv[i] = o;
-    }
-    cnt = n;
-    if (merge) {
-      for (int a = 1; a < n; a++) {                                // insertion sort by lo; empty intervals merge away below
-        const unsigned int key = iv[a];
-        int b = a - 1;
-        while (b >= 0 && (iv[b] & 0xffffu) > (key & 0xffffu)) { iv[b + 1] = iv[b]; b--; }
-        iv[b + 1] = key;
-      }
-      int m = 0;
-      unsigned int cur = 1u;
-      for (int a = 0; a < n; a++) {
-        const unsigned int v = iv[a], lo = v & 0xffffu, hi = v >> 16;
-        if (lo > hi) continue;
-        if (m > 0 && lo <= (cur >> 16) + 1u) { if (hi > (cur >> 16)) cur = (cur & 0xffffu) | (hi << 16); }
-        else { if (m > 0) out[m - 1] = cur; cur = v; m++; }
-      }
-      if (m > 0) out[m - 1] = cur;
-      cnt = m;
-    }
-  }
-  row_cnt[(size_t)row * nplanes + p] = cnt;
+  row_cnt[(size_t)row * nplanes + p] = popup_row_item(L, row, p, Ws, s_scr + tid * kRowMergeCap, row_iv + (size_t)row * E + L.off[p] + p);
 }
 
 // Fused K5 + K6.  grid = (ceil(W / 256), ceil(H / PX)): a thread owns one column of PX consecutive rows and compares its
 // column with the row intervals k_popup_rows derived (loaded into LDS for the PX rows of the workgroup).
-template <int PX>
+// FUSED (frames up to 640 x 480: BASELINE config 5): the workgroup derives the intervals of ITS rows itself -- polygon set-up and
+// the (row, polygon) items of pps_raster.h in LDS -- instead of reading what a k_popup_rows launch in front wrote: one launch
+// per frame.  On large frames every one of thousands of workgroups would repeat the set-up (1920 x 1080: 60.9 against 46.8 us),
+// so those keep the two launches.
+template <int PX, bool FUSED>
 __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const float* __restrict__ seg2d, int n,
-                                                     const int* __restrict__ poly_off, int nplanes,
+                                                     const float* __restrict__ polys, const int* __restrict__ poly_off, int nplanes,
                                                      const unsigned int* __restrict__ row_iv, const int* __restrict__ row_cnt,
                                                      const int4* __restrict__ boxes, const unsigned char* __restrict__ bgr,
                                                      float* __restrict__ planes_out, pps_point* __restrict__ cloud,
@@ -221,8 +247,10 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
   const int S = prm.step;
   const int W = prm.width, H = prm.height;
   const int y0 = blockIdx.y * PX;
-  for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
-  if (tid < nplanes) s_box[tid] = boxes[tid];
+  if (!FUSED) {
+    for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
+    if (tid < nplanes) s_box[tid] = boxes[tid];
+  }
   // ---- K5: plane equations of this frame (every workgroup; block 0 publishes them) ----
   if (tid <= n && tid <= kMaxPlanes) {
     float gs[4], pl[4];
@@ -246,15 +274,51 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
     s_cnt = 0;
   }
   __syncthreads();
-  const int E = s_off[nplanes] + nplanes;                       // entries per row of row_iv
-  // interval lists of this workgroup's rows (rows that are not a multiple of the step have none)
-  for (int i = tid; i < nplanes * PX; i += 256) {
-    const int k = i / nplanes, p = i - k * nplanes, Y = y0 + k;
-    s_ivcnt[k * nplanes + p] = (Y < H && Y % S == 0) ? row_cnt[(size_t)(Y / S) * nplanes + p] : 0;
-  }
-  for (int i = tid; i < E * PX; i += 256) {
-    const int k = i / E, Y = y0 + k;
-    s_iv[i] = (Y < H && Y % S == 0) ? row_iv[(size_t)(Y / S) * E + (i - k * E)] : 1u;
+  int E;                                                        // entries per row of the interval lists
+  if (FUSED) {
+    __shared__ PolySetup L;
+    __shared__ unsigned int s_scr[kMaxPlanes * PX * kRowMergeCap];
+    popup_poly_setup(prm, polys, poly_off, nplanes, L);
+    for (int i = tid; i <= nplanes; i += 256) s_off[i] = L.off[i];
+    if (tid < nplanes) s_box[tid] = L.box[tid];
+    E = L.off[nplanes] + nplanes;
+    const int Ws = (W + S - 1) / S;
+    // one thread per sub-interval (the fill span of a row is the long one: it replays fillConvexPoly's edge events), raw
+    // values straight into the row's list; then one thread per (row, polygon) sorts and merges its list in place
+    for (int e = tid; e < E * PX; e += 256) {
+      const int k = e / E, r = e - k * E, Y = y0 + k;
+      int p = 0;
+      while (L.off[p + 1] + p + 1 <= r) p++;
+      s_iv[e] = (Y < H && Y % S == 0) ? popup_raw_interval(L, Y / S, p, r - L.off[p] - p, Ws) : 1u;
+    }
+    __syncthreads();
+    for (int i = tid; i < nplanes * PX; i += 256) {             // (nplanes * PX <= 128 items, one thread each)
+      const int k = i / nplanes, p = i - k * nplanes, Y = y0 + k;
+      const int npts = L.off[p + 1] - L.off[p], n = npts + 1;
+      const int cy = Y / S - L.box[p].y;
+      int cnt = 0;
+      if (Y < H && Y % S == 0 && npts > 0 && cy >= 0 && cy < L.box[p].w) {
+        unsigned int* lst = s_iv + k * E + L.off[p] + p;
+        cnt = n;
+        if (n <= kRowMergeCap) {
+          unsigned int* scr = s_scr + i * kRowMergeCap;
+          for (int a = 0; a < n; a++) scr[a] = lst[a];
+          cnt = popup_merge_intervals(scr, n, lst);
+        }
+      }
+      s_ivcnt[k * nplanes + p] = cnt;
+    }
+  } else {
+    E = s_off[nplanes] + nplanes;
+    // interval lists of this workgroup's rows (rows that are not a multiple of the step have none)
+    for (int i = tid; i < nplanes * PX; i += 256) {
+      const int k = i / nplanes, p = i - k * nplanes, Y = y0 + k;
+      s_ivcnt[k * nplanes + p] = (Y < H && Y % S == 0) ? row_cnt[(size_t)(Y / S) * nplanes + p] : 0;
+    }
+    for (int i = tid; i < E * PX; i += 256) {
+      const int k = i / E, Y = y0 + k;
+      s_iv[i] = (Y < H && Y % S == 0) ? row_iv[(size_t)(Y / S) * E + (i - k * E)] : 1u;
+    }
   }
   __syncthreads();
 
@@ -342,7 +406,8 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
   }
   if ((tid & 63) == 0 && kept) atomicAdd(&s_cnt, kept);
   __syncthreads();
-  if (tid == 0 && s_cnt) atomicAdd(n_valid, s_cnt);
+  // one count per workgroup, summed on the host: hundreds of workgroups finish together, and as many atomics on one word queue up at the L2
+  if (tid == 0) n_valid[blockIdx.y * gridDim.x + blockIdx.x] = s_cnt;
 }
 
 // K5 feeding the graph: one thread per (frame, plane).  Pose comes from the fp64 estimate, is cast to
@@ -416,7 +481,8 @@ struct pps_popup {
   unsigned int* d_row_iv = nullptr;   // row intervals of the last run (k_popup_rows): height x (kMaxVerts + kMaxPlanes)
   int* d_row_cnt = nullptr;           // height x kMaxPlanes
   int4* d_boxes = nullptr;            // kMaxPlanes
-  unsigned int* d_count = nullptr;
+  unsigned int* d_count = nullptr;   // kept points per workgroup of the last run
+  size_t count_cap = 0;
   unsigned int* h_count = nullptr;   // pinned
   int last_n = 0;
   double last_kernel_s = 0;
@@ -474,11 +540,12 @@ int pps_popup_create(int device, int width, int height, const float invK[9], pps
     p->d_seg = reinterpret_cast<float*>(p->d_in + kInSegOff);
     p->d_polys = reinterpret_cast<float*>(p->d_in + kInPolyOff);
   }
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_count), sizeof(unsigned int));
+  p->count_cap = (size_t)((width + 255) / 256) * (size_t)((height + 1) / 2);      // workgroups of the finest launch geometry (2 rows each)
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_count), sizeof(unsigned int) * p->count_cap);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_iv), sizeof(unsigned int) * (size_t)height * (kMaxVerts + kMaxPlanes));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_cnt), sizeof(int) * (size_t)height * kMaxPlanes);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_boxes), sizeof(int4) * kMaxPlanes);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_count), sizeof(unsigned int), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_count), sizeof(unsigned int) * p->count_cap, hipHostMallocDefault);
   if (e != hipSuccess) { pps_popup_destroy(p); return PPS_EHIP; }
   *out = p;
   return PPS_OK;
@@ -530,36 +597,41 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   const size_t poly_bytes = sizeof(float) * 2 * (size_t)poly_off[nplanes];
   if (poly_bytes > 0) memcpy(p->h_in + kInPolyOff, polys, poly_bytes);
   PHIP(p, hipMemcpyAsync(p->d_in, p->h_in, kInPolyOff + poly_bytes, hipMemcpyHostToDevice, p->stream));
-  PHIP(p, hipMemsetAsync(p->d_count, 0, sizeof(unsigned int), p->stream));
   const int npx = p->width * p->height;
   PHIP(p, hipEventRecord(p->ev[0], p->stream));
-  // column strips of 256 x PX pixels: 2 rows per thread on small frames (640x480: 720 workgroups), 8 from ~1 Mpixel up
-  int pxt = npx >= (1 << 20) ? 8 : 2;
-  if (const char* e = getenv("PPS_POPUP_PXT")) pxt = atoi(e) >= 8 ? 8 : 2;
+  // column strips of 256 x PX pixels: 2 rows per thread on small frames (640x480: 720 workgroups), 8 from ~1 Mpixel up;
+  // frames up to 640 x 480 derive their row intervals inside the frame kernel (one launch), larger ones in a launch of their own
+  const int pxt = npx >= (1 << 20) ? 8 : 2;
+  const bool fused = npx <= 640 * 480 && nplanes > 0;
   const dim3 grid((p->width + 255) / 256, (p->height + pxt - 1) / pxt);
-  if (nplanes > 0) {
+  const unsigned char* img = p->has_image ? p->d_bgr : nullptr;
+  float* dep = p->want_depth ? p->d_depth : nullptr;
+  int* pidp = p->want_pid ? p->d_pid : nullptr;
+  if (nplanes > 0 && !fused) {
     const int hs = (p->height + step - 1) / step;
     hipLaunchKernelGGL(k_popup_rows, dim3((hs * nplanes + 255) / 256), dim3(256), 0, p->stream, prm, p->d_polys, p->d_off, nplanes,
                        p->d_row_iv, p->d_row_cnt, p->d_boxes);
   }
-  if (pxt == 8)
-    hipLaunchKernelGGL(k_popup_frame<8>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
-                       p->want_pid ? p->d_pid : nullptr, p->d_count);
+  if (fused)
+    hipLaunchKernelGGL((k_popup_frame<2, true>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
+                       p->d_boxes, img, p->d_planes, p->d_cloud, dep, pidp, p->d_count);
+  else if (pxt == 8)
+    hipLaunchKernelGGL((k_popup_frame<8, false>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
+                       p->d_boxes, img, p->d_planes, p->d_cloud, dep, pidp, p->d_count);
   else
-    hipLaunchKernelGGL(k_popup_frame<2>, grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, p->has_image ? p->d_bgr : nullptr, p->d_planes, p->d_cloud, p->want_depth ? p->d_depth : nullptr,
-                       p->want_pid ? p->d_pid : nullptr, p->d_count);
+    hipLaunchKernelGGL((k_popup_frame<2, false>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
+                       p->d_boxes, img, p->d_planes, p->d_cloud, dep, pidp, p->d_count);
   PHIP(p, hipGetLastError());
   PHIP(p, hipEventRecord(p->ev[1], p->stream));
-  PHIP(p, hipMemcpyAsync(p->h_count, p->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, p->stream));
+  const size_t n_wg = (size_t)grid.x * grid.y;
+  PHIP(p, hipMemcpyAsync(p->h_count, p->d_count, sizeof(unsigned int) * n_wg, hipMemcpyDeviceToHost, p->stream));
   PHIP(p, hipStreamSynchronize(p->stream));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, p->ev[0], p->ev[1]);
   p->last_kernel_s = 1e-3 * ms;
   p->last_n = n; p->last_step = step;
   memcpy(p->last_T, T_wc, sizeof p->last_T);
-  if (n_valid) *n_valid = (int)*p->h_count;
+  if (n_valid) { unsigned int tot = 0; for (size_t i = 0; i < n_wg; i++) tot += p->h_count[i]; *n_valid = (int)tot; }
   return PPS_OK;
 }
 

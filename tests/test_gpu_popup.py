@@ -210,7 +210,7 @@ def test_plane_info_matches_oracle(built):
         assert abs(dist[0] - T[2, 3]) == 0 and (far > 10.5) == (good[2] == 0)     # the end wall drops out beyond 10 m
 
 
-@pytest.mark.parametrize("size", [(640, 480), (321, 243), (1920, 1080)])
+@pytest.mark.parametrize("size", [(640, 480), (321, 243), (800, 600), (1920, 1080)])
 def test_plane_id_map_bit_exact_on_random_polygons(built, size):
     """convex, non-convex, degenerate, partly outside the frame, up to 64 planes; both resolutions; the 2-rows-per-thread and the
     8-rows-per-thread kernel instantiations (1920x1080 takes the latter)"""
