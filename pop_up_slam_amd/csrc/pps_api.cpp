@@ -355,7 +355,7 @@ int flush_uploads(pps_graph* g) {
     hi = std::max(hi, g->up_high); hi = std::min(hi, g->stage_cap);
     HIP_TRY(g, hipMemcpyAsync(g->up.base + lo, g->stage + lo, hi - lo, hipMemcpyHostToDevice, g->stream));
     g->up_bytes_sent = hi - lo;
-  } else if (g->up_patches.size() <= 3 || getenv("PPS_NO_PATCH_UPLOAD")) {
+  } else if (g->up_patches.size() <= 3) {
     for (const auto& pt : g->up_patches)        // a few pieces: straight from the pinned mirror
       HIP_TRY(g, hipMemcpyAsync(g->up.base + pt.off, g->stage + pt.off, pt.len, hipMemcpyHostToDevice, g->stream));
   } else {
@@ -528,8 +528,6 @@ int run_analysis(pps_graph* g) {
   g->cmp_valid = !any_deleted && sn.size() == g->nodes.size();
   }
   g->cmp_nodes = g->nodes.size(); g->cmp_factors = g->factors.size();
-  if (const char* e = getenv("PPS_LEAF_POSES")) g->aprm.leaf_poses = atoi(e);
-  if (const char* e = getenv("PPS_MAX_PIVOTS")) g->aprm.max_pivots = atoi(e);
   // band depth: 4 levels per launch when the solve is latency bound (C2: 512 fronts; 113.3 vs 115.0 us per LM iteration
   // with 3), 2 when the lower levels are throughput bound (C3: 5 360 fronts; 637 vs 710 us)
   g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 4;
@@ -537,17 +535,12 @@ int run_analysis(pps_graph* g) {
   // (ground plane, 32 contributions = 16 dependent load rounds) are K2's critical path; long on large ones, where the
   // number of waves is (C2: 23.3 -> 18.7 us with 8; C3: 82 -> 102 us)
   g->aprm.seg_len = g->pose_ids.size() >= 4000 ? 32 : 8;
-  if (const char* e = getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = atoi(e);
-  if (const char* e = getenv("PPS_ARITY")) g->aprm.arity = atoi(e);
   // a graph that is re-analysed after pure appends is a frame loop: absolute cut positions keep the left part of its tree
   g->aprm.aligned_cuts = (g->n_analyses > 0 && g->grown_only) ? 1 : 0;
-  if (const char* e = getenv("PPS_ALIGNED_CUTS")) g->aprm.aligned_cuts = atoi(e);
   // ... and its aligned cuts leave a few fronts of 65 .. 80 rows, whose 25 KB triangles let 5 waves share a CU's LDS, not 8:
   // groups of 4 leaves (3 levels per launch) keep every front of a level on its own wave (C5: 1 580 vs 1 500 frames/s)
-  if (g->aprm.aligned_cuts && g->pose_ids.size() < 4000 && !getenv("PPS_BAND_LEVELS")) g->aprm.band_levels = 3;
-  if (const char* e = getenv("PPS_SEG_LEN")) g->aprm.seg_len = atoi(e);
+  if (g->aprm.aligned_cuts && g->pose_ids.size() < 4000) g->aprm.band_levels = 3;
   g->aprm.band_rows = band_front_limit();
-  if (const char* e = getenv("PPS_ORDERING")) g->aprm.ordering = atoi(e);
   const char* msg = "";
   try {
   if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "compaction (api)", 1e3 * (now_s() - t0));
@@ -556,7 +549,7 @@ int run_analysis(pps_graph* g) {
     return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
   // fronts beyond the wave-per-front kernels (loop-closure separators) run in the dense-front form, whose cost is
   // per tree level: split their supernodes into 64-pivot chunks instead of 48 (a quarter fewer levels)
-  if (g->an.max_front > band_front_limit() && g->aprm.max_pivots < dense_front_max_pivots() && !getenv("PPS_MAX_PIVOTS")) {
+  if (g->an.max_front > band_front_limit() && g->aprm.max_pivots < dense_front_max_pivots()) {
     AnalysisParams wide = g->aprm;
     wide.max_pivots = dense_front_max_pivots();
     if (!analyze(sn, sf, wide, g->an, &msg, getenv("PPS_NO_INCREMENTAL") ? nullptr : g->acache))
@@ -578,10 +571,10 @@ int run_analysis(pps_graph* g) {
     for (int s = 0; s < A.n_fronts; s++) { int& m = g->stage_max_piv[A.f_level[s] / Bn]; m = std::max(m, A.f_p[s]); }
     int max_piv = 0;
     for (int m : g->stage_max_piv) max_piv = std::max(max_piv, m);
-    g->use_band = A.max_front <= band_front_limit() && max_piv <= 64 && !getenv("PPS_NO_BAND");
+    g->use_band = A.max_front <= band_front_limit() && max_piv <= 64;
     // the dense-front solve keeps a front's boundary values in LDS: 15 000 scalars is the ceiling (2-D loop-closure
     // meshes such as torus10000 reach 24 540 under this chain-based dissection and are refused, see below)
-    g->use_dense = !g->use_band && max_piv <= dense_front_max_pivots() && A.max_front <= 15000 && !getenv("PPS_NO_DENSE");
+    g->use_dense = !g->use_band && max_piv <= dense_front_max_pivots() && A.max_front <= 15000;
     g->level_max_b.assign(A.n_levels, 0);
     g->max_el_per_front = 0;
     for (int s = 0; s < A.n_fronts; s++) {
@@ -605,8 +598,7 @@ int run_analysis(pps_graph* g) {
     g->stage_max_grp_fronts.assign(A.n_stages, 1); g->stage_max_panel.assign(A.n_stages, 1);
     for (int s = 0; s < A.n_fronts; s++) { int& m = g->stage_max_panel[A.f_level[s] / Bn]; m = std::max(m, (A.f_p[s] + A.f_b[s] + 1) * A.f_p[s]); }
     const size_t lds_budget = 150 * 1024;
-    int max_waves = 8;
-    if (const char* e = getenv("PPS_BAND_WAVES")) max_waves = std::max(1, std::min(8, atoi(e)));
+    const int max_waves = 8;
     for (int st = 0; st < A.n_stages; st++) {
       const int want = std::max(1, std::min(max_waves, A.stage_max_width[st]));
       g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st], A.stage_max_front[st] + 1 <= band_reg_rows() && !getenv("PPS_TRACE"))));
@@ -751,7 +743,7 @@ int upload_all(pps_graph* g) {
     for (const HostFactor& f : g->factors) if (!f.deleted) { n_obs_new += f.type == F_PLANE_OBS; n_lp_new += f.type == F_PLANE_PRIOR; any_repop = any_repop || (f.type == F_PLANE_OBS && f.repop); }
     keep_meas = g->grown_only_upload && !g->up_unknown && !g->up_unknown_meas && g->up.spill == 0 && !any_repop && g->dev.n_obs == g->dev.n_obs_fixed &&
                 j_capacity((int64_t)n_obs_new) == g->dev.obs_ld && j_capacity((int64_t)n_lp_new) == g->dev.lp_ld && g->slot_obs_meas < g->up_slots.size() &&
-                !getenv("PPS_NO_KEEP_MEAS");
+                true;
     if (!keep_meas) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
   }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
@@ -795,7 +787,7 @@ int upload_all(pps_graph* g) {
   };
   std::vector<double> tmp;
   // the previous upload's packed arrays are still right for the old factors when nothing was removed since (slots only append)
-  const bool incr_pack = was_grown_only && !getenv("PPS_NO_INCR_PACK");
+  const bool incr_pack = was_grown_only;
   d.obs_ld = (int)j_capacity(d.n_obs); d.odo_ld = (int)j_capacity(d.n_odo); d.pp_ld = (int)j_capacity(d.n_pp); d.lp_ld = (int)j_capacity(d.n_lp);
   {
     // one pass over the plane observations (a HostFactor is 300 bytes: four passes were four times the memory traffic), and
@@ -997,27 +989,12 @@ int do_linearize(pps_graph* g, const LinGuard* guard = nullptr) {
 }
 
 // delta = (J'J + lambda diag(J'J))^-1 J'b  (Optimizer::compute_gauss_newton_step, Optimizer.cpp:49-67)
-// The root stage (one group) is factored and back-substituted in one launch; its LDS must fit both phases with the
-// factor's wave count.
-static bool root_fusable(const pps_graph* g) {
-  const Analysis& A = g->an;
-  const int st = A.n_stages - 1;
-  if (st < 0 || !getenv("PPS_ROOT_FUSE")) return false;      // opt-in: measured neutral on C2 / C3 (121.5 vs 120.5 us per iteration)
-  const size_t need = band_solve_lds_bytes(g->stage_max_panel[st]) * g->stage_nw_factor[st] +
-                      (size_t)g->stage_max_grp_fronts[st] * band_max_rows() * sizeof(double);
-  return need <= 150 * 1024;
-}
-
 int do_solve_on(pps_graph* g, const DevGraph& dv, double lambda, hipStream_t st_) {
   const Analysis& A = g->an;
-  const bool fuse = root_fusable(g);
-  for (int st = 0; st < A.n_stages; st++) {
-    const bool last = fuse && st == A.n_stages - 1;
+  for (int st = 0; st < A.n_stages; st++)
     HIP_TRY(g, launch_band_factor(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
-                                  A.stage_max_front[st], lambda, st_, last ? g->stage_max_panel[st] : 0,
-                                  last ? g->stage_max_grp_fronts[st] : 0));
-  }
-  for (int st = A.n_stages - 1 - (fuse ? 1 : 0); st >= 0; st--)
+                                  A.stage_max_front[st], lambda, st_));
+  for (int st = A.n_stages - 1; st >= 0; st--)
     HIP_TRY(g, launch_band_solve(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
                                  g->stage_max_panel[st], g->stage_max_grp_fronts[st], st_));
   return PPS_OK;
@@ -1026,7 +1003,7 @@ int do_solve_on(pps_graph* g, const DevGraph& dv, double lambda, hipStream_t st_
 int do_solve(pps_graph* g, double lambda) {
   const Analysis& A = g->an;
   if (g->use_band) {
-    if (g->profiling < 2) {            // no per-phase timing: root stage fused (factor + solve in one launch)
+    if (g->profiling < 2) {            // no per-phase timing
       int rc = do_solve_on(g, g->dev, lambda, g->stream);
       if (rc != PPS_OK) return rc;
       g->stats.n_factorize++;
@@ -1766,10 +1743,12 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     g->status_clean = false;
     max_stages = std::max(max_stages, g->an.n_stages);
   }
-  // both damping values of a linearisation in the same launches (lm_solve_dual's scheme), when every handle has its second
+  // both damping values of a linearisation in the same launches (lm_solve_dual's scheme): every uploaded handle has its second
   // factor / state set
-  bool dual = !getenv("PPS_MULTI_NO_DUAL");
-  for (int i = 0; i < G && dual; i++) dual = m->gs[i]->spec_L && m->gs[i]->spec_U && m->gs[i]->spec_delta && m->gs[i]->spec_pose && m->gs[i]->spec_result;
+  for (int i = 0; i < G; i++)
+    if (!(m->gs[i]->spec_L && m->gs[i]->spec_U && m->gs[i]->spec_delta && m->gs[i]->spec_pose && m->gs[i]->spec_result))
+      return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + " has no second factor set (not uploaded)");
+  const bool dual = true;
   if (!m->stream) MHIP(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   if (m->cap_results < (size_t)G) {
     if (m->results) (void)hipHostFree(m->results);
@@ -1835,10 +1814,10 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
-    q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_LANES")) || getenv("PPS_MULTI_THREAD_FORM");
-    q.k1_direct = (q.lin_thread_form || mode == PPS_JAC_ANALYTIC) && !getenv("PPS_MULTI_NO_DIRECT");   // the analytic sweep always runs one thread per factor
+    q.lin_thread_form = q.n_factors_total > 200000 || getenv("PPS_MULTI_THREAD_FORM");      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
+    q.k1_direct = q.lin_thread_form || mode == PPS_JAC_ANALYTIC;   // the analytic sweep always runs one thread per factor
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
-    q.level_form = level_ok && ((q.n_factors_total > 200000 && !getenv("PPS_MULTI_BANDS")) || getenv("PPS_MULTI_LEVELS"));   // (PPS_MULTI_LEVELS: forced onto small batches by the parity test)
+    q.level_form = level_ok && (q.n_factors_total > 200000 || getenv("PPS_MULTI_LEVELS"));
     { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));
@@ -1857,7 +1836,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         const Analysis& A = m->gs[i]->an;
         if (stg < A.n_stages) total_groups += (dual ? 2 : 1) * (A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
       }
-      if (!getenv("PPS_MULTI_WIDE") && total_groups > 0) {
+      if (total_groups > 0) {
         const long long slots_f = (long long)n_cu * std::max<size_t>(1, lds_budget / fw);
         const long long slots_s = (long long)n_cu * std::max<size_t>(1, (lds_budget - std::min(lds_budget / 2, xbytes)) / sw);
         q.stage_nw_factor[stg] = (int)std::max<long long>(1, std::min<long long>(q.stage_nw_factor[stg], (slots_f + total_groups - 1) / total_groups));
@@ -1866,7 +1845,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
   }
   // ---- dual-lambda form: every graph walks lm_solve_dual's scheme, in lockstep rounds of one linearisation each ----
-  if (dual) {
+  {
     std::vector<BatchAlt> ha(G);
     for (int i = 0; i < G; i++) {
       pps_graph* g = m->gs[i];
@@ -2045,164 +2024,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     if (first_bad != PPS_OK) return mfail(m, first_bad, "at least one graph ended on a factorisation that was not positive definite (see status[])");
     return PPS_OK;
   }
-  // ---- LM state per graph ----
-  struct LM { double lambda, error, dnorm; int num_iter; bool done, swap, trial_pending, relin, active, last_notpd; int n_notpd; };
-  std::vector<LM> lm(G);
-  for (int i = 0; i < G; i++) lm[i] = LM{m->gs[i]->props.lm_lambda0, 0.0, 0.0, 0, false, false, true, true, true, false, 0};
-  auto make_args = [&](int c) {
-    BatchArgs a{};
-    a.gs = m->d_gs; a.stage_tab = m->d_stage; a.results = m->results; a.n_total = G; a.b0 = c * kBatchMax;
-    a.n = std::min(G, (c + 1) * kBatchMax) - a.b0; a.seq = m->seq;
-    for (int k = 0; k < a.n; k++) {
-      const LM& s = lm[a.b0 + k];
-      a.lambda[k] = s.lambda;
-      a.flags[k] = (unsigned char)((s.active ? BF_ACTIVE : 0) | (s.relin ? BF_RELIN : 0) | (s.swap ? BF_SWAP : 0));
-    }
-    return a;
-  };
-  auto wait_round = [&](int slot) -> int {
-    const double tw = now_s();
-    unsigned spins = 0;
-    for (int i = 0; i < G; i++) {
-      if (!lm[i].active) continue;
-      volatile double* r = m->results + 8 * (size_t)i + 4 * slot;
-      while (r[3] != m->seq) {
-        if ((++spins & 0x3ff) == 0 && now_s() - tw > 2.0) {
-          MHIP(m, hipStreamSynchronize(m->stream));
-          if (r[3] != m->seq) return mfail(m, PPS_EHIP, "result record of graph " + std::to_string(i) + " did not arrive");
-        }
-      }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return PPS_OK;
-  };
-  m->ev_used = 0; m->n_relin = 0; m->n_solves = 0;
-  for (double& t : m->t_phase) t = 0;
-  auto mark = [&]() -> hipEvent_t {          // next event of the pool, recorded on the stream (profiling only)
-    if (!m->profiling) return nullptr;
-    if (m->ev_used == m->evs.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; m->evs.push_back(e); }
-    hipEvent_t e = m->evs[m->ev_used++];
-    (void)hipEventRecord(e, m->stream);
-    return e;
-  };
-  auto next_event = [&]() -> hipEvent_t {    // next event of the pool, recorded by the callee
-    if (!m->profiling) return nullptr;
-    if (m->ev_used == m->evs.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; m->evs.push_back(e); }
-    return m->evs[m->ev_used++];
-  };
-  // one round of one chunk: 6 events e0 | K1 | e1 | K2 | e2 | factor | e3 | solve | e4 | trial | e5
-  auto run_round = [&](const BatchArgs& a, const BatchGeom& q, bool first, bool any_relin) -> int {
-    if (first) MHIP(m, launch_batch_begin(a, q, m->stream));
-    mark();
-    if (any_relin) MHIP(m, launch_batch_linearize(a, q, q.lin_thread_form ? mode | 2 : mode, m->stream));
-    mark();
-    if (any_relin) MHIP(m, launch_batch_hblocks(a, q, m->stream));
-    if (first) MHIP(m, launch_batch_chi2(a, q, 0, m->stream));
-    mark();
-    hipEvent_t ef = next_event();
-    MHIP(m, launch_batch_solve(a, q, m->stream, ef));
-    mark();
-    MHIP(m, launch_batch_trial(a, q, m->stream));
-    mark();
-    return PPS_OK;
-  };
-  // ---- round 0: lin <- est, linearise, chi2 at the linearisation point, first trial ----
-  m->seq += 1.0; m->rounds = 0;
-  for (int c = 0; c < n_chunks; c++) {
-    const BatchArgs a = make_args(c);
-    int rc = run_round(a, geom[c], true, true); if (rc != PPS_OK) return rc;
-  }
-  m->n_relin += G; m->n_solves += G;
-  { int rc = wait_round(1); if (rc != PPS_OK) return rc; }
-  m->rounds++;
-  for (int i = 0; i < G; i++) {
-    pps_graph* g = m->gs[i];
-    const double* r0 = m->results + 8 * (size_t)i;
-    lm[i].error = r0[0]; g->stats.chi2_initial = r0[0];
-    lm[i].dnorm = std::sqrt(r0[5]); lm[i].last_notpd = r0[6] != 0.0; lm[i].n_notpd = lm[i].last_notpd ? 1 : 0;
-    g->stats.n_linearize = 1; g->stats.n_factorize = 1;
-  }
-  // ---- rounds: Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) per graph, in lockstep ----
-  for (;;) {
-    int n_active = 0;
-    for (int i = 0; i < G; i++) {
-      LM& s = lm[i];
-      s.active = false; s.relin = false;
-      if (s.done) continue;
-      pps_graph* g = m->gs[i];
-      const pps_props& prop = g->props;
-      if (!((prop.max_iterations <= 0 || s.num_iter < prop.max_iterations) && s.dnorm > prop.epsilon2 && s.error > prop.epsilon_abs)) { s.done = true; continue; }
-      s.num_iter++;
-      const double error_new = m->results[8 * (size_t)i + 4];
-      const double error_diff = s.error - error_new;
-      const bool accepted = error_diff > 0.;
-      g->tr_lambda.push_back(s.lambda); g->tr_chi2.push_back(error_new); g->tr_acc.push_back(accepted ? 1 : 0);
-      if (accepted) {
-        g->stats.lm_trials_accepted++;
-        if (error_diff < prop.epsilon_rel * s.error) { s.error = error_new; s.trial_pending = false; s.done = true; continue; }   // (:431-434)
-        s.lambda /= prop.lm_lambda_factor;
-        s.error = error_new;
-        s.relin = true;                                              // relinearise around the accepted point (:444)
-        g->stats.n_linearize++;
-      } else {
-        g->stats.lm_trials_rejected++;
-        s.lambda *= prop.lm_lambda_factor;
-        s.swap = !s.swap;                                            // estimate_to_linpoint: restore (:454)
-      }
-      s.active = true;
-      g->stats.n_factorize++;
-      n_active++;
-    }
-    if (n_active == 0) break;
-    m->seq += 1.0;
-    for (int c = 0; c < n_chunks; c++) {
-      const BatchArgs a = make_args(c);
-      bool any = false, any_relin = false;
-      for (int k = 0; k < a.n; k++) { any = any || (a.flags[k] & BF_ACTIVE); any_relin = any_relin || (a.flags[k] & BF_RELIN); }
-      if (!any) continue;
-      for (int k = 0; k < a.n; k++) { m->n_solves += (a.flags[k] & BF_ACTIVE) ? 1 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
-      int rc = run_round(a, geom[c], false, any_relin); if (rc != PPS_OK) return rc;
-    }
-    { int rc = wait_round(1); if (rc != PPS_OK) return rc; }
-    m->rounds++;
-    for (int i = 0; i < G; i++) {
-      if (!lm[i].active) continue;
-      const double* r1 = m->results + 8 * (size_t)i + 4;
-      lm[i].dnorm = std::sqrt(r1[1]);
-      lm[i].last_notpd = r1[2] != 0.0;
-      lm[i].n_notpd += lm[i].last_notpd ? 1 : 0;
-    }
-  }
-  MHIP(m, hipStreamSynchronize(m->stream));
-  for (size_t k = 0; k + 6 <= m->ev_used; k += 6) {          // e0 e1 e2 ef(after factor) e3 e4 in recording order
-    const hipEvent_t* e = &m->evs[k];
-    // recording order inside run_round: mark, mark, mark, next_event (= after factor), mark (after solve), mark (after trial)
-    const int from[5] = {0, 1, 2, 3, 4}, to[5] = {1, 2, 3, 4, 5};
-    for (int ph = 0; ph < 5; ph++) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, e[from[ph]], e[to[ph]]) == hipSuccess) m->t_phase[ph] += 1e-3 * ms;
-    }
-  }
-  // ---- hand the estimates back to the handles ----
-  int first_bad = PPS_OK;
-  m->t_total = now_s() - t0;
-  for (int i = 0; i < G; i++) {
-    pps_graph* g = m->gs[i];
-    const LM& s = lm[i];
-    // the estimate is the logical `est` copy when the last trial is still pending (it is undone), else the logical `lin`
-    // copy (linpoint_to_estimate, :466); `swap` says whether logical and physical copies are exchanged
-    if (s.swap == s.trial_pending) swap_state(g);
-    g->dev_values_newer = true; g->lin_is_est = false;
-    g->stats.lm_iterations = s.num_iter; g->stats.chi2_final = s.error; g->stats.lambda_final = s.lambda; g->stats.last_delta_norm = s.dnorm;
-    g->stats.lm_trials_notpd = s.n_notpd; g->stats.t_total = m->t_total;
-    if (iterations) iterations[i] = s.num_iter;
-    const int st_i = s.last_notpd ? PPS_ENOTPD : PPS_OK;
-    if (st_i != PPS_OK) g->err = "normal equations not positive definite at the last LM trial";
-    if (status) status[i] = st_i;
-    if (st_i != PPS_OK && first_bad == PPS_OK) first_bad = st_i;
-  }
-  if (first_bad != PPS_OK) return mfail(m, first_bad, "at least one graph ended on a factorisation that was not positive definite (see status[])");
-  return PPS_OK;
 }
 
 int pps_multi_set_profiling(pps_multi* m, int level) { if (!m) return PPS_EINVAL; m->profiling = level > 0 ? 1 : 0; return PPS_OK; }

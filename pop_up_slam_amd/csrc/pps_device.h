@@ -104,7 +104,6 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
                                hipStream_t st);
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);
 // wave-per-front band kernels: one workgroup per group of the stage, `nwaves` fronts in flight per workgroup
-// fused_solve_panel > 0: the back-substitution of the same groups follows inside the launch (used for the root stage)
 // Two damping values of one linearisation in the same launches (blockIdx.y = 0 / 1): the second factorisation has its own
 // L / U / delta, not-PD flag and reduction scratch, everything else (J, H, the index arrays) is shared.  A rejected LM trial only
 // changes lambda, so the step for lambda * factor is computed next to the step for lambda (Optimizer.cpp:448-458).
@@ -113,8 +112,7 @@ struct DualAlt {
   unsigned int* ticket;
   double lambda;
 };
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
-                              int fused_solve_panel = 0, int fused_solve_group_fronts = 0);
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st);
 hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
                              const DualAlt* alt = nullptr);
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
@@ -161,8 +159,7 @@ hipError_t launch_dense_solve_level(const DevGraph& d, int level_begin, int leve
 // copies is the linearisation point -- travels in the kernel arguments.
 constexpr int kBatchMax = 128;
 enum { BF_ACTIVE = 1,      // the graph takes part in this round
-       BF_RELIN = 2,       // ... and is re-linearised first (its last trial was accepted)
-       BF_SWAP = 4 };      // est / lin exchanged (an odd number of rejections since the pointers were last in order)
+       BF_RELIN = 2 };     // ... and is re-linearised first (its last trial was accepted)
 struct BatchStage { int grp_begin, grp_count; };
 // Dual-lambda form of a batch (the lm_solve_dual scheme per graph): what the second factorisation of a graph writes, and the
 // three copies of its state.  x = state[xsel] is the linearisation point, state[(xsel + 1) % 3] / [(xsel + 2) % 3] receive
@@ -209,12 +206,10 @@ struct BatchGeom {
   int solve_per_wave_all = 0;           // LDS doubles per wave of the level solve (largest panel of the chunk)
   int stage_max_front[32] = {0};    // largest front (scalars, without the rhs row) of the stage over the chunk's graphs
 };
-hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // lin <- est for every active graph
 hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st);   // K1 of the BF_RELIN graphs (mode | 2: thread-per-factor form)
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st);               // K2 of the BF_RELIN graphs
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st);        // chi2 at lin -> results[8 b + 4 slot]
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor = nullptr);   // K3, lambda per graph
-hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st);        // est <- lin, lin <- lin (+) delta, chi2 -> slot 1
 hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // not-PD flags of both factorisations cleared
 hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // state[..] <- x (+) delta_z, chi2 -> slots 1 / 2
 

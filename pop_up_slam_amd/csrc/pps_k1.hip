@@ -28,8 +28,9 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, 
 
 __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double* __restrict__ pose,
                                                         const double* __restrict__ plane, LinGuard gd) {
+  __shared__ double repop_lds[64 * 31];
   if (!lin_guard(gd, pose, plane)) return;
-  body_linearize_repop(d, pose, plane, blockIdx.x);
+  body_linearize_repop(d, pose, plane, blockIdx.x, repop_lds);
 }
 
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard) {
@@ -149,8 +150,9 @@ __global__ __launch_bounds__(kLinBlock) void kb_linearize(BatchArgs a) {
 
 __global__ __launch_bounds__(64) void kb_linearize_repop(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  __shared__ double repop_lds[64 * 31];
   if ((int)blockIdx.x * 64 >= d.n_obs - d.n_obs_fixed) return;
-  body_linearize_repop(d, pose_lin, plane_lin, blockIdx.x);
+  body_linearize_repop(d, pose_lin, plane_lin, blockIdx.x, repop_lds);
 }
 
 hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st) {

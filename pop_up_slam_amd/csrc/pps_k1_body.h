@@ -426,12 +426,14 @@ constexpr int kLaneParallelMaxFactors = 200000;
 // Pose3d_Plane3d_Factor2 edges (slots [n_obs_fixed, n_obs)): central differences in both Jacobian modes -- the
 // measurement moves with the pose perturbation (the reference differentiates it numerically too).
 __device__ __forceinline__ void body_linearize_repop(const DevGraph& d, const double* __restrict__ pose,
-                                                     const double* __restrict__ plane, int bx) {
+                                                     const double* __restrict__ plane, int bx, double* __restrict__ lds_wave) {
   const int n2 = d.n_obs - d.n_obs_fixed;
-  const int k = bx * 64 + threadIdx.x;
-  if (k >= n2) return;
+  const int k0 = bx * 64;                                             // first edge of this wave (one wave per workgroup)
+  if (k0 >= n2) return;
+  const int k = min(k0 + (int)threadIdx.x, n2 - 1);                   // clamped: every lane stays active for the staged store
   const int i = d.n_obs_fixed + k;
-  double pz[7], pl[4], ray[6], w[6], e[3], r[3], Jp[18], Jl[9];
+  double pz[7], pl[4], ray[6], w[6], e[3], r[3];
+  double* __restrict__ out = lds_wave + (threadIdx.x & 63) * 31;      // the record is built in LDS (the loops below stay rolled)
   load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
   load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
   load_soa<6>(d.obs_ray, n2, k, ray);
@@ -445,7 +447,7 @@ __device__ __forceinline__ void body_linearize_repop(const DevGraph& d, const do
     pose_exmap(pz, dl, pp); res_plane_obs2(pp, pl, ray, e); whiten<3>(w, e, yp);
     dl[j] = -kNumDiffEps;
     pose_exmap(pz, dl, pp); res_plane_obs2(pp, pl, ray, e); whiten<3>(w, e, ym);
-    for (int q = 0; q < 3; q++) Jp[q * 6 + j] = (yp[q] - ym[q]) * inv2e;
+    for (int q = 0; q < 3; q++) out[q * 6 + j] = (yp[q] - ym[q]) * inv2e;
   }
   for (int j = 0; j < 3; j++) {
     double dl[3] = {0, 0, 0}, pp[4], yp[3], ym[3];
@@ -453,12 +455,11 @@ __device__ __forceinline__ void body_linearize_repop(const DevGraph& d, const do
     plane_exmap(pl, dl, pp); res_plane_obs2(pz, pp, ray, e); whiten<3>(w, e, yp);
     dl[j] = -kNumDiffEps;
     plane_exmap(pl, dl, pp); res_plane_obs2(pz, pp, ray, e); whiten<3>(w, e, ym);
-    for (int q = 0; q < 3; q++) Jl[q * 3 + j] = (yp[q] - ym[q]) * inv2e;
+    for (int q = 0; q < 3; q++) out[18 + q * 3 + j] = (yp[q] - ym[q]) * inv2e;
   }
-  double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
-  for (int q = 0; q < 18; q++) out[q] = Jp[q];
-  for (int q = 0; q < 9; q++) out[18 + q] = Jl[q];
   for (int q = 0; q < 3; q++) out[27 + q] = r[q];
+  // 64 records of 240 bytes leave as one contiguous stream (a record per lane would be 30 scattered 8-byte stores per lane)
+  flush_records_coalesced<30>(d.J + d.joff_obs + (size_t)(d.n_obs_fixed + k0) * 30, min(64, n2 - k0), lds_wave);
 }
 
 }  // namespace pps

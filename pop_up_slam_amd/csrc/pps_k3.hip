@@ -795,13 +795,12 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int
   body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
-// REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the fused
-// root solve are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
+// REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the phase trace
+// are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
 // REG_STRIP (with REG_ONLY): the stage also holds fronts of 65 .. 80 rows -- ten register tiles + the LDS strip -- and still
-// nothing that needs the LDS-tile path, the trace or the fused root solve (frame-loop trees, C3)
+// nothing that needs the LDS-tile path or the trace (frame-loop trees, C3)
 template <bool REG_ONLY, bool REG_STRIP = false, bool TR = false>
-__device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave,
-                                                 int solve_doubles_per_wave, double* __restrict__ lds) {
+__device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* F = lds + (size_t)wave * lds_doubles_per_wave;
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
@@ -822,42 +821,25 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
   }
-  if (REG_ONLY) return;
-  // root stage: the back-substitution of the same group follows at once (one launch less per solve); the factor's
-  // LDS is dead by now and is re-partitioned for the solve
-  if (solve_doubles_per_wave > 0) {
-    double* W = lds + (size_t)wave * solve_doubles_per_wave;
-    double* X = lds + (size_t)nw * solve_doubles_per_wave;
-    const int g0 = d.glvl_front_off[l0];
-    for (int l = l1 - 1; l >= l0; l--) {
-      const int i1 = d.glvl_front_off[l + 1];
-      for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
-        const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
-        wave_front_solve(d, rec, W, X, i - g0);
-      }
-      __syncthreads();
-    }
-  }
 }
 
 template <bool REG_ONLY>
-__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave,
-                                                     int solve_doubles_per_wave) {
+__global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
-  body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, solve_doubles_per_wave, lds);
+  body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
-// PPS_TRACE=1 PPS_TRACE_LEAN=1: the phase trace compiled into the register-only (one front at a time) kernel
+// PPS_TRACE=1 on a register-only stage: the phase trace compiled into the register-only kernel
 __global__ __launch_bounds__(512) void k_band_factor_lean_trace(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
-  body_band_factor<true, false, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, 0, lds);
+  body_band_factor<true, false, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
 __global__ __launch_bounds__(512) void k_band_factor_strip(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
-  body_band_factor<true, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, 0, lds);
+  body_band_factor<true, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
 static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
@@ -877,29 +859,20 @@ static hipError_t ensure_band_attrs() {
   return hipSuccess;
 }
 
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
-                              int fused_solve_panel, int fused_solve_group_fronts) {
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st) {
   if (grp_count == 0) return hipSuccess;
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
-  const bool reg_only = max_front + 1 <= kRegRows && fused_solve_panel <= 0 && d.trace == nullptr;
+  const bool reg_only = max_front + 1 <= kRegRows;
   const int per_wave = (int)(band_lds_bytes(max_front, reg_only) / sizeof(double));
-  size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
-  int solve_per_wave = 0;
-  if (fused_solve_panel > 0) {       // the stage's back-substitution runs in the same launch (root stage)
-    solve_per_wave = (int)(band_solve_lds_bytes(fused_solve_panel) / sizeof(double));
-    bytes = std::max(bytes, ((size_t)solve_per_wave * nwaves + (size_t)fused_solve_group_fronts * kBandMaxRows) * sizeof(double));
-  }
-  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace != nullptr && getenv("PPS_TRACE_LEAN")) {      // phase trace of the register-only kernel
-    const int pw = (int)(band_lds_bytes(max_front, true) / sizeof(double));
-    PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count), dim3(64 * nwaves), (size_t)pw * nwaves * sizeof(double), st, d, DualAlt{}, grp_begin, lambda, pw);
-    return hipGetLastError();
-  }
-  if (max_front + 1 <= kRegRows && solve_per_wave == 0 && d.trace == nullptr)   // (the phase trace lives in the full kernel)
-    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, 0);
-  else if (max_front + 1 <= kRegRowsMax && solve_per_wave == 0 && d.trace == nullptr && !d.no_strip)
+  const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
+  if (reg_only && d.trace != nullptr)      // phase trace of the register-only kernel
+    PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
+  else if (reg_only)
+    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
+  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
     PPS_LAUNCH(k_band_factor_strip, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
   else
-    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave, solve_per_wave);
+    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
   return hipGetLastError();
 }
 
@@ -910,11 +883,11 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
   const int per_wave = (int)(band_lds_bytes(max_front, max_front + 1 <= kRegRows && d.trace == nullptr) / sizeof(double));
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   if (max_front + 1 <= kRegRows && d.trace == nullptr)
-    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
     PPS_LAUNCH(k_band_factor_strip, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else
-    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave, 0);
+    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   return hipGetLastError();
 }
 
@@ -972,10 +945,10 @@ __global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, in
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
     DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
-    body_band_factor<REG_ONLY>(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, 0, lds);
+    body_band_factor<REG_ONLY>(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, lds);
     return;
   }
-  body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, 0, lds);
+  body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, lds);
 }
 
 __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int lds_doubles_per_wave) {

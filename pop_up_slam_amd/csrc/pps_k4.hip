@@ -326,33 +326,14 @@ hipError_t launch_chi2_trial(const DevGraph& d, double* host_result, double seq,
 }
 
 // ---- batched forms ----
-// lin <- est (estimate_to_linpoint, Optimizer.cpp:376) for the graphs of the chunk
-__global__ __launch_bounds__(256) void kb_begin(BatchArgs a) {
-  PPS_BATCH_PROLOGUE(BF_ACTIVE)
-  const int np = 7 * d.pose_ld, nl = 4 * d.plane_ld;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < np + nl; i += gridDim.x * 256) {
-    if (i < np) pose_lin[i] = pose_est[i]; else plane_lin[i - np] = plane_est[i - np];
-  }
-  if (blockIdx.x == 0 && threadIdx.x < 4) d.result_dev[threadIdx.x] = 0.0;
-}
-
-__global__ __launch_bounds__(256) void kb_retract_trial(BatchArgs a) {
-  __shared__ double red[4];
-  PPS_BATCH_PROLOGUE(BF_ACTIVE)
-  if ((int)blockIdx.x * 256 >= d.n_pose + d.n_plane) return;
-  body_retract<true>(d, pose_lin, pose_est, plane_lin, plane_est, blockIdx.x, red);
-}
-
 __global__ __launch_bounds__(kChiBlock) void kb_chi2(BatchArgs a, int slot) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   const int nb_obs = dcdiv(d.n_obs, kChiBlock), nb_odo = dcdiv(d.n_odo, kChiBlock), nb_pp = dcdiv(d.n_pp, kChiBlock),
             nb_lp = dcdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if ((int)blockIdx.x >= nb) return;
-  double* const out = a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot;
-  // slot 1: the trial of a one-lambda round -- kb_retract_trial has left x in est; chi2 at est (+) delta on the spot (k_chi2_trial)
-  if (slot == 1) body_chi2<false, true>(d, pose_est, plane_est, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256), out, a.seq, blockIdx.x, nb);
-  else body_chi2<false>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256), out, a.seq, blockIdx.x, nb);
+  body_chi2<false>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
+                   a.results + (size_t)(a.alt ? 12 : 8) * (size_t)(a.b0 + b) + 4 * slot, a.seq, blockIdx.x, nb);
 }
 
 // the result records of a batch: one block per graph (and per trial: grid z) sums the partials of the sweep before it
@@ -369,21 +350,11 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2_finish(BatchArgs a, int slo
   chi2_finish(d2, nb, n_dn, a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + blockIdx.z), a.seq);
 }
 
-hipError_t launch_batch_begin(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
-  PPS_LAUNCH(kb_begin, dim3(std::max(1, std::min(8, g.retract)), a.n), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
-
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st) {
   if (g.chi2 <= 0) return hipErrorInvalidValue;
   PPS_LAUNCH(kb_chi2, dim3(g.chi2, a.n), dim3(kChiBlock), 0, st, a, slot);
   PPS_LAUNCH(kb_chi2_finish, dim3(1, a.n), dim3(kChiBlock), 0, st, a, slot, 0);
   return hipGetLastError();
-}
-
-hipError_t launch_batch_trial(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
-  if (g.retract > 0) PPS_LAUNCH(kb_retract_trial, dim3(g.retract, a.n), dim3(256), 0, st, a);
-  return launch_batch_chi2(a, g, 1, st);
 }
 
 // ---- dual-lambda batch (BatchAlt): both trials of a graph in one launch, grid z = 0 / 1 ----

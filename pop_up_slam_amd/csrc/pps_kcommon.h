@@ -97,23 +97,20 @@ __device__ __forceinline__ BatchAlt load_alt(const BatchAlt* ap) {
 }
 __device__ __forceinline__ double* sel3(double* const (&p)[3], int k) { return k == 0 ? p[0] : (k == 1 ? p[1] : p[2]); }
 
-// single-lambda form: est / lin exchanged by BF_SWAP.  Dual form (a.alt): the linearisation point is state[xsel] -- it takes the
-// place of `lin` for K1 and chi2 -- and nothing is ever written over it.
+// The linearisation point of a graph in a round is state[xsel] of its three state copies -- it takes the place of `lin` for K1
+// and chi2 -- and nothing is ever written over it.
 #define PPS_BATCH_PROLOGUE(NEED)                                                                             \
   const int b = blockIdx.y;                                                                                  \
   const unsigned int fl = a.flags[b];                                                                        \
   if ((fl & (NEED)) != (NEED)) return;                                                                       \
   const DevGraph d = load_graph(a.gs + a.b0 + b);                                                            \
-  const bool swp = (fl & BF_SWAP) != 0;                                                                      \
-  double* pose_lin = swp ? d.pose_est : d.pose_lin;                                                          \
-  double* pose_est = swp ? d.pose_lin : d.pose_est;                                                          \
-  double* plane_lin = swp ? d.plane_est : d.plane_lin;                                                       \
-  double* plane_est = swp ? d.plane_lin : d.plane_est;                                                       \
+  double* pose_lin = d.pose_lin;                                                                             \
+  double* plane_lin = d.plane_lin;                                                                           \
   if (a.alt) {                                                                                               \
     const BatchAlt al_ = load_alt(a.alt + a.b0 + b);                                                         \
     pose_lin = sel3(al_.pose, a.xsel[b]); plane_lin = sel3(al_.plane, a.xsel[b]);                            \
   }                                                                                                          \
-  (void)pose_lin; (void)pose_est; (void)plane_lin; (void)plane_est;
+  (void)pose_lin; (void)plane_lin;
 
 __device__ __forceinline__ int dcdiv(int a, int b) { return (a + b - 1) / b; }
 
