@@ -407,7 +407,7 @@ hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipSt
   return hipGetLastError();
 }
 
-// patch upload of a re-uploaded topology (pps_api.cpp: flush_uploads): piece i of the patch buffer -> its place in the arena
+// patch upload of a re-uploaded topology (pps_upload.cpp: flush_uploads): piece i of the patch buffer -> its place in the arena
 __global__ __launch_bounds__(256) void k_scatter_patches(const char* __restrict__ patch, char* __restrict__ arena) {
   const long long* tab = reinterpret_cast<const long long*>(patch) + 4 * (size_t)blockIdx.x;
   const long long dst = tab[0], src = tab[1], len = tab[2];

@@ -1,0 +1,688 @@
+// pps_upload.cpp -- from the host tables to HBM: compaction + symbolic analysis (once per topology; incremental for frame
+// loops), the two device arenas, the difference upload (pinned mirror, patch buffer + scatter kernel), state and measurement
+// transfers.  pps_graph.h lists the other implementation files.
+#include "pps_graph.h"
+
+using namespace pps;
+using namespace pps_impl;
+
+namespace pps_impl {
+
+void free_device(pps_graph* g) {
+  for (void* p : g->allocs) (void)hipFree(p);
+  g->allocs.clear();
+  // arenas are kept; grow them when the last layout spilled into fallback allocations
+  for (pps_graph::Arena* a : {&g->up, &g->scr}) {
+    const size_t want = (a == &g->up ? std::max(a->off, g->up_high) : a->off) + a->spill;
+    if (a->spill > 0 || a->base == nullptr) {
+      if (a->base) (void)hipFree(a->base);
+      a->cap = std::max<size_t>(size_t(1) << 20, 2 * want);
+      if (hipMalloc(reinterpret_cast<void**>(&a->base), a->cap) != hipSuccess) { a->base = nullptr; a->cap = 0; }
+      if (a == &g->up) { g->up_slots.clear(); g->up_high = 0; g->up_unknown = true; }
+    }
+    a->off = 0; a->spill = 0;
+  }
+  g->up_cursor = 0; g->up_patches.clear();
+  if (g->stage_cap < g->up.cap) {
+    if (g->stage) (void)hipHostFree(g->stage);
+    g->stage = nullptr; g->stage_cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&g->stage), g->up.cap, hipHostMallocDefault) == hipSuccess) g->stage_cap = g->up.cap;
+    g->up_unknown = true;
+  }
+  g->stage_lo = g->stage_hi = 0;
+  g->dev = DevGraph();
+}
+
+void release_arenas(pps_graph* g) {
+  for (pps_graph::Arena* a : {&g->up, &g->scr}) { if (a->base) (void)hipFree(a->base); a->base = nullptr; a->cap = a->off = a->spill = 0; }
+  if (g->stage) (void)hipHostFree(g->stage);
+  g->stage = nullptr; g->stage_cap = 0;
+  if (g->patch_host) (void)hipHostFree(g->patch_host);
+  if (g->state_pin) (void)hipHostFree(g->state_pin);
+  g->state_pin = nullptr; g->state_pin_cap = 0;
+  if (g->patch_dev) (void)hipFree(g->patch_dev);
+  g->patch_host = g->patch_dev = nullptr; g->patch_cap = g->patch_dev_cap = 0;
+  g->up_slots.clear(); g->up_high = 0; g->up_unknown = true;
+}
+
+// bytes [0, n) of `src` against the mirror at offset o: record (and copy into the mirror) the range that differs
+void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force) {
+  if (n == 0) return;
+  char* mir = g->stage + o;
+  g->up_bytes_total += n;
+  if (g->up_unknown || force) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n, false}); return; }
+  // first and last 64-byte chunk that differs from what the device holds (4 KB strides first: most arrays of a frame loop
+  // are unchanged from end to end, or up to a short tail)
+  size_t lo = 0, hi = n;
+  while (lo + 4096 <= hi && memcmp(mir + lo, src + lo, 4096) == 0) lo += 4096;
+  while (lo + 64 <= hi && memcmp(mir + lo, src + lo, 64) == 0) lo += 64;
+  if (lo + 64 > hi && memcmp(mir + lo, src + lo, hi - lo) == 0) return;      // identical
+  while (hi >= lo + 4096 && memcmp(mir + hi - 4096, src + hi - 4096, 4096) == 0) hi -= 4096;
+  while (hi >= lo + 64 && memcmp(mir + hi - 64, src + hi - 64, 64) == 0) hi -= 64;
+  lo &= ~size_t(15);
+  memcpy(mir + lo, src + lo, hi - lo);
+  g->up_patches.push_back(pps_graph::UpPatch{o + lo, hi - lo, false});
+}
+
+// The k-th upload of a layout goes where the k-th upload of the previous layout went, as long as it fits the slot.
+// rows > 0: an SoA array of `rows` rows with leading dimension ld of which the first `used` entries per row are live -- the
+// rows are compared one by one (appending a factor touches the end of every row, not the array from end to end).
+
+// send what differs: everything in one copy when the device content is unknown or most of it changed, else the patches
+int flush_uploads(pps_graph* g) {
+  // callers: upload_all (after its opening stream sync) and the frame tables of pps_refresh_measurements (which settles
+  // up_inflight first) -- the pinned mirror and the patch buffer are never rewritten under a copy that still reads them
+  size_t sent = 0;
+  for (const auto& pt : g->up_patches) sent += pt.len;
+  g->up_bytes_sent = sent;
+  if (g->up_patches.empty()) { g->up_bytes_total = 0; return PPS_OK; }
+  // One copy of the whole arena only when the device content is unknown.  Otherwise nothing but the changed pieces may be
+  // written: the span between two pieces can hold what kernels have refreshed behind the mirror's back (the observation
+  // measurements that stay on the device) -- a copy "from the first to the last change" would put stale values over them.
+  if (g->up_unknown) {
+    size_t lo = 0, hi = 0;
+    for (const auto& pt : g->up_patches) hi = std::max(hi, pt.off + pt.len);
+    hi = std::max(hi, g->up_high); hi = std::min(hi, g->stage_cap);
+    HIP_TRY(g, hipMemcpyAsync(g->up.base + lo, g->stage + lo, hi - lo, hipMemcpyHostToDevice, g->stream));
+    g->up_bytes_sent = hi - lo;
+  } else if (g->up_patches.size() <= 3) {
+    for (const auto& pt : g->up_patches)        // a few pieces: straight from the pinned mirror
+      HIP_TRY(g, hipMemcpyAsync(g->up.base + pt.off, g->stage + pt.off, pt.len, hipMemcpyHostToDevice, g->stream));
+  } else {
+    // [table: 4 x int64 per patch | data, 16-byte aligned pieces] -> one copy -> scatter kernel
+    const size_t np = g->up_patches.size();
+    size_t need = np * 32;
+    std::vector<size_t> src_off(np);
+    auto plen = [&](size_t i) { const auto& pt = g->up_patches[i]; return pt.exact8 ? pt.len : ((pt.len + 15) & ~size_t(15)); };   // (exact pieces are multiples of 8)
+    for (size_t i = 0; i < np; i++) { need = (need + 15) & ~size_t(15); src_off[i] = need; need += plen(i); }
+    if (need > g->patch_cap) {
+      if (g->patch_host) (void)hipHostFree(g->patch_host);
+      g->patch_host = nullptr; g->patch_cap = 0;
+      const size_t cap = std::max<size_t>(1 << 16, 2 * need);
+      HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->patch_host), cap, hipHostMallocDefault));
+      g->patch_cap = cap;
+    }
+    if (need > g->patch_dev_cap) {
+      if (g->patch_dev) (void)hipFree(g->patch_dev);
+      g->patch_dev = nullptr; g->patch_dev_cap = 0;
+      const size_t cap = std::max<size_t>(1 << 16, 2 * need);
+      HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->patch_dev), cap));
+      g->patch_dev_cap = cap;
+    }
+    long long* tab = reinterpret_cast<long long*>(g->patch_host);
+    for (size_t i = 0; i < np; i++) {
+      const auto& pt = g->up_patches[i];
+      tab[4 * i + 0] = (long long)pt.off; tab[4 * i + 1] = (long long)src_off[i]; tab[4 * i + 2] = (long long)plen(i); tab[4 * i + 3] = pt.exact8 ? 1 : 0;
+      memcpy(g->patch_host + src_off[i], g->stage + pt.off, plen(i));    // the mirror already holds the new bytes
+    }
+    HIP_TRY(g, hipMemcpyAsync(g->patch_dev, g->patch_host, need, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(g, launch_scatter_patches(g->patch_dev, (int)np, g->up.base, g->stream));
+    // (the mirror and the patch buffer are written again by the next upload_all, which begins and ends with a stream sync)
+  }
+  g->up_unknown = false;
+  g->up_patches.clear();
+  g->stage_lo = g->stage_hi = 0;
+  return PPS_OK;
+}
+
+// PPS_DEBUG_VERIFY_UPLOAD=1: after a flush, the arena on the device must equal the pinned mirror (except the observation
+// measurements, which kernels refresh behind the mirror's back) -- PPS_ESTATE if not.  tests/test_gpu_pipeline.py runs a frame
+// loop under it.
+int verify_uploads(pps_graph* g, const char* where) {
+  if (!getenv("PPS_DEBUG_VERIFY_UPLOAD") || g->up_high == 0 || g->up.spill) return PPS_OK;
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  std::vector<char> dev(g->up_high);
+  HIP_TRY(g, hipMemcpy(dev.data(), g->up.base, g->up_high, hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < g->up_slots.size() && k < g->up_cursor; k++) {
+    if (k == g->slot_obs_meas || k == g->slot_lp_meas) continue;
+    const size_t o = g->up_slots[k].off, n = std::min(g->up_slots[k].cap, g->up_high - std::min(g->up_high, o));
+    if (o >= g->up_high) continue;
+    if (memcmp(dev.data() + o, g->stage + o, n) != 0) {
+      size_t b = 0; while (b < n && dev[o + b] == g->stage[o + b]) b++;
+      return fail(g, PPS_ESTATE, std::string("upload verification (") + where + "): slot " + std::to_string(k) + " (offset " + std::to_string(o) + ", capacity " +
+                                     std::to_string(g->up_slots[k].cap) + ") differs from the mirror at byte " + std::to_string(b));
+    }
+  }
+  return PPS_OK;
+}
+
+int ensure_device(pps_graph* g) {
+  if (g->dev_ready) return PPS_OK;
+  HIP_TRY(g, hipSetDevice(g->props.device));
+  HIP_TRY(g, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->host_result), 12 * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(g, hipEventCreate(&g->ev[0]));
+  HIP_TRY(g, hipEventCreate(&g->ev[1]));
+  g->dev_ready = true;
+  return PPS_OK;
+}
+
+// Offsets of the four per-type slabs of the J buffer: [plane obs | odometry | pose priors | plane priors].  Every slab is
+// sized for a capacity that grows in powers of two, so that a graph that gains a few factors per frame keeps all of its J
+// offsets -- and with them the whole contribution list of the H-block kernel -- from one frame to the next.
+int64_t j_capacity(int64_t n) { int64_t c = 16; while (c < n) c <<= 1; return c; }
+void j_bases(const pps_graph* g, int64_t base[4], int64_t* total) {
+  const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(),
+                n_obs = g->fslot_ids[F_PLANE_OBS].size(), n_lp = g->fslot_ids[F_PLANE_PRIOR].size();
+  const int64_t joff_obs = 0, joff_odo = j_capacity(n_obs) * 30, joff_pp = joff_odo + j_capacity(n_odo) * 78,
+                joff_lp = joff_pp + j_capacity(n_pp) * 42;
+  base[F_POSE_PRIOR] = joff_pp; base[F_ODOMETRY] = joff_odo; base[F_PLANE_OBS] = joff_obs; base[F_PLANE_PRIOR] = joff_lp;
+  if (total) *total = joff_lp + j_capacity(n_lp) * 12;
+}
+
+// ---- compaction + symbolic analysis (host only) -------------------------------------------
+int run_analysis(pps_graph* g) {
+  const double t0 = now_s();
+  std::vector<SymNode>& sn = g->sym_nodes;
+  std::vector<SymFactor>& sf = g->sym_factors;
+  // A graph that only grew since the last analysis (the frame loop) appends to the compacted tables instead of walking
+  // every node and factor again; re-popping edges are ordered behind the fixed ones, which moves slots: they take the full path.
+  bool append = g->cmp_valid && g->grown_only && g->n_analyses > 0 && !g->cmp_has_repop && g->cmp_nodes <= g->nodes.size() &&
+                g->cmp_factors <= g->factors.size() && !getenv("PPS_NO_INCR_COMPACT");
+  for (size_t i = g->cmp_factors; append && i < g->factors.size(); i++)
+    append = !g->factors[i].deleted && !(g->factors[i].type == F_PLANE_OBS && g->factors[i].repop);
+  for (size_t i = g->cmp_nodes; append && i < g->nodes.size(); i++) append = !g->nodes[i].deleted;
+  if (append) {
+    for (size_t i = g->cmp_nodes; i < g->nodes.size(); i++) {
+      HostNode& n = g->nodes[i];
+      n.compact = (int)sn.size();
+      if (n.type == NODE_POSE) { n.slot = (int)g->pose_ids.size(); g->pose_ids.push_back((int)i); sn.push_back({NODE_POSE, 6, n.slot}); }
+      else { n.slot = (int)g->plane_ids.size(); g->plane_ids.push_back((int)i); sn.push_back({NODE_PLANE, 3, -1}); }
+    }
+    for (size_t i = g->cmp_factors; i < g->factors.size(); i++) {
+      HostFactor& f = g->factors[i];
+      f.slot = (int)g->fslot_ids[f.type].size();
+      g->fslot_ids[f.type].push_back((int)i);
+    }
+    g->n_obs_fixed = (int)g->fslot_ids[F_PLANE_OBS].size();
+    int64_t base[4], j_total = 0;
+    j_bases(g, base, &j_total);
+    if (j_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
+    if (memcmp(base, g->cmp_base, sizeof(base)) != 0) {          // a J slab outgrew its capacity: every offset moves
+      int cnt[4] = {0, 0, 0, 0};
+      for (SymFactor& q : sf) q.joff = (int)(base[q.type] + (int64_t)(cnt[q.type]++) * kJSize[q.type]);
+      memcpy(g->cmp_base, base, sizeof(base));
+    }
+    for (size_t i = g->cmp_factors; i < g->factors.size(); i++) {
+      const HostFactor& f = g->factors[i];
+      SymFactor q;
+      q.type = f.type;
+      q.a = g->nodes[f.a].compact;
+      q.b = f.b >= 0 ? g->nodes[f.b].compact : -1;
+      q.joff = (int)(base[f.type] + (int64_t)f.slot * kJSize[f.type]);
+      q.direct_ok = f.type == F_PLANE_OBS ? 1 : 0;
+      sf.push_back(q);
+    }
+  } else {
+  g->pose_ids.clear(); g->plane_ids.clear();
+  for (int t = 0; t < 4; t++) g->fslot_ids[t].clear();
+  sn.clear(); sf.clear();
+  for (size_t i = 0; i < g->nodes.size(); i++) {
+    HostNode& n = g->nodes[i];
+    if (n.deleted) { n.compact = n.slot = -1; continue; }
+    n.compact = (int)sn.size();
+    if (n.type == NODE_POSE) { n.slot = (int)g->pose_ids.size(); g->pose_ids.push_back((int)i); sn.push_back({NODE_POSE, 6, n.slot}); }
+    else { n.slot = (int)g->plane_ids.size(); g->plane_ids.push_back((int)i); sn.push_back({NODE_PLANE, 3, -1}); }
+  }
+  // plane observations with a fixed measurement first, the re-popping ones (Factor2) behind them
+  g->cmp_has_repop = false;
+  for (int pass = 0; pass < 2; pass++)
+    for (size_t i = 0; i < g->factors.size(); i++) {
+      HostFactor& f = g->factors[i];
+      if (f.deleted) { f.slot = -1; continue; }
+      if ((f.type == F_PLANE_OBS && f.repop) != (pass == 1)) continue;
+      if (pass == 1) g->cmp_has_repop = true;
+      f.slot = (int)g->fslot_ids[f.type].size();
+      g->fslot_ids[f.type].push_back((int)i);
+    }
+  g->n_obs_fixed = 0;
+  for (int id : g->fslot_ids[F_PLANE_OBS]) g->n_obs_fixed += g->factors[id].repop ? 0 : 1;
+  int64_t base[4], j_total = 0;
+  j_bases(g, base, &j_total);
+  if (j_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
+  memcpy(g->cmp_base, base, sizeof(base));
+  sf.reserve(g->factors.size());
+  bool any_deleted = false;
+  for (size_t i = 0; i < g->factors.size(); i++) {
+    const HostFactor& f = g->factors[i];
+    if (f.deleted) { any_deleted = true; continue; }
+    SymFactor s;
+    s.type = f.type;
+    s.a = g->nodes[f.a].compact;
+    s.b = f.b >= 0 ? g->nodes[f.b].compact : -1;
+    s.joff = (int)(base[f.type] + (int64_t)f.slot * kJSize[f.type]);
+    s.direct_ok = (f.type == F_PLANE_OBS && !f.repop) ? 1 : 0;
+    sf.push_back(s);
+  }
+  // the append path relies on: table index == host index order with nothing skipped
+  g->cmp_valid = !any_deleted && sn.size() == g->nodes.size();
+  }
+  g->cmp_nodes = g->nodes.size(); g->cmp_factors = g->factors.size();
+  // band depth: 4 levels per launch when the solve is latency bound (C2: 512 fronts; 113.3 vs 115.0 us per LM iteration
+  // with 3), 2 when the lower levels are throughput bound (C3: 5 360 fronts; 637 vs 710 us)
+  g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 4;
+  // H-block segments (contributions reduced by one wave of K2): short on small graphs, where the few long segments
+  // (ground plane, 32 contributions = 16 dependent load rounds) are K2's critical path; long on large ones, where the
+  // number of waves is (C2: 23.3 -> 18.7 us with 8; C3: 82 -> 102 us)
+  g->aprm.seg_len = g->pose_ids.size() >= 4000 ? 32 : 8;
+  // a graph that is re-analysed after pure appends is a frame loop: absolute cut positions keep the left part of its tree
+  g->aprm.aligned_cuts = (g->n_analyses > 0 && g->grown_only) ? 1 : 0;
+  // ... and its aligned cuts leave a few fronts of 65 .. 80 rows, whose 25 KB triangles let 5 waves share a CU's LDS, not 8:
+  // groups of 4 leaves (3 levels per launch) keep every front of a level on its own wave (C5: 1 580 vs 1 500 frames/s)
+  if (g->aprm.aligned_cuts && g->pose_ids.size() < 4000) g->aprm.band_levels = 3;
+  g->aprm.band_rows = band_front_limit();
+  const char* msg = "";
+  try {
+  if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "compaction (api)", 1e3 * (now_s() - t0));
+  if (!g->acache) g->acache = analysis_cache_new();
+  if (!analyze(sn, sf, g->aprm, g->an, &msg, getenv("PPS_NO_INCREMENTAL") ? nullptr : g->acache))
+    return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+  // fronts beyond the wave-per-front kernels (loop-closure separators) run in the dense-front form, whose cost is
+  // per tree level: split their supernodes into 64-pivot chunks instead of 48 (a quarter fewer levels)
+  if (g->an.max_front > band_front_limit() && g->aprm.max_pivots < dense_front_max_pivots()) {
+    AnalysisParams wide = g->aprm;
+    wide.max_pivots = dense_front_max_pivots();
+    if (!analyze(sn, sf, wide, g->an, &msg, getenv("PPS_NO_INCREMENTAL") ? nullptr : g->acache))
+      return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
+  }
+  } catch (const std::bad_alloc&) {
+    g->an = Analysis();
+    return fail(g, PPS_ENOMEM, "symbolic analysis ran out of host memory (fronts too wide for this ordering)");
+  }
+  g->level_max_front.assign(g->an.n_levels, 0);
+  for (int s = 0; s < g->an.n_fronts; s++) {
+    int& m = g->level_max_front[g->an.f_level[s]];
+    m = std::max(m, g->an.f_p[s] + g->an.f_b[s]);
+  }
+  {
+    const Analysis& A = g->an;
+    const int Bn = std::max(1, g->aprm.band_levels);
+    g->stage_max_piv.assign(A.n_stages, 1);
+    for (int s = 0; s < A.n_fronts; s++) { int& m = g->stage_max_piv[A.f_level[s] / Bn]; m = std::max(m, A.f_p[s]); }
+    int max_piv = 0;
+    for (int m : g->stage_max_piv) max_piv = std::max(max_piv, m);
+    g->use_band = A.max_front <= band_front_limit() && max_piv <= 64;
+    // the dense-front solve keeps a front's boundary values in LDS: 15 000 scalars is the ceiling (2-D loop-closure
+    // meshes such as torus10000 reach 24 540 under this chain-based dissection and are refused, see below)
+    g->use_dense = !g->use_band && max_piv <= dense_front_max_pivots() && A.max_front <= 15000;
+    g->level_max_b.assign(A.n_levels, 0);
+    g->max_el_per_front = 0;
+    for (int s = 0; s < A.n_fronts; s++) {
+      g->level_max_b[A.f_level[s]] = std::max(g->level_max_b[A.f_level[s]], A.f_b[s]);
+      g->max_el_per_front = std::max(g->max_el_per_front, A.f_el_off[s + 1] - A.f_el_off[s]);
+    }
+    g->dw_asm.clear(); g->dw_pan.clear(); g->dw_trl.clear();
+    if (g->use_dense)
+      for (int l = 0; l < A.n_levels; l++) {
+        int a = 0, pn = 0, t = 0;
+        g->dw_asm.push_back(0); g->dw_pan.push_back(0); g->dw_trl.push_back(0);
+        for (int k = A.level_off[l]; k < A.level_off[l + 1]; k++) {
+          const int s = A.level_fronts[k];
+          const int fa = A.f_p[s] + A.f_b[s] + 1, b1 = A.f_b[s] + 1;
+          const int T32 = (fa + 31) / 32, T64 = (b1 + 63) / 64;
+          a += T32 * ((A.f_p[s] + 31) / 32); pn += (fa - A.f_p[s] + 255) / 256; t += T64 * (T64 + 1) / 2;
+          g->dw_asm.push_back(a); g->dw_pan.push_back(pn); g->dw_trl.push_back(t);
+        }
+      }
+    g->stage_nw_factor.assign(A.n_stages, 1); g->stage_nw_solve.assign(A.n_stages, 1);
+    g->stage_max_grp_fronts.assign(A.n_stages, 1); g->stage_max_panel.assign(A.n_stages, 1);
+    for (int s = 0; s < A.n_fronts; s++) { int& m = g->stage_max_panel[A.f_level[s] / Bn]; m = std::max(m, (A.f_p[s] + A.f_b[s] + 1) * A.f_p[s]); }
+    const size_t lds_budget = 150 * 1024;
+    const int max_waves = 8;
+    for (int st = 0; st < A.n_stages; st++) {
+      const int want = std::max(1, std::min(max_waves, A.stage_max_width[st]));
+      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st], A.stage_max_front[st] + 1 <= band_reg_rows() && !getenv("PPS_TRACE"))));
+      int mg = 1;
+      for (int gi = A.stage_grp_off[st]; gi < A.stage_grp_off[st + 1]; gi++)
+        mg = std::max(mg, A.glvl_front_off[A.grp_lvl_off[gi + 1]] - A.glvl_front_off[A.grp_lvl_off[gi]]);
+      g->stage_max_grp_fronts[st] = mg;
+      // per workgroup: one local solution vector per front of a group + per wave xb and the factor panel.  A group that does
+      // not fit (very wide elimination trees: hundreds of fronts in one band group) takes the graph off the band kernels.
+      const size_t xbytes = (size_t)mg * band_max_rows() * sizeof(double);
+      const size_t per_wave = band_solve_lds_bytes(g->stage_max_panel[st]);
+      if (xbytes + per_wave > lds_budget) { g->use_band = false; g->stage_nw_solve[st] = 1; continue; }
+      g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, (lds_budget - xbytes) / per_wave));
+    }
+    // (such a graph then runs on the level-per-launch kernels: its fronts are <= 127 rows by the use_band test above)
+  }
+  if (!g->use_band && !g->use_dense && g->an.max_front > 4096)
+    return fail(g, PPS_ENOMEM, "fronts too wide for this ordering (max front " + std::to_string(g->an.max_front) +
+                               " scalars): the pose chain is not a good dissection backbone for this graph");
+  if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "total incl. api", 1e3 * (now_s() - t0));
+  g->analyzed = true; g->analysis_stale = false;
+  g->n_analyses++; g->grown_only = true;
+  g->stats.n_fronts = g->an.n_fronts; g->stats.n_levels = g->an.n_levels; g->stats.max_front = g->an.max_front;
+  g->stats.nnz_L = g->an.L_size;
+  g->stats.t_analysis = now_s() - t0;
+  return PPS_OK;
+}
+
+// pinned staging for the estimate (pose rows, then plane rows): copies to and from pageable memory are staged by the runtime
+// and cost a synchronisation each
+int state_pin_reserve(pps_graph* g, size_t doubles) {
+  if (doubles <= g->state_pin_cap) return PPS_OK;
+  if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }
+  if (g->state_pin) (void)hipHostFree(g->state_pin);
+  g->state_pin = nullptr; g->state_pin_cap = 0;
+  const size_t cap = std::max<size_t>(4096, 2 * doubles);
+  HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->state_pin), cap * sizeof(double), hipHostMallocDefault));
+  g->state_pin_cap = cap;
+  return PPS_OK;
+}
+
+// pull the device estimate back into the host node table
+int download_state(pps_graph* g) {
+  if (!g->dev_values_newer) return PPS_OK;
+  HIP_TRY(g, hipSetDevice(g->props.device));
+  const DevGraph& d = g->dev;
+  const size_t np = (size_t)7 * d.pose_ld, nl = (size_t)4 * d.plane_ld;
+  int rc = state_pin_reserve(g, np + nl);
+  if (rc != PPS_OK) return rc;
+  double* bp = g->state_pin; double* bl = g->state_pin + np;
+  HIP_TRY(g, hipMemcpyAsync(bp, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToHost, g->stream));   // [poses | planes], one block
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) g->nodes[g->pose_ids[s]].v[k] = bp[(size_t)k * d.pose_ld + s];
+  for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) g->nodes[g->plane_ids[s]].v[k] = bl[(size_t)k * d.plane_ld + s];
+  g->dev_values_newer = false;
+  return PPS_OK;
+}
+
+int upload_state(pps_graph* g, bool sync) {
+  DevGraph& d = g->dev;
+  if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }   // the staging buffer is still being read
+  const size_t np = (size_t)7 * d.pose_ld, nl = (size_t)4 * d.plane_ld;
+  int rc = state_pin_reserve(g, np + nl);
+  if (rc != PPS_OK) return rc;
+  double* bp = g->state_pin; double* bl = g->state_pin + np;
+  for (int k = 0; k < 7; k++) for (int s = d.n_pose; s < d.pose_ld; s++) bp[(size_t)k * d.pose_ld + s] = 0.0;
+  for (int k = 0; k < 4; k++) for (int s = d.n_plane; s < d.plane_ld; s++) bl[(size_t)k * d.plane_ld + s] = 0.0;
+  for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) bp[(size_t)k * d.pose_ld + s] = g->nodes[g->pose_ids[s]].v[k];
+  for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) bl[(size_t)k * d.plane_ld + s] = g->nodes[g->plane_ids[s]].v[k];
+  HIP_TRY(g, hipMemcpyAsync(d.pose_est, bp, (np + nl) * 8, hipMemcpyHostToDevice, g->stream));
+  HIP_TRY(g, hipMemcpyAsync(d.pose_lin, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToDevice, g->stream));
+  g->lin_is_est = true;
+  if (sync) HIP_TRY(g, hipStreamSynchronize(g->stream));
+  else g->up_inflight = true;
+  g->host_values_newer = false;
+  return PPS_OK;
+}
+
+// SoA with leading dimension ld (>= count): value k of slot s at [k * ld + s]
+template <int K>
+void pack_soa(const pps_graph* g, int type, const double HostFactor::*dummy, bool weights, std::vector<double>& out, size_t ld) {
+  (void)dummy;
+  const std::vector<int>& ids = g->fslot_ids[type];
+  const size_t n = ids.size();
+  out.assign((size_t)K * ld, 0.0);
+  for (size_t s = 0; s < n; s++) {
+    const HostFactor& f = g->factors[ids[s]];
+    const double* src = weights ? f.w : f.meas;
+    for (int k = 0; k < K; k++) out[(size_t)k * ld + s] = src[k];
+  }
+}
+
+// pull device-refreshed plane-observation measurements back into the host factor table
+int download_measurements(pps_graph* g) {
+  if (!g->dev_meas_newer) return PPS_OK;
+  HIP_TRY(g, hipSetDevice(g->props.device));
+  const DevGraph& d = g->dev;
+  const size_t n = g->fslot_ids[F_PLANE_OBS].size(), ld = (size_t)d.obs_ld;
+  std::vector<double> m((size_t)4 * ld);
+  if (n) HIP_TRY(g, hipMemcpyAsync(m.data(), d.obs_meas, m.size() * 8, hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  for (size_t s2 = 0; s2 < n && s2 < (size_t)d.n_obs; s2++) {
+    HostFactor& f = g->factors[g->fslot_ids[F_PLANE_OBS][s2]];
+    for (int k = 0; k < 4; k++) f.meas[k] = m[(size_t)k * ld + s2];
+  }
+  g->dev_meas_newer = false;
+  g->pk_meas_ok = false;
+  return PPS_OK;
+}
+
+int upload_measurements(pps_graph* g) {
+  DevGraph& d = g->dev;
+  std::vector<double> m;
+  pack_soa<4>(g, F_PLANE_OBS, nullptr, false, m, (size_t)d.obs_ld);
+  if (d.n_obs) HIP_TRY(g, hipMemcpyAsync(d.obs_meas, m.data(), m.size() * 8, hipMemcpyHostToDevice, g->stream));
+  std::vector<double> m2;
+  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, m2, (size_t)d.lp_ld);
+  if (d.n_lp) HIP_TRY(g, hipMemcpyAsync(d.lp_meas, m2.data(), m2.size() * 8, hipMemcpyHostToDevice, g->stream));
+  // (the upload mirror no longer describes these arrays: the next topology upload sends them whole)
+  g->up_unknown_meas = true;
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  g->meas_dirty = false;
+  return PPS_OK;
+}
+
+int upload_all(pps_graph* g) {
+  const double t0 = now_s();
+  const bool was_grown_only = g->grown_only_upload;
+  const bool tm = getenv("PPS_UPLOAD_TIMING") != nullptr;
+  double tl = t0;
+  auto lap = [&](const char* what) { if (!tm) return; const double t = now_s(); g->up_laps[what] += t - tl; tl = t; };
+  int rc = ensure_device(g);
+  if (rc != PPS_OK) return rc;
+  if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
+  // Refreshed measurements may stay on the device across an upload that only appends (see the obs_meas upload below): same
+  // arena, same slot with room for the new rows, same leading dimension, no re-popping edges (their slots sit behind the
+  // fixed ones and would move).
+  bool keep_meas = false;
+  const size_t n_obs_on_device = (size_t)g->dev.n_obs;         // (free_device below resets g->dev)
+  if (g->dev_meas_newer) {
+    size_t n_obs_new = 0, n_lp_new = 0; bool any_repop = false;
+    for (const HostFactor& f : g->factors) if (!f.deleted) { n_obs_new += f.type == F_PLANE_OBS; n_lp_new += f.type == F_PLANE_PRIOR; any_repop = any_repop || (f.type == F_PLANE_OBS && f.repop); }
+    keep_meas = g->grown_only_upload && !g->up_unknown && !g->up_unknown_meas && g->up.spill == 0 && !any_repop && g->dev.n_obs == g->dev.n_obs_fixed &&
+                j_capacity((int64_t)n_obs_new) == g->dev.obs_ld && j_capacity((int64_t)n_lp_new) == g->dev.lp_ld && g->slot_obs_meas < g->up_slots.size() &&
+                true;
+    if (!keep_meas) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
+  }
+  HIP_TRY(g, hipStreamSynchronize(g->stream));
+  g->up_inflight = false;
+  lap("1 state/meas download + syncs");
+  free_device(g);
+  g->spec_L = g->spec_U = g->spec_delta = nullptr; g->spec_result = nullptr;
+  g->spec_pose = g->spec_plane = g->spec_chi2_partials = g->spec_dn_partials = nullptr; g->spec_ticket = nullptr;
+  g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
+  g->frames_dirty = true;
+  g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
+  lap("2 free_device");
+  if (!g->analyzed || g->analysis_stale) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
+  lap("3 analysis");
+  const Analysis& A = g->an;
+  DevGraph& d = g->dev;
+  d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
+  d.no_strip = getenv("PPS_NO_STRIP") ? 1 : 0;
+  d.pose_ld = std::max(1, (d.n_pose + 63) / 64 * 64); d.plane_ld = std::max(1, (d.n_plane + 63) / 64 * 64);
+#define TRY(x) do { rc = (x); if (rc != PPS_OK) return rc; } while (0)
+  // every copy of the state is one block [poses | planes]: one transfer moves it (copies rotate by pointer pairs, so a
+  // plane array always sits behind its pose array)
+  const size_t state_doubles = (size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld;
+  TRY(dev_alloc(g, &d.pose_est, state_doubles)); d.plane_est = d.pose_est + (size_t)7 * d.pose_ld;
+  TRY(dev_alloc(g, &d.pose_lin, state_doubles)); d.plane_lin = d.pose_lin + (size_t)7 * d.pose_ld;
+  std::vector<int> pv(d.n_pose), lv(d.n_plane);
+  for (int s = 0; s < d.n_pose; s++) pv[s] = A.node_voff[g->nodes[g->pose_ids[s]].compact];
+  for (int s = 0; s < d.n_plane; s++) lv[s] = A.node_voff[g->nodes[g->plane_ids[s]].compact];
+  TRY(dev_upload(g, &d.pose_voff, pv)); TRY(dev_upload(g, &d.plane_voff, lv));
+  // factors
+  d.n_obs = (int)g->fslot_ids[F_PLANE_OBS].size(); d.n_odo = (int)g->fslot_ids[F_ODOMETRY].size();
+  d.n_pp = (int)g->fslot_ids[F_POSE_PRIOR].size(); d.n_lp = (int)g->fslot_ids[F_PLANE_PRIOR].size();
+  { int64_t base[4]; j_bases(g, base, nullptr); d.joff_obs = base[F_PLANE_OBS]; d.joff_odo = base[F_ODOMETRY]; d.joff_pp = base[F_POSE_PRIOR]; d.joff_lp = base[F_PLANE_PRIOR]; }
+  auto idx_of = [&](int type, bool second) {
+    std::vector<int> v(g->fslot_ids[type].size());
+    for (size_t s = 0; s < v.size(); s++) {
+      const HostFactor& f = g->factors[g->fslot_ids[type][s]];
+      v[s] = g->nodes[second ? f.b : f.a].slot;
+    }
+    return v;
+  };
+  std::vector<double> tmp;
+  // the previous upload's packed arrays are still right for the old factors when nothing was removed since (slots only append)
+  const bool incr_pack = was_grown_only;
+  d.obs_ld = (int)j_capacity(d.n_obs); d.odo_ld = (int)j_capacity(d.n_odo); d.pp_ld = (int)j_capacity(d.n_pp); d.lp_ld = (int)j_capacity(d.n_lp);
+  {
+    // one pass over the plane observations (a HostFactor is 300 bytes: four passes were four times the memory traffic), and
+    // only over the new ones when the graph has just grown
+    const std::vector<int>& ids = g->fslot_ids[F_PLANE_OBS];
+    const size_t n = ids.size(), ld = (size_t)d.obs_ld;
+    std::vector<int>& ia = g->pk_obs_a; std::vector<int>& ib = g->pk_obs_b;
+    std::vector<double>& pm = g->pk_obs_m; std::vector<double>& pw = g->pk_obs_w;
+    size_t s_begin = 0;
+    if (incr_pack && g->pk_ld_obs == ld && g->pk_n_obs <= n && pm.size() == 4 * ld && g->pk_obs_ids.size() == g->pk_n_obs &&
+        std::equal(g->pk_obs_ids.begin(), g->pk_obs_ids.end(), ids.begin())) s_begin = g->pk_n_obs;   // (re-popping edges sit behind the fixed ones: their slots move)
+    ia.resize(n); ib.resize(n); pm.resize(4 * ld); pw.resize(6 * ld);
+    for (size_t s2 = s_begin; s2 < n; s2++) {
+      const HostFactor& f = g->factors[ids[s2]];
+      ia[s2] = g->nodes[f.a].slot; ib[s2] = g->nodes[f.b].slot;
+      for (int k = 0; k < 4; k++) pm[(size_t)k * ld + s2] = f.meas[k];
+      for (int k = 0; k < 6; k++) pw[(size_t)k * ld + s2] = f.w[k];
+    }
+    if (s_begin > 0 && !g->pk_meas_ok)                                 // the host's measurements changed: those rows again
+      for (size_t s2 = 0; s2 < s_begin; s2++) { const HostFactor& f = g->factors[ids[s2]]; for (int k = 0; k < 4; k++) pm[(size_t)k * ld + s2] = f.meas[k]; }
+    g->pk_n_obs = n; g->pk_ld_obs = ld; g->pk_obs_ids.resize(s_begin); g->pk_obs_ids.insert(g->pk_obs_ids.end(), ids.begin() + (std::ptrdiff_t)s_begin, ids.end());
+    TRY(dev_upload(g, &d.obs_pose, ia)); TRY(dev_upload(g, &d.obs_plane, ib));
+    // Measurements that a device-side refresh has rewritten (pps_refresh_measurements) stay where they are when this upload
+    // only appends: the host packs its (older) copies, the mirror holds the same bytes, so nothing is sent for them and the
+    // device keeps the refreshed values; only the new observations travel.  dev_meas_newer stays set.
+    g->slot_obs_meas = g->up_cursor;
+    TRY(dev_upload_rows(g, &d.obs_meas, pm, 4, ld, n, g->up_unknown_meas, keep_meas ? std::min(n, n_obs_on_device) : kNoExact));
+    TRY(dev_upload_rows(g, &d.obs_w, pw, 6, ld, n, false));
+  }
+  d.n_obs_fixed = g->n_obs_fixed;
+  {
+    const std::vector<int>& ids = g->fslot_ids[F_PLANE_OBS];
+    const size_t n2 = ids.size() - (size_t)g->n_obs_fixed;
+    if (n2 > 0) {
+      tmp.assign(6 * n2, 0.0);
+      for (size_t k = 0; k < n2; k++)
+        for (int c = 0; c < 6; c++) tmp[(size_t)c * n2 + k] = g->factors[ids[g->n_obs_fixed + k]].ray[c];
+      TRY(dev_upload(g, &d.obs_ray, tmp));
+    }
+  }
+  {
+    const std::vector<int>& ids = g->fslot_ids[F_ODOMETRY];
+    const size_t n = ids.size(), ld = (size_t)d.odo_ld;
+    std::vector<int>& ia = g->pk_odo_a; std::vector<int>& ib = g->pk_odo_b;
+    std::vector<double>& pm = g->pk_odo_m; std::vector<double>& pw = g->pk_odo_w;
+    size_t s_begin = 0;
+    if (incr_pack && g->pk_ld_odo == ld && g->pk_n_odo <= n && pm.size() == 6 * ld && g->pk_odo_ids.size() == g->pk_n_odo &&
+        std::equal(g->pk_odo_ids.begin(), g->pk_odo_ids.end(), ids.begin())) s_begin = g->pk_n_odo;
+    ia.resize(n); ib.resize(n); pm.resize(6 * ld); pw.resize(21 * ld);
+    for (size_t s2 = s_begin; s2 < n; s2++) {
+      const HostFactor& f = g->factors[ids[s2]];
+      ia[s2] = g->nodes[f.a].slot; ib[s2] = g->nodes[f.b].slot;
+      for (int k = 0; k < 6; k++) pm[(size_t)k * ld + s2] = f.meas[k];
+      for (int k = 0; k < 21; k++) pw[(size_t)k * ld + s2] = f.w[k];
+    }
+    g->pk_n_odo = n; g->pk_ld_odo = ld; g->pk_odo_ids.resize(s_begin); g->pk_odo_ids.insert(g->pk_odo_ids.end(), ids.begin() + (std::ptrdiff_t)s_begin, ids.end());
+    TRY(dev_upload(g, &d.odo_a, ia)); TRY(dev_upload(g, &d.odo_b, ib));
+    TRY(dev_upload_rows(g, &d.odo_meas, pm, 6, ld, n, false));
+    TRY(dev_upload_rows(g, &d.odo_w, pw, 21, ld, n, false));
+  }
+  TRY(dev_upload(g, &d.pp_pose, idx_of(F_POSE_PRIOR, false)));
+  pack_soa<6>(g, F_POSE_PRIOR, nullptr, false, tmp, (size_t)d.pp_ld); TRY(dev_upload_rows(g, &d.pp_meas, tmp, 6, (size_t)d.pp_ld, (size_t)d.n_pp, false));
+  pack_soa<21>(g, F_POSE_PRIOR, nullptr, true, tmp, (size_t)d.pp_ld); TRY(dev_upload_rows(g, &d.pp_w, tmp, 21, (size_t)d.pp_ld, (size_t)d.n_pp, false));
+  TRY(dev_upload(g, &d.lp_plane, idx_of(F_PLANE_PRIOR, false)));
+  pack_soa<4>(g, F_PLANE_PRIOR, nullptr, false, tmp, (size_t)d.lp_ld); g->slot_lp_meas = g->up_cursor; TRY(dev_upload_rows(g, &d.lp_meas, tmp, 4, (size_t)d.lp_ld, (size_t)d.n_lp, g->up_unknown_meas));
+  pack_soa<6>(g, F_PLANE_PRIOR, nullptr, true, tmp, (size_t)d.lp_ld); TRY(dev_upload_rows(g, &d.lp_w, tmp, 6, (size_t)d.lp_ld, (size_t)d.n_lp, false));
+  g->up_unknown_meas = false;
+  g->pk_meas_ok = true;
+  lap("4 factor packing + diff");
+  // linear system storage
+  TRY(dev_alloc(g, &d.J, (size_t)A.J_size)); TRY(dev_alloc(g, &d.H, (size_t)A.H_size));
+  TRY(dev_alloc(g, &d.L, (size_t)A.L_size)); TRY(dev_alloc(g, &d.U, (size_t)A.U_size));
+  TRY(dev_alloc(g, &g->spec_L, (size_t)A.L_size)); TRY(dev_alloc(g, &g->spec_U, (size_t)A.U_size));
+  const size_t delta_doubles = (size_t)std::max(1, A.n_scalars);   // (delta and the second delta sit in the zeroed block below)
+  d.n_scalars = A.n_scalars;
+  d.n_fronts = A.n_fronts; d.n_levels = A.n_levels; d.max_front = A.max_front; d.n_segs = A.n_segs; d.n_blocks = A.n_blocks;
+  TRY(dev_upload(g, &d.f_p, A.f_p)); TRY(dev_upload(g, &d.f_b, A.f_b)); TRY(dev_upload(g, &d.f_poff, A.f_poff)); TRY(dev_upload(g, &d.pidx, A.pidx));
+  TRY(dev_upload(g, &d.f_Loff, A.f_Loff)); TRY(dev_upload(g, &d.f_Uoff, A.f_Uoff));
+  TRY(dev_upload(g, &d.f_bidx_off, A.f_bidx_off)); TRY(dev_upload(g, &d.bidx, A.bidx));
+  TRY(dev_upload(g, &d.f_child_off, A.f_child_off)); TRY(dev_upload(g, &d.child, A.child));
+  TRY(dev_upload(g, &d.f_cmap_off, A.f_cmap_off)); TRY(dev_upload(g, &d.cmap, A.cmap));
+  TRY(dev_upload(g, &d.level_fronts, A.level_fronts));
+  TRY(dev_upload(g, &d.f_asm_off, A.f_asm_off)); TRY(dev_upload(g, &d.asm_blk, A.asm_blk));
+  TRY(dev_upload(g, &d.asm_lrow, A.asm_lrow)); TRY(dev_upload(g, &d.asm_lcol, A.asm_lcol));
+  TRY(dev_upload(g, &d.blk_rows, A.blk_rows)); TRY(dev_upload(g, &d.blk_cols, A.blk_cols));
+  TRY(dev_upload(g, &d.blk_size, A.blk_size)); TRY(dev_upload(g, &d.blk_nseg, A.blk_nseg));
+  TRY(dev_upload(g, &d.blk_hoff, A.blk_hoff));
+  TRY(dev_upload(g, &d.seg_blk, A.seg_blk)); TRY(dev_upload(g, &d.seg_c0, A.seg_c0)); TRY(dev_upload(g, &d.seg_cnt, A.seg_cnt));
+  TRY(dev_upload(g, &d.seg_hoff, A.seg_hoff));
+  TRY(dev_upload(g, &d.contrib, A.contrib));
+  {
+    std::vector<int> mseg;
+    for (int bk = 0; bk < A.n_blocks; bk++) if (A.blk_nseg[bk] > 1) mseg.push_back(bk);
+    d.n_mseg = (int)mseg.size();
+    TRY(dev_upload(g, &d.mseg_blk, mseg));
+  }
+  TRY(dev_upload(g, &d.f_el_off, A.f_el_off)); TRY(dev_alloc(g, &d.el_tgt, (size_t)std::max<int64_t>(1, A.el_total)));   // filled by k_expand_el below
+  TRY(dev_upload(g, &d.asm_el0, A.asm_el0)); TRY(dev_upload(g, &d.asm_fsz, A.asm_fsz));
+  TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
+  TRY(dev_upload(g, &d.blk_doff, A.blk_doff)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
+  TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
+  TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
+  TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
+  TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec));
+  TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
+  TRY(dev_upload(g, &d.cls_off, A.cls_off)); TRY(dev_upload(g, &d.cls_fronts, A.cls_fronts));
+  if (g->use_dense) { TRY(dev_upload(g, &g->d_dw_asm, g->dw_asm)); TRY(dev_upload(g, &g->d_dw_pan, g->dw_pan)); TRY(dev_upload(g, &g->d_dw_trl, g->dw_trl)); }
+  d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
+  TRY(dev_alloc(g, &d.chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
+
+  {
+    // one zeroed block: [dn_partials | ticket | spec ticket | result record | the second factorisation's result record |
+    // delta | the second delta]
+    const size_t n_dn = (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1;
+    double* zb = nullptr;
+    TRY(dev_alloc(g, &zb, n_dn + 2 + 8 + 2 * delta_doubles));
+    HIP_TRY(g, hipMemsetAsync(zb, 0, (n_dn + 2 + 8 + 2 * delta_doubles) * 8, g->stream));
+    d.delta = zb + n_dn + 10; g->spec_delta = d.delta + delta_doubles;
+    d.dn_partials = zb;
+    d.ticket = reinterpret_cast<unsigned int*>(zb + n_dn);
+    g->spec_ticket = reinterpret_cast<unsigned int*>(zb + n_dn + 1);
+    d.result_dev = zb + n_dn + 2; g->spec_result = zb + n_dn + 6;
+    g->status_clean = true;
+  }
+  TRY(dev_alloc(g, &g->spec_pose, state_doubles + 1)); g->spec_plane = g->spec_pose + (size_t)7 * d.pose_ld;
+  TRY(dev_alloc(g, &g->spec_chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
+  TRY(dev_alloc(g, &g->spec_dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
+  if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
+  // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
+  if (!g->use_band && !g->use_dense && A.max_front > lds_front_limit()) {
+    const int fa = A.max_front + 1;
+    d.gwork_stride = (int64_t)fa * (fa | 1);
+    int widest = 0;
+    for (int l = 0; l < A.n_levels; l++)
+      if (g->level_max_front[l] > lds_front_limit()) widest = std::max(widest, A.level_off[l + 1] - A.level_off[l]);
+    TRY(dev_alloc(g, &d.gwork, (size_t)d.gwork_stride * std::max(1, widest)));
+  }
+#undef TRY
+  lap("5 index arrays + diff");
+  rc = flush_uploads(g); if (rc != PPS_OK) return rc;
+  rc = verify_uploads(g, "upload_all"); if (rc != PPS_OK) return rc;
+  lap("6 flush");
+  if (A.ea_total > 0) HIP_TRY(g, launch_expand_ea(d, A.n_fronts, g->stream));
+  HIP_TRY(g, hipMemsetAsync(d.blk_dst, 0xff, sizeof(int) * (size_t)std::max(1, A.blk_doff[A.n_blocks]), g->stream));
+  HIP_TRY(g, launch_expand_el(d, (int)A.asm_blk.size(), g->stream));
+  g->topo_dirty = false;
+  g->meas_dirty = false;
+  g->grown_only_upload = true;
+  lap("7 expand kernels + sync");
+  // no sync: the solve that follows runs on the same stream (and ends with one); whatever writes the pinned buffers
+  // again checks up_inflight or follows upload_all's opening sync
+  rc = upload_state(g, false);
+  lap("8 upload_state");
+  g->stats.t_upload = now_s() - t0 - g->stats.t_analysis;
+  return rc;
+}
+
+int prepare_solve(pps_graph* g) {
+  int rc;
+  if (g->n_live_nodes == 0) return fail(g, PPS_ESTATE, "empty graph");
+  if (g->dev_ready) HIP_TRY(g, hipSetDevice(g->props.device));   // handles may be driven from any host thread
+  if (g->topo_dirty || !g->dev_ready || g->dev.n_scalars == 0) { rc = upload_all(g); if (rc != PPS_OK) return rc; }
+  if (g->host_values_newer) { rc = upload_state(g); if (rc != PPS_OK) return rc; }
+  if (g->meas_dirty) { rc = upload_measurements(g); if (rc != PPS_OK) return rc; }
+  return PPS_OK;
+}
+
+}  // namespace pps_impl
