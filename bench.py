@@ -346,11 +346,14 @@ def main():
         pmc_js, pmc_src = load_pmc()
         pmc = pmc_js.get("kernels", {})
         roofline_batched = {}
-        for mname, mcode in (("analytic", P.JAC_ANALYTIC), ("numeric", P.JAC_NUMERIC)):
+        # numeric_lanes: the lane-parallel central differences (3 plane observations per wavefront) -- the form a graph below
+        # 200 000 factors runs; numeric: one thread per factor (large batches); analytic: closed-form Jacobians
+        for mname, mcode in (("analytic", P.JAC_ANALYTIC), ("numeric_lanes", 2), ("numeric", P.JAC_NUMERIC)):
             (sec_all, sec_pl, sec_od), npl, nod = g.bench_sweep(mcode, reps, 10)
             ent = {}
-            for part, sec_k, nbytes, kname in (("plane_edges", sec_pl, npl * B_PLANE_EDGE, "k_sweep_bench<%d,0>" % mcode),
-                                               ("odometry", sec_od, nod * B_ODO_EDGE, "k_sweep_bench<%d,1>" % mcode)):
+            kfmt = "k_sweep_bench_lanes<%d>" if mcode == 2 else "k_sweep_bench<" + str(mcode) + ",%d>"
+            for part, sec_k, nbytes, kname in (("plane_edges", sec_pl, npl * B_PLANE_EDGE, kfmt % 0),
+                                               ("odometry", sec_od, nod * B_ODO_EDGE, kfmt % 1)):
                 rec = pmc.get(f"{mname}_{part}")
                 traffic = None
                 if rec and reps == pmc_js.get("replicas") and "hbm_bytes_corrected" in rec:   # same replica count as the PMC passes

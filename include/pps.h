@@ -201,7 +201,9 @@ int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed);
 /* Replicates the handle's plane-observation and odometry edges `replicas` times in device
  * memory (state shared), runs `iters` sweeps and returns mean kernel times (HIP events, seconds):
  * sec[0] = both launches, sec[1] = plane-edge launch alone, sec[2] = odometry launch alone; plus the
- * number of plane / odometry edges per sweep.  Used for the HBM roofline figure. */
+ * number of plane / odometry edges per sweep.  Used for the HBM roofline figure.  mode: PPS_JAC_NUMERIC / PPS_JAC_ANALYTIC = the
+ * thread-per-factor kernels, 2 = the lane-parallel numeric form (19 lanes per plane observation; what a graph below 200 000
+ * factors runs). */
 /* K1 of the handle's own graph, `iters` back-to-back launches on the solver's stream between two HIP events */
 int pps_time_linearize(pps_graph* g, int mode, int iters, double* sec_per_launch);
 int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double sec_per_sweep[3],

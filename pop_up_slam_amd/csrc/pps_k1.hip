@@ -47,7 +47,7 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
   // PPS_K1_THREAD_FORM=1 forces the thread-per-factor kernels on small graphs (parity tests of that form)
   if (mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !getenv("PPS_K1_THREAD_FORM")) {
-    const int lb_obs = cdiv(d.n_obs_fixed, kFactorsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
+    const int lb_obs = cdiv(d.n_obs_fixed, kObsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
               lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
     PPS_LAUNCH(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
                        lb_obs, lb_odo, lb_pp, gd);
@@ -115,7 +115,31 @@ __global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* _
   }
 }
 
+// the lane-parallel numeric form over the replicated edges (mode 2 of the sweep benchmark): PART 0 plane observations (19 lanes
+// each), PART 1 odometry edges (32 lanes each)
+template <int PART>
+__global__ __launch_bounds__(kLanesPerBlock) void k_sweep_bench_lanes(DevGraph d, double* __restrict__ Jbig, int lb_obs_per, int lb_odo_per) {
+  const int per = PART == 0 ? lb_obs_per : lb_odo_per;
+  const int rep = blockIdx.x / per;
+  const int b = blockIdx.x % per + (PART == 0 ? 0 : lb_obs_per);
+  const size_t slab = (size_t)d.n_obs * 30 + (size_t)d.n_odo * 78;
+  DevGraph r = d;                       // replica `rep` reads shifted copies of the edge arrays and writes its own J slab
+  r.J = Jbig + (size_t)rep * slab; r.joff_obs = 0; r.joff_odo = (int64_t)d.n_obs * 30;
+  r.obs_meas = d.obs_meas + (size_t)rep * 4 * d.obs_ld; r.obs_w = d.obs_w + (size_t)rep * 6 * d.obs_ld;
+  r.obs_pose = d.obs_pose + (size_t)rep * d.n_obs; r.obs_plane = d.obs_plane + (size_t)rep * d.n_obs;
+  r.odo_meas = d.odo_meas + (size_t)rep * 6 * d.odo_ld; r.odo_w = d.odo_w + (size_t)rep * 21 * d.odo_ld;
+  r.odo_a = d.odo_a + (size_t)rep * d.n_odo; r.odo_b = d.odo_b + (size_t)rep * d.n_odo;
+  r.n_obs_fixed = d.n_obs;
+  body_linearize_lanes(r, d.pose_lin, d.plane_lin, lb_obs_per, lb_odo_per, 0, b);
+}
+
 hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, int part, hipStream_t st) {
+  if (mode == 2) {
+    const int lb_obs = cdiv(d.n_obs, kObsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock);
+    if (lb_obs && part != 1) PPS_LAUNCH(k_sweep_bench_lanes<0>, dim3(lb_obs * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo);
+    if (lb_odo && part != 0) PPS_LAUNCH(k_sweep_bench_lanes<1>, dim3(lb_odo * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo);
+    return hipGetLastError();
+  }
   const int nb_obs = cdiv(d.n_obs, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock);
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   if (nb_obs + nb_odo == 0) return hipSuccess;
@@ -132,7 +156,7 @@ hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double*
 // ---- batched forms ----
 __global__ __launch_bounds__(kLanesPerBlock) void kb_linearize_lanes(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
-  const int nb_obs = dcdiv(d.n_obs_fixed, kFactorsPerBlock), nb_odo = dcdiv(d.n_odo, kFactorsPerBlock),
+  const int nb_obs = dcdiv(d.n_obs_fixed, kObsPerBlock), nb_odo = dcdiv(d.n_odo, kFactorsPerBlock),
             nb_pp = dcdiv(d.n_pp, kFactorsPerBlock), nb_lp = dcdiv(d.n_lp, kFactorsPerBlock);
   if ((int)blockIdx.x >= nb_obs + nb_odo + nb_pp + nb_lp) return;
   body_linearize_lanes(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x);

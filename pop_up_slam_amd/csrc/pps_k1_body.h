@@ -276,11 +276,13 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
 }
 
 // ------------------------------------------------------------------------------------------
-// K1, lane-parallel central differences (the reference's numericalDiff, one evaluation per lane):
-// 32 lanes per factor = 2 factors per wavefront.  Lane 2q evaluates the residual at x (+) eps e_q,
-// lane 2q+1 at x (-) eps e_q, lane 2*ncols the nominal residual; a lane pair differences through
-// one DPP-style shuffle and lane 2q stores column q.  All lanes of a group read the same edge record
-// (a broadcast load), state is gathered by index from the SoA arrays.
+// K1, lane-parallel central differences (the reference's numericalDiff, one evaluation per lane).
+// Plane observations -- 5 of every 6 factors -- take 19 lanes each (the nominal residual + 2 x 9 perturbed ones): 3 edges per
+// wavefront, 57 of 64 lanes at work (two edges on 32 lanes each left 38).  Lane 0 of a group evaluates the nominal residual,
+// lanes 2q+1 / 2q+2 the residual at x (+) / (-) eps e_q; the pair differences through one shuffle and the odd lane stores
+// column q.  The other factor types keep 32 lanes per factor: lane 2q at x (+) eps e_q, lane 2q+1 at x (-) eps e_q, lane
+// 2*ncols the nominal residual.  All lanes of a group read the same edge record (a broadcast load), state is gathered by index
+// from the SoA arrays.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void perturb6(const double p[7], int q, double sgn, double o[7]) {
   double dl[6];
@@ -298,6 +300,9 @@ __device__ __forceinline__ void perturb3(const double p[4], int q, double sgn, d
 constexpr int kLaneGroup = 32;
 constexpr int kLanesPerBlock = 256;
 constexpr int kFactorsPerBlock = kLanesPerBlock / kLaneGroup;
+constexpr int kObsLanes = 19;                                         // evaluations of one plane observation
+constexpr int kObsPerWave = 64 / kObsLanes;                           // 3
+constexpr int kObsPerBlock = (kLanesPerBlock / 64) * kObsPerWave;     // 12
 
 __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const double* __restrict__ pose,
                                                      const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx) {
@@ -307,8 +312,11 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
   const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
   int b = bx;
   if (b < nb_obs) {
-    const int i = b * kFactorsPerBlock + grp;
-    if (i >= d.n_obs_fixed) return;
+    const int lane = threadIdx.x & 63, g3 = lane / kObsLanes, l3 = lane - g3 * kObsLanes;
+    const int i = b * kObsPerBlock + (threadIdx.x >> 6) * kObsPerWave + g3;
+    if (g3 >= kObsPerWave || i >= d.n_obs_fixed) return;
+    const int q3 = l3 > 0 ? (l3 - 1) >> 1 : 9;                    // perturbed column (9: none, the nominal residual)
+    const double s3 = (l3 & 1) ? 1.0 : -1.0;                      // odd lane: + eps, the even lane after it: - eps
     double pz[7], pl[4], ms[4], w[6], e[3], y[3];
     load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
     load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
@@ -318,9 +326,9 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
       // every lane takes the same path: a perturbation that does not apply is the zero step, which is the
       // exact identity for a pose; the plane keeps its stored value unless it is the perturbed node
       double pp[7], lp[4];
-      perturb6(pz, q, sgn, pp);                       // q >= 6: zero delta -> pp == pz bit for bit
-      perturb3(pl, q - 6, sgn, lp);
-      const bool pert_plane = q >= 6 && q < 9;
+      perturb6(pz, q3, s3, pp);                       // q3 >= 6: zero delta -> pp == pz bit for bit
+      perturb3(pl, q3 - 6, s3, lp);
+      const bool pert_plane = q3 >= 6 && q3 < 9;
 #pragma unroll
       for (int k = 0; k < 4; k++) lp[k] = pert_plane ? lp[k] : pl[k];
       res_plane_obs(pp, lp, ms, e);
@@ -329,13 +337,12 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const double other = __shfl_xor(y[r], 1, 64);
-      if (!(gl & 1)) {
+      const double other = __shfl_down(y[r], 1, 64);             // the (-) evaluation of the same column sits in the next lane
+      if (l3 & 1) {
         const double dcol = (y[r] - other) * inv2e;
-        if (q < 6) out[r * 6 + q] = dcol;
-        else if (q < 9) out[18 + r * 3 + (q - 6)] = dcol;
-        else if (gl == 18) out[27 + r] = y[r];
-      }
+        if (q3 < 6) out[r * 6 + q3] = dcol;
+        else out[18 + r * 3 + (q3 - 6)] = dcol;
+      } else if (l3 == 0) out[27 + r] = y[r];
     }
     return;
   }

@@ -141,7 +141,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       const pps_graph* g = m->gs[i];
       const DevGraph& d = g->dev;
       const Analysis& A = g->an;
-      q.lin_blocks = std::max(q.lin_blocks, (d.n_obs_fixed + 7) / 8 + (d.n_odo + 7) / 8 + (d.n_pp + 7) / 8 + (d.n_lp + 7) / 8);
+      q.lin_blocks = std::max(q.lin_blocks, (d.n_obs_fixed + 11) / 12 + (d.n_odo + 7) / 8 + (d.n_pp + 7) / 8 + (d.n_lp + 7) / 8);   // (lane form: 12 plane observations / 8 other factors per block)
       q.lin_obs_blocks = std::max(q.lin_obs_blocks, (d.n_obs_fixed + 127) / 128);
       q.lin_rest_blocks = std::max(q.lin_rest_blocks, (d.n_odo + 127) / 128 + (d.n_pp + 127) / 128 + (d.n_lp + 127) / 128);
       q.repop_blocks = std::max(q.repop_blocks, (d.n_obs - d.n_obs_fixed + 63) / 64);

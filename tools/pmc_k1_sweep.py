@@ -58,13 +58,19 @@ def main():
     except Exception:
         out["git_head"] = None                # (no .git on the GPU box: the source hash is what binds the file to a build)
     acc = {}
-    for mode, mname in ((1, "analytic"), (0, "numeric")):
+    for mode, mname in ((1, "analytic"), (0, "numeric"), (2, "numeric_lanes")):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             for name, c, v, n, dur in run_pass(outdir, counter, f"sweep_{mname}", [sys.executable, "tools/sweep_only.py", str(mode), str(REPLICAS)]):
-                m = re.search(r"k_sweep_bench<(\d), (\d)>", name)
-                if not m or int(m.group(1)) != mode:
-                    continue
-                part = "plane_edges" if m.group(2) == "0" else "odometry"
+                if mode == 2:
+                    m = re.search(r"k_sweep_bench_lanes<(\d)>", name)
+                    if not m:
+                        continue
+                    part = "plane_edges" if m.group(1) == "0" else "odometry"
+                else:
+                    m = re.search(r"k_sweep_bench<(\d), (\d)>", name)
+                    if not m or int(m.group(1)) != mode:
+                        continue
+                    part = "plane_edges" if m.group(2) == "0" else "odometry"
                 key = f"{mname}_{part}"
                 acc.setdefault(key, {"kernel": name.split("(")[0]})
                 acc[key]["fetch_kib_raw" if c == "FETCH_SIZE" else "write_kib"] = v
