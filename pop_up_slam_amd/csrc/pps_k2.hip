@@ -89,20 +89,34 @@ constexpr int kH2Slots = 8;          // contributions staged per chunk
 constexpr int kH2Stride = 80;        // doubles per slot: [row block <= 36 | column block <= 36 | residual <= 6 | pad]
 constexpr int kH2WaveDoubles = kH2Slots * kH2Stride;
 
-__device__ __forceinline__ void wave_hblock_segment(const DevGraph& d, int seg, double* __restrict__ S) {
-  const int lane = threadIdx.x & 63;
-  // one coalesced load of the packed segment record, fields broadcast with v_readlane
-  const int rec = d.srec[(size_t)seg * 8 + (lane & 7)];
-  const int rows = __builtin_amdgcn_readlane(rec, 0), cols = __builtin_amdgcn_readlane(rec, 1), size = __builtin_amdgcn_readlane(rec, 2);
-  const int c0 = __builtin_amdgcn_readlane(rec, 3), cnt = __builtin_amdgcn_readlane(rec, 4);
-  const int hoff = __builtin_amdgcn_readlane(rec, 5), doff = __builtin_amdgcn_readlane(rec, 6), nsegb = __builtin_amdgcn_readlane(rec, 7);
+// what a wave knows about a segment before it touches the Jacobians: the packed record, then its contribution descriptors and
+// the front-order destination of its entries -- two dependent loads, requested for ALL segments of the wave before the first
+// segment is worked on
+struct SegHdr { int rec; int4 mine; int dst; };
+__device__ __forceinline__ void seg_fetch_record(const DevGraph& d, int seg, int lane, SegHdr& h) {
+  h.rec = seg >= 0 ? d.srec[(size_t)seg * 8 + (lane & 7)] : 0;      // (size 0, cnt 0 for a slot past the end of the list)
+}
+__device__ __forceinline__ void seg_fetch_contrib(const DevGraph& d, int lane, SegHdr& h) {
+  const int size = __builtin_amdgcn_readlane(h.rec, 2), c0 = __builtin_amdgcn_readlane(h.rec, 3), cnt = __builtin_amdgcn_readlane(h.rec, 4);
+  const int doff = __builtin_amdgcn_readlane(h.rec, 6), nsegb = __builtin_amdgcn_readlane(h.rec, 7);
   // one contribution descriptor per lane, fetched in a single coalesced load (cnt <= 64)
-  int4 mine = make_int4(0, 0, 0, 0);
-  if (lane < cnt) mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
+  h.mine = make_int4(0, 0, 0, 0);
+  if (lane < cnt) h.mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
+  // where the finished entry goes in front-gather order: does not depend on the values, so the load is issued now
+  h.dst = (lane < size && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
+}
+
+__device__ __forceinline__ void wave_hblock_segment(const DevGraph& d, const SegHdr& h, double* __restrict__ S) {
+  const int lane = threadIdx.x & 63;
+  const int rec = h.rec;
+  const int4 mine = h.mine;
+  const int dst = h.dst;
+  const int rows = __builtin_amdgcn_readlane(rec, 0), cols = __builtin_amdgcn_readlane(rec, 1), size = __builtin_amdgcn_readlane(rec, 2);
+  const int cnt = __builtin_amdgcn_readlane(rec, 4);
+  const int hoff = __builtin_amdgcn_readlane(rec, 5);
+  if (size == 0) return;
   const int rc = rows * cols;
   const bool act = lane < size;
-  // where the finished entry goes in front-gather order: does not depend on the values, so the load is issued now
-  const int dst = (act && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
   const bool is_g = lane >= rc;
   const int cdiv_ = cols > 0 ? cols : 1;
   const int i = is_g ? lane - rc : lane / cdiv_;
@@ -115,6 +129,14 @@ __device__ __forceinline__ void wave_hblock_segment(const DevGraph& d, int seg, 
     // before requesting the next one's).  Lanes past a slice repeat its last element and slots past the chunk repeat its last
     // contribution -- the same value to the same LDS word, or to a slot nobody reads -- so nothing is predicated (skipping the
     // unused slots by wave-uniform branches measured slower: 18.1 against 14.9 ms of K2 per G = 128 batch solve).
+    if (nc == 1) {                                             // one contribution (every pose-pose block): one slot, not eight
+      const int jv = __builtin_amdgcn_readlane(mine.x, cb), ju = __builtin_amdgcn_readlane(mine.y, cb);
+      const int ro = __builtin_amdgcn_readlane(mine.z, cb), m = __builtin_amdgcn_readlane(mine.w, cb);
+      const int nv = m * rows - 1, nu = m * cols - 1, nr = m - 1;
+      const int lv1 = lane < nv ? lane : nv, lu1 = lane < nu ? lane : nu, lr1 = lane < nr ? lane : nr;
+      const double xv1 = J[jv + lv1], xu1 = J[ju + lu1], xr1 = J[ro + lr1];
+      S[lv1] = xv1; S[36 + lu1] = xu1; S[72 + lr1] = xr1;
+    } else {
     double xv[kH2Slots], xu[kH2Slots], xr[kH2Slots];
     int lv[kH2Slots], lu[kH2Slots], lr[kH2Slots];
 #pragma unroll
@@ -130,6 +152,7 @@ __device__ __forceinline__ void wave_hblock_segment(const DevGraph& d, int seg, 
     for (int u = 0; u < kH2Slots; u++) {
       double* __restrict__ slot = S + u * kH2Stride;
       slot[lv[u]] = xv[u]; slot[36 + lu[u]] = xu[u]; slot[72 + lr[u]] = xr[u];
+    }
     }
     __builtin_amdgcn_wave_barrier();
     for (int u = 0; u < nc; u++) {
@@ -153,17 +176,24 @@ __device__ __forceinline__ void wave_hblock_segment(const DevGraph& d, int seg, 
   if (dst >= 0) d.Hf[dst] = acc;                          // final value (single-segment block): also where its front gathers it
 }
 
-// Throughput form (many graphs per launch): a wave takes S consecutive segments of the list of non-direct segments (the
-// single-observation pose-plane blocks are written by K1 itself in that mode).
+// A wave takes S consecutive segments of the list of non-direct segments (the single-observation pose-plane blocks are written
+// by K1 itself in this mode).
 template <int S>
 __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
   __shared__ double h2_lds[4 * kH2WaveDoubles];
-  const int wave = uni(threadIdx.x >> 6);
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int slot0 = uni((bx * 4 + wave) * S);        // position in the list of non-direct segments
-  for (int q = 0; q < S; q++) {
-    if (slot0 + q >= d.n_nd_segs) return;
-    wave_hblock_segment(d, uni(d.nd_segs[slot0 + q]), h2_lds + wave * kH2WaveDoubles);
+  if (slot0 >= d.n_nd_segs) return;
+  SegHdr h[S];
+  {
+    const int sidx = (lane >> 3) < S && slot0 + (lane >> 3) < d.n_nd_segs ? d.nd_segs[slot0 + (lane >> 3)] : -1;   // lanes 8q..8q+7: segment q
+#pragma unroll
+    for (int q = 0; q < S; q++) seg_fetch_record(d, __builtin_amdgcn_readlane(sidx, 8 * q), lane, h[q]);
   }
+#pragma unroll
+  for (int q = 0; q < S; q++) seg_fetch_contrib(d, lane, h[q]);
+#pragma unroll
+  for (int q = 0; q < S; q++) wave_hblock_segment(d, h[q], h2_lds + wave * kH2WaveDoubles);
 }
 
 // fold the partial sums of multi-segment blocks (the ground plane's diagonal) into their first slot
