@@ -192,7 +192,6 @@ struct BatchGeom {
   int hblocks = 0, hblocks_nd = 0, hreduce = 0, retract = 0, chi2 = 0;
   long long n_factors_total = 0;
   bool lin_thread_form = false;   // numeric K1 as one thread per factor (many graphs) instead of 32 lanes per factor
-  bool k1_direct = false;         // the thread-per-factor K1 writes the single-contribution (pose, plane) blocks of H; K2 takes the rest (kb_hblocks_t)
   int n_stages = 0;
   int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
   int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const doubl
                                                           int nb_pp, LinGuard gd) {
   extern __shared__ double lin_lds[];
   if (!lin_guard(gd, pose, plane)) return;
-  body_linearize<MODE, PART>(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);
+  body_linearize<MODE, PART, PART == 0>(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);      // (the plane-observation launch writes the direct H blocks)
 }
 
 static thread_local unsigned long long t_launches = 0;
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_sweep_bench_lanes(DevGraph d
   r.odo_meas = d.odo_meas + (size_t)rep * 6 * d.odo_ld; r.odo_w = d.odo_w + (size_t)rep * 21 * d.odo_ld;
   r.odo_a = d.odo_a + (size_t)rep * d.n_odo; r.odo_b = d.odo_b + (size_t)rep * d.n_odo;
   r.n_obs_fixed = d.n_obs;
+  r.obs_dir = nullptr;
   body_linearize_lanes(r, d.pose_lin, d.plane_lin, lb_obs_per, lb_odo_per, 0, b);
 }
 
@@ -186,14 +187,12 @@ hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mo
     if (g.lin_blocks > 0) PPS_LAUNCH(kb_linearize_lanes, dim3(g.lin_blocks, a.n), dim3(kLanesPerBlock), 0, st, a);
   } else if (mode == 2) {          // numeric, one thread per factor
     if (g.lin_obs_blocks > 0) {
-      if (g.k1_direct) PPS_LAUNCH((kb_linearize<0, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
-      else PPS_LAUNCH((kb_linearize<0, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      PPS_LAUNCH((kb_linearize<0, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
     }
     if (g.lin_rest_blocks > 0) PPS_LAUNCH((kb_linearize<0, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   } else {
     if (g.lin_obs_blocks > 0) {
-      if (g.k1_direct) PPS_LAUNCH((kb_linearize<1, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
-      else PPS_LAUNCH((kb_linearize<1, 0, false>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
+      PPS_LAUNCH((kb_linearize<1, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);
     }
     if (g.lin_rest_blocks > 0) PPS_LAUNCH((kb_linearize<1, 1, false>), dim3(g.lin_rest_blocks, a.n), dim3(kLinBlock), lds1, st, a);
   }

@@ -188,7 +188,7 @@ __device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gba
 
 // PART 0: plane-observation edges (16 KB of staging LDS per wave); PART 1: odometry edges and priors
 // (40 KB per wave in analytic mode) -- separate launches so that the big edge class keeps its occupancy.
-// DIRECT (many-graph batches): a plane observation that is the only contribution of its (pose, plane) block writes that H
+// DIRECT (every launch of the solver; off in the sweep benchmark): a plane observation that is the only contribution of its (pose, plane) block writes that H
 // block itself -- the product of its own two Jacobian blocks, summed in the order the H-block kernel uses -- into H and into
 // the front-ordered copy; kb_hblocks_t then skips those segments (60 % of the segments of a C2 graph).
 template <int MODE, int PART, bool DIRECT = false>
@@ -335,14 +335,35 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     }
     whiten<3>(w, e, y);
     double* __restrict__ out = d.J + d.joff_obs + (size_t)i * 30;
+    double jc[3];                                                 // odd lanes: column q3 of [Jp | Jl], rows 0 .. 2
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const double other = __shfl_down(y[r], 1, 64);             // the (-) evaluation of the same column sits in the next lane
+      jc[r] = (y[r] - other) * inv2e;
       if (l3 & 1) {
-        const double dcol = (y[r] - other) * inv2e;
-        if (q3 < 6) out[r * 6 + q3] = dcol;
-        else out[18 + r * 3 + (q3 - 6)] = dcol;
+        if (q3 < 6) out[r * 6 + q3] = jc[r];
+        else out[18 + r * 3 + (q3 - 6)] = jc[r];
       } else if (l3 == 0) out[27 + r] = y[r];
+    }
+    // The (pose, plane) block of H that this observation alone contributes to (Analysis::obs_dir) is the product of its own
+    // two Jacobian blocks: lane e < 18 of the group gathers the two columns it needs from the odd lanes and writes entry e --
+    // summed in the order the H-block kernel uses -- into H and into the front-ordered copy; K2 only visits the other segments.
+    if (d.obs_dir) {                                            // (null in the sweep benchmark: Jacobians only)
+      const int hoff = d.obs_dir[3 * (size_t)i], el0 = d.obs_dir[3 * (size_t)i + 1], rows6 = d.obs_dir[3 * (size_t)i + 2];
+      const int e = l3 < 18 ? l3 : 17;
+      const int ri = rows6 ? e / 3 : e / 6, cj = rows6 ? e - 3 * (e / 3) : e - 6 * (e / 6);
+      const int col_a = rows6 ? ri : 6 + ri, col_b = rows6 ? 6 + cj : cj;       // columns of [Jp | Jl]: the row node's block, the column node's
+      const int src_a = g3 * kObsLanes + 2 * col_a + 1, src_b = g3 * kObsLanes + 2 * col_b + 1;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double av = __shfl(jc[k], src_a, 64), bv = __shfl(jc[k], src_b, 64);
+        acc = PPS_MAC(acc, av, bv);
+      }
+      if (hoff >= 0 && l3 < 18) {
+        d.H[hoff + e] = acc;
+        if (el0 >= 0) d.Hf[el0 + e] = acc;
+      }
     }
     return;
   }

@@ -8,9 +8,10 @@ namespace pps {
 // every lane fetching its own scalars (two contributions' loads in flight).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
-  const int seg = uni(bx * 4 + (threadIdx.x >> 6));
+  const int slot = uni(bx * 4 + (threadIdx.x >> 6));        // position in the list of segments K1 has not written itself
   const int lane = threadIdx.x & 63;
-  if (seg >= d.n_segs) return;
+  if (slot >= d.n_nd_segs) return;
+  const int seg = uni(d.nd_segs[slot]);
   // one coalesced load of the packed segment record, fields broadcast with v_readlane
   const int rec = d.srec[(size_t)seg * 8 + (lane & 7)];
   const int rows = __builtin_amdgcn_readlane(rec, 0), cols = __builtin_amdgcn_readlane(rec, 1), size = __builtin_amdgcn_readlane(rec, 2);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64) void k_hreduce(DevGraph d, LinGuard gd) { if (!
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard) {
   if (d.n_segs == 0) return hipSuccess;
   const LinGuard gd = guard ? *guard : LinGuard{};
-  PPS_LAUNCH(k_hblocks, dim3(cdiv(d.n_segs, 4)), dim3(256), 0, st, d, gd);
+  if (d.n_nd_segs > 0) PPS_LAUNCH(k_hblocks, dim3(cdiv(d.n_nd_segs, 4)), dim3(256), 0, st, d, gd);
   if (d.n_mseg > 0) PPS_LAUNCH(k_hreduce, dim3(d.n_mseg), dim3(64), 0, st, d, gd);
   return hipGetLastError();
 }
@@ -229,7 +230,7 @@ hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* gua
 // ---- batched forms ----
 __global__ __launch_bounds__(256, 2) void kb_hblocks(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
-  if ((int)blockIdx.x * 4 >= d.n_segs) return;
+  if ((int)blockIdx.x * 4 >= d.n_nd_segs) return;
   body_hblocks(d, blockIdx.x);
 }
 
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(64) void kb_hreduce(BatchArgs a) {
 
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
   if (g.hblocks > 0) {
-    if (g.k1_direct) PPS_LAUNCH(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form, direct blocks done by K1
-    else PPS_LAUNCH(kb_hblocks, dim3(g.hblocks, a.n), dim3(256), 0, st, a);
+    if (g.lin_thread_form) PPS_LAUNCH(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form
+    else PPS_LAUNCH(kb_hblocks, dim3(std::max(1, g.hblocks), a.n), dim3(256), 0, st, a);
   }
   if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
   return hipGetLastError();

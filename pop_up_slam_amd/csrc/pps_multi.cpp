@@ -145,7 +145,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.lin_obs_blocks = std::max(q.lin_obs_blocks, (d.n_obs_fixed + 127) / 128);
       q.lin_rest_blocks = std::max(q.lin_rest_blocks, (d.n_odo + 127) / 128 + (d.n_pp + 127) / 128 + (d.n_lp + 127) / 128);
       q.repop_blocks = std::max(q.repop_blocks, (d.n_obs - d.n_obs_fixed + 63) / 64);
-      q.hblocks = std::max(q.hblocks, (d.n_segs + 3) / 4);
+      q.hblocks = std::max(q.hblocks, (d.n_nd_segs + 3) / 4);                     // (the segments K1 does not write itself)
       q.hblocks_nd = std::max(q.hblocks_nd, (d.n_nd_segs + 15) / 16);
       q.hreduce = std::max(q.hreduce, d.n_mseg);
       q.retract = std::max(q.retract, (d.n_pose + d.n_plane + 255) / 256);
@@ -171,7 +171,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
     q.lin_thread_form = q.n_factors_total > 200000 || getenv("PPS_MULTI_THREAD_FORM");      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
-    q.k1_direct = q.lin_thread_form || mode == PPS_JAC_ANALYTIC;   // the analytic sweep always runs one thread per factor
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
     q.level_form = level_ok && (q.n_factors_total > 200000 || getenv("PPS_MULTI_LEVELS"));
     { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
