@@ -197,33 +197,60 @@ __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
   for (int q = 0; q < S; q++) wave_hblock_segment(d, h[q], h2_lds + wave * kH2WaveDoubles);
 }
 
-// fold the partial sums of multi-segment blocks (the ground plane's diagonal) into their first slot
+// Fold the partial sums of a multi-segment block (the ground plane's diagonal: a hundred segments on C2) into its first slot.
+// The segments are summed as four interleaved partial sums -- p_w = segments w, w + 4, w + 8, ... in order -- combined as
+// (p0 + p1) + (p2 + p3): the same bits in every form.  NW = 4 (one graph): a 256-thread workgroup per block, one partial sum
+// per wave, up to 32 independent loads per thread in flight -- two memory round trips for the ground plane instead of one per
+// 16 segments -- and the combination through LDS.  NW = 1 (batches, where the launch is wide anyway): one wave computes the four
+// partial sums one after the other.
+template <int NW>
 __device__ __forceinline__ void body_hreduce(const DevGraph& d, int bx) {
+  __shared__ double part[4][64];
   const int blk = d.mseg_blk[bx];
   const int size = d.blk_size[blk], nseg = d.blk_nseg[blk];
   double* __restrict__ h = d.H + d.blk_hoff[blk];
-  const int lane = threadIdx.x;
-  if (lane >= size) return;
-  double v = 0.0;
-  for (int q = 0; q < nseg; q += 16) {
-    double x[16];
+  const int lane = threadIdx.x & 63, w0 = NW == 4 ? (int)(threadIdx.x >> 6) : 0;
+  const int ln = lane < size ? lane : 0;                       // (idle lanes shadow entry 0: no predicated loads)
+  double pv[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int u = 0; u < 16; u++) x[u] = (q + u < nseg) ? h[(size_t)(q + u) * size + lane] : 0.0;
+  for (int w = 0; w < 4; w++) {
+    if (NW == 4 && w != w0) continue;
+    double v = 0.0;
+    if (nseg <= 4) {                                           // an ordinary landmark: one segment per partial sum
+      const double t = h[(size_t)(w < nseg ? w : 0) * size + ln];
+      pv[w] = w < nseg ? t : 0.0;
+      continue;
+    }
+    for (int q = w; q < nseg; q += 4 * 16) {
+      double x[16];
 #pragma unroll
-    for (int u = 0; u < 16; u++) v += x[u];
+      for (int u = 0; u < 16; u++) { const int sg = q + 4 * u; const double t = h[(size_t)(sg < nseg ? sg : 0) * size + ln]; x[u] = sg < nseg ? t : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 16; u++) v += x[u];
+    }
+    pv[w] = v;
   }
-  h[lane] = v;
+  if (NW == 4) {
+    part[w0][lane] = pv[0] + pv[1] + pv[2] + pv[3];            // (three of them are zero: this wave's partial sum, exactly)
+    __syncthreads();
+    if (w0 != 0) return;
+#pragma unroll
+    for (int w = 0; w < 4; w++) pv[w] = part[w][lane];
+  }
+  if (lane >= size) return;
+  const double tot = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+  h[lane] = tot;
   const int dst = d.blk_dst[d.blk_doff[blk] + lane];
-  if (dst >= 0) d.Hf[dst] = v;
+  if (dst >= 0) d.Hf[dst] = tot;
 }
 
-__global__ __launch_bounds__(64) void k_hreduce(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hreduce(d, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_hreduce(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hreduce<4>(d, blockIdx.x); }
 
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard) {
   if (d.n_segs == 0) return hipSuccess;
   const LinGuard gd = guard ? *guard : LinGuard{};
   if (d.n_nd_segs > 0) PPS_LAUNCH(k_hblocks, dim3(cdiv(d.n_nd_segs, 4)), dim3(256), 0, st, d, gd);
-  if (d.n_mseg > 0) PPS_LAUNCH(k_hreduce, dim3(d.n_mseg), dim3(64), 0, st, d, gd);
+  if (d.n_mseg > 0) PPS_LAUNCH(k_hreduce, dim3(d.n_mseg), dim3(256), 0, st, d, gd);
   return hipGetLastError();
 }
 
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(256) void kb_hblocks_t(BatchArgs a) {
 __global__ __launch_bounds__(64) void kb_hreduce(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
   if ((int)blockIdx.x >= d.n_mseg) return;
-  body_hreduce(d, blockIdx.x);
+  body_hreduce<1>(d, blockIdx.x);
 }
 
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
