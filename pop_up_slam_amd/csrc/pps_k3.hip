@@ -203,7 +203,8 @@ int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
 size_t band_lds_bytes(int max_front, bool reg_only_kernel) {       // (the register-only kernels keep a 64-row panel buffer, the others 80 rows: strip)
   const size_t fa = (size_t)max_front + 1;
-  return (fa * (fa + 1) / 2 + 1 + (reg_only_kernel ? kRegRows : kRegRowsMax) * kPStride) * sizeof(double);
+  const size_t n = fa * (fa + 1) / 2 + 1 + (reg_only_kernel ? kRegRows : kRegRowsMax) * kPStride;
+  return ((n + 1) & ~size_t(1)) * sizeof(double);      // (an even number of doubles: every wave's triangle starts 16-byte aligned)
 }   // packed triangle + one spare double (where masked-off lanes of a scatter-add land: P[-1]) + panel buffer
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
@@ -408,6 +409,9 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
 // ---- assembly of a front's packed triangle in LDS, in pieces (one wave) ----
 // Eight scatter-add items per lane in flight: (target index, value) pairs of the front-ordered H, or of a child's packed update
 // matrix.  Issued as 16 independent coalesced loads, applied as LDS read-modify-writes (targets are unique inside one source).
+// scatter-add items per lane in flight in the extend-add.  Measured on C2 (us per LM iteration): 8 -> 78.9, 10 -> 77.6,
+// 12 -> 78.5, 16 -> 92.4 -- more loads in flight than about two dozen per lane cost more than the round trips they save
+constexpr int kEaDepth = 10;
 template <int N> struct ElBatch { int tg[N]; double v[N]; };
 // loads are issued unconditionally from clamped (always valid) addresses and masked by selects afterwards: predicated loads
 // become one exec-masked basic block each and serialise
@@ -449,7 +453,12 @@ __device__ __forceinline__ void front_pre_issue(const DevGraph& d, int rec, int 
 }
 __device__ __forceinline__ void front_clear(int rec, int lane, double* __restrict__ F) {
   const int ntri = tri(__builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1);
-  for (int i = lane; i < ntri; i += 64) F[i] = 0.0;
+  // 16 bytes per lane and store (the triangle starts 16-byte aligned; an odd tail is one more 8-byte store)
+  double2* __restrict__ F2 = reinterpret_cast<double2*>(F);
+  const int n2 = ntri >> 1;
+#pragma unroll 4
+  for (int i = lane; i < n2; i += 64) F2[i] = make_double2(0.0, 0.0);
+  if (lane == 0) F[ntri - 1] = 0.0;
   __builtin_amdgcn_wave_barrier();
 }
 template <int NPRE>
@@ -475,7 +484,9 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
     for (; cj < 8 && cb + cj < nch; cj++) {
       int n; const double* Uc; const int* tgc;
       child(cj, n, Uc, tgc);
-      for (int e = 0; e < n; e += 64 * 8) { ElBatch<8> q; el_issue(tgc, Uc, e, n, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<false>(q, 0.0, F, tr); }
+      // batches of kEaDepth x 64 = 640 entries: the update matrix of a separator front of a corridor tree (34 rows + rhs: 595
+      // entries) is one memory round trip, not a full batch of 512 followed by a nearly empty one
+      for (int e = 0; e < n; e += 64 * kEaDepth) { ElBatch<kEaDepth> q; el_issue(tgc, Uc, e, n, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<false>(q, 0.0, F, tr); }
       __builtin_amdgcn_wave_barrier();
     }
   }
