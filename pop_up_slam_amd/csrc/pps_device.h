@@ -76,6 +76,7 @@ struct DevGraph {
   unsigned int* ticket = nullptr;    // last-block election of the chi2 reduction
   double* result_dev = nullptr;      // [0] chi2, [1] |delta|^2, [2] not-PD flag (as double), [3] reserved
   long long* trace = nullptr;        // PPS_TRACE=1: 8 timestamps (s_memtime) per front of the last factorisation
+  int trace_solve = 0;               // PPS_TRACE=2: the trace slots take the phases of the back-substitution instead of the factorisation's
   int no_strip = 0;                  // PPS_NO_STRIP=1: fronts of 65 .. 80 rows take the LDS-tile path (A/B, parity tests)
   double* gwork = nullptr;           // global-memory front workspace for fronts that exceed LDS
   int64_t gwork_stride = 0;

@@ -723,29 +723,44 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
 // t_j, x_k is broadcast with v_readlane).  scratch: xb[128] + the panel.
 // GROUP: the front belongs to a band group (boundary values may come from the parent's local solution in LDS, the own solution
 // is left there for the children); false: level-per-launch form, everything through delta
-template <bool GROUP = true>
+// TR (PPS_TRACE=2): phase stamps of the back-substitution in the trace slots of the front: 0 start | 1 panel in LDS | 2 boundary
+// values in place | 3 y - L_B^T x_b | 4 back-substitution done | 5 end
+template <bool GROUP = true, bool TR = false>
 __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
   const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readlane(rec, 0);
+  (void)s;
+  if (TR) PPS_TR(0);
   const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
   const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   const int pslot = GROUP ? __builtin_amdgcn_readlane(rec, 14) : -1;
   // boundary values: from the parent's local solution vector in LDS (through cmap) when the parent was solved by this
   // workgroup, else gathered from delta.  The index load does not depend on the parent and is issued first.
-  const int* __restrict__ ix = pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8);
+  // (unpredicated loads at clamped positions -- a predicated load is a basic block of its own that waits for its data, i.e. one more
+  // memory round trip per index register in front of the panel's; the root has no list: any readable address does)
+  const int* __restrict__ ix = b == 0 ? d.frec : (pslot >= 0 ? d.cmap + __builtin_amdgcn_readlane(rec, 15) : d.bidx + __builtin_amdgcn_readlane(rec, 8));
   double* xb = W;
   double* PL = W + kBandMaxRows;
-  const int ix0 = lane < b ? ix[lane] : 0, ix1 = lane + 64 < b ? ix[lane + 64] : 0;
+  const int ix0r = ix[lane < b ? lane : 0], ix1r = ix[lane + 64 < b ? lane + 64 : 0];
+  const int n = (f + 1) * p;
+  // first batch of the panel (all of it for n <= 1024) issued right behind the index loads: the gather from delta below then waits
+  // for the indices only, with the panel in flight
+  double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; v[u] = Lp[e < n ? e : n - 1]; }
+  const int ix0 = lane < b ? ix0r : 0, ix1 = lane + 64 < b ? ix1r : 0;
   double g0 = 0.0, g1 = 0.0;
   if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }          // clamped index 0 when out of range: harmless
-  const int n = (f + 1) * p;
   // (entries past the end of the panel land in xb[127], which no front uses: b <= 126 -- unpredicated LDS writes)
-  for (int e0 = 0; e0 < n; e0 += 64 * 16) {
-    double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; PL[e < n ? e : -1] = v[u]; }
+  for (int e0 = 64 * 16; e0 < n; e0 += 64 * 16) {
 #pragma unroll
     for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; v[u] = Lp[e < n ? e : n - 1]; }
 #pragma unroll
     for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; PL[e < n ? e : -1] = v[u]; }
   }
+  if (TR) PPS_TR(1);
   if (pslot >= 0) {
     const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows;
     g0 = Xp[ix0]; g1 = Xp[ix1];
@@ -753,30 +768,56 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane < b) xb[lane] = g0;
   if (lane + 64 < b) xb[lane + 64] = g1;
   __builtin_amdgcn_wave_barrier();
+  if (TR) PPS_TR(2);
   double tj = 0.0, dinv = 0.0;
   {
 #ifndef PPS_NO_FMA
 #pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
 #endif
-    if (lane < p) {
-      // y - L_B^T x_b in two interleaved partial sums (half the dependent chain)
-      double acc = PL[f * p + lane], acc2 = 0.0;
-      const double* __restrict__ lb = PL + p * p + lane;
-      int i = 0;
-#pragma unroll 2
-      for (; i + 2 <= b; i += 2) { acc -= lb[i * p] * xb[i]; acc2 -= lb[(i + 1) * p] * xb[i + 1]; }
-      if (i < b) acc -= lb[i * p] * xb[i];
-      tj = acc + acc2;
-      dinv = 1.0 / PL[lane * p + lane];
+    // Everything the dependent chain of the back-substitution reads is fetched before the chain starts: column k of L_A sits in
+    // lk[k - k0] of lane j (16 columns at a time), the reciprocal diagonal in dinv -- the chain itself is v_readlane + multiply +
+    // fma per pivot, no LDS round trip in it.
+    const int lc = lane < p ? lane : 0;
+    int k0 = (p - 1) & ~15;
+    double lk[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int k = k0 + u; lk[u] = PL[(k < p ? k : p - 1) * p + lc]; }
+    dinv = 1.0 / PL[lc * p + lc];
+    // y - L_B^T x_b: column j of L_B is summed by 64 / W lanes (W = 16, 32 or 64 >= p: rows i = part (mod 64 / W) each, four
+    // independent partial sums per lane), then the parts are added across the wave -- 9 LDS rounds for b = 36, p = 15 instead of 36
+    const int W = p <= 16 ? 16 : (p <= 32 ? 32 : 64), sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
+    const int j = lane & (W - 1), part = lane >> sh, np = 64 >> sh;
+    const int jc = j < p ? j : 0;
+    double a0 = (part == 0) ? PL[f * p + jc] : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double* __restrict__ lb = PL + p * p + jc;
+    for (int i = part; i < b; i += 4 * np) {              // (b is wave-uniform, `part` is not: rows past b contribute 0)
+      const int i1 = i + np, i2 = i + 2 * np, i3 = i + 3 * np;
+      const double l0 = lb[i * p], l1 = lb[(i1 < b ? i1 : i) * p], l2 = lb[(i2 < b ? i2 : i) * p], l3 = lb[(i3 < b ? i3 : i) * p];
+      const double x0 = xb[i], x1 = i1 < b ? xb[i1] : 0.0, x2 = i2 < b ? xb[i2] : 0.0, x3 = i3 < b ? xb[i3] : 0.0;
+      a0 -= l0 * x0; a1 -= l1 * x1; a2 -= l2 * x2; a3 -= l3 * x3;
     }
-#pragma unroll 4
-    for (int k = p - 1; k >= 0; k--) {
-      const double lkj = (lane < k) ? PL[k * p + lane] : 0.0;      // independent of the chain
-      const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
-      tj = (lane == k) ? xk : tj - lkj * xk;
+    tj = (a0 + a1) + (a2 + a3);
+    if (W <= 32) tj += __shfl_xor(tj, 32);
+    if (W == 16) tj += __shfl_xor(tj, 16);
+    if (TR) PPS_TR(3);
+    for (;;) {
+#pragma unroll
+      for (int u = 15; u >= 0; u--) {
+        const int k = k0 + u;
+        if (k < p) {                                         // (wave-uniform)
+          const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
+          tj = (lane == k) ? xk : tj - ((lane < k) ? lk[u] : 0.0) * xk;
+        }
+      }
+      if (k0 == 0) break;
+      k0 -= 16;
+#pragma unroll
+      for (int u = 0; u < 16; u++) lk[u] = PL[(k0 + u) * p + lc];
     }
   }
+  if (TR) PPS_TR(4);
   if (lane < p) d.delta[d.pidx[__builtin_amdgcn_readlane(rec, 7) + lane]] = tj;
+  if (TR) PPS_TR(5);
   if (!GROUP) return;
   // own local solution [x_p | x_b] for the children inside this group
   double* __restrict__ Xs = X + (size_t)slot * kBandMaxRows;
@@ -784,17 +825,28 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane < b) Xs[p + lane] = g0;
   if (lane + 64 < b) Xs[p + lane + 64] = g1;
 }
+template <bool TR = false>
 __device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
   double* X = lds + (size_t)nw * lds_doubles_per_wave;          // one local solution vector per front of the group
-  const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
-  const int g0 = d.glvl_front_off[l0];
+  const int l0 = uni(d.grp_lvl_off[g]), l1 = uni(d.grp_lvl_off[g + 1]);
+  // The front lists of the group's levels and the record of this wave's first front on each of them are fetched before the walk
+  // starts: a level then begins with the loads of its panel, not with two dependent round trips (offsets, record) behind the barrier.
+  // (a group has at most band_levels <= 4 local levels; deeper ones would take the in-loop loads)
+  int off[5], r4[4];
+#pragma unroll
+  for (int k = 0; k < 5; k++) off[k] = uni(d.glvl_front_off[l0 + k <= l1 ? l0 + k : l1]);
+  const int g0 = off[0];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int i = off[k] + wave; r4[k] = d.frec[(size_t)(i < off[k + 1] ? i : g0) * 16 + (threadIdx.x & 15)]; }
   for (int l = l1 - 1; l >= l0; l--) {
-    const int i1 = d.glvl_front_off[l + 1];
-    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
-      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
-      wave_front_solve(d, rec, W, X, i - g0);
+    const int k = l - l0;
+    const int i0 = k < 4 ? (k == 3 ? off[3] : k == 2 ? off[2] : k == 1 ? off[1] : off[0]) : uni(d.glvl_front_off[l]);
+    const int i1 = k < 4 ? (k == 3 ? off[4] : k == 2 ? off[3] : k == 1 ? off[2] : off[1]) : uni(d.glvl_front_off[l + 1]);
+    for (int i = i0 + wave; i < i1; i += nw) {
+      const int rec = (k < 4 && i == i0 + wave) ? (k == 3 ? r4[3] : k == 2 ? r4[2] : k == 1 ? r4[1] : r4[0]) : d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+      wave_front_solve<true, TR>(d, rec, W, X, i - g0);
     }
     __syncthreads();   // delta of this local level is visible to the children
   }
@@ -805,6 +857,10 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
   body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
+__global__ __launch_bounds__(512) void k_band_solve_trace(DevGraph d, int grp_begin, int lds_doubles_per_wave) {     // PPS_TRACE=2
+  extern __shared__ double lds[];
+  body_band_solve<true>(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+}
 
 // REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the phase trace
 // are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
@@ -814,6 +870,9 @@ template <bool REG_ONLY, bool REG_STRIP = false, bool TR = false>
 __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* F = lds + (size_t)wave * lds_doubles_per_wave;
+  // (Fetching the level offsets and the wave's first record of every level up front, as body_band_solve does, was measured here
+  // twice: held in registers the five live values push the register-tile code into spills inside the elimination -- C2 stage
+  // 25.6 -> 33.4 us --; parked in LDS it gains nothing on C2 and costs C3 a third of its factor time.)
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
   for (int l = l0; l < l1; l++) {
     const int i1 = d.glvl_front_off[l + 1];
@@ -862,6 +921,7 @@ static hipError_t ensure_band_attrs() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_strip), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_lean_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
@@ -911,7 +971,8 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
   const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const size_t bytes = ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
-  PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
+  if (d.trace != nullptr && d.trace_solve && !alt) PPS_LAUNCH(k_band_solve_trace, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, per_wave);
+  else PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
   return hipGetLastError();
 }
 

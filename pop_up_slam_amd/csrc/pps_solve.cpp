@@ -454,6 +454,23 @@ static int lm_solve(pps_graph* g, int* iterations) {
     const Analysis& A = g->an;
     std::vector<long long> tr((size_t)A.n_fronts * 8);
     (void)hipMemcpy(tr.data(), g->dev.trace, tr.size() * 8, hipMemcpyDeviceToHost);
+    if (g->dev.trace_solve) {
+      // PPS_TRACE=2: the slots hold the back-substitution of the last solve (parents before children)
+      for (int l = A.n_levels - 1; l >= 0; l--) {
+        double ph[5] = {0, 0, 0, 0, 0}, gap = 0; int n = 0, ng = 0;
+        for (int s2 = 0; s2 < A.n_fronts; s2++) {
+          if (A.f_level[s2] != l) continue;
+          n++;
+          for (int k = 0; k < 5; k++) ph[k] += (double)(tr[(size_t)s2 * 8 + k + 1] - tr[(size_t)s2 * 8 + k]);
+          const int par = A.f_parent[s2];
+          if (par >= 0) { gap += (double)(tr[(size_t)s2 * 8] - tr[(size_t)par * 8 + 5]); ng++; }
+        }
+        if (!n) continue;
+        fprintf(stderr, "  solve level %d (%d fronts): panel load %.0f boundary values %.0f y - L_B^T x_b %.0f back-substitution %.0f store %.0f | start after parent's end %.0f\n",
+                l, n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ng ? gap / ng : 0.0);
+      }
+      return PPS_OK;
+    }
     double acc[5] = {0, 0, 0, 0, 0};
     std::vector<double> lvl_tot(A.n_levels, 0.0); std::vector<int> lvl_n(A.n_levels, 0);
     for (int s2 = 0; s2 < A.n_fronts; s2++) {
