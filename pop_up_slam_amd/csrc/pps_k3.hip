@@ -717,6 +717,14 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
 }
 
 
+// lane K of every row of 16 lanes, broadcast to the row (DPP row_newbcast: two v_mov_b32_dpp, no SGPR hop, no LDS)
+template <int K> __device__ __forceinline__ double row_bcast_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // x_p = L_A^-T (y - L_B^T x_b) for one front, one wave (p <= 64).  The factor panel ((f+1) x p, contiguous) is
 // copied to LDS in batches of 16 independent coalesced loads per lane -- two round trips for a C2 front instead of one
 // per 8 rows -- and everything after that reads LDS; the back-substitution chain runs in registers (lane j holds
@@ -742,6 +750,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   double* xb = W;
   double* PL = W + kBandMaxRows;
   const int ix0r = ix[lane < b ? lane : 0], ix1r = ix[lane + 64 < b ? lane + 64 : 0];
+  const int pix = d.pidx[__builtin_amdgcn_readlane(rec, 7) + (lane < p ? lane : 0)];      // (where x_p goes: fetched with the rest)
   const int n = (f + 1) * p;
   // first batch of the panel (all of it for n <= 1024) issued right behind the index loads: the gather from delta below then waits
   // for the indices only, with the panel in flight
@@ -774,14 +783,14 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
 #ifndef PPS_NO_FMA
 #pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
 #endif
-    // Everything the dependent chain of the back-substitution reads is fetched before the chain starts: column k of L_A sits in
-    // lk[k - k0] of lane j (16 columns at a time), the reciprocal diagonal in dinv -- the chain itself is v_readlane + multiply +
-    // fma per pivot, no LDS round trip in it.
+    // Everything the dependent chain of the back-substitution reads is prepared before the chain starts: lk[k - k0] of lane j holds
+    // L_kj / L_kk for j < k (0 elsewhere), 16 pivots at a time, so that t_j -= lk * t_k is all a pivot costs -- v_readlane + fma, no
+    // LDS round trip, no select -- and x = t / diag(L) is one multiplication at the end.
     const int lc = lane < p ? lane : 0;
     int k0 = (p - 1) & ~15;
     double lk[16];
 #pragma unroll
-    for (int u = 0; u < 16; u++) { const int k = k0 + u; lk[u] = PL[(k < p ? k : p - 1) * p + lc]; }
+    for (int u = 0; u < 16; u++) { const int k = k0 + u; const double l = PL[(k < p ? k : p - 1) * p + lc]; lk[u] = lane < k ? l : 0.0; }
     dinv = 1.0 / PL[lc * p + lc];
     // y - L_B^T x_b: column j of L_B is summed by 64 / W lanes (W = 16, 32 or 64 >= p: rows i = part (mod 64 / W) each, four
     // independent partial sums per lane), then the parts are added across the wave -- 9 LDS rounds for b = 36, p = 15 instead of 36
@@ -799,24 +808,37 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     tj = (a0 + a1) + (a2 + a3);
     if (W <= 32) tj += __shfl_xor(tj, 32);
     if (W == 16) tj += __shfl_xor(tj, 16);
+    tj = lane < p ? tj : 0.0;
     if (TR) PPS_TR(3);
-    for (;;) {
+    // pivots 16 and up (leaves and roots only: p <= 16 on every other front): t_k crosses rows of 16 lanes through v_readlane
+    for (; k0 >= 16; k0 -= 16) {
 #pragma unroll
       for (int u = 15; u >= 0; u--) {
         const int k = k0 + u;
-        if (k < p) {                                         // (wave-uniform)
-          const double xk = readlane_d(tj, k) * readlane_d(dinv, k);
-          tj = (lane == k) ? xk : tj - ((lane < k) ? lk[u] : 0.0) * xk;
-        }
+        if (k < p) tj -= lk[u] * readlane_d(dinv, k) * readlane_d(tj, k);        // (wave-uniform branch)
       }
-      if (k0 == 0) break;
-      k0 -= 16;
 #pragma unroll
-      for (int u = 0; u < 16; u++) lk[u] = PL[(k0 + u) * p + lc];
+      for (int u = 0; u < 16; u++) { const int k = k0 - 16 + u; const double l = PL[k * p + lc]; lk[u] = lane < k ? l : 0.0; }
     }
+    // pivots 15 .. 0 live in the first row of 16 lanes: t_k and 1 / L_kk reach the other lanes of the row as DPP row broadcasts --
+    // a pivot is two v_mov_dpp + one v_fma_f64, nothing leaves the vector ALU
+    // (lk is 0 on and above the diagonal since it was loaded: a select around the DPP move would be turned into a branch that
+    // switches the source lane off)
+#define PPS_SC(U) lk[U] *= row_bcast_d<U>(dinv);
+    PPS_SC(1) PPS_SC(2) PPS_SC(3) PPS_SC(4) PPS_SC(5) PPS_SC(6) PPS_SC(7) PPS_SC(8) PPS_SC(9) PPS_SC(10) PPS_SC(11) PPS_SC(12) PPS_SC(13) PPS_SC(14) PPS_SC(15)
+#undef PPS_SC
+#define PPS_BS(U) case U: tj -= lk[U] * row_bcast_d<U>(tj); [[fallthrough]];
+    switch (p < 16 ? p - 1 : 15) {                            // (wave-uniform: the chain is entered at the last pivot)
+      PPS_BS(15) PPS_BS(14) PPS_BS(13) PPS_BS(12) PPS_BS(11) PPS_BS(10) PPS_BS(9) PPS_BS(8)
+      PPS_BS(7) PPS_BS(6) PPS_BS(5) PPS_BS(4) PPS_BS(3) PPS_BS(2)
+      case 1: tj -= lk[1] * row_bcast_d<1>(tj); [[fallthrough]];
+      default: break;
+    }
+#undef PPS_BS
+    tj *= dinv;
   }
   if (TR) PPS_TR(4);
-  if (lane < p) d.delta[d.pidx[__builtin_amdgcn_readlane(rec, 7) + lane]] = tj;
+  if (lane < p) d.delta[pix] = tj;
   if (TR) PPS_TR(5);
   if (!GROUP) return;
   // own local solution [x_p | x_b] for the children inside this group
