@@ -870,7 +870,10 @@ __device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int ld
       const int rec = (k < 4 && i == i0 + wave) ? (k == 3 ? r4[3] : k == 2 ? r4[2] : k == 1 ? r4[1] : r4[0]) : d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
       wave_front_solve<true, TR>(d, rec, W, X, i - g0);
     }
-    __syncthreads();   // delta of this local level is visible to the children
+    // The children inside the group read their parent's solution from LDS (X), never from delta: the barrier orders LDS only.
+    // (__syncthreads() is a workgroup-scope release -- it would also wait for the acknowledgement of the stores to delta, a
+    // memory round trip per level)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
