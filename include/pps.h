@@ -209,6 +209,16 @@ int pps_time_linearize(pps_graph* g, int mode, int iters, double* sec_per_launch
 int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double sec_per_sweep[3],
                     int64_t* n_plane_edges, int64_t* n_odo_edges);
 
+/* ---- K3 diagnostic: one frontal matrix through the register-tile elimination, outside any graph ---- */
+/* The dense partial Cholesky a front of the multifrontal factorisation goes through (the part of Cholesky.cpp's factorisation,
+ * isam/Cholesky.cpp:86-130 via CHOLMOD's supernodal kernel, that happens inside one supernode), with the right-hand side as the
+ * front's last row.  A: packed lower triangle, p + b + 1 rows (pivot rows, boundary rows, rhs row; row i holds i + 1 values).
+ * L: (p + b + 1) x p row-major factor panel [L_A; L_B; y^T] (entries above the diagonal of L_A unspecified); U: packed lower
+ * triangle of the (b + 1)-row update matrix [S; r^T].  tiles: 16-row tile rows held in registers, 2 .. 5, or 0 for what the solver
+ * picks for a front of this size; strip != 0: rows 64 .. 79 as a strip of the LDS triangle under four tile rows (fronts of 65 .. 80
+ * rows only).  not_pd: 1.0 when a pivot was not positive.  p <= 64, p + b + 1 <= 80.  Runs on the current device. */
+int pps_debug_front_factor(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd);
+
 /* ---- pop-up (fp32), /root/reference/pop_up_wall --------------------------------------- */
 /* popup_plane::update_plane_equation_from_seg (libs/popup_plane.cpp:654-705).
  * seg2d n x 4 (u1,v1,u2,v2); invK 3x3, T_wc 4x4 row-major; planes_out (n+1) x 4, row 0 = ground.

@@ -104,7 +104,7 @@ SYMBOLS = [
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
     "pps_find_closest_planes", "pps_graph_save", "pps_graph_load", "pps_add_plane_obs2", "pps_edge_ray",
-    "pps_time_linearize", "pps_reproject_points", "pps_popup_set_outputs",
+    "pps_time_linearize", "pps_debug_front_factor", "pps_reproject_points", "pps_popup_set_outputs",
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
     "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
@@ -211,6 +211,7 @@ def lib():
         L.pps_add_plane_obs2.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _ip]
         L.pps_edge_ray.argtypes = [_fp, _fp, _dp]
         L.pps_time_linearize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.pps_debug_front_factor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_double)]
         L.pps_reproject_points.argtypes = [C.c_void_p, C.c_int, _ip, _fp, _fp]
         L.pps_graph_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.pps_graph_load.argtypes = [C.c_char_p, C.POINTER(PpsProps), C.POINTER(C.c_void_p)]
@@ -798,3 +799,17 @@ def edges_host_select(contour_xy, width, height, lsd_lines, prm=None):
     if rc != PPS_OK:
         raise PpsError(rc, "pps_edges_host_select")
     return o[:no.value].copy(), cl[:ncl.value].copy(), idx[:no.value].copy()
+
+
+def debug_front_factor(A_tri, p, b, tiles=0, strip=False):
+    """One frontal matrix (packed lower triangle, p pivot rows + b boundary rows + the rhs row) through the register-tile
+    elimination of the band kernels: returns (L (p+b+1) x p, U packed triangle of b+1 rows, not_pd)."""
+    L_ = lib()
+    fa = p + b + 1
+    a = np.ascontiguousarray(A_tri, dtype=np.float64)
+    assert a.size == fa * (fa + 1) // 2
+    Lp = np.zeros((fa, p)); U = np.zeros((b + 1) * (b + 2) // 2 + (b + 1) * (b + 1)); bad = C.c_double()
+    rc = L_.pps_debug_front_factor(int(tiles), int(bool(strip)), int(p), int(b), a.ctypes.data_as(_dp), Lp.ctypes.data_as(_dp), U.ctypes.data_as(_dp), C.byref(bad))
+    if rc != 0:
+        raise PpsError(rc, "pps_debug_front_factor(tiles=%d, strip=%d, p=%d, b=%d)" % (tiles, strip, p, b))
+    return Lp, U[:(b + 1) * (b + 2) // 2], bad.value

@@ -376,6 +376,12 @@ int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed) 
 
 // K1 alone on the solver's stream: `iters` back-to-back sweeps of the handle's graph between two HIP events
 // (an event pair around ONE ~10 us launch also measures the command processor's event handling, about as long again)
+int pps_debug_front_factor(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd) {
+  if (!A || !L || !U) return PPS_EINVAL;
+  const int rc = pps::debug_front_factor(tiles, strip, p, b, A, L, U, not_pd);
+  return rc == 0 ? PPS_OK : (rc < 0 ? PPS_EINVAL : PPS_EHIP);
+}
+
 int pps_time_linearize(pps_graph* g, int mode, int iters, double* sec_per_launch) {
   if (!g || iters < 1 || !sec_per_launch) return PPS_EINVAL;
   int rc = prepare_solve(g);

@@ -527,6 +527,7 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
   const int l16 = lane & 15, lq = lane >> 4;
   const int f = p + b, fa = f + 1;
   const bool strip = STRIP && fa > kRegRows;
+  constexpr bool R5 = NT == 5;                                 // rows 64 .. 79 are a fifth tile row in registers, not an LDS strip
   // The right-hand side rides along as row f of the front.  Without a strip it is kept as a VECTOR (lane = column) next to
   // the tiles instead of inside them: a front of 48 rows + rhs then needs three tile rows, not four (6 MFMA per panel instead of
   // 10, 24 tile registers to load and store instead of 40) -- every separator front of a C2 tree.  mr = rows held in the tiles.
@@ -551,7 +552,7 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
   double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
   long long cyc_panel = 0, cyc_trail = 0;
   bool bad = false;                                            // a pivot that is not positive: reported once, after the last panel
-  for (int K = 0; K < p; K += 4) {
+  auto panel_step = [&](const int K) __attribute__((always_inline)) {
     const long long tk0 = (TR && d.trace) ? clock64() : 0;
     const int nb = p - K < 4 ? p - K : 4;
     const int tjK = K >> 4, c0 = K & 15;
@@ -563,7 +564,7 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
     }
     const int row2 = kRegRows + (lane & 15);                   // the strip row of this lane (lanes 0 .. 15)
     const bool has2 = STRIP && strip && lane < 16 && row2 < fa;
-    if (has2) {
+    if (has2 && !R5) {                                         // (with a fifth tile row the extraction above wrote these panel rows)
 #pragma unroll
       for (int m = 0; m < 4; m++) P[row2 * kPStride + m] = F[tri(row2) + K + m];   // (K + m < 64 <= row2: inside the row)
     }
@@ -641,7 +642,7 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (STRIP && strip) {
+    if (STRIP && strip && !R5) {
       // F[r][c] -= sum_k L[r][k] L[c][k] for the strip rows r and the live columns c >= K + nb: the strip is tile row 4 of the
       // front; its five 16x16 tiles are loaded from the LDS triangle, updated with one MFMA each and written back (only the
       // entries that exist: c <= r < fa).  Tile columns left of the panel are finished and skipped.
@@ -680,6 +681,14 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
     }
     __builtin_amdgcn_wave_barrier();
     if (TR && d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
+  };
+  if constexpr (NT == 5) {
+    // (hipcc 7.2 miscompiles this loop with fifteen accumulator tiles once it peels the first panel: rows 8 and up of every later
+    // panel come out wrong, deterministically -- tests/test_gpu_fronts.py holds the case; without peeling the code is correct)
+#pragma clang loop unroll(disable)
+    for (int K = 0; K < p; K += 4) panel_step(K);
+  } else {
+    for (int K = 0; K < p; K += 4) panel_step(K);
   }
   if (bad && lane == 0) d.result_dev[2] = 1.0;             // not positive definite
   if (TR) PPS_TR(4);
@@ -708,7 +717,7 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
       }
     }
   }
-  if (STRIP && strip) {
+  if (STRIP && strip && !R5) {
     for (int r = kRegRows; r < fa; r++)
       for (int col = p + lane; col <= r; col += 64) Us[tri(r - p) + col - p] = F[tri(r) + col];
   }
@@ -889,9 +898,10 @@ __global__ __launch_bounds__(512) void k_band_solve_trace(DevGraph d, int grp_be
 
 // REG_ONLY: every front of the stage fits the register-resident path (C2: all stages) -- the LDS-tile path and the phase trace
 // are compiled out, which halves the kernel's code (the instruction cache is shared by two CUs)
-// REG_STRIP (with REG_ONLY): the stage also holds fronts of 65 .. 80 rows -- ten register tiles + the LDS strip -- and still
-// nothing that needs the LDS-tile path or the trace (frame-loop trees, C3)
-template <bool REG_ONLY, bool REG_STRIP = false, bool TR = false>
+// REG_STRIP + R5 (with REG_ONLY): the stage also holds fronts of 65 .. 80 rows -- fifteen register tiles, k_band_factor_r5 -- and
+// still nothing that needs the LDS-tile path or the trace (frame-loop trees, C3).  The general kernel (REG_ONLY = false: traces,
+// pps_multi) carries such fronts as ten register tiles + a strip of the LDS triangle.
+template <bool REG_ONLY, bool REG_STRIP = false, bool TR = false, bool R5 = false>
 __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* F = lds + (size_t)wave * lds_doubles_per_wave;
@@ -909,7 +919,7 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       if (REG_ONLY && fa <= 33) wave_front_factor_reg<2, TR>(d, rec, lambda, F, Pn);                    // (without a strip the rhs row is a vector next to the tiles)
       else if (REG_ONLY && fa <= 49) wave_front_factor_reg<3, TR>(d, rec, lambda, F, Pn);
       else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, TR>(d, rec, lambda, F, Pn);
-      else if (REG_ONLY) wave_front_factor_reg<4, false, true>(d, rec, lambda, F, Pn);                   // 65 .. 80 rows: register tiles + LDS strip
+      else if (REG_ONLY && R5) wave_front_factor_reg<5, false, true>(d, rec, lambda, F, Pn);             // 65 .. 80 rows: fifteen register tiles
       else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true, true>(d, rec, lambda, F, Pn);
       else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);
       else wave_front_factor(d, s, lambda, F);
@@ -931,10 +941,13 @@ __global__ __launch_bounds__(512) void k_band_factor_lean_trace(DevGraph d, Dual
   body_band_factor<true, false, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
-__global__ __launch_bounds__(512) void k_band_factor_strip(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
+// Stages with fronts of 65 .. 80 rows, all of it in registers: four waves per workgroup, one per SIMD, so that a wave may hold
+// fifteen accumulator tiles (120 registers) next to everything else -- the unified register file gives a lone wave 512.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_band_factor_r5(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
-  body_band_factor<true, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
+  body_band_factor<true, true, false, true>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
 static std::atomic<bool> g_band_attr_set[64];   // per device ordinal
@@ -947,7 +960,7 @@ static hipError_t ensure_band_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_strip), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_r5), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_lean_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
@@ -965,9 +978,10 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
     PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
   else if (reg_only)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
-  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
-    PPS_LAUNCH(k_band_factor_strip, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
-  else
+  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
+    const int nw5 = nwaves < 4 ? nwaves : 4;                // (one wave per SIMD: see k_band_factor_r5)
+    PPS_LAUNCH(k_band_factor_r5, dim3(grp_count), dim3(64 * nw5), (size_t)per_wave * nw5 * sizeof(double), st, d, DualAlt{}, grp_begin, lambda, per_wave);
+  } else
     PPS_LAUNCH(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
   return hipGetLastError();
 }
@@ -980,9 +994,10 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   if (max_front + 1 <= kRegRows && d.trace == nullptr)
     PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
-  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip)
-    PPS_LAUNCH(k_band_factor_strip, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
-  else
+  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
+    const int nw5 = nwaves < 4 ? nwaves : 4;
+    PPS_LAUNCH(k_band_factor_r5, dim3(grp_count, 2), dim3(64 * nw5), (size_t)per_wave * nw5 * sizeof(double), st, d, alt, grp_begin, lambda, per_wave);
+  } else
     PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   return hipGetLastError();
 }
@@ -1161,4 +1176,66 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
   return hipGetLastError();
 }
 
+}  // namespace pps
+
+// ---- diagnostic: one front through the register-tile elimination, outside any graph (pps_debug_front_factor) ----
+namespace pps {
+template <int NT, bool STRIP>
+__global__ __launch_bounds__(64) void k_debug_front(DevGraph d, int p, int b, const double* A, int per_wave) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int fa = p + b + 1;
+  double* F = lds;
+  double* P = F + per_wave - kRegRowsMax * kPStride;
+  for (int i = lane; i < fa * (fa + 1) / 2; i += 64) F[i] = A[i];
+  __builtin_amdgcn_wave_barrier();
+  int rec = 0;                                    // (L and U of the front start at offset 0)
+  if (lane == 1) rec = p;
+  if (lane == 2) rec = b;
+  front_reg_eliminate<NT, false, STRIP>(d, rec, F, P);
+}
+
+// tiles: 2 .. 5 tile rows; 0 = the choice the band kernels make for the front (by its row count); strip: rows 64 .. 79 as a strip of
+// the LDS triangle under four tile rows instead of a fifth tile row.  Returns a hipError_t (0 = ok), -1 for arguments no path takes.
+int debug_front_factor(int tiles, int strip, int p, int b, const double* A_host, double* L_host, double* U_host, double* not_pd) {
+  const int f = p + b, fa = f + 1;
+  if (p < 1 || b < 0 || fa > kRegRowsMax || p > kRegRows) return -1;
+  if (tiles == 0) tiles = fa <= 33 ? 2 : fa <= 49 ? 3 : fa <= kRegRows ? 4 : (strip ? 4 : 5);
+  const bool wide = fa > kRegRows;
+  if (tiles < 2 || tiles > 5 || (wide && tiles < 4) || (!wide && (tiles == 5 || strip)) || (tiles < 4 && f > 16 * tiles) || (wide && tiles == 4 && !strip)) return -1;
+  const size_t ntri = (size_t)fa * (fa + 1) / 2, nL = (size_t)fa * p, nU = (size_t)(b + 1) * (b + 1);
+  double *A = nullptr, *L = nullptr, *U = nullptr, *res = nullptr;
+  hipError_t e = hipMalloc(&A, ntri * 8);
+  if (e == hipSuccess) e = hipMalloc(&L, nL * 8);
+  if (e == hipSuccess) e = hipMalloc(&U, nU * 8);
+  if (e == hipSuccess) e = hipMalloc(&res, 32);
+  if (e == hipSuccess) e = hipMemcpy(A, A_host, ntri * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(L, 0, nL * 8);
+  if (e == hipSuccess) e = hipMemset(U, 0, nU * 8);
+  if (e == hipSuccess) e = hipMemset(res, 0, 32);
+  if (e == hipSuccess) {
+    DevGraph d{}; d.L = L; d.U = U; d.result_dev = res;
+    const int per_wave = (int)(band_lds_bytes(fa - 1, false) / 8);
+    const size_t bytes = (size_t)per_wave * 8;
+#define PPS_DBG_FRONT(NT_, STRIP_)                                                                                                      \
+    do {                                                                                                                                \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_front<NT_, STRIP_>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes); \
+      if (e == hipSuccess) { hipLaunchKernelGGL((k_debug_front<NT_, STRIP_>), dim3(1), dim3(64), bytes, 0, d, p, b, A, per_wave); e = hipGetLastError(); } \
+    } while (0)
+    if (tiles == 5) PPS_DBG_FRONT(5, true);
+    else if (tiles == 4 && wide) PPS_DBG_FRONT(4, true);
+    else if (tiles == 4) PPS_DBG_FRONT(4, false);
+    else if (tiles == 3) PPS_DBG_FRONT(3, false);
+    else PPS_DBG_FRONT(2, false);
+#undef PPS_DBG_FRONT
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(L_host, L, nL * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(U_host, U, nU * 8, hipMemcpyDeviceToHost);
+    double r4[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(r4, res, 32, hipMemcpyDeviceToHost);
+    if (not_pd) *not_pd = r4[2];
+  }
+  (void)hipFree(A); (void)hipFree(L); (void)hipFree(U); (void)hipFree(res);
+  return (int)e;
+}
 }  // namespace pps

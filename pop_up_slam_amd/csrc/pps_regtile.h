@@ -40,7 +40,7 @@ constexpr int kRegRowsMax = 80;                   // ... plus up to 16 boundary 
 
 __device__ __forceinline__ constexpr int tile_id(int ti, int tj) { return ti * (ti + 1) / 2 + tj; }
 
-// NT = tile rows held (4: up to 64 rows, 10 tiles; 3: up to 48 rows, 6 tiles -- same tile_id numbering)
+// NT = tile rows held (5: up to 80 rows, 15 tiles; 4: up to 64 rows, 10 tiles; 3: up to 48 rows, 6 tiles -- same tile_id numbering)
 template <int TJ, int NT = 4>
 __device__ __forceinline__ void reg_extract_panel(const double4_t (&c)[NT * (NT + 1) / 2], double* __restrict__ P, int c0, int lane) {
   const int l16 = lane & 15, lq = lane >> 4;
@@ -60,7 +60,7 @@ template <int TJ, int NT = 4>
 __device__ __forceinline__ void reg_trailing(double4_t (&c)[NT * (NT + 1) / 2], const double* __restrict__ P, int nb, int lane, int tjn = TJ) {
   const int l16 = lane & 15, lq = lane >> 4;
   const bool kvalid = lq < nb;
-  double opnd[4];
+  double opnd[NT];
 #pragma unroll
   for (int t = TJ; t < NT; t++) { const double x = P[(16 * t + l16) * kPStride + lq]; opnd[t] = kvalid ? x : 0.0; }
   if (tjn == TJ) {
