@@ -279,7 +279,7 @@ int pps_restore_state(pps_graph* g) {
   const DevGraph& d = g->dev;
   HIP_TRY(g, hipMemcpyAsync(d.pose_est, g->snap_pose, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
   g->lin_is_est = false;
-  g->dev_values_newer = true; g->lin_is_est = false;
+  g->dev_values_newer = true; g->lin_is_est = false; g->pin_holds_est = false;
   return PPS_OK;
 }
 

@@ -123,7 +123,7 @@ hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
                              double seq1, hipStream_t st);
 // ea_tgt (packed update matrix of a front -> packed index in its parent) expanded from cmap / f_cmap_off / f_ea_off
-hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st);
+hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_t n_zero, int* ones, size_t n_ones, hipStream_t st);   // + the upload's two fills
 // el_tgt / blk_dst (H block element <-> front-ordered H <-> packed front index) expanded from the per-block records;
 // blk_dst must be filled with -1 beforehand
 hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st);

@@ -121,6 +121,7 @@ struct pps_graph {
   bool lin_is_est = false;       // upload_state has just filled est AND lin: the estimate_to_linpoint copy of the next solve is a no-op
   bool up_inflight = false;      // upload_all left copies from the pinned buffers in flight on `stream`
   double* state_pin = nullptr; size_t state_pin_cap = 0;     // pinned staging of upload_state / download_state
+  bool pin_holds_est = false;                                // state_pin holds the device estimate as it is now (enqueue_state_download)
   std::unordered_map<std::string, double> up_laps;         // PPS_UPLOAD_TIMING=1: seconds per phase of upload_all, summed; printed at destroy
   struct UpPatch { size_t off, len; bool exact8 = false; };   // exact8: 8-byte granularity, nothing around the piece may be written
   std::vector<UpPatch> up_patches;
@@ -204,6 +205,8 @@ void j_bases(const pps_graph* g, int64_t base[4], int64_t* total);
 int run_analysis(pps_graph* g);
 int state_pin_reserve(pps_graph* g, size_t doubles);
 int download_state(pps_graph* g);
+int enqueue_state_download(pps_graph* g);      // ... before the synchronisation a solve ends with,
+void state_download_arrived(pps_graph* g);     // ... and this after it
 int upload_state(pps_graph* g, bool sync = true);
 int download_measurements(pps_graph* g);
 int upload_measurements(pps_graph* g);

@@ -150,7 +150,11 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
 constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
 
 // One workgroup per front: row i of its (b+1)-row packed update matrix goes to row cmap[i] of the parent.
-__global__ __launch_bounds__(64) void k_expand_ea(DevGraph d) {
+// The launch also clears what an upload needs cleared -- the zeroed block behind delta (tickets, result records, partial sums) and
+// blk_dst (0xff: "no element") for k_expand_el, which follows on the same stream -- instead of one fill kernel each.
+__global__ __launch_bounds__(64) void k_expand_ea(DevGraph d, double* __restrict__ zero, int n_zero, int* __restrict__ ones, int n_ones) {
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < n_zero; i += gridDim.x * 64) zero[i] = 0.0;
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < n_ones; i += gridDim.x * 64) ones[i] = -1;
   const int s = blockIdx.x;
   const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
   const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
@@ -192,9 +196,9 @@ hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, hipStream_t st) {
+hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_t n_zero, int* ones, size_t n_ones, hipStream_t st) {
   if (n_fronts <= 0) return hipSuccess;
-  PPS_LAUNCH(k_expand_ea, dim3(n_fronts), dim3(64), 0, st, d);
+  PPS_LAUNCH(k_expand_ea, dim3(n_fronts), dim3(64), 0, st, d, zero, (int)n_zero, ones, (int)n_ones);
   return hipGetLastError();
 }
 

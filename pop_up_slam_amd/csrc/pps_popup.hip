@@ -27,6 +27,7 @@
 namespace pps {
 
 constexpr int kMaxPlanes = 64;
+constexpr int kPlaneBlock = 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * kMaxPlanes;   // floats: plane equations | ground segments | plane info
 constexpr int kMaxVerts = 512;
 constexpr size_t kInSegOff = 512, kInPolyOff = kInSegOff + sizeof(float) * 4 * kMaxPlanes, kInBytes = kInPolyOff + sizeof(float) * 2 * kMaxVerts;
 static_assert(sizeof(int) * (kMaxPlanes + 2) <= kInSegOff, "poly_off does not fit its part of the input block");
@@ -472,7 +473,7 @@ struct pps_popup {
   float last_T[16] = {0};          // pose of the last run
   int* d_pid = nullptr;
   bool want_depth = true, want_pid = true;   // optional per-pixel outputs (pps_popup_set_outputs)
-  float* d_planes = nullptr;   // (kMaxPlanes+1) x 4 plane equations, then kMaxPlanes x 6 world ground segments
+  float* d_planes = nullptr;   // (kMaxPlanes+1) x 4 plane equations, then kMaxPlanes x 6 world ground segments, kMaxPlanes x 2 plane info; d_count behind
   float* d_seg = nullptr;      // kMaxPlanes x 4
   float* d_polys = nullptr;    // 2*kMaxVerts
   int* d_off = nullptr;        // kMaxPlanes+2
@@ -483,7 +484,8 @@ struct pps_popup {
   int4* d_boxes = nullptr;            // kMaxPlanes
   unsigned int* d_count = nullptr;   // kept points per workgroup of the last run
   size_t count_cap = 0;
-  unsigned int* h_count = nullptr;   // pinned
+  unsigned int* h_count = nullptr;   // pinned (behind h_planes)
+  float* h_planes = nullptr;         // pinned mirror of d_planes as the last run left it: [plane equations | ground segments | plane info]
   int last_n = 0;
   double last_kernel_s = 0;
 };
@@ -531,7 +533,6 @@ int pps_popup_create(int device, int width, int height, const float invK[9], pps
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_cloud), npx * sizeof(pps_point));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_depth), npx * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_pid), npx * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * (4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * kMaxPlanes));
   // per-frame inputs in one block (one transfer per frame): [poly_off | seg2d | polygons]
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_in), kInBytes);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_in), kInBytes, hipHostMallocDefault);
@@ -541,11 +542,15 @@ int pps_popup_create(int device, int width, int height, const float invK[9], pps
     p->d_polys = reinterpret_cast<float*>(p->d_in + kInPolyOff);
   }
   p->count_cap = (size_t)((width + 255) / 256) * (size_t)((height + 1) / 2);      // workgroups of the finest launch geometry (2 rows each)
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_count), sizeof(unsigned int) * p->count_cap);
+  // small results in one block (one transfer per frame, arriving with the run's synchronisation): [plane equations | ground
+  // segments | plane info | kept points per workgroup]
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_planes), sizeof(float) * kPlaneBlock + sizeof(unsigned int) * p->count_cap);
+  if (e == hipSuccess) p->d_count = reinterpret_cast<unsigned int*>(p->d_planes + kPlaneBlock);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_iv), sizeof(unsigned int) * (size_t)height * (kMaxVerts + kMaxPlanes));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_row_cnt), sizeof(int) * (size_t)height * kMaxPlanes);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_boxes), sizeof(int4) * kMaxPlanes);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_count), sizeof(unsigned int) * p->count_cap, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_planes), sizeof(float) * kPlaneBlock + sizeof(unsigned int) * p->count_cap, hipHostMallocDefault);
+  if (e == hipSuccess) p->h_count = reinterpret_cast<unsigned int*>(p->h_planes + kPlaneBlock);
   if (e != hipSuccess) { pps_popup_destroy(p); return PPS_EHIP; }
   *out = p;
   return PPS_OK;
@@ -556,9 +561,9 @@ int pps_popup_destroy(pps_popup* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   (void)hipFree(p->d_bgr); (void)hipFree(p->d_cloud); (void)hipFree(p->d_depth); (void)hipFree(p->d_depth_fill); (void)hipFree(p->d_pid);
-  (void)hipFree(p->d_planes); (void)hipFree(p->d_in); if (p->h_in) (void)hipHostFree(p->h_in); (void)hipFree(p->d_count);
+  (void)hipFree(p->d_planes); (void)hipFree(p->d_in); if (p->h_in) (void)hipHostFree(p->h_in);
   (void)hipFree(p->d_row_iv); (void)hipFree(p->d_row_cnt); (void)hipFree(p->d_boxes);
-  if (p->h_count) (void)hipHostFree(p->h_count);
+  if (p->h_planes) (void)hipHostFree(p->h_planes);
   if (p->ev[0]) (void)hipEventDestroy(p->ev[0]);
   if (p->ev[1]) (void)hipEventDestroy(p->ev[1]);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -624,7 +629,7 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   PHIP(p, hipGetLastError());
   PHIP(p, hipEventRecord(p->ev[1], p->stream));
   const size_t n_wg = (size_t)grid.x * grid.y;
-  PHIP(p, hipMemcpyAsync(p->h_count, p->d_count, sizeof(unsigned int) * n_wg, hipMemcpyDeviceToHost, p->stream));
+  PHIP(p, hipMemcpyAsync(p->h_planes, p->d_planes, sizeof(float) * kPlaneBlock + sizeof(unsigned int) * n_wg, hipMemcpyDeviceToHost, p->stream));
   PHIP(p, hipStreamSynchronize(p->stream));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, p->ev[0], p->ev[1]);
@@ -678,7 +683,7 @@ int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* dep
   if (!p) return PPS_EINVAL;
   PHIP(p, hipSetDevice(p->device));
   const size_t npx = (size_t)p->width * p->height;
-  if (planes) PHIP(p, hipMemcpy(planes, p->d_planes, sizeof(float) * 4 * (size_t)(p->last_n + 1), hipMemcpyDeviceToHost));
+  if (planes) memcpy(planes, p->h_planes, sizeof(float) * 4 * (size_t)(p->last_n + 1));     // (came back with the run)
   if (cloud) PHIP(p, hipMemcpy(cloud, p->d_cloud, npx * sizeof(pps_point), hipMemcpyDeviceToHost));
   if (depth && !p->want_depth) return pfail(p, PPS_ESTATE, "depth output is switched off (pps_popup_set_outputs)");
   if (plane_id && !p->want_pid) return pfail(p, PPS_ESTATE, "plane-id output is switched off (pps_popup_set_outputs)");
@@ -699,7 +704,7 @@ int pps_popup_plane_info(pps_popup* p, float plane_cam_dist_thre, const int* act
   PHIP(p, hipSetDevice(p->device));
   const int n = p->last_n;
   std::vector<float> info(2 * (size_t)(n > 0 ? n : 1));
-  if (n > 0) PHIP(p, hipMemcpy(info.data(), p->d_planes + 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost));
+  if (n > 0) memcpy(info.data(), p->h_planes + 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes, sizeof(float) * 2 * (size_t)n);
   if (dist_to_cam) dist_to_cam[0] = p->last_T[11];                 // the ground: camera height (transToWolrd(2,3), :617)
   if (good) good[0] = 1;                                           // "always push ground plane" (:620)
   for (int sgi = 0; sgi < n; sgi++) {
@@ -719,7 +724,7 @@ int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world) {
   if (!p || !seg3d_world) return PPS_EINVAL;
   PHIP(p, hipSetDevice(p->device));
   if (p->last_n > 0)
-    PHIP(p, hipMemcpy(seg3d_world, p->d_planes + 4 * (kMaxPlanes + 1), sizeof(float) * 6 * (size_t)p->last_n, hipMemcpyDeviceToHost));
+    memcpy(seg3d_world, p->h_planes + 4 * (kMaxPlanes + 1), sizeof(float) * 6 * (size_t)p->last_n);
   return PPS_OK;
 }
 

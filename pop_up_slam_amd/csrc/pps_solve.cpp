@@ -215,6 +215,7 @@ int pps_update(pps_graph* g) {
   rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:119)
   rc = do_solve(g, 0.0); if (rc != PPS_OK) return rc;             // compute_gauss_newton_step, lambda = 0 (:122)
   { PhaseTimer t(g, &g->stats.t_retract_chi2); HIP_TRY(g, launch_retract_apply(g->dev, g->stream)); }   // apply_exmap (:183)
+  rc = enqueue_state_download(g); if (rc != PPS_OK) return rc;   // (arrives with read_result's synchronisation)
   double chi2, dn; bool notpd;
   rc = read_result(g, true, &chi2, &dn, &notpd); if (rc != PPS_OK) return rc;
   resolve_k1_events(g);
@@ -226,6 +227,7 @@ int pps_update(pps_graph* g) {
     return fail(g, PPS_ENOTPD, "normal equations not positive definite");
   }
   g->dev_values_newer = true; g->lin_is_est = false;
+  state_download_arrived(g);
   g->status_clean = true;                                         // the chi2 kernel took the flag with it
   g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
   g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
@@ -359,8 +361,10 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   d.pose_est = d.pose_lin; d.plane_est = d.plane_lin;
   d.pose_lin = t_pose[0]; d.plane_lin = t_plane[0];
   g->spec_pose = t_pose[1]; g->spec_plane = t_plane[1];
+  { const int rc2 = enqueue_state_download(g); if (rc2 != PPS_OK) return rc2; }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->dev_values_newer = true; g->lin_is_est = false;
+  state_download_arrived(g);
   g->status_clean = true;                // every dual solve was followed by both chi2 kernels
   resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;
@@ -443,8 +447,10 @@ static int lm_solve(pps_graph* g, int* iterations) {
   }
   if (trial_pending) swap_state(g);                               // undo the pending step
   swap_state(g);                                                  // linpoint_to_estimate (:466)
+  { const int rc2 = enqueue_state_download(g); if (rc2 != PPS_OK) return rc2; }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->dev_values_newer = true; g->lin_is_est = false;
+  state_download_arrived(g);
   g->status_clean = true;                                         // every solve was followed by its chi2 kernel
   resolve_k1_events(g);
   g->stats.lm_iterations = num_iter;

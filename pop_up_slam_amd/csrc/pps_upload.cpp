@@ -39,7 +39,7 @@ void release_arenas(pps_graph* g) {
   g->stage = nullptr; g->stage_cap = 0;
   if (g->patch_host) (void)hipHostFree(g->patch_host);
   if (g->state_pin) (void)hipHostFree(g->state_pin);
-  g->state_pin = nullptr; g->state_pin_cap = 0;
+  g->state_pin = nullptr; g->state_pin_cap = 0; g->pin_holds_est = false;
   if (g->patch_dev) (void)hipFree(g->patch_dev);
   g->patch_host = g->patch_dev = nullptr; g->patch_cap = g->patch_dev_cap = 0;
   g->up_slots.clear(); g->up_high = 0; g->up_unknown = true;
@@ -363,7 +363,7 @@ int state_pin_reserve(pps_graph* g, size_t doubles) {
   if (doubles <= g->state_pin_cap) return PPS_OK;
   if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }
   if (g->state_pin) (void)hipHostFree(g->state_pin);
-  g->state_pin = nullptr; g->state_pin_cap = 0;
+  g->state_pin = nullptr; g->state_pin_cap = 0; g->pin_holds_est = false;
   const size_t cap = std::max<size_t>(4096, 2 * doubles);
   HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->state_pin), cap * sizeof(double), hipHostMallocDefault));
   g->state_pin_cap = cap;
@@ -371,16 +371,33 @@ int state_pin_reserve(pps_graph* g, size_t doubles) {
 }
 
 // pull the device estimate back into the host node table
+// The solves end with this: the estimate travels to the pinned buffer behind their last kernels and arrives with the
+// synchronisation they end with anyway -- whoever reads a value next (a frame loop does, every frame) finds it on the host
+// instead of paying a copy and a synchronisation of its own.  Call before that synchronisation, state_download_arrived() after it.
+int enqueue_state_download(pps_graph* g) {
+  const DevGraph& d = g->dev;
+  const size_t np = (size_t)7 * d.pose_ld, nl = (size_t)4 * d.plane_ld;
+  g->pin_holds_est = false;
+  int rc = state_pin_reserve(g, np + nl);
+  if (rc != PPS_OK) return rc;
+  HIP_TRY(g, hipMemcpyAsync(g->state_pin, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToHost, g->stream));   // [poses | planes], one block
+  return PPS_OK;
+}
+void state_download_arrived(pps_graph* g) { g->pin_holds_est = true; }
+
 int download_state(pps_graph* g) {
   if (!g->dev_values_newer) return PPS_OK;
   HIP_TRY(g, hipSetDevice(g->props.device));
   const DevGraph& d = g->dev;
   const size_t np = (size_t)7 * d.pose_ld, nl = (size_t)4 * d.plane_ld;
-  int rc = state_pin_reserve(g, np + nl);
-  if (rc != PPS_OK) return rc;
+  if (!g->pin_holds_est) {
+    int rc = state_pin_reserve(g, np + nl);
+    if (rc != PPS_OK) return rc;
+    HIP_TRY(g, hipMemcpyAsync(g->state_pin, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToHost, g->stream));   // [poses | planes], one block
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+  }
+  g->pin_holds_est = false;
   double* bp = g->state_pin; double* bl = g->state_pin + np;
-  HIP_TRY(g, hipMemcpyAsync(bp, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToHost, g->stream));   // [poses | planes], one block
-  HIP_TRY(g, hipStreamSynchronize(g->stream));
   for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) g->nodes[g->pose_ids[s]].v[k] = bp[(size_t)k * d.pose_ld + s];
   for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) g->nodes[g->plane_ids[s]].v[k] = bl[(size_t)k * d.plane_ld + s];
   g->dev_values_newer = false;
@@ -394,6 +411,7 @@ int upload_state(pps_graph* g, bool sync) {
   int rc = state_pin_reserve(g, np + nl);
   if (rc != PPS_OK) return rc;
   double* bp = g->state_pin; double* bl = g->state_pin + np;
+  g->pin_holds_est = false;
   for (int k = 0; k < 7; k++) for (int s = d.n_pose; s < d.pose_ld; s++) bp[(size_t)k * d.pose_ld + s] = 0.0;
   for (int k = 0; k < 4; k++) for (int s = d.n_plane; s < d.plane_ld; s++) bl[(size_t)k * d.plane_ld + s] = 0.0;
   for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) bp[(size_t)k * d.pose_ld + s] = g->nodes[g->pose_ids[s]].v[k];
@@ -490,6 +508,7 @@ int upload_all(pps_graph* g) {
   lap("3 analysis");
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
+  double* zero_block = nullptr; size_t zero_doubles = 0;
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
   d.no_strip = getenv("PPS_NO_STRIP") ? 1 : 0;
   d.pose_ld = std::max(1, (d.n_pose + 63) / 64 * 64); d.plane_ld = std::max(1, (d.n_plane + 63) / 64 * 64);
@@ -634,7 +653,7 @@ int upload_all(pps_graph* g) {
     const size_t n_dn = (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1;
     double* zb = nullptr;
     TRY(dev_alloc(g, &zb, n_dn + 2 + 8 + 2 * delta_doubles));
-    HIP_TRY(g, hipMemsetAsync(zb, 0, (n_dn + 2 + 8 + 2 * delta_doubles) * 8, g->stream));
+    zero_block = zb; zero_doubles = n_dn + 2 + 8 + 2 * delta_doubles;     // (cleared by k_expand_ea below, or by a memset when that launch has nothing to expand)
     d.delta = zb + n_dn + 10; g->spec_delta = d.delta + delta_doubles;
     d.dn_partials = zb;
     d.ticket = reinterpret_cast<unsigned int*>(zb + n_dn);
@@ -661,8 +680,16 @@ int upload_all(pps_graph* g) {
   rc = flush_uploads(g); if (rc != PPS_OK) return rc;
   rc = verify_uploads(g, "upload_all"); if (rc != PPS_OK) return rc;
   lap("6 flush");
-  if (A.ea_total > 0) HIP_TRY(g, launch_expand_ea(d, A.n_fronts, g->stream));
-  HIP_TRY(g, hipMemsetAsync(d.blk_dst, 0xff, sizeof(int) * (size_t)std::max(1, A.blk_doff[A.n_blocks]), g->stream));
+  {
+    const size_t n_dst = (size_t)std::max(1, A.blk_doff[A.n_blocks]);
+    if (A.ea_total > 0 && zero_doubles < (size_t)1 << 30 && n_dst < (size_t)1 << 30)
+      HIP_TRY(g, launch_expand_ea(d, A.n_fronts, zero_block, zero_doubles, d.blk_dst, n_dst, g->stream));
+    else {
+      if (A.ea_total > 0) HIP_TRY(g, launch_expand_ea(d, A.n_fronts, nullptr, 0, nullptr, 0, g->stream));
+      HIP_TRY(g, hipMemsetAsync(zero_block, 0, zero_doubles * 8, g->stream));
+      HIP_TRY(g, hipMemsetAsync(d.blk_dst, 0xff, sizeof(int) * n_dst, g->stream));
+    }
+  }
   HIP_TRY(g, launch_expand_el(d, (int)A.asm_blk.size(), g->stream));
   g->topo_dirty = false;
   g->meas_dirty = false;
