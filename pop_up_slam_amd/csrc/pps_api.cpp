@@ -278,8 +278,7 @@ int pps_restore_state(pps_graph* g) {
   if (g->host_values_newer) return fail(g, PPS_ESTATE, "host values were modified after the snapshot");
   const DevGraph& d = g->dev;
   HIP_TRY(g, hipMemcpyAsync(d.pose_est, g->snap_pose, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
-  g->lin_is_est = false;
-  g->dev_values_newer = true; g->lin_is_est = false; g->pin_holds_est = false;
+  g->dev_values_newer = true; g->pin_holds_est = false;
   return PPS_OK;
 }
 
@@ -320,6 +319,7 @@ int pps_eval_factor(pps_graph* g, int fid, int mode, double* J, double* r) {
   if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "eval_factor: unknown id");
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
+  rc = linpoint_from_estimate(g); if (rc != PPS_OK) return rc;
   HIP_TRY(g, launch_linearize(g->dev, mode, true, g->stream));
   const HostFactor& f = g->factors[fid];
   const int m = kFDim[f.type];
@@ -386,6 +386,7 @@ int pps_time_linearize(pps_graph* g, int mode, int iters, double* sec_per_launch
   if (!g || iters < 1 || !sec_per_launch) return PPS_EINVAL;
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
+  rc = linpoint_from_estimate(g); if (rc != PPS_OK) return rc;
   for (int k = 0; k < 3; k++) HIP_TRY(g, launch_linearize(g->dev, mode, false, g->stream));
   HIP_TRY(g, hipEventRecord(g->ev[0], g->stream));
   for (int k = 0; k < iters; k++) HIP_TRY(g, launch_linearize(g->dev, mode, false, g->stream));
@@ -402,6 +403,7 @@ int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double* sec
   if (!g || replicas < 1 || iters < 1 || !sec_per_sweep) return PPS_EINVAL;
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
+  rc = linpoint_from_estimate(g); if (rc != PPS_OK) return rc;
   if (g->dev.n_obs_fixed != g->dev.n_obs) return fail(g, PPS_ESTATE, "bench_sweep: graph holds re-popping plane edges (Factor2)");
   DevGraph d = g->dev;   // shallow copy with replicated edge arrays
   std::vector<void*> tmp;

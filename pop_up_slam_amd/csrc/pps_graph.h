@@ -118,7 +118,6 @@ struct pps_graph {
   size_t pk_n_obs = 0, pk_n_odo = 0, pk_ld_obs = 0, pk_ld_odo = 0;
   bool pk_meas_ok = false;
   bool status_clean = false;     // result_dev / spec_result are zero: upload_all zeroed them, or the last solve's chi2 kernels consumed the flags
-  bool lin_is_est = false;       // upload_state has just filled est AND lin: the estimate_to_linpoint copy of the next solve is a no-op
   bool up_inflight = false;      // upload_all left copies from the pinned buffers in flight on `stream`
   double* state_pin = nullptr; size_t state_pin_cap = 0;     // pinned staging of upload_state / download_state
   bool pin_holds_est = false;                                // state_pin holds the device estimate as it is now (enqueue_state_download)
@@ -204,6 +203,7 @@ int64_t j_capacity(int64_t n);
 void j_bases(const pps_graph* g, int64_t base[4], int64_t* total);
 int run_analysis(pps_graph* g);
 int state_pin_reserve(pps_graph* g, size_t doubles);
+int linpoint_from_estimate(pps_graph* g);
 int download_state(pps_graph* g);
 int enqueue_state_download(pps_graph* g);      // ... before the synchronisation a solve ends with,
 void state_download_arrived(pps_graph* g);     // ... and this after it

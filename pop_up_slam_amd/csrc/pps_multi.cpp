@@ -367,7 +367,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       g->dev.pose_est = sp[fin]; g->dev.plane_est = sl[fin];
       g->dev.pose_lin = sp[(fin + 1) % 3]; g->dev.plane_lin = sl[(fin + 1) % 3];
       g->spec_pose = sp[(fin + 2) % 3]; g->spec_plane = sl[(fin + 2) % 3];
-      g->dev_values_newer = true; g->lin_is_est = false; g->pin_holds_est = false;
+      g->dev_values_newer = true; g->pin_holds_est = false;
       g->stats.lm_iterations = q.num_iter; g->stats.chi2_final = q.error; g->stats.lambda_final = q.lambda; g->stats.last_delta_norm = q.dnorm;
       g->stats.lm_trials_notpd = q.n_notpd; g->stats.t_total = m->t_total;
       if (iterations) iterations[i] = q.num_iter;

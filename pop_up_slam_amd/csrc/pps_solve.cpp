@@ -136,12 +136,20 @@ void swap_state(pps_graph* g) {
   std::swap(g->dev.plane_est, g->dev.plane_lin);
 }
 
+// est_to_lin (estimate_to_linpoint): every caller goes on to overwrite the whole estimate -- a Gauss-Newton step retracts into it,
+// an LM solve uses it as the target of its first trial -- before anything reads it, and puts it back from lin when the step
+// fails: the two copies trade places by pointer, no data moves.  lin -> est (that putting back) is a real copy.
 int copy_state(pps_graph* g, bool est_to_lin) {
   const DevGraph& d = g->dev;
-  double *ps = est_to_lin ? d.pose_est : d.pose_lin, *pd = est_to_lin ? d.pose_lin : d.pose_est;
-  if (est_to_lin && g->lin_is_est) { g->lin_is_est = false; return PPS_OK; }       // upload_state has just written both copies
-  g->lin_is_est = false;
-  HIP_TRY(g, hipMemcpyAsync(pd, ps, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
+  if (est_to_lin) { swap_state(g); return PPS_OK; }
+  HIP_TRY(g, hipMemcpyAsync(d.pose_est, d.pose_lin, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
+  return PPS_OK;
+}
+
+// est -> lin as data (the diagnostic entry points that linearise outside a solve and leave the estimate in place)
+int linpoint_from_estimate(pps_graph* g) {
+  const DevGraph& d = g->dev;
+  HIP_TRY(g, hipMemcpyAsync(d.pose_lin, d.pose_est, ((size_t)7 * d.pose_ld + (size_t)4 * d.plane_ld) * 8, hipMemcpyDeviceToDevice, g->stream));
   return PPS_OK;
 }
 
@@ -226,7 +234,7 @@ int pps_update(pps_graph* g) {
     g->stats.t_total = now_s() - t0; g->stats.n_launches = (int)(launch_count() - g->launches0);
     return fail(g, PPS_ENOTPD, "normal equations not positive definite");
   }
-  g->dev_values_newer = true; g->lin_is_est = false;
+  g->dev_values_newer = true;
   state_download_arrived(g);
   g->status_clean = true;                                         // the chi2 kernel took the flag with it
   g->stats.chi2_final = chi2; g->stats.last_delta_norm = dn; g->stats.lambda_final = 0;
@@ -269,9 +277,9 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   double* slot0 = g->host_result;                                   // chi2 at the linearisation point
   double* slot[2] = {g->host_result + 4, g->host_result + 8};       // trial for lambda / for lambda * factor
   DevGraph& d = g->dev;
+  int rc = copy_state(g, true); if (rc != PPS_OK) return rc;       // estimate_to_linpoint (Optimizer.cpp:376): est is dead from here on
   // three state copies: x = the linearisation point (d.pose_lin), t[0] / t[1] = x (+) delta for the two damping values
   double *t_pose[2] = {d.pose_est, g->spec_pose}, *t_plane[2] = {d.plane_est, g->spec_plane};
-  int rc = copy_state(g, true); if (rc != PPS_OK) return rc;       // estimate_to_linpoint (Optimizer.cpp:376): est is dead from here on
   double seqs[2] = {0, 0};
   auto enqueue_dual = [&](double lam) -> int {
     DualAlt alt{g->spec_L, g->spec_U, g->spec_delta, g->spec_result, g->spec_chi2_partials, g->spec_dn_partials, g->spec_ticket,
@@ -363,7 +371,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   g->spec_pose = t_pose[1]; g->spec_plane = t_plane[1];
   { const int rc2 = enqueue_state_download(g); if (rc2 != PPS_OK) return rc2; }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
-  g->dev_values_newer = true; g->lin_is_est = false;
+  g->dev_values_newer = true;
   state_download_arrived(g);
   g->status_clean = true;                // every dual solve was followed by both chi2 kernels
   resolve_k1_events(g);
@@ -449,7 +457,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
   swap_state(g);                                                  // linpoint_to_estimate (:466)
   { const int rc2 = enqueue_state_download(g); if (rc2 != PPS_OK) return rc2; }
   HIP_TRY(g, hipStreamSynchronize(g->stream));
-  g->dev_values_newer = true; g->lin_is_est = false;
+  g->dev_values_newer = true;
   state_download_arrived(g);
   g->status_clean = true;                                         // every solve was followed by its chi2 kernel
   resolve_k1_events(g);

@@ -417,8 +417,7 @@ int upload_state(pps_graph* g, bool sync) {
   for (int s = 0; s < d.n_pose; s++) for (int k = 0; k < 7; k++) bp[(size_t)k * d.pose_ld + s] = g->nodes[g->pose_ids[s]].v[k];
   for (int s = 0; s < d.n_plane; s++) for (int k = 0; k < 4; k++) bl[(size_t)k * d.plane_ld + s] = g->nodes[g->plane_ids[s]].v[k];
   HIP_TRY(g, hipMemcpyAsync(d.pose_est, bp, (np + nl) * 8, hipMemcpyHostToDevice, g->stream));
-  HIP_TRY(g, hipMemcpyAsync(d.pose_lin, d.pose_est, (np + nl) * 8, hipMemcpyDeviceToDevice, g->stream));
-  g->lin_is_est = true;
+  // (the linearisation point is set by whoever linearises next: copy_state / linpoint_from_estimate)
   if (sync) HIP_TRY(g, hipStreamSynchronize(g->stream));
   else g->up_inflight = true;
   g->host_values_newer = false;
