@@ -1,0 +1,71 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): tools/evidence_run.sh [TAG]
+# Collects everything profiles/ holds for a round into gpurun_out/TAG/: the bench line, the rocprofv3 kernel summaries of the bench
+# command, of the C2 timeline and of the frame loop, and the PMC passes (K1 sweep traffic; instruction mix / occupancy of the
+# pps_multi kernels in both of their forms).  PMC passes run on their own, with --kernel-trace only.
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+ROOT=$(pwd); tag=${1:-r3}; out=$ROOT/gpurun_out/$tag; raw=/tmp/evidence_$tag; mkdir -p $out $raw   # (raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
+export TMPDIR=/tmp
+cd /tmp
+# 1. the bench line, then the same command under the kernel trace
+( cd $ROOT && timeout 900 python bench.py > $out/bench.json 2> $out/bench.err ); echo "bench rc $?"
+timeout 900 rocprofv3 --kernel-trace --stats -d $raw/kt_bench -o t -- python $ROOT/bench.py --steps 10 --warmup 2 > $out/kt_bench.log 2>&1
+python $ROOT/tools/rocprof_summary.py $(ls $raw/kt_bench/*.db $raw/kt_bench/*/*.db 2>/dev/null | head -1) $out/kernel_stats_bench.txt > /dev/null
+# 2. C2 timeline (csv) of one LM solve
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $raw/tl_c2 -- python $ROOT/tools/timeline_c2.py run > $out/tl_c2.log 2>&1
+python $ROOT/tools/timeline_c2.py show $raw/tl_c2 > $out/timeline_c2.txt 2>&1
+# 3. the frame loop (Python host loop) under the kernel trace + memory-copy trace
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $raw/kt_c5 -o t -- python $ROOT/tools/c5_bench.py 1000 > $out/kt_c5.log 2>&1
+python $ROOT/tools/rocprof_summary.py $(ls $raw/kt_c5/*.db $raw/kt_c5/*/*.db 2>/dev/null | head -1) $out/c5_kernel_stats.txt > /dev/null
+python - $out $raw <<'PY'
+import sqlite3, sys, glob, os
+out, raw = sys.argv[1], sys.argv[2]
+db = sqlite3.connect(sorted(glob.glob(os.path.join(raw, "kt_c5", "**", "*.db"), recursive=True))[0])
+n = 1000
+with open(os.path.join(out, "c5_kernel_stats.txt"), "a") as f:
+    f.write("\n# per frame (1000 frames): dispatches and device time\n")
+    for name, c, tot in db.execute("select name, count(*), sum(end-start) from kernels group by name order by 3 desc"):
+        f.write("%-70s %7.2f launches/frame %8.1f us/frame\n" % (name[:70], c / n, tot / 1e3 / n))
+    tot = db.execute("select count(*), sum(end-start) from kernels").fetchone()
+    f.write("%-70s %7.2f launches/frame %8.1f us/frame\n" % ("all kernels", tot[0] / n, tot[1] / 1e3 / n))
+    cf = db.execute("select count(*) from kernels where name like '%copyBuffer%' or name like '%fillBuffer%'").fetchone()[0]
+    f.write("copyBuffer + fillBuffer kernels per frame: %.2f\n" % (cf / n))
+    for name, c, tot, sz in db.execute("select name, count(*), sum(end-start), avg(size) from memory_copies group by name"):
+        f.write("memory copy %-28s %7.2f per frame %8.1f us/frame  mean %.0f B\n" % (name, c / n, tot / 1e3 / n, sz or 0))
+PY
+# 4. PMC: HBM traffic of the batched K1 sweep (FETCH_SIZE / WRITE_SIZE passes + calibration)
+( cd $ROOT && timeout 900 python tools/pmc_k1_sweep.py $raw/pmc_k1 > $out/pmc_k1.log 2>&1 ); cp $raw/pmc_k1/pmc_k1_sweep.json $out/pmc_k1_sweep.json 2>/dev/null
+# 5. PMC: the pps_multi kernels, band form (G = 32 stays below the level-form threshold) against the level-per-launch form
+for form in band levels; do
+  for pass in "SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU"; do
+    d=$raw/pmc_multi_${form}_$(echo $pass | tr ' ' '_')
+    if [ $form = levels ]; then export PPS_MULTI_LEVELS=1; else unset PPS_MULTI_LEVELS; fi
+    timeout 300 rocprofv3 --pmc $pass --kernel-trace -d $d -o t -- python $ROOT/tools/ab_bench.py multi 32 1 > $d.log 2>&1
+  done
+done
+unset PPS_MULTI_LEVELS
+python - $out $raw <<'PY'
+import sqlite3, sys, glob, os, collections
+out, raw = sys.argv[1], sys.argv[2]
+rows = collections.defaultdict(dict)
+for form in ("band", "levels"):
+    for d in sorted(glob.glob(os.path.join(raw, "pmc_multi_%s_*" % form))):
+        if not os.path.isdir(d): continue
+        for path in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+            db = sqlite3.connect(path)
+            for name, c, v, n, dur in db.execute("select kernel_name, counter_name, avg(value), count(*), avg(duration) from counters_collection group by kernel_name, counter_name"):
+                if "rocclr" in name or not name.startswith(("pps::kb_", "void pps::kb_")): continue
+                k = name.split("(")[0].replace("void ", "").replace("pps::", "")
+                rows[(form, k)][c] = v; rows[(form, k)]["dispatches"] = n; rows[(form, k)]["duration_us"] = dur / 1e3
+with open(os.path.join(out, "pmc_multi_kernels.txt"), "w") as f:
+    f.write("# rocprofv3 --pmc <two counters per pass> --kernel-trace -- python tools/ab_bench.py multi 32 1   (MI355X; 32 C2-size graphs, one\n"
+            "# pps_multi solve + the profiling solve; means per dispatch).  form = band: groups of sub-trees, one workgroup per group, levels\n"
+            "# behind workgroup barriers (what a chunk below 200 000 factors runs); form = levels (PPS_MULTI_LEVELS=1): one launch per tree\n"
+            "# level and tile count, one wave per front, 5 / 3 / 2 waves per SIMD (what G = 128 runs).\n"
+            "# waves/CU-busy = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / 4 (mean resident waves per SIMD while the kernel runs)\n")
+    cs = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU"]
+    f.write("%-7s %-26s %6s %9s " % ("form", "kernel", "disp", "dur_us") + " ".join("%15s" % c for c in cs) + "\n")
+    for (form, k), r in sorted(rows.items()):
+        f.write("%-7s %-26s %6d %9.1f " % (form, k[:26], r.get("dispatches", 0), r.get("duration_us", 0)) + " ".join("%15.0f" % r.get(c, float("nan")) for c in cs) + "\n")
+PY
+ls $out | tr '\n' ' '
