@@ -538,18 +538,21 @@ __device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, 
   const int mr = STRIP ? fa : f;
   (void)s;
   // ---- packed triangle -> register tiles ----
+  // One address per (tile row, register): row base + lane column, the tile columns are immediate offsets of the LDS reads.  Entries
+  // that do not exist are NOT zeroed: above the diagonal of a diagonal tile the read lands in the next rows of the triangle, a row
+  // past the front reads row 0 -- finite values in entries that stay dead (an MFMA update of entry (i, j) reads row i and column j
+  // only; nothing stores or extracts a dead row or a column right of the diagonal), and 3 selects + an address clamp per element
+  // less in front of the first panel.
   double4_t c[NT * (NT + 1) / 2];
 #pragma unroll
   for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-    for (int tj = 0; tj <= ti; tj++)
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * ti + lq + 4 * r;
+      const double* __restrict__ Fr = F + (tri24(row < mr ? row : 0) + l16);
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = 16 * ti + lq + 4 * r, col = 16 * tj + l16;
-        const bool ok = row < mr && col <= row;
-        const double x = F[ok ? tri24(row) + col : 0];
-        c[tile_id(ti, tj)][r] = ok ? x : 0.0;
-      }
+      for (int tj = 0; tj <= ti; tj++) c[tile_id(ti, tj)][r] = Fr[16 * tj];
+    }
   double y = 0.0;                                              // (lane f: the rhs . rhs corner, which nothing reads)
   if (!STRIP) { const double t = F[lane <= f ? tri24(f) + lane : 0]; y = lane < f ? t : 0.0; }
   __builtin_amdgcn_wave_barrier();
