@@ -18,6 +18,7 @@ struct pps_multi {
   int device = 0;
   std::string err;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // chunks alternate between the two streams: one chunk's narrow tree levels run under the other's wide ones
   DevGraph* d_gs = nullptr; size_t cap_gs = 0;
   BatchStage* d_stage = nullptr; size_t cap_stage = 0;
   BatchAlt* d_alt = nullptr; size_t cap_alt = 0;          // dual-lambda form: second factorisation + the three state copies per graph
@@ -51,6 +52,7 @@ int pps_multi_create(int n, pps_graph* const* graphs, pps_multi** out) {
 
 int pps_multi_destroy(pps_multi* m) {
   if (!m) return PPS_EINVAL;
+  if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); m->stream2 = nullptr; }
   if (m->stream) {
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
@@ -74,6 +76,7 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
   const int rc = multi_optimize(m, iterations, status);
   if (rc != PPS_OK && rc != PPS_ENOTPD && rc != PPS_EINVAL && rc != PPS_ESTATE) {       // a HIP failure in the middle of the rounds: as a failed single solve
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->stream2) (void)hipStreamSynchronize(m->stream2);
     for (pps_graph* g : m->gs) abandon_device_copy(g);
   }
   return rc;
@@ -106,6 +109,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + " has no second factor set (not uploaded)");
   const bool dual = true;
   if (!m->stream) MHIP(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  if (!m->stream2) MHIP(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
   if (m->cap_results < (size_t)G) {
     if (m->results) (void)hipHostFree(m->results);
     m->results = nullptr; m->cap_results = 0;
@@ -128,7 +132,12 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   // ---- launch geometry per chunk of kBatchMax graphs ----
   int n_cu = 256;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
-  const int n_chunks = (G + kBatchMax - 1) / kBatchMax;
+  // More than 64 graphs are split into (at least) two chunks of equal size, launched on two streams: the launches of a chunk's upper
+  // tree levels hold a few hundred wavefronts each and leave most of the device to the other chunk's kernels.  (Event-timed
+  // profiling keeps one stream and whole chunks: the phases must not overlap.)
+  const bool two_streams = G > 64 && !m->profiling;
+  const int CH = two_streams ? std::min(kBatchMax, (G + 1) / 2) : kBatchMax;
+  const int n_chunks = (G + CH - 1) / CH;
   std::vector<BatchGeom> geom(n_chunks);
   const size_t lds_budget = 150 * 1024;
   for (int c = 0; c < n_chunks; c++) {
@@ -137,7 +146,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     int max_panel[32] = {0};
     for (int stg = 0; stg < 32; stg++) q.stage_reg_only[stg] = true;
     bool level_ok = true;
-    for (int i = c * kBatchMax; i < std::min(G, (c + 1) * kBatchMax); i++) {
+    for (int i = c * CH; i < std::min(G, (c + 1) * CH); i++) {
       const pps_graph* g = m->gs[i];
       const DevGraph& d = g->dev;
       const Analysis& A = g->an;
@@ -187,7 +196,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       // groups than the device has wave-slots, fewer waves per group keep every slot on a front (2 waves: 94 % instead of
       // 47 %); the groups of the upper stages stay wide, there the tree depth is the cost.
       long long total_groups = 0;
-      for (int i = c * kBatchMax; i < std::min(G, (c + 1) * kBatchMax); i++) {
+      for (int i = c * CH; i < std::min(G, (c + 1) * CH); i++) {
         const Analysis& A = m->gs[i]->an;
         if (stg < A.n_stages) total_groups += (dual ? 2 : 1) * (A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
       }
@@ -214,8 +223,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     for (int i = 0; i < G; i++) lm[i] = LMD{m->gs[i]->props.lm_lambda0, 0.0, 0.0, 0, 0, 0, false, true, true, true, false, false, 0};
     auto make_args = [&](int c) {
       BatchArgs a{};
-      a.gs = m->d_gs; a.stage_tab = m->d_stage; a.results = m->results; a.n_total = G; a.b0 = c * kBatchMax;
-      a.n = std::min(G, (c + 1) * kBatchMax) - a.b0; a.seq = m->seq;
+      a.gs = m->d_gs; a.stage_tab = m->d_stage; a.results = m->results; a.n_total = G; a.b0 = c * CH;
+      a.n = std::min(G, (c + 1) * CH) - a.b0; a.seq = m->seq;
       a.alt = m->d_alt; a.rstride = 12;
       for (int k = 0; k < a.n; k++) {
         const LMD& q = lm[a.b0 + k];
@@ -235,6 +244,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
           while (r[3] != m->seq) {
             if ((++spins & 0x3ff) == 0 && now_s() - tw > 2.0) {
               MHIP(m, hipStreamSynchronize(m->stream));
+              MHIP(m, hipStreamSynchronize(m->stream2));
               if (r[3] != m->seq) return mfail(m, PPS_EHIP, "result record of graph " + std::to_string(i) + " did not arrive");
             }
           }
@@ -256,18 +266,18 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       return m->evs[m->ev_used++];
     };
     // one round of one chunk: e0 | K1 | e1 | K2 (+ chi2 at x) | e2 | factor x 2 | e3 | solve x 2 | e4 | both trials | e5
-    auto run_round = [&](const BatchArgs& a, const BatchGeom& q, bool first, bool any_relin) -> int {
-      if (first) MHIP(m, launch_batch_begin_dual(a, q, m->stream));
+    auto run_round = [&](const BatchArgs& a, const BatchGeom& q, bool first, bool any_relin, hipStream_t st) -> int {
+      if (first) MHIP(m, launch_batch_begin_dual(a, q, st));
       mark();
-      if (any_relin) MHIP(m, launch_batch_linearize(a, q, q.lin_thread_form ? mode | 2 : mode, m->stream));
+      if (any_relin) MHIP(m, launch_batch_linearize(a, q, q.lin_thread_form ? mode | 2 : mode, st));
       mark();
-      if (any_relin) MHIP(m, launch_batch_hblocks(a, q, m->stream));
-      if (first) MHIP(m, launch_batch_chi2(a, q, 0, m->stream));
+      if (any_relin) MHIP(m, launch_batch_hblocks(a, q, st));
+      if (first) MHIP(m, launch_batch_chi2(a, q, 0, st));
       mark();
       hipEvent_t ef = next_event();
-      MHIP(m, launch_batch_solve(a, q, m->stream, ef));
+      MHIP(m, launch_batch_solve(a, q, st, ef));
       mark();
-      MHIP(m, launch_batch_trial_dual(a, q, m->stream));
+      MHIP(m, launch_batch_trial_dual(a, q, st));
       mark();
       return PPS_OK;
     };
@@ -312,7 +322,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     m->seq += 1.0; m->rounds = 0;
     for (int c = 0; c < n_chunks; c++) {
       const BatchArgs a = make_args(c);
-      int rc = run_round(a, geom[c], true, true); if (rc != PPS_OK) return rc;
+      int rc = run_round(a, geom[c], true, true, (c & 1) && n_chunks > 1 && !m->profiling ? m->stream2 : m->stream); if (rc != PPS_OK) return rc;
     }
     m->n_relin += G; m->n_solves += 2 * (long long)G;
     { int rc = wait_round(); if (rc != PPS_OK) return rc; }
@@ -335,7 +345,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         for (int k = 0; k < a.n; k++) { any = any || (a.flags[k] & BF_ACTIVE); any_relin = any_relin || (a.flags[k] & BF_RELIN); }
         if (!any) continue;
         for (int k = 0; k < a.n; k++) { m->n_solves += (a.flags[k] & BF_ACTIVE) ? 2 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
-        int rc = run_round(a, geom[c], false, any_relin); if (rc != PPS_OK) return rc;
+        int rc = run_round(a, geom[c], false, any_relin, (c & 1) && n_chunks > 1 && !m->profiling ? m->stream2 : m->stream); if (rc != PPS_OK) return rc;
       }
       { int rc = wait_round(); if (rc != PPS_OK) return rc; }
       m->rounds++;
@@ -348,6 +358,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       }
     }
     MHIP(m, hipStreamSynchronize(m->stream));
+    MHIP(m, hipStreamSynchronize(m->stream2));
     for (size_t k = 0; k + 6 <= m->ev_used; k += 6) {
       const hipEvent_t* e = &m->evs[k];
       for (int ph = 0; ph < 5; ph++) {
