@@ -360,7 +360,7 @@ def main():
             (sec_all, sec_pl, sec_od), npl, nod = g.bench_sweep(mcode, reps, 10)
             ent = {}
             kfmt = "k_sweep_bench_lanes<%d>" if mcode == 2 else "k_sweep_bench<" + str(mcode) + ",%d>"
-            for part, sec_k, nbytes, kname in (("plane_edges", sec_pl, npl * B_PLANE_EDGE, kfmt % 0),
+            for part, sec_k, nbytes, kname in (("plane_edges", sec_pl, npl * B_PLANE_EDGE, "k_sweep_bench_obs_numeric" if mcode == P.JAC_NUMERIC else kfmt % 0),
                                                ("odometry", sec_od, nod * B_ODO_EDGE, kfmt % 1)):
                 rec = pmc.get(f"{mname}_{part}")
                 traffic = None

@@ -68,9 +68,14 @@ def main():
                     part = "plane_edges" if m.group(1) == "0" else "odometry"
                 else:
                     m = re.search(r"k_sweep_bench<(\d), (\d)>", name)
-                    if not m or int(m.group(1)) != mode:
+                    if "k_sweep_bench_obs_numeric" in name:       # the numeric plane-edge launch has a kernel of its own (two waves per SIMD)
+                        if mode != 0:
+                            continue
+                        part = "plane_edges"
+                    elif not m or int(m.group(1)) != mode:
                         continue
-                    part = "plane_edges" if m.group(2) == "0" else "odometry"
+                    else:
+                        part = "plane_edges" if m.group(2) == "0" else "odometry"
                 key = f"{mname}_{part}"
                 acc.setdefault(key, {"kernel": name.split("(")[0]})
                 acc[key]["fetch_kib_raw" if c == "FETCH_SIZE" else "write_kib"] = v
