@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PPS_VERSION 300   /* round.minor: bump whenever a struct of this header changes layout (pps_stats grew in 200) */
+#define PPS_VERSION 301   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301) */
 
 typedef struct pps_graph pps_graph;
 

@@ -25,7 +25,7 @@ _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 
 
-PPS_VERSION = 300      # include/pps.h: the struct layouts mirrored below
+PPS_VERSION = 301      # include/pps.h: the struct layouts mirrored below
 
 
 class PpsProps(C.Structure):
