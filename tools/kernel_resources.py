@@ -22,7 +22,7 @@ SOLVER = {"pps_k1.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip", "pps_dense.hip
 def resources(src, extra):
     with tempfile.TemporaryDirectory() as td:
         bundle, elf = os.path.join(td, "k.bundle"), os.path.join(td, "k.elf")
-        fp = "-ffp-contract=fast" if os.path.basename(src) in SOLVER else "-ffp-contract=off"
+        fp = "-ffp-contract=fast-honor-pragmas" if os.path.basename(src) in SOLVER else "-ffp-contract=off"   # (the Makefile's SOLVER_FP)
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", fp, "--cuda-device-only", "-c", src, "-o", bundle] + extra
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         subprocess.check_call([LLVM + "/clang-offload-bundler", "--type=o", "--input=" + bundle, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
