@@ -341,9 +341,9 @@ def main():
                     "in_solve_event_pairs": {"launches": k1_launches, "avg_us": k1_pairs * 1e6},
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "note": "K1 of the C2 graph on the solver's stream: 400 back-to-back launches between two HIP events "
-                            "(rocprofv3 of this command reports 8.4-9.1 us for these launches and ~11.4 us for the launches "
-                            "inside the solves, where the state has just been rewritten: "
-                            "its mean over both kinds is ~10.8 us, profiles/r1_v8_kernel_stats_c2.txt; an event pair around "
+                            "(rocprofv3 of this command: profiles/r3_kernel_stats_bench.txt, k_linearize_lanes -- its mean also "
+                            "covers the launches of the other graph sizes the bench runs; inside a C2 solve, where the state has "
+                            "just been rewritten, a launch takes 10.6 us: profiles/r3_timeline_c2.txt; an event pair around "
                             "every single launch of one extra solve, in_solve_event_pairs, also measures the event handling "
                             "itself). One C2 "
                             "graph is 2.8 MB per sweep: cache-resident and latency bound, so HBM traffic is not meaningful "
