@@ -203,3 +203,47 @@ def test_handles_on_different_host_threads(built):
     assert not errs, errs
     for k in range(len(specs)):
         assert got[k][0] == want[k][0] and got[k][1] == want[k][1], (k, got[k], want[k])
+
+
+def test_estimate_read_back_with_the_solve_equals_a_download_of_its_own(built):
+    """Every solve sends the estimate to a pinned buffer behind its last kernels (round 3) and trades estimate and linearisation
+    point by pointer: what get_pose / get_plane then return must be what a separate download of the device state returns -- after
+    update(), after batch_optimize(), after a host edit in between, and after a solve that failed."""
+    spec = synth.small_world(24, 7, seed=3, obs_per_pose=5)
+    g, o, ng, fg, no, fo = _pair(spec)
+    ids = [int(i) for i in ng]
+    types = spec.node_type
+
+    def values():
+        return [g.get_pose(i) if t == synth.NODE_POSE else g.get_plane(i) for i, t in zip(ids, types)]
+
+    def fresh_values():
+        g.save_state(); g.restore_state()            # the device estimate rewritten from a device snapshot: the pinned copy is stale
+        return values()
+
+    for step in range(4):
+        if step % 2 == 0:
+            g.update(); o.update()
+        else:
+            g.batch_optimize(); o.batch_optimize()
+        a = values()
+        c = g.chi2()
+        b = fresh_values()
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        assert abs(g.chi2() - c) <= 1e-13 * max(c, 1e-300)
+        _same(g, o)
+        if step == 1:                                 # a host edit between two solves
+            p = next(i for i, t in zip(range(len(types)), types) if t == synth.NODE_POSE and i > 2)
+            v = g.get_pose(ids[p]); v[:3] += 0.01
+            g.set_pose(ids[p], v); o.set_pose(int(no[p]), v)
+    # a failed solve leaves estimate and read-back alone
+    extra = g.add_plane(np.array([0.0, 1.0, 0.0, -3.0]))
+    before = values()
+    with pytest.raises(P.PpsError):
+        g.update()
+    for x, y in zip(before, values()):
+        np.testing.assert_array_equal(x, y)
+    g.remove_node(extra)
+    g.update(); o.update()
+    _same(g, o)
