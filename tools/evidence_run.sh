@@ -68,4 +68,29 @@ with open(os.path.join(out, "pmc_multi_kernels.txt"), "w") as f:
     for (form, k), r in sorted(rows.items()):
         f.write("%-7s %-26s %6d %9.1f " % (form, k[:26], r.get("dispatches", 0), r.get("duration_us", 0)) + " ".join("%15.0f" % r.get(c, float("nan")) for c in cs) + "\n")
 PY
+# 6. PMC: the single-graph kernels of a C2 LM solve (instruction mix per launch; two factorisations / trials per launch)
+for pass in "SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR"; do
+  d=$raw/pmc_c2_$(echo $pass | tr ' ' '_')
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace -d $d -o t -- python $ROOT/tools/timeline_c2.py run > $d.log 2>&1
+done
+python - $out $raw <<'PY'
+import sqlite3, sys, glob, os, collections
+out, raw = sys.argv[1], sys.argv[2]
+rows = collections.defaultdict(dict)
+for d in sorted(glob.glob(os.path.join(raw, "pmc_c2_*"))):
+    if not os.path.isdir(d): continue
+    for path in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+        db = sqlite3.connect(path)
+        for name, c, v, n, dur in db.execute("select kernel_name, counter_name, avg(value), count(*), avg(duration) from counters_collection group by kernel_name, counter_name"):
+            if "rocclr" in name or "pps::" not in name: continue
+            k = name.split("(")[0].replace("void ", "").replace("pps::", "")
+            rows[k][c] = v; rows[k]["dispatches"] = n; rows[k]["duration_us"] = dur / 1e3
+cs = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
+with open(os.path.join(out, "pmc_c2_kernels.txt"), "w") as f:
+    f.write("# rocprofv3 --pmc <two counters per pass> --kernel-trace -- python tools/timeline_c2.py run   (MI355X, C2 graph, two LM solves of 63\n"
+            "# iterations; means per dispatch; the K3 / K4 launches carry two factorisations / trials: 511 fronts x 2 in 3 band launches)\n")
+    f.write("%-28s %6s %9s " % ("kernel", "disp", "dur_us") + " ".join("%16s" % c.replace("SQ_", "") for c in cs) + "\n")
+    for k, r in sorted(rows.items(), key=lambda kv: -kv[1].get("duration_us", 0) * kv[1].get("dispatches", 0)):
+        f.write("%-28s %6d %9.1f " % (k[:28], r.get("dispatches", 0), r.get("duration_us", 0)) + " ".join("%16.0f" % r.get(c, float("nan")) for c in cs) + "\n")
+PY
 ls $out | tr '\n' ' '
