@@ -11,11 +11,10 @@
 
 #include "pps_kcommon.h"
 #include "pps_regtile.h"
+#include "pps_front_reg.h"
 
 namespace pps {
 
-// PPS_TRACE=1 instrumentation: lane 0 stamps s_memtime at phase boundaries of a front
-#define PPS_TR(k) do { if (d.trace && lane == 0) d.trace[(size_t)s * 8 + (k)] = clock64(); } while (0)
 
 // ------------------------------------------------------------------------------------------
 // K3: multifrontal partial Cholesky.  One 256-thread workgroup per front; the (f+1)x(f+1) front
@@ -205,15 +204,15 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_
 int band_front_limit() { return kBandMaxRows - 1; }
 int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
-size_t band_lds_bytes(int max_front, bool reg_only_kernel) {       // (the register-only kernels keep a 64-row panel buffer, the others 80 rows: strip)
-  const size_t fa = (size_t)max_front + 1;
-  const size_t n = fa * (fa + 1) / 2 + 1 + (reg_only_kernel ? kRegRows : kRegRowsMax) * kPStride;
+// LDS of one wave in the factor kernels.  Register-only kernels (every front of the stage <= 64 rows; the level kernels): the packed
+// triangle, whose first 64 x kP8Stride doubles double as the panel buffer once the tiles are loaded (the triangle is dead from then
+// on), and one spare double at the end (where masked-off items of a scatter-add land).  The other kernels (LDS strip, fifth tile
+// row, LDS-tile path): triangle | spare | panel buffer of 80 rows.
+size_t band_lds_bytes(int max_front, bool reg_only_kernel) {
+  const size_t fa = (size_t)max_front + 1, ntri = fa * (fa + 1) / 2;
+  const size_t n = reg_only_kernel ? std::max<size_t>(ntri, (size_t)kRegRows * kP8Stride) + 1 : ntri + 1 + (size_t)kRegRowsMax * kP8Stride;
   return ((n + 1) & ~size_t(1)) * sizeof(double);      // (an even number of doubles: every wave's triangle starts 16-byte aligned)
-}   // packed triangle + one spare double (where masked-off lanes of a scatter-add land: P[-1]) + panel buffer
-
-__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
-// the same for 0 <= i < 4096 with the full-rate 24-bit multiplier (per-lane index arithmetic of the register-tile code)
-__device__ __forceinline__ int tri24(int i) { return __mul24(i, i + 1) >> 1; }
+}
 
 // One row of 16x16 tiles (I, J = o, o+16, ..., I) of the trailing lower triangle gets its rank-nb
 // update C -= P_I P_J^T: all LDS reads are issued unconditionally from clamped (always valid)
@@ -408,8 +407,6 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // 4x4 diagonal block (broadcast with v_readlane, Cholesky-factored redundantly by every lane) ->
 // P feeds the MFMA operands.  Entries left of / above the current block are dead and may hold garbage.
 // ------------------------------------------------------------------------------------------
-template <int NT, bool TR, bool STRIP>
-__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P);
 // ---- assembly of a front's packed triangle in LDS, in pieces (one wave) ----
 // Eight scatter-add items per lane in flight: (target index, value) pairs of the front-ordered H, or of a child's packed update
 // matrix.  Issued as 16 independent coalesced loads, applied as LDS read-modify-writes (targets are unique inside one source).
@@ -503,7 +500,7 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
 // triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
 template <int NT, bool TR, bool STRIP = false>
 __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
-                                                      double* __restrict__ P) {
+                                                      double* __restrict__ P, int tr) {
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0);
   (void)s;
@@ -514,224 +511,13 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   front_pre_issue(d, rec, lane, pre);
   front_clear(rec, lane, F);
   if (TR) PPS_TR(1);
-  const int tr = (int)(P - F) - 1;                         // the spare double in front of the panel buffer
+  // tr: the spare double of the wave's LDS (band_lds_bytes), where the items of a scatter-add batch past its end land
   front_pre_finish(d, rec, lane, pre, 1.0 + lambda, F, tr);
   if (TR) PPS_TR(2);
   front_extend_add(d, rec, pre.crv, lane, F, tr);
   if (TR) PPS_TR(3);
   front_reg_eliminate<NT, TR, STRIP>(d, rec, F, P);
 }
-
-// Second half of a register-resident front: the assembled packed triangle in F -> register tiles -> panels -> factor panel and
-// update matrix in HBM.
-template <int NT, bool TR, bool STRIP>
-__device__ __forceinline__ void front_reg_eliminate(const DevGraph& d, int rec, double* __restrict__ F, double* __restrict__ P) {
-  const int lane = threadIdx.x & 63;
-  const int s = __builtin_amdgcn_readlane(rec, 0), p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
-  const int l16 = lane & 15, lq = lane >> 4;
-  const int f = p + b, fa = f + 1;
-  const bool strip = STRIP && fa > kRegRows;
-  constexpr bool R5 = NT == 5;                                 // rows 64 .. 79 are a fifth tile row in registers, not an LDS strip
-  // The right-hand side rides along as row f of the front.  Without a strip it is kept as a VECTOR (lane = column) next to
-  // the tiles instead of inside them: a front of 48 rows + rhs then needs three tile rows, not four (6 MFMA per panel instead of
-  // 10, 24 tile registers to load and store instead of 40) -- every separator front of a C2 tree.  mr = rows held in the tiles.
-  const int mr = STRIP ? fa : f;
-  (void)s;
-  // ---- packed triangle -> register tiles ----
-  // One address per (tile row, register): row base + lane column, the tile columns are immediate offsets of the LDS reads.  Entries
-  // that do not exist are NOT zeroed: above the diagonal of a diagonal tile the read lands in the next rows of the triangle, a row
-  // past the front reads row 0 -- finite values in entries that stay dead (an MFMA update of entry (i, j) reads row i and column j
-  // only; nothing stores or extracts a dead row or a column right of the diagonal), and 3 selects + an address clamp per element
-  // less in front of the first panel.
-  double4_t c[NT * (NT + 1) / 2];
-#pragma unroll
-  for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = 16 * ti + lq + 4 * r;
-      const double* __restrict__ Fr = F + (tri24(row < mr ? row : 0) + l16);
-#pragma unroll
-      for (int tj = 0; tj <= ti; tj++) c[tile_id(ti, tj)][r] = Fr[16 * tj];
-    }
-  double y = 0.0;                                              // (lane f: the rhs . rhs corner, which nothing reads)
-  if (!STRIP) { const double t = F[lane <= f ? tri24(f) + lane : 0]; y = lane < f ? t : 0.0; }
-  __builtin_amdgcn_wave_barrier();
-  double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
-  long long cyc_panel = 0, cyc_trail = 0;
-  bool bad = false;                                            // a pivot that is not positive: reported once, after the last panel
-  auto panel_step = [&](const int K) __attribute__((always_inline)) {
-    const long long tk0 = (TR && d.trace) ? clock64() : 0;
-    const int nb = p - K < 4 ? p - K : 4;
-    const int tjK = K >> 4, c0 = K & 15;
-    switch (tjK) {
-      case 0: reg_extract_panel<0, NT>(c, P, c0, lane); break;
-      case 1: reg_extract_panel<1, NT>(c, P, c0, lane); break;
-      case 2: if (NT > 2) reg_extract_panel<(NT > 2 ? 2 : 1), NT>(c, P, c0, lane); break;
-      default: if (NT > 3) reg_extract_panel<(NT > 3 ? 3 : NT - 1), NT>(c, P, c0, lane); break;
-    }
-    const int row2 = kRegRows + (lane & 15);                   // the strip row of this lane (lanes 0 .. 15)
-    const bool has2 = STRIP && strip && lane < 16 && row2 < fa;
-    if (has2 && !R5) {                                         // (with a fifth tile row the extraction above wrote these panel rows)
-#pragma unroll
-      for (int m = 0; m < 4; m++) P[row2 * kPStride + m] = F[tri(row2) + K + m];   // (K + m < 64 <= row2: inside the row)
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- panel: lane = row ----
-    double r0 = P[lane * kPStride + 0], r1 = P[lane * kPStride + 1], r2 = P[lane * kPStride + 2], r3 = P[lane * kPStride + 3];
-    const double d00 = readlane_d(r0, K);
-    const double d10 = readlane_d(r0, K + 1), d11 = readlane_d(r1, K + 1);
-    const double d20 = readlane_d(r0, K + 2), d21 = readlane_d(r1, K + 2), d22 = readlane_d(r2, K + 2);
-    const double d30 = readlane_d(r0, K + 3), d31 = readlane_d(r1, K + 3), d32 = readlane_d(r2, K + 3), d33 = readlane_d(r3, K + 3);
-    double i0 = 0, i1 = 0, i2 = 0, i3 = 0, l10 = 0, l20 = 0, l30 = 0, l21 = 0, l31 = 0, l32 = 0;
-    double x0, x1, x2, x3;
-    {
-#ifndef PPS_NO_FMA
-#pragma clang fp contract(fast)     // the serial pivot chain: a - b * c is one operation here
-#endif
-      // (the reciprocal square root is evaluated unconditionally -- NaN for a pivot that is not positive -- and selected away:
-      // a branch per pivot would split the serial chain into basic blocks; a panel narrower than four columns, the last one of a
-      // front, zeroes the factors of the columns it does not have the same way)
-      { const double q = rsqrt_nr(d00); bad |= !(d00 > 0.0); i0 = d00 > 0.0 ? q : 0.0; l10 = d10 * i0; l20 = d20 * i0; l30 = d30 * i0; }
-      { const double t = d11 - l10 * l10; const double q = rsqrt_nr(t); const bool on = nb > 1; bad |= on && !(t > 0.0); i1 = (on && t > 0.0) ? q : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
-      { const double t = d22 - l20 * l20 - l21 * l21; const double q = rsqrt_nr(t); const bool on = nb > 2; bad |= on && !(t > 0.0); i2 = (on && t > 0.0) ? q : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
-      { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; const double q = rsqrt_nr(t); const bool on = nb > 3; bad |= on && !(t > 0.0); i3 = (on && t > 0.0) ? q : 0.0; }
-      x0 = r0 * i0;
-      x1 = (r1 - x0 * l10) * i1;
-      x2 = (r2 - x0 * l20 - x1 * l21) * i2;
-      x3 = (r3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
-    }
-    P[lane * kPStride + 0] = x0; P[lane * kPStride + 1] = x1; P[lane * kPStride + 2] = x2; P[lane * kPStride + 3] = x3;
-    if (!STRIP) {
-      // the rhs row through the same triangular solve (its four panel entries sit in lanes K .. K+3 of y), then its rank-nb
-      // update: y_j -= sum_m L[f][K+m] L[j][K+m], lane j holding row j's panel entries x0 .. x3 already
-      const double q0 = readlane_d(y, K), q1 = readlane_d(y, K + 1), q2 = readlane_d(y, K + 2), q3 = readlane_d(y, K + 3);
-      double y0, y1, y2, y3;
-      {
-#ifndef PPS_NO_FMA
-#pragma clang fp contract(fast)
-#endif
-        y0 = q0 * i0;
-        y1 = (q1 - y0 * l10) * i1;
-        y2 = (q2 - y0 * l20 - y1 * l21) * i2;
-        y3 = (q3 - y0 * l30 - y1 * l31 - y2 * l32) * i3;
-        y = y - x0 * y0 - x1 * y1 - x2 * y2 - x3 * y3;
-      }
-      if (lane < nb) Lp[(unsigned)(__mul24(f, p) + K + lane)] = lane == 0 ? y0 : (lane == 1 ? y1 : (lane == 2 ? y2 : y3));
-    }
-    if (lane < mr) {
-      // rows above the diagonal get whatever their lanes computed: (row, col > row) of a factor panel is never read
-      // (wave_front_solve, k_front_solve), and one exec-masked block with uniform branches replaces four masked ones
-      double* __restrict__ lrow = Lp + (unsigned)(__mul24(lane, p) + K);
-      lrow[0] = x0;
-      if (nb > 1) lrow[1] = x1;
-      if (nb > 2) lrow[2] = x2;
-      if (nb > 3) lrow[3] = x3;
-    }
-    if (STRIP && strip) {
-      const double q0 = P[row2 * kPStride + 0], q1 = P[row2 * kPStride + 1], q2 = P[row2 * kPStride + 2], q3 = P[row2 * kPStride + 3];
-      double y0, y1, y2, y3;
-      {
-#ifndef PPS_NO_FMA
-#pragma clang fp contract(fast)
-#endif
-        y0 = q0 * i0;
-        y1 = (q1 - y0 * l10) * i1;
-        y2 = (q2 - y0 * l20 - y1 * l21) * i2;
-        y3 = (q3 - y0 * l30 - y1 * l31 - y2 * l32) * i3;
-      }
-      if (has2) {
-        P[row2 * kPStride + 0] = y0; P[row2 * kPStride + 1] = y1; P[row2 * kPStride + 2] = y2; P[row2 * kPStride + 3] = y3;
-        double* __restrict__ lrow = Lp + (size_t)row2 * p + K;
-        lrow[0] = y0;
-        if (nb > 1) lrow[1] = y1;
-        if (nb > 2) lrow[2] = y2;
-        if (nb > 3) lrow[3] = y3;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (STRIP && strip && !R5) {
-      // F[r][c] -= sum_k L[r][k] L[c][k] for the strip rows r and the live columns c >= K + nb: the strip is tile row 4 of the
-      // front; its five 16x16 tiles are loaded from the LDS triangle, updated with one MFMA each and written back (only the
-      // entries that exist: c <= r < fa).  Tile columns left of the panel are finished and skipped.
-      const int cmin = K + nb;
-      const bool kvalid = lq < nb;
-      const double a4r = P[(kRegRows + l16) * kPStride + lq];
-      const double a4 = kvalid ? -a4r : 0.0;
-#pragma unroll 1                                    // one tile at a time: eight registers next to the ten resident tiles
-      for (int tj = cmin >> 4; tj < 5; tj++) {
-        const double br = P[(16 * tj + l16) * kPStride + lq];
-        const double bj = kvalid ? br : 0.0;
-        const int col = 16 * tj + l16;
-        double4_t t;
-        bool ok[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = kRegRows + lq + 4 * r;
-          ok[r] = row < fa && col <= row && col >= cmin;
-          const double x = F[ok[r] ? tri(row) + col : 0];
-          t[r] = ok[r] ? x : 0.0;
-        }
-        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, bj, t, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = kRegRows + lq + 4 * r;
-          if (ok[r]) F[tri(row) + col] = t[r];
-        }
-      }
-    }
-    const long long tk1 = (TR && d.trace) ? clock64() : 0;
-    switch (tjK) {
-      case 0: reg_trailing<0, NT>(c, P, nb, lane, (K + 4) >> 4); break;
-      case 1: reg_trailing<1, NT>(c, P, nb, lane, (K + 4) >> 4); break;
-      case 2: if (NT > 2) reg_trailing<(NT > 2 ? 2 : 1), NT>(c, P, nb, lane, (K + 4) >> 4); break;
-      default: if (NT > 3) reg_trailing<(NT > 3 ? 3 : NT - 1), NT>(c, P, nb, lane, (K + 4) >> 4); break;
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (TR && d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
-  };
-  if constexpr (NT == 5) {
-    // (hipcc 7.2 miscompiles this loop with fifteen accumulator tiles once it peels the first panel: rows 8 and up of every later
-    // panel come out wrong, deterministically -- tests/test_gpu_fronts.py holds the case; without peeling the code is correct)
-#pragma clang loop unroll(disable)
-    for (int K = 0; K < p; K += 4) panel_step(K);
-  } else {
-    for (int K = 0; K < p; K += 4) panel_step(K);
-  }
-  if (bad && lane == 0) d.result_dev[2] = 1.0;             // not positive definite
-  if (TR) PPS_TR(4);
-  if (TR && d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
-  // ---- update matrix: live part of the tiles -> packed global ----
-  // Every store is issued by all lanes: an entry that does not exist (row >= fa, col > row, col < p) goes to the last double of
-  // the front's (b+1) x (b+1) slab, which the packed triangle never reaches -- no exec-masked block per store, the sixteen row
-  // bases are computed once, and whole tiles left of the pivots or below the front are skipped by wave-uniform branches.
-  double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
-  const unsigned trash_u = (unsigned)(__mul24(b + 1, b + 1) - 1);
-#pragma unroll
-  for (int ti = 0; ti < NT; ti++) {
-    if (16 * ti >= mr) continue;                             // (wave-uniform)
-    int rbase[4]; bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int row = 16 * ti + lq + 4 * r; rok[r] = row < mr; rbase[r] = tri24(row - p) - p; }
-#pragma unroll
-    for (int tj = 0; tj <= ti; tj++) {
-      if (16 * tj + 15 < p) continue;                        // (wave-uniform)
-      const int col = 16 * tj + l16;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = 16 * ti + lq + 4 * r;
-        const bool ok = rok[r] && col <= row && col >= p;
-        Us[ok ? (unsigned)(rbase[r] + col) : trash_u] = c[tile_id(ti, tj)][r];
-      }
-    }
-  }
-  if (STRIP && strip && !R5) {
-    for (int r = kRegRows; r < fa; r++)
-      for (int col = p + lane; col <= r; col += 64) Us[tri(r - p) + col - p] = F[tri(r) + col];
-  }
-  if (!STRIP) Us[(lane >= p && lane <= f) ? (unsigned)(tri24(b) + lane - p) : trash_u] = lane < f ? y : 0.0;      // the rhs row of the update matrix
-  if (TR) PPS_TR(5);
-}
-
 
 // lane K of every row of 16 lanes, broadcast to the row (DPP row_newbcast: two v_mov_b32_dpp, no SGPR hop, no LDS)
 template <int K> __device__ __forceinline__ double row_bcast_d(double v) {
@@ -922,13 +708,17 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      double* const Pn = F + lds_doubles_per_wave - ((REG_ONLY && !REG_STRIP) ? kRegRows : kRegRowsMax) * kPStride;
-      if (REG_ONLY && fa <= 33) wave_front_factor_reg<2, TR>(d, rec, lambda, F, Pn);                    // (without a strip the rhs row is a vector next to the tiles)
-      else if (REG_ONLY && fa <= 49) wave_front_factor_reg<3, TR>(d, rec, lambda, F, Pn);
-      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, TR>(d, rec, lambda, F, Pn);
-      else if (REG_ONLY && R5) wave_front_factor_reg<5, false, true>(d, rec, lambda, F, Pn);             // 65 .. 80 rows: fifteen register tiles
-      else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true, true>(d, rec, lambda, F, Pn);
-      else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn);
+      // register-only kernels: the panel buffer is the head of the (by then dead) triangle, the spare double the last one of the
+      // wave's LDS; the others keep the panel buffer (80 rows) behind triangle and spare double
+      constexpr bool ALIAS = REG_ONLY && !REG_STRIP;
+      double* const Pn = ALIAS ? F : F + lds_doubles_per_wave - kRegRowsMax * kP8Stride;
+      const int tr = ALIAS ? lds_doubles_per_wave - 1 : lds_doubles_per_wave - kRegRowsMax * kP8Stride - 1;
+      if (REG_ONLY && fa <= 33) wave_front_factor_reg<2, TR>(d, rec, lambda, F, Pn, tr);                    // (without a strip the rhs row is a vector next to the tiles)
+      else if (REG_ONLY && fa <= 49) wave_front_factor_reg<3, TR>(d, rec, lambda, F, Pn, tr);
+      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, TR>(d, rec, lambda, F, Pn, tr);
+      else if (REG_ONLY && R5) wave_front_factor_reg<5, false, true>(d, rec, lambda, F, Pn, tr);             // 65 .. 80 rows: fifteen register tiles
+      else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true, true>(d, rec, lambda, F, Pn, tr);
+      else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn, tr);
       else wave_front_factor(d, s, lambda, F);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
@@ -1100,15 +890,16 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
     if (k >= d.cls_off[3 * level + (NT - 2) + 1]) return;                                                           \
     const int rec = d.frec[(size_t)d.cls_fronts[k] * 16 + (threadIdx.x & 15)];                                      \
     double* F = lds + (size_t)wave * lds_doubles_per_wave;                                                           \
-    double* const Pn = F + lds_doubles_per_wave - kRegRows * kPStride;                                               \
+    double* const Pn = F;                     /* (panel buffer = head of the dead triangle: band_lds_bytes) */          \
+    const int tr = lds_doubles_per_wave - 1;                                                                         \
     if (blockIdx.z) {                                                                                                \
       const BatchAlt al = load_alt(a.alt + a.b0 + b);                                                                \
       DevGraph d2 = d;                                                                                               \
       d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;                                  \
-      wave_front_factor_reg<NT, false>(d2, rec, a.lambda2[b], F, Pn);                                                \
+      wave_front_factor_reg<NT, false>(d2, rec, a.lambda2[b], F, Pn, tr);                                             \
       return;                                                                                                        \
     }                                                                                                                \
-    wave_front_factor_reg<NT, false>(d, rec, a.lambda[b], F, Pn);                                                    \
+    wave_front_factor_reg<NT, false>(d, rec, a.lambda[b], F, Pn, tr);                                                 \
   }
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor2, 2, 5)
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, 3)
@@ -1193,7 +984,9 @@ __global__ __launch_bounds__(64) void k_debug_front(DevGraph d, int p, int b, co
   const int lane = threadIdx.x;
   const int fa = p + b + 1;
   double* F = lds;
-  double* P = F + per_wave - kRegRowsMax * kPStride;
+  // the layouts of the production kernels: without a strip the panel buffer is the head of the triangle (register-only and level
+  // kernels), with a strip / a fifth tile row it sits behind triangle and spare double (general and r5 kernels)
+  double* P = STRIP ? F + per_wave - kRegRowsMax * kP8Stride : F;
   for (int i = lane; i < fa * (fa + 1) / 2; i += 64) F[i] = A[i];
   __builtin_amdgcn_wave_barrier();
   int rec = 0;                                    // (L and U of the front start at offset 0)
@@ -1222,7 +1015,7 @@ int debug_front_factor(int tiles, int strip, int p, int b, const double* A_host,
   if (e == hipSuccess) e = hipMemset(res, 0, 32);
   if (e == hipSuccess) {
     DevGraph d{}; d.L = L; d.U = U; d.result_dev = res;
-    const int per_wave = (int)(band_lds_bytes(fa - 1, false) / 8);
+    const int per_wave = (int)(band_lds_bytes(fa - 1, !(tiles == 5 || wide)) / 8);
     const size_t bytes = (size_t)per_wave * 8;
 #define PPS_DBG_FRONT(NT_, STRIP_)                                                                                                      \
     do {                                                                                                                                \
@@ -1237,7 +1030,8 @@ int debug_front_factor(int tiles, int strip, int p, int b, const double* A_host,
 #undef PPS_DBG_FRONT
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(L_host, L, nL * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(U_host, U, nU * 8, hipMemcpyDeviceToHost);
+    // (the device slab is (b+1)^2 doubles -- its last one is the kernel's trash slot --, the caller's buffer the packed triangle)
+    if (e == hipSuccess) e = hipMemcpy(U_host, U, (size_t)(b + 1) * (b + 2) / 2 * 8, hipMemcpyDeviceToHost);
     double r4[4] = {0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(r4, res, 32, hipMemcpyDeviceToHost);
     if (not_pd) *not_pd = r4[2];

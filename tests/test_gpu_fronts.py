@@ -1,5 +1,7 @@
 """The register-tile elimination of one front (pps_debug_front_factor) against numpy's Cholesky: every tile count the band kernels
-use, fronts of one panel and of many, the LDS strip and the fifth tile row for fronts of 65 .. 80 rows.  The case that motivated the
+use, fronts of one panel and of many (8-column panels since round 4: every panel width 1 .. 8, panels that end a tile column or stop
+short of it), the LDS strip and the fifth tile row for fronts of 65 .. 80 rows.  tests/test_front_emu.py runs the same source on the
+CPU (wave emulation) for every pivot count.  The case that motivated the
 test: with fifteen accumulator tiles hipcc 7.2 miscompiled the panel loop once it peeled the first panel (rows 8 and up of every
 later panel wrong, a whole frame-loop stage not positive definite); no graph-level test isolates a single front."""
 import numpy as np
@@ -42,7 +44,8 @@ def _check(p, b, tiles, strip, seed=0):
         assert np.abs(Ut[b, :b] - r).max() <= 1e-11 * max(1.0, np.abs(r).max())
 
 
-@pytest.mark.parametrize("p,b", [(4, 8), (6, 8), (15, 16), (15, 33), (18, 30), (27, 36), (6, 57), (33, 30), (48, 15), (63, 0)])
+@pytest.mark.parametrize("p,b", [(4, 8), (6, 8), (15, 16), (15, 33), (18, 30), (27, 36), (6, 57), (33, 30), (48, 15), (63, 0),
+                                 (1, 2), (5, 3), (8, 8), (9, 20), (12, 0), (13, 0), (16, 10), (17, 30), (24, 24), (40, 23), (56, 7)])
 def test_fronts_up_to_64_rows(built, p, b):
     """the solver's own choice of tile rows, then every larger tile count that holds the front"""
     fa = p + b + 1
@@ -53,7 +56,7 @@ def test_fronts_up_to_64_rows(built, p, b):
     assert fa <= 64
 
 
-@pytest.mark.parametrize("p,b", [(4, 61), (6, 70), (8, 70), (21, 50), (27, 52), (24, 55), (48, 31)])
+@pytest.mark.parametrize("p,b", [(4, 61), (6, 70), (8, 70), (13, 60), (21, 50), (27, 52), (24, 55), (48, 31), (60, 19), (64, 15)])
 def test_fronts_of_65_to_80_rows_both_ways(built, p, b):
     """fifteen register tiles (what the band kernels run) and four tile rows + LDS strip: same factor, same update matrix"""
     _check(p, b, 5, False)
