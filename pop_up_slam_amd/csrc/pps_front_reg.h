@@ -28,7 +28,7 @@ __device__ __forceinline__ int tri24(int i) { return __mul24(i, i + 1) >> 1; }
 // P: the panel buffer, 16 NT rows of kP8Stride doubles (at least 80 rows with STRIP).  Without STRIP, and with NT = 5, F is dead
 // once the tiles are loaded, and P may be F itself.
 template <int NT, bool TR, bool STRIP, class G>
-__device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double* __restrict__ F, double* __restrict__ P) {
+__device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double* F, double* P) {      // (no __restrict__: P may be F)
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0), p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
   const int l16 = lane & 15, lq = lane >> 4;
@@ -52,7 +52,7 @@ __device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double*
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = 16 * ti + lq + 4 * r;
-      const double* __restrict__ Fr = F + (tri24(row < mr ? row : 0) + l16);
+      const double* Fr = F + (tri24(row < mr ? row : 0) + l16);
 #pragma unroll
       for (int tj = 0; tj <= ti; tj++) c[tile_id(ti, tj)][r] = Fr[16 * tj];
     }

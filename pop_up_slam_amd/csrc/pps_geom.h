@@ -30,11 +30,17 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 2.0 * kPi;
 constexpr double kNumDiffEps = 0.0001;  // isamlib/numericalDiff.cpp:34
 
-// isam/util.h:101-108
+// isam/util.h:101-108: fmod(t + pi, 2 pi) - pi for t >= 0, fmod(t - pi, -2 pi) + pi otherwise.
+// fmod is exact, and for an argument within one period of the range it is the argument itself or one exact subtraction
+// (Sterbenz): an angle difference (|t| <= 2 pi) never reaches the library call, whose remainder loop is ~60 instructions on
+// the GPU; the results are the reference's bit for bit either way.
 PPS_HD double standard_rad(double t) {
-  if (t >= 0.) t = fmod(t + kPi, kTwoPi) - kPi;
-  else         t = fmod(t - kPi, -kTwoPi) + kPi;
-  return t;
+  if (t >= 0.) {
+    const double x = t + kPi;
+    return (x < kTwoPi ? x : (x < 2.0 * kTwoPi ? x - kTwoPi : fmod(x, kTwoPi))) - kPi;
+  }
+  const double x = t - kPi;
+  return (x > -kTwoPi ? x : (x > -2.0 * kTwoPi ? x + kTwoPi : fmod(x, -kTwoPi))) + kPi;
 }
 
 // Eigen quaternion product a*b
@@ -156,6 +162,33 @@ PPS_HD void normalize4(double v[4]) {
   v[0] /= n; v[1] /= n; v[2] /= n; v[3] /= n;
 }
 
+// 1 / sqrt(x) to fp64 round-off.  On the device: the hardware estimate + two Newton steps in explicit fused multiply-adds (the
+// same bits wherever it is inlined) -- 9 vector instructions where sqrt + division are 27; on the host: 1 / sqrt.
+PPS_HD double rsqrt_acc(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const double t = x * y, hy = 0.5 * y;
+    const double e = __builtin_fma(-t, hy, 0.5);       // 0.5 - 0.5 x y^2
+    y = __builtin_fma(y, e, y);
+  }
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
+// v / |v| as v * (1 / |v|): what the hot loops use (the residual of a plane observation normalises the transformed plane in each of
+// the 19 evaluations of a numerical Jacobian; four divisions + a square root were 66 of ~310 vector instructions of one
+// evaluation, this is 13).  Eigen's Vector4d::normalize() is either form depending on its version (3.2: coefficient * inverse,
+// 3.3: coefficient / norm); the two differ by an ulp, far inside the parity tolerance (chi2 rel 1e-5, measured 1e-13).
+PPS_HD void normalize4_r(double v[4]) {
+  PPS_FP_EXACT
+  const double r = rsqrt_acc(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+  v[0] *= r; v[1] *= r; v[2] *= r; v[3] *= r;
+}
+
 // Pose3d::exmap  (isam/Pose3d.h:131-136): t += d[0:3] ; q <- q * Exp(d[3:6])
 PPS_HD void pose_exmap(const double p[7], const double d[6], double o[7]) {
   PPS_FP_EXACT
@@ -166,13 +199,49 @@ PPS_HD void pose_exmap(const double p[7], const double d[6], double o[7]) {
   o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
 }
 
+// Pose3d::exmap for the rotation steps of a numerical Jacobian: d = +-eps e_k (k = 0, 1, 2 of the rotation part).  Rot3d::exmap's
+// quaternion of such a step is (+-a e_k, c) with (a, 0, 0, c) = rot_exp((eps, 0, 0)) -- theta = sqrt(eps^2) = eps whichever
+// component carries it, S * 0 = 0 -- so the square root, the sine / cosine pair and the division are evaluated once per factor
+// (rot_step_quat) instead of once per step; the product is quat_mul itself: the same bits as pose_exmap(p, d, o).
+PPS_HD void rot_step_quat(double ac[2]) {
+  const double d1[3] = {kNumDiffEps, 0.0, 0.0};
+  double q[4];
+  rot_exp(d1, q);
+  ac[0] = q[0]; ac[1] = q[3];
+}
+PPS_HD void pose_exmap_rot_step(const double p[7], int k, bool minus, const double ac[2], double o[7]) {
+  PPS_FP_EXACT
+  const double a = minus ? -ac[0] : ac[0];
+  const double dq[4] = {k == 0 ? a : 0.0, k == 1 ? a : 0.0, k == 2 ? a : 0.0, ac[1]};
+  double q[4];
+  quat_mul(p + 3, dq, q);
+  o[0] = p[0] + 0.0; o[1] = p[1] + 0.0; o[2] = p[2] + 0.0;
+  o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+}
+
+// Plane3d::exmap_3dof for the steps d = +-eps e_k of a numerical Jacobian: the step quaternion is (+-a e_k, c) with
+// (a, 0, 0, c) = plane_exp((eps, 0, 0)), evaluated once per factor; the same bits as plane_exmap(pl, d, o).
+PPS_HD void plane_step_quat(double ac[2]) {
+  const double d1[3] = {kNumDiffEps, 0.0, 0.0};
+  double q[4];
+  plane_exp(d1, q);
+  ac[0] = q[0]; ac[1] = q[3];
+}
+PPS_HD void plane_exmap_step(const double pl[4], int k, bool minus, const double ac[2], double o[4]) {
+  PPS_FP_EXACT
+  const double a = minus ? -ac[0] : ac[0];
+  const double dq[4] = {k == 0 ? a : 0.0, k == 1 ? a : 0.0, k == 2 ? a : 0.0, ac[1]};
+  quat_mul(dq, pl, o);
+  normalize4_r(o);
+}
+
 // Plane3d::exmap_3dof  (src/isam_plane3d.h:101-127), plane_type == -1
 PPS_HD void plane_exmap(const double pl[4], const double d[3], double o[4]) {
   PPS_FP_EXACT
   double dq[4];
   plane_exp(d, dq);
   quat_mul(dq, pl, o);
-  normalize4(o);
+  normalize4_r(o);
 }
 
 // Plane3d::transform_to(wTo) = normalise(wTo^T pi)  (src/isam_plane3d.h:180-182); un-normalised u also returned
@@ -202,11 +271,11 @@ PPS_HD void plane_transform_from(const double pl[4], const double pose[7], doubl
 PPS_HD void log_diff(const double q[4], const double qm[4], double e[3], double dq[4]) {
   const double c[4] = {-qm[0], -qm[1], -qm[2], qm[3]};
   quat_mul(q, c, dq);
-  double n = sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]);
-  if (n != 0.0) {
-    const double angle = 2.0 * atan2(n, fabs(dq[3]));
-    if (dq[3] < 0) n = -n;
-    const double s = angle / n;
+  const double nn = dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2];
+  if (nn != 0.0) {
+    const double ri = rsqrt_acc(nn);              // n = |v| = nn / sqrt(nn), angle / n = angle * ri: one reciprocal root, no division
+    const double angle = 2.0 * atan2(nn * ri, fabs(dq[3]));
+    const double s = dq[3] < 0 ? -(angle * ri) : angle * ri;
     e[0] = dq[0] * s; e[1] = dq[1] * s; e[2] = dq[2] * s;
   } else {
     e[0] = e[1] = e[2] = 0.0;
@@ -220,7 +289,7 @@ PPS_HD void res_plane_obs(const double pose[7], const double plane[4], const dou
   double R[9], u[4], dq[4];
   quat_to_R(pose + 3, R);
   plane_transform_to_raw(plane, pose, R, u);
-  normalize4(u);
+  normalize4_r(u);
   log_diff(u, meas, e, dq);
 }
 
@@ -288,16 +357,39 @@ PPS_HD void ominus_Rt(const double p2[7], const double p1[7], double R12[9], dou
   }
 }
 
-// Pose3d_Pose3d_Factor::basic_error  (isam/slam3d.h:174-191): matrix -> quaternion -> Euler, as Pose3d(Matrix4d)
-PPS_HD void res_odometry(const double p1[7], const double p2[7], const double meas6[6], double e[6]) {
-  double R12[9], t12[3], R1[9], q[4], ypr[3];
-  ominus_Rt(p2, p1, R12, t12, R1);
+// the rotational half of a relative-pose residual: R12 -> quaternion -> Euler angles (as Pose3d(Matrix4d) does) -> wrapped differences
+PPS_HD void euler_residual(const double R12[9], const double meas6[6], double e3[3]) {
+  double q[4], ypr[3];
   R_to_quat(R12, q);
   quat_to_euler(q, ypr);
+  e3[0] = standard_rad(ypr[0] - meas6[3]);
+  e3[1] = standard_rad(ypr[1] - meas6[4]);
+  e3[2] = standard_rad(ypr[2] - meas6[5]);
+}
+
+// Pose3d_Pose3d_Factor::basic_error  (isam/slam3d.h:174-191): matrix -> quaternion -> Euler, as Pose3d(Matrix4d)
+PPS_HD void res_odometry(const double p1[7], const double p2[7], const double meas6[6], double e[6]) {
+  double R12[9], t12[3], R1[9];
+  ominus_Rt(p2, p1, R12, t12, R1);
   e[0] = t12[0] - meas6[0]; e[1] = t12[1] - meas6[1]; e[2] = t12[2] - meas6[2];
-  e[3] = standard_rad(ypr[0] - meas6[3]);
-  e[4] = standard_rad(ypr[1] - meas6[4]);
-  e[5] = standard_rad(ypr[2] - meas6[5]);
+  euler_residual(R12, meas6, e + 3);
+}
+
+// The translation of p2.ominus(p1) alone, for a p1 / p2 whose ROTATION is the one R1 was built from: the same expressions, in
+// the same order, as ominus_Rt's (C = -R1^T t1, then R1^T t2 + C).  What a translation column of the numerical Jacobian needs.
+PPS_HD void ominus_t(const double R1[9], const double t1[3], const double t2[3], double t12[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double C = -(R1[0 * 3 + i] * t1[0] + R1[1 * 3 + i] * t1[1] + R1[2 * 3 + i] * t1[2]);
+    t12[i] = R1[0 * 3 + i] * t2[0] + R1[1 * 3 + i] * t2[1] + R1[2 * 3 + i] * t2[2] + C;
+  }
+}
+
+// res_plane_obs from the un-normalised transformed plane u = wTo^T pi (src/isam_plane3d.h:180-182, 271-304)
+PPS_HD void res_plane_obs_u(const double u_raw[4], const double meas[4], double e[3]) {
+  double u[4] = {u_raw[0], u_raw[1], u_raw[2], u_raw[3]}, dq[4];
+  normalize4_r(u);
+  log_diff(u, meas, e, dq);
 }
 
 // r = U e for a packed upper-triangular U (Factor::error, isam/Factor.h:67-77)

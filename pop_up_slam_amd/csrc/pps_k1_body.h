@@ -4,149 +4,10 @@
 // difference evaluation per lane (numeric mode, the reference's arithmetic), and the re-popping Factor2 edges.
 #pragma once
 #include "pps_geom.h"
+#include "pps_lin.h"
 #include "pps_kcommon.h"
 
 namespace pps {
-
-template <int MODE>
-__device__ __forceinline__ void lin_plane_obs(const double pz[7], const double pl[4], const double ms[4],
-                                              const double w[6], double* __restrict__ out) {
-  double Jp[18], Jl[9], r[3];
-  if (MODE == 1) {
-    double e[3];
-    jac_plane_obs(pz, pl, ms, e, Jp, Jl);
-    whiten<3>(w, e, r);
-    whiten_rows<3, 6>(w, Jp);
-    whiten_rows<3, 3>(w, Jl);
-  } else {
-    double e[3];
-    res_plane_obs(pz, pl, ms, e);
-    whiten<3>(w, e, r);
-    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      double d[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[3], ym[3];
-      d[j] = kNumDiffEps;
-      pose_exmap(pz, d, pp); res_plane_obs(pp, pl, ms, e); whiten<3>(w, e, yp);
-      d[j] = -kNumDiffEps;
-      pose_exmap(pz, d, pp); res_plane_obs(pp, pl, ms, e); whiten<3>(w, e, ym);
-#pragma unroll
-      for (int i = 0; i < 3; i++) Jp[i * 6 + j] = (yp[i] - ym[i]) * inv2e;
-    }
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      double d[3] = {0, 0, 0}, pp[4], yp[3], ym[3];
-      d[j] = kNumDiffEps;
-      plane_exmap(pl, d, pp); res_plane_obs(pz, pp, ms, e); whiten<3>(w, e, yp);
-      d[j] = -kNumDiffEps;
-      plane_exmap(pl, d, pp); res_plane_obs(pz, pp, ms, e); whiten<3>(w, e, ym);
-#pragma unroll
-      for (int i = 0; i < 3; i++) Jl[i * 3 + j] = (yp[i] - ym[i]) * inv2e;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 18; k++) out[k] = Jp[k];
-#pragma unroll
-  for (int k = 0; k < 9; k++) out[18 + k] = Jl[k];
-#pragma unroll
-  for (int k = 0; k < 3; k++) out[27 + k] = r[k];
-}
-
-template <int MODE>
-__device__ __forceinline__ void lin_odometry(const double p1[7], const double p2[7], const double ms[6],
-                                             const double* w, double* __restrict__ out) {
-  double e[6], r[6];
-  if (MODE == 1) {
-    double J1[36], J2[36];
-    jac_odometry(p1, p2, ms, e, J1, J2);
-    whiten<6>(w, e, r);
-    whiten_rows<6, 6>(w, J1);
-    whiten_rows<6, 6>(w, J2);
-#pragma unroll
-    for (int k = 0; k < 36; k++) out[k] = J1[k];
-#pragma unroll
-    for (int k = 0; k < 36; k++) out[36 + k] = J2[k];
-  } else {
-    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
-    for (int n = 0; n < 2; n++) {
-      for (int j = 0; j < 6; j++) {
-        double d[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[6], ym[6];
-        d[j] = kNumDiffEps;
-        pose_exmap(n == 0 ? p1 : p2, d, pp);
-        if (n == 0) res_odometry(pp, p2, ms, e); else res_odometry(p1, pp, ms, e);
-        whiten<6>(w, e, yp);
-        d[j] = -kNumDiffEps;
-        pose_exmap(n == 0 ? p1 : p2, d, pp);
-        if (n == 0) res_odometry(pp, p2, ms, e); else res_odometry(p1, pp, ms, e);
-        whiten<6>(w, e, ym);
-#pragma unroll
-        for (int i = 0; i < 6; i++) out[n * 36 + i * 6 + j] = (yp[i] - ym[i]) * inv2e;
-      }
-    }
-    res_odometry(p1, p2, ms, e);
-    whiten<6>(w, e, r);
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) out[72 + k] = r[k];
-}
-
-template <int MODE>
-__device__ __forceinline__ void lin_pose_prior(const double pz[7], const double ms[6], const double* w,
-                                               double* __restrict__ out) {
-  double e[6], r[6];
-  if (MODE == 1) {
-    double J[36];
-    jac_pose_prior(pz, ms, e, J);
-    whiten<6>(w, e, r);
-    whiten_rows<6, 6>(w, J);
-#pragma unroll
-    for (int k = 0; k < 36; k++) out[k] = J[k];
-  } else {
-    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
-    for (int j = 0; j < 6; j++) {
-      double d[6] = {0, 0, 0, 0, 0, 0}, pp[7], yp[6], ym[6];
-      d[j] = kNumDiffEps;
-      pose_exmap(pz, d, pp); res_pose_prior(pp, ms, e); whiten<6>(w, e, yp);
-      d[j] = -kNumDiffEps;
-      pose_exmap(pz, d, pp); res_pose_prior(pp, ms, e); whiten<6>(w, e, ym);
-#pragma unroll
-      for (int i = 0; i < 6; i++) out[i * 6 + j] = (yp[i] - ym[i]) * inv2e;
-    }
-    res_pose_prior(pz, ms, e);
-    whiten<6>(w, e, r);
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) out[36 + k] = r[k];
-}
-
-template <int MODE>
-__device__ __forceinline__ void lin_plane_prior(const double pl[4], const double ms[4], const double w[6],
-                                                double* __restrict__ out) {
-  double e[3], r[3], Jl[9];
-  if (MODE == 1) {
-    jac_plane_prior(pl, ms, e, Jl);
-    whiten<3>(w, e, r);
-    whiten_rows<3, 3>(w, Jl);
-  } else {
-    const double inv2e = 1.0 / (kNumDiffEps + kNumDiffEps);
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      double d[3] = {0, 0, 0}, pp[4], yp[3], ym[3];
-      d[j] = kNumDiffEps;
-      plane_exmap(pl, d, pp); res_plane_prior(pp, ms, e); whiten<3>(w, e, yp);
-      d[j] = -kNumDiffEps;
-      plane_exmap(pl, d, pp); res_plane_prior(pp, ms, e); whiten<3>(w, e, ym);
-#pragma unroll
-      for (int i = 0; i < 3; i++) Jl[i * 3 + j] = (yp[i] - ym[i]) * inv2e;
-    }
-    res_plane_prior(pl, ms, e);
-    whiten<3>(w, e, r);
-  }
-#pragma unroll
-  for (int k = 0; k < 9; k++) out[k] = Jl[k];
-#pragma unroll
-  for (int k = 0; k < 3; k++) out[9 + k] = r[k];
-}
 
 constexpr int kLinBlock = 128;
 
@@ -230,6 +91,7 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
     if (i0 < d.n_obs_fixed) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs_fixed - i0), lds_wave);
     return;
   }
+  if (PART == 0) return;          // (a PART 0 launch has nb_obs blocks: without this the other factor types are compiled in, 68 KB of dead code)
   b -= nb_obs;
   if (b < nb_odo) {
     // both Jacobian modes leave through the LDS-staged store: written straight from the lanes, a 624-byte record per lane

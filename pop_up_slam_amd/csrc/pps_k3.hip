@@ -499,8 +499,7 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
 // are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried along panel by panel:
 // triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
 template <int NT, bool TR, bool STRIP = false>
-__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* __restrict__ F,
-                                                      double* __restrict__ P, int tr) {
+__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* F, double* P, int tr) {   // (P may be F)
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0);
   (void)s;

@@ -104,7 +104,7 @@ __device__ __forceinline__ void reg_trailing(double4_t (&c)[NT * (NT + 1) / 2], 
 constexpr int kP8Stride = 9;                      // doubles per panel row: eight columns + one pad (odd: conflict-free row reads)
 
 template <int TJ, int NT>
-__device__ __forceinline__ void reg_extract_panel8(const double4_t (&c)[NT * (NT + 1) / 2], double* __restrict__ P, int c0, int lane) {
+__device__ __forceinline__ void reg_extract_panel8(const double4_t (&c)[NT * (NT + 1) / 2], double* P, int c0, int lane) {
   const int l16 = lane & 15, lq = lane >> 4;
   const int m = l16 - c0;                         // c0 = 0 or 8: half of the lanes hold a panel column
   if (m >= 0 && m < 8) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ double rank4(double r, double x0, double x1, double x
 // the next step extracts its panel from them and then spends ~1000 cycles on the pivot blocks, during which the remaining
 // (independent) MFMAs drain in the matrix core instead of being waited for.
 template <int TJ, int NT>
-__device__ __forceinline__ void reg_trailing8(double4_t (&c)[NT * (NT + 1) / 2], const double* __restrict__ P, int nb, int lane, int tjn) {
+__device__ __forceinline__ void reg_trailing8(double4_t (&c)[NT * (NT + 1) / 2], const double* P, int nb, int lane, int tjn) {
   const int l16 = lane & 15, lq = lane >> 4;
   const bool v0 = lq < nb, v1 = lq + 4 < nb;
   const bool two = nb > 4;                                      // (wave-uniform)

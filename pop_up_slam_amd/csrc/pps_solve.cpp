@@ -205,8 +205,16 @@ void abandon_device_copy(pps_graph* g) {
 
 extern "C" {
 
+static int update_impl(pps_graph* g);
+// estimate_to_linpoint is a pointer trade (copy_state): a HIP failure behind it would leave est / lin exchanged with est holding
+// dead data -- like the LM drivers, a failed update abandons the device copy, and the next call uploads from the host's values.
 int pps_update(pps_graph* g) {
   if (!g) return PPS_EINVAL;
+  const int rc = update_impl(g);
+  if (rc != PPS_OK && rc != PPS_ENOTPD) abandon_device_copy(g);
+  return rc;
+}
+static int update_impl(pps_graph* g) {
   const double t0 = now_s();
   reset_solve_stats(g);
   if (g->n_live_nodes > 0 && g->n_live_factors == 0) return PPS_OK;   // no factor, no step
@@ -483,8 +491,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
         fprintf(stderr, "  solve level %d (%d fronts): panel load %.0f boundary values %.0f y - L_B^T x_b %.0f back-substitution %.0f store %.0f | start after parent's end %.0f\n",
                 l, n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ng ? gap / ng : 0.0);
       }
-      return PPS_OK;
-    }
+    } else {                        // (PPS_TRACE=1; either way the common epilogue below reports iterations and the not-PD status)
     double acc[5] = {0, 0, 0, 0, 0};
     std::vector<double> lvl_tot(A.n_levels, 0.0); std::vector<int> lvl_n(A.n_levels, 0);
     for (int s2 = 0; s2 < A.n_fronts; s2++) {
@@ -529,6 +536,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
     long long tmin = tr[0], tmax = tr[5];
     for (int s2 = 0; s2 < A.n_fronts; s2++) { tmin = std::min(tmin, tr[(size_t)s2 * 8]); tmax = std::max(tmax, tr[(size_t)s2 * 8 + 5]); }
     fprintf(stderr, "  first start -> last end: %lld cycles\n", tmax - tmin);
+    }
   }
   if (iterations) *iterations = num_iter;
   g->stats.lm_trials_notpd = n_notpd;

@@ -498,10 +498,19 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       int top_dim = 0, border_dim = 0;
       if (top >= 0) for (int u : B.tree[top].piv) top_dim += nodes[u].dim;
       for (int u : border) border_dim += nodes[u].dim;
+      // A top taken over from the previous analysis (a re-analysis of an unchanged graph) already ends with the border: its
+      // pivots must not be counted twice by the size test -- a 45-scalar separator + the 3-scalar ground plane against max_pivots
+      // 48 passed the first time and would fail the second, building a separate root over nodes the top already holds.
+      bool already = false;
+      if (top >= 0) {
+        const std::vector<int>& tp = B.tree[top].piv;
+        already = tp.size() >= border.size() && std::equal(border.begin(), border.end(), tp.end() - (std::ptrdiff_t)border.size());
+        if (already) top_dim -= border_dim;
+      }
       if (top >= 0 && !general_ordering && top_dim + border_dim <= prm.max_pivots) {
-        std::vector<int>& tp = B.tree[top].piv;
-        const bool already = tp.size() >= border.size() && std::equal(border.begin(), border.end(), tp.end() - (std::ptrdiff_t)border.size());   // (a top taken over from the previous analysis)
-        if (!already) tp.insert(tp.end(), border.begin(), border.end());
+        if (!already) B.tree[top].piv.insert(B.tree[top].piv.end(), border.begin(), border.end());
+      } else if (already) {
+        return 2;                    // (a taken-over top that holds the border although the merge no longer applies: from scratch)
       } else {
         root = B.new_tnode();
         B.tree[root].piv = border;

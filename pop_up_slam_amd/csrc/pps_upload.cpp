@@ -171,7 +171,15 @@ void j_bases(const pps_graph* g, int64_t base[4], int64_t* total) {
 }
 
 // ---- compaction + symbolic analysis (host only) -------------------------------------------
+static int run_analysis_impl(pps_graph* g);
+// A failed analysis may have rewritten g->an in place (the incremental path) before it gave up: the handle is marked as not
+// analysed, so that no later upload sends a half-rewritten Analysis to the device -- the next solve runs the analysis again.
 int run_analysis(pps_graph* g) {
+  const int rc = run_analysis_impl(g);
+  if (rc != PPS_OK) { g->analyzed = false; g->analysis_stale = true; g->topo_dirty = true; g->cmp_valid = false; }
+  return rc;
+}
+static int run_analysis_impl(pps_graph* g) {
   const double t0 = now_s();
   std::vector<SymNode>& sn = g->sym_nodes;
   std::vector<SymFactor>& sf = g->sym_factors;
