@@ -78,6 +78,9 @@ struct DevGraph {
   long long* trace = nullptr;        // PPS_TRACE=1: 8 timestamps (s_memtime) per front of the last factorisation
   int trace_solve = 0;               // PPS_TRACE=2: the trace slots take the phases of the back-substitution instead of the factorisation's
   int no_strip = 0;                  // PPS_NO_STRIP=1: fronts of 65 .. 80 rows take the LDS-tile path (A/B, parity tests)
+  // step quaternions of the numerical Jacobian's rotation / plane columns: (a, 0, 0, c) = rot_exp((eps, 0, 0)) and plane_exp((eps, 0, 0)),
+  // evaluated ONCE per device by the device's own functions (step_constants) -- the same bits as evaluating them per step
+  double step_ac[4] = {0, 0, 0, 0};
   double* gwork = nullptr;           // global-memory front workspace for fronts that exceed LDS
   int64_t gwork_stride = 0;
 };
@@ -98,6 +101,8 @@ unsigned long long launch_count();
 void count_launch();
 #define PPS_LAUNCH(...) do { ::pps::count_launch(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+// fills ac[4] = {a_rot, c_rot, a_plane, c_plane} for the current device (one tiny kernel + a synchronous copy the first time)
+hipError_t step_constants(double ac[4]);
 // All launchers enqueue on `st` and return the HIP error of the launch.
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard = nullptr);
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard = nullptr);

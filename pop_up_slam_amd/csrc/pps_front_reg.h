@@ -27,7 +27,8 @@ __device__ __forceinline__ int tri24(int i) { return __mul24(i, i + 1) >> 1; }
 // is a vector next to them.
 // P: the panel buffer, 16 NT rows of kP8Stride doubles (at least 80 rows with STRIP).  Without STRIP, and with NT = 5, F is dead
 // once the tiles are loaded, and P may be F itself.
-template <int NT, bool TR, bool STRIP, class G>
+// W: pivot columns per panel step, 8 or 4 (4 = the second pivot block never runs: the form up to round 3, kept for A/B).
+template <int NT, bool TR, bool STRIP, int W = 8, class G>
 __device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double* F, double* P) {      // (no __restrict__: P may be F)
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0), p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
@@ -64,7 +65,7 @@ __device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double*
   bool bad = false;                                            // a pivot that is not positive: reported once, after the last panel
   auto panel_step = [&](const int K) __attribute__((always_inline)) {
     const long long tk0 = (TR && d.trace) ? clock64() : 0;
-    const int nb = p - K < 8 ? p - K : 8;
+    const int nb = p - K < W ? p - K : W;
     const bool two = nb > 4;                                   // (wave-uniform) the panel has a second pivot block
     const int tjK = K >> 4, c0 = K & 15;
     switch (tjK) {
@@ -192,10 +193,10 @@ __device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double*
     }
     const long long tk1 = (TR && d.trace) ? clock64() : 0;
     switch (tjK) {
-      case 0: reg_trailing8<0, NT>(c, P, nb, lane, (K + 8) >> 4); break;
-      case 1: reg_trailing8<1, NT>(c, P, nb, lane, (K + 8) >> 4); break;
-      case 2: if (NT > 2) reg_trailing8<(NT > 2 ? 2 : 1), NT>(c, P, nb, lane, (K + 8) >> 4); break;
-      default: if (NT > 3) reg_trailing8<(NT > 3 ? 3 : NT - 1), NT>(c, P, nb, lane, (K + 8) >> 4); break;
+      case 0: reg_trailing8<0, NT>(c, P, nb, lane, (K + W) >> 4, c0 + nb < 16); break;
+      case 1: reg_trailing8<1, NT>(c, P, nb, lane, (K + W) >> 4, c0 + nb < 16); break;
+      case 2: if (NT > 2) reg_trailing8<(NT > 2 ? 2 : 1), NT>(c, P, nb, lane, (K + W) >> 4, c0 + nb < 16); break;
+      default: if (NT > 3) reg_trailing8<(NT > 3 ? 3 : NT - 1), NT>(c, P, nb, lane, (K + W) >> 4, c0 + nb < 16); break;
     }
     __builtin_amdgcn_wave_barrier();
     if (TR && d.trace) { const long long tk2 = clock64(); cyc_panel += tk1 - tk0; cyc_trail += tk2 - tk1; }
@@ -204,9 +205,9 @@ __device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double*
     // (hipcc 7.2 miscompiled this loop with fifteen accumulator tiles once it peeled the first panel: rows 8 and up of every later
     // panel came out wrong, deterministically -- tests/test_gpu_fronts.py holds the case; without peeling the code is correct)
 #pragma clang loop unroll(disable)
-    for (int K = 0; K < p; K += 8) panel_step(K);
+    for (int K = 0; K < p; K += W) panel_step(K);
   } else {
-    for (int K = 0; K < p; K += 8) panel_step(K);
+    for (int K = 0; K < p; K += W) panel_step(K);
   }
   if (bad && lane == 0) d.result_dev[2] = 1.0;             // not positive definite
   if (TR) PPS_TR(4);

@@ -203,8 +203,8 @@ PPS_HD void pose_exmap(const double p[7], const double d[6], double o[7]) {
 // quaternion of such a step is (+-a e_k, c) with (a, 0, 0, c) = rot_exp((eps, 0, 0)) -- theta = sqrt(eps^2) = eps whichever
 // component carries it, S * 0 = 0 -- so the square root, the sine / cosine pair and the division are evaluated once per factor
 // (rot_step_quat) instead of once per step; the product is quat_mul itself: the same bits as pose_exmap(p, d, o).
-PPS_HD void rot_step_quat(double ac[2]) {
-  const double d1[3] = {kNumDiffEps, 0.0, 0.0};
+PPS_HD void rot_step_quat(double ac[2], double eps = kNumDiffEps) {      // (eps as a run-time value: no compile-time folding of the sine)
+  const double d1[3] = {eps, 0.0, 0.0};
   double q[4];
   rot_exp(d1, q);
   ac[0] = q[0]; ac[1] = q[3];
@@ -221,8 +221,8 @@ PPS_HD void pose_exmap_rot_step(const double p[7], int k, bool minus, const doub
 
 // Plane3d::exmap_3dof for the steps d = +-eps e_k of a numerical Jacobian: the step quaternion is (+-a e_k, c) with
 // (a, 0, 0, c) = plane_exp((eps, 0, 0)), evaluated once per factor; the same bits as plane_exmap(pl, d, o).
-PPS_HD void plane_step_quat(double ac[2]) {
-  const double d1[3] = {kNumDiffEps, 0.0, 0.0};
+PPS_HD void plane_step_quat(double ac[2], double eps = kNumDiffEps) {
+  const double d1[3] = {eps, 0.0, 0.0};
   double q[4];
   plane_exp(d1, q);
   ac[0] = q[0]; ac[1] = q[3];

@@ -1,6 +1,8 @@
 // pps_k1.hip -- K1 kernels: k_linearize<MODE,PART>, k_linearize_lanes, k_linearize_repop, the batched forms (blockIdx.y =
 // graph) and the replicated-edge sweep of the roofline micro-benchmark (k_sweep_bench).  Bodies: pps_k1_body.h.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "pps_k1_body.h"
 
@@ -34,6 +36,39 @@ void k_linearize_obs_numeric(DevGraph d, const double* __restrict__ pose, const 
   extern __shared__ double lin_lds[];
   if (!lin_guard(gd, pose, plane)) return;
   body_linearize<0, 0, true>(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);
+}
+
+// rot_exp / plane_exp of the one step size a numerical Jacobian uses, by the device's own arithmetic, once per device
+// (eps arrives as a kernel argument: with a literal the compiler folds sqrt / sincos at build time, with the HOST's libm, which may
+// round the last bit differently from the device's own evaluation that a step computed in a lane would see)
+__global__ void k_step_constants(double* out, double eps) {
+  double ac[2];
+  rot_step_quat(ac, eps); out[0] = ac[0]; out[1] = ac[1];
+  plane_step_quat(ac, eps); out[2] = ac[0]; out[3] = ac[1];
+}
+static std::atomic<int> g_step_state[64];          // per device ordinal: 0 unset, 2 ready
+static double g_step_ac[64][4];
+static std::mutex g_step_mutex;
+hipError_t step_constants(double ac[4]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  if (g_step_state[dev].load(std::memory_order_acquire) != 2) {
+    std::lock_guard<std::mutex> lk(g_step_mutex);
+    if (g_step_state[dev].load(std::memory_order_acquire) != 2) {
+      double* o = nullptr;
+      hipError_t e = hipMalloc(&o, 4 * sizeof(double));
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_step_constants, dim3(1), dim3(1), 0, 0, o, kNumDiffEps);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpy(g_step_ac[dev], o, 4 * sizeof(double), hipMemcpyDeviceToHost);
+      (void)hipFree(o);
+      if (e != hipSuccess) return e;
+      g_step_state[dev].store(2, std::memory_order_release);
+    }
+  }
+  for (int k = 0; k < 4; k++) ac[k] = g_step_ac[dev][k];
+  return hipSuccess;
 }
 
 static thread_local unsigned long long t_launches = 0;

@@ -146,17 +146,29 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
 // 2*ncols the nominal residual.  All lanes of a group read the same edge record (a broadcast load), state is gathered by index
 // from the SoA arrays.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void perturb6(const double p[7], int q, double sgn, double o[7]) {
-  double dl[6];
+// Pose3d::exmap / Plane3d::exmap_3dof by the step sgn * eps * e_q (q out of range: the zero step, which is the exact identity for a
+// pose).  The step quaternions come from DevGraph::step_ac -- (a, 0, 0, c) = rot_exp / plane_exp of (eps, 0, 0), evaluated once per
+// device by those very functions -- instead of a square root, a sine / cosine pair and a division in every lane: S * (sgn eps) =
+// sgn (S eps) exactly, theta = eps whichever component carries the step, and the zero step is (0, 0, 0, 1) in both maps.  The
+// quaternion product (and the plane's normalisation) are the ones of pose_exmap / plane_exmap: the same bits.
+__device__ __forceinline__ void perturb6(const double p[7], int q, double sgn, const double ac[4], double o[7]) {
+  PPS_FP_EXACT
+  const bool rot = q >= 3 && q < 6;
+  const double a = sgn * ac[0];
+  const double dq[4] = {q == 3 ? a : 0.0, q == 4 ? a : 0.0, q == 5 ? a : 0.0, rot ? ac[1] : 1.0};
+  double qq[4];
+  quat_mul(p + 3, dq, qq);
 #pragma unroll
-  for (int k = 0; k < 6; k++) dl[k] = (k == q) ? sgn * kNumDiffEps : 0.0;
-  pose_exmap(p, dl, o);
+  for (int k = 0; k < 3; k++) o[k] = p[k] + ((k == q) ? sgn * kNumDiffEps : 0.0);
+  o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
 }
-__device__ __forceinline__ void perturb3(const double p[4], int q, double sgn, double o[4]) {
-  double dl[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) dl[k] = (k == q) ? sgn * kNumDiffEps : 0.0;
-  plane_exmap(p, dl, o);
+__device__ __forceinline__ void perturb3(const double p[4], int q, double sgn, const double ac[4], double o[4]) {
+  PPS_FP_EXACT
+  const bool on = q >= 0 && q < 3;
+  const double a = sgn * ac[2];
+  const double dq[4] = {q == 0 ? a : 0.0, q == 1 ? a : 0.0, q == 2 ? a : 0.0, on ? ac[3] : 1.0};
+  quat_mul(dq, p, o);
+  normalize4_r(o);
 }
 
 constexpr int kLaneGroup = 32;
@@ -188,8 +200,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
       // every lane takes the same path: a perturbation that does not apply is the zero step, which is the
       // exact identity for a pose; the plane keeps its stored value unless it is the perturbed node
       double pp[7], lp[4];
-      perturb6(pz, q3, s3, pp);                       // q3 >= 6: zero delta -> pp == pz bit for bit
-      perturb3(pl, q3 - 6, s3, lp);
+      perturb6(pz, q3, s3, d.step_ac, pp);                       // q3 >= 6: zero delta -> pp == pz bit for bit
+      perturb3(pl, q3 - 6, s3, d.step_ac, lp);
       const bool pert_plane = q3 >= 6 && q3 < 9;
 #pragma unroll
       for (int k = 0; k < 4; k++) lp[k] = pert_plane ? lp[k] : pl[k];
@@ -240,8 +252,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     load_soa<21>(d.odo_w, d.odo_ld, i, w);
     {
       double pa[7], pb[7];
-      perturb6(p1, q, sgn, pa);                       // out-of-range q: zero step == identity
-      perturb6(p2, q - 6, sgn, pb);
+      perturb6(p1, q, sgn, d.step_ac, pa);                       // out-of-range q: zero step == identity
+      perturb6(p2, q - 6, sgn, d.step_ac, pb);
       res_odometry(pa, pb, ms, e);
     }
     whiten<6>(w, e, y);
@@ -266,7 +278,7 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
     load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
     load_soa<21>(d.pp_w, d.pp_ld, i, w);
-    { double pp[7]; perturb6(pz, q, sgn, pp); res_pose_prior(pp, ms, e); }
+    { double pp[7]; perturb6(pz, q, sgn, d.step_ac, pp); res_pose_prior(pp, ms, e); }
     whiten<6>(w, e, y);
     double* __restrict__ out = d.J + d.joff_pp + (size_t)i * 42;
 #pragma unroll
@@ -290,7 +302,7 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     load_soa<6>(d.lp_w, d.lp_ld, i, w);
     {
       double lp[4];
-      perturb3(pl, q, sgn, lp);
+      perturb3(pl, q, sgn, d.step_ac, lp);
 #pragma unroll
       for (int k = 0; k < 4; k++) lp[k] = q < 3 ? lp[k] : pl[k];
       res_plane_prior(lp, ms, e);

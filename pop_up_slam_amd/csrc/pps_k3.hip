@@ -498,8 +498,19 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
 // Fronts of 65 .. 80 rows (STRIP): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary rows, the pivots
 // are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried along panel by panel:
 // triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
-template <int NT, bool TR, bool STRIP = false>
-__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* F, double* P, int tr) {   // (P may be F)
+// panel widths of the two families of kernels (build-time, A/B: -DPPS_PANEL_W_BAND=4 / -DPPS_PANEL_W_LEVEL=4)
+#ifndef PPS_PANEL_W_BAND
+#define PPS_PANEL_W_BAND 4      // (C2: 73.1 us per LM iteration against 74.1 with 8 -- a lone wave per SIMD is bound by the pivot chain)
+#endif
+#ifndef PPS_PANEL_W_LEVEL
+#define PPS_PANEL_W_LEVEL 8
+#endif
+#ifndef PPS_PANEL_W_R5                 // the kernels that also hold fronts of 65 .. 80 rows (fifth tile row / LDS strip) and the general one
+#define PPS_PANEL_W_R5 8
+#endif
+// First half of a register-resident front, the same for every tile count: the packed triangle assembled in LDS.
+template <bool TR>
+__device__ __forceinline__ void front_assemble(const DevGraph& d, int rec, double lambda, double* F, int tr) {
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0);
   (void)s;
@@ -515,7 +526,17 @@ __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec
   if (TR) PPS_TR(2);
   front_extend_add(d, rec, pre.crv, lane, F, tr);
   if (TR) PPS_TR(3);
-  front_reg_eliminate<NT, TR, STRIP>(d, rec, F, P);
+}
+// Second half: elimination in registers, factor panel and update matrix out.
+template <int NT, bool TR, bool STRIP = false, int W = PPS_PANEL_W_BAND>
+__device__ __forceinline__ void front_eliminate_out(const DevGraph& d, int rec, double* F, double* P) {
+  front_reg_eliminate<NT, TR, STRIP, W>(d, rec, F, P);
+}
+// One front from start to end (the level-per-launch kernels: one tile count per kernel)
+template <int NT, bool TR, bool STRIP = false, int W = PPS_PANEL_W_BAND>
+__device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* F, double* P, int tr) {   // (P may be F)
+  front_assemble<TR>(d, rec, lambda, F, tr);
+  front_eliminate_out<NT, TR, STRIP, W>(d, rec, F, P);
 }
 
 // lane K of every row of 16 lanes, broadcast to the row (DPP row_newbcast: two v_mov_b32_dpp, no SGPR hop, no LDS)
@@ -712,12 +733,18 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       constexpr bool ALIAS = REG_ONLY && !REG_STRIP;
       double* const Pn = ALIAS ? F : F + lds_doubles_per_wave - kRegRowsMax * kP8Stride;
       const int tr = ALIAS ? lds_doubles_per_wave - 1 : lds_doubles_per_wave - kRegRowsMax * kP8Stride - 1;
-      if (REG_ONLY && fa <= 33) wave_front_factor_reg<2, TR>(d, rec, lambda, F, Pn, tr);                    // (without a strip the rhs row is a vector next to the tiles)
-      else if (REG_ONLY && fa <= 49) wave_front_factor_reg<3, TR>(d, rec, lambda, F, Pn, tr);
-      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) wave_front_factor_reg<4, TR>(d, rec, lambda, F, Pn, tr);
-      else if (REG_ONLY && R5) wave_front_factor_reg<5, false, true>(d, rec, lambda, F, Pn, tr);             // 65 .. 80 rows: fifteen register tiles
-      else if (fa <= kRegRowsMax && !d.no_strip) wave_front_factor_reg<4, true, true>(d, rec, lambda, F, Pn, tr);
-      else if (fa <= kRegRows) wave_front_factor_reg<4, true>(d, rec, lambda, F, Pn, tr);
+      constexpr int WB = PPS_PANEL_W_BAND, WR = PPS_PANEL_W_R5;
+      // the assembly is the same code for every tile count (one copy in the kernel); the elimination is per tile count
+      if (REG_ONLY || fa <= kRegRowsMax) {
+        if (REG_ONLY) front_assemble<TR>(d, rec, lambda, F, tr);
+        else if ((fa <= kRegRowsMax && !d.no_strip) || fa <= kRegRows) front_assemble<true>(d, rec, lambda, F, tr);
+      }
+      if (REG_ONLY && fa <= 33) front_eliminate_out<2, TR, false, REG_STRIP ? WR : WB>(d, rec, F, Pn);   // (without a strip the rhs row is a vector next to the tiles)
+      else if (REG_ONLY && fa <= 49) front_eliminate_out<3, TR, false, REG_STRIP ? WR : WB>(d, rec, F, Pn);
+      else if (REG_ONLY && (!REG_STRIP || fa <= kRegRows)) front_eliminate_out<4, TR, false, REG_STRIP ? WR : WB>(d, rec, F, Pn);
+      else if (REG_ONLY && R5) front_eliminate_out<5, false, true, WR>(d, rec, F, Pn);             // 65 .. 80 rows: fifteen register tiles
+      else if (fa <= kRegRowsMax && !d.no_strip) front_eliminate_out<4, true, true, WR>(d, rec, F, Pn);
+      else if (fa <= kRegRows) front_eliminate_out<4, true, false, WR>(d, rec, F, Pn);
       else wave_front_factor(d, s, lambda, F);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
@@ -764,38 +791,33 @@ static hipError_t ensure_band_attrs() {
   return hipSuccess;
 }
 
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st) {
+// one launcher for both: ny = 1 (alt unused) or 2 (dual)
+static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt, int ny, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
+                                          hipStream_t st) {
   if (grp_count == 0) return hipSuccess;
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
-  const bool reg_only = max_front + 1 <= kRegRows;
+  const bool reg_only = max_front + 1 <= kRegRows && !(ny == 2 && d.trace != nullptr);     // (a traced dual solve runs the general kernel)
   const int per_wave = (int)(band_lds_bytes(max_front, reg_only) / sizeof(double));
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   if (reg_only && d.trace != nullptr)      // phase trace of the register-only kernel
-    PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
+    PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (reg_only)
-    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
+    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
     const int nw5 = nwaves < 4 ? nwaves : 4;                // (one wave per SIMD: see k_band_factor_r5)
-    PPS_LAUNCH(k_band_factor_r5, dim3(grp_count), dim3(64 * nw5), (size_t)per_wave * nw5 * sizeof(double), st, d, DualAlt{}, grp_begin, lambda, per_wave);
+    PPS_LAUNCH(k_band_factor_r5, dim3(grp_count, ny), dim3(64 * nw5), (size_t)per_wave * nw5 * sizeof(double), st, d, alt, grp_begin, lambda, per_wave);
   } else
-    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, DualAlt{}, grp_begin, lambda, per_wave);
+    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   return hipGetLastError();
+}
+
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st) {
+  return launch_band_factor_impl(d, DualAlt{}, 1, grp_begin, grp_count, nwaves, max_front, lambda, st);
 }
 
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
                                    hipStream_t st) {
-  if (grp_count == 0) return hipSuccess;
-  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
-  const int per_wave = (int)(band_lds_bytes(max_front, max_front + 1 <= kRegRows && d.trace == nullptr) / sizeof(double));
-  const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
-  if (max_front + 1 <= kRegRows && d.trace == nullptr)
-    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
-  else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
-    const int nw5 = nwaves < 4 ? nwaves : 4;
-    PPS_LAUNCH(k_band_factor_r5, dim3(grp_count, 2), dim3(64 * nw5), (size_t)per_wave * nw5 * sizeof(double), st, d, alt, grp_begin, lambda, per_wave);
-  } else
-    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, 2), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
-  return hipGetLastError();
+  return launch_band_factor_impl(d, alt, 2, grp_begin, grp_count, nwaves, max_front, lambda, st);
 }
 
 size_t band_solve_lds_bytes(int max_panel) { return (size_t)(kBandMaxRows + max_panel) * sizeof(double); }   // xb + the factor panel
@@ -895,10 +917,10 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
       const BatchAlt al = load_alt(a.alt + a.b0 + b);                                                                \
       DevGraph d2 = d;                                                                                               \
       d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;                                  \
-      wave_front_factor_reg<NT, false>(d2, rec, a.lambda2[b], F, Pn, tr);                                             \
+      wave_front_factor_reg<NT, false, false, PPS_PANEL_W_LEVEL>(d2, rec, a.lambda2[b], F, Pn, tr);                                             \
       return;                                                                                                        \
     }                                                                                                                \
-    wave_front_factor_reg<NT, false>(d, rec, a.lambda[b], F, Pn, tr);                                                 \
+    wave_front_factor_reg<NT, false, false, PPS_PANEL_W_LEVEL>(d, rec, a.lambda[b], F, Pn, tr);                                              \
   }
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor2, 2, 5)
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, 3)

@@ -155,7 +155,7 @@ __device__ __forceinline__ double rank4(double r, double x0, double x1, double x
 // the next step extracts its panel from them and then spends ~1000 cycles on the pivot blocks, during which the remaining
 // (independent) MFMAs drain in the matrix core instead of being waited for.
 template <int TJ, int NT>
-__device__ __forceinline__ void reg_trailing8(double4_t (&c)[NT * (NT + 1) / 2], const double* P, int nb, int lane, int tjn) {
+__device__ __forceinline__ void reg_trailing8(double4_t (&c)[NT * (NT + 1) / 2], const double* P, int nb, int lane, int tjn, bool short_of_end) {
   const int l16 = lane & 15, lq = lane >> 4;
   const bool v0 = lq < nb, v1 = lq + 4 < nb;
   const bool two = nb > 4;                                      // (wave-uniform)
@@ -203,8 +203,8 @@ __device__ __forceinline__ void reg_trailing8(double4_t (&c)[NT * (NT + 1) / 2],
 #pragma unroll
         for (int tj = TJ + 2; tj <= ti; tj++) c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[ti], a1[tj], c[tile_id(ti, tj)], 0, 0, 0);
     }
-    if (nb < 8) {
-      // the last panel of a front stops short of the tile column's end: columns K + nb .. K + 7 are boundary columns, whose
+    if (short_of_end) {
+      // the last panel of a front stops short of the tile column's end: the columns behind it are boundary columns, whose
       // entries in tile column TJ go into the update matrix
 #pragma unroll
       for (int ti = TJ; ti < NT; ti++) c[tile_id(ti, TJ)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[ti], a0[TJ], c[tile_id(ti, TJ)], 0, 0, 0);

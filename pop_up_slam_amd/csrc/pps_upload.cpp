@@ -518,6 +518,7 @@ int upload_all(pps_graph* g) {
   double* zero_block = nullptr; size_t zero_doubles = 0;
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
   d.no_strip = getenv("PPS_NO_STRIP") ? 1 : 0;
+  HIP_TRY(g, step_constants(d.step_ac));
   d.pose_ld = std::max(1, (d.n_pose + 63) / 64 * 64); d.plane_ld = std::max(1, (d.n_plane + 63) / 64 * 64);
 #define TRY(x) do { rc = (x); if (rc != PPS_OK) return rc; } while (0)
   // every copy of the state is one block [poses | planes]: one transfer moves it (copies rotate by pointer pairs, so a

@@ -10,7 +10,7 @@
 namespace {
 struct EmuGraph { double* L; double* U; double* result_dev; long long* trace; };
 
-template <int NT, bool STRIP>
+template <int NT, bool STRIP, int W>
 void run_front(int p, int b, const double* A, double* L, double* U, double* res, bool alias) {
   using namespace pps;
   const int fa = p + b + 1;
@@ -27,12 +27,13 @@ void run_front(int p, int b, const double* A, double* L, double* U, double* res,
     int rec = 0;                                  // (L and U of the front start at offset 0)
     if (lane == 1) rec = p;
     if (lane == 2) rec = b;
-    front_reg_eliminate<NT, false, STRIP>(d, rec, F, P);
+    front_reg_eliminate<NT, false, STRIP, W>(d, rec, F, P);
   });
 }
 }  // namespace
 
-extern "C" int emu_front_factor(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd, long long* counts) {
+template <int W>
+static int front_factor_w(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd, long long* counts) {
   using namespace pps;
   const int f = p + b, fa = f + 1;
   if (p < 1 || b < 0 || fa > kRegRowsMax || p > kRegRows) return -1;
@@ -43,14 +44,22 @@ extern "C" int emu_front_factor(int tiles, int strip, int p, int b, const double
   double res[4] = {0, 0, 0, 0};
   pps_emu::Wave& w = pps_emu::W();
   w.n_yields = w.n_readlane = w.n_mfma = w.n_barrier = 0;
-  if (tiles == 5) run_front<5, true>(p, b, A, Lb.data(), Ub.data(), res, false);
-  else if (tiles == 4 && wide) run_front<4, true>(p, b, A, Lb.data(), Ub.data(), res, false);
-  else if (tiles == 4) run_front<4, false>(p, b, A, Lb.data(), Ub.data(), res, true);
-  else if (tiles == 3) run_front<3, false>(p, b, A, Lb.data(), Ub.data(), res, true);
-  else run_front<2, false>(p, b, A, Lb.data(), Ub.data(), res, true);
+  if (tiles == 5) run_front<5, true, W>(p, b, A, Lb.data(), Ub.data(), res, false);
+  else if (tiles == 4 && wide) run_front<4, true, W>(p, b, A, Lb.data(), Ub.data(), res, false);
+  else if (tiles == 4) run_front<4, false, W>(p, b, A, Lb.data(), Ub.data(), res, true);
+  else if (tiles == 3) run_front<3, false, W>(p, b, A, Lb.data(), Ub.data(), res, true);
+  else run_front<2, false, W>(p, b, A, Lb.data(), Ub.data(), res, true);
   std::memcpy(L, Lb.data(), Lb.size() * 8);
   std::memcpy(U, Ub.data(), (size_t)(b + 1) * (b + 2) / 2 * 8);
   if (not_pd) *not_pd = res[2];
   if (counts) { counts[0] = w.n_readlane / pps_emu::kLanes; counts[1] = w.n_mfma / pps_emu::kLanes; counts[2] = w.n_barrier / pps_emu::kLanes; }
   return 0;
+}
+
+// W = 8: what the r5 / general / level kernels run; W = 4: the register-only band kernels (one pivot block per panel step)
+extern "C" int emu_front_factor(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd, long long* counts) {
+  return front_factor_w<8>(tiles, strip, p, b, A, L, U, not_pd, counts);
+}
+extern "C" int emu_front_factor_w4(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd, long long* counts) {
+  return front_factor_w<4>(tiles, strip, p, b, A, L, U, not_pd, counts);
 }

@@ -23,13 +23,14 @@ def emu():
                                "-I" + os.path.join(ROOT, "pop_up_slam_amd", "csrc"), src, "-o", out])
     lib = C.CDLL(out)
     lib.emu_front_factor.argtypes = [C.c_int] * 4 + [_dp, _dp, _dp, _dp, C.POINTER(C.c_longlong)]
+    lib.emu_front_factor_w4.argtypes = lib.emu_front_factor.argtypes
 
-    def run(tri, p, b, tiles=0, strip=False):
+    def run(tri, p, b, tiles=0, strip=False, w=8):
         fa = p + b + 1
         a = np.ascontiguousarray(tri, dtype=np.float64)
         assert a.size == fa * (fa + 1) // 2
         L = np.zeros((fa, p)); U = np.zeros((b + 1) * (b + 2) // 2); bad = C.c_double(); cnt = (C.c_longlong * 3)()
-        rc = lib.emu_front_factor(tiles, int(strip), p, b, a.ctypes.data_as(_dp), L.ctypes.data_as(_dp), U.ctypes.data_as(_dp), C.byref(bad), cnt)
+        rc = (lib.emu_front_factor if w == 8 else lib.emu_front_factor_w4)(tiles, int(strip), p, b, a.ctypes.data_as(_dp), L.ctypes.data_as(_dp), U.ctypes.data_as(_dp), C.byref(bad), cnt)
         if rc != 0:
             raise ValueError(rc)
         return L, U, bad.value, list(cnt)
@@ -47,10 +48,10 @@ def _front(p, b, seed):
     return H, rhs, tri
 
 
-def _check(run, p, b, tiles, strip, seed=0):
+def _check(run, p, b, tiles, strip, seed=0, w=8):
     H, rhs, tri = _front(p, b, seed)
     f = p + b
-    L, U, bad, cnt = run(tri, p, b, tiles, strip)
+    L, U, bad, cnt = run(tri, p, b, tiles, strip, w)
     assert bad == 0.0
     LA = np.linalg.cholesky(H[:p, :p])
     LB = np.linalg.solve(LA, H[p:, :p].T).T
@@ -89,6 +90,16 @@ def test_fronts_of_65_to_80_rows_both_ways(emu):
     for p, b in [(4, 61), (6, 70), (8, 70), (13, 60), (21, 50), (27, 52), (24, 55), (48, 31), (60, 19), (64, 15)]:
         _check(emu, p, b, 5, False, seed=p)
         _check(emu, p, b, 4, True, seed=p)
+
+
+def test_four_column_panels(emu):
+    """the register-only band kernels run the same code with one pivot block per panel step (PPS_PANEL_W_BAND = 4: a lone wave per
+    SIMD is bound by the pivot chain, and two 4-column steps are shorter than one 8-column step there)"""
+    for p, b in [(1, 2), (4, 8), (6, 8), (13, 0), (15, 33), (18, 30), (27, 36), (33, 30), (48, 15), (63, 0)]:
+        _check(emu, p, b, 0, False, seed=p, w=4)
+    for p, b in [(6, 70), (21, 50), (48, 31), (64, 15)]:
+        _check(emu, p, b, 5, False, seed=p, w=4)
+        _check(emu, p, b, 4, True, seed=p, w=4)
 
 
 def test_cross_lane_operations_per_front(emu):
