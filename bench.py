@@ -128,8 +128,8 @@ def cpu_baseline(spec, budget_s=12.0, optimised=False, threads=1, min_runs=5, ma
 C4_SEEDS = [42, 135, 110, 143, 225, 154, 169, 185]
 
 
-def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisation, k1_bytes, torch, k3_bytes=0):
-    """G in {1, 8, 64, 128} C4 timing graphs (seeds cycle through C4_SEEDS) solved by pps_multi_optimize from their initial
+def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisation, k1_bytes, torch, k3_bytes=0, g_list=None):
+    """G in {1, 8, 64, 128} (g_list) C4 timing graphs (seeds cycle through C4_SEEDS) solved by pps_multi_optimize from their initial
     estimates; per graph the chi2 / iteration count must equal the single-handle solve of the same seed."""
     specs = {sd: synth.corridor(seed=sd) for sd in C4_SEEDS}
     single = {}
@@ -137,7 +137,7 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         g1 = P.Graph(device=device, jacobian_mode=mode); sp.replay(g1)
         single[sd] = (g1.batch_optimize(), g1.chi2()); g1.close()
     res = {}
-    for G in tuple(int(x) for x in os.environ.get("PPS_BENCH_MULTI_G", "1,8,64,128").split(",")):
+    for G in (g_list or tuple(int(x) for x in os.environ.get("PPS_BENCH_MULTI_G", "1,8,64,128").split(","))):
         gs = []
         for k in range(G):
             gk = P.Graph(device=device, jacobian_mode=mode)
@@ -190,6 +190,28 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         for gk in gs:
             gk.close()
     return res
+
+
+def factorisation_work(A):
+    """flops of one multifrontal factorisation (right-looking partial Cholesky of every front incl. the rhs row) and its algorithmic
+    bytes: front-ordered H + targets 12 B per entry, children's update matrices + targets 12 B per entry read and 8 B written,
+    factor panels 8 B per entry written (SURVEY 8(d) / DESIGN section 5)"""
+    fl = 0
+    for p_, b_ in zip(A["f_p"].tolist(), A["f_b"].tolist()):
+        fa = p_ + b_ + 1
+        for k in range(p_):
+            fl += (fa - k - 1) * (fa - k) + (fa - k - 1)
+    nbytes = int(A["f_el_off"][-1]) * 12 + int(A["f_ea_off"][-1]) * 20 + int(A["L_size"]) * 8
+    return fl, nbytes
+
+
+def gather_objects(dist, obj, world):
+    """every rank's object on every rank (outside any timed region; the data path has no collective)"""
+    if dist is None:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
 
 
 def rank_seed(rank):
@@ -326,28 +348,45 @@ def main():
 
     elapsed, total_iters = aggregate(dist, elapsed, iters, "cpu" if shared else "cuda")
 
+    # N > 1 (BASELINE config 4 / north_star: "graphs/sec and achieved-HBM-fraction at 1/2/4/8 GPUs"): every rank also runs the
+    # many-graphs-per-launch form on ITS device -- G = 8 (config 4's size) and G = 128 (where one GPU saturates) -- and rank 0
+    # adds the graphs/s up and reports the per-rank roofline fractions.  No collective on the data path: the ranks meet at a
+    # barrier before and after, and exchange their result dictionaries afterwards.
+    multi_ranks = None
+    if world > 1:
+        cnt_r = spec.counts()
+        k1_bytes_r = cnt_r[synth.F_PLANE_OBS] * B_PLANE_EDGE + cnt_r[synth.F_ODOMETRY] * B_ODO_EDGE
+        fl_r, k3_bytes_r = factorisation_work(g.analysis_dump())
+        g_list = tuple(int(x) for x in os.environ.get("PPS_BENCH_MULTI_G", "8,128").split(","))
+        barrier()
+        mine = multi_graph_bench(P, synth, local_rank, mode, args, spec, fl_r, k1_bytes_r, torch, k3_bytes_r, g_list=g_list)
+        barrier()
+        multi_ranks = gather_objects(dist, mine, world)
+
     if rank == 0:
         counts = spec.counts()
         n_obs, n_odo = counts[synth.F_PLANE_OBS], counts[synth.F_ODOMETRY]
         bytes_per_launch = n_obs * B_PLANE_EDGE + n_odo * B_ODO_EDGE
-        k1_pairs = k1_time / max(1, k1_launches)          # event pair around every launch inside the timed solves
+        # K1 INSIDE a solve: every launch of one extra solve is made with hipExtLaunchKernelGGL, whose start / stop events carry
+        # the dispatch's own begin / end timestamps (what rocprofv3 reports for the kernel: profiles/r4_kernel_stats_c2.txt)
+        k1_in_solve = k1_time / max(1, k1_launches)
         g.restore_state()
-        k1_avg = g.time_linearize(mode, 400)                # 400 back-to-back launches between two events
-        achieved = bytes_per_launch / k1_avg / 1e9 if k1_avg > 0 else 0.0
+        k1_replay = g.time_linearize(mode, 400)             # 400 back-to-back launches between two events: hot caches
+        achieved = bytes_per_launch / k1_in_solve / 1e9 if k1_in_solve > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "kernel": "k_linearize_lanes" if mode == P.JAC_NUMERIC else "k_linearize<1,0>+<1,1>",
-                    "launches": 400, "avg_launch_us": k1_avg * 1e6,
-                    "in_solve_event_pairs": {"launches": k1_launches, "avg_us": k1_pairs * 1e6},
+                    "launches": k1_launches, "avg_launch_us": k1_in_solve * 1e6,
+                    "replay_avg_launch_us": k1_replay * 1e6, "replay_launches": 400,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "note": "K1 of the C2 graph on the solver's stream: 400 back-to-back launches between two HIP events "
-                            "(rocprofv3 of this command: profiles/r3_kernel_stats_bench.txt, k_linearize_lanes -- its mean also "
-                            "covers the launches of the other graph sizes the bench runs; inside a C2 solve, where the state has "
-                            "just been rewritten, a launch takes 10.6 us: profiles/r3_timeline_c2.txt; an event pair around "
-                            "every single launch of one extra solve, in_solve_event_pairs, also measures the event handling "
-                            "itself). One C2 "
-                            "graph is 2.8 MB per sweep: cache-resident and latency bound, so HBM traffic is not meaningful "
-                            "here (traffic: null); see roofline_batched for the same kernel family over > 256 MB"}
+                    "note": "K1 of the C2 graph inside an LM solve, on the solver's stream: mean dispatch duration (start / stop "
+                            "events of hipExtLaunchKernelGGL = the kernel's own begin / end timestamps) over every sweep of one "
+                            "solve; the same kernel in profiles/r4_kernel_stats_c2.txt (rocprofv3 of tools/timeline_c2.py, C2 "
+                            "only).  replay_avg_launch_us: 400 back-to-back launches between two events (hot caches, the more "
+                            "flattering figure; not used for frac).  One C2 graph is 2.8 MB per sweep: cache-resident and "
+                            "latency bound, so HBM traffic is not meaningful here (traffic: null); see roofline_batched for "
+                            "the same kernel family over > 256 MB"}
+        dual_factor_us = 1e6 * st["t_factor"] / max(1, st["n_factorize"] // 2)     # the same solve: factor launches of the dual loop
         # batched variant: replicate the edge arrays until one sweep moves > 256 MB; the plane-edge launch
         # (5 of every 6 factors) is the dominant kernel, the odometry launch is reported next to it
         reps = args.batched_replicas or int(np.ceil(300e6 / bytes_per_launch))
@@ -393,6 +432,26 @@ def main():
             "launches_per_lm_iteration": st["n_launches"] / max(1, st["lm_iterations"]), "launches_per_solve": st["n_launches"],
             "roofline": roofline, "roofline_batched": roofline_batched,
         }
+        if multi_ranks is not None:
+            # whole-job figures of the many-graphs-per-launch form: graphs/s added up over the ranks (every rank ran the same G
+            # graphs on its own device between the same two barriers), roofline fractions as the range over the ranks
+            agg = {}
+            for G in multi_ranks[0]:
+                per = [mr[G] for mr in multi_ranks]
+                ent = {"graphs_per_rank": int(G), "graphs_per_sec": float(sum(p_["graphs_per_sec"] for p_ in per)),
+                       "value": float(sum(p_["value"] for p_ in per)), "unit": "LM iters/s",
+                       "graphs_per_sec_per_rank": [p_["graphs_per_sec"] for p_ in per],
+                       "bit_identical_to_single_handle": all(p_["bit_identical_to_single_handle"] for p_ in per),
+                       "same_iteration_counts": all(p_["same_iteration_counts"] for p_ in per)}
+                for key in ("roofline_k1", "roofline_k3_hbm", "roofline_k3"):
+                    fr = [p_[key]["frac"] for p_ in per if key in p_]
+                    if fr:
+                        ent[key] = {"bound": per[0][key]["bound"], "peak": per[0][key]["peak"], "unit": per[0][key]["unit"],
+                                    "frac_min": min(fr), "frac_max": max(fr), "achieved_per_rank": [p_[key]["achieved"] for p_ in per if key in p_]}
+                agg[G] = ent
+            out["multi_graph_per_gpu"] = agg
+            out["config"]["scale_line"] = ("the SCALE curve of north_star's quantities is multi_graph_per_gpu['128'].graphs_per_sec (and ['8'], config 4's "
+                                           "size) with its roofline_k1 / roofline_k3_hbm fractions; `value` stays the BASELINE metric on single handles")
         if world == 1:
             # the closed-form Jacobian mode on the same graph (not the reference's arithmetic; reported, not the headline)
             other = P.JAC_ANALYTIC if mode == P.JAC_NUMERIC else P.JAC_NUMERIC
@@ -414,19 +473,23 @@ def main():
             # fp64 MFMA peak.  The fronts are <= 51 rows on a 10-level tree, so this is a dependency chain (tree depth x
             # per-front latency), not a throughput kernel -- the fraction says how far from a compute bound it sits.
             A = g.analysis_dump()
-            fl = 0
-            for p_, b_ in zip(A["f_p"].tolist(), A["f_b"].tolist()):
-                fa = p_ + b_ + 1
-                for k in range(p_):
-                    fl += (fa - k - 1) * (fa - k) + (fa - k - 1)
+            fl, k3_bytes_c2 = factorisation_work(A)
             g.restore_state(); g.set_profiling(2); g.batch_optimize(); st2 = g.stats(); g.set_profiling(0)
             t_fac = st2["t_factor"] / max(1, st2["n_factorize"])
             out["roofline_k3"] = {"bound": "mfma", "kernel": "k_band_factor (one factorisation = %d launches)" % int(A["n_stages"]),
-                                  "achieved": fl / t_fac / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / t_fac / 1e12 / 78.6,
-                                  "flops_per_factorisation": fl, "us_per_factorisation": 1e6 * t_fac,
-                                  "us_per_backsolve": 1e6 * st2["t_backsolve"] / max(1, st2["n_factorize"]),
-                                  "note": "latency bound by construction (512 fronts of <= 51 rows, 10 levels); peak = fp64 matrix "
-                                          "rate of MI355X (public spec; the CDNA4 guide lists none)"}
+                                  "achieved": 2 * fl / (dual_factor_us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                  "frac": 2 * fl / (dual_factor_us * 1e-6) / 1e12 / 78.6,
+                                  "flops_per_factorisation": fl, "us_per_pair_of_factorisations": dual_factor_us,
+                                  "one_step_loop": {"us_per_factorisation": 1e6 * t_fac, "frac": fl / t_fac / 1e12 / 78.6,
+                                                    "us_per_backsolve": 1e6 * st2["t_backsolve"] / max(1, st2["n_factorize"])},
+                                  "hbm": {"bound": "hbm", "achieved": 2 * k3_bytes_c2 / (dual_factor_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": 2 * k3_bytes_c2 / (dual_factor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_factorisation": k3_bytes_c2},
+                                  "note": "the shipped dual-lambda loop factors H for lambda and lambda * 10 in the same launches: "
+                                          "us_per_pair_of_factorisations = sum of the dispatch durations of the factor launches of one "
+                                          "solve / number of launch sets (profiles/r4_kernel_stats_c2.txt: k_band_factor<true>, %d "
+                                          "launches per set); one_step_loop = the profiling loop with one factorisation at a time.  "
+                                          "Latency bound by construction (511 fronts of <= 51 rows, 9 levels); peak = fp64 matrix "
+                                          "rate of MI355X (public spec; the CDNA4 guide lists none)" % int(A["n_stages"])}
             # headroom on one GPU: one C2 solve keeps a few dozen of the 256 CUs busy, so independent graphs (one handle
             # + one host thread each, no shared state) overlap.  Reported next to the headline, which stays the
             # one-graph-per-GPU configuration BASELINE.json names.
@@ -459,9 +522,8 @@ def main():
         if world == 1:
             # pps_multi: G independent C2 graphs per launch (BASELINE config 4 on ONE device; north_star's graphs/sec).  The
             # headline above stays the single graph BASELINE.json's metric is quoted on.
-            k3_bytes = int(A["f_el_off"][-1]) * 12 + int(A["f_ea_off"][-1]) * 20 + int(A["L_size"]) * 8
             out["multi_graph_one_gpu"] = multi_graph_bench(P, synth, local_rank, mode, args, spec, out["roofline_k3"]["flops_per_factorisation"],
-                                                           bytes_per_launch, torch, k3_bytes)
+                                                           bytes_per_launch, torch, k3_bytes_c2)
         if world == 1 and not args.no_c3:
             # BASELINE config 3: 10 000 poses / 2 000 planes / 60 000 plane edges (one 31.9 MB Jacobian sweep per linearisation)
             spec3 = synth.manhattan_rooms()
@@ -477,6 +539,10 @@ def main():
             g3.restore_state(); g3.set_profiling(2); g3.batch_optimize(); s3 = g3.stats(); g3.set_profiling(0)
             cnt3 = spec3.counts()
             bytes3 = cnt3[synth.F_PLANE_OBS] * B_PLANE_EDGE + cnt3[synth.F_ODOMETRY] * B_ODO_EDGE
+            g3.restore_state(); g3.set_profiling(1); g3.batch_optimize(); s3d = g3.stats(); g3.set_profiling(0)      # dual loop, dispatch timestamps
+            fl3, k3_bytes3 = factorisation_work(g3.analysis_dump())
+            pair3 = s3d["t_factor"] / max(1, s3d["n_factorize"] // 2)
+            k1_3_solve = s3d["t_linearize"] / max(1, s3d["n_linearize"])
             g3.restore_state()
             k1_3 = g3.time_linearize(mode, 100)
             nf3, nl3 = max(1, s3["n_factorize"]), max(1, s3["n_linearize"])
@@ -487,8 +553,16 @@ def main():
                          "phase_us_per_call": {"k1": 1e6 * s3["t_linearize"] / nl3, "k2": 1e6 * s3["t_assemble"] / nl3, "factor": 1e6 * s3["t_factor"] / nf3,
                                                "backsolve": 1e6 * s3["t_backsolve"] / nf3, "trial": 1e6 * s3["t_retract_chi2"] / nf3},
                          "roofline_k1": {"bound": "hbm", "kernel": "k_linearize_lanes" if mode == P.JAC_NUMERIC else "k_linearize<1,*>",
-                                         "achieved": bytes3 / k1_3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes3 / k1_3 / 1e9 / HBM_PEAK_GBS,
-                                         "algorithmic_bytes_per_launch": bytes3, "avg_launch_us": 1e6 * k1_3, "launches": 100, "traffic": None}}
+                                         "achieved": bytes3 / k1_3_solve / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes3 / k1_3_solve / 1e9 / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_launch": bytes3, "avg_launch_us": 1e6 * k1_3_solve, "launches": s3d["n_linearize"],
+                                         "replay_avg_launch_us": 1e6 * k1_3, "traffic": None,
+                                         "note": "inside the solve (dispatch timestamps); profiles/r4_kernel_stats_c3.txt"},
+                         "roofline_k3_hbm": {"bound": "hbm", "kernel": "k_band_factor<true> + k_band_factor_r5 (two factorisations per launch set)",
+                                             "achieved": 2 * k3_bytes3 / pair3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": 2 * k3_bytes3 / pair3 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_factorisation": k3_bytes3,
+                                             "us_per_pair_of_factorisations": 1e6 * pair3, "traffic": None},
+                         "roofline_k3": {"bound": "mfma", "achieved": 2 * fl3 / pair3 / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": 2 * fl3 / pair3 / 1e12 / 78.6,
+                                         "flops_per_factorisation": fl3}}
             g3.close()
         if world == 1 and not args.no_c5:
             # BASELINE config 5: 1000 synthetic 640x480 frames, pop-up (half resolution) fused with the incremental solve

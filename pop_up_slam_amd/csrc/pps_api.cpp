@@ -51,6 +51,7 @@ int pps_graph_destroy(pps_graph* g) {
     if (g->ev[0]) (void)hipEventDestroy(g->ev[0]);
     if (g->ev[1]) (void)hipEventDestroy(g->ev[1]);
     for (hipEvent_t e : g->k1_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->fk_events) (void)hipEventDestroy(e);
     if (g->d_lms) (void)hipFree(g->d_lms);
     if (g->d_queries) (void)hipFree(g->d_queries);
     if (g->d_results) (void)hipFree(g->d_results);

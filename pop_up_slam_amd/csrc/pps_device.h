@@ -100,11 +100,19 @@ struct LinGuard {
 unsigned long long launch_count();
 void count_launch();
 #define PPS_LAUNCH(...) do { ::pps::count_launch(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+// the same with a start / stop event that take the dispatch's own timestamps (hipExtLaunchKernelGGL; include <hip/hip_ext.h>)
+#define PPS_LAUNCH_EV(ev0, ev1, kernel, grid, block, lds, st, ...)                                                     \
+  do {                                                                                                                 \
+    ::pps::count_launch();                                                                                             \
+    if (ev0) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev0, ev1, 0, __VA_ARGS__);                            \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                                \
+  } while (0)
 
 // fills ac[4] = {a_rot, c_rot, a_plane, c_plane} for the current device (one tiny kernel + a synchronous copy the first time)
 hipError_t step_constants(double ac[4]);
 // All launchers enqueue on `st` and return the HIP error of the launch.
-hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard = nullptr);
+hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard = nullptr, hipEvent_t ev0 = nullptr,
+                            hipEvent_t ev1 = nullptr);      // ev0 / ev1: start / stop of the sweep itself (profiling level 1)
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard = nullptr);
 hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
                                hipStream_t st);
@@ -122,7 +130,7 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
 hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
                              const DualAlt* alt = nullptr);
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                                   hipStream_t st);
+                                   hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);      // ev0 / ev1: the dispatch's start / stop (profiling level 1)
 // both trials of a dual solve: out_k <- base (+) delta_k, chi2 and |delta|^2 of each into its own result record
 hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,

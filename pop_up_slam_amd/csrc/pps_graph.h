@@ -143,6 +143,8 @@ struct pps_graph {
   unsigned long long launches0 = 0;   // launch_count() at the start of the solve call
   std::vector<char> k1_skip;          // per K1 event pair: not a linearisation that ran
   std::vector<hipEvent_t> k1_events;   // pairs (start, stop) recorded around the sweep
+  std::vector<hipEvent_t> fk_events;   // profiling level 1: start / stop of every factor launch of the dual loop (dispatch timestamps)
+  int fk_used = 0;
   int k1_used = 0;
   // registered frames (pps_frames_add): 2-D ground segments that re-derive edge measurements on the device
   float frames_invK[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

@@ -9,6 +9,8 @@
 #include <atomic>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "pps_kcommon.h"
 #include "pps_regtile.h"
 #include "pps_front_reg.h"
@@ -793,7 +795,7 @@ static hipError_t ensure_band_attrs() {
 
 // one launcher for both: ny = 1 (alt unused) or 2 (dual)
 static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt, int ny, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                                          hipStream_t st) {
+                                          hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   if (grp_count == 0) return hipSuccess;
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const bool reg_only = max_front + 1 <= kRegRows && !(ny == 2 && d.trace != nullptr);     // (a traced dual solve runs the general kernel)
@@ -802,12 +804,12 @@ static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt,
   if (reg_only && d.trace != nullptr)      // phase trace of the register-only kernel
     PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (reg_only)
-    PPS_LAUNCH(k_band_factor<true>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+    PPS_LAUNCH_EV(ev0, ev1, k_band_factor<true>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
     const int nw5 = nwaves < 4 ? nwaves : 4;                // (one wave per SIMD: see k_band_factor_r5)
-    PPS_LAUNCH(k_band_factor_r5, dim3(grp_count, ny), dim3(64 * nw5), (size_t)per_wave * nw5 * sizeof(double), st, d, alt, grp_begin, lambda, per_wave);
+    PPS_LAUNCH_EV(ev0, ev1, k_band_factor_r5, dim3(grp_count, ny), dim3(64 * nw5), (size_t)per_wave * nw5 * sizeof(double), st, d, alt, grp_begin, lambda, per_wave);
   } else
-    PPS_LAUNCH(k_band_factor<false>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+    PPS_LAUNCH_EV(ev0, ev1, k_band_factor<false>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   return hipGetLastError();
 }
 
@@ -816,8 +818,8 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
 }
 
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                                   hipStream_t st) {
-  return launch_band_factor_impl(d, alt, 2, grp_begin, grp_count, nwaves, max_front, lambda, st);
+                                   hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  return launch_band_factor_impl(d, alt, 2, grp_begin, grp_count, nwaves, max_front, lambda, st, ev0, ev1);
 }
 
 size_t band_solve_lds_bytes(int max_panel) { return (size_t)(kBandMaxRows + max_panel) * sizeof(double); }   // xb + the factor panel

@@ -32,9 +32,7 @@ int do_linearize(pps_graph* g, const LinGuard* guard = nullptr) {
     }
     g->k1_skip.resize(g->k1_events.size() / 2, 0);
     g->k1_skip[g->k1_used / 2] = 0;
-    HIP_TRY(g, hipEventRecord(g->k1_events[g->k1_used], g->stream));
-    HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream, guard));
-    HIP_TRY(g, hipEventRecord(g->k1_events[g->k1_used + 1], g->stream));
+    HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream, guard, g->k1_events[g->k1_used], g->k1_events[g->k1_used + 1]));
     g->k1_used += 2;
   } else
   { PhaseTimer t(g, &g->stats.t_linearize); HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream, guard)); }
@@ -175,6 +173,11 @@ void resolve_k1_events(pps_graph* g) {
     if (hipEventElapsedTime(&ms, g->k1_events[k], g->k1_events[k + 1]) == hipSuccess) g->stats.t_linearize += 1e-3 * ms;
   }
   g->k1_used = 0;
+  for (int k = 0; k + 1 < g->fk_used; k += 2) {                // factor launches of the dual loop (two factorisations per launch)
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g->fk_events[k], g->fk_events[k + 1]) == hipSuccess) g->stats.t_factor += 1e-3 * ms;
+  }
+  g->fk_used = 0;
 }
 
 void reset_solve_stats(pps_graph* g) {
@@ -292,9 +295,15 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   auto enqueue_dual = [&](double lam) -> int {
     DualAlt alt{g->spec_L, g->spec_U, g->spec_delta, g->spec_result, g->spec_chi2_partials, g->spec_dn_partials, g->spec_ticket,
                 lam * prop.lm_lambda_factor};
-    for (int st = 0; st < A.n_stages; st++)
+    for (int st = 0; st < A.n_stages; st++) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (g->profiling == 1) {                                     // the launch's own start / stop: resolve_k1_events sums them into t_factor
+        if (g->fk_used + 2 > (int)g->fk_events.size()) for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->fk_events.push_back(e); }
+        e0 = g->fk_events[g->fk_used]; e1 = g->fk_events[g->fk_used + 1]; g->fk_used += 2;
+      }
       HIP_TRY(g, launch_band_factor_dual(d, alt, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
-                                         A.stage_max_front[st], lam, g->stream));
+                                         A.stage_max_front[st], lam, g->stream, e0, e1));
+    }
     for (int st = A.n_stages - 1; st >= 0; st--)
       HIP_TRY(g, launch_band_solve(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
                                    g->stage_max_panel[st], g->stage_max_grp_fronts[st], g->stream, &alt));
