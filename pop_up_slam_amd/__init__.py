@@ -509,6 +509,8 @@ def parse_analysis_dump(buf):
         out[name] = vec()
     for name in _DUMP_VECTORS[-2:]:
         out[name] = vec()
+    out["factor_poff"] = vec()                       # offset of every factor's product record (round 4)
+    out["P_size"] = int(buf[k]); k += 1
     assert k == len(buf), (k, len(buf))
     return out
 

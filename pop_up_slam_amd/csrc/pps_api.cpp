@@ -370,6 +370,10 @@ int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed) 
   int64_t base[4]; j_bases(g, base, nullptr);
   v.push_back((int32_t)g->factors.size());
   for (const auto& f : g->factors) v.push_back(f.deleted ? -1 : (int32_t)(base[f.type] + (int64_t)f.slot * kJSize[f.type]));
+  int64_t pbase[4]; p_bases(g, pbase, nullptr);                  // ... and factor id -> offset of its product record
+  v.push_back((int32_t)g->factors.size());
+  for (const auto& f : g->factors) v.push_back(f.deleted ? -1 : (int32_t)(pbase[f.type] + (int64_t)f.slot * kPSize[f.type]));
+  v.push_back((int32_t)g->an.P_size);
   *needed = (int64_t)v.size();
   if (out && cap >= (int64_t)v.size()) memcpy(out, v.data(), v.size() * sizeof(int32_t));
   return PPS_OK;

@@ -37,6 +37,9 @@ struct DevGraph {
   // ---- linear system ----
   double* J = nullptr;
   int64_t joff_obs = 0, joff_odo = 0, joff_pp = 0, joff_lp = 0;
+  // product records of the plane observations (pps_symbolic.h: kPSize): slot i at P + poff_obs + 54 i = [J_p' J_p 36 | -J_p' r 6 | J_l' J_l 9 | -J_l' r 3]
+  double* P = nullptr;
+  int64_t poff_obs = 0;
   double* H = nullptr;       // segment slots
   double* L = nullptr;
   double* U = nullptr;
@@ -68,6 +71,11 @@ struct DevGraph {
   int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
   int* obs_dir = nullptr;                                   // direct (pose, plane) blocks: 3 ints per plane-observation slot (pps_symbolic.h)
   int* nd_segs = nullptr; int n_nd_segs = 0;                // H segments that are not direct
+  // K2 work lists (round 4): the non-direct segments of single-segment blocks (one wave each) and, per block of several
+  // segments, its first segment (one workgroup each: the partial sums meet in LDS)
+  int* k2_single = nullptr; int n_k2_single = 0;
+  int* k2_multi = nullptr; int n_k2_multi = 0;                // pairs: first segment of a chunk of <= 16 segments | segments in the chunk + (1 << 16 when it is the whole block)
+  int* k2_finish = nullptr; int n_k2_finish = 0;              // first segment of every block of more than 16 segments (its chunks' partial sums are added by k_hfinish)
   int *cls_off = nullptr, *cls_fronts = nullptr;             // level-per-launch lists (pps_symbolic.h)
   // ---- reductions / status ----
   double* chi2_partials = nullptr;   // one per block of the residual sweep
@@ -113,7 +121,9 @@ hipError_t step_constants(double ac[4]);
 // All launchers enqueue on `st` and return the HIP error of the launch.
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard = nullptr, hipEvent_t ev0 = nullptr,
                             hipEvent_t ev1 = nullptr);      // ev0 / ev1: start / stop of the sweep itself (profiling level 1)
-hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard = nullptr);
+// products: K1 wrote the plane observations' product records (its lane form does; see k1_lane_form)
+hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard = nullptr, bool products = true);
+bool k1_lane_form(const DevGraph& d, int mode);      // which form launch_linearize takes for this graph and Jacobian mode
 hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
                                hipStream_t st);
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);
@@ -205,6 +215,7 @@ struct BatchArgs {
 struct BatchGeom {
   int lin_blocks = 0, lin_obs_blocks = 0, lin_rest_blocks = 0, repop_blocks = 0;
   int hblocks = 0, hblocks_nd = 0, hreduce = 0, retract = 0, chi2 = 0;
+  int k2_blocks = 0, k2_finish = 0;   // workgroups of the K2 launch: maximum over the chunk's graphs of ceil(single / 16) + multi; blocks of its second pass
   long long n_factors_total = 0;
   bool lin_thread_form = false;   // numeric K1 as one thread per factor (many graphs) instead of 32 lanes per factor
   int n_stages = 0;
@@ -221,7 +232,7 @@ struct BatchGeom {
   int stage_max_front[32] = {0};    // largest front (scalars, without the rhs row) of the stage over the chunk's graphs
 };
 hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mode, hipStream_t st);   // K1 of the BF_RELIN graphs (mode | 2: thread-per-factor form)
-hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st);               // K2 of the BF_RELIN graphs
+hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st, bool products);   // K2 of the BF_RELIN graphs (products: their K1 ran in the lane form)
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st);        // chi2 at lin -> results[8 b + 4 slot]
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor = nullptr);   // K3, lambda per graph
 hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // not-PD flags of both factorisations cleared

@@ -203,6 +203,7 @@ int verify_uploads(pps_graph* g, const char* where);
 int ensure_device(pps_graph* g);
 int64_t j_capacity(int64_t n);
 void j_bases(const pps_graph* g, int64_t base[4], int64_t* total);
+void p_bases(const pps_graph* g, int64_t base[4], int64_t* total);      // product records (pps_symbolic.h: kPSize), same slab capacities
 int run_analysis(pps_graph* g);
 int state_pin_reserve(pps_graph* g, size_t doubles);
 int linpoint_from_estimate(pps_graph* g);

@@ -91,6 +91,11 @@ __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double
   body_linearize_repop(d, pose, plane, blockIdx.x, repop_lds);
 }
 
+// PPS_K1_THREAD_FORM=1 forces the thread-per-factor kernels on small graphs (parity tests of that form)
+bool k1_lane_form(const DevGraph& d, int mode) {
+  return mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !getenv("PPS_K1_THREAD_FORM");
+}
+
 // ev0 / ev1 (profiling level 1): the launch is made with hipExtLaunchKernelGGL, whose start / stop events take the DISPATCH's own
 // begin / end timestamps -- what rocprofv3 reports as the kernel's duration -- instead of two event records around the launch,
 // which also time the event packets themselves (13.6 us against 10.6 us for the C2 sweep inside a solve).
@@ -106,8 +111,7 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   if (nb == 0) return hipSuccess;
   const double* pose = at_estimate ? d.pose_est : d.pose_lin;
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
-  // PPS_K1_THREAD_FORM=1 forces the thread-per-factor kernels on small graphs (parity tests of that form)
-  if (mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !getenv("PPS_K1_THREAD_FORM")) {
+  if (k1_lane_form(d, mode)) {
     const int lb_obs = cdiv(d.n_obs_fixed, kObsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
               lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
     if (ev0 && ev1) {
@@ -123,12 +127,14 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   if (ev0) { const hipError_t e = hipEventRecord(ev0, st); if (e != hipSuccess) return e; }      // (two launches: the pair goes around both)
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   const int nb_rest = nb - nb_obs;
+  DevGraph dn = d;
+  dn.P = nullptr;                       // the thread-per-factor form writes Jacobians (and the direct blocks) only: K2 multiplies
   if (mode == 1) {
-    if (nb_obs) PPS_LAUNCH((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
-    if (nb_rest) PPS_LAUNCH((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_obs) PPS_LAUNCH((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, dn, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_rest) PPS_LAUNCH((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, dn, pose, plane, nb_obs, nb_odo, nb_pp, gd);
   } else {
-    if (nb_obs) PPS_LAUNCH(k_linearize_obs_numeric, dim3(nb_obs), dim3(kLinBlock), lds0, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
-    if (nb_rest) PPS_LAUNCH((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, d, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_obs) PPS_LAUNCH(k_linearize_obs_numeric, dim3(nb_obs), dim3(kLinBlock), lds0, st, dn, pose, plane, nb_obs, nb_odo, nb_pp, gd);
+    if (nb_rest) PPS_LAUNCH((k_linearize<0, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, dn, pose, plane, nb_obs, nb_odo, nb_pp, gd);
   }
   if (ev1) { const hipError_t e = hipEventRecord(ev1, st); if (e != hipSuccess) return e; }
   return hipGetLastError();
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_sweep_bench_lanes(DevGraph d
   r.odo_meas = d.odo_meas + (size_t)rep * 6 * d.odo_ld; r.odo_w = d.odo_w + (size_t)rep * 21 * d.odo_ld;
   r.odo_a = d.odo_a + (size_t)rep * d.n_odo; r.odo_b = d.odo_b + (size_t)rep * d.n_odo;
   r.n_obs_fixed = d.n_obs;
-  r.obs_dir = nullptr;
+  r.obs_dir = nullptr; r.P = nullptr;
   body_linearize_lanes(r, d.pose_lin, d.plane_lin, lb_obs_per, lb_odo_per, 0, b);
 }
 

@@ -219,6 +219,31 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
         else out[18 + r * 3 + (q3 - 6)] = jc[r];
       } else if (l3 == 0) out[27 + r] = y[r];
     }
+    // The observation's PRODUCT record (pps_symbolic.h: kPSize): what it adds to the diagonal H blocks of its pose and its plane
+    // -- J_p' J_p (36, row-major), -J_p' r (6), J_l' J_l (9), -J_l' r (3) -- so that K2 only sums such records, one coalesced load per
+    // contribution, instead of gathering Jacobian columns.  The group's nine columns and the residual meet in LDS ([row][column],
+    // column 9 = r); every lane multiplies three of the 54 entries, k ascending as explicit multiply-adds.
+    if (d.P) {                                                  // (null in the sweep benchmark: Jacobians only)
+      __shared__ double prod_lds[kObsPerBlock * 32];
+      double* __restrict__ S = prod_lds + ((threadIdx.x >> 6) * kObsPerWave + g3) * 32;
+      if (l3 & 1) { S[q3] = jc[0]; S[10 + q3] = jc[1]; S[20 + q3] = jc[2]; }
+      else if (l3 == 0) { S[9] = y[0]; S[19] = y[1]; S[29] = y[2]; }
+      __builtin_amdgcn_wave_barrier();
+      double* __restrict__ Pr = d.P + d.poff_obs + (size_t)i * 54;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int e = l3 + kObsLanes * t;                       // 0 .. 56
+        int ca, cb;
+        if (e < 36) { ca = e / 6; cb = e - 6 * (e / 6); }
+        else if (e < 42) { ca = e - 36; cb = 9; }
+        else if (e < 51) { ca = 6 + (e - 42) / 3; cb = 6 + (e - 42) - 3 * ((e - 42) / 3); }
+        else { ca = 6 + (e < 54 ? e - 51 : 0); cb = 9; }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc = PPS_MAC(acc, S[10 * k + ca], S[10 * k + cb]);
+        if (e < 54) Pr[e] = cb == 9 ? -acc : acc;               // b = -J' r (isam/Jacobian.h:98)
+      }
+    }
     // The (pose, plane) block of H that this observation alone contributes to (Analysis::obs_dir) is the product of its own
     // two Jacobian blocks: lane e < 18 of the group gathers the two columns it needs from the odd lanes and writes entry e --
     // summed in the order the H-block kernel uses -- into H and into the front-ordered copy; K2 only visits the other segments.

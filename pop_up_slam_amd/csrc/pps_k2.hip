@@ -1,50 +1,61 @@
 // pps_k2.hip -- K2: block-sparse J'J / J'b reduction (cholmod_ssmult / cholmod_sdmult, isamlib/Cholesky.cpp:87-89,120).
 #include "pps_kcommon.h"
+#include "pps_symbolic.h"
 
 namespace pps {
 
 // ------------------------------------------------------------------------------------------
-// K2, latency form (one graph): one wavefront per H-block segment; lane = block entry, loop over <= seg_len contributions,
-// every lane fetching its own scalars (two contributions' loads in flight).
+// K2 (round 4): one wavefront per H-block segment, lane = block entry, up to 64 contributions per segment.
+//  * A plain plane observation -- five of every six factors -- reaches K2 as its PRODUCT record: K1 has multiplied J' J and
+//    -J' r for the two diagonal blocks it feeds (pps_k1_body.h), so a contribution is ONE coalesced load per lane and a wave keeps
+//    eight of them in flight.  (Up to round 3 every contribution was twelve strided gathers from the Jacobian: the kernel was
+//    bound by the texture-address path -- as long as K1 itself on C3.)
+//  * The other contributions (odometry, priors, re-popping edges, off-diagonal blocks K1 does not write itself) multiply the
+//    Jacobian slices as before.
+//  * A block of several segments (the ground plane: a thousand observations) is one workgroup: its sixteen waves take the
+//    segments w, w + 16, ... and the partial sums meet in LDS in a fixed order -- no second launch (k_hreduce is gone).
+// Sums are deterministic: Jacobian-based contributions first, in list order, as explicit multiply-adds; then the product records
+// in list order; partial sums of a block by wave index.  The same body serves one graph and the batches: same bits.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
-  const int slot = uni(bx * 4 + (threadIdx.x >> 6));        // position in the list of segments K1 has not written itself
-  const int lane = threadIdx.x & 63;
-  if (slot >= d.n_nd_segs) return;
-  const int seg = uni(d.nd_segs[slot]);
-  // one coalesced load of the packed segment record, fields broadcast with v_readlane
-  const int rec = d.srec[(size_t)seg * 8 + (lane & 7)];
+#ifndef PPS_K2_WAVES            // (build-time, A/B) waves per workgroup
+#define PPS_K2_WAVES 16
+#endif
+constexpr int kK2Waves = PPS_K2_WAVES;
+
+// plist: 64 ints of LDS of this wave (the offsets of the segment's product records, compacted)
+__device__ __forceinline__ double wave_segment_sum(const DevGraph& d, int rec, int4 mine, int lane, int* __restrict__ plist) {
   const int rows = __builtin_amdgcn_readlane(rec, 0), cols = __builtin_amdgcn_readlane(rec, 1), size = __builtin_amdgcn_readlane(rec, 2);
-  const int c0 = __builtin_amdgcn_readlane(rec, 3), cnt = __builtin_amdgcn_readlane(rec, 4);
-  const int hoff = __builtin_amdgcn_readlane(rec, 5), doff = __builtin_amdgcn_readlane(rec, 6), nsegb = __builtin_amdgcn_readlane(rec, 7);
-  // one contribution descriptor per lane, fetched in a single coalesced load (cnt <= 64)
-  int4 mine = make_int4(0, 0, 0, 0);
-  if (lane < cnt) mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
+  const int cnt = __builtin_amdgcn_readlane(rec, 4);
   const int rc = rows * cols;
   const bool act = lane < size;
-  // where the finished entry goes in front-gather order: does not depend on the values, so the load is issued now
-  const int dst = (act && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
   const bool is_g = lane >= rc;
-  const int i = is_g ? lane - rc : lane / cols;
-  const int j = is_g ? 0 : lane - (lane / cols) * cols;
+  const int cdiv_ = cols > 0 ? cols : 1;
+  const int i = is_g ? lane - rc : lane / cdiv_;
+  const int j = is_g ? 0 : lane - (lane / cdiv_) * cdiv_;
+  const bool isp = lane < cnt && mine.w >= kProductFlag;
+  const unsigned long long pmask = __ballot(isp);
+  unsigned long long jmask = __ballot(lane < cnt && !isp);
   const double* __restrict__ J = d.J;
   double acc = 0.0;
-  int c = 0;
-  for (; c + 2 <= cnt; c += 2) {                          // two contributions' loads in flight (64 VGPRs: 8 waves per SIMD)
+  // ---- contributions that come as Jacobian slices (odometry, priors, re-popping edges, off-diagonal blocks): two in flight ----
+  while (jmask) {                                               // (wave-uniform)
+    const int c0 = __builtin_ctzll(jmask);
+    jmask &= jmask - 1;
+    const bool two = jmask != 0;
+    const int c1 = two ? __builtin_ctzll(jmask) : c0;
+    jmask &= jmask - 1;                                         // (0 stays 0)
     double a[2][6], bb[2][6];
-    int m[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      const int cc = c + u;
+      const int cc = u ? c1 : c0;
       const int jv = __builtin_amdgcn_readlane(mine.x, cc), ju = __builtin_amdgcn_readlane(mine.y, cc);
-      const int ro = __builtin_amdgcn_readlane(mine.z, cc);
-      m[u] = __builtin_amdgcn_readlane(mine.w, cc);
+      const int ro = __builtin_amdgcn_readlane(mine.z, cc), mm = __builtin_amdgcn_readlane(mine.w, cc);
       const double* pa = J + jv + i;
       const double* pb = is_g ? J + ro : J + ju + j;
       const int sb = is_g ? 1 : cols;
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        const bool ok = act && k < m[u];
+        const bool ok = act && k < mm && (u == 0 || two);
         a[u][k] = ok ? pa[k * rows] : 0.0;
         bb[u][k] = ok ? pb[k * sb] : 0.0;
       }
@@ -54,32 +65,144 @@ __device__ __forceinline__ void body_hblocks(const DevGraph& d, int bx) {
 #pragma unroll
       for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a[u][k], bb[u][k]);
   }
-  for (; c < cnt; c++) {                                  // tail, and the single-contribution segments (most pose-plane blocks)
-    const int jv = __builtin_amdgcn_readlane(mine.x, c), ju = __builtin_amdgcn_readlane(mine.y, c);
-    const int ro = __builtin_amdgcn_readlane(mine.z, c), mm = __builtin_amdgcn_readlane(mine.w, c);
-    const double* pa = J + jv + i;
-    const double* pb = is_g ? J + ro : J + ju + j;
-    const int sb = is_g ? 1 : cols;
-    double a[6], bb[6];
+  if (is_g) acc = -acc;                                         // b = -r (isam/Jacobian.h:98); the product records carry the sign already
+  if (!act) acc = 0.0;
+  // ---- product records: one coalesced load per contribution and lane.  A small block (a plane's 12 entries) is summed by several
+  // SLICES of the wave at once -- slice s takes the records s, s + S, ... -- and the slices' sums are added in slice order. ----
+  const int np = __builtin_popcountll(pmask);
+  if (np > 0) {                                                 // (wave-uniform)
+    const int rank = __builtin_popcountll(pmask & ((1ull << lane) - 1ull));
+    if (isp) plist[rank] = mine.y;
+    __builtin_amdgcn_wave_barrier();
+    const int S = size <= 12 ? 5 : (size <= 21 ? 3 : (size <= 32 ? 2 : 1));
+    const int sl = lane / size, en = lane - sl * size;
+    const bool live = sl < S;
+    const int enc = live ? en : 0;
+    const double* __restrict__ P = d.P;
+    double pacc = 0.0;
+    for (int k0 = 0; k0 < np; k0 += 16 * S) {
+      double v[16]; bool on[16];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const bool ok = act && k < mm;
-      a[k] = ok ? pa[k * rows] : 0.0;
-      bb[k] = ok ? pb[k * sb] : 0.0;
+      for (int u = 0; u < 16; u++) {
+        const int k = k0 + sl + S * u;
+        on[u] = live && k < np;
+        const int off = plist[k < np ? k : np - 1];
+        v[u] = P[off + enc];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) pacc += on[u] ? v[u] : 0.0;
     }
-#pragma unroll
-    for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, a[k], bb[k]);
+    __builtin_amdgcn_wave_barrier();                            // (plist is rewritten by the wave's next segment)
+    double tot = pacc;
+    for (int sg = 1; sg < S; sg++) tot += __shfl(pacc, lane + sg * size, 64);      // (lanes < size: slice sg of the same entry)
+    acc += act ? tot : 0.0;
   }
-  if (!act) return;
-  if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
-  d.H[hoff + lane] = acc;
-  if (dst >= 0) d.Hf[dst] = acc;                          // final value (single-segment block): also where its front gathers it
+  return acc;
 }
 
-__global__ __launch_bounds__(256, 2) void k_hblocks(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hblocks(d, blockIdx.x); }
+__device__ __forceinline__ void seg_header(const DevGraph& d, int seg, int lane, int& rec, int4& mine) {
+  rec = d.srec[(size_t)seg * 8 + (lane & 7)];                   // one coalesced load of the packed segment record
+  const int c0 = __builtin_amdgcn_readlane(rec, 3), cnt = __builtin_amdgcn_readlane(rec, 4);
+  mine = make_int4(0, 0, 0, 0);
+  if (lane < cnt) mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];      // one contribution descriptor per lane (cnt <= 64)
+  // (no product records -- the thread-per-factor K1 writes none: every contribution multiplies its Jacobian slices)
+  if (!d.P && mine.w >= kProductFlag) { mine.w -= kProductFlag; mine.y = mine.x; }
+}
+
+__device__ __forceinline__ void body_hblocks2(const DevGraph& d, int bx) {
+  __shared__ double part[kK2Waves][64];
+  __shared__ int plist_lds[kK2Waves][64];
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int* const plist = plist_lds[wave];
+  const int nbs = (d.n_k2_single + kK2Waves - 1) / kK2Waves;
+  if (bx < nbs) {
+    const int slot = bx * kK2Waves + wave;
+    if (slot >= d.n_k2_single) return;
+    int rec; int4 mine;
+    seg_header(d, uni(d.k2_single[slot]), lane, rec, mine);
+    const int size = __builtin_amdgcn_readlane(rec, 2), hoff = __builtin_amdgcn_readlane(rec, 5), doff = __builtin_amdgcn_readlane(rec, 6);
+    // where the finished entry goes in front-gather order: does not depend on the values, so the load is issued now
+    const int dst = lane < size ? d.blk_dst[doff + lane] : -1;
+    const double acc = wave_segment_sum(d, rec, mine, lane, plist);
+    if (lane >= size) return;
+    d.H[hoff + lane] = acc;
+    if (dst >= 0) d.Hf[dst] = acc;                              // also where the block's front gathers it
+    return;
+  }
+  // a block of several segments, sixteen at a time: the chunk's waves take one segment each, the partial sums meet in LDS in wave
+  // order.  A block of at most sixteen segments (the ground plane of a thousand-pose graph) is finished here; a larger one leaves
+  // one partial sum per chunk in the slot of the chunk's first segment and k_hfinish adds those up.
+  const int b = bx - nbs;
+  if (b >= d.n_k2_multi) return;
+  const int seg0 = uni(d.k2_multi[2 * b]), info = uni(d.k2_multi[2 * b + 1]);
+  const int nsc = info & 0xffff;
+  const bool fin = (info >> 16) != 0;
+  int rec0; int4 mine0;
+  seg_header(d, seg0, lane, rec0, mine0);                       // every wave reads the chunk's first record (size, slot)
+  const int size = __builtin_amdgcn_readlane(rec0, 2), hoff = __builtin_amdgcn_readlane(rec0, 5), doff = __builtin_amdgcn_readlane(rec0, 6);
+  const int dst = (fin && wave == 0 && lane < size) ? d.blk_dst[doff + lane] : -1;
+  double acc = 0.0;
+  for (int sgi = wave; sgi < nsc; sgi += kK2Waves) {
+    int rec; int4 mine;
+    if (sgi == 0) { rec = rec0; mine = mine0; } else seg_header(d, seg0 + sgi, lane, rec, mine);
+    acc += wave_segment_sum(d, rec, mine, lane, plist);
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0 || lane >= size) return;
+  // four interleaved sums q_w = part[w] + part[w + 4] + ..., combined as (q0 + q1) + (q2 + q3): for a chunk (<= 16 segments, one per
+  // wave) the order in which kb_hreduce adds the segments of a block -- the two forms of K2 give the same bits
+  const int nw = nsc < kK2Waves ? nsc : kK2Waves;
+  double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    for (int v = w; v < nw; v += 4) q[w] += part[v][lane];
+  const double tot = (q[0] + q[1]) + (q[2] + q[3]);
+  d.H[hoff + lane] = tot;
+  if (dst >= 0) d.Hf[dst] = tot;
+}
+
+// the blocks of more than kK2Chunk segments: their chunks' partial sums (slot of every kK2Chunk-th segment) added in chunk order
+constexpr int kK2Chunk = 16;
+__device__ __forceinline__ void body_hfinish(const DevGraph& d, int bx) {
+  const int lane = threadIdx.x & 63;
+  const int seg0 = uni(d.k2_finish[bx]);
+  const int rec = d.srec[(size_t)seg0 * 8 + (lane & 7)];
+  const int size = __builtin_amdgcn_readlane(rec, 2), hoff = __builtin_amdgcn_readlane(rec, 5), doff = __builtin_amdgcn_readlane(rec, 6);
+  const int nseg = __builtin_amdgcn_readlane(rec, 7);
+  const int nch = (nseg + kK2Chunk - 1) / kK2Chunk;
+  const int ln = lane < size ? lane : 0;
+  const int dst = lane < size ? d.blk_dst[doff + lane] : -1;
+  double* __restrict__ h = d.H + hoff;
+  double tot = 0.0;
+  for (int c0 = 0; c0 < nch; c0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int c = c0 + u; v[u] = h[(size_t)(c < nch ? c : 0) * kK2Chunk * size + ln]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) tot += c0 + u < nch ? v[u] : 0.0;
+  }
+  if (lane >= size) return;
+  h[lane] = tot;
+  if (dst >= 0) d.Hf[dst] = tot;
+}
+__global__ __launch_bounds__(64) void k_hfinish(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hfinish(d, blockIdx.x); }
+
+__global__ __launch_bounds__(64 * kK2Waves) void k_hblocks2(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hblocks2(d, blockIdx.x); }
+
+hipError_t launch_hblocks(const DevGraph& d_in, hipStream_t st, const LinGuard* guard, bool products) {
+  const int nb = (d_in.n_k2_single + kK2Waves - 1) / kK2Waves + d_in.n_k2_multi;
+  if (nb == 0) return hipSuccess;
+  const LinGuard gd = guard ? *guard : LinGuard{};
+  DevGraph d = d_in;
+  if (!products) d.P = nullptr;                                 // (K1 ran one thread per factor: Jacobians only)
+  PPS_LAUNCH(k_hblocks2, dim3(nb), dim3(64 * kK2Waves), 0, st, d, gd);
+  if (d.n_k2_finish > 0) PPS_LAUNCH(k_hfinish, dim3(d.n_k2_finish), dim3(64), 0, st, d, gd);      // (only graphs with a landmark of > 1 024 observations)
+  return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------------
-// K2, throughput form (many graphs per launch).  The Jacobian slices of a segment's contributions are staged in LDS first --
+// K2, throughput form (batches of more than 200 000 factors, whose K1 runs one thread per factor and writes no product records).  The Jacobian slices of a segment's contributions are staged in LDS first --
 // three coalesced loads per contribution (the row node's block, the column node's block, the residual), a chunk of eight
 // contributions in flight at once -- and the products read LDS.  In the latency form every J element is fetched a dozen times
 // over by different lanes, which makes a large batch bound by the texture-address path (kb_hblocks_t: 21.0 -> 14.9 ms per
@@ -103,6 +226,9 @@ __device__ __forceinline__ void seg_fetch_contrib(const DevGraph& d, int lane, S
   // one contribution descriptor per lane, fetched in a single coalesced load (cnt <= 64)
   h.mine = make_int4(0, 0, 0, 0);
   if (lane < cnt) h.mine = reinterpret_cast<const int4*>(d.contrib)[c0 + lane];
+  // (a plane observation's contribution to a diagonal block names its product record in `ju`: this form multiplies the Jacobian
+  // slices of every contribution -- the thread-per-factor K1 it pairs with writes no product records)
+  if (h.mine.w >= kProductFlag) { h.mine.w -= kProductFlag; h.mine.y = h.mine.x; }
   // where the finished entry goes in front-gather order: does not depend on the values, so the load is issued now
   h.dst = (lane < size && nsegb == 1) ? d.blk_dst[doff + lane] : -1;
 }
@@ -244,21 +370,22 @@ __device__ __forceinline__ void body_hreduce(const DevGraph& d, int bx) {
   if (dst >= 0) d.Hf[dst] = tot;
 }
 
-__global__ __launch_bounds__(256) void k_hreduce(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hreduce<4>(d, blockIdx.x); }
-
-hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard) {
-  if (d.n_segs == 0) return hipSuccess;
-  const LinGuard gd = guard ? *guard : LinGuard{};
-  if (d.n_nd_segs > 0) PPS_LAUNCH(k_hblocks, dim3(cdiv(d.n_nd_segs, 4)), dim3(256), 0, st, d, gd);
-  if (d.n_mseg > 0) PPS_LAUNCH(k_hreduce, dim3(d.n_mseg), dim3(256), 0, st, d, gd);
-  return hipGetLastError();
-}
 
 // ---- batched forms ----
-__global__ __launch_bounds__(256, 2) void kb_hblocks(BatchArgs a) {
+template <bool PRODUCTS>
+__global__ __launch_bounds__(64 * kK2Waves) void kb_hblocks2(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
-  if ((int)blockIdx.x * 4 >= d.n_nd_segs) return;
-  body_hblocks(d, blockIdx.x);
+  if ((int)blockIdx.x >= (d.n_k2_single + kK2Waves - 1) / kK2Waves + d.n_k2_multi) return;
+  if (PRODUCTS) { body_hblocks2(d, blockIdx.x); return; }
+  DevGraph dn = d;
+  dn.P = nullptr;                                               // (the chunk's K1 wrote Jacobians only: closed-form mode)
+  body_hblocks2(dn, blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void kb_hfinish(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  if ((int)blockIdx.x >= d.n_k2_finish) return;
+  body_hfinish(d, blockIdx.x);
 }
 
 constexpr int kHblocksT = 4;      // segments per wave of the throughput form
@@ -274,12 +401,17 @@ __global__ __launch_bounds__(64) void kb_hreduce(BatchArgs a) {
   body_hreduce<1>(d, blockIdx.x);
 }
 
-hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
-  if (g.hblocks > 0) {
-    if (g.lin_thread_form) PPS_LAUNCH(kb_hblocks_t, dim3(std::max(1, g.hblocks_nd), a.n), dim3(256), 0, st, a);   // many graphs: throughput form
-    else PPS_LAUNCH(kb_hblocks, dim3(std::max(1, g.hblocks), a.n), dim3(256), 0, st, a);
+hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st, bool products) {
+  if (g.lin_thread_form) {                                      // many graphs: throughput form over the Jacobians + the second pass
+    if (g.hblocks_nd > 0) PPS_LAUNCH(kb_hblocks_t, dim3(g.hblocks_nd, a.n), dim3(256), 0, st, a);
+    if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
+    return hipGetLastError();
   }
-  if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
+  if (g.k2_blocks > 0) {
+    if (products) PPS_LAUNCH(kb_hblocks2<true>, dim3(g.k2_blocks, a.n), dim3(64 * kK2Waves), 0, st, a);
+    else PPS_LAUNCH(kb_hblocks2<false>, dim3(g.k2_blocks, a.n), dim3(64 * kK2Waves), 0, st, a);
+  }
+  if (g.k2_finish > 0) PPS_LAUNCH(kb_hfinish, dim3(g.k2_finish, a.n), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -157,6 +157,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.hblocks = std::max(q.hblocks, (d.n_nd_segs + 3) / 4);                     // (the segments K1 does not write itself)
       q.hblocks_nd = std::max(q.hblocks_nd, (d.n_nd_segs + 15) / 16);
       q.hreduce = std::max(q.hreduce, d.n_mseg);
+      q.k2_blocks = std::max(q.k2_blocks, (d.n_k2_single + 15) / 16 + d.n_k2_multi);
+      q.k2_finish = std::max(q.k2_finish, d.n_k2_finish);
       q.retract = std::max(q.retract, (d.n_pose + d.n_plane + 255) / 256);
       q.chi2 = std::max(q.chi2, d.chi2_blocks);
       q.n_factors_total += (long long)d.n_obs + d.n_odo + d.n_pp + d.n_lp;
@@ -271,7 +273,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       mark();
       if (any_relin) MHIP(m, launch_batch_linearize(a, q, q.lin_thread_form ? mode | 2 : mode, st));
       mark();
-      if (any_relin) MHIP(m, launch_batch_hblocks(a, q, st));
+      if (any_relin) MHIP(m, launch_batch_hblocks(a, q, st, mode == PPS_JAC_NUMERIC && !q.lin_thread_form));
       if (first) MHIP(m, launch_batch_chi2(a, q, 0, st));
       mark();
       hipEvent_t ef = next_event();

@@ -36,7 +36,7 @@ int do_linearize(pps_graph* g, const LinGuard* guard = nullptr) {
     g->k1_used += 2;
   } else
   { PhaseTimer t(g, &g->stats.t_linearize); HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream, guard)); }
-  { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream, guard)); }
+  { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream, guard, k1_lane_form(g->dev, g->props.jacobian_mode))); }
   if (!guard) g->stats.n_linearize++;
   return PPS_OK;
 }

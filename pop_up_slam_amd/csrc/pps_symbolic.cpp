@@ -432,7 +432,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     for (size_t i = 0; ok && i < N0; i++) ok = nodes[i].type == C->nodes[i].type && nodes[i].dim == C->nodes[i].dim && nodes[i].rank == C->nodes[i].rank;
     for (size_t i = 0; ok && i < M0; i++)
       ok = factors[i].type == C->factors[i].type && factors[i].a == C->factors[i].a && factors[i].b == C->factors[i].b &&
-           factors[i].joff == C->factors[i].joff && factors[i].direct_ok == C->factors[i].direct_ok;
+           factors[i].joff == C->factors[i].joff && factors[i].poff == C->factors[i].poff && factors[i].direct_ok == C->factors[i].direct_ok;
     for (size_t i = M0; ok && i < factors.size(); i++) ok = factors[i].a >= (int)N0 || factors[i].b >= (int)N0;
     if (!ok) return 2;
   }
@@ -790,7 +790,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   const int64_t H0 = B0 > 0 ? (B0 < (int)A.blk_hoff.size() ? A.blk_hoff[B0] : A.H_size) : 0;
   std::vector<Ctr> ctr;
   ctr.reserve(factors.size() * 3);
-  A.J_size = 0;
+  A.J_size = 0; A.P_size = 0;
   int n_obs_slots = 0;
   for (size_t fi2 = 0; fi2 < factors.size(); fi2++) {
     const auto& f = factors[fi2];
@@ -801,11 +801,15 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     const int db = f.b >= 0 ? nodes[f.b].dim : 0;
     const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
     A.J_size = std::max<int64_t>(A.J_size, (int64_t)roff + m);
+    // A plain plane observation (direct_ok) hands K2 its PRODUCT record instead of its Jacobian for the two diagonal blocks it
+    // feeds: the contribution carries the record's offset in `ju` and kProductFlag on top of the row count.
+    const bool prod = f.type == F_PLANE_OBS && f.direct_ok;
+    if (prod) A.P_size = std::max<int64_t>(A.P_size, (int64_t)f.poff + kPSize[f.type]);
     const int pa = A.node_pos[f.a];
-    if (pa >= P0) ctr.push_back({pa, pa, ja, ja, roff, m, fi});
+    if (pa >= P0) ctr.push_back({pa, pa, ja, prod ? f.poff : ja, roff, prod ? m + kProductFlag : m, fi});
     if (f.b >= 0) {
       const int pb = A.node_pos[f.b];
-      if (pb >= P0) ctr.push_back({pb, pb, jb, jb, roff, m, fi});
+      if (pb >= P0) ctr.push_back({pb, pb, jb, prod ? f.poff + da * da + da : jb, roff, prod ? m + kProductFlag : m, fi});
       if (pa > pb) { if (pb >= P0) ctr.push_back({pa, pb, ja, jb, roff, m, fi}); }   // rows = later node
       else         { if (pa >= P0) ctr.push_back({pb, pa, jb, ja, roff, m, fi}); }
     }

@@ -23,9 +23,13 @@ enum { F_POSE_PRIOR = 0, F_ODOMETRY = 1, F_PLANE_OBS = 2, F_PLANE_PRIOR = 3 };
 // doubles of Jacobian storage per factor type: [J_a | J_b | r]
 constexpr int kJSize[4] = {36 + 6, 36 + 36 + 6, 18 + 9 + 3, 9 + 3};
 constexpr int kFDim[4] = {6, 6, 3, 3};
+// doubles of a factor's PRODUCT record (round 4): what it adds to the diagonal H blocks of its nodes -- J_a' J_a (row-major, full)
+// followed by -J_a' r for node a, then the same for node b.  K1 writes it next to the Jacobian, K2 only sums such records.
+constexpr int kPSize[4] = {36 + 6, 2 * (36 + 6), (36 + 6) + (9 + 3), 9 + 3};
+constexpr int kProductFlag = 256;     // added to a contribution's row count m: `ju` is the offset of a product sub-record (plane observations only, so far)
 
 struct SymNode { int type; int dim; int rank; };        // rank: insertion index among poses (time order), -1 for planes
-struct SymFactor { int type; int a, b; int joff; int direct_ok = 0; };   // compact node ids (b = -1 when unary); joff: offset in the J buffer;
+struct SymFactor { int type; int a, b; int joff; int direct_ok = 0; int poff = 0; };   // compact node ids (b = -1 when unary); joff / poff: offsets in the J / product buffers;
                                                                        // direct_ok: a plain plane observation (slot = joff / 30) whose pose-plane block K1 may write itself
 
 struct AnalysisParams {
@@ -117,9 +121,10 @@ struct Analysis {
   int n_segs = 0;
   std::vector<int> seg_blk, seg_c0, seg_cnt;
   std::vector<int64_t> seg_hoff;
-  std::vector<int> contrib;              // 4 ints per contribution: jv, ju, roff, m
+  std::vector<int> contrib;              // 4 ints per contribution: jv, ju, roff, m -- a plain plane observation's contribution to a DIAGONAL block
+                                         // carries the offset of its product sub-record for that node in ju and kProductFlag in m
   int64_t H_size = 0;
-  int64_t J_size = 0;
+  int64_t J_size = 0, P_size = 0;
 
   // ---- "direct" blocks: the off-diagonal H block of a (pose, plane) pair that ONE plane observation contributes to is a
   // product of that factor's own two Jacobian blocks; the thread-per-factor sweep can write it itself (many-graph batches),

@@ -169,6 +169,15 @@ void j_bases(const pps_graph* g, int64_t base[4], int64_t* total) {
   base[F_POSE_PRIOR] = joff_pp; base[F_ODOMETRY] = joff_odo; base[F_PLANE_OBS] = joff_obs; base[F_PLANE_PRIOR] = joff_lp;
   if (total) *total = joff_lp + j_capacity(n_lp) * 12;
 }
+// the product records (pps_symbolic.h: kPSize) in slabs of the same capacities: a product offset moves exactly when the J offset does
+void p_bases(const pps_graph* g, int64_t base[4], int64_t* total) {
+  const int64_t n_pp = g->fslot_ids[F_POSE_PRIOR].size(), n_odo = g->fslot_ids[F_ODOMETRY].size(),
+                n_obs = g->fslot_ids[F_PLANE_OBS].size(), n_lp = g->fslot_ids[F_PLANE_PRIOR].size();
+  const int64_t p_obs = 0, p_odo = j_capacity(n_obs) * kPSize[F_PLANE_OBS], p_pp = p_odo + j_capacity(n_odo) * kPSize[F_ODOMETRY],
+                p_lp = p_pp + j_capacity(n_pp) * kPSize[F_POSE_PRIOR];
+  base[F_POSE_PRIOR] = p_pp; base[F_ODOMETRY] = p_odo; base[F_PLANE_OBS] = p_obs; base[F_PLANE_PRIOR] = p_lp;
+  if (total) *total = p_lp + j_capacity(n_lp) * kPSize[F_PLANE_PRIOR];
+}
 
 // ---- compaction + symbolic analysis (host only) -------------------------------------------
 static int run_analysis_impl(pps_graph* g);
@@ -203,12 +212,13 @@ static int run_analysis_impl(pps_graph* g) {
       g->fslot_ids[f.type].push_back((int)i);
     }
     g->n_obs_fixed = (int)g->fslot_ids[F_PLANE_OBS].size();
-    int64_t base[4], j_total = 0;
+    int64_t base[4], j_total = 0, pbase[4], p_total = 0;
     j_bases(g, base, &j_total);
-    if (j_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
+    p_bases(g, pbase, &p_total);
+    if (j_total > 0x7fffffffLL || p_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
     if (memcmp(base, g->cmp_base, sizeof(base)) != 0) {          // a J slab outgrew its capacity: every offset moves
       int cnt[4] = {0, 0, 0, 0};
-      for (SymFactor& q : sf) q.joff = (int)(base[q.type] + (int64_t)(cnt[q.type]++) * kJSize[q.type]);
+      for (SymFactor& q : sf) { const int k = cnt[q.type]++; q.joff = (int)(base[q.type] + (int64_t)k * kJSize[q.type]); q.poff = (int)(pbase[q.type] + (int64_t)k * kPSize[q.type]); }
       memcpy(g->cmp_base, base, sizeof(base));
     }
     for (size_t i = g->cmp_factors; i < g->factors.size(); i++) {
@@ -218,6 +228,7 @@ static int run_analysis_impl(pps_graph* g) {
       q.a = g->nodes[f.a].compact;
       q.b = f.b >= 0 ? g->nodes[f.b].compact : -1;
       q.joff = (int)(base[f.type] + (int64_t)f.slot * kJSize[f.type]);
+      q.poff = (int)(pbase[f.type] + (int64_t)f.slot * kPSize[f.type]);
       q.direct_ok = f.type == F_PLANE_OBS ? 1 : 0;
       sf.push_back(q);
     }
@@ -245,9 +256,10 @@ static int run_analysis_impl(pps_graph* g) {
     }
   g->n_obs_fixed = 0;
   for (int id : g->fslot_ids[F_PLANE_OBS]) g->n_obs_fixed += g->factors[id].repop ? 0 : 1;
-  int64_t base[4], j_total = 0;
+  int64_t base[4], j_total = 0, pbase[4], p_total = 0;
   j_bases(g, base, &j_total);
-  if (j_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
+  p_bases(g, pbase, &p_total);
+  if (j_total > 0x7fffffffLL || p_total > 0x7fffffffLL) return fail(g, PPS_ENOMEM, "graph too large for int32 J offsets");
   memcpy(g->cmp_base, base, sizeof(base));
   sf.reserve(g->factors.size());
   bool any_deleted = false;
@@ -259,6 +271,7 @@ static int run_analysis_impl(pps_graph* g) {
     s.a = g->nodes[f.a].compact;
     s.b = f.b >= 0 ? g->nodes[f.b].compact : -1;
     s.joff = (int)(base[f.type] + (int64_t)f.slot * kJSize[f.type]);
+    s.poff = (int)(pbase[f.type] + (int64_t)f.slot * kPSize[f.type]);
     s.direct_ok = (f.type == F_PLANE_OBS && !f.repop) ? 1 : 0;
     sf.push_back(s);
   }
@@ -272,7 +285,9 @@ static int run_analysis_impl(pps_graph* g) {
   // H-block segments (contributions reduced by one wave of K2): short on small graphs, where the few long segments
   // (ground plane, 32 contributions = 16 dependent load rounds) are K2's critical path; long on large ones, where the
   // number of waves is (C2: 23.3 -> 18.7 us with 8; C3: 82 -> 102 us)
-  g->aprm.seg_len = g->pose_ids.size() >= 4000 ? 32 : 8;
+  // (round 4: a plane observation reaches K2 as ONE coalesced load per lane -- its product record -- so a wave sums up to 64
+  // contributions per segment: every landmark but the ground plane is one segment, and no second reduction pass)
+  g->aprm.seg_len = 64;
   // a graph that is re-analysed after pure appends is a frame loop: absolute cut positions keep the left part of its tree
   g->aprm.aligned_cuts = (g->n_analyses > 0 && g->grown_only) ? 1 : 0;
   // ... and its aligned cuts leave a few fronts of 65 .. 80 rows, whose 25 KB triangles let 5 waves share a CU's LDS, not 8:
@@ -616,6 +631,8 @@ int upload_all(pps_graph* g) {
   lap("4 factor packing + diff");
   // linear system storage
   TRY(dev_alloc(g, &d.J, (size_t)A.J_size)); TRY(dev_alloc(g, &d.H, (size_t)A.H_size));
+  TRY(dev_alloc(g, &d.P, (size_t)std::max<int64_t>(1, A.P_size)));
+  { int64_t pb[4]; p_bases(g, pb, nullptr); d.poff_obs = pb[F_PLANE_OBS]; }
   TRY(dev_alloc(g, &d.L, (size_t)A.L_size)); TRY(dev_alloc(g, &d.U, (size_t)A.U_size));
   TRY(dev_alloc(g, &g->spec_L, (size_t)A.L_size)); TRY(dev_alloc(g, &g->spec_U, (size_t)A.U_size));
   const size_t delta_doubles = (size_t)std::max(1, A.n_scalars);   // (delta and the second delta sit in the zeroed block below)
@@ -640,6 +657,17 @@ int upload_all(pps_graph* g) {
     for (int bk = 0; bk < A.n_blocks; bk++) if (A.blk_nseg[bk] > 1) mseg.push_back(bk);
     d.n_mseg = (int)mseg.size();
     TRY(dev_upload(g, &d.mseg_blk, mseg));
+    // K2's two work lists: segments of single-segment blocks that K1 does not write itself; first segment of every other block
+    std::vector<int> k2s, k2m, k2f;
+    for (int sg : A.nd_segs) if (A.blk_nseg[A.seg_blk[sg]] == 1) k2s.push_back(sg);
+    for (int sg = 0; sg < A.n_segs; sg++) {
+      const int ns = A.blk_nseg[A.seg_blk[sg]];
+      if (ns <= 1 || (sg > 0 && A.seg_blk[sg - 1] == A.seg_blk[sg])) continue;      // (first segment of a block of several)
+      for (int c0 = 0; c0 < ns; c0 += 16) { k2m.push_back(sg + c0); k2m.push_back(std::min(16, ns - c0) | (ns <= 16 ? 1 << 16 : 0)); }
+      if (ns > 16) k2f.push_back(sg);
+    }
+    d.n_k2_single = (int)k2s.size(); d.n_k2_multi = (int)k2m.size() / 2; d.n_k2_finish = (int)k2f.size();
+    TRY(dev_upload(g, &d.k2_single, k2s)); TRY(dev_upload(g, &d.k2_multi, k2m)); TRY(dev_upload(g, &d.k2_finish, k2f));
   }
   TRY(dev_upload(g, &d.f_el_off, A.f_el_off)); TRY(dev_alloc(g, &d.el_tgt, (size_t)std::max<int64_t>(1, A.el_total)));   // filled by k_expand_el below
   TRY(dev_upload(g, &d.asm_el0, A.asm_el0)); TRY(dev_upload(g, &d.asm_fsz, A.asm_fsz));

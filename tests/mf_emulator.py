@@ -16,8 +16,9 @@ def solve_with_analysis(A, Jbuf, lam):
         acc = np.zeros(size)
         for c in range(A["seg_c0"][s], A["seg_c0"][s] + A["seg_cnt"][s]):
             jv, ju, roff, m = ctr[c]
+            m = m & 255                      # (bit 8: the contribution also names a product record in ju -- this emulation multiplies the Jacobians)
             Jv = Jbuf[jv:jv + m * rows].reshape(m, rows)
-            Ju = Jbuf[ju:ju + m * cols].reshape(m, cols)
+            Ju = Jv if size > rows * cols else Jbuf[ju:ju + m * cols].reshape(m, cols)
             acc[:rows * cols] += (Jv.T @ Ju).ravel()
             if size > rows * cols:
                 acc[rows * cols:] -= Jv.T @ Jbuf[roff:roff + m]
@@ -76,7 +77,7 @@ def _tri(i):
     return i * (i + 1) // 2
 
 
-def solve_with_band_schedule(A, Jbuf, lam):
+def solve_with_band_schedule(A, Jbuf, lam, Pbuf=None):
     """Emulates the wave-per-front band kernels from the arrays THEY read: packed segment / front / child
     records, the front-ordered H (Hf) with its flat gather targets, the packed extend-add targets and the
     stage -> group -> local level -> front schedule.  Returns delta in elimination order."""
@@ -87,8 +88,14 @@ def solve_with_band_schedule(A, Jbuf, lam):
         acc = np.zeros(size)
         for c in range(c0, c0 + cnt):
             jv, ju, roff, m = ctr[c]
+            if m >= 256 and Pbuf is not None:      # a plane observation's product record (what K2 sums since round 4)
+                assert size > rows * cols
+                acc += Pbuf[ju:ju + size]
+                continue
+            m = m & 255
             Jv = Jbuf[jv:jv + m * rows].reshape(m, rows)
-            acc[:rows * cols] += (Jv.T @ Jbuf[ju:ju + m * cols].reshape(m, cols)).ravel()
+            Ju = Jv if size > rows * cols else Jbuf[ju:ju + m * cols].reshape(m, cols)
+            acc[:rows * cols] += (Jv.T @ Ju).ravel()
             if size > rows * cols:
                 acc[rows * cols:] -= Jv.T @ Jbuf[roff:roff + m]
         H[hoff:hoff + size] = acc

@@ -23,6 +23,7 @@ def _dense_and_jbuf(spec, A, lam):
     starts = np.concatenate([[0], np.cumsum(dims)])
     ncol = int(starts[-1])
     Jbuf = np.zeros(A["J_size"])
+    Pbuf = np.zeros(A["P_size"])
     rows, rhs = [], []
     for k in range(o.num_factors()):
         Hk, rk = o.factor_jacobian(k, 1)
@@ -31,13 +32,20 @@ def _dense_and_jbuf(spec, A, lam):
         Jbuf[off:off + m * da] = Hk[:, :da].ravel()
         Jbuf[off + m * da:off + m * (da + db)] = Hk[:, da:].ravel()
         Jbuf[off + m * (da + db):off + m * (da + db) + m] = rk
+        # the factor's product record: [J_a' J_a | -J_a' r] then the same for node b
+        # (plane observations only: the other factor types still reach K2 through their Jacobians)
+        po = A["factor_poff"][k]
+        if b >= 0 and da == 6 and db == 3:
+            Ja = Hk[:, :da]; Pbuf[po:po + da * da] = (Ja.T @ Ja).ravel(); Pbuf[po + da * da:po + da * da + da] = -Ja.T @ rk
+            pb_ = po + da * da + da; Jb = Hk[:, da:]
+            Pbuf[pb_:pb_ + db * db] = (Jb.T @ Jb).ravel(); Pbuf[pb_ + db * db:pb_ + db * db + db] = -Jb.T @ rk
         R = np.zeros((m, ncol)); R[:, starts[a]:starts[a] + da] = Hk[:, :da]
         if b >= 0:
             R[:, starts[b]:starts[b] + db] = Hk[:, da:]
         rows.append(R); rhs.append(-rk)
     J = np.vstack(rows); bvec = np.concatenate(rhs)
     H = J.T @ J; H[np.diag_indices(ncol)] *= (1 + lam)
-    return np.linalg.solve(H, J.T @ bvec), Jbuf, starts, dims
+    return np.linalg.solve(H, J.T @ bvec), Jbuf, starts, dims, Pbuf
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -47,15 +55,16 @@ def test_multifrontal_structure_solves_the_normal_equations(built, case, lam):
     g = P.Graph(); spec.replay(g)
     g.analyze()
     A = g.analysis_dump()
-    dref, Jbuf, starts, dims = _dense_and_jbuf(spec, A, lam)
-    # (1) the level-per-launch arrays, (2) the arrays of the wave-per-front band kernels
-    for solver in (solve_with_analysis, solve_with_band_schedule):
+    dref, Jbuf, starts, dims, Pbuf = _dense_and_jbuf(spec, A, lam)
+    # (1) the level-per-launch arrays, (2) the arrays of the wave-per-front band kernels, (3) the same with the diagonal H blocks
+    # summed from the factors' product records, as K2 does
+    for solver in (solve_with_analysis, solve_with_band_schedule, lambda A_, J_, l_: solve_with_band_schedule(A_, J_, l_, Pbuf)):
         d = solver(A, Jbuf, lam)
         dm = np.zeros_like(dref)
         for i in range(len(dims)):
             c = A["node_compact"][i]
             dm[starts[i]:starts[i] + dims[i]] = d[A["node_voff"][c]:A["node_voff"][c] + dims[i]]
-        assert np.abs(dm - dref).max() <= 1e-9 * np.abs(dref).max(), solver.__name__
+        assert np.abs(dm - dref).max() <= 1e-9 * np.abs(dref).max(), getattr(solver, '__name__', 'band schedule + product records')
 
 
 def test_analysis_invariants_c2(built):

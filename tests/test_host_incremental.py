@@ -78,9 +78,9 @@ def test_incremental_analysis_solves_the_normal_equations(built):
     g.analyze()
     A = g.analysis_dump()
     for lam in (0.0, 1e-3):
-        dref, Jbuf, starts, dims = _dense_and_jbuf(spec, A, lam)
+        dref, Jbuf, starts, dims, Pbuf = _dense_and_jbuf(spec, A, lam)
         for solver in (solve_with_analysis, solve_with_band_schedule):
-            d = solver(A, Jbuf, lam)
+            d = solver(A, Jbuf, lam) if solver is solve_with_analysis else solver(A, Jbuf, lam, Pbuf)      # (diagonal blocks from the product records)
             dm = np.zeros_like(dref)
             for i in range(len(dims)):
                 c = A["node_compact"][i]
