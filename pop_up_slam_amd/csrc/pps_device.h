@@ -101,7 +101,7 @@ struct LinGuard {
   const double* pose[2];
   const double* plane[2];
   double error;              // chi2 at the linearisation point the trials started from
-  int on, pad;
+  int on, single;            // single: only trial 0 was computed (the second record is stale: never consulted)
 };
 
 // kernel launches issued by the calling host thread (pps_stats::n_launches is the difference over a solve call)

@@ -47,12 +47,12 @@ __device__ __forceinline__ bool lin_guard(const LinGuard& gd, const double* __re
   if (!gd.on) return true;
   const double c0 = *gd.chi[0], c1 = *gd.chi[1];
   if (gd.error - c0 > 0.) { pose = gd.pose[0]; plane = gd.plane[0]; return true; }
-  if (gd.error - c1 > 0.) { pose = gd.pose[1]; plane = gd.plane[1]; return true; }
+  if (!gd.single && gd.error - c1 > 0.) { pose = gd.pose[1]; plane = gd.plane[1]; return true; }
   return false;
 }
 __device__ __forceinline__ bool lin_guard(const LinGuard& gd) {
   if (!gd.on) return true;
-  return gd.error - *gd.chi[0] > 0. || gd.error - *gd.chi[1] > 0.;
+  return gd.error - *gd.chi[0] > 0. || (!gd.single && gd.error - *gd.chi[1] > 0.);
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

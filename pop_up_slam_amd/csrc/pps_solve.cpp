@@ -292,9 +292,32 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   // three state copies: x = the linearisation point (d.pose_lin), t[0] / t[1] = x (+) delta for the two damping values
   double *t_pose[2] = {d.pose_est, g->spec_pose}, *t_plane[2] = {d.plane_est, g->spec_plane};
   double seqs[2] = {0, 0};
+  // Speculation costs what it computes: on a graph whose lower tree levels fill the GPU by themselves (C3: 5 359 fronts) the second
+  // factorisation + back-substitution of a launch set are extra time, not idle lanes -- and LM accepts most steps there.  Such a
+  // graph factors the second damping value only while LM zig-zags (after a rejection); the trace is the same either way.
+  const bool adaptive = A.n_fronts >= 2048 && !getenv("PPS_ALWAYS_DUAL");
+  bool use_alt = !adaptive;
+  bool have_next = true;                 // trial 1 of the last launch is the step for the next lambda after a rejection
   auto enqueue_dual = [&](double lam) -> int {
     DualAlt alt{g->spec_L, g->spec_U, g->spec_delta, g->spec_result, g->spec_chi2_partials, g->spec_dn_partials, g->spec_ticket,
                 lam * prop.lm_lambda_factor};
+    have_next = use_alt;
+    if (!use_alt) {
+      // one damping value: the single-lambda launches; the trial kernel still walks both copies (the second one's step is a stale
+      // delta: finite, never read -- have_next is false)
+      for (int st = 0; st < A.n_stages; st++)
+        HIP_TRY(g, launch_band_factor(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
+                                      A.stage_max_front[st], lam, g->stream));
+      for (int st = A.n_stages - 1; st >= 0; st--)
+        HIP_TRY(g, launch_band_solve(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
+                                     g->stage_max_panel[st], g->stage_max_grp_fronts[st], g->stream, nullptr));
+      g->stats.n_factorize += 1;
+      g->seq += 1.0; seqs[0] = g->seq;
+      g->seq2 += 1.0; seqs[1] = g->seq2;
+      HIP_TRY(g, launch_trial_dual(d, alt, d.pose_lin, d.plane_lin, t_pose[0], t_plane[0], t_pose[1], t_plane[1], slot[0], seqs[0], slot[1], seqs[1],
+                                   g->stream));
+      return PPS_OK;
+    }
     for (int st = 0; st < A.n_stages; st++) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (g->profiling == 1) {                                     // the launch's own start / stop: resolve_k1_events sums them into t_factor
@@ -325,7 +348,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   int spec_pair = -1;                    // K1 event pair of the queued speculative linearisation
   auto enqueue_spec_lin = [&](double err) -> int {
     if (!spec_lin) return PPS_OK;
-    LinGuard gd{{d.result_dev, g->spec_result}, {t_pose[0], t_pose[1]}, {t_plane[0], t_plane[1]}, err, 1, 0};
+    LinGuard gd{{d.result_dev, g->spec_result}, {t_pose[0], t_pose[1]}, {t_plane[0], t_plane[1]}, err, 1, have_next ? 0 : 1};
     spec_pair = g->profiling == 1 ? g->k1_used / 2 : -1;
     return do_linearize(g, &gd);
   };
@@ -337,7 +360,6 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;
   rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
   int cur = 0;                           // which of the two trials the loop is looking at
-  bool have_next = true;                 // trial 1 of the last launch is the step for the next lambda after a rejection
   double dnorm = std::sqrt(slot[0][1]);
   bool last_notpd = slot[0][2] != 0.0;
   int n_notpd = last_notpd ? 1 : 0;
@@ -354,13 +376,14 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
       if (error_diff < prop.epsilon_rel * error) { error = error_new; trial_taken = true; break; }   // (:431-434)
       lambda /= prop.lm_lambda_factor;
       error = error_new;
+      if (adaptive) use_alt = cur != 0;                           // (accepted at once: no speculation next time; after a rejection: keep it)
       // the accepted copy becomes the linearisation point; the old one is the spare now
       std::swap(d.pose_lin, t_pose[cur]); std::swap(d.plane_lin, t_plane[cur]);
       if (spec_lin) { g->stats.n_linearize++; spec_pair = -1; }    // relinearise (:444): queued already, at this very copy
       else { rc = do_linearize(g); if (rc != PPS_OK) return rc; }
       rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;      // (:458)
       rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;
-      cur = 0; have_next = true;
+      cur = 0;
       rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
     } else {
       g->stats.lm_trials_rejected++;
@@ -370,9 +393,10 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
         rc = wait_result(g, slot[1], seqs[1]); if (rc != PPS_OK) return rc;
       } else {
         drop_spec_lin();                                           // both trials rejected: its kernels left J and H alone
+        if (adaptive) use_alt = true;                              // LM is zig-zagging: the next rejection should be free again
         rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;    // (:458), same J and H
         rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;
-        cur = 0; have_next = true;
+        cur = 0;
         rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
       }
     }
