@@ -1,17 +1,31 @@
 #!/bin/bash
 # usage (on the GPU box, through gpurun): tools/evidence_run.sh [TAG]
-# Collects everything profiles/ holds for a round into gpurun_out/TAG/: the bench line, the rocprofv3 kernel summaries of the bench
-# command, of the C2 timeline and of the frame loop, and the PMC passes (K1 sweep traffic; instruction mix / occupancy of the
-# pps_multi kernels in both of their forms).  PMC passes run on their own, with --kernel-trace only.
+# Collects everything profiles/ holds for a round into gpurun_out/TAG/: the bench line; ONE rocprofv3 kernel summary PER WORKLOAD (C2,
+# C3, the frame loop, pps_multi at G = 128, the batched K1 sweeps) so that every roofline figure of the bench line can be recomputed
+# as bytes / mean duration of the named kernel in the matching summary; the C2 timeline; the PMC passes (K1 sweep traffic;
+# instruction mix / occupancy of the C2 and the pps_multi kernels; one front under the counters, this build and round 3's).
+# PMC passes run on their own, with --kernel-trace only.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ROOT=$(pwd); tag=${1:-r3}; out=$ROOT/gpurun_out/$tag; raw=/tmp/evidence_$tag; mkdir -p $out $raw   # (raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
+ROOT=$(pwd); tag=${1:-r4}; out=$ROOT/gpurun_out/$tag; raw=/tmp/evidence_$tag; mkdir -p $out $raw   # (raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
 export TMPDIR=/tmp
 cd /tmp
-# 1. the bench line, then the same command under the kernel trace
+summary() {   # summary NAME -- cmd...: rocprofv3 kernel trace of the command, summarised into $out/kernel_stats_NAME.txt
+  name=$1; shift; shift
+  timeout 600 rocprofv3 --kernel-trace --stats -d $raw/kt_$name -o t -- "$@" > $out/kt_$name.log 2>&1
+  python $ROOT/tools/rocprof_summary.py $(ls $raw/kt_$name/*.db $raw/kt_$name/*/*.db 2>/dev/null | head -1) $out/kernel_stats_$name.txt > /dev/null
+  sed -i "1i # workload: $*" $out/kernel_stats_$name.txt
+}
+# 1. the bench line
 ( cd $ROOT && timeout 900 python bench.py > $out/bench.json 2> $out/bench.err ); echo "bench rc $?"
-timeout 900 rocprofv3 --kernel-trace --stats -d $raw/kt_bench -o t -- python $ROOT/bench.py --steps 10 --warmup 2 > $out/kt_bench.log 2>&1
-python $ROOT/tools/rocprof_summary.py $(ls $raw/kt_bench/*.db $raw/kt_bench/*/*.db 2>/dev/null | head -1) $out/kernel_stats_bench.txt > /dev/null
-# 2. C2 timeline (csv) of one LM solve
+# 2. one kernel summary per workload
+summary c2 -- python $ROOT/tools/timeline_c2.py run                 # two LM solves of the C2 graph: nothing else
+summary c3 -- python $ROOT/tools/ab_bench.py c3 3                   # C3 (incl. one solve of the one-step profiling loop)
+summary multi128 -- python $ROOT/tools/ab_bench.py multi 128 1      # G = 128 through pps_multi (level-per-launch kernels)
+summary multi8 -- python $ROOT/tools/ab_bench.py multi 8 2          # G = 8 (band kernels, lane-form K1)
+summary sweep_numeric -- python $ROOT/tools/sweep_only.py 0 108     # roofline_batched: numeric thread form
+summary sweep_analytic -- python $ROOT/tools/sweep_only.py 1 108
+summary sweep_lanes -- python $ROOT/tools/sweep_only.py 2 108
+# C2 timeline (csv) of one LM solve
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $raw/tl_c2 -- python $ROOT/tools/timeline_c2.py run > $out/tl_c2.log 2>&1
 python $ROOT/tools/timeline_c2.py show $raw/tl_c2 > $out/timeline_c2.txt 2>&1
 # 3. the frame loop (Python host loop) under the kernel trace + memory-copy trace
@@ -92,5 +106,39 @@ with open(os.path.join(out, "pmc_c2_kernels.txt"), "w") as f:
     f.write("%-28s %6s %9s " % ("kernel", "disp", "dur_us") + " ".join("%16s" % c.replace("SQ_", "") for c in cs) + "\n")
     for k, r in sorted(rows.items(), key=lambda kv: -kv[1].get("duration_us", 0) * kv[1].get("dispatches", 0)):
         f.write("%-28s %6d %9.1f " % (k[:28], r.get("dispatches", 0), r.get("duration_us", 0)) + " ".join("%16.0f" % r.get(c, float("nan")) for c in cs) + "\n")
+PY
+# 7. one front under the counters: this build (8-column panels in the level / r5 kernels: tiles given -> W = 8 harness) against round 3's library
+for lib in libpps.so libpps_r3.so; do
+  [ -f $ROOT/pop_up_slam_amd/$lib ] || continue
+  for pb in "6 8 2" "15 33 3" "18 30 3" "33 30 4"; do
+    set -- $pb
+    for pass in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+      d=$raw/pmc_front_${lib%.so}_$1_$2_$(echo $pass | tr ' ' '_')
+      PPS_LIB=$ROOT/pop_up_slam_amd/$lib timeout 120 rocprofv3 --pmc $pass --kernel-trace -d $d -o t -- python $ROOT/tools/front_pmc.py $1 $2 $3 3 > $d.log 2>&1
+    done
+  done
+done
+python - $out $raw <<'PY'
+import sqlite3, sys, glob, os, collections
+out, raw = sys.argv[1], sys.argv[2]
+rows = collections.defaultdict(dict)
+for d in sorted(glob.glob(os.path.join(raw, "pmc_front_*"))):
+    if not os.path.isdir(d): continue
+    name = os.path.basename(d)[len("pmc_front_"):]
+    lib = "r3" if name.startswith("libpps_r3") else "r4"
+    toks = name.replace("libpps_r3_", "").replace("libpps_", "").split("_")
+    p, b = toks[0], toks[1]
+    for path in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+        db = sqlite3.connect(path)
+        for kname, c, v, n, dur in db.execute("select kernel_name, counter_name, avg(value), count(*), avg(duration) from counters_collection group by kernel_name, counter_name"):
+            if "k_debug_front" not in kname: continue
+            rows[(p, b, lib)][c] = v; rows[(p, b, lib)]["dur_us"] = dur / 1e3
+cs = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES"]
+with open(os.path.join(out, "pmc_front.txt"), "w") as f:
+    f.write("# one front through pps_debug_front_factor under rocprofv3 --pmc (tools/front_pmc.py p b tiles): instructions of the ONE wave that\n"
+            "# eliminates it, round 3's library (4-column panels) against this build (8-column panels: two chained pivot blocks per LDS round trip)\n")
+    f.write("%4s %4s %4s " % ("p", "b", "lib") + " ".join("%15s" % c.replace("SQ_", "") for c in cs) + "\n")
+    for (p, b, lib), r in sorted(rows.items(), key=lambda kv: (int(kv[0][0]), kv[0][2])):
+        f.write("%4s %4s %4s " % (p, b, lib) + " ".join("%15.0f" % r.get(c, float("nan")) for c in cs) + "\n")
 PY
 ls $out | tr '\n' ' '
