@@ -386,7 +386,10 @@ def main():
                             "flattering figure; not used for frac).  One C2 graph is 2.8 MB per sweep: cache-resident and "
                             "latency bound, so HBM traffic is not meaningful here (traffic: null); see roofline_batched for "
                             "the same kernel family over > 256 MB"}
-        dual_factor_us = 1e6 * st["t_factor"] / max(1, st["n_factorize"] // 2)     # the same solve: factor launches of the dual loop
+        # the same solve: dispatch durations of its factor launches; a launch set holds two factorisations (lambda and lambda * 10)
+        # -- or one, where the loop dropped the speculation (graphs that fill the GPU: pps_solve.cpp)
+        fact_us = 1e6 * st["t_factor"] / max(1, st["n_factorize"])               # device time per factorisation, amortised
+        dual_factor_us = 2 * fact_us
         # batched variant: replicate the edge arrays until one sweep moves > 256 MB; the plane-edge launch
         # (5 of every 6 factors) is the dominant kernel, the odometry launch is reported next to it
         reps = args.batched_replicas or int(np.ceil(300e6 / bytes_per_launch))
@@ -541,7 +544,7 @@ def main():
             bytes3 = cnt3[synth.F_PLANE_OBS] * B_PLANE_EDGE + cnt3[synth.F_ODOMETRY] * B_ODO_EDGE
             g3.restore_state(); g3.set_profiling(1); g3.batch_optimize(); s3d = g3.stats(); g3.set_profiling(0)      # dual loop, dispatch timestamps
             fl3, k3_bytes3 = factorisation_work(g3.analysis_dump())
-            pair3 = s3d["t_factor"] / max(1, s3d["n_factorize"] // 2)
+            pair3 = 2 * s3d["t_factor"] / max(1, s3d["n_factorize"])               # (amortised: C3 runs most launch sets with one factorisation)
             k1_3_solve = s3d["t_linearize"] / max(1, s3d["n_linearize"])
             g3.restore_state()
             k1_3 = g3.time_linearize(mode, 100)
@@ -557,10 +560,12 @@ def main():
                                          "algorithmic_bytes_per_launch": bytes3, "avg_launch_us": 1e6 * k1_3_solve, "launches": s3d["n_linearize"],
                                          "replay_avg_launch_us": 1e6 * k1_3, "traffic": None,
                                          "note": "inside the solve (dispatch timestamps); profiles/r4_kernel_stats_c3.txt"},
-                         "roofline_k3_hbm": {"bound": "hbm", "kernel": "k_band_factor<true> + k_band_factor_r5 (two factorisations per launch set)",
+                         "roofline_k3_hbm": {"bound": "hbm", "kernel": "k_band_factor<true> + k_band_factor_r5",
                                              "achieved": 2 * k3_bytes3 / pair3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": 2 * k3_bytes3 / pair3 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_factorisation": k3_bytes3,
-                                             "us_per_pair_of_factorisations": 1e6 * pair3, "traffic": None},
+                                             "us_per_factorisation_amortised": 1e6 * pair3 / 2, "factorisations": s3d["n_factorize"], "traffic": None,
+                                             "note": "sum of the dispatch durations of the factor launches of one solve / factorisations done (adaptive "
+                                                     "speculation: most launch sets of C3 hold ONE factorisation); profiles/r4_kernel_stats_c3.txt"},
                          "roofline_k3": {"bound": "mfma", "achieved": 2 * fl3 / pair3 / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": 2 * fl3 / pair3 / 1e12 / 78.6,
                                          "flops_per_factorisation": fl3}}
             g3.close()

@@ -121,9 +121,10 @@ hipError_t step_constants(double ac[4]);
 // All launchers enqueue on `st` and return the HIP error of the launch.
 hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipStream_t st, const LinGuard* guard = nullptr, hipEvent_t ev0 = nullptr,
                             hipEvent_t ev1 = nullptr);      // ev0 / ev1: start / stop of the sweep itself (profiling level 1)
-// products: K1 wrote the plane observations' product records (its lane form does; see k1_lane_form)
+// products: K1 wrote the plane observations' product records (see k1_products)
 hipError_t launch_hblocks(const DevGraph& d, hipStream_t st, const LinGuard* guard = nullptr, bool products = true);
 bool k1_lane_form(const DevGraph& d, int mode);      // which form launch_linearize takes for this graph and Jacobian mode
+bool k1_products(const DevGraph& d, int mode);       // whether that launch writes the product records K2 sums
 hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_count, int level_max_front, double lambda,
                                hipStream_t st);
 hipError_t launch_backsolve_level(const DevGraph& d, int level_begin, int level_count, hipStream_t st);
@@ -136,7 +137,8 @@ struct DualAlt {
   unsigned int* ticket;
   double lambda;
 };
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st);
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
                              const DualAlt* alt = nullptr);
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
@@ -200,7 +202,7 @@ struct BatchArgs {
   const BatchStage* stage_tab; // [n_stages_max][n_total]
   double* results;             // pinned host, 8 doubles per graph: [0..3] chi2 at the linearisation point, [4..7] the trial
   int n_total, b0, n;          // graphs in the batch / first graph of this chunk / graphs in this chunk
-  int pad;
+  int no_products;             // the chunk's K1 writes no product records (thread-per-factor form of a large chunk: its K2 multiplies the Jacobians)
   double seq;
   double lambda[kBatchMax];
   unsigned char flags[kBatchMax];

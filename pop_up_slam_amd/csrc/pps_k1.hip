@@ -96,6 +96,9 @@ bool k1_lane_form(const DevGraph& d, int mode) {
   return mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !getenv("PPS_K1_THREAD_FORM");
 }
 
+// does K1 write the plane observations' product records (and K2 sum them)?  Every form does, except under the test switch above
+bool k1_products(const DevGraph& d, int mode) { (void)d; (void)mode; return !getenv("PPS_K1_THREAD_FORM"); }
+
 // ev0 / ev1 (profiling level 1): the launch is made with hipExtLaunchKernelGGL, whose start / stop events take the DISPATCH's own
 // begin / end timestamps -- what rocprofv3 reports as the kernel's duration -- instead of two event records around the launch,
 // which also time the event packets themselves (13.6 us against 10.6 us for the C2 sweep inside a solve).
@@ -127,8 +130,10 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   if (ev0) { const hipError_t e = hipEventRecord(ev0, st); if (e != hipSuccess) return e; }      // (two launches: the pair goes around both)
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   const int nb_rest = nb - nb_obs;
+  // PPS_K1_THREAD_FORM=1 (the parity test of the batched throughput forms) also switches the product records off: K2 then
+  // multiplies the Jacobians of every contribution, as the throughput form of a large batch does
   DevGraph dn = d;
-  dn.P = nullptr;                       // the thread-per-factor form writes Jacobians (and the direct blocks) only: K2 multiplies
+  if (!k1_products(d, mode)) dn.P = nullptr;
   if (mode == 1) {
     if (nb_obs) PPS_LAUNCH((k_linearize<1, 0>), dim3(nb_obs), dim3(kLinBlock), lds0, st, dn, pose, plane, nb_obs, nb_odo, nb_pp, gd);
     if (nb_rest) PPS_LAUNCH((k_linearize<1, 1>), dim3(nb_rest), dim3(kLinBlock), lds1, st, dn, pose, plane, nb_obs, nb_odo, nb_pp, gd);
@@ -253,7 +258,9 @@ __global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void kb_lineari
   const int nb_obs = dcdiv(d.n_obs_fixed, kLinBlock), nb_odo = dcdiv(d.n_odo, kLinBlock), nb_pp = dcdiv(d.n_pp, kLinBlock),
             nb_lp = dcdiv(d.n_lp, kLinBlock);
   if ((int)blockIdx.x >= (PART == 0 ? nb_obs : nb_odo + nb_pp + nb_lp)) return;
-  body_linearize<MODE, PART, DIRECT>(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);   // DIRECT pairs with kb_hblocks_t
+  DevGraph dn = d;
+  if (a.no_products) dn.P = nullptr;    // a chunk of > 200 000 factors: its K2 (kb_hblocks_t) multiplies the Jacobians itself
+  body_linearize<MODE, PART, DIRECT>(dn, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, lin_lds);
 }
 
 __global__ __launch_bounds__(64) void kb_linearize_repop(BatchArgs a) {

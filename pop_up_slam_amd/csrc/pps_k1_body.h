@@ -47,6 +47,42 @@ __device__ __forceinline__ void flush_records_coalesced(double* __restrict__ gba
   __builtin_amdgcn_wave_barrier();
 }
 
+// NS doubles per lane (a slice of a wider record) staged through the wave's LDS rows (stride 31: the buffer of the Jacobian record)
+// and written to rows of STRIDE doubles in global memory: runs of NS contiguous doubles per record.
+template <int NS, int STRIDE>
+__device__ __forceinline__ void store_slices_staged(const double (&v)[NS], double* __restrict__ gbase, int n_valid, double* __restrict__ lds_wave) {
+  static_assert(NS <= 30, "the wave buffer holds 31 doubles per lane");
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NS; k++) lds_wave[lane * 31 + k] = v[k];
+  __builtin_amdgcn_wave_barrier();
+  const int total = n_valid * NS;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int idx = lane + 64 * k;
+    if (idx < total) { const int r0 = idx / NS, c0 = idx - r0 * NS; gbase[(size_t)r0 * STRIDE + c0] = lds_wave[r0 * 31 + c0]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// the product record of a plane observation from its Jacobian record out = [J_p 3x6 | J_l 3x3 | r 3] (see body_linearize_lanes)
+__device__ __forceinline__ void obs_products(const double (&out)[30], double (&lo)[27], double (&hi)[27]) {
+  double pr[54];
+#pragma unroll
+  for (int e = 0; e < 54; e++) {
+    const bool pose = e < 42;
+    const int q = pose ? e : e - 42, n = pose ? 6 : 3, base = pose ? 0 : 18;
+    const bool grad = q >= n * n;
+    const int ca = grad ? q - n * n : q / n, cb = grad ? 0 : q - n * (q / n);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc = PPS_MAC(acc, out[base + k * n + ca], grad ? out[27 + k] : out[base + k * n + cb]);
+    pr[e] = grad ? -acc : acc;
+  }
+#pragma unroll
+  for (int e = 0; e < 27; e++) { lo[e] = pr[e]; hi[e] = pr[27 + e]; }
+}
+
 // PART 0: plane-observation edges (16 KB of staging LDS per wave); PART 1: odometry edges and priors
 // (40 KB per wave in analytic mode) -- separate launches so that the big edge class keeps its occupancy.
 // DIRECT (every launch of the solver; off in the sweep benchmark): a plane observation that is the only contribution of its (pose, plane) block writes that H
@@ -89,6 +125,13 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
       }
     }
     if (i0 < d.n_obs_fixed) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs_fixed - i0), lds_wave);
+    if (DIRECT && d.P && i0 < d.n_obs_fixed) {                  // the product record K2 sums (two staged halves of 27 doubles); P is null where K2 multiplies the Jacobians itself
+      double lo[27], hi[27];
+      obs_products(out, lo, hi);
+      double* __restrict__ Pr = d.P + d.poff_obs + (size_t)i0 * 54;
+      store_slices_staged<27, 54>(lo, Pr, min(64, d.n_obs_fixed - i0), lds_wave);
+      store_slices_staged<27, 54>(hi, Pr + 27, min(64, d.n_obs_fixed - i0), lds_wave);
+    }
     return;
   }
   if (PART == 0) return;          // (a PART 0 launch has nb_obs blocks: without this the other factor types are compiled in, 68 KB of dead code)

@@ -38,7 +38,25 @@ __device__ __forceinline__ double wave_segment_sum(const DevGraph& d, int rec, i
   const unsigned long long pmask = __ballot(isp);
   unsigned long long jmask = __ballot(lane < cnt && !isp);
   const double* __restrict__ J = d.J;
+  const double* __restrict__ P = d.P;
   double acc = 0.0;
+  // ---- product records, first batch: requested BEFORE the Jacobian-based contributions are worked on, so that a pose block's
+  // odometry slices and its observations' records are one memory round trip.  One coalesced load per contribution and lane; a small
+  // block (a plane's 12 entries) is summed by several SLICES of the wave at once -- slice s takes the records s, s + S, ... -- and
+  // the slices' sums are added in slice order. ----
+  const int np = __builtin_popcountll(pmask);
+  const int S = size <= 12 ? 5 : (size <= 21 ? 3 : (size <= 32 ? 2 : 1));
+  const int sl = lane / (size > 0 ? size : 1), en = lane - sl * size;
+  const bool live = sl < S && size > 0;
+  const int enc = live ? en : 0;
+  double v0[16];
+  if (np > 0) {                                                 // (wave-uniform)
+    const int rank = __builtin_popcountll(pmask & ((1ull << lane) - 1ull));
+    if (isp) plist[rank] = mine.y;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int k = sl + S * u; v0[u] = P[plist[k < np ? k : np - 1] + enc]; }
+  }
   // ---- contributions that come as Jacobian slices (odometry, priors, re-popping edges, off-diagonal blocks): two in flight ----
   while (jmask) {                                               // (wave-uniform)
     const int c0 = __builtin_ctzll(jmask);
@@ -69,30 +87,16 @@ __device__ __forceinline__ double wave_segment_sum(const DevGraph& d, int rec, i
   }
   if (is_g) acc = -acc;                                         // b = -r (isam/Jacobian.h:98); the product records carry the sign already
   if (!act) acc = 0.0;
-  // ---- product records: one coalesced load per contribution and lane.  A small block (a plane's 12 entries) is summed by several
-  // SLICES of the wave at once -- slice s takes the records s, s + S, ... -- and the slices' sums are added in slice order. ----
-  const int np = __builtin_popcountll(pmask);
-  if (np > 0) {                                                 // (wave-uniform)
-    const int rank = __builtin_popcountll(pmask & ((1ull << lane) - 1ull));
-    if (isp) plist[rank] = mine.y;
-    __builtin_amdgcn_wave_barrier();
-    const int S = size <= 12 ? 5 : (size <= 21 ? 3 : (size <= 32 ? 2 : 1));
-    const int sl = lane / size, en = lane - sl * size;
-    const bool live = sl < S;
-    const int enc = live ? en : 0;
-    const double* __restrict__ P = d.P;
+  if (np > 0) {
     double pacc = 0.0;
-    for (int k0 = 0; k0 < np; k0 += 16 * S) {
-      double v[16]; bool on[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int k = k0 + sl + S * u;
-        on[u] = live && k < np;
-        const int off = plist[k < np ? k : np - 1];
-        v[u] = P[off + enc];
-      }
+    for (int u = 0; u < 16; u++) pacc += (live && sl + S * u < np) ? v0[u] : 0.0;
+    for (int k0 = 16 * S; k0 < np; k0 += 16 * S) {              // (more than 16 records per slice: the ground plane's segments)
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) pacc += on[u] ? v[u] : 0.0;
+      for (int u = 0; u < 16; u++) { const int k = k0 + sl + S * u; v[u] = P[plist[k < np ? k : np - 1] + enc]; }
+#pragma unroll
+      for (int u = 0; u < 16; u++) pacc += (live && k0 + sl + S * u < np) ? v[u] : 0.0;
     }
     __builtin_amdgcn_wave_barrier();                            // (plist is rewritten by the wave's next segment)
     double tot = pacc;

@@ -813,8 +813,9 @@ static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt,
   return hipGetLastError();
 }
 
-hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st) {
-  return launch_band_factor_impl(d, DualAlt{}, 1, grp_begin, grp_count, nwaves, max_front, lambda, st);
+hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st, hipEvent_t ev0,
+                              hipEvent_t ev1) {
+  return launch_band_factor_impl(d, DualAlt{}, 1, grp_begin, grp_count, nwaves, max_front, lambda, st, ev0, ev1);
 }
 
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,

@@ -228,6 +228,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       a.gs = m->d_gs; a.stage_tab = m->d_stage; a.results = m->results; a.n_total = G; a.b0 = c * CH;
       a.n = std::min(G, (c + 1) * CH) - a.b0; a.seq = m->seq;
       a.alt = m->d_alt; a.rstride = 12;
+      a.no_products = geom[c].lin_thread_form ? 1 : 0;
       for (int k = 0; k < a.n; k++) {
         const LMD& q = lm[a.b0 + k];
         a.lambda[k] = q.lambda; a.lambda2[k] = q.lambda * m->gs[a.b0 + k]->props.lm_lambda_factor;
@@ -273,7 +274,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       mark();
       if (any_relin) MHIP(m, launch_batch_linearize(a, q, q.lin_thread_form ? mode | 2 : mode, st));
       mark();
-      if (any_relin) MHIP(m, launch_batch_hblocks(a, q, st, mode == PPS_JAC_NUMERIC && !q.lin_thread_form));
+      if (any_relin) MHIP(m, launch_batch_hblocks(a, q, st, !q.lin_thread_form));
       if (first) MHIP(m, launch_batch_chi2(a, q, 0, st));
       mark();
       hipEvent_t ef = next_event();

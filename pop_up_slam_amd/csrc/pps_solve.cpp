@@ -36,7 +36,7 @@ int do_linearize(pps_graph* g, const LinGuard* guard = nullptr) {
     g->k1_used += 2;
   } else
   { PhaseTimer t(g, &g->stats.t_linearize); HIP_TRY(g, launch_linearize(g->dev, g->props.jacobian_mode, false, g->stream, guard)); }
-  { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream, guard, k1_lane_form(g->dev, g->props.jacobian_mode))); }
+  { PhaseTimer t(g, &g->stats.t_assemble); HIP_TRY(g, launch_hblocks(g->dev, g->stream, guard, k1_products(g->dev, g->props.jacobian_mode))); }
   if (!guard) g->stats.n_linearize++;
   return PPS_OK;
 }
@@ -305,9 +305,15 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
     if (!use_alt) {
       // one damping value: the single-lambda launches; the trial kernel still walks both copies (the second one's step is a stale
       // delta: finite, never read -- have_next is false)
-      for (int st = 0; st < A.n_stages; st++)
+      for (int st = 0; st < A.n_stages; st++) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g->profiling == 1) {
+          if (g->fk_used + 2 > (int)g->fk_events.size()) for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->fk_events.push_back(e); }
+          e0 = g->fk_events[g->fk_used]; e1 = g->fk_events[g->fk_used + 1]; g->fk_used += 2;
+        }
         HIP_TRY(g, launch_band_factor(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
-                                      A.stage_max_front[st], lam, g->stream));
+                                      A.stage_max_front[st], lam, g->stream, e0, e1));
+      }
       for (int st = A.n_stages - 1; st >= 0; st--)
         HIP_TRY(g, launch_band_solve(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
                                      g->stage_max_panel[st], g->stage_max_grp_fronts[st], g->stream, nullptr));
