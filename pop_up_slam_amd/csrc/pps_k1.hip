@@ -176,6 +176,8 @@ __device__ __forceinline__ void body_sweep_bench(const DevGraph& d, double* __re
     if (i0 < d.n_obs) store_records_coalesced<30>(out, Jr + (size_t)i0 * 30, min(64, d.n_obs - i0), lds_wave);
     return;
   }
+  if (PART == 0) return;                // (a PART 0 launch holds plane-observation blocks only: without this the odometry path is compiled in
+                                        // and its register needs -- 66 spilled registers under the two-waves cap -- are the kernel's)
   b -= nb_obs_per;
   const int i0 = b * kLinBlock + (threadIdx.x & ~63);
   const int i = min(b * kLinBlock + (int)threadIdx.x, d.n_odo - 1);
