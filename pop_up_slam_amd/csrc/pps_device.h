@@ -142,7 +142,11 @@ hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, i
 hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
                              const DualAlt* alt = nullptr);
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                                   hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);      // ev0 / ev1: the dispatch's start / stop (profiling level 1)
+                                   hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// the last factor stage and the first back-substitution stage as one launch, where band_root_fusable says so
+bool band_root_fusable(const DevGraph& d, int grp_count, int max_front);
+hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,
+                            int max_group_fronts, double lambda, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);      // ev0 / ev1: the dispatch's start / stop (profiling level 1)
 // both trials of a dual solve: out_k <- base (+) delta_k, chi2 and |delta|^2 of each into its own result record
 hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,

@@ -549,6 +549,34 @@ template <int K> __device__ __forceinline__ double row_bcast_d(double v) {
   return __hiloint2double(hi, lo);
 }
 
+#ifndef PPS_SOLVE_DIRECT
+#define PPS_SOLVE_DIRECT 1
+#endif
+constexpr bool kSolveDirect = PPS_SOLVE_DIRECT != 0;
+
+// The last sixteen pivots of a back-substitution (all of them for p <= 16), chain in registers.
+__device__ __forceinline__ void solve_pivot_chain(int p, double (&lk)[16], double dinv, double& tj) {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
+#endif
+    // pivots 15 .. 0 live in the first row of 16 lanes: t_k and 1 / L_kk reach the other lanes of the row as DPP row broadcasts --
+    // a pivot is two v_mov_dpp + one v_fma_f64, nothing leaves the vector ALU
+    // (lk is 0 on and above the diagonal since it was loaded: a select around the DPP move would be turned into a branch that
+    // switches the source lane off)
+#define PPS_SC(U) lk[U] *= row_bcast_d<U>(dinv);
+    PPS_SC(1) PPS_SC(2) PPS_SC(3) PPS_SC(4) PPS_SC(5) PPS_SC(6) PPS_SC(7) PPS_SC(8) PPS_SC(9) PPS_SC(10) PPS_SC(11) PPS_SC(12) PPS_SC(13) PPS_SC(14) PPS_SC(15)
+#undef PPS_SC
+#define PPS_BS(U) case U: tj -= lk[U] * row_bcast_d<U>(tj); [[fallthrough]];
+    switch (p < 16 ? p - 1 : 15) {                            // (wave-uniform: the chain is entered at the last pivot)
+      PPS_BS(15) PPS_BS(14) PPS_BS(13) PPS_BS(12) PPS_BS(11) PPS_BS(10) PPS_BS(9) PPS_BS(8)
+      PPS_BS(7) PPS_BS(6) PPS_BS(5) PPS_BS(4) PPS_BS(3) PPS_BS(2)
+      case 1: tj -= lk[1] * row_bcast_d<1>(tj); [[fallthrough]];
+      default: break;
+    }
+#undef PPS_BS
+    tj *= dinv;
+}
+
 // x_p = L_A^-T (y - L_B^T x_b) for one front, one wave (p <= 64).  The factor panel ((f+1) x p, contiguous) is
 // copied to LDS in batches of 16 independent coalesced loads per lane -- two round trips for a C2 front instead of one
 // per 8 rows -- and everything after that reads LDS; the back-substitution chain runs in registers (lane j holds
@@ -576,6 +604,62 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   const int ix0r = ix[lane < b ? lane : 0], ix1r = ix[lane + 64 < b ? lane + 64 : 0];
   const int pix = d.pidx[__builtin_amdgcn_readlane(rec, 7) + (lane < p ? lane : 0)];      // (where x_p goes: fetched with the rest)
   const int n = (f + 1) * p;
+  double tj = 0.0, dinv = 0.0;
+  double lk[16];
+  if (kSolveDirect && GROUP && p <= 16) {                       // (wave-uniform) every separator front of a corridor tree; band form only:
+    // the level-per-launch form of a large batch is issue-bound and 3 % slower with the extra address arithmetic (G = 128: 11.4 against 11.0 ms)
+    // DIRECT form: no LDS copy of the panel.  Every lane requests exactly the entries it will multiply -- rows part, part + 4, ... of
+    // L_B in column j (lane = 16 part + j), the sixteen rows of L_A^T in its column, the diagonal, the rhs row -- 30 independent loads
+    // in one round trip, issued before the boundary values are waited for; the products then read registers.  The sums run in the
+    // order of the LDS form below (same bits).
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)
+#endif
+    const int j = lane & 15, part = lane >> 4;
+    const int jc = j < p ? j : 0, lc = lane < p ? lane : 0;
+    const double* __restrict__ LB = Lp + p * p + jc;            // (b = 0: row 0 of "L_B" is the rhs row -- readable, multiplied by 0)
+    const int blast = b > 0 ? b - 1 : 0;
+    double lbv[12];
+#pragma unroll
+    for (int u = 0; u < 12; u++) { const int i = part + 4 * u; lbv[u] = LB[(i < b ? i : blast) * p]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const double l = Lp[(u < p ? u : p - 1) * p + lc]; lk[u] = lane < u ? l : 0.0; }
+    const double dg = Lp[lc * p + lc], yr = Lp[f * p + jc];
+    const int ix0 = lane < b ? ix0r : 0, ix1 = lane + 64 < b ? ix1r : 0;
+    double g0 = 0.0, g1 = 0.0;
+    if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }
+    else { const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows; g0 = Xp[ix0]; g1 = Xp[ix1]; }
+    if (TR) PPS_TR(1);
+    if (lane < b) xb[lane] = g0;
+    if (lane + 64 < b) xb[lane + 64] = g1;
+    __builtin_amdgcn_wave_barrier();
+    if (TR) PPS_TR(2);
+    dinv = 1.0 / dg;
+    double a[4] = {part == 0 ? yr : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 12; u++) { const int i = part + 4 * u; const double x = i < b ? xb[i] : 0.0; a[u & 3] -= lbv[u] * x; }
+    for (int i0 = 48; i0 < b; i0 += 48) {                       // (boundaries of more than 48 rows: one more round trip per 48)
+#pragma unroll
+      for (int u = 0; u < 12; u++) { const int i = i0 + part + 4 * u; lbv[u] = LB[(i < b ? i : blast) * p]; }
+#pragma unroll
+      for (int u = 0; u < 12; u++) { const int i = i0 + part + 4 * u; const double x = i < b ? xb[i] : 0.0; a[u & 3] -= lbv[u] * x; }
+    }
+    tj = (a[0] + a[1]) + (a[2] + a[3]);
+    tj += __shfl_xor(tj, 32);
+    tj += __shfl_xor(tj, 16);
+    tj = lane < p ? tj : 0.0;
+    if (TR) PPS_TR(3);
+    solve_pivot_chain(p, lk, dinv, tj);
+    if (TR) PPS_TR(4);
+    if (lane < p) d.delta[pix] = tj;
+    if (TR) PPS_TR(5);
+    if (!GROUP) return;
+    double* __restrict__ Xs = X + (size_t)slot * kBandMaxRows;
+    if (lane < p) Xs[lane] = tj;
+    if (lane < b) Xs[p + lane] = g0;
+    if (lane + 64 < b) Xs[p + lane + 64] = g1;
+    return;
+  }
   // first batch of the panel (all of it for n <= 1024) issued right behind the index loads: the gather from delta below then waits
   // for the indices only, with the panel in flight
   double v[16];
@@ -602,7 +686,6 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane + 64 < b) xb[lane + 64] = g1;
   __builtin_amdgcn_wave_barrier();
   if (TR) PPS_TR(2);
-  double tj = 0.0, dinv = 0.0;
   {
 #ifndef PPS_NO_FMA
 #pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
@@ -612,7 +695,6 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     // LDS round trip, no select -- and x = t / diag(L) is one multiplication at the end.
     const int lc = lane < p ? lane : 0;
     int k0 = (p - 1) & ~15;
-    double lk[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) { const int k = k0 + u; const double l = PL[(k < p ? k : p - 1) * p + lc]; lk[u] = lane < k ? l : 0.0; }
     dinv = 1.0 / PL[lc * p + lc];
@@ -644,22 +726,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
 #pragma unroll
       for (int u = 0; u < 16; u++) { const int k = k0 - 16 + u; const double l = PL[k * p + lc]; lk[u] = lane < k ? l : 0.0; }
     }
-    // pivots 15 .. 0 live in the first row of 16 lanes: t_k and 1 / L_kk reach the other lanes of the row as DPP row broadcasts --
-    // a pivot is two v_mov_dpp + one v_fma_f64, nothing leaves the vector ALU
-    // (lk is 0 on and above the diagonal since it was loaded: a select around the DPP move would be turned into a branch that
-    // switches the source lane off)
-#define PPS_SC(U) lk[U] *= row_bcast_d<U>(dinv);
-    PPS_SC(1) PPS_SC(2) PPS_SC(3) PPS_SC(4) PPS_SC(5) PPS_SC(6) PPS_SC(7) PPS_SC(8) PPS_SC(9) PPS_SC(10) PPS_SC(11) PPS_SC(12) PPS_SC(13) PPS_SC(14) PPS_SC(15)
-#undef PPS_SC
-#define PPS_BS(U) case U: tj -= lk[U] * row_bcast_d<U>(tj); [[fallthrough]];
-    switch (p < 16 ? p - 1 : 15) {                            // (wave-uniform: the chain is entered at the last pivot)
-      PPS_BS(15) PPS_BS(14) PPS_BS(13) PPS_BS(12) PPS_BS(11) PPS_BS(10) PPS_BS(9) PPS_BS(8)
-      PPS_BS(7) PPS_BS(6) PPS_BS(5) PPS_BS(4) PPS_BS(3) PPS_BS(2)
-      case 1: tj -= lk[1] * row_bcast_d<1>(tj); [[fallthrough]];
-      default: break;
-    }
-#undef PPS_BS
-    tj *= dinv;
+    solve_pivot_chain(p, lk, dinv, tj);
   }
   if (TR) PPS_TR(4);
   if (lane < p) d.delta[pix] = tj;
@@ -760,6 +827,16 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, in
   body_band_factor<REG_ONLY>(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
+// The root stage of a tree whose top is ONE group of register-resident fronts (C2: the root front), factored and solved by one launch:
+// the workgroup that has eliminated the top fronts walks back down them.  L and the forward-solved rhs rows reach the back-substitution
+// through the CU's own cache behind the workgroup barrier that ends the last level of the factorisation.
+__global__ __launch_bounds__(512) void k_band_root(DevGraph d, DualAlt alt, int grp, double lambda, int per_wave_factor, int per_wave_solve) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
+  body_band_factor<true>(d, grp, lambda, per_wave_factor, lds);
+  body_band_solve(d, grp, per_wave_solve, lds);
+}
+
 // PPS_TRACE=1 on a register-only stage: the phase trace compiled into the register-only kernel
 __global__ __launch_bounds__(512) void k_band_factor_lean_trace(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
@@ -787,6 +864,7 @@ static hipError_t ensure_band_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_r5), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_lean_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
   }
@@ -834,6 +912,21 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
   const size_t bytes = ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
   if (d.trace != nullptr && d.trace_solve && !alt) PPS_LAUNCH(k_band_solve_trace, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, per_wave);
   else PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
+  return hipGetLastError();
+}
+
+// the root stage as one launch (k_band_root): one group, every front register-resident, no trace
+bool band_root_fusable(const DevGraph& d, int grp_count, int max_front) {
+  static const bool off = getenv("PPS_NO_ROOT_FUSE") != nullptr;
+  return !off && grp_count == 1 && max_front + 1 <= kRegRows && d.trace == nullptr;
+}
+hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,
+                            int max_group_fronts, double lambda, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
+  const int nw = nwaves_factor > nwaves_solve ? nwaves_factor : nwaves_solve;
+  const int pwf = (int)(band_lds_bytes(max_front, true) / sizeof(double)), pws = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
+  const size_t bf = (size_t)pwf * nw * sizeof(double), bs = ((size_t)pws * nw + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
+  PPS_LAUNCH_EV(ev0, ev1, k_band_root, dim3(1, alt ? 2 : 1), dim3(64 * nw), bf > bs ? bf : bs, st, d, alt ? *alt : DualAlt{}, grp, lambda, pwf, pws);
   return hipGetLastError();
 }
 
@@ -903,6 +996,9 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
 // One launch per tree level and size class; a workgroup is four independent fronts (no group, no barrier), the kernel of a
 // class holds exactly its tile rows: 86 / 118 VGPRs for fronts of <= 32 / <= 48 rows against the 256 of the band kernel that
 // carries all three, so 5 / 3 waves share a SIMD instead of 2 (the 12 KB triangle of a 48-row front is what stops at 3).
+#ifndef PPS_LVL3_WAVES
+#define PPS_LVL3_WAVES 3
+#endif
 #define PPS_LEVEL_FACTOR_KERNEL(NAME, NT, WAVES)                                                                      \
   __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(BatchArgs a, int level,   \
                                                                                                 int lds_doubles_per_wave) { \
@@ -926,7 +1022,7 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
     wave_front_factor_reg<NT, false, false, PPS_PANEL_W_LEVEL>(d, rec, a.lambda[b], F, Pn, tr);                                              \
   }
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor2, 2, 5)
-PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, 3)
+PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, PPS_LVL3_WAVES)
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor4, 4, 2)
 #undef PPS_LEVEL_FACTOR_KERNEL
 

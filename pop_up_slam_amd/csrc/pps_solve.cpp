@@ -42,16 +42,33 @@ int do_linearize(pps_graph* g, const LinGuard* guard = nullptr) {
 }
 
 // delta = (J'J + lambda diag(J'J))^-1 J'b  (Optimizer::compute_gauss_newton_step, Optimizer.cpp:49-67)
-int do_solve_on(pps_graph* g, const DevGraph& dv, double lambda, hipStream_t st_) {
+// Factor stages leaves -> root, back-substitution stages root -> leaves, for one damping value (alt == nullptr) or two.  The root stage
+// is one launch for both directions where its fronts allow it (band_root_fusable).  events: the factor launches carry their own start /
+// stop events (profiling level 1; the fused root launch's pair spans its back-substitution as well).
+static int enqueue_factor_solve(pps_graph* g, const DevGraph& dv, const DualAlt* alt, double lambda, hipStream_t st_, bool events) {
   const Analysis& A = g->an;
-  for (int st = 0; st < A.n_stages; st++)
-    HIP_TRY(g, launch_band_factor(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
-                                  A.stage_max_front[st], lambda, st_));
-  for (int st = A.n_stages - 1; st >= 0; st--)
+  const int top = A.n_stages - 1;
+  const bool fuse = top >= 0 && band_root_fusable(dv, A.stage_grp_off[top + 1] - A.stage_grp_off[top], A.stage_max_front[top]);
+  for (int st = 0; st < A.n_stages; st++) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (events) {                                                  // the launch's own start / stop: resolve_k1_events sums them into t_factor
+      if (g->fk_used + 2 > (int)g->fk_events.size()) for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->fk_events.push_back(e); }
+      e0 = g->fk_events[g->fk_used]; e1 = g->fk_events[g->fk_used + 1]; g->fk_used += 2;
+    }
+    const int g0 = A.stage_grp_off[st], ng = A.stage_grp_off[st + 1] - g0;
+    if (fuse && st == top)
+      HIP_TRY(g, launch_band_root(dv, alt, g0, g->stage_nw_factor[st], g->stage_nw_solve[st], A.stage_max_front[st], g->stage_max_panel[st],
+                                  g->stage_max_grp_fronts[st], lambda, st_, e0, e1));
+    else if (alt) HIP_TRY(g, launch_band_factor_dual(dv, *alt, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1));
+    else HIP_TRY(g, launch_band_factor(dv, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1));
+  }
+  for (int st = fuse ? top - 1 : top; st >= 0; st--)
     HIP_TRY(g, launch_band_solve(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
-                                 g->stage_max_panel[st], g->stage_max_grp_fronts[st], st_));
+                                 g->stage_max_panel[st], g->stage_max_grp_fronts[st], st_, alt));
   return PPS_OK;
 }
+
+int do_solve_on(pps_graph* g, const DevGraph& dv, double lambda, hipStream_t st_) { return enqueue_factor_solve(g, dv, nullptr, lambda, st_, false); }
 
 int do_solve(pps_graph* g, double lambda) {
   const Analysis& A = g->an;
@@ -305,18 +322,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
     if (!use_alt) {
       // one damping value: the single-lambda launches; the trial kernel still walks both copies (the second one's step is a stale
       // delta: finite, never read -- have_next is false)
-      for (int st = 0; st < A.n_stages; st++) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g->profiling == 1) {
-          if (g->fk_used + 2 > (int)g->fk_events.size()) for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->fk_events.push_back(e); }
-          e0 = g->fk_events[g->fk_used]; e1 = g->fk_events[g->fk_used + 1]; g->fk_used += 2;
-        }
-        HIP_TRY(g, launch_band_factor(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
-                                      A.stage_max_front[st], lam, g->stream, e0, e1));
-      }
-      for (int st = A.n_stages - 1; st >= 0; st--)
-        HIP_TRY(g, launch_band_solve(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
-                                     g->stage_max_panel[st], g->stage_max_grp_fronts[st], g->stream, nullptr));
+      { const int rc2 = enqueue_factor_solve(g, d, nullptr, lam, g->stream, g->profiling == 1); if (rc2 != PPS_OK) return rc2; }
       g->stats.n_factorize += 1;
       g->seq += 1.0; seqs[0] = g->seq;
       g->seq2 += 1.0; seqs[1] = g->seq2;
@@ -324,18 +330,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
                                    g->stream));
       return PPS_OK;
     }
-    for (int st = 0; st < A.n_stages; st++) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (g->profiling == 1) {                                     // the launch's own start / stop: resolve_k1_events sums them into t_factor
-        if (g->fk_used + 2 > (int)g->fk_events.size()) for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->fk_events.push_back(e); }
-        e0 = g->fk_events[g->fk_used]; e1 = g->fk_events[g->fk_used + 1]; g->fk_used += 2;
-      }
-      HIP_TRY(g, launch_band_factor_dual(d, alt, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_factor[st],
-                                         A.stage_max_front[st], lam, g->stream, e0, e1));
-    }
-    for (int st = A.n_stages - 1; st >= 0; st--)
-      HIP_TRY(g, launch_band_solve(d, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],
-                                   g->stage_max_panel[st], g->stage_max_grp_fronts[st], g->stream, &alt));
+    { const int rc2 = enqueue_factor_solve(g, d, &alt, lam, g->stream, g->profiling == 1); if (rc2 != PPS_OK) return rc2; }
     g->stats.n_factorize += 2;
     g->seq += 1.0; seqs[0] = g->seq;
     g->seq2 += 1.0; seqs[1] = g->seq2;

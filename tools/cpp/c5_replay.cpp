@@ -65,7 +65,13 @@ int main(int argc, char** argv) {
     std::vector<float> planes;
     std::vector<int> fids;
     long lm_iterations = 0, lm_calls = 0, points = 0;
+    // C5_TIMING=1: host wall time per call site, printed to stderr (where the frame's 0.5 ms goes)
+    const bool timing = getenv("C5_TIMING") != nullptr;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](int k) { if (!timing) return; const auto t = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::micro>(t - tick).count(); tick = t; };
     const auto t0 = std::chrono::steady_clock::now();
+    tick = t0;
     for (int k = 0; k < n_frames; k++) {
       const FrameIn& fr = frames[k];
       const int n = (int)fr.ids.size();
@@ -75,10 +81,13 @@ int main(int argc, char** argv) {
       float T32[16];
       for (int i = 0; i < 16; i++) T32[i] = (float)T[i];
       int n_valid = 0;
+      lap(0);
       CK(pps_popup_run(pp, fr.seg.data(), n, T32, fr.polys.data(), fr.poly_off.data(), n + 1, step, 10.0f, 2.5f, &n_valid));
       points += n_valid;
+      lap(1);
       planes.resize(4 * (size_t)(n + 1));
       CK(pps_popup_download(pp, planes.data(), nullptr, nullptr, nullptr));
+      lap(2);
       Pose3d_Node* poseNode = new Pose3d_Node();
       slam.add_node(poseNode);                                                   // Mapping.cpp:464-465
       poseNode->init(est);
@@ -103,17 +112,23 @@ int main(int argc, char** argv) {
         slam.add_factor(fac);
         fids[j] = fac->backend_id();
       }
-      if (k % 5 == 0) { lm_iterations += slam.batch_optimization(); lm_calls++; }   // :551-554
-      else slam.update();
+      lap(3);
+      if (k % 5 == 0) { lm_iterations += slam.batch_optimization(); lm_calls++; lap(4); }   // :551-554
+      else { slam.update(); lap(5); }
       int frame_id = 0;
       CK(pps_frames_add(g, poseNode->backend_id(), n, fr.seg.data(), fids.data(), &frame_id));
       CK(pps_refresh_measurements(g));                                           // main_3d.cpp:504 -> Mapping.cpp:590-607
+      lap(6);
     }
     const double chi2 = slam.chi2();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("{\"frames\": %d, \"frames_per_sec\": %.3f, \"wall_s\": %.6f, \"pixel_step\": %d, \"final_chi2\": %.17g, \"lm_calls\": %ld, "
            "\"lm_iterations\": %ld, \"points_per_frame\": %.1f, \"nodes\": %d, \"factors\": %d, \"host\": \"C++ facade (include/pps_isam.hpp)\"}\n",
            n_frames, n_frames / wall, wall, step, chi2, lm_calls, lm_iterations, (double)points / n_frames, slam.num_nodes(), slam.num_factors());
+    if (timing)
+      fprintf(stderr, "[c5 timing] us per frame: pose prediction %.1f | popup_run %.1f | popup_download %.1f | graph construction %.1f | "
+              "batch_optimization %.1f (per frame; 1 in 5) | update %.1f (per frame; 4 in 5) | frames_add + refresh %.1f\n",
+              acc[0] / n_frames, acc[1] / n_frames, acc[2] / n_frames, acc[3] / n_frames, acc[4] / n_frames, acc[5] / n_frames, acc[6] / n_frames);
     pps_popup_destroy(pp);
   } catch (const std::exception& e) {
     fprintf(stderr, "error: %s\n", e.what());
