@@ -71,6 +71,53 @@ struct Builder {
   }
   int degree(int u) const { return adj_off[u + 1] - adj_off[u]; }
 
+  // The same adjacency from the one of the previous analysis (rows of the first n0 nodes, edges of the first m0 factors) and the
+  // factors behind m0, every one of which touches a node >= n0 (checked by the caller): an old row gains neighbours >= n0 only, i.e.
+  // behind everything it holds -- one copy of the old rows with the sorted additions appended, instead of a counting sort over
+  // every factor of the graph on every frame.  keep(u, v): rows / entries to leave out (the dense border for the dissection's view).
+  template <class Keep>
+  void extend_adjacency(const std::vector<int>& off0, const std::vector<int>& adj0, size_t n0, size_t m0, std::vector<int>& off1,
+                        std::vector<int>& adj1, Keep keep) const {
+    static thread_local std::vector<int> cnt, raw, fill;
+    cnt.assign(N + 1, 0);
+    for (size_t i = m0; i < factors.size(); i++) {
+      const auto& f = factors[i];
+      if (f.b >= 0 && f.a != f.b) { cnt[f.a + 1]++; cnt[f.b + 1]++; }
+    }
+    for (int i = 0; i < N; i++) cnt[i + 1] += cnt[i];
+    raw.resize(cnt[N]); fill.assign(cnt.begin(), cnt.end() - 1);
+    for (size_t i = m0; i < factors.size(); i++) {
+      const auto& f = factors[i];
+      if (f.b >= 0 && f.a != f.b) { raw[fill[f.a]++] = f.b; raw[fill[f.b]++] = f.a; }
+    }
+    off1.assign(N + 1, 0);
+    adj1.clear();
+    adj1.reserve(adj0.size() + raw.size());
+    for (int u = 0; u < N; u++) {
+      if ((size_t)u < n0) adj1.insert(adj1.end(), adj0.begin() + off0[u], adj0.begin() + off0[u + 1]);
+      int* b = raw.data() + cnt[u];
+      int* e = raw.data() + cnt[u + 1];
+      if (b != e) {
+        if (!std::is_sorted(b, e)) std::sort(b, e);
+        e = std::unique(b, e);
+        for (int* q = b; q < e; q++) if (keep(u, *q)) adj1.push_back(*q);
+      }
+      off1[u + 1] = (int)adj1.size();
+    }
+  }
+  // any pose-pose edge between poses that are not neighbours in rank?  (none in a frame loop: dissect() then has no cross edges to
+  // look for in any sub-chain -- two poses of consecutive rank are neighbours in every sub-chain that holds both)
+  bool cross_edges_among(size_t m0) const {
+    for (size_t i = m0; i < factors.size(); i++) {
+      const auto& f = factors[i];
+      if (f.b < 0 || f.a == f.b || nodes[f.a].type != NODE_POSE || nodes[f.b].type != NODE_POSE) continue;
+      const int dr = nodes[f.a].rank - nodes[f.b].rank;
+      if (dr != 1 && dr != -1) return true;
+    }
+    return false;
+  }
+  bool any_cross = true;           // (false: proven that no sub-chain has a pose-pose edge between non-neighbours)
+
   int new_tnode() { tree.emplace_back(); t_reused.push_back(0); t_old.push_back(-1); return (int)tree.size() - 1; }
 
   // General fill-reducing ordering for graphs the pose chain does not dissect well (pose graphs with many loop
@@ -228,7 +275,7 @@ struct Builder {
     }
     // pose-pose edges that are not between chain neighbours
     std::vector<std::pair<int, int>> cross;
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; any_cross && i < n; i++) {
       const int u = poses[i];
       for (int q = adj_off[u]; q < adj_off[u + 1]; q++) {
         const int v = adj[q];
@@ -393,9 +440,17 @@ struct AnalysisCache {
   std::vector<DissectMemo> memo;
   std::vector<int> memo_of_first, memo_next;
   std::vector<int> post;                  // post-order sequence of tree nodes
+  std::vector<int> post_fend;             // fronts emitted up to and including post[k]
   std::vector<int> f_pos0, f_npiv;        // first position / node count of every front
   std::vector<std::vector<int>> bnd;      // boundary nodes of every front, in elimination order
   std::vector<int> blk_pu;                // column position of every H block (blocks are sorted by it)
+  std::vector<int> adj_off, adj;          // node adjacency (CSR, sorted unique) ...
+  std::vector<int> adj2_off, adj2;        // ... and the dissection's view of it (dense border left out)
+  bool any_cross = true;                  // a pose-pose edge between poses that are not rank neighbours exists
+  std::vector<std::vector<int>> inc;      // factors of every node, in factor order, for the first inc_factors factors
+  size_t inc_factors = 0;
+  int64_t J_size = 0, P_size = 0;         // running maxima over those factors
+  int n_obs_slots = 0;
   int fronts_reused = 0, fronts_total = 0;
 };
 AnalysisCache* analysis_cache_new() { return new AnalysisCache(); }
@@ -440,7 +495,15 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   A.n_nodes = N;
   lap("validate / reset");
   Builder B(nodes, factors, prm);
-  B.build_adjacency();
+  // (the adjacency of the previous analysis extended by the new factors, when there is one to extend)
+  const bool adj_inc = reuse && C->adj_off.size() == C->nodes.size() + 1 && C->adj2_off.size() == C->nodes.size() + 1;
+  if (adj_inc) {
+    B.extend_adjacency(C->adj_off, C->adj, C->nodes.size(), C->factors.size(), B.adj_off, B.adj, [](int, int) { return true; });
+    B.any_cross = C->any_cross || B.cross_edges_among(C->factors.size());
+  } else {
+    B.build_adjacency();
+    B.any_cross = B.cross_edges_among(0);
+  }
   lap("adjacency");
   B.lidx.assign(N, -1);
   B.dense.assign(N, 0);
@@ -457,21 +520,30 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     for (size_t u = 0; u < C->dense.size(); u++) if (C->dense[u] != B.dense[u]) return 2;
     for (size_t u = C->dense.size(); u < (size_t)N; u++) if (B.dense[u]) return 2;
   }
+  lap("  dense / lists");
   std::sort(poses.begin(), poses.end(), [&](int a, int b) { return nodes[a].rank < nodes[b].rank; });
+  lap("  pose sort");
   // strip dense nodes from the adjacency the dissection sees
   std::vector<int> post;
   std::vector<int> f_pos0, f_npiv;
+  std::vector<int> adj2_off_keep, adj2_keep;
   int root = -1;
   {
-    std::vector<int> off(N + 1, 0), a2;
-    a2.reserve(B.adj.size());
-    for (int u = 0; u < N; u++) {
-      for (int q = B.adj_off[u]; q < B.adj_off[u + 1]; q++)
-        if (!B.dense[B.adj[q]] && !B.dense[u]) a2.push_back(B.adj[q]);
-      off[u + 1] = (int)a2.size();
+    std::vector<int> off, a2;
+    if (adj_inc) {                 // (the border is the one it was: checked above)
+      B.extend_adjacency(C->adj2_off, C->adj2, C->nodes.size(), C->factors.size(), off, a2, [&](int u, int v) { return !B.dense[u] && !B.dense[v]; });
+    } else {
+      off.assign(N + 1, 0);
+      a2.reserve(B.adj.size());
+      for (int u = 0; u < N; u++) {
+        for (int q = B.adj_off[u]; q < B.adj_off[u + 1]; q++)
+          if (!B.dense[B.adj[q]] && !B.dense[u]) a2.push_back(B.adj[q]);
+        off[u + 1] = (int)a2.size();
+      }
     }
     B.adj_off.swap(off);           // (off / a2 hold the full adjacency until the swap back below)
     B.adj.swap(a2);
+    lap("  border stripped");
     int top = -1;
     if (!poses.empty() || !planes.empty()) {
       if (general_ordering) {
@@ -486,6 +558,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     }
     B.adj_off.swap(off);
     B.adj.swap(a2);
+    adj2_off_keep.swap(off); adj2_keep.swap(a2);       // (the dissection's view: what the next analysis extends)
     root = top;
     if (!dense_nodes.empty()) {
       // planes first, poses last
@@ -536,53 +609,68 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   // keep their numbers, positions and everything indexed by them
   size_t K0 = 0;
   if (reuse) while (K0 < post.size() && K0 < C->post.size() && B.t_reused[post[K0]] && B.t_old[post[K0]] == C->post[K0]) K0++;
-  A.node_pos.assign(N, -1);
   A.node_voff.assign(N, -1);
   { int off = 0; for (int u = 0; u < N; u++) { A.node_voff[u] = off; off += nodes[u].dim; } }   // creation order: append-only
-  A.order.clear();
-  A.pidx.clear();
-  A.f_p.clear(); A.f_poff.clear(); A.f_parent.clear();
   std::vector<int> tn_last(B.tree.size(), -1);
+  std::vector<int> post_fend(post.size(), 0);             // fronts emitted up to and including post[k]
   int pos = 0, voff = 0;
   int F0 = 0;                                             // fronts kept from the previous analysis
-  for (size_t pi = 0; pi < post.size(); pi++) {
+  // The first K0 tree nodes are the previous analysis' own, in the same places: their fronts, positions and pivot index lists are
+  // what `A` still holds -- nothing of that part is written again (a frame of a frame loop redoes its right spine only).
+  if (K0 > 0 && C->post_fend.size() >= K0 && (int)A.order.size() == (int)C->nodes.size() && A.node_pos.size() == C->nodes.size()) {
+    F0 = C->post_fend[K0 - 1];
+    if (F0 > (int)C->f_pos0.size() || F0 > (int)A.f_b.size() || F0 > (int)A.f_p.size() || F0 <= 0) return 2;
+    for (size_t k = 0; k < K0; k++) { post_fend[k] = C->post_fend[k]; tn_last[post[k]] = C->post_fend[k] - 1; }
+    f_pos0.assign(C->f_pos0.begin(), C->f_pos0.begin() + F0);
+    f_npiv.assign(C->f_npiv.begin(), C->f_npiv.begin() + F0);
+    pos = f_pos0[F0 - 1] + f_npiv[F0 - 1];
+    voff = A.f_poff[F0 - 1] + A.f_p[F0 - 1];
+    for (size_t k = (size_t)pos; k < A.order.size(); k++) A.node_pos[A.order[k]] = -1;
+    A.node_pos.resize(N, -1);
+    A.order.resize(pos);
+    A.pidx.resize(voff);
+    A.f_p.resize(F0); A.f_poff.resize(F0); A.f_parent.resize(F0);
+  } else {
+    K0 = 0;
+    A.node_pos.assign(N, -1);
+    A.order.clear();
+    A.pidx.clear();
+    A.f_p.clear(); A.f_poff.clear(); A.f_parent.clear();
+  }
+  for (size_t pi = K0; pi < post.size(); pi++) {
     const int t = post[pi];
     const TNode& tn = B.tree[t];
-    std::vector<std::vector<int>> chunks(1);
-    int acc = 0;
-    for (int u : tn.piv) {
-      if (acc + nodes[u].dim > prm.max_pivots && acc > 0) { chunks.emplace_back(); acc = 0; }
-      chunks.back().push_back(u);
-      acc += nodes[u].dim;
-    }
-    for (size_t k = 0; k < chunks.size(); k++) {
-      const int s = (int)A.f_p.size();
-      f_pos0.push_back(pos);
-      A.f_poff.push_back(voff);
-      for (int u : chunks[k]) {
-        if (A.node_pos[u] != -1) { *msg = "internal: node placed twice"; return 0; }
-        A.node_pos[u] = pos++;
-        for (int dd = 0; dd < nodes[u].dim; dd++) A.pidx.push_back(A.node_voff[u] + dd);
-        voff += nodes[u].dim;
-        A.order.push_back(u);
-      }
-      f_npiv.push_back(pos - f_pos0[s]);
-      A.f_p.push_back(voff - A.f_poff[s]);
+    // oversized supernodes are emitted as a chain of fronts: a new one starts where the next node would exceed max_pivots scalars
+    int acc = 0, s = -1;
+    bool first = true;
+    auto open_front = [&]() {
+      s = (int)A.f_p.size();
+      f_pos0.push_back(pos); f_npiv.push_back(0);
+      A.f_poff.push_back(voff); A.f_p.push_back(0);
       A.f_parent.push_back(-1);
-      if (k == 0) { for (int c : tn.kids) A.f_parent[tn_last[c]] = s; }
+      if (first) { for (int c : tn.kids) A.f_parent[tn_last[c]] = s; }
       else A.f_parent[s - 1] = s;
+      first = false;
+    };
+    open_front();
+    for (int u : tn.piv) {
+      if (acc + nodes[u].dim > prm.max_pivots && acc > 0) { open_front(); acc = 0; }
+      if (A.node_pos[u] != -1) { *msg = "internal: node placed twice"; return 0; }
+      A.node_pos[u] = pos++;
+      for (int dd = 0; dd < nodes[u].dim; dd++) A.pidx.push_back(A.node_voff[u] + dd);
+      voff += nodes[u].dim;
+      A.order.push_back(u);
+      acc += nodes[u].dim;
+      f_npiv[s] = pos - f_pos0[s];
+      A.f_p[s] = voff - A.f_poff[s];
     }
     tn_last[t] = (int)A.f_p.size() - 1;
-    if (pi + 1 == K0) F0 = (int)A.f_p.size();
+    post_fend[pi] = (int)A.f_p.size();
   }
   const int F = (int)A.f_p.size();
   A.n_fronts = F;
   if (pos != N) { *msg = "internal: ordering does not cover all nodes"; return 0; }
   A.n_scalars = voff;
-  if (reuse) {
-    if (F0 > (int)C->f_pos0.size() || F0 > (int)A.f_b.size()) return 2;
-    for (int s = 0; s < F0; s++) if (f_pos0[s] != C->f_pos0[s] || f_npiv[s] != C->f_npiv[s]) return 2;
-  }
   A.f_b.resize(F, 0); A.f_level.assign(F, 0);
 
   lap("post-order / chains");
@@ -789,77 +877,87 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   const int C0 = S0 > 0 ? (S0 < (int)A.seg_c0.size() ? A.seg_c0[S0] : (int)(A.contrib.size() / 4)) : 0;
   const int64_t H0 = B0 > 0 ? (B0 < (int)A.blk_hoff.size() ? A.blk_hoff[B0] : A.H_size) : 0;
   std::vector<Ctr> ctr;
-  ctr.reserve(factors.size() * 3);
-  A.J_size = 0; A.P_size = 0;
-  int n_obs_slots = 0;
-  for (size_t fi2 = 0; fi2 < factors.size(); fi2++) {
+  // The factors of every node, in factor order (append-only: the next analysis of the grown graph adds the new factors).  The
+  // contributions are listed COLUMN BY COLUMN from them -- only the columns of the redone positions are visited, so a frame of a
+  // frame loop walks the factors of its right spine and of the border, not every factor of the graph.
+  std::vector<std::vector<int>> inc_local;
+  std::vector<std::vector<int>>& inc = C ? C->inc : inc_local;
+  size_t m_from = 0;
+  if (reuse && C->inc_factors <= factors.size() && C->inc.size() <= (size_t)N && C->inc_factors == C->factors.size()) {
+    m_from = C->inc_factors;
+    A.J_size = C->J_size; A.P_size = C->P_size;
+  } else {
+    for (auto& v : inc) v.clear();
+    A.J_size = 0; A.P_size = 0;
+    if (C) C->n_obs_slots = 0;
+  }
+  inc.resize(N);
+  int n_obs_slots = (C && m_from > 0) ? C->n_obs_slots : 0;
+  for (size_t fi2 = m_from; fi2 < factors.size(); fi2++) {
     const auto& f = factors[fi2];
-    const int fi = (int)fi2;
     if (f.type == F_PLANE_OBS) n_obs_slots = std::max(n_obs_slots, f.joff / kJSize[F_PLANE_OBS] + 1);
     const int m = kFDim[f.type];
     const int da = nodes[f.a].dim;
     const int db = f.b >= 0 ? nodes[f.b].dim : 0;
-    const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
-    A.J_size = std::max<int64_t>(A.J_size, (int64_t)roff + m);
-    // A plain plane observation (direct_ok) hands K2 its PRODUCT record instead of its Jacobian for the two diagonal blocks it
-    // feeds: the contribution carries the record's offset in `ju` and kProductFlag on top of the row count.
-    const bool prod = f.type == F_PLANE_OBS && f.direct_ok;
-    if (prod) A.P_size = std::max<int64_t>(A.P_size, (int64_t)f.poff + kPSize[f.type]);
-    const int pa = A.node_pos[f.a];
-    if (pa >= P0) ctr.push_back({pa, pa, ja, prod ? f.poff : ja, roff, prod ? m + kProductFlag : m, fi});
-    if (f.b >= 0) {
-      const int pb = A.node_pos[f.b];
-      if (pb >= P0) ctr.push_back({pb, pb, jb, prod ? f.poff + da * da + da : jb, roff, prod ? m + kProductFlag : m, fi});
-      if (pa > pb) { if (pb >= P0) ctr.push_back({pa, pb, ja, jb, roff, m, fi}); }   // rows = later node
-      else         { if (pa >= P0) ctr.push_back({pb, pa, jb, ja, roff, m, fi}); }
-    }
+    A.J_size = std::max<int64_t>(A.J_size, (int64_t)f.joff + m * (da + db) + m);
+    if (f.type == F_PLANE_OBS && f.direct_ok) A.P_size = std::max<int64_t>(A.P_size, (int64_t)f.poff + kPSize[f.type]);
+    inc[f.a].push_back((int)fi2);
+    if (f.b >= 0 && f.b != f.a) inc[f.b].push_back((int)fi2);
   }
-  // every node needs a diagonal block even when it has no factor (it will then fail as not PD)
-  {
-    std::vector<char> has_diag(N, 0);
-    for (auto& c : ctr) if (c.pv == c.pu) has_diag[c.pv] = 1;
-    for (int p2 = P0; p2 < N; p2++) if (!has_diag[p2]) ctr.push_back({p2, p2, 0, 0, 0, 0, -1});
-  }
-  // stable sort by (COLUMN position, row position) -- the column is the node eliminated first, i.e. the front that assembles
-  // the block: the blocks of a front are contiguous, and the numbering of everything that belongs to an unchanged part of
-  // the tree does not move when nodes are appended behind it (a row-major order would renumber every block whose row is a
-  // late separator -- the ground plane's thousand blocks -- with every new pose).  Counting sort on the column, then a
-  // stable insertion sort on the row inside each column (a handful of blocks; long columns fall back to std::stable_sort)
-  {
-    const int NC = N - P0;
-    std::vector<int> col_off(NC + 1, 0);
-    for (const auto& c : ctr) col_off[c.pu - P0 + 1]++;
-    for (int p2 = 0; p2 < NC; p2++) col_off[p2 + 1] += col_off[p2];
-    std::vector<Ctr> sorted(ctr.size());
-    std::vector<int> fill(col_off.begin(), col_off.end() - 1);
-    for (const auto& c : ctr) sorted[fill[c.pu - P0]++] = c;
-    for (int p2 = 0; p2 < NC; p2++) {
-      Ctr* b = sorted.data() + col_off[p2];
-      const int n = col_off[p2 + 1] - col_off[p2];
-      if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pv < y.pv; }); continue; }
-      for (int i = 1; i < n; i++) {
-        const Ctr c = b[i];
-        int j = i - 1;
-        while (j >= 0 && b[j].pv > c.pv) { b[j + 1] = b[j]; j--; }
-        b[j + 1] = c;
+  if (C) { C->inc_factors = factors.size(); C->J_size = A.J_size; C->P_size = A.P_size; C->n_obs_slots = n_obs_slots; }
+  // Column p2 holds: the diagonal block of its node (one contribution per factor of the node), and the off-diagonal blocks towards
+  // the nodes eliminated later (rows = the later node).  Inside a column the contributions come in factor order; a stable insertion
+  // sort on the row position then groups the blocks -- (column, row) ascending, factor order inside a block.
+  // A plain plane observation (direct_ok) hands K2 its PRODUCT record instead of its Jacobian for the two diagonal blocks it
+  // feeds: the contribution carries the record's offset in `ju` and kProductFlag on top of the row count.
+  for (int p2 = P0; p2 < N; p2++) {
+    const int u = A.order[p2];
+    const size_t c_begin = ctr.size();
+    for (const int fi : inc[u]) {
+      const auto& f = factors[fi];
+      const int m = kFDim[f.type];
+      const int da = nodes[f.a].dim;
+      const int db = f.b >= 0 ? nodes[f.b].dim : 0;
+      const int ja = f.joff, jb = f.joff + m * da, roff = f.joff + m * (da + db);
+      const bool prod = f.type == F_PLANE_OBS && f.direct_ok;
+      if (f.a == u) {
+        ctr.push_back({p2, p2, ja, prod ? f.poff : ja, roff, prod ? m + kProductFlag : m, fi});
+        if (f.b >= 0 && f.b != f.a) { const int pb = A.node_pos[f.b]; if (pb >= p2) ctr.push_back({pb, p2, jb, ja, roff, m, fi}); }   // rows = later node
+      } else {
+        ctr.push_back({p2, p2, jb, prod ? f.poff + da * da + da : jb, roff, prod ? m + kProductFlag : m, fi});
+        const int pa = A.node_pos[f.a];
+        if (pa > p2) ctr.push_back({pa, p2, ja, jb, roff, m, fi});
       }
     }
-    ctr.swap(sorted);
+    // every node needs a diagonal block even when it has no factor (it will then fail as not PD)
+    if (inc[u].empty()) ctr.push_back({p2, p2, 0, 0, 0, 0, -1});
+    Ctr* b = ctr.data() + c_begin;
+    const int n = (int)(ctr.size() - c_begin);
+    if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pv < y.pv; }); continue; }
+    for (int i = 1; i < n; i++) {
+      const Ctr c = b[i];
+      int j = i - 1;
+      while (j >= 0 && b[j].pv > c.pv) { b[j + 1] = b[j]; j--; }
+      b[j + 1] = c;
+    }
   }
   lap("  contributions sorted");
   A.contrib.resize((size_t)C0 * 4);
-  A.contrib.reserve((size_t)C0 * 4 + ctr.size() * 4);
+  // (no exact-size reserve here: it would re-allocate and copy the whole list on every frame of a frame loop; push_back grows
+  // geometrically)
   A.obs_dir.resize(3 * (size_t)n_obs_slots, -1);
   // an observation whose (pose, plane) block is redone starts as "not direct"
   for (const auto& c : ctr)
     if (c.pv != c.pu && c.fi >= 0 && factors[c.fi].direct_ok) A.obs_dir[3 * (size_t)(factors[c.fi].joff / kJSize[F_PLANE_OBS])] = -1;
-  { size_t k = 0; while (k < A.nd_segs.size() && A.nd_segs[k] < S0) k++; A.nd_segs.resize(k); }
+  A.nd_segs.resize((size_t)(std::lower_bound(A.nd_segs.begin(), A.nd_segs.end(), S0) - A.nd_segs.begin()));      // (ascending)
   A.blk_rows.resize(B0); A.blk_cols.resize(B0); A.blk_size.resize(B0); A.blk_nseg.resize(B0); A.blk_hoff.resize(B0);
   A.seg_blk.resize(S0); A.seg_c0.resize(S0); A.seg_cnt.resize(S0); A.seg_hoff.resize(S0);
   A.n_blocks = B0; A.n_segs = S0; A.H_size = H0;
+  lap("   resizes");
   std::vector<int> blk_pu;                             // column position per block (kept part from the cache)
   if (B0 > 0) blk_pu.assign(C->blk_pu.begin(), C->blk_pu.begin() + B0);
   std::vector<std::vector<int>> asm_of(F);             // block ids per (redone) front
+  lap("   blk_pu / asm_of");
   std::vector<int> blk_v, blk_u;                       // row / column node of the redone blocks (index blk - B0)
   std::vector<int> blk_is_direct_slot;                 // redone block -> observation slot when direct, else -1
   for (size_t i = 0; i < ctr.size();) {
@@ -1016,9 +1114,13 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       C->memo_of_first[fp] = mi;
     }
     C->post.swap(post);
+    C->post_fend.swap(post_fend);
     C->f_pos0.swap(f_pos0); C->f_npiv.swap(f_npiv);
     C->bnd.swap(bnd);
     C->blk_pu.swap(blk_pu);
+    C->adj_off.swap(B.adj_off); C->adj.swap(B.adj);
+    C->adj2_off.swap(adj2_off_keep); C->adj2.swap(adj2_keep);
+    C->any_cross = B.any_cross;
     C->fronts_reused = F0; C->fronts_total = F;
     C->valid = valid;                                    // (a chain fall-back is not something to build upon)
   } else if (C) {
