@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -476,20 +477,28 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     fprintf(stderr, "[analysis] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
   };
+  auto from_scratch = [&](int why) { if (timing) fprintf(stderr, "[analysis] reuse abandoned at check %d\n", why); return 2; };
   // ---- 0. may the previous result be built upon?  The graph must be the cached one plus appended nodes / factors, every
   // new factor touching a new node (then nothing left of the new poses has a new neighbour) ----
+  bool offsets_changed = false;
   if (reuse) {
     const size_t N0 = C->nodes.size(), M0 = C->factors.size();
     bool ok = C->valid && !general_ordering && prm.aligned_cuts && std::max(2, prm.arity) == 2 && N0 <= nodes.size() && M0 <= factors.size() &&
               C->prm.leaf_poses == prm.leaf_poses && C->prm.max_pivots == prm.max_pivots && C->prm.seg_len == prm.seg_len &&
               C->prm.band_levels == prm.band_levels && C->prm.band_rows == prm.band_rows && C->prm.aligned_cuts == prm.aligned_cuts &&
               C->prm.dense_min == prm.dense_min && C->prm.dense_mult == prm.dense_mult && (int)A.f_b.size() == C->fronts_total;
-    for (size_t i = 0; ok && i < N0; i++) ok = nodes[i].type == C->nodes[i].type && nodes[i].dim == C->nodes[i].dim && nodes[i].rank == C->nodes[i].rank;
-    for (size_t i = 0; ok && i < M0; i++)
-      ok = factors[i].type == C->factors[i].type && factors[i].a == C->factors[i].a && factors[i].b == C->factors[i].b &&
-           factors[i].joff == C->factors[i].joff && factors[i].poff == C->factors[i].poff && factors[i].direct_ok == C->factors[i].direct_ok;
+    // (SymNode / SymFactor are plain ints without padding: the old parts are compared as bytes)
+    static_assert(sizeof(SymNode) == 3 * sizeof(int) && sizeof(SymFactor) == 6 * sizeof(int), "byte-wise comparison of the cached graph");
+    ok = ok && (N0 == 0 || memcmp(nodes.data(), C->nodes.data(), N0 * sizeof(SymNode)) == 0);
+    if (ok && M0 > 0 && memcmp(factors.data(), C->factors.data(), M0 * sizeof(SymFactor)) != 0) {
+      // The same factors between the same nodes at other buffer offsets (a Jacobian slab outgrew its capacity and the slabs behind it
+      // moved): the tree and everything indexed by fronts is still the previous one; the H blocks and their contribution lists,
+      // which hold the offsets, are listed again in full.
+      for (size_t i = 0; ok && i < M0; i++) ok = factors[i].type == C->factors[i].type && factors[i].a == C->factors[i].a && factors[i].b == C->factors[i].b;
+      offsets_changed = true;
+    }
     for (size_t i = M0; ok && i < factors.size(); i++) ok = factors[i].a >= (int)N0 || factors[i].b >= (int)N0;
-    if (!ok) return 2;
+    if (!ok) return from_scratch(1);
   }
   if (!reuse) reset_keep_capacity(A);
   A.n_nodes = N;
@@ -517,8 +526,8 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     else planes.push_back(u);
   }
   if (reuse) {                                            // the border block must be the one it was
-    for (size_t u = 0; u < C->dense.size(); u++) if (C->dense[u] != B.dense[u]) return 2;
-    for (size_t u = C->dense.size(); u < (size_t)N; u++) if (B.dense[u]) return 2;
+    for (size_t u = 0; u < C->dense.size(); u++) if (C->dense[u] != B.dense[u]) return from_scratch(2);
+    for (size_t u = C->dense.size(); u < (size_t)N; u++) if (B.dense[u]) return from_scratch(3);
   }
   lap("  dense / lists");
   std::sort(poses.begin(), poses.end(), [&](int a, int b) { return nodes[a].rank < nodes[b].rank; });
@@ -583,7 +592,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       if (top >= 0 && !general_ordering && top_dim + border_dim <= prm.max_pivots) {
         if (!already) B.tree[top].piv.insert(B.tree[top].piv.end(), border.begin(), border.end());
       } else if (already) {
-        return 2;                    // (a taken-over top that holds the border although the merge no longer applies: from scratch)
+        return from_scratch(4);                    // (a taken-over top that holds the border although the merge no longer applies: from scratch)
       } else {
         root = B.new_tnode();
         B.tree[root].piv = border;
@@ -619,7 +628,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   // what `A` still holds -- nothing of that part is written again (a frame of a frame loop redoes its right spine only).
   if (K0 > 0 && C->post_fend.size() >= K0 && (int)A.order.size() == (int)C->nodes.size() && A.node_pos.size() == C->nodes.size()) {
     F0 = C->post_fend[K0 - 1];
-    if (F0 > (int)C->f_pos0.size() || F0 > (int)A.f_b.size() || F0 > (int)A.f_p.size() || F0 <= 0) return 2;
+    if (F0 > (int)C->f_pos0.size() || F0 > (int)A.f_b.size() || F0 > (int)A.f_p.size() || F0 <= 0) return from_scratch(5);
     for (size_t k = 0; k < K0; k++) { post_fend[k] = C->post_fend[k]; tn_last[post[k]] = C->post_fend[k] - 1; }
     f_pos0.assign(C->f_pos0.begin(), C->f_pos0.begin() + F0);
     f_npiv.assign(C->f_npiv.begin(), C->f_npiv.begin() + F0);
@@ -689,7 +698,8 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     if (!same) { F0 = s; break; }
   }
   if (reuse) C->valid = false;                            // its boundary lists are gone: from here on a failure means "from scratch"
-  const int P0 = F0 < F ? f_pos0[F0] : N;                 // positions below P0 belong to kept fronts
+  const int F0b = offsets_changed ? 0 : F0;               // fronts whose H blocks / contribution lists / assembly lists are kept
+  const int P0 = F0b < F ? f_pos0[F0b] : N;               // positions below P0 belong to fronts whose blocks are kept
   auto compute_boundaries = [&](int s_begin) {
     std::vector<int> stamp(N, -1);
     for (int s = s_begin; s < F; s++) {
@@ -709,7 +719,9 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       std::sort(b.begin(), b.end(), [&](int x, int y) { return A.node_pos[x] < A.node_pos[y]; });
     }
   };
+  lap("  kept boundaries");
   compute_boundaries(F0);
+  lap("  new boundaries");
   // verify the separator property: every boundary node of s is a pivot of an ancestor of s,
   // and every boundary node of a child is inside the parent's front.
   std::vector<int> node_front(N);
@@ -724,12 +736,13 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     }
   }
   if (!valid) {
-    if (reuse) return 2;
+    if (reuse) return from_scratch(6);
     // fall back to a chain: every later front is an ancestor, which is always a valid assembly tree
     for (int s = 0; s < F; s++) { A.f_parent[s] = (s + 1 < F) ? s + 1 : -1; kids[s].clear(); }
     for (int s = 0; s + 1 < F; s++) kids[s + 1].push_back(s);
     compute_boundaries(0);
   }
+  lap("  separator check");
   // levels
   A.n_levels = 0;
   for (int s = 0; s < F; s++) {
@@ -828,7 +841,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   {
     std::vector<int> cm_off(F + 1, 0);
     for (int s = 0; s < F; s++) cm_off[s + 1] = cm_off[s] + (A.f_parent[s] >= 0 ? A.f_b[s] + 1 : 0);
-    if (F0 > 0) for (int s = 0; s <= F0; s++) if (cm_off[s] != A.f_cmap_off[s]) return 2;
+    if (F0 > 0) for (int s = 0; s <= F0; s++) if (cm_off[s] != A.f_cmap_off[s]) return from_scratch(7);
     A.f_cmap_off = cm_off;
     A.cmap.resize(cm_off[F]);
     for (int s = F0; s < F; s++) {
@@ -872,7 +885,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   // segments and contribution lists, are the ones of the previous analysis.
   struct Ctr { int pv, pu, jv, ju, roff, m, fi; };   // (row position, column position) of the H block, the J slices, the factor
   int B0 = 0;                                          // blocks kept
-  if (F0 > 0) B0 = (int)(std::lower_bound(C->blk_pu.begin(), C->blk_pu.end(), P0) - C->blk_pu.begin());
+  if (F0b > 0) B0 = (int)(std::lower_bound(C->blk_pu.begin(), C->blk_pu.end(), P0) - C->blk_pu.begin());
   const int S0 = B0 > 0 ? (B0 < (int)A.blk_hoff.size() ? (int)(std::lower_bound(A.seg_blk.begin(), A.seg_blk.end(), B0) - A.seg_blk.begin()) : (int)A.seg_blk.size()) : 0;
   const int C0 = S0 > 0 ? (S0 < (int)A.seg_c0.size() ? A.seg_c0[S0] : (int)(A.contrib.size() / 4)) : 0;
   const int64_t H0 = B0 > 0 ? (B0 < (int)A.blk_hoff.size() ? A.blk_hoff[B0] : A.H_size) : 0;
@@ -883,7 +896,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   std::vector<std::vector<int>> inc_local;
   std::vector<std::vector<int>>& inc = C ? C->inc : inc_local;
   size_t m_from = 0;
-  if (reuse && C->inc_factors <= factors.size() && C->inc.size() <= (size_t)N && C->inc_factors == C->factors.size()) {
+  if (reuse && !offsets_changed && C->inc_factors <= factors.size() && C->inc.size() <= (size_t)N && C->inc_factors == C->factors.size()) {
     m_from = C->inc_factors;
     A.J_size = C->J_size; A.P_size = C->P_size;
   } else {
@@ -945,6 +958,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   A.contrib.resize((size_t)C0 * 4);
   // (no exact-size reserve here: it would re-allocate and copy the whole list on every frame of a frame loop; push_back grows
   // geometrically)
+  if (offsets_changed) A.obs_dir.clear();                 // (slots are Jacobian offsets)
   A.obs_dir.resize(3 * (size_t)n_obs_slots, -1);
   // an observation whose (pose, plane) block is redone starts as "not direct"
   for (const auto& c : ctr)
@@ -1006,10 +1020,10 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   }
   lap("  blocks / segments");
   // per-front assembly lists with local offsets
-  const int asm0 = F0 > 0 ? A.f_asm_off[F0] : 0;
-  A.el_total = F0 > 0 ? A.f_el_off[F0] : 0;
+  const int asm0 = F0b > 0 ? A.f_asm_off[F0b] : 0;
+  A.el_total = F0b > 0 ? A.f_el_off[F0b] : 0;
   A.f_asm_off.resize(F + 1, 0); A.f_el_off.resize(F + 1, 0);
-  if (F0 == 0) { A.f_asm_off[0] = 0; A.f_el_off[0] = 0; }
+  if (F0b == 0) { A.f_asm_off[0] = 0; A.f_el_off[0] = 0; }
   A.asm_blk.resize(asm0); A.asm_lrow.resize(asm0); A.asm_lcol.resize(asm0); A.asm_el0.resize(asm0); A.asm_fsz.resize(asm0);
   A.el_tgt.clear();
   A.blk_doff.resize(A.n_blocks + 1, 0);
@@ -1017,7 +1031,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   for (int bk = B0; bk < A.n_blocks; bk++) A.blk_doff[bk + 1] = A.blk_doff[bk] + A.blk_size[bk];
   A.blk_dst.clear();
   if (A.H_size > 0x3fffffffLL) { *msg = "H too large for int32 gather offsets"; return 0; }
-  for (int s = F0; s < F; s++) {
+  for (int s = F0b; s < F; s++) {
     int off = 0;
     for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
     for (int v : bnd[s]) { loc[v] = off; off += nodes[v].dim; }
@@ -1101,7 +1115,11 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   }
   // ---- what the next analysis of this graph may build upon ----
   if (C && !general_ordering) {
-    C->nodes = nodes; C->factors = factors; C->prm = prm;
+    if (reuse && !offsets_changed && C->nodes.size() <= nodes.size() && C->factors.size() <= factors.size()) {      // (the old parts were found equal above)
+      C->nodes.insert(C->nodes.end(), nodes.begin() + C->nodes.size(), nodes.end());
+      C->factors.insert(C->factors.end(), factors.begin() + C->factors.size(), factors.end());
+    } else { C->nodes = nodes; C->factors = factors; }
+    C->prm = prm;
     C->dense = B.dense;
     C->tree.swap(B.tree);
     C->memo.swap(B.memo);
