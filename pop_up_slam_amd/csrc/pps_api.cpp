@@ -105,6 +105,7 @@ static int add_factor(pps_graph* g, int type, int a, int b, const double* meas, 
   for (int k = 0; k < nw; k++) f.w[k] = ut[k];
   g->factors.push_back(f);
   g->n_live_factors++;
+  g->n_live_type[type]++;
   g->dim_measure += kFDim[type];
   g->topo_dirty = true; g->analysis_stale = true;
   if (fid) *fid = (int)g->factors.size() - 1;
@@ -136,6 +137,7 @@ int pps_add_plane_obs2(pps_graph* g, int pose, int plane, const double meas4[4],
   int rc = pps_add_plane_obs(g, pose, plane, meas4, ut, &id);
   if (rc != PPS_OK) return rc;
   g->factors[id].repop = 1;
+  g->n_live_repop++;
   memcpy(g->factors[id].ray, ray6, sizeof g->factors[id].ray);
   if (fid) *fid = id;
   return PPS_OK;
@@ -183,6 +185,8 @@ int pps_remove_factor(pps_graph* g, int fid) {
   g->factors[fid].deleted = true;
   g->grown_only = false; g->grown_only_upload = false;
   g->n_live_factors--;
+  g->n_live_type[g->factors[fid].type]--;
+  if (g->factors[fid].type == F_PLANE_OBS && g->factors[fid].repop) g->n_live_repop--;
   g->dim_measure -= kFDim[g->factors[fid].type];
   g->topo_dirty = true; g->analysis_stale = true;
   return PPS_OK;

@@ -61,6 +61,7 @@ struct pps_graph {
   std::vector<pps_impl::HostNode> nodes;
   std::vector<pps_impl::HostFactor> factors;
   int n_live_nodes = 0, n_live_factors = 0, dim_nodes = 0, dim_measure = 0;
+  int n_live_type[4] = {0, 0, 0, 0}, n_live_repop = 0;      // live factors per type / live re-popping plane observations
   bool topo_dirty = true;       // structure changed since the last upload
   bool analysis_stale = true;   // structure changed since the last analysis
   bool host_values_newer = true;   // host node values must be pushed before the next solve
@@ -108,6 +109,11 @@ struct pps_graph {
   std::vector<UpSlot> up_slots;
   size_t up_cursor = 0, up_high = 0;
   bool up_unknown = true;              // the arena was (re)allocated: the mirror says nothing about the device
+  // Which analysis the upload mirror holds: `an` (sequence number an_seq) was built upon the analysis an_base_seq; when that is the
+  // one whose arrays were uploaded last (up_an_seq), the leading entries `an.kept` names are in the mirror already and are not
+  // compared again.  PPS_DEBUG_VERIFY_UPLOAD=1 checks every such claim (hint_violation -> PPS_ESTATE).
+  long an_seq = 0, an_base_seq = -1, up_an_seq = -1;
+  bool hint_violation = false;
   bool up_unknown_meas = false;        // ... only about the measurement arrays (written behind the mirror's back)
   size_t slot_obs_meas = (size_t)-1;   // which upload slot holds obs_meas
   size_t slot_lp_meas = (size_t)-1;    // ... and lp_meas (pps_set_measurement writes both arrays behind the mirror's back)
@@ -197,7 +203,7 @@ inline bool live_node(const pps_graph* g, int id, int type) {
 // ---- pps_upload.cpp ----
 void free_device(pps_graph* g);
 void release_arenas(pps_graph* g);
-void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force);
+void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force, size_t same_prefix = 0);
 int flush_uploads(pps_graph* g);
 int verify_uploads(pps_graph* g, const char* where);
 int ensure_device(pps_graph* g);
@@ -245,17 +251,19 @@ int dev_alloc(pps_graph* g, T** out, size_t count) { return arena_alloc(g, g->sc
 // and nothing around them (a piece rounded to the 64-byte compare stride or to the 16-byte copy unit would put the mirror's
 // stale values over up to seven refreshed neighbours)
 constexpr size_t kNoExact = (size_t)-1;
+// same: leading ELEMENTS (of the array, or of every row) that the caller knows to be what this slot received last time
 template <class T>
-int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from);
+int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from, size_t same);
 template <class T>
-int dev_upload(pps_graph* g, T** out, const std::vector<T>& v) { return dev_upload_impl(g, out, v, 0, 0, 0, false, kNoExact); }
+int dev_upload(pps_graph* g, T** out, const std::vector<T>& v, size_t same = 0) { return dev_upload_impl(g, out, v, 0, 0, 0, false, kNoExact, same); }
 template <class T>
-int dev_upload_rows(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from = kNoExact) {
-  return dev_upload_impl(g, out, v, rows, ld, used, force, exact_from);
+int dev_upload_rows(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from = kNoExact,
+                    size_t same = 0) {
+  return dev_upload_impl(g, out, v, rows, ld, used, force, exact_from, same);
 }
 
 template <class T>
-int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from) {
+int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows, size_t ld, size_t used, bool force, size_t exact_from, size_t same) {
   *out = nullptr;
   pps_graph::Arena& a = g->up;
   const size_t bytes = std::max<size_t>(1, v.size()) * sizeof(T);
@@ -300,17 +308,19 @@ int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows,
   }
   if (v.empty()) return PPS_OK;
   const char* src = reinterpret_cast<const char*>(v.data());
-  if (rows == 0 || g->up_unknown) { up_diff(g, o, src, v.size() * sizeof(T), force); return PPS_OK; }
+  if (rows == 0 || g->up_unknown) { up_diff(g, o, src, v.size() * sizeof(T), force, rows == 0 ? std::min(same, v.size()) * sizeof(T) : 0); return PPS_OK; }
+  const size_t keep = std::min(same, used);
   if (exact_from != kNoExact && !force && sizeof(T) == 8) {
     for (size_t r = 0; r < rows; r++) {
       const size_t ro = r * ld * sizeof(T);
-      memcpy(g->stage + o + ro, src + ro, used * sizeof(T));          // the mirror keeps the host's view of the row
+      if (keep && getenv("PPS_DEBUG_VERIFY_UPLOAD") && memcmp(g->stage + o + ro, src + ro, keep * sizeof(T)) != 0) g->hint_violation = true;
+      memcpy(g->stage + o + ro + keep * sizeof(T), src + ro + keep * sizeof(T), (used - keep) * sizeof(T));   // the mirror keeps the host's view of the row
       g->up_bytes_total += used * sizeof(T);
       if (used > exact_from) g->up_patches.push_back(pps_graph::UpPatch{o + ro + exact_from * sizeof(T), (used - exact_from) * sizeof(T), true});
     }
     return PPS_OK;
   }
-  for (size_t r = 0; r < rows; r++) up_diff(g, o + r * ld * sizeof(T), src + r * ld * sizeof(T), used * sizeof(T), force);
+  for (size_t r = 0; r < rows; r++) up_diff(g, o + r * ld * sizeof(T), src + r * ld * sizeof(T), used * sizeof(T), force, keep * sizeof(T));
   return PPS_OK;
 }
 

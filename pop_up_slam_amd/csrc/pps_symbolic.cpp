@@ -370,6 +370,7 @@ struct Builder {
 // A fresh analysis in an Analysis that has been used before: every vector keeps its capacity, so a frame loop (one new pose
 // per call, every array a little longer than last time) does not go back to the allocator for megabytes per frame.
 void reset_keep_capacity(Analysis& A) {
+  A.kept = Analysis::Kept();
   A.node_pos.clear();
   A.node_voff.clear();
   A.order.clear();
@@ -646,6 +647,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     A.pidx.clear();
     A.f_p.clear(); A.f_poff.clear(); A.f_parent.clear();
   }
+  const int pos_keep = pos;                               // positions below it: nodes of the kept tree nodes, where they were
   for (size_t pi = K0; pi < post.size(); pi++) {
     const int t = post[pi];
     const TNode& tn = B.tree[t];
@@ -685,16 +687,29 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   lap("post-order / chains");
   // ---- 4. boundaries ----
   std::vector<std::vector<int>> bnd(F);
-  std::vector<std::vector<int>> kids(F);
-  for (int s = 0; s < F; s++) if (A.f_parent[s] >= 0) kids[A.f_parent[s]].push_back(s);
+  // children CSR (ascending inside a parent), from f_parent
+  auto build_children = [&]() {
+    A.f_child_off.assign(F + 1, 0);
+    for (int s = 0; s < F; s++) if (A.f_parent[s] >= 0) A.f_child_off[A.f_parent[s] + 1]++;
+    for (int s = 0; s < F; s++) A.f_child_off[s + 1] += A.f_child_off[s];
+    A.child.resize(A.f_child_off[F]);
+    std::vector<int> w(A.f_child_off.begin(), A.f_child_off.end() - 1);
+    for (int s = 0; s < F; s++) if (A.f_parent[s] >= 0) A.child[w[A.f_parent[s]]++] = s;
+  };
+  build_children();
+  struct KidRange { const int* b; const int* e; const int* begin() const { return b; } const int* end() const { return e; } };
+  auto kids_of = [&](int s) { return KidRange{A.child.data() + A.f_child_off[s], A.child.data() + A.f_child_off[s + 1]}; };
   for (int s = 0; s < F0; s++) {
     bnd[s].swap(C->bnd[s]);
     // The boundary nodes of a kept front lie in later fronts, kept or redone; they must still come in the order they had
     // (a plane that moved to another separator of the redone spine changes the local layout of the fronts it bounds):
     // the kept part ends at the first front for which that no longer holds.
+    // (The list is sorted by the OLD positions: the nodes of kept positions come first and have not moved; only its tail -- the
+    // nodes of redone positions, the border and a few separators of the spine -- can have changed order.)
     bool same = true;
-    for (size_t k = 0; same && k + 1 < bnd[s].size(); k++) same = A.node_pos[bnd[s][k]] < A.node_pos[bnd[s][k + 1]];
-    for (size_t k = 0; same && k < bnd[s].size(); k++) same = A.node_pos[bnd[s][k]] >= f_pos0[s] + f_npiv[s];
+    const std::vector<int>& b = bnd[s];
+    for (size_t k = b.size(); same && k > 0 && A.node_pos[b[k - 1]] >= pos_keep; k--)
+      if (k < b.size()) same = A.node_pos[b[k - 1]] < A.node_pos[b[k]];
     if (!same) { F0 = s; break; }
   }
   if (reuse) C->valid = false;                            // its boundary lists are gone: from here on a failure means "from scratch"
@@ -713,7 +728,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
           if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
         }
       }
-      for (int c : kids[s])
+      for (int c : kids_of(s))
         for (int v : bnd[c])
           if (A.node_pos[v] >= end && stamp[v] != s) { stamp[v] = s; b.push_back(v); }
       std::sort(b.begin(), b.end(), [&](int x, int y) { return A.node_pos[x] < A.node_pos[y]; });
@@ -738,8 +753,8 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   if (!valid) {
     if (reuse) return from_scratch(6);
     // fall back to a chain: every later front is an ancestor, which is always a valid assembly tree
-    for (int s = 0; s < F; s++) { A.f_parent[s] = (s + 1 < F) ? s + 1 : -1; kids[s].clear(); }
-    for (int s = 0; s + 1 < F; s++) kids[s + 1].push_back(s);
+    for (int s = 0; s < F; s++) A.f_parent[s] = (s + 1 < F) ? s + 1 : -1;
+    build_children();
     compute_boundaries(0);
   }
   lap("  separator check");
@@ -747,7 +762,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   A.n_levels = 0;
   for (int s = 0; s < F; s++) {
     int lv = 0;
-    for (int c : kids[s]) lv = std::max(lv, A.f_level[c] + 1);
+    for (int c : kids_of(s)) lv = std::max(lv, A.f_level[c] + 1);
     A.f_level[s] = lv;
     A.n_levels = std::max(A.n_levels, lv + 1);
   }
@@ -774,7 +789,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     }
     for (int s = 0; s < F; s++) {             // children before parents
       int l = 0;
-      for (int c : kids[s]) if (grp[c] == grp[s]) l = std::max(l, ll[c] + 1);
+      for (int c : kids_of(s)) if (grp[c] == grp[s]) l = std::max(l, ll[c] + 1);
       ll[s] = l;
     }
     const int G = (int)grp_stage.size();
@@ -807,11 +822,6 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
         A.stage_max_width[st] = std::max(A.stage_max_width[st], A.glvl_front_off[l + 1] - A.glvl_front_off[l]);
     }
   }
-  // children CSR
-  A.f_child_off.assign(F + 1, 0);
-  for (int s = 0; s < F; s++) A.f_child_off[s + 1] = A.f_child_off[s] + (int)kids[s].size();
-  A.child.clear();
-  for (int s = 0; s < F; s++) for (int c : kids[s]) A.child.push_back(c);
   // boundary scalar indices, sizes, storage: the kept fronts keep theirs (every offset is cumulative in front order)
   const int bidx0 = F0 > 0 ? A.f_bidx_off[F0] : 0;
   A.L_size = F0 > 0 ? (F0 < (int)A.f_Loff.size() ? A.f_Loff[F0] : A.L_size) : 0;
@@ -849,7 +859,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       for (int k = f_pos0[s]; k < f_pos0[s] + f_npiv[s]; k++) { loc[A.order[k]] = off; off += nodes[A.order[k]].dim; }
       for (int v : bnd[s]) { loc[v] = off; off += nodes[v].dim; }
       const int rhs_row = off;   // == f
-      for (int c : kids[s]) {
+      for (int c : kids_of(s)) {
         int* out = A.cmap.data() + cm_off[c];
         for (int v : bnd[c]) {
           if (loc[v] < 0) { *msg = "internal: child boundary not inside parent front"; return 0; }
@@ -946,7 +956,11 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     if (inc[u].empty()) ctr.push_back({p2, p2, 0, 0, 0, 0, -1});
     Ctr* b = ctr.data() + c_begin;
     const int n = (int)(ctr.size() - c_begin);
-    if (n > 64) { std::stable_sort(b, b + n, [](const Ctr& x, const Ctr& y) { return x.pv < y.pv; }); continue; }
+    if (n > 64) {                // (the border's column: a thousand contributions to its diagonal block, in order as they come)
+      const auto by_row = [](const Ctr& x, const Ctr& y) { return x.pv < y.pv; };
+      if (!std::is_sorted(b, b + n, by_row)) std::stable_sort(b, b + n, by_row);
+      continue;
+    }
     for (int i = 1; i < n; i++) {
       const Ctr c = b[i];
       int j = i - 1;
@@ -964,6 +978,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   for (const auto& c : ctr)
     if (c.pv != c.pu && c.fi >= 0 && factors[c.fi].direct_ok) A.obs_dir[3 * (size_t)(factors[c.fi].joff / kJSize[F_PLANE_OBS])] = -1;
   A.nd_segs.resize((size_t)(std::lower_bound(A.nd_segs.begin(), A.nd_segs.end(), S0) - A.nd_segs.begin()));      // (ascending)
+  const int nd_kept = (int)A.nd_segs.size();
   A.blk_rows.resize(B0); A.blk_cols.resize(B0); A.blk_size.resize(B0); A.blk_nseg.resize(B0); A.blk_hoff.resize(B0);
   A.seg_blk.resize(S0); A.seg_c0.resize(S0); A.seg_cnt.resize(S0); A.seg_hoff.resize(S0);
   A.n_blocks = B0; A.n_segs = S0; A.H_size = H0;
@@ -1062,6 +1077,11 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     A.crec.clear();
     std::vector<int> pos_of(F, -1);
     for (int i = 0; i < F; i++) pos_of[A.glvl_fronts[i]] = i;
+    std::vector<int> grp_first(F, 0);                    // position -> first position of its group
+    for (int g2 = 0; g2 < A.n_groups; g2++) {
+      const int i0 = A.glvl_front_off[A.grp_lvl_off[g2]], i1 = A.glvl_front_off[A.grp_lvl_off[g2 + 1]];
+      for (int i = i0; i < i1; i++) grp_first[i] = i0;
+    }
     for (int i = 0; i < F; i++) {
       const int s2 = A.glvl_fronts[i];
       int* r = &A.frec[(size_t)i * 16];
@@ -1078,14 +1098,9 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       {
         const int par = A.f_parent[s2];
         const int Bn2 = std::max(1, prm.band_levels);
-        if (par >= 0 && A.f_level[par] / Bn2 == A.f_level[s2] / Bn2) {
-          // slot = position inside the group (groups are contiguous in glvl_fronts: first position of the group's
-          // first local level)
-          const int ip = pos_of[par];
-          const int l = (int)(std::upper_bound(A.glvl_front_off.begin(), A.glvl_front_off.end(), ip) - A.glvl_front_off.begin()) - 1;
-          const int g2 = (int)(std::upper_bound(A.grp_lvl_off.begin(), A.grp_lvl_off.end(), l) - A.grp_lvl_off.begin()) - 1;
-          r[14] = ip - A.glvl_front_off[A.grp_lvl_off[g2]];
-        }
+        // slot = position inside the group (groups are contiguous in glvl_fronts: grp_first = first position of the group's
+        // first local level)
+        if (par >= 0 && A.f_level[par] / Bn2 == A.f_level[s2] / Bn2) r[14] = pos_of[par] - grp_first[pos_of[par]];
       }
       for (int ci = A.f_child_off[s2]; ci < A.f_child_off[s2 + 1]; ci++) {
         const int c = A.child[ci];
@@ -1113,6 +1128,8 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     }
     lap("packed records");
   }
+  A.kept.fronts = reuse ? F0 : 0; A.kept.fronts_lists = reuse ? F0b : 0; A.kept.blocks = reuse ? B0 : 0; A.kept.segs = reuse ? S0 : 0;
+  A.kept.contribs = reuse ? C0 : 0; A.kept.nd_segs = reuse ? nd_kept : 0;
   // ---- what the next analysis of this graph may build upon ----
   if (C && !general_ordering) {
     if (reuse && !offsets_changed && C->nodes.size() <= nodes.size() && C->factors.size() <= factors.size()) {      // (the old parts were found equal above)

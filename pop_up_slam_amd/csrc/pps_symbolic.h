@@ -49,6 +49,14 @@ struct AnalysisParams {
 };
 
 struct Analysis {
+  // What this analysis left exactly as the analysis it was built upon had it (all 0 after an analysis from scratch): LEADING
+  // entries of the index arrays, which an uploader that still holds the previous arrays need not compare again.
+  //   fronts        f_p f_b f_poff f_Loff f_Uoff [fronts]; f_bidx_off f_child_off f_cmap_off f_ea_off [fronts + 1]; pidx [f_poff[fronts]];
+  //                 bidx [f_bidx_off[fronts]]; child [f_child_off[fronts]]
+  //   fronts_lists  f_asm_off f_el_off [fronts_lists + 1]; asm_blk asm_lrow asm_lcol asm_el0 asm_fsz [f_asm_off[fronts_lists]]
+  //   blocks        blk_rows blk_cols blk_size blk_nseg blk_hoff [blocks]; blk_doff [blocks + 1]
+  //   segs          seg_blk seg_c0 seg_cnt seg_hoff [segs]; srec [8 segs];   contribs: contrib [4 contribs];   nd_segs: nd_segs
+  struct Kept { int fronts = 0, fronts_lists = 0, blocks = 0, segs = 0, contribs = 0, nd_segs = 0; } kept;
   int n_nodes = 0, n_scalars = 0;
   std::vector<int> node_pos;    // [n_nodes] elimination position
   std::vector<int> node_voff;   // [n_nodes] scalar offset of the node in delta: nodes in CREATION order (compact id), so an offset

@@ -46,14 +46,17 @@ void release_arenas(pps_graph* g) {
 }
 
 // bytes [0, n) of `src` against the mirror at offset o: record (and copy into the mirror) the range that differs
-void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force) {
+// same_prefix: leading bytes the caller knows to be in the mirror already (pps_graph::an_seq): the comparison starts behind them
+void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force, size_t same_prefix) {
   if (n == 0) return;
   char* mir = g->stage + o;
   g->up_bytes_total += n;
   if (g->up_unknown || force) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n, false}); return; }
+  same_prefix = std::min(same_prefix, n) & ~size_t(63);
+  if (same_prefix && getenv("PPS_DEBUG_VERIFY_UPLOAD") && memcmp(mir, src, same_prefix) != 0) g->hint_violation = true;
   // first and last 64-byte chunk that differs from what the device holds (4 KB strides first: most arrays of a frame loop
   // are unchanged from end to end, or up to a short tail)
-  size_t lo = 0, hi = n;
+  size_t lo = same_prefix, hi = n;
   while (lo + 4096 <= hi && memcmp(mir + lo, src + lo, 4096) == 0) lo += 4096;
   while (lo + 64 <= hi && memcmp(mir + lo, src + lo, 64) == 0) lo += 64;
   if (lo + 64 > hi && memcmp(mir + lo, src + lo, hi - lo) == 0) return;      // identical
@@ -129,6 +132,7 @@ int flush_uploads(pps_graph* g) {
 // measurements, which kernels refresh behind the mirror's back) -- PPS_ESTATE if not.  tests/test_gpu_pipeline.py runs a frame
 // loop under it.
 int verify_uploads(pps_graph* g, const char* where) {
+  if (g->hint_violation) { g->hint_violation = false; return fail(g, PPS_ESTATE, std::string("upload verification (") + where + "): an array differs from the mirror inside the part the analysis reported as kept"); }
   if (!getenv("PPS_DEBUG_VERIFY_UPLOAD") || g->up_high == 0 || g->up.spill) return PPS_OK;
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   std::vector<char> dev(g->up_high);
@@ -185,7 +189,7 @@ static int run_analysis_impl(pps_graph* g);
 // analysed, so that no later upload sends a half-rewritten Analysis to the device -- the next solve runs the analysis again.
 int run_analysis(pps_graph* g) {
   const int rc = run_analysis_impl(g);
-  if (rc != PPS_OK) { g->analyzed = false; g->analysis_stale = true; g->topo_dirty = true; g->cmp_valid = false; }
+  if (rc != PPS_OK) { g->analyzed = false; g->analysis_stale = true; g->topo_dirty = true; g->cmp_valid = false; g->an_seq++; g->an_base_seq = -1; }
   return rc;
 }
 static int run_analysis_impl(pps_graph* g) {
@@ -374,6 +378,7 @@ static int run_analysis_impl(pps_graph* g) {
   if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "total incl. api", 1e3 * (now_s() - t0));
   g->analyzed = true; g->analysis_stale = false;
   g->n_analyses++; g->grown_only = true;
+  g->an_base_seq = g->an_seq; g->an_seq++;                // (an.kept is relative to the analysis this one replaced)
   g->stats.n_fronts = g->an.n_fronts; g->stats.n_levels = g->an.n_levels; g->stats.max_front = g->an.max_front;
   g->stats.nnz_L = g->an.L_size;
   g->stats.t_analysis = now_s() - t0;
@@ -509,8 +514,9 @@ int upload_all(pps_graph* g) {
   bool keep_meas = false;
   const size_t n_obs_on_device = (size_t)g->dev.n_obs;         // (free_device below resets g->dev)
   if (g->dev_meas_newer) {
-    size_t n_obs_new = 0, n_lp_new = 0; bool any_repop = false;
-    for (const HostFactor& f : g->factors) if (!f.deleted) { n_obs_new += f.type == F_PLANE_OBS; n_lp_new += f.type == F_PLANE_PRIOR; any_repop = any_repop || (f.type == F_PLANE_OBS && f.repop); }
+    // (live counts kept by the add / remove calls: a walk over the 300-byte factor records here was 30 us per frame at 7 600 factors)
+    const size_t n_obs_new = (size_t)g->n_live_type[F_PLANE_OBS], n_lp_new = (size_t)g->n_live_type[F_PLANE_PRIOR];
+    const bool any_repop = g->n_live_repop > 0;
     keep_meas = g->grown_only_upload && !g->up_unknown && !g->up_unknown_meas && g->up.spill == 0 && !any_repop && g->dev.n_obs == g->dev.n_obs_fixed &&
                 j_capacity((int64_t)n_obs_new) == g->dev.obs_ld && j_capacity((int64_t)n_lp_new) == g->dev.lp_ld && g->slot_obs_meas < g->up_slots.size() &&
                 true;
@@ -530,6 +536,11 @@ int upload_all(pps_graph* g) {
   lap("3 analysis");
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
+  // the mirror holds the arrays of the analysis this one was built upon: its kept parts are not compared again
+  const bool hints = was_grown_only && !g->up_unknown && g->up_an_seq >= 0 && g->an_base_seq == g->up_an_seq && !getenv("PPS_NO_UPLOAD_HINTS");
+  const Analysis::Kept K = hints ? A.kept : Analysis::Kept();
+  const size_t kF = (size_t)K.fronts, kFl = (size_t)K.fronts_lists, kB = (size_t)K.blocks, kS = (size_t)K.segs;
+  auto at = [](const auto& v, size_t i) -> size_t { return i < v.size() ? (size_t)v[i] : 0; };     // (0 = no claim)
   double* zero_block = nullptr; size_t zero_doubles = 0;
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
   d.no_strip = getenv("PPS_NO_STRIP") ? 1 : 0;
@@ -581,13 +592,14 @@ int upload_all(pps_graph* g) {
     if (s_begin > 0 && !g->pk_meas_ok)                                 // the host's measurements changed: those rows again
       for (size_t s2 = 0; s2 < s_begin; s2++) { const HostFactor& f = g->factors[ids[s2]]; for (int k = 0; k < 4; k++) pm[(size_t)k * ld + s2] = f.meas[k]; }
     g->pk_n_obs = n; g->pk_ld_obs = ld; g->pk_obs_ids.resize(s_begin); g->pk_obs_ids.insert(g->pk_obs_ids.end(), ids.begin() + (std::ptrdiff_t)s_begin, ids.end());
-    TRY(dev_upload(g, &d.obs_pose, ia)); TRY(dev_upload(g, &d.obs_plane, ib));
+    const size_t same_idx = hints ? s_begin : 0, same_meas = (hints && g->pk_meas_ok) ? s_begin : 0;       // (rows packed and sent by the previous upload)
+    TRY(dev_upload(g, &d.obs_pose, ia, same_idx)); TRY(dev_upload(g, &d.obs_plane, ib, same_idx));
     // Measurements that a device-side refresh has rewritten (pps_refresh_measurements) stay where they are when this upload
     // only appends: the host packs its (older) copies, the mirror holds the same bytes, so nothing is sent for them and the
     // device keeps the refreshed values; only the new observations travel.  dev_meas_newer stays set.
     g->slot_obs_meas = g->up_cursor;
-    TRY(dev_upload_rows(g, &d.obs_meas, pm, 4, ld, n, g->up_unknown_meas, keep_meas ? std::min(n, n_obs_on_device) : kNoExact));
-    TRY(dev_upload_rows(g, &d.obs_w, pw, 6, ld, n, false));
+    TRY(dev_upload_rows(g, &d.obs_meas, pm, 4, ld, n, g->up_unknown_meas, keep_meas ? std::min(n, n_obs_on_device) : kNoExact, same_meas));
+    TRY(dev_upload_rows(g, &d.obs_w, pw, 6, ld, n, false, kNoExact, same_idx));
   }
   d.n_obs_fixed = g->n_obs_fixed;
   {
@@ -616,9 +628,10 @@ int upload_all(pps_graph* g) {
       for (int k = 0; k < 21; k++) pw[(size_t)k * ld + s2] = f.w[k];
     }
     g->pk_n_odo = n; g->pk_ld_odo = ld; g->pk_odo_ids.resize(s_begin); g->pk_odo_ids.insert(g->pk_odo_ids.end(), ids.begin() + (std::ptrdiff_t)s_begin, ids.end());
-    TRY(dev_upload(g, &d.odo_a, ia)); TRY(dev_upload(g, &d.odo_b, ib));
-    TRY(dev_upload_rows(g, &d.odo_meas, pm, 6, ld, n, false));
-    TRY(dev_upload_rows(g, &d.odo_w, pw, 21, ld, n, false));
+    const size_t same_idx = hints ? s_begin : 0;
+    TRY(dev_upload(g, &d.odo_a, ia, same_idx)); TRY(dev_upload(g, &d.odo_b, ib, same_idx));
+    TRY(dev_upload_rows(g, &d.odo_meas, pm, 6, ld, n, false, kNoExact, (hints && g->pk_meas_ok) ? s_begin : 0));
+    TRY(dev_upload_rows(g, &d.odo_w, pw, 21, ld, n, false, kNoExact, same_idx));
   }
   TRY(dev_upload(g, &d.pp_pose, idx_of(F_POSE_PRIOR, false)));
   pack_soa<6>(g, F_POSE_PRIOR, nullptr, false, tmp, (size_t)d.pp_ld); TRY(dev_upload_rows(g, &d.pp_meas, tmp, 6, (size_t)d.pp_ld, (size_t)d.n_pp, false));
@@ -638,20 +651,21 @@ int upload_all(pps_graph* g) {
   const size_t delta_doubles = (size_t)std::max(1, A.n_scalars);   // (delta and the second delta sit in the zeroed block below)
   d.n_scalars = A.n_scalars;
   d.n_fronts = A.n_fronts; d.n_levels = A.n_levels; d.max_front = A.max_front; d.n_segs = A.n_segs; d.n_blocks = A.n_blocks;
-  TRY(dev_upload(g, &d.f_p, A.f_p)); TRY(dev_upload(g, &d.f_b, A.f_b)); TRY(dev_upload(g, &d.f_poff, A.f_poff)); TRY(dev_upload(g, &d.pidx, A.pidx));
-  TRY(dev_upload(g, &d.f_Loff, A.f_Loff)); TRY(dev_upload(g, &d.f_Uoff, A.f_Uoff));
-  TRY(dev_upload(g, &d.f_bidx_off, A.f_bidx_off)); TRY(dev_upload(g, &d.bidx, A.bidx));
-  TRY(dev_upload(g, &d.f_child_off, A.f_child_off)); TRY(dev_upload(g, &d.child, A.child));
-  TRY(dev_upload(g, &d.f_cmap_off, A.f_cmap_off)); TRY(dev_upload(g, &d.cmap, A.cmap));
+  TRY(dev_upload(g, &d.f_p, A.f_p, kF)); TRY(dev_upload(g, &d.f_b, A.f_b, kF)); TRY(dev_upload(g, &d.f_poff, A.f_poff, kF)); TRY(dev_upload(g, &d.pidx, A.pidx, kF ? at(A.f_poff, kF) : 0));
+  TRY(dev_upload(g, &d.f_Loff, A.f_Loff, kF)); TRY(dev_upload(g, &d.f_Uoff, A.f_Uoff, kF));
+  TRY(dev_upload(g, &d.f_bidx_off, A.f_bidx_off, kF ? kF + 1 : 0)); TRY(dev_upload(g, &d.bidx, A.bidx, kF ? at(A.f_bidx_off, kF) : 0));
+  TRY(dev_upload(g, &d.f_child_off, A.f_child_off, kF ? kF + 1 : 0)); TRY(dev_upload(g, &d.child, A.child, kF ? at(A.f_child_off, kF) : 0));
+  TRY(dev_upload(g, &d.f_cmap_off, A.f_cmap_off, kF ? kF + 1 : 0)); TRY(dev_upload(g, &d.cmap, A.cmap));      // (cmap: kept fronts below a redone parent are rewritten)
   TRY(dev_upload(g, &d.level_fronts, A.level_fronts));
-  TRY(dev_upload(g, &d.f_asm_off, A.f_asm_off)); TRY(dev_upload(g, &d.asm_blk, A.asm_blk));
-  TRY(dev_upload(g, &d.asm_lrow, A.asm_lrow)); TRY(dev_upload(g, &d.asm_lcol, A.asm_lcol));
-  TRY(dev_upload(g, &d.blk_rows, A.blk_rows)); TRY(dev_upload(g, &d.blk_cols, A.blk_cols));
-  TRY(dev_upload(g, &d.blk_size, A.blk_size)); TRY(dev_upload(g, &d.blk_nseg, A.blk_nseg));
-  TRY(dev_upload(g, &d.blk_hoff, A.blk_hoff));
-  TRY(dev_upload(g, &d.seg_blk, A.seg_blk)); TRY(dev_upload(g, &d.seg_c0, A.seg_c0)); TRY(dev_upload(g, &d.seg_cnt, A.seg_cnt));
-  TRY(dev_upload(g, &d.seg_hoff, A.seg_hoff));
-  TRY(dev_upload(g, &d.contrib, A.contrib));
+  const size_t kA = kFl ? at(A.f_asm_off, kFl) : 0;
+  TRY(dev_upload(g, &d.f_asm_off, A.f_asm_off, kFl ? kFl + 1 : 0)); TRY(dev_upload(g, &d.asm_blk, A.asm_blk, kA));
+  TRY(dev_upload(g, &d.asm_lrow, A.asm_lrow, kA)); TRY(dev_upload(g, &d.asm_lcol, A.asm_lcol, kA));
+  TRY(dev_upload(g, &d.blk_rows, A.blk_rows, kB)); TRY(dev_upload(g, &d.blk_cols, A.blk_cols, kB));
+  TRY(dev_upload(g, &d.blk_size, A.blk_size, kB)); TRY(dev_upload(g, &d.blk_nseg, A.blk_nseg, kB));
+  TRY(dev_upload(g, &d.blk_hoff, A.blk_hoff, kB));
+  TRY(dev_upload(g, &d.seg_blk, A.seg_blk, kS)); TRY(dev_upload(g, &d.seg_c0, A.seg_c0, kS)); TRY(dev_upload(g, &d.seg_cnt, A.seg_cnt, kS));
+  TRY(dev_upload(g, &d.seg_hoff, A.seg_hoff, kS));
+  TRY(dev_upload(g, &d.contrib, A.contrib, 4 * (size_t)K.contribs));
   {
     std::vector<int> mseg;
     for (int bk = 0; bk < A.n_blocks; bk++) if (A.blk_nseg[bk] > 1) mseg.push_back(bk);
@@ -669,15 +683,15 @@ int upload_all(pps_graph* g) {
     d.n_k2_single = (int)k2s.size(); d.n_k2_multi = (int)k2m.size() / 2; d.n_k2_finish = (int)k2f.size();
     TRY(dev_upload(g, &d.k2_single, k2s)); TRY(dev_upload(g, &d.k2_multi, k2m)); TRY(dev_upload(g, &d.k2_finish, k2f));
   }
-  TRY(dev_upload(g, &d.f_el_off, A.f_el_off)); TRY(dev_alloc(g, &d.el_tgt, (size_t)std::max<int64_t>(1, A.el_total)));   // filled by k_expand_el below
-  TRY(dev_upload(g, &d.asm_el0, A.asm_el0)); TRY(dev_upload(g, &d.asm_fsz, A.asm_fsz));
-  TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
-  TRY(dev_upload(g, &d.blk_doff, A.blk_doff)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
+  TRY(dev_upload(g, &d.f_el_off, A.f_el_off, kFl ? kFl + 1 : 0)); TRY(dev_alloc(g, &d.el_tgt, (size_t)std::max<int64_t>(1, A.el_total)));   // filled by k_expand_el below
+  TRY(dev_upload(g, &d.asm_el0, A.asm_el0, kA)); TRY(dev_upload(g, &d.asm_fsz, A.asm_fsz, kA));
+  TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off, kF ? kF + 1 : 0)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
+  TRY(dev_upload(g, &d.blk_doff, A.blk_doff, kB ? kB + 1 : 0)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
   TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
-  TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec));
-  TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
+  TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec, 8 * kS));
+  TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs, (size_t)K.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
   TRY(dev_upload(g, &d.cls_off, A.cls_off)); TRY(dev_upload(g, &d.cls_fronts, A.cls_fronts));
   if (g->use_dense) { TRY(dev_upload(g, &g->d_dw_asm, g->dw_asm)); TRY(dev_upload(g, &g->d_dw_pan, g->dw_pan)); TRY(dev_upload(g, &g->d_dw_trl, g->dw_trl)); }
   d.chi2_blocks = (d.n_obs + 255) / 256 + (d.n_odo + 255) / 256 + (d.n_pp + 255) / 256 + (d.n_lp + 255) / 256;
@@ -730,6 +744,7 @@ int upload_all(pps_graph* g) {
   g->topo_dirty = false;
   g->meas_dirty = false;
   g->grown_only_upload = true;
+  g->up_an_seq = g->an_seq;
   lap("7 expand kernels + sync");
   // no sync: the solve that follows runs on the same stream (and ends with one); whatever writes the pinned buffers
   // again checks up_inflight or follows upload_all's opening sync
