@@ -183,6 +183,7 @@ int pps_remove_factor(pps_graph* g, int fid) {
   if (!g) return PPS_EINVAL;
   if (fid < 0 || fid >= (int)g->factors.size() || g->factors[fid].deleted) return fail(g, PPS_EINVAL, "remove_factor: unknown id");
   g->factors[fid].deleted = true;
+  g->n_removals++;
   g->grown_only = false; g->grown_only_upload = false;
   g->n_live_factors--;
   g->n_live_type[g->factors[fid].type]--;
@@ -201,6 +202,7 @@ int pps_remove_node(pps_graph* g, int nid) {
     if (!f.deleted && (f.a == nid || f.b == nid)) pps_remove_factor(g, (int)i);
   }
   g->nodes[nid].deleted = true;
+  g->n_removals++;
   g->grown_only = false; g->grown_only_upload = false;
   g->n_live_nodes--;
   g->dim_nodes -= g->nodes[nid].type == NODE_POSE ? 6 : 3;

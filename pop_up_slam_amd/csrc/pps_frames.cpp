@@ -39,22 +39,36 @@ int pps_refresh_measurements(pps_graph* g) {
   if (rc != PPS_OK) return rc;
   if (g->fr_item_frame.empty()) return PPS_OK;
   if (g->frames_dirty) {
-    std::vector<int> slot(g->fr_item_fid.size()), pslot(g->fr_pose.size());
-    for (size_t i = 0; i < slot.size(); i++) {
+    // factor and pose slots only append while nothing is removed: the tables are extended by the new frame's items
+    std::vector<int>& slot = g->fr_slot; std::vector<int>& pslot = g->fr_pslot;
+    const bool inc = g->fr_cache_removals == g->n_removals && slot.size() <= g->fr_item_fid.size() && pslot.size() <= g->fr_pose.size();
+    if (!inc) { slot.clear(); pslot.clear(); }
+    const size_t i0 = slot.size(), f0 = pslot.size();
+    slot.resize(g->fr_item_fid.size()); pslot.resize(g->fr_pose.size());
+    for (size_t i = i0; i < slot.size(); i++) {
       const int fid = g->fr_item_fid[i];
       slot[i] = (fid >= 0 && !g->factors[fid].deleted && !g->factors[fid].repop) ? g->factors[fid].slot : -1;
       if (slot[i] >= 0 && g->nodes[g->fr_pose[g->fr_item_frame[i]]].deleted) slot[i] = -1;
     }
-    for (size_t f = 0; f < pslot.size(); f++) pslot[f] = g->nodes[g->fr_pose[f]].deleted ? 0 : g->nodes[g->fr_pose[f]].slot;
+    for (size_t f = f0; f < pslot.size(); f++) pslot[f] = g->nodes[g->fr_pose[f]].deleted ? 0 : g->nodes[g->fr_pose[f]].slot;
+    g->fr_cache_removals = g->n_removals;
     // tables live in the allocation list of the current upload; older copies are simply abandoned until then.  (The topology
     // upload may still be copying out of the pinned mirror and the patch buffer this is about to write.)
     if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }
-    rc = dev_upload(g, &g->d_item_frame, g->fr_item_frame); if (rc != PPS_OK) return rc;
-    rc = dev_upload(g, &g->d_item_plane, g->fr_item_plane); if (rc != PPS_OK) return rc;
-    rc = dev_upload(g, &g->d_item_slot, slot); if (rc != PPS_OK) return rc;
-    rc = dev_upload(g, &g->d_frame_pose_slot, pslot); if (rc != PPS_OK) return rc;
-    rc = dev_upload(g, &g->d_frame_seg_off, g->fr_seg_off); if (rc != PPS_OK) return rc;
-    rc = dev_upload(g, &g->d_fr_seg, g->fr_seg); if (rc != PPS_OK) return rc;
+    // The first table upload after an upload_all goes to the slots the previous layout's first table upload went to (same number of
+    // uploads in front of it: same cursor), which nothing has written since: the entries it sent are in the mirror.
+    const size_t c0 = g->up_cursor;
+    const bool first = g->fr_hint_version != g->upload_version;
+    const bool hint = inc && first && !g->up_unknown && g->fr_hint_version + 1 == g->upload_version && g->fr_hint_cursor == c0 &&
+                      g->fr_hint_items <= slot.size() && g->fr_hint_frames <= pslot.size() && i0 >= g->fr_hint_items && f0 >= g->fr_hint_frames;
+    const size_t hi = hint ? g->fr_hint_items : 0, hf = hint ? g->fr_hint_frames : 0;
+    rc = dev_upload(g, &g->d_item_frame, g->fr_item_frame, hi); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_item_plane, g->fr_item_plane, hi); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_item_slot, slot, hi); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_frame_pose_slot, pslot, hf); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_frame_seg_off, g->fr_seg_off, hf ? hf + 1 : 0); if (rc != PPS_OK) return rc;
+    rc = dev_upload(g, &g->d_fr_seg, g->fr_seg, hf ? 4 * (size_t)g->fr_seg_off[hf] : 0); if (rc != PPS_OK) return rc;
+    if (first) { g->fr_hint_version = g->upload_version; g->fr_hint_cursor = c0; g->fr_hint_items = slot.size(); g->fr_hint_frames = pslot.size(); }
     rc = flush_uploads(g); if (rc != PPS_OK) return rc;
     rc = verify_uploads(g, "frames"); if (rc != PPS_OK) return rc;
     g->up_inflight = true;                                  // (whoever writes the mirror next waits for this copy)

@@ -159,6 +159,11 @@ struct pps_graph {
   std::vector<float> fr_seg;         // 4 floats per segment
   std::vector<int> fr_item_frame, fr_item_plane, fr_item_fid;
   bool frames_dirty = true;          // device tables must be rebuilt
+  // the slot tables of the registered frames only grow while nothing is removed (n_removals): cached, and the first upload of the
+  // tables after an upload_all lands on the slots of the previous layout's -- whose leading entries (fr_hint_*) are not compared again
+  std::vector<int> fr_slot, fr_pslot;
+  long n_removals = 0, fr_cache_removals = -1;
+  int fr_hint_version = -2; size_t fr_hint_cursor = 0, fr_hint_items = 0, fr_hint_frames = 0;
   int frames_version = -1;
   int *d_item_frame = nullptr, *d_item_plane = nullptr, *d_item_slot = nullptr, *d_frame_pose_slot = nullptr, *d_frame_seg_off = nullptr;
   float* d_fr_seg = nullptr;

@@ -252,17 +252,19 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
     for (int i = tid; i <= nplanes; i += 256) s_off[i] = poly_off[i];
     if (tid < nplanes) s_box[tid] = boxes[tid];
   }
-  // ---- K5: plane equations of this frame (every workgroup; block 0 publishes them) ----
+  // ---- K5: plane equations of this frame (every workgroup; block (0, 0) publishes them -- straight into the pinned host block the
+  // caller reads, like the per-workgroup point counts: posted writes, no copy engine hop behind the kernel) ----
+  const bool publish = blockIdx.x == 0 && blockIdx.y == 0;
   if (tid <= n && tid <= kMaxPlanes) {
     float gs[4], pl[4];
     ground_plane_sensor(prm.T, gs);
     if (tid == 0) { pl[0] = gs[0]; pl[1] = gs[1]; pl[2] = gs[2]; pl[3] = gs[3]; }
     else seg_to_plane(seg2d + 4 * (tid - 1), prm.invK, prm.T, gs, pl,
-                      (blockIdx.x == 0 && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * (tid - 1) : nullptr,
-                      (blockIdx.x == 0 && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * (tid - 1) : nullptr);
+                      (publish && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * (tid - 1) : nullptr,
+                      (publish && planes_out) ? planes_out + 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * (tid - 1) : nullptr);
 #pragma unroll
     for (int k = 0; k < 4; k++) s_planes[tid][k] = pl[k];
-    if (blockIdx.x == 0 && planes_out) {
+    if (publish && planes_out) {
 #pragma unroll
       for (int k = 0; k < 4; k++) planes_out[4 * tid + k] = pl[k];
     }
@@ -619,17 +621,17 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   }
   if (fused)
     hipLaunchKernelGGL((k_popup_frame<2, true>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, img, p->d_planes, p->d_cloud, dep, pidp, p->d_count);
+                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count);
   else if (pxt == 8)
     hipLaunchKernelGGL((k_popup_frame<8, false>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, img, p->d_planes, p->d_cloud, dep, pidp, p->d_count);
+                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count);
   else
     hipLaunchKernelGGL((k_popup_frame<2, false>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, img, p->d_planes, p->d_cloud, dep, pidp, p->d_count);
+                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count);
   PHIP(p, hipGetLastError());
   PHIP(p, hipEventRecord(p->ev[1], p->stream));
   const size_t n_wg = (size_t)grid.x * grid.y;
-  PHIP(p, hipMemcpyAsync(p->h_planes, p->d_planes, sizeof(float) * kPlaneBlock + sizeof(unsigned int) * n_wg, hipMemcpyDeviceToHost, p->stream));
+  // (plane block and point counts were written into pinned host memory by the kernel itself)
   PHIP(p, hipStreamSynchronize(p->stream));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, p->ev[0], p->ev[1]);

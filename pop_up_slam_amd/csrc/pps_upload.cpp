@@ -507,7 +507,9 @@ int upload_all(pps_graph* g) {
   auto lap = [&](const char* what) { if (!tm) return; const double t = now_s(); g->up_laps[what] += t - tl; tl = t; };
   int rc = ensure_device(g);
   if (rc != PPS_OK) return rc;
+  lap("0 ensure_device");
   if (g->dev_values_newer) { rc = download_state(g); if (rc != PPS_OK) return rc; }
+  lap("1a state download");
   // Refreshed measurements may stay on the device across an upload that only appends (see the obs_meas upload below): same
   // arena, same slot with room for the new rows, same leading dimension, no re-popping edges (their slots sit behind the
   // fixed ones and would move).
@@ -522,9 +524,10 @@ int upload_all(pps_graph* g) {
                 true;
     if (!keep_meas) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
   }
+  lap("1b measurements");
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->up_inflight = false;
-  lap("1 state/meas download + syncs");
+  lap("1c opening stream sync");
   free_device(g);
   g->spec_L = g->spec_U = g->spec_delta = nullptr; g->spec_result = nullptr;
   g->spec_pose = g->spec_plane = g->spec_chi2_partials = g->spec_dn_partials = nullptr; g->spec_ticket = nullptr;
