@@ -194,6 +194,10 @@ int pps_analyze(pps_graph* g);
  * is analysed incrementally -- the part of the elimination tree left of the new poses, with all of its index arrays, is
  * kept (csrc/pps_symbolic.h).  fronts_kept of fronts_total of the last analysis were taken over (0 = from scratch). */
 int pps_analysis_reuse(const pps_graph* g, int* fronts_kept, int* fronts_total);
+/* What the last analysis left exactly as the analysis before it had it: leading entries of its index arrays (csrc/pps_symbolic.h,
+ * Analysis::Kept) -- kept[6] = fronts, fronts_lists, blocks, segs, contribs, nd_segs.  The topology upload of a frame loop does not
+ * compare those parts with its mirror again; tests/test_host_incremental.py checks the claim array by array. */
+int pps_analysis_kept(const pps_graph* g, int kept[6]);
 /* Flat dump of the analysis for host-logic tests.  Call with out == NULL to get the needed length. */
 int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed);
 

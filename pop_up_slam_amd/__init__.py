@@ -108,7 +108,7 @@ SYMBOLS = [
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
     "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
-    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times", "pps_popup_polygons_simple", "pps_analysis_reuse",
+    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times", "pps_popup_polygons_simple", "pps_analysis_reuse", "pps_analysis_kept",
 ]
 
 
@@ -465,6 +465,12 @@ class Graph:
         a, b = C.c_int(), C.c_int()
         self._ck(self.L.pps_analysis_reuse(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def analysis_kept(self):
+        """leading entries of the index arrays the last analysis took over unchanged: dict fronts / fronts_lists / blocks / segs / contribs / nd_segs"""
+        k = (C.c_int * 6)()
+        self._ck(self.L.pps_analysis_kept(self.h, k))
+        return dict(zip(("fronts", "fronts_lists", "blocks", "segs", "contribs", "nd_segs"), [int(x) for x in k]))
 
     def analyze(self):
         self._ck(self.L.pps_analyze(self.h))

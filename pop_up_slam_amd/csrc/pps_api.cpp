@@ -365,6 +365,13 @@ int pps_analysis_reuse(const pps_graph* g, int* fronts_kept, int* fronts_total) 
   return PPS_OK;
 }
 
+int pps_analysis_kept(const pps_graph* g, int kept[6]) {
+  if (!g || !kept) return PPS_EINVAL;
+  const Analysis::Kept& k = g->an.kept;
+  kept[0] = k.fronts; kept[1] = k.fronts_lists; kept[2] = k.blocks; kept[3] = k.segs; kept[4] = k.contribs; kept[5] = k.nd_segs;
+  return PPS_OK;
+}
+
 int pps_analysis_dump(pps_graph* g, int64_t cap, int32_t* out, int64_t* needed) {
   if (!g || !needed) return PPS_EINVAL;
   if (!g->analyzed || g->analysis_stale) { int rc = pps_analyze(g); if (rc != PPS_OK) return rc; }

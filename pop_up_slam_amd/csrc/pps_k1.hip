@@ -19,6 +19,9 @@ namespace pps {
 #else
 #define PPS_ODO_ATTR(M, P)
 #endif
+#ifndef PPS_OBS_WAVES
+#define PPS_OBS_WAVES 2
+#endif
 
 template <int MODE, int PART>
 __global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void k_linearize(DevGraph d, const double* __restrict__ pose,
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void k_lineariz
 // registers + spill moves into the accumulator half (one wave per SIMD); held to two waves per SIMD (256 registers) it is a fifth
 // faster on the batched sweep (540 000 edges: 160 -> 126 us; three waves: 134, four: 153).  The odometry launch is fastest alone
 // on its SIMD (103 us; 154 with two waves) and keeps the default.
-__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(PPS_OBS_WAVES, PPS_OBS_WAVES)))
 void k_linearize_obs_numeric(DevGraph d, const double* __restrict__ pose, const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, LinGuard gd) {
   extern __shared__ double lin_lds[];
   if (!lin_guard(gd, pose, plane)) return;
@@ -200,7 +203,7 @@ template <int MODE, int PART>
 __global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void k_sweep_bench(DevGraph d, double* __restrict__ Jbig, int nb_obs_per, int nb_odo_per, int replicas) {
   body_sweep_bench<MODE, PART>(d, Jbig, nb_obs_per, nb_odo_per, replicas);
 }
-__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))      // (see k_linearize_obs_numeric)
+__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(PPS_OBS_WAVES, PPS_OBS_WAVES)))      // (see k_linearize_obs_numeric)
 void k_sweep_bench_obs_numeric(DevGraph d, double* __restrict__ Jbig, int nb_obs_per, int nb_odo_per, int replicas) {
   body_sweep_bench<0, 0>(d, Jbig, nb_obs_per, nb_odo_per, replicas);
 }

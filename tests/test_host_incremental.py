@@ -52,6 +52,47 @@ def test_incremental_analysis_equals_analysis_from_scratch(built, monkeypatch):
     assert (kept[100:, 0] / kept[100:, 1]).mean() > 0.8          # ... and keeps most of its fronts
 
 
+def test_kept_parts_are_what_the_previous_analysis_held(built):
+    """Analysis::Kept (pps_analysis_kept) names leading parts of the index arrays that the incremental analysis did not touch:
+    the topology upload of a frame loop skips comparing them with its mirror of the previous upload.  Every claim is checked
+    against the previous analysis' arrays, frame by frame -- also across the frames where a Jacobian slab outgrows its capacity
+    (all buffer offsets move: blocks and lists are redone, the fronts are still kept)."""
+    n = 200
+    frames = pipeline.popup_sequence(n, seed=9)
+    g = P.Graph(); st = {"prev": None, "lm": {}}
+    prev = None
+    claims = 0; moved = 0
+    for k, fr in enumerate(frames):
+        _grow(g, st, fr)
+        g.analyze()
+        a = g.analysis_dump(); kp = g.analysis_kept()
+        if g.analysis_reuse()[0] == 0:
+            assert all(v == 0 for v in kp.values()), (k, kp)       # from scratch: nothing claimed
+        if prev is not None and kp["fronts"] > 0:
+            F, Fl, B, S, Cn, ND = kp["fronts"], kp["fronts_lists"], kp["blocks"], kp["segs"], kp["contribs"], kp["nd_segs"]
+            assert Fl <= F
+            moved += Fl == 0
+            def same(name, count):
+                count = int(count)
+                assert count <= len(a[name]) and count <= len(prev[name]), (k, name, count)
+                np.testing.assert_array_equal(a[name][:count], prev[name][:count], err_msg=f"frame {k}: {name}[:{count}]")
+            for name in ("f_p", "f_b", "f_poff", "f_Loff", "f_Uoff"): same(name, F)
+            for name in ("f_bidx_off", "f_child_off", "f_cmap_off", "f_ea_off"): same(name, F + 1)
+            same("pidx", a["f_poff"][F] if F < len(a["f_poff"]) else 0)
+            same("bidx", a["f_bidx_off"][F]); same("child", a["f_child_off"][F])
+            if Fl > 0:
+                for name in ("f_asm_off", "f_el_off"): same(name, Fl + 1)
+                for name in ("asm_blk", "asm_lrow", "asm_lcol"): same(name, a["f_asm_off"][Fl])
+            for name in ("blk_rows", "blk_cols", "blk_size", "blk_nseg", "blk_hoff"): same(name, B)
+            if B > 0: same("blk_doff", B + 1)
+            for name in ("seg_blk", "seg_c0", "seg_cnt", "seg_hoff"): same(name, S)
+            same("srec", 8 * S); same("contrib", 4 * Cn); same("nd_segs", ND)
+            claims += 1
+        prev = a
+    assert claims > 0.8 * n                                        # the frame loop builds on the previous analysis nearly always ...
+    assert moved >= 2                                              # ... including frames whose buffer offsets all moved
+
+
 def test_incremental_analysis_solves_the_normal_equations(built):
     """the arrays an incremental analysis leaves behind, replayed by the numpy emulation of the level and the band kernels"""
     from test_host_analysis import _dense_and_jbuf
