@@ -479,7 +479,7 @@ def main():
             fl, k3_bytes_c2 = factorisation_work(A)
             g.restore_state(); g.set_profiling(2); g.batch_optimize(); st2 = g.stats(); g.set_profiling(0)
             t_fac = st2["t_factor"] / max(1, st2["n_factorize"])
-            out["roofline_k3"] = {"bound": "mfma", "kernel": "k_band_factor (one factorisation = %d launches)" % int(A["n_stages"]),
+            out["roofline_k3"] = {"bound": "mfma", "kernel": "k_band_factor x %d + k_band_root (root stage: factorisation and back-substitution in one launch)" % (int(A["n_stages"]) - 1),
                                   "achieved": 2 * fl / (dual_factor_us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                   "frac": 2 * fl / (dual_factor_us * 1e-6) / 1e12 / 78.6,
                                   "flops_per_factorisation": fl, "us_per_pair_of_factorisations": dual_factor_us,
@@ -490,9 +490,11 @@ def main():
                                   "note": "the shipped dual-lambda loop factors H for lambda and lambda * 10 in the same launches: "
                                           "us_per_pair_of_factorisations = sum of the dispatch durations of the factor launches of one "
                                           "solve / number of launch sets (profiles/r4_kernel_stats_c2.txt: k_band_factor<true>, %d "
-                                          "launches per set); one_step_loop = the profiling loop with one factorisation at a time.  "
+                                          "launches per set, + k_band_root, whose duration includes the root front's "
+                                          "back-substitution, ~3 us); one_step_loop = the profiling loop with one factorisation at a time "
+                                          "(unfused launches).  " 
                                           "Latency bound by construction (511 fronts of <= 51 rows, 9 levels); peak = fp64 matrix "
-                                          "rate of MI355X (public spec; the CDNA4 guide lists none)" % int(A["n_stages"])}
+                                          "rate of MI355X (public spec; the CDNA4 guide lists none)" % (int(A["n_stages"]) - 1)}
             # headroom on one GPU: one C2 solve keeps a few dozen of the 256 CUs busy, so independent graphs (one handle
             # + one host thread each, no shared state) overlap.  Reported next to the headline, which stays the
             # one-graph-per-GPU configuration BASELINE.json names.

@@ -36,6 +36,7 @@ struct Builder {
   std::vector<DissectMemo>* old_memo = nullptr;
   const std::vector<int>* old_memo_of_first = nullptr;   // pose id -> first memo index of the sub-chains starting there (-1)
   const std::vector<int>* old_memo_next = nullptr;       // memo index -> next memo with the same first pose (-1)
+  const std::vector<char>* touched = nullptr;            // old nodes a new factor is attached to: their sub-trees' boundaries gain a node
   std::vector<DissectMemo> memo;                         // of THIS run
   std::vector<char> t_reused;                            // tree node copied from the previous analysis
   std::vector<int> t_old;                                // ... and which one it was there
@@ -219,6 +220,15 @@ struct Builder {
       for (int mi = (*old_memo_of_first)[poses[0]]; mi >= 0; mi = (*old_memo_next)[mi]) {
         const DissectMemo& m = (*old_memo)[mi];
         if (m.last != poses[n - 1] || m.count != n || m.planes != planes) continue;
+        // ... none of whose nodes has a new neighbour: a new factor may hang on an old node that stays where it was -- the last old
+        // pose when the first new one becomes a cut (several frames between two analyses), a pose a new one closes a loop with, a
+        // plane seen again from a cut pose -- and the fronts of that node's sub-tree then gain a boundary node
+        if (touched) {
+          bool hit = false;
+          for (int u : poses) hit = hit || (*touched)[u];
+          for (int u : planes) hit = hit || (*touched)[u];
+          if (hit) continue;
+        }
         // the same sub-chain with the same planes: copy its block of tree nodes
         const int t0 = (int)tree.size(), delta = t0 - m.t0, m_t0 = m.t0, m_t1 = m.t1;
         for (int q = m_t0; q < m_t1; q++) {
@@ -537,6 +547,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   std::vector<int> post;
   std::vector<int> f_pos0, f_npiv;
   std::vector<int> adj2_off_keep, adj2_keep;
+  std::vector<char> touched;
   int root = -1;
   {
     std::vector<int> off, a2;
@@ -562,7 +573,14 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
         top = B.mindeg_tree(live);
       } else {
         if (reuse) { C->valid = false;   // its tree and memos are moved from; set again when this analysis has succeeded
-          B.old_tree = &C->tree; B.old_memo = &C->memo; B.old_memo_of_first = &C->memo_of_first; B.old_memo_next = &C->memo_next; }
+          B.old_tree = &C->tree; B.old_memo = &C->memo; B.old_memo_of_first = &C->memo_of_first; B.old_memo_next = &C->memo_next;
+          touched.assign(N, 0);
+          const int n_old = (int)C->nodes.size();
+          for (size_t i = C->factors.size(); i < factors.size(); i++) {
+            if (factors[i].a < n_old) touched[factors[i].a] = 1;
+            if (factors[i].b >= 0 && factors[i].b < n_old) touched[factors[i].b] = 1;
+          }
+          B.touched = &touched; }
         top = B.dissect(poses, planes);
       }
     }

@@ -25,7 +25,7 @@ def _grow(g, st, fr):
             st["lm"][key] = g.add_plane(np.array([0, 1.0, 0, -1.0]))
             if key == "g":
                 g.add_plane_prior(st["lm"][key], np.array([0, 0, 1.0, 0]), I3)
-        g.add_plane_obs(p, st["lm"][key], np.array([0, 1.0, 0, -1.0]), I3)
+        st["last_obs"] = g.add_plane_obs(p, st["lm"][key], np.array([0, 1.0, 0, -1.0]), I3)
 
 
 def test_incremental_analysis_equals_analysis_from_scratch(built, monkeypatch):
@@ -50,6 +50,47 @@ def test_incremental_analysis_equals_analysis_from_scratch(built, monkeypatch):
     kept = np.array(kept)
     assert (kept[100:, 0] > 0).mean() > 0.9                     # nearly every frame builds on the previous one ...
     assert (kept[100:, 0] / kept[100:, 1]).mean() > 0.8          # ... and keeps most of its fronts
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_incremental_analysis_survives_removals_and_odd_sequences(built, monkeypatch, seed):
+    """what invalidates the caches of the incremental analysis (adjacency, node -> factor lists, kept tree prefix, moved offsets): factors
+    and nodes removed, an edge between two old poses (a loop closure: a cross edge of the chain), a prior added to an old node, an
+    analysis repeated without a change, several frames between two analyses -- after every analysis the arrays must be the ones of an
+    analysis from scratch of the same graph"""
+    rng = np.random.default_rng(seed)
+    frames = pipeline.popup_sequence(150, seed=20 + seed)
+    gi, gf = P.Graph(), P.Graph()
+    si, sf = {"prev": None, "lm": {}}, {"prev": None, "lm": {}}
+    poses = []                                                     # ids are the same in both graphs (same call sequence)
+    n_cmp = 0
+    for k, fr in enumerate(frames):
+        _grow(gi, si, fr); _grow(gf, sf, fr)
+        poses.append(si["prev"])
+        r = rng.random()
+        if k > 20 and r < 0.06 and len(poses) > 12:                # loop closure: the new pose, or the one before it, with an old pose
+            a, b = poses[-1 - int(rng.integers(0, 2))], poses[int(rng.integers(0, len(poses) - 10))]
+            for g in (gi, gf): g.add_odometry(b, a, np.zeros(6), I6)
+        elif k > 20 and r < 0.12:                                  # a prior on an old plane
+            key = list(si["lm"])[int(rng.integers(0, len(si["lm"])))]
+            for g, st in ((gi, si), (gf, sf)): g.add_plane_prior(st["lm"][key], np.array([0, 0, 1.0, 0]), I3)
+        elif k > 20 and r < 0.18 and len(fr.ids) > 0:              # remove the newest plane observation (not the ground's: the pose keeps one)
+            for g, st in ((gi, si), (gf, sf)): g.remove_factor(st["last_obs"])
+        elif k > 40 and r < 0.21:                                  # remove a landmark with everything attached to it
+            keys = [q for q in si["lm"] if q != "g"]
+            key = keys[int(rng.integers(0, len(keys)))]
+            for g, st in ((gi, si), (gf, sf)): g.remove_node(st["lm"].pop(key))
+        if rng.random() < 0.3: continue                            # several frames between two analyses
+        reps = 2 if rng.random() < 0.1 else 1                      # ... or the same graph analysed twice
+        for _ in range(reps): gi.analyze()
+        monkeypatch.setenv("PPS_NO_INCREMENTAL", "1"); monkeypatch.setenv("PPS_NO_INCR_COMPACT", "1")
+        for _ in range(reps): gf.analyze()                         # (the same number of analyses: an unchanged graph analysed again takes the frame-loop parameters)
+        monkeypatch.delenv("PPS_NO_INCREMENTAL"); monkeypatch.delenv("PPS_NO_INCR_COMPACT")
+        a, b = gi.analysis_dump(), gf.analysis_dump()
+        for key in b:
+            np.testing.assert_array_equal(np.atleast_1d(a[key]), np.atleast_1d(b[key]), err_msg=f"seed {seed} frame {k}: {key}")
+        n_cmp += 1
+    assert n_cmp > 60
 
 
 def test_kept_parts_are_what_the_previous_analysis_held(built):
