@@ -1,6 +1,7 @@
 """GPU: randomised graph mutation against the oracle.  Each round builds a small random world, then interleaves
 solves with random edits -- new poses with odometry and observations, new landmarks, removed observations, a landmark
-merge (Mapping.cpp:659-700), changed measurements -- and compares chi2, iteration counts and the state after every
+merge (Mapping.cpp:659-700), changed measurements, several frames appended between two solves, an odometry edge that closes a loop
+with an old pose -- and compares chi2, iteration counts and the state after every
 solve.  The edits walk the topology paths that a fixed scenario does not: re-analysis after every kind of change,
 factor slots that move, nodes that disappear, fronts whose shape changes between solves."""
 import os
@@ -53,24 +54,25 @@ def _ut(s):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PPS_FUZZ_SEEDS", "8"))))
 def test_random_edits(built, seed):
     rng = np.random.default_rng(seed)
-    spec = synth.small_world(int(rng.integers(6, 30)), int(rng.integers(3, 9)), seed=100 + seed, obs_per_pose=int(rng.integers(2, 5)))
+    spec = synth.small_world(int(rng.integers(6, 30)) if seed % 4 else int(rng.integers(40, 90)), int(rng.integers(3, 9)), seed=100 + seed, obs_per_pose=int(rng.integers(2, 5)))
     t = Twin(spec)
     t.solve(True)
     pose_ut = synth._ut_diag([0.5] * 6)
-    for step in range(int(os.environ.get("PPS_FUZZ_STEPS", "12"))):
-        kind = rng.integers(0, 6)
-        if kind == 0:        # a new pose with odometry and a few observations of live landmarks
-            prev_g, prev_o = t.poses[-1]
-            odo = synth.pose_exmap(np.array([0, 0, 0, 0, 0, 0, 1.0]), rng.normal(0, 1, 6) * np.array([0.05, 0.05, 0.1, 0.01, 0.01, 0.01]))
-            est = synth.pose_oplus(t.g.get_pose(prev_g), odo)
-            pg, po = t.g.add_pose(est), t.o.add_pose(est)
-            t.g.add_odometry(prev_g, pg, synth.pose_vector(odo), pose_ut); t.o.add_odometry(prev_o, po, synth.pose_vector(odo), pose_ut)
-            t.poses.append((pg, po))
-            live = [k for k, ok in enumerate(t.live_plane) if ok]
-            for k in rng.choice(live, size=min(len(live), int(rng.integers(2, 4))), replace=False):
-                lg, lo = t.planes[k]
-                m = synth.plane_exmap(synth.plane_transform_to(t.g.get_plane(lg), est), rng.normal(0, 0.01, 3))
-                t.obs[(len(t.poses) - 1, int(k))] = (t.g.add_plane_obs(pg, lg, m, _ut(0.1)), t.o.add_plane_obs(po, lo, m, _ut(0.1)))
+    for step in range(int(os.environ.get("PPS_FUZZ_STEPS", "16"))):
+        kind = rng.integers(0, 7)
+        if kind == 0 or kind == 6:   # new poses with odometry and a few observations of live landmarks -- one, or several frames between two solves
+          for _rep in range(1 if kind == 0 else int(rng.integers(2, 5))):
+              prev_g, prev_o = t.poses[-1]
+              odo = synth.pose_exmap(np.array([0, 0, 0, 0, 0, 0, 1.0]), rng.normal(0, 1, 6) * np.array([0.05, 0.05, 0.1, 0.01, 0.01, 0.01]))
+              est = synth.pose_oplus(t.g.get_pose(prev_g), odo)
+              pg, po = t.g.add_pose(est), t.o.add_pose(est)
+              t.g.add_odometry(prev_g, pg, synth.pose_vector(odo), pose_ut); t.o.add_odometry(prev_o, po, synth.pose_vector(odo), pose_ut)
+              t.poses.append((pg, po))
+              live = [k for k, ok in enumerate(t.live_plane) if ok]
+              for k in rng.choice(live, size=min(len(live), int(rng.integers(2, 4))), replace=False):
+                  lg, lo = t.planes[k]
+                  m = synth.plane_exmap(synth.plane_transform_to(t.g.get_plane(lg), est), rng.normal(0, 0.01, 3))
+                  t.obs[(len(t.poses) - 1, int(k))] = (t.g.add_plane_obs(pg, lg, m, _ut(0.1)), t.o.add_plane_obs(po, lo, m, _ut(0.1)))
         elif kind == 1:      # a new landmark seen from two recent poses
             if len(t.poses) < 2:
                 continue
@@ -116,5 +118,12 @@ def test_random_edits(built, seed):
             pg, _ = t.poses[key[0]]; lg, _ = t.planes[key[1]]
             m = synth.plane_exmap(synth.plane_transform_to(t.g.get_plane(lg), t.g.get_pose(pg)), rng.normal(0, 0.02, 3))
             t.g.set_measurement(fg, m); t.o.set_measurement(fo, m)
+        elif kind == 5:      # an odometry edge between the newest pose and an old one (a pose-graph loop closure)
+            if len(t.poses) < 6:
+                continue
+            k_old = int(rng.integers(0, len(t.poses) - 3))
+            (pg, po), (qg, qo) = t.poses[-1], t.poses[k_old]
+            rel = synth.pose_ominus(t.g.get_pose(pg), t.g.get_pose(qg))      # the newest pose in the old pose's frame: the edge agrees with the estimate
+            t.g.add_odometry(qg, pg, synth.pose_vector(rel), pose_ut); t.o.add_odometry(qo, po, synth.pose_vector(rel), pose_ut)
         t.solve(batch=bool(step % 3 == 0))
     assert t.g.num_nodes() == len(t.poses) + sum(t.live_plane)
