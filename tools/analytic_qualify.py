@@ -3,6 +3,11 @@ modes on the same graphs -- C2 over many seeds, C3, the stable C4 seeds.  The nu
 (tests); this tool reports the relative chi2 difference of the analytic path to it, against north_star's 1e-5.
 
   python tools/analytic_qualify.py [n_c2_seeds]
+
+Control (`numeric_nofma`): the SAME numeric mode run by the build without any contracted multiply-add (`make -C pop_up_slam_amd/csrc
+nofma` -> libpps_nofma.so, selected through PPS_LIB in a child process).  Its final chi2 differs from the default build's by rounding
+alone, so the spread of that pair over the seeds is the yardstick for the analytic-vs-numeric pair: a seed on which rounding alone
+moves the final chi2 by 1e-6 cannot certify an analytic mode to 1e-7.
 """
 import json
 import os
@@ -23,7 +28,23 @@ def pair(spec):
     return {"iters_numeric": itn, "iters_analytic": ita, "chi2_numeric": cn, "chi2_analytic": ca, "rel": abs(ca - cn) / abs(cn)}
 
 
+def numeric_only(seeds, c4, c3):
+    """child process (PPS_LIB = the no-FMA build): numeric chi2 + iterations of every graph, as JSON on stdout"""
+    out = {"c2": {}, "c4_stable": {}}
+    for group, sds in (("c2", seeds), ("c4_stable", c4)):
+        for sd in sds:
+            g = P.Graph(jacobian_mode=P.JAC_NUMERIC); synth.corridor(seed=sd).replay(g)
+            it = g.batch_optimize(); out[group][sd] = (it, g.chi2()); g.close()
+    if c3:
+        g = P.Graph(jacobian_mode=P.JAC_NUMERIC); synth.manhattan_rooms().replay(g)
+        it = g.batch_optimize(); out["c3"] = (it, g.chi2()); g.close()
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--numeric-only":
+        numeric_only(json.loads(sys.argv[2]), json.loads(sys.argv[3]), True)
+        sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     res = {"c2": {}, "c4_stable": {}}
     for sd in [42] + list(range(200, 200 + n - 1)):
@@ -36,4 +57,29 @@ if __name__ == "__main__":
     res["within_1e-5"] = bool(worst <= 1e-5)
     rels = sorted(v["rel"] for v in res["c2"].values())
     res["c2_summary"] = {"seeds": len(rels), "median_rel": rels[len(rels) // 2], "max_rel": rels[-1], "over_1e-5": sum(r > 1e-5 for r in rels)}
+    # the control: numeric mode, build without FMA
+    import subprocess
+    nofma = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pop_up_slam_amd", "libpps_nofma.so")
+    if os.path.exists(nofma):
+        seeds = [int(k) for k in res["c2"]]; c4 = [int(k) for k in res["c4_stable"]]
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--numeric-only", json.dumps(seeds), json.dumps(c4)],
+                           env=dict(os.environ, PPS_LIB=nofma), capture_output=True, text=True, timeout=1800)
+        if p.returncode == 0:
+            ctl = json.loads(p.stdout.strip().splitlines()[-1])
+            crel = []
+            for group in ("c2", "c4_stable"):
+                for sd, (it, c) in ctl[group].items():
+                    v = res[group][int(sd)]
+                    v["chi2_numeric_nofma"] = c; v["iters_numeric_nofma"] = it; v["rel_nofma"] = abs(c - v["chi2_numeric"]) / abs(v["chi2_numeric"])
+                    if group == "c2": crel.append(v["rel_nofma"])
+            res["c3"]["chi2_numeric_nofma"] = ctl["c3"][1]; res["c3"]["rel_nofma"] = abs(ctl["c3"][1] - res["c3"]["chi2_numeric"]) / abs(res["c3"]["chi2_numeric"])
+            crel.sort()
+            res["numeric_nofma_control"] = {"what": "numeric mode, libpps_nofma.so (no contracted multiply-add) against the default build: rounding alone",
+                                            "c2_median_rel": crel[len(crel) // 2], "c2_max_rel": crel[-1], "c2_over_1e-5": sum(r > 1e-5 for r in crel),
+                                            "c3_rel": res["c3"]["rel_nofma"]}
+            # seeds on which the analytic mode differs by more than rounding alone does
+            res["analytic_beyond_rounding"] = {str(sd): {"rel_analytic": v["rel"], "rel_rounding": v["rel_nofma"]}
+                                               for sd, v in res["c2"].items() if v["rel"] > 10 * max(v["rel_nofma"], 1e-12)}
+        else:
+            res["numeric_nofma_control"] = {"error": p.stderr[-500:]}
     print(json.dumps(res))
