@@ -522,7 +522,10 @@ int upload_all(pps_graph* g) {
     keep_meas = g->grown_only_upload && !g->up_unknown && !g->up_unknown_meas && g->up.spill == 0 && !any_repop && g->dev.n_obs == g->dev.n_obs_fixed &&
                 j_capacity((int64_t)n_obs_new) == g->dev.obs_ld && j_capacity((int64_t)n_lp_new) == g->dev.lp_ld && g->slot_obs_meas < g->up_slots.size() &&
                 true;
-    if (!keep_meas) { rc = download_measurements(g); if (rc != PPS_OK) return rc; }
+    if (!keep_meas) {
+      if (tm) g->up_laps["(measurement downloads, count)"] += 1e-3;      // (printed as ms: the count)
+      rc = download_measurements(g); if (rc != PPS_OK) return rc;
+    }
   }
   lap("1b measurements");
   HIP_TRY(g, hipStreamSynchronize(g->stream));
