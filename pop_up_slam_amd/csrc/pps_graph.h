@@ -114,6 +114,7 @@ struct pps_graph {
   // compared again.  PPS_DEBUG_VERIFY_UPLOAD=1 checks every such claim (hint_violation -> PPS_ESTATE).
   long an_seq = 0, an_base_seq = -1, up_an_seq = -1;
   bool hint_violation = false;
+  bool verify_hints = false;           // PPS_DEBUG_VERIFY_UPLOAD, read once per upload
   bool up_unknown_meas = false;        // ... only about the measurement arrays (written behind the mirror's back)
   size_t slot_obs_meas = (size_t)-1;   // which upload slot holds obs_meas
   size_t slot_lp_meas = (size_t)-1;    // ... and lp_meas (pps_set_measurement writes both arrays behind the mirror's back)
@@ -318,7 +319,7 @@ int dev_upload_impl(pps_graph* g, T** out, const std::vector<T>& v, size_t rows,
   if (exact_from != kNoExact && !force && sizeof(T) == 8) {
     for (size_t r = 0; r < rows; r++) {
       const size_t ro = r * ld * sizeof(T);
-      if (keep && getenv("PPS_DEBUG_VERIFY_UPLOAD") && memcmp(g->stage + o + ro, src + ro, keep * sizeof(T)) != 0) g->hint_violation = true;
+      if (keep && g->verify_hints && memcmp(g->stage + o + ro, src + ro, keep * sizeof(T)) != 0) g->hint_violation = true;
       memcpy(g->stage + o + ro + keep * sizeof(T), src + ro + keep * sizeof(T), (used - keep) * sizeof(T));   // the mirror keeps the host's view of the row
       g->up_bytes_total += used * sizeof(T);
       if (used > exact_from) g->up_patches.push_back(pps_graph::UpPatch{o + ro + exact_from * sizeof(T), (used - exact_from) * sizeof(T), true});

@@ -53,7 +53,7 @@ void up_diff(pps_graph* g, size_t o, const char* src, size_t n, bool force, size
   g->up_bytes_total += n;
   if (g->up_unknown || force) { memcpy(mir, src, n); g->up_patches.push_back(pps_graph::UpPatch{o, n, false}); return; }
   same_prefix = std::min(same_prefix, n) & ~size_t(63);
-  if (same_prefix && getenv("PPS_DEBUG_VERIFY_UPLOAD") && memcmp(mir, src, same_prefix) != 0) g->hint_violation = true;
+  if (same_prefix && g->verify_hints && memcmp(mir, src, same_prefix) != 0) g->hint_violation = true;
   // first and last 64-byte chunk that differs from what the device holds (4 KB strides first: most arrays of a frame loop
   // are unchanged from end to end, or up to a short tail)
   size_t lo = same_prefix, hi = n;
@@ -503,6 +503,7 @@ int upload_all(pps_graph* g) {
   const double t0 = now_s();
   const bool was_grown_only = g->grown_only_upload;
   const bool tm = getenv("PPS_UPLOAD_TIMING") != nullptr;
+  g->verify_hints = getenv("PPS_DEBUG_VERIFY_UPLOAD") != nullptr;
   double tl = t0;
   auto lap = [&](const char* what) { if (!tm) return; const double t = now_s(); g->up_laps[what] += t - tl; tl = t; };
   int rc = ensure_device(g);
