@@ -181,9 +181,9 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
-    q.lin_thread_form = q.n_factors_total > 200000 || getenv("PPS_MULTI_THREAD_FORM");      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
+    q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_NO_THREAD_FORM")) || getenv("PPS_MULTI_THREAD_FORM");      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
-    q.level_form = level_ok && (q.n_factors_total > 200000 || getenv("PPS_MULTI_LEVELS"));
+    q.level_form = level_ok && ((q.n_factors_total > 200000 && !getenv("PPS_MULTI_NO_LEVELS")) || getenv("PPS_MULTI_LEVELS"));      // (PPS_MULTI_NO_*: A/B)
     { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));
