@@ -549,16 +549,23 @@ template <int K> __device__ __forceinline__ double row_bcast_d(double v) {
   return __hiloint2double(hi, lo);
 }
 
+#ifndef PPS_FLOW_SLEEP
+#define PPS_FLOW_SLEEP 1
+#endif
+__device__ __forceinline__ void flow_wait(int* flow, int q) {
+  // (a parent never waits for a child, so this cannot lock up; the bound turns a logic error into wrong numbers instead of a hung GPU)
+  int spin = 0;
+  while (*(volatile int*)(flow + q) == 0 && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(PPS_FLOW_SLEEP);
+}
+
 #ifndef PPS_SOLVE_DIRECT
 #define PPS_SOLVE_DIRECT 1
 #endif
 constexpr bool kSolveDirect = PPS_SOLVE_DIRECT != 0;
 
-// The last sixteen pivots of a back-substitution (all of them for p <= 16), chain in registers.
-__device__ __forceinline__ void solve_pivot_chain(int p, double (&lk)[16], double dinv, double& tj) {
-#ifndef PPS_NO_FMA
-#pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
-#endif
+// The last sixteen pivots of a back-substitution (all of them for p <= 16), chain in registers: the scaling of the multipliers (does
+// not depend on the right-hand side) and the chain itself.
+__device__ __forceinline__ void solve_pivot_scale(double (&lk)[16], double dinv) {
     // pivots 15 .. 0 live in the first row of 16 lanes: t_k and 1 / L_kk reach the other lanes of the row as DPP row broadcasts --
     // a pivot is two v_mov_dpp + one v_fma_f64, nothing leaves the vector ALU
     // (lk is 0 on and above the diagonal since it was loaded: a select around the DPP move would be turned into a branch that
@@ -566,6 +573,13 @@ __device__ __forceinline__ void solve_pivot_chain(int p, double (&lk)[16], doubl
 #define PPS_SC(U) lk[U] *= row_bcast_d<U>(dinv);
     PPS_SC(1) PPS_SC(2) PPS_SC(3) PPS_SC(4) PPS_SC(5) PPS_SC(6) PPS_SC(7) PPS_SC(8) PPS_SC(9) PPS_SC(10) PPS_SC(11) PPS_SC(12) PPS_SC(13) PPS_SC(14) PPS_SC(15)
 #undef PPS_SC
+}
+template <bool SCALED = false>
+__device__ __forceinline__ void solve_pivot_chain(int p, double (&lk)[16], double dinv, double& tj) {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here
+#endif
+    if (!SCALED) solve_pivot_scale(lk, dinv);
 #define PPS_BS(U) case U: tj -= lk[U] * row_bcast_d<U>(tj); [[fallthrough]];
     switch (p < 16 ? p - 1 : 15) {                            // (wave-uniform: the chain is entered at the last pivot)
       PPS_BS(15) PPS_BS(14) PPS_BS(13) PPS_BS(12) PPS_BS(11) PPS_BS(10) PPS_BS(9) PPS_BS(8)
@@ -585,8 +599,11 @@ __device__ __forceinline__ void solve_pivot_chain(int p, double (&lk)[16], doubl
 // is left there for the children); false: level-per-launch form, everything through delta
 // TR (PPS_TRACE=2): phase stamps of the back-substitution in the trace slots of the front: 0 start | 1 panel in LDS | 2 boundary
 // values in place | 3 y - L_B^T x_b | 4 back-substitution done | 5 end
+// flow (band groups, body_band_solve_flow): every front of the group has been started at once; flow[q] != 0 <=> the local solution of the
+// group's front q is in X.  The front does everything that does not need its parent's solution, waits for the parent's flag right where
+// the boundary values are read, and raises its own flag behind its solution.
 template <bool GROUP = true, bool TR = false>
-__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot) {
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot, int* flow = nullptr) {
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0);
   (void)s;
@@ -628,13 +645,17 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     const int ix0 = lane < b ? ix0r : 0, ix1 = lane + 64 < b ? ix1r : 0;
     double g0 = 0.0, g1 = 0.0;
     if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }
-    else { const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows; g0 = Xp[ix0]; g1 = Xp[ix1]; }
+    if (flow) { dinv = 1.0 / dg; solve_pivot_scale(lk, dinv); }       // (all that can be done without the parent, before waiting for it)
+    if (pslot >= 0) {
+      if (flow) flow_wait(flow, pslot);
+      const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows; g0 = Xp[ix0]; g1 = Xp[ix1];
+    }
     if (TR) PPS_TR(1);
     if (lane < b) xb[lane] = g0;
     if (lane + 64 < b) xb[lane + 64] = g1;
     __builtin_amdgcn_wave_barrier();
     if (TR) PPS_TR(2);
-    dinv = 1.0 / dg;
+    if (!flow) dinv = 1.0 / dg;
     double a[4] = {part == 0 ? yr : 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 12; u++) { const int i = part + 4 * u; const double x = i < b ? xb[i] : 0.0; a[u & 3] -= lbv[u] * x; }
@@ -649,7 +670,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     tj += __shfl_xor(tj, 16);
     tj = lane < p ? tj : 0.0;
     if (TR) PPS_TR(3);
-    solve_pivot_chain(p, lk, dinv, tj);
+    if (flow) solve_pivot_chain<true>(p, lk, dinv, tj); else solve_pivot_chain(p, lk, dinv, tj);
     if (TR) PPS_TR(4);
     if (lane < p) d.delta[pix] = tj;
     if (TR) PPS_TR(5);
@@ -658,6 +679,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     if (lane < p) Xs[lane] = tj;
     if (lane < b) Xs[p + lane] = g0;
     if (lane + 64 < b) Xs[p + lane + 64] = g1;
+    if (flow && lane == 0) *(volatile int*)(flow + slot) = 1;            // (behind the solution: one wave's LDS operations complete in order)
     return;
   }
   // first batch of the panel (all of it for n <= 1024) issued right behind the index loads: the gather from delta below then waits
@@ -678,7 +700,17 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     for (int u = 0; u < 16; u++) { const int e = e0 + 64 * u + lane; PL[e < n ? e : -1] = v[u]; }
   }
   if (TR) PPS_TR(1);
+  const int lc = lane < p ? lane : 0;
+  int k0 = (p - 1) & ~15;
+  if (flow) {
+    // (data flow: the multipliers of the first sixteen pivots of the chain and the diagonal are read before the parent is waited for)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int k = k0 + u; const double l = PL[(k < p ? k : p - 1) * p + lc]; lk[u] = lane < k ? l : 0.0; }
+    dinv = 1.0 / PL[lc * p + lc];
+  }
   if (pslot >= 0) {
+    if (flow) flow_wait(flow, pslot);
     const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows;
     g0 = Xp[ix0]; g1 = Xp[ix1];
   }
@@ -693,11 +725,11 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     // Everything the dependent chain of the back-substitution reads is prepared before the chain starts: lk[k - k0] of lane j holds
     // L_kj / L_kk for j < k (0 elsewhere), 16 pivots at a time, so that t_j -= lk * t_k is all a pivot costs -- v_readlane + fma, no
     // LDS round trip, no select -- and x = t / diag(L) is one multiplication at the end.
-    const int lc = lane < p ? lane : 0;
-    int k0 = (p - 1) & ~15;
+    if (!flow) {
 #pragma unroll
-    for (int u = 0; u < 16; u++) { const int k = k0 + u; const double l = PL[(k < p ? k : p - 1) * p + lc]; lk[u] = lane < k ? l : 0.0; }
-    dinv = 1.0 / PL[lc * p + lc];
+      for (int u = 0; u < 16; u++) { const int k = k0 + u; const double l = PL[(k < p ? k : p - 1) * p + lc]; lk[u] = lane < k ? l : 0.0; }
+      dinv = 1.0 / PL[lc * p + lc];
+    }
     // y - L_B^T x_b: column j of L_B is summed by 64 / W lanes (W = 16, 32 or 64 >= p: rows i = part (mod 64 / W) each, four
     // independent partial sums per lane), then the parts are added across the wave -- 9 LDS rounds for b = 36, p = 15 instead of 36
     const int W = p <= 16 ? 16 : (p <= 32 ? 32 : 64), sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
@@ -737,6 +769,35 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane < p) Xs[lane] = tj;
   if (lane < b) Xs[p + lane] = g0;
   if (lane + 64 < b) Xs[p + lane + 64] = g1;
+  if (flow && lane == 0) *(volatile int*)(flow + slot) = 1;
+}
+
+// The back-substitution of a band group as a data flow: the group's fronts, top level first, are dealt to the waves round-robin and
+// every wave starts on its front at once -- record, index lists, factor panel, scaled multipliers: everything but the boundary values --
+// and only then waits for its parent's solution (a flag per front in LDS).  What is left between a parent's solution and its child's is
+// the gather of the boundary values, y - L_B^T x_b and the pivot chain; a level no longer costs the memory round trips of its panels,
+// and no workgroup barrier holds the fast fronts of a level back.  Same arithmetic as body_band_solve, same bits.
+// mg: solution slots behind the waves' scratch (fronts of the largest group of the stage); the flags sit behind them.
+template <bool TR = false>
+__device__ __forceinline__ void body_band_solve_flow(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds, int mg) {
+  const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* W = lds + (size_t)wave * lds_doubles_per_wave;
+  double* X = lds + (size_t)nw * lds_doubles_per_wave;
+  int* flow = reinterpret_cast<int*>(X + (size_t)mg * kBandMaxRows);
+  const int l0 = uni(d.grp_lvl_off[g]), l1 = uni(d.grp_lvl_off[g + 1]);
+  const int g0 = uni(d.glvl_front_off[l0]), gn = uni(d.glvl_front_off[l1]) - g0;
+  for (int q = threadIdx.x; q < gn; q += blockDim.x) flow[q] = 0;
+  __syncthreads();
+  int t = 0;                                                    // fronts dealt so far
+  for (int l = l1 - 1; l >= l0; l--) {
+    const int i0 = uni(d.glvl_front_off[l]), i1 = uni(d.glvl_front_off[l + 1]);
+    const int first = ((wave - t) % nw + nw) % nw;
+    for (int i = i0 + first; i < i1; i += nw) {
+      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
+      wave_front_solve<true, TR>(d, rec, W, X, i - g0, flow);
+    }
+    t += i1 - i0;
+  }
 }
 template <bool TR = false>
 __device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds) {
@@ -773,7 +834,16 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
   body_band_solve(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
-__global__ __launch_bounds__(512) void k_band_solve_trace(DevGraph d, int grp_begin, int lds_doubles_per_wave) {     // PPS_TRACE=2
+__global__ __launch_bounds__(768) void k_band_solve_flow(DevGraph d, DualAlt alt, int grp_begin, int lds_doubles_per_wave, int mg) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
+  body_band_solve_flow(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
+}
+__global__ __launch_bounds__(768) void k_band_solve_flow_trace(DevGraph d, int grp_begin, int lds_doubles_per_wave, int mg) {     // PPS_TRACE=2
+  extern __shared__ double lds[];
+  body_band_solve_flow<true>(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
+}
+__global__ __launch_bounds__(512) void k_band_solve_trace(DevGraph d, int grp_begin, int lds_doubles_per_wave) {     // PPS_TRACE=2, PPS_NO_SOLVE_FLOW=1
   extern __shared__ double lds[];
   body_band_solve<true>(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
@@ -862,6 +932,8 @@ static hipError_t ensure_band_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_flow), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_flow_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_r5), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_lean_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
@@ -910,6 +982,21 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
   const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const size_t bytes = ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
+  static const bool no_flow = getenv("PPS_NO_SOLVE_FLOW") != nullptr;
+  if (!no_flow && !(d.trace != nullptr && d.trace_solve && alt) && max_group_fronts > 1) {
+    // data-flow form: up to twelve waves (three per SIMD), as many as the group has fronts and the LDS holds
+    const size_t fixed = ((size_t)max_group_fronts * kBandMaxRows + (size_t)(max_group_fronts + 1) / 2) * sizeof(double);
+    const size_t room = (size_t)kLdsLimitBytes > fixed ? ((size_t)kLdsLimitBytes - fixed) / ((size_t)per_wave * sizeof(double)) : 0;
+    const int nwf = (int)std::min<size_t>(std::min<size_t>(12, (size_t)max_group_fronts), room);
+    if (nwf >= 1) {
+      if (d.trace != nullptr && d.trace_solve)
+        PPS_LAUNCH(k_band_solve_flow_trace, dim3(grp_count), dim3(64 * nwf), (size_t)per_wave * nwf * sizeof(double) + fixed, st, d, grp_begin, per_wave, max_group_fronts);
+      else
+        PPS_LAUNCH(k_band_solve_flow, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwf), (size_t)per_wave * nwf * sizeof(double) + fixed, st, d, alt ? *alt : DualAlt{}, grp_begin,
+                   per_wave, max_group_fronts);
+      return hipGetLastError();
+    }
+  }
   if (d.trace != nullptr && d.trace_solve && !alt) PPS_LAUNCH(k_band_solve_trace, dim3(grp_count), dim3(64 * nwaves), bytes, st, d, grp_begin, per_wave);
   else PPS_LAUNCH(k_band_solve, dim3(grp_count, alt ? 2 : 1), dim3(64 * nwaves), bytes, st, d, alt ? *alt : DualAlt{}, grp_begin, per_wave);
   return hipGetLastError();
