@@ -702,12 +702,31 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (TR) PPS_TR(1);
   const int lc = lane < p ? lane : 0;
   int k0 = (p - 1) & ~15;
+  bool pre_scaled = false;
+  const bool pre32 = flow != nullptr && p <= 32;                 // (wave-uniform) L_B operands of y - L_B^T x_b in registers before the wait
+  double lbq[12], yq = 0.0;
   if (flow) {
-    // (data flow: the multipliers of the first sixteen pivots of the chain and the diagonal are read before the parent is waited for)
+    // (data flow: the multipliers of the first sixteen pivots of the chain, the diagonal -- and for p <= 32 the entries of L_B this lane
+    // multiplies, rows part, part + np, ... -- are read before the parent is waited for)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 16; u++) { const int k = k0 + u; const double l = PL[(k < p ? k : p - 1) * p + lc]; lk[u] = lane < k ? l : 0.0; }
     dinv = 1.0 / PL[lc * p + lc];
+    if (k0 >= 16) {
+      // the multipliers of the pivots >= 16 of the first chunk take their 1 / L_kk here (the product the chain below forms first)
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int k = k0 + u; if (k < p) lk[u] = lk[u] * readlane_d(dinv, k); }
+      pre_scaled = true;
+    }
+    if (pre32) {
+      const int sh = p <= 16 ? 4 : 5, np = 64 >> sh;
+      const int j = lane & ((1 << sh) - 1), part = lane >> sh;
+      const int jc = j < p ? j : 0;
+      const int blast = b > 0 ? b - 1 : 0;
+#pragma unroll
+      for (int u = 0; u < 12; u++) { const int i = part + np * u; lbq[u] = PL[(p + (i < b ? i : blast)) * p + jc]; }
+      yq = PL[f * p + jc];
+    }
   }
   if (pslot >= 0) {
     if (flow) flow_wait(flow, pslot);
@@ -735,9 +754,20 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     const int W = p <= 16 ? 16 : (p <= 32 ? 32 : 64), sh = p <= 16 ? 4 : (p <= 32 ? 5 : 6);
     const int j = lane & (W - 1), part = lane >> sh, np = 64 >> sh;
     const int jc = j < p ? j : 0;
-    double a0 = (part == 0) ? PL[f * p + jc] : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double a0 = (part == 0) ? (pre32 ? yq : PL[f * p + jc]) : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const double* __restrict__ lb = PL + p * p + jc;
-    for (int i = part; i < b; i += 4 * np) {              // (b is wave-uniform, `part` is not: rows past b contribute 0)
+    int i_from = part;
+    if (pre32) {
+      // rows part + np u, u = 0 .. 11, from registers: the same sums in the same order as the loop below (u = 4 t + m: accumulator m)
+#pragma unroll
+      for (int u = 0; u < 12; u += 4) {
+        const int i = part + np * u, i1 = i + np, i2 = i + 2 * np, i3 = i + 3 * np;
+        const double x0 = i < b ? xb[i] : 0.0, x1 = i1 < b ? xb[i1] : 0.0, x2 = i2 < b ? xb[i2] : 0.0, x3 = i3 < b ? xb[i3] : 0.0;
+        if (i < b) { a0 -= lbq[u] * x0; a1 -= lbq[u + 1] * x1; a2 -= lbq[u + 2] * x2; a3 -= lbq[u + 3] * x3; }
+      }
+      i_from = part + 12 * np;
+    }
+    for (int i = i_from; i < b; i += 4 * np) {            // (b is wave-uniform, `part` is not: rows past b contribute 0)
       const int i1 = i + np, i2 = i + 2 * np, i3 = i + 3 * np;
       const double l0 = lb[i * p], l1 = lb[(i1 < b ? i1 : i) * p], l2 = lb[(i2 < b ? i2 : i) * p], l3 = lb[(i3 < b ? i3 : i) * p];
       const double x0 = xb[i], x1 = i1 < b ? xb[i1] : 0.0, x2 = i2 < b ? xb[i2] : 0.0, x3 = i3 < b ? xb[i3] : 0.0;
@@ -753,8 +783,9 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
 #pragma unroll
       for (int u = 15; u >= 0; u--) {
         const int k = k0 + u;
-        if (k < p) tj -= lk[u] * readlane_d(dinv, k) * readlane_d(tj, k);        // (wave-uniform branch)
+        if (k < p) tj -= (pre_scaled ? lk[u] : lk[u] * readlane_d(dinv, k)) * readlane_d(tj, k);        // (wave-uniform branch)
       }
+      pre_scaled = false;
 #pragma unroll
       for (int u = 0; u < 16; u++) { const int k = k0 - 16 + u; const double l = PL[k * p + lc]; lk[u] = lane < k ? l : 0.0; }
     }
@@ -784,19 +815,18 @@ __device__ __forceinline__ void body_band_solve_flow(const DevGraph& d, int g, i
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
   double* X = lds + (size_t)nw * lds_doubles_per_wave;
   int* flow = reinterpret_cast<int*>(X + (size_t)mg * kBandMaxRows);
-  const int l0 = uni(d.grp_lvl_off[g]), l1 = uni(d.grp_lvl_off[g + 1]);
-  const int g0 = uni(d.glvl_front_off[l0]), gn = uni(d.glvl_front_off[l1]) - g0;
+  const int2 span = reinterpret_cast<const int2*>(d.grp_span)[g];
+  const int g0 = uni(span.x), gn = uni(span.y);
+  // The group's fronts sit at consecutive positions, a parent behind its children: dealt from the last position down, every wave
+  // meets a parent before any of its children -- nobody waits for a front that sits later in a queue, so the waits cannot form a cycle.
+  // (the flags are cleared while the first records are on their way)
+  const int i_first = g0 + gn - 1 - wave;
+  int rec = i_first >= g0 ? d.frec[(size_t)i_first * 16 + (threadIdx.x & 15)] : 0;
   for (int q = threadIdx.x; q < gn; q += blockDim.x) flow[q] = 0;
   __syncthreads();
-  int t = 0;                                                    // fronts dealt so far
-  for (int l = l1 - 1; l >= l0; l--) {
-    const int i0 = uni(d.glvl_front_off[l]), i1 = uni(d.glvl_front_off[l + 1]);
-    const int first = ((wave - t) % nw + nw) % nw;
-    for (int i = i0 + first; i < i1; i += nw) {
-      const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];
-      wave_front_solve<true, TR>(d, rec, W, X, i - g0, flow);
-    }
-    t += i1 - i0;
+  for (int i = i_first; i >= g0; i -= nw) {
+    wave_front_solve<true, TR>(d, rec, W, X, i - g0, flow);
+    if (i - nw >= g0) rec = d.frec[(size_t)(i - nw) * 16 + (threadIdx.x & 15)];
   }
 }
 template <bool TR = false>

@@ -81,7 +81,7 @@ __device__ __forceinline__ DevGraph load_graph(const DevGraph* gp) {
   PPS_G(f_cmap_off) PPS_G(cmap) PPS_G(level_fronts) PPS_G(f_asm_off) PPS_G(asm_blk) PPS_G(asm_lrow) PPS_G(asm_lcol) PPS_G(asm_el0) PPS_G(asm_fsz)
   PPS_G(blk_rows) PPS_G(blk_cols) PPS_G(blk_size) PPS_G(blk_nseg) PPS_G(blk_hoff) PPS_G(seg_blk) PPS_G(seg_c0) PPS_G(seg_cnt) PPS_G(seg_hoff)
   PPS_G(contrib) PPS_G(mseg_blk) PPS_G(k2_single) PPS_G(k2_multi) PPS_G(k2_finish) PPS_G(f_el_off) PPS_G(el_src) PPS_G(el_tgt) PPS_G(blk_doff) PPS_G(blk_dst) PPS_G(Hf) PPS_G(f_ea_off) PPS_G(ea_tgt)
-  PPS_G(grp_lvl_off) PPS_G(glvl_front_off) PPS_G(glvl_fronts) PPS_G(frec) PPS_G(crec) PPS_G(srec) PPS_G(cls_off) PPS_G(cls_fronts)
+  PPS_G(grp_lvl_off) PPS_G(glvl_front_off) PPS_G(glvl_fronts) PPS_G(grp_span) PPS_G(frec) PPS_G(crec) PPS_G(srec) PPS_G(cls_off) PPS_G(cls_fronts)
   PPS_G(chi2_partials) PPS_G(dn_partials) PPS_G(ticket) PPS_G(result_dev) PPS_G(trace) PPS_G(gwork)
 #undef PPS_G
   return d;

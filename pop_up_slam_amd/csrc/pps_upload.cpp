@@ -696,6 +696,14 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.blk_doff, A.blk_doff, kB ? kB + 1 : 0)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
   TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
+  {
+    std::vector<int> span(2 * (size_t)std::max(1, A.n_groups), 0);
+    for (int gi = 0; gi < A.n_groups; gi++) {
+      span[2 * gi] = A.glvl_front_off[A.grp_lvl_off[gi]];
+      span[2 * gi + 1] = A.glvl_front_off[A.grp_lvl_off[gi + 1]] - span[2 * gi];
+    }
+    TRY(dev_upload(g, &d.grp_span, span));
+  }
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
   TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec, 8 * kS));
   TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs, (size_t)K.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
