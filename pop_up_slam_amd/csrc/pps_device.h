@@ -138,12 +138,13 @@ struct DualAlt {
   unsigned int* ticket;
   double lambda;
 };
+// pre: every group of the stage has the shape the pre-assembling walk needs (k_band_factor_pre)
 hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
-                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool pre = false);
 hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_panel, int max_group_fronts, hipStream_t st,
                              const DualAlt* alt = nullptr);
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                                   hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                                   hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool pre = false);
 // the last factor stage and the first back-substitution stage as one launch, where band_root_fusable says so
 bool band_root_fusable(const DevGraph& d, int grp_count, int max_front);
 hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,

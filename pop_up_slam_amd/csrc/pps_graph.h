@@ -88,6 +88,7 @@ struct pps_graph {
   std::vector<int> dw_asm, dw_pan, dw_trl;
   int *d_dw_asm = nullptr, *d_dw_pan = nullptr, *d_dw_trl = nullptr;
   std::vector<int> stage_max_piv, stage_nw_factor, stage_nw_solve, stage_max_grp_fronts, stage_max_panel;
+  std::vector<char> stage_pre;      // every group of the stage fits the pre-assembling walk of k_band_factor_pre
   // device
   bool dev_ready = false;
   hipStream_t stream = nullptr;

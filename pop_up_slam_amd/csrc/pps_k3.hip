@@ -920,6 +920,62 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
   }
 }
 
+// The register-only walk with the fronts of the upper local levels on waves of their own.  A band group of a dissection tree is a
+// sub-tree of 8 + 4 + 2 + 1 fronts walked by 8 waves: from the second level on, half of the waves -- and the LDS triangles they own --
+// idle.  Here the fronts of local level 2 (and 3) are dealt to the waves that have nothing to do on level 1: while level 1 is being
+// eliminated, such a wave clears its triangle and gathers the ORIGINAL entries of its upper front into it -- the part of the assembly
+// that does not depend on the children --, so that its level starts with the extend-add.  Same order of the sums (original entries,
+// then the children in order): same bits.  Groups of another shape (more fronts on a level than waves, fewer than three levels, upper
+// levels that do not fit the idle waves) take the plain walk.
+__device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
+  // (the host has checked the shape of every group of the stage: stage_pre in pps_upload.cpp.  Few values stay live across the levels:
+  // this kernel's register allocation is at its limit, see body_band_factor)
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int l0 = uni(d.grp_lvl_off[g]), nl = uni(d.grp_lvl_off[g + 1]) - l0;
+  double* F = lds + (size_t)wave * lds_doubles_per_wave;
+  const int tr = lds_doubles_per_wave - 1;
+  // this wave's front on an upper level: its record and local level (0: none)
+  int up_ll = 0, up_rec = 0;
+  {
+    const int o1 = uni(d.glvl_front_off[l0 + 1]), o2 = uni(d.glvl_front_off[l0 + 2]), o3 = uni(d.glvl_front_off[l0 + 3]);
+    const int o4 = nl > 3 ? uni(d.glvl_front_off[l0 + 4]) : o3;
+    const int c1 = o2 - o1, c2 = o3 - o2, c3 = o4 - o3;
+    int up_i = 0;
+    if (wave >= c1 && wave < c1 + c2) { up_ll = 2; up_i = o2 + wave - c1; }
+    else if (wave >= c1 + c2 && wave < c1 + c2 + c3) { up_ll = 3; up_i = o3 + wave - c1 - c2; }
+    if (up_ll) up_rec = d.frec[(size_t)up_i * 16 + (threadIdx.x & 15)];
+  }
+  int crv = 0;
+  for (int ll = 0; ll < nl; ll++) {
+    const int i0 = uni(d.glvl_front_off[l0 + ll]), cnt = uni(d.glvl_front_off[l0 + ll + 1]) - i0;
+    const bool mine_low = ll <= 1 && wave < cnt;
+    const bool mine_up = ll >= 2 && up_ll == ll;
+    if (mine_low || mine_up) {                                  // (wave-uniform)
+      const int rec = mine_up ? up_rec : d.frec[(size_t)(i0 + wave) * 16 + (threadIdx.x & 15)];
+      const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
+      if (!mine_up) {
+        FrontPre<8> pre;
+        front_pre_issue(d, rec, lane, pre);
+        front_clear(rec, lane, F);
+        front_pre_finish(d, rec, lane, pre, 1.0 + lambda, F, tr);
+        crv = pre.crv;
+      }
+      front_extend_add(d, rec, crv, lane, F, tr);
+      if (fa <= 33) front_eliminate_out<2, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+      else if (fa <= 49) front_eliminate_out<3, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+      else front_eliminate_out<4, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+    } else if (ll == 1 && up_ll) {
+      // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
+      FrontPre<8> pre;
+      front_pre_issue(d, up_rec, lane, pre);
+      front_clear(up_rec, lane, F);
+      front_pre_finish(d, up_rec, lane, pre, 1.0 + lambda, F, tr);
+      crv = pre.crv;
+    }
+    __syncthreads();   // children of the next local level are complete and visible (same CU)
+  }
+}
+
 template <bool REG_ONLY>
 __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
@@ -935,6 +991,12 @@ __global__ __launch_bounds__(512) void k_band_root(DevGraph d, DualAlt alt, int 
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
   body_band_factor<true>(d, grp, lambda, per_wave_factor, lds);
   body_band_solve(d, grp, per_wave_solve, lds);
+}
+
+__global__ __launch_bounds__(512) void k_band_factor_pre(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
+  body_band_factor_pre(d, grp_begin + blockIdx.x, lambda, lds_doubles_per_wave, lds);
 }
 
 // PPS_TRACE=1 on a register-only stage: the phase trace compiled into the register-only kernel
@@ -963,6 +1025,7 @@ static hipError_t ensure_band_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_flow), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_pre), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_flow_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_r5), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_lean_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
@@ -975,7 +1038,7 @@ static hipError_t ensure_band_attrs() {
 
 // one launcher for both: ny = 1 (alt unused) or 2 (dual)
 static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt, int ny, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                                          hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+                                          hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool pre = false) {
   if (grp_count == 0) return hipSuccess;
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const bool reg_only = max_front + 1 <= kRegRows && !(ny == 2 && d.trace != nullptr);     // (a traced dual solve runs the general kernel)
@@ -983,6 +1046,8 @@ static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt,
   const size_t bytes = (size_t)per_wave * nwaves * sizeof(double);
   if (reg_only && d.trace != nullptr)      // phase trace of the register-only kernel
     PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+  else if (reg_only && pre)
+    PPS_LAUNCH_EV(ev0, ev1, k_band_factor_pre, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (reg_only)
     PPS_LAUNCH_EV(ev0, ev1, k_band_factor<true>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
@@ -994,13 +1059,13 @@ static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt,
 }
 
 hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st, hipEvent_t ev0,
-                              hipEvent_t ev1) {
-  return launch_band_factor_impl(d, DualAlt{}, 1, grp_begin, grp_count, nwaves, max_front, lambda, st, ev0, ev1);
+                              hipEvent_t ev1, bool pre) {
+  return launch_band_factor_impl(d, DualAlt{}, 1, grp_begin, grp_count, nwaves, max_front, lambda, st, ev0, ev1, pre);
 }
 
 hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int grp_begin, int grp_count, int nwaves, int max_front, double lambda,
-                                   hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-  return launch_band_factor_impl(d, alt, 2, grp_begin, grp_count, nwaves, max_front, lambda, st, ev0, ev1);
+                                   hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool pre) {
+  return launch_band_factor_impl(d, alt, 2, grp_begin, grp_count, nwaves, max_front, lambda, st, ev0, ev1, pre);
 }
 
 size_t band_solve_lds_bytes(int max_panel) { return (size_t)(kBandMaxRows + max_panel) * sizeof(double); }   // xb + the factor panel

@@ -56,11 +56,12 @@ static int enqueue_factor_solve(pps_graph* g, const DevGraph& dv, const DualAlt*
       e0 = g->fk_events[g->fk_used]; e1 = g->fk_events[g->fk_used + 1]; g->fk_used += 2;
     }
     const int g0 = A.stage_grp_off[st], ng = A.stage_grp_off[st + 1] - g0;
+    const bool pre = st < (int)g->stage_pre.size() && g->stage_pre[st] != 0;
     if (fuse && st == top)
       HIP_TRY(g, launch_band_root(dv, alt, g0, g->stage_nw_factor[st], g->stage_nw_solve[st], A.stage_max_front[st], g->stage_max_panel[st],
                                   g->stage_max_grp_fronts[st], lambda, st_, e0, e1));
-    else if (alt) HIP_TRY(g, launch_band_factor_dual(dv, *alt, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1));
-    else HIP_TRY(g, launch_band_factor(dv, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1));
+    else if (alt) HIP_TRY(g, launch_band_factor_dual(dv, *alt, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1, pre));
+    else HIP_TRY(g, launch_band_factor(dv, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1, pre));
   }
   for (int st = fuse ? top - 1 : top; st >= 0; st--)
     HIP_TRY(g, launch_band_solve(dv, A.stage_grp_off[st], A.stage_grp_off[st + 1] - A.stage_grp_off[st], g->stage_nw_solve[st],

@@ -370,6 +370,25 @@ static int run_analysis_impl(pps_graph* g) {
       if (xbytes + per_wave > lds_budget) { g->use_band = false; g->stage_nw_solve[st] = 1; continue; }
       g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, (lds_budget - xbytes) / per_wave));
     }
+    // k_band_factor_pre: groups of three or four local levels, every level in one round of the stage's waves, and the fronts of local
+    // levels 2 and up on waves that idle from level 1 on (8 + 4 + 2 + 1 on eight waves: 4 + 2 + 1 <= 8)
+    g->stage_pre.assign(A.n_stages, 0);
+    if (!getenv("PPS_NO_PREASSEMBLE"))
+      for (int st = 0; st < A.n_stages; st++) {
+        bool ok = A.stage_grp_off[st + 1] > A.stage_grp_off[st] && A.stage_max_front[st] + 1 <= band_reg_rows();
+        const int nw = g->stage_nw_factor[st];
+        for (int gi = A.stage_grp_off[st]; ok && gi < A.stage_grp_off[st + 1]; gi++) {
+          const int l0 = A.grp_lvl_off[gi], nl = A.grp_lvl_off[gi + 1] - l0;
+          ok = nl >= 3 && nl <= 4;
+          int upper = 0;
+          for (int k = 0; ok && k < nl; k++) {
+            const int c = A.glvl_front_off[l0 + k + 1] - A.glvl_front_off[l0 + k];
+            if (k == 0) ok = c <= nw; else upper += c;
+          }
+          ok = ok && upper <= nw;
+        }
+        g->stage_pre[st] = ok ? 1 : 0;
+      }
     // (such a graph then runs on the level-per-launch kernels: its fronts are <= 127 rows by the use_band test above)
   }
   if (!g->use_band && !g->use_dense && g->an.max_front > 4096)
