@@ -230,6 +230,8 @@ struct BatchGeom {
   int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
   int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};
   bool stage_reg_only[32] = {false};
+  bool stage_pre[32] = {false};      // every group of every graph of the chunk has the shape of the pre-assembling walk at this stage's wave count
+  int stage_nw_flow[32] = {0};       // waves of the data-flow back-substitution of the stage (0: the barrier form)
   // level-per-launch form (large chunks whose fronts all take the register path): one launch per tree level and size class,
   // every front on its own wave, no groups -- more waves per SIMD on the small classes than the band kernels can hold
   bool level_form = false;

@@ -1159,6 +1159,36 @@ __global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, in
   body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, lds);
 }
 
+__global__ __launch_bounds__(512) void kb_band_factor_pre(BatchArgs a, int stage, int lds_doubles_per_wave) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
+  if ((int)blockIdx.x >= sg.grp_count) return;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
+    body_band_factor_pre(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, lds);
+    return;
+  }
+  body_band_factor_pre(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, lds);
+}
+
+__global__ __launch_bounds__(768) void kb_band_solve_flow(BatchArgs a, int stage, int lds_doubles_per_wave, int mg) {
+  extern __shared__ double lds[];
+  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
+  if ((int)blockIdx.x >= sg.grp_count) return;
+  if (blockIdx.z) {
+    const BatchAlt al = load_alt(a.alt + a.b0 + b);
+    DevGraph d2 = d;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
+    body_band_solve_flow(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
+    return;
+  }
+  body_band_solve_flow(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
+}
+
 __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
@@ -1238,6 +1268,8 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_solve_flow), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_band_factor_pre), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_level_factor2), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_level_factor3), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kb_level_factor4), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
@@ -1261,7 +1293,9 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
     const size_t bytes = (size_t)per_wave * nw * sizeof(double);
-    if (g.stage_reg_only[stg])
+    if (g.stage_reg_only[stg] && g.stage_pre[stg])
+      PPS_LAUNCH(kb_band_factor_pre, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+    else if (g.stage_reg_only[stg])
       PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else
       PPS_LAUNCH(kb_band_factor<false>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
@@ -1271,6 +1305,12 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     if (g.stage_groups[stg] <= 0) continue;
     const int per_wave = g.stage_per_wave_solve[stg], nw = g.stage_nw_solve[stg];
     const size_t bytes = ((size_t)per_wave * nw + (size_t)g.stage_grp_fronts[stg] * kBandMaxRows) * sizeof(double);
+    if (g.stage_nw_flow[stg] > 0) {
+      const int nwf = g.stage_nw_flow[stg], mg = g.stage_grp_fronts[stg];
+      const size_t fb = ((size_t)per_wave * nwf + (size_t)mg * kBandMaxRows + (size_t)(mg + 1) / 2) * sizeof(double);
+      PPS_LAUNCH(kb_band_solve_flow, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nwf), fb, st, a, stg, per_wave, mg);
+      continue;
+    }
     PPS_LAUNCH(kb_band_solve, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
   }
   return hipGetLastError();
