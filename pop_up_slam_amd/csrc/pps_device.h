@@ -68,7 +68,7 @@ struct DevGraph {
   double* Hf = nullptr;      // H in front gather order: front s reads Hf[f_el_off[s] .. f_el_off[s+1])
   int64_t* f_ea_off = nullptr; int* ea_tgt = nullptr;
   int *grp_lvl_off = nullptr, *glvl_front_off = nullptr, *glvl_fronts = nullptr;
-  int* grp_span = nullptr;          // per band group: first position in glvl order, number of fronts (one 8-byte load for k_band_solve_flow)
+  int* grp_span = nullptr;          // per band group, 8 ints: first position in glvl order, fronts, local levels, first position of local levels 1 .. 4, 0
   int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
   int* obs_dir = nullptr;                                   // direct (pose, plane) blocks: 3 ints per plane-observation slot (pps_symbolic.h)
   int* nd_segs = nullptr; int n_nd_segs = 0;                // H segments that are not direct

@@ -815,7 +815,7 @@ __device__ __forceinline__ void body_band_solve_flow(const DevGraph& d, int g, i
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
   double* X = lds + (size_t)nw * lds_doubles_per_wave;
   int* flow = reinterpret_cast<int*>(X + (size_t)mg * kBandMaxRows);
-  const int2 span = reinterpret_cast<const int2*>(d.grp_span)[g];
+  const int2 span = reinterpret_cast<const int2*>(d.grp_span)[4 * (size_t)g];
   const int g0 = uni(span.x), gn = uni(span.y);
   // The group's fronts sit at consecutive positions, a parent behind its children: dealt from the last position down, every wave
   // meets a parent before any of its children -- nobody waits for a front that sits later in a queue, so the waits cannot form a cycle.
@@ -837,10 +837,12 @@ __device__ __forceinline__ void body_band_solve(const DevGraph& d, int g, int ld
   const int l0 = uni(d.grp_lvl_off[g]), l1 = uni(d.grp_lvl_off[g + 1]);
   // The front lists of the group's levels and the record of this wave's first front on each of them are fetched before the walk
   // starts: a level then begins with the loads of its panel, not with two dependent round trips (offsets, record) behind the barrier.
-  // (a group has at most band_levels <= 4 local levels; deeper ones would take the in-loop loads)
+  // (a group has at most band_levels <= 4 local levels; deeper ones would take the in-loop loads; the offsets come with the group's record)
   int off[5], r4[4];
-#pragma unroll
-  for (int k = 0; k < 5; k++) off[k] = uni(d.glvl_front_off[l0 + k <= l1 ? l0 + k : l1]);
+  {
+    const int4 ga = reinterpret_cast<const int4*>(d.grp_span)[2 * (size_t)g], gb = reinterpret_cast<const int4*>(d.grp_span)[2 * (size_t)g + 1];
+    off[0] = uni(ga.x); off[1] = uni(ga.w); off[2] = uni(gb.x); off[3] = uni(gb.y); off[4] = uni(gb.z);
+  }
   const int g0 = off[0];
 #pragma unroll
   for (int k = 0; k < 4; k++) { const int i = off[k] + wave; r4[k] = d.frec[(size_t)(i < off[k + 1] ? i : g0) * 16 + (threadIdx.x & 15)]; }
@@ -891,9 +893,11 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
   // twice: held in registers the five live values push the register-tile code into spills inside the elimination -- C2 stage
   // 25.6 -> 33.4 us --; parked in LDS it gains nothing on C2 and costs C3 a third of its factor time.)
   const int l0 = d.grp_lvl_off[g], l1 = d.grp_lvl_off[g + 1];
+  // (the first level's positions come with the group's record: one look-up less in front of the first front of the launch)
+  const int4 ga = reinterpret_cast<const int4*>(d.grp_span)[2 * (size_t)g];
   for (int l = l0; l < l1; l++) {
-    const int i1 = d.glvl_front_off[l + 1];
-    for (int i = d.glvl_front_off[l] + wave; i < i1; i += nw) {
+    const int i1 = l == l0 ? ga.w : d.glvl_front_off[l + 1];
+    for (int i = (l == l0 ? ga.x : d.glvl_front_off[l]) + wave; i < i1; i += nw) {
       const int rec = d.frec[(size_t)i * 16 + (threadIdx.x & 15)];          // packed front record, one coalesced load
       const int s = __builtin_amdgcn_readlane(rec, 0);
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
@@ -931,14 +935,14 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
   // (the host has checked the shape of every group of the stage: stage_pre in pps_upload.cpp.  Few values stay live across the levels:
   // this kernel's register allocation is at its limit, see body_band_factor)
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int l0 = uni(d.grp_lvl_off[g]), nl = uni(d.grp_lvl_off[g + 1]) - l0;
+  const int4 ga = reinterpret_cast<const int4*>(d.grp_span)[2 * (size_t)g], gb = reinterpret_cast<const int4*>(d.grp_span)[2 * (size_t)g + 1];
+  const int g0 = uni(ga.x), nl = uni(ga.z), lo1 = uni(ga.w), lo2 = uni(gb.x);       // first positions of local levels 0, 1, 2
   double* F = lds + (size_t)wave * lds_doubles_per_wave;
   const int tr = lds_doubles_per_wave - 1;
   // this wave's front on an upper level: its record and local level (0: none)
   int up_ll = 0, up_rec = 0;
   {
-    const int o1 = uni(d.glvl_front_off[l0 + 1]), o2 = uni(d.glvl_front_off[l0 + 2]), o3 = uni(d.glvl_front_off[l0 + 3]);
-    const int o4 = nl > 3 ? uni(d.glvl_front_off[l0 + 4]) : o3;
+    const int o1 = uni(ga.w), o2 = uni(gb.x), o3 = uni(gb.y), o4 = uni(gb.z);
     const int c1 = o2 - o1, c2 = o3 - o2, c3 = o4 - o3;
     int up_i = 0;
     if (wave >= c1 && wave < c1 + c2) { up_ll = 2; up_i = o2 + wave - c1; }
@@ -947,7 +951,7 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
   }
   int crv = 0;
   for (int ll = 0; ll < nl; ll++) {
-    const int i0 = uni(d.glvl_front_off[l0 + ll]), cnt = uni(d.glvl_front_off[l0 + ll + 1]) - i0;
+    const int i0 = ll == 0 ? g0 : lo1, cnt = ll == 0 ? lo1 - g0 : lo2 - lo1;              // (used on local levels 0 and 1 only)
     const bool mine_low = ll <= 1 && wave < cnt;
     const bool mine_up = ll >= 2 && up_ll == ll;
     if (mine_low || mine_up) {                                  // (wave-uniform)

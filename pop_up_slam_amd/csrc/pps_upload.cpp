@@ -716,10 +716,14 @@ int upload_all(pps_graph* g) {
   TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
   {
-    std::vector<int> span(2 * (size_t)std::max(1, A.n_groups), 0);
+    // per group, one 32-byte record: first position, fronts, local levels, first position of local levels 1 .. 4 (the last one
+    // repeated), 0 -- what the band kernels would otherwise fetch with two dependent look-ups (levels of the group, their offsets)
+    std::vector<int> span(8 * (size_t)std::max(1, A.n_groups), 0);
     for (int gi = 0; gi < A.n_groups; gi++) {
-      span[2 * gi] = A.glvl_front_off[A.grp_lvl_off[gi]];
-      span[2 * gi + 1] = A.glvl_front_off[A.grp_lvl_off[gi + 1]] - span[2 * gi];
+      const int l0 = A.grp_lvl_off[gi], nl = A.grp_lvl_off[gi + 1] - l0;
+      int* r = &span[8 * (size_t)gi];
+      r[0] = A.glvl_front_off[l0]; r[1] = A.glvl_front_off[l0 + nl] - r[0]; r[2] = nl;
+      for (int k = 1; k <= 4; k++) r[2 + k] = A.glvl_front_off[l0 + std::min(k, nl)];
     }
     TRY(dev_upload(g, &d.grp_span, span));
   }
