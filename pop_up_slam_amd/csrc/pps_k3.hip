@@ -924,6 +924,27 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
   }
 }
 
+#ifndef PPS_NPRE_BIG
+#define PPS_NPRE_BIG 8
+#endif
+// clear + original entries of a front, the first batch of NPRE x 64 entries requested before the clearing (front_pre_issue).  A
+// separator front of a corridor tree has 120 - 180 original entries, a leaf up to 650: three loads per lane cover the former -- eight
+// were five wasted load / read-modify-write pairs per lane (C2, same box, five runs each: 63.59 -> 63.33 us per LM iteration); eleven
+// for the leaves (one round trip instead of two for the largest) measured the same as eight: PPS_NPRE_BIG.
+template <int NPRE>
+__device__ __forceinline__ int front_orig_entries(const DevGraph& d, int rec, int lane, double damp, double* F, int tr) {
+  FrontPre<NPRE> pre;
+  front_pre_issue(d, rec, lane, pre);
+  front_clear(rec, lane, F);
+  front_pre_finish(d, rec, lane, pre, damp, F, tr);
+  return pre.crv;
+}
+__device__ __forceinline__ int front_orig_entries_sized(const DevGraph& d, int rec, int lane, double damp, double* F, int tr) {
+  const int n_el = __builtin_amdgcn_readlane(rec, 4) - __builtin_amdgcn_readlane(rec, 3);
+  if (n_el <= 192) return front_orig_entries<3>(d, rec, lane, damp, F, tr);        // (wave-uniform)
+  return front_orig_entries<PPS_NPRE_BIG>(d, rec, lane, damp, F, tr);
+}
+
 // The register-only walk with the fronts of the upper local levels on waves of their own.  A band group of a dissection tree is a
 // sub-tree of 8 + 4 + 2 + 1 fronts walked by 8 waves: from the second level on, half of the waves -- and the LDS triangles they own --
 // idle.  Here the fronts of local level 2 (and 3) are dealt to the waves that have nothing to do on level 1: while level 1 is being
@@ -957,24 +978,14 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
     if (mine_low || mine_up) {                                  // (wave-uniform)
       const int rec = mine_up ? up_rec : d.frec[(size_t)(i0 + wave) * 16 + (threadIdx.x & 15)];
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
-      if (!mine_up) {
-        FrontPre<8> pre;
-        front_pre_issue(d, rec, lane, pre);
-        front_clear(rec, lane, F);
-        front_pre_finish(d, rec, lane, pre, 1.0 + lambda, F, tr);
-        crv = pre.crv;
-      }
+      if (!mine_up) crv = front_orig_entries_sized(d, rec, lane, 1.0 + lambda, F, tr);
       front_extend_add(d, rec, crv, lane, F, tr);
       if (fa <= 33) front_eliminate_out<2, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
       else if (fa <= 49) front_eliminate_out<3, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
       else front_eliminate_out<4, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
     } else if (ll == 1 && up_ll) {
       // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
-      FrontPre<8> pre;
-      front_pre_issue(d, up_rec, lane, pre);
-      front_clear(up_rec, lane, F);
-      front_pre_finish(d, up_rec, lane, pre, 1.0 + lambda, F, tr);
-      crv = pre.crv;
+      crv = front_orig_entries_sized(d, up_rec, lane, 1.0 + lambda, F, tr);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
   }
