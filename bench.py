@@ -479,7 +479,7 @@ def main():
             fl, k3_bytes_c2 = factorisation_work(A)
             g.restore_state(); g.set_profiling(2); g.batch_optimize(); st2 = g.stats(); g.set_profiling(0)
             t_fac = st2["t_factor"] / max(1, st2["n_factorize"])
-            out["roofline_k3"] = {"bound": "mfma", "kernel": "k_band_factor x %d + k_band_root (root stage: factorisation and back-substitution in one launch)" % (int(A["n_stages"]) - 1),
+            out["roofline_k3"] = {"bound": "mfma", "kernel": "k_band_factor_pre x %d + k_band_root (root stage: factorisation and back-substitution in one launch)" % (int(A["n_stages"]) - 1),
                                   "achieved": 2 * fl / (dual_factor_us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                   "frac": 2 * fl / (dual_factor_us * 1e-6) / 1e12 / 78.6,
                                   "flops_per_factorisation": fl, "us_per_pair_of_factorisations": dual_factor_us,
@@ -489,7 +489,7 @@ def main():
                                           "frac": 2 * k3_bytes_c2 / (dual_factor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_factorisation": k3_bytes_c2},
                                   "note": "the shipped dual-lambda loop factors H for lambda and lambda * 10 in the same launches: "
                                           "us_per_pair_of_factorisations = sum of the dispatch durations of the factor launches of one "
-                                          "solve / number of launch sets (profiles/r4_kernel_stats_c2.txt: k_band_factor<true>, %d "
+                                          "solve / number of launch sets (profiles/r4_kernel_stats_c2.txt: k_band_factor_pre, %d "
                                           "launches per set, + k_band_root, whose duration includes the root front's "
                                           "back-substitution, ~3 us); one_step_loop = the profiling loop with one factorisation at a time "
                                           "(unfused launches).  " 
@@ -562,7 +562,7 @@ def main():
                                          "algorithmic_bytes_per_launch": bytes3, "avg_launch_us": 1e6 * k1_3_solve, "launches": s3d["n_linearize"],
                                          "replay_avg_launch_us": 1e6 * k1_3, "traffic": None,
                                          "note": "inside the solve (dispatch timestamps); profiles/r4_kernel_stats_c3.txt"},
-                         "roofline_k3_hbm": {"bound": "hbm", "kernel": "k_band_factor<true> + k_band_factor_r5",
+                         "roofline_k3_hbm": {"bound": "hbm", "kernel": "k_band_factor_pre / k_band_factor<true> + k_band_factor_r5",
                                              "achieved": 2 * k3_bytes3 / pair3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": 2 * k3_bytes3 / pair3 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_factorisation": k3_bytes3,
                                              "us_per_factorisation_amortised": 1e6 * pair3 / 2, "factorisations": s3d["n_factorize"], "traffic": None,
