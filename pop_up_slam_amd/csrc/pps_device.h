@@ -158,6 +158,7 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_
 // el_tgt / blk_dst (H block element <-> front-ordered H <-> packed front index) expanded from the per-block records;
 // blk_dst must be filled with -1 beforehand
 hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st);
+hipError_t launch_expand_lists(const DevGraph& d, int n_fronts, int n_asm, double* zero, size_t n_zero, hipStream_t st);   // both + the zero fill, one launch
 int band_max_rows();
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels

@@ -191,6 +191,49 @@ __global__ __launch_bounds__(256) void k_expand_el(DevGraph d, int n_asm) {
   }
 }
 
+// Both expansions and the upload's zero fill in ONE launch (frame loops: a launch less per frame).  Workgroups [0, n_fronts) do what
+// k_expand_ea does, the others what k_expand_el does, 64 assembled blocks each; an assembled block defines EVERY entry of its blk_dst
+// range itself (-1 for the upper triangle of a diagonal block, which no front gathers), so no fill has to run before it -- valid when
+// every H block is assembled by exactly one front (the caller checks).
+__global__ __launch_bounds__(64) void k_expand_lists(DevGraph d, double* __restrict__ zero, int n_zero, int n_fronts, int n_asm) {
+  for (int i = blockIdx.x * 64 + threadIdx.x; i < n_zero; i += gridDim.x * 64) zero[i] = 0.0;
+  if ((int)blockIdx.x < n_fronts) {
+    const int s = blockIdx.x;
+    const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
+    const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
+    int* __restrict__ out = d.ea_tgt + d.f_ea_off[s];
+    const int n = len * (len + 1) / 2;
+    int i = 0;                                  // row of entry e: tri(i) <= e < tri(i+1)
+    for (int e = threadIdx.x; e < n; e += 64) {
+      while ((i + 1) * (i + 2) / 2 <= e) i++;
+      const int j = e - i * (i + 1) / 2;
+      out[e] = m[i] * (m[i] + 1) / 2 + m[j];
+    }
+    return;
+  }
+  const int a = ((int)blockIdx.x - n_fronts) * 64 + threadIdx.x;
+  if (a >= n_asm) return;
+  const int blk = d.asm_blk[a], rows = d.blk_rows[blk], cols = d.blk_cols[blk];
+  const int lrow = d.asm_lrow[a], lcol = d.asm_lcol[a];
+  const bool diag = d.blk_size[blk] != rows * cols;
+  int* __restrict__ dst = d.blk_dst + d.blk_doff[blk];
+  int e = d.asm_el0[a];
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) {
+      if (diag && j > i) { dst[i * cols + j] = -1; continue; }
+      dst[i * cols + j] = e;
+      d.el_tgt[e++] = (((lrow + i) * (lrow + i + 1)) / 2 + lcol + j) | ((diag && i == j) ? (1 << 30) : 0);
+    }
+  if (diag) {
+    const int fsz = d.asm_fsz[a];
+    for (int i = 0; i < rows; i++) { dst[rows * cols + i] = e; d.el_tgt[e++] = (fsz * (fsz + 1)) / 2 + lcol + i; }
+  }
+}
+hipError_t launch_expand_lists(const DevGraph& d, int n_fronts, int n_asm, double* zero, size_t n_zero, hipStream_t st) {
+  PPS_LAUNCH(k_expand_lists, dim3(n_fronts + (n_asm + 63) / 64), dim3(64), 0, st, d, zero, (int)n_zero, n_fronts, n_asm);
+  return hipGetLastError();
+}
+
 hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st) {
   if (n_asm <= 0) return hipSuccess;
   PPS_LAUNCH(k_expand_el, dim3((n_asm + 255) / 256), dim3(256), 0, st, d, n_asm);

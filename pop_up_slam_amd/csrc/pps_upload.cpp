@@ -768,7 +768,12 @@ int upload_all(pps_graph* g) {
   rc = flush_uploads(g); if (rc != PPS_OK) return rc;
   rc = verify_uploads(g, "upload_all"); if (rc != PPS_OK) return rc;
   lap("6 flush");
-  {
+  // one launch for both expansions when every H block is assembled by exactly one front (always, unless an analysis ever lists a block
+  // twice or not at all: then the fill of blk_dst has to run first, in a launch of its own)
+  const bool one_launch = A.ea_total > 0 && zero_doubles < (size_t)1 << 30 && (int)A.asm_blk.size() == A.n_blocks && A.n_fronts > 0 &&
+                          !getenv("PPS_SPLIT_EXPAND");
+  if (one_launch) HIP_TRY(g, launch_expand_lists(d, A.n_fronts, (int)A.asm_blk.size(), zero_block, zero_doubles, g->stream));
+  else {
     const size_t n_dst = (size_t)std::max(1, A.blk_doff[A.n_blocks]);
     if (A.ea_total > 0 && zero_doubles < (size_t)1 << 30 && n_dst < (size_t)1 << 30)
       HIP_TRY(g, launch_expand_ea(d, A.n_fronts, zero_block, zero_doubles, d.blk_dst, n_dst, g->stream));
@@ -777,8 +782,8 @@ int upload_all(pps_graph* g) {
       HIP_TRY(g, hipMemsetAsync(zero_block, 0, zero_doubles * 8, g->stream));
       HIP_TRY(g, hipMemsetAsync(d.blk_dst, 0xff, sizeof(int) * n_dst, g->stream));
     }
+    HIP_TRY(g, launch_expand_el(d, (int)A.asm_blk.size(), g->stream));
   }
-  HIP_TRY(g, launch_expand_el(d, (int)A.asm_blk.size(), g->stream));
   g->topo_dirty = false;
   g->meas_dirty = false;
   g->grown_only_upload = true;
