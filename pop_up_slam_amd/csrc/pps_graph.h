@@ -146,6 +146,7 @@ struct pps_graph {
   double* spec_result = nullptr;   // result_dev of the speculative set: its own not-PD flag
   double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
   int snap_version = -1, upload_version = 0;
+  int k2t_version = -1;              // upload_version the class lists of K2's throughput form (dev.k2t) were built for
   int profiling = 0;               // 0 off, 1 = K1 event pairs without host syncs, 2 = every phase (adds syncs)
   hipEvent_t ev[2] = {nullptr, nullptr};
   unsigned long long launches0 = 0;   // launch_count() at the start of the solve call

@@ -329,6 +329,183 @@ __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
   for (int q = 0; q < S; q++) wave_hblock_segment(d, h[q], h2_lds + wave * kH2WaveDoubles);
 }
 
+// ------------------------------------------------------------------------------------------
+// K2, throughput form by segment class.  The generic wave-per-segment body above spends ~55 wave instructions on every
+// contribution whatever the block holds (three clamped loads, three LDS writes, a dozen LDS reads with computed addresses, the lane
+// -> (i, j) division by a run-time column count) -- and a C2 graph has 13 000 contributions in three shapes only.  pps_multi sorts a
+// graph's non-direct segments into classes once per upload (pps_device.h: k2t) and the classes get their own bodies:
+//  * pose diagonal (6 x 6 + g, rows of 3 from plane observations / 6 from odometry; row slice = column slice): ONE load and ONE LDS
+//    write per contribution -- lanes [0, 6 m) take the slice, the next m the residual, stored at 36 + 6 k so that the rhs lanes
+//    read their second operand with the same stride (immediate offsets) as the matrix lanes;
+//  * pose-pose off-diagonal (6 x 6, rows of 6): two loads, compile-time strides;
+//  * plane diagonal (3 x 3 + g, rows of 3: 12 of 64 lanes in the generic body, 20-64 contributions each): FOUR segments per wave, one
+//    per 16-lane group, a contribution of each per step -- one descriptor load (the same address across a group) and one load
+//    of slice + residual per step.
+// Everything else keeps the generic body.  Per entry the sum runs over the contributions in list order and k ascending as explicit
+// multiply-adds -- the same bits as every other form of K2.
+// ------------------------------------------------------------------------------------------
+constexpr int kT66Slots = 8;
+constexpr int kT66Stride = 72;       // doubles per slot: [slice, k-major <= 36 | r[k] at 36 + 6 k]  /  [row slice 36 | column slice 36]
+constexpr int kT33U = 4;             // contributions in flight per 16-lane group
+constexpr int kTcWaveDoubles = kH2WaveDoubles;          // (the generic body's area: the largest)
+static_assert(kTcWaveDoubles >= kT33U * 4 * 16 && kTcWaveDoubles >= kT66Slots * kT66Stride, "one LDS area per wave serves all bodies");
+
+__device__ __forceinline__ void wave_hblock_66_diag(const DevGraph& d, const SegHdr& h, double* __restrict__ S) {
+  const int lane = threadIdx.x & 63;
+  const int4 mine = h.mine;
+  const int cnt = __builtin_amdgcn_readlane(h.rec, 4), hoff = __builtin_amdgcn_readlane(h.rec, 5);
+  const bool is_g = lane >= 36;
+  const int i = is_g ? lane - 36 : lane / 6;
+  const int j = is_g ? 0 : lane - 6 * (lane / 6);
+  const int pb0 = is_g ? 36 : j;
+  // what a lane fetches and where it puts it, for rows of 3 and of 6: slice element / residual (lanes past both repeat the last residual)
+  const int t3 = lane - 18 < 2 ? lane - 18 : 2, t6 = lane - 36 < 5 ? lane - 36 : 5;
+  const int l3 = lane < 18 ? lane : t3, l6 = lane < 36 ? lane : t6;
+  const int w3 = lane < 18 ? lane : 36 + 6 * t3, w6 = lane < 36 ? lane : 36 + 6 * t6;
+  const double* __restrict__ J = d.J;
+  double acc = 0.0;
+  for (int cb = 0; cb < cnt; cb += kT66Slots) {
+    const int nc = cnt - cb < kT66Slots ? cnt - cb : kT66Slots;
+    double x[kT66Slots];
+    int w[kT66Slots];
+#pragma unroll
+    for (int u = 0; u < kT66Slots; u++) {
+      const int cu = cb + (u < nc ? u : nc - 1);
+      const int jv = __builtin_amdgcn_readlane(mine.x, cu), ro = __builtin_amdgcn_readlane(mine.z, cu), m = __builtin_amdgcn_readlane(mine.w, cu);
+      const bool six = m > 3;
+      const bool isr = six ? lane >= 36 : lane >= 18;
+      w[u] = six ? w6 : w3;
+      x[u] = J[(isr ? ro : jv) + (six ? l6 : l3)];
+    }
+#pragma unroll
+    for (int u = 0; u < kT66Slots; u++) S[u * kT66Stride + w[u]] = x[u];
+    __builtin_amdgcn_wave_barrier();
+    for (int u = 0; u < nc; u++) {
+      const int m = __builtin_amdgcn_readlane(mine.w, cb + u);
+      const double* __restrict__ pa = S + u * kT66Stride + i;
+      const double* __restrict__ pb = S + u * kT66Stride + pb0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc = PPS_MAC(acc, pa[6 * k], pb[6 * k]);
+      if (m > 3) {
+#pragma unroll
+        for (int k = 3; k < 6; k++) acc = PPS_MAC(acc, pa[6 * k], pb[6 * k]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane >= 42) return;
+  if (is_g) acc = -acc;                                   // b = -r (isam/Jacobian.h:98)
+  d.H[hoff + lane] = acc;
+  if (h.dst >= 0) d.Hf[h.dst] = acc;
+}
+
+__device__ __forceinline__ void wave_hblock_66_off(const DevGraph& d, const SegHdr& h, double* __restrict__ S) {
+  const int lane = threadIdx.x & 63;
+  const int4 mine = h.mine;
+  const int cnt = __builtin_amdgcn_readlane(h.rec, 4), hoff = __builtin_amdgcn_readlane(h.rec, 5);
+  const int lc = lane < 36 ? lane : 35;
+  const int i = lc / 6, j = lc - 6 * (lc / 6);
+  const double* __restrict__ J = d.J;
+  double acc = 0.0;
+  for (int c = 0; c < cnt; c++) {                         // (one, unless two factors join the same pair of poses)
+    const int jv = __builtin_amdgcn_readlane(mine.x, c), ju = __builtin_amdgcn_readlane(mine.y, c);
+    const double xv = J[jv + lc], xu = J[ju + lc];
+    S[lc] = xv; S[36 + lc] = xu;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc = PPS_MAC(acc, S[6 * k + i], S[36 + 6 * k + j]);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane >= 36) return;
+  d.H[hoff + lane] = acc;
+  if (h.dst >= 0) d.Hf[h.dst] = acc;
+}
+
+// four plane diagonals per wave: 16-lane group q works on list entry first + q
+__device__ __forceinline__ void wave_hblock_33x4(const DevGraph& d, int first, double* __restrict__ S) {
+  const int lane = threadIdx.x & 63;
+  const int grp = lane >> 4, gl = lane & 15;
+  const int at = first + grp;
+  int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
+  if (at < d.n_k2t_small) {
+    const int seg = d.k2t[d.n_k2t_big + at];
+    r0 = reinterpret_cast<const int4*>(d.srec)[2 * (size_t)seg]; r1 = reinterpret_cast<const int4*>(d.srec)[2 * (size_t)seg + 1];
+  }
+  const int size = r0.z, c0 = r0.w, cnt = r1.x, hoff = r1.y, doff = r1.z, nsegb = r1.w;
+  const int dst = (gl < size && nsegb == 1) ? d.blk_dst[doff + gl] : -1;
+  int cmax = __builtin_amdgcn_readlane(cnt, 0);
+  { const int c1 = __builtin_amdgcn_readlane(cnt, 16), c2 = __builtin_amdgcn_readlane(cnt, 32), c3 = __builtin_amdgcn_readlane(cnt, 48);
+    cmax = cmax > c1 ? cmax : c1; cmax = cmax > c2 ? cmax : c2; cmax = cmax > c3 ? cmax : c3; }
+  const bool is_g = gl >= 9;
+  const int t = gl - 9 < 2 ? gl - 9 : 2;                   // residual row of the lanes past the slice (lanes 12 .. 15 repeat row 2)
+  const int i = is_g ? t : gl / 3;
+  const int j = is_g ? 0 : gl - 3 * (gl / 3);
+  const int pb0 = is_g ? 9 : j;
+  const int loff = is_g ? t : gl, wpos = is_g ? 9 + 3 * t : gl;    // [slice, k-major 9 | r[k] at 9 + 3 k]
+  const int last = cnt > 0 ? c0 + cnt - 1 : 0;
+  const double* __restrict__ J = d.J;
+  double* __restrict__ Sg = S + grp * 16;
+  double acc = 0.0;
+  for (int k0 = 0; k0 < cmax; k0 += kT33U) {
+    int4 ds[kT33U];
+#pragma unroll
+    for (int u = 0; u < kT33U; u++) ds[u] = reinterpret_cast<const int4*>(d.contrib)[k0 + u < cnt ? c0 + k0 + u : last];
+    double x[kT33U];
+#pragma unroll
+    for (int u = 0; u < kT33U; u++) x[u] = J[(is_g ? ds[u].z : ds[u].x) + loff];
+#pragma unroll
+    for (int u = 0; u < kT33U; u++) Sg[u * 64 + wpos] = x[u];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < kT33U; u++) {
+      if (k0 + u < cnt) {
+        const double* __restrict__ pa = Sg + u * 64 + i;
+        const double* __restrict__ pb = Sg + u * 64 + pb0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc = PPS_MAC(acc, pa[3 * k], pb[3 * k]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (gl >= size) return;
+  if (is_g) acc = -acc;
+  d.H[hoff + gl] = acc;
+  if (dst >= 0) d.Hf[dst] = acc;
+}
+
+__device__ __forceinline__ void body_hblocks_tc(const DevGraph& d, int bx) {
+  __shared__ double tc_lds[4 * kTcWaveDoubles];
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  double* __restrict__ S = tc_lds + wave * kTcWaveDoubles;
+  const int nb_big = (d.n_k2t_big + 15) / 16;
+  if (bx >= nb_big) {
+    const int first = uni(((bx - nb_big) * 4 + wave) * 4);
+    if (first < d.n_k2t_small) wave_hblock_33x4(d, first, S);
+    return;
+  }
+  const int slot0 = uni((bx * 4 + wave) * 4);
+  if (slot0 >= d.n_k2t_big) return;
+  SegHdr h[4];
+  int cls[4];
+  {
+    const int e = slot0 + (lane >> 3) < d.n_k2t_big && (lane >> 3) < 4 ? d.k2t[slot0 + (lane >> 3)] : -1;   // lanes 8q..8q+7: entry q
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int eq = __builtin_amdgcn_readlane(e, 8 * q);
+      cls[q] = eq >= 0 ? eq >> 28 : 0;
+      seg_fetch_record(d, eq >= 0 ? (eq & 0x0fffffff) : -1, lane, h[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) seg_fetch_contrib(d, lane, h[q]);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (cls[q] == 1) wave_hblock_66_diag(d, h[q], S);
+    else if (cls[q] == 2) wave_hblock_66_off(d, h[q], S);
+    else wave_hblock_segment(d, h[q], S);
+  }
+}
+
 // Fold the partial sums of a multi-segment block (the ground plane's diagonal: a hundred segments on C2) into its first slot.
 // The segments are summed as four interleaved partial sums -- p_w = segments w, w + 4, w + 8, ... in order -- combined as
 // (p0 + p1) + (p2 + p3): the same bits in every form.  NW = 4 (one graph): a 256-thread workgroup per block, one partial sum
@@ -401,6 +578,12 @@ __global__ __launch_bounds__(256) void kb_hblocks_t(BatchArgs a) {
   body_hblocks_t<kHblocksT>(d, blockIdx.x);
 }
 
+__global__ __launch_bounds__(256) void kb_hblocks_tc(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  if ((int)blockIdx.x >= (d.n_k2t_big + 15) / 16 + (d.n_k2t_small + 15) / 16) return;
+  body_hblocks_tc(d, blockIdx.x);
+}
+
 __global__ __launch_bounds__(64) void kb_hreduce(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
   if ((int)blockIdx.x >= d.n_mseg) return;
@@ -411,7 +594,9 @@ hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStrea
   if (g.lin_thread_form) {                                      // many graphs: throughput form over the Jacobians + the second pass
     // (the wave-per-segment kernel in its Jacobian-only mode, measured on the same G = 128 batch: 23.9 ms of K2 per batch solve
     // against 13.7 ms -- at this size the LDS-staged form's four segments per wave and prefetched headers win)
-    if (g.hblocks_nd > 0) PPS_LAUNCH(kb_hblocks_t, dim3(g.hblocks_nd, a.n), dim3(256), 0, st, a);
+    static const bool by_class = !getenv("PPS_K2T_GENERIC");          // (A/B: the one-body form)
+    if (by_class) { if (g.k2t_blocks > 0) PPS_LAUNCH(kb_hblocks_tc, dim3(g.k2t_blocks, a.n), dim3(256), 0, st, a); }
+    else if (g.hblocks_nd > 0) PPS_LAUNCH(kb_hblocks_t, dim3(g.hblocks_nd, a.n), dim3(256), 0, st, a);
     if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
     return hipGetLastError();
   }

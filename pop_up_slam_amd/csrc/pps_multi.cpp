@@ -71,6 +71,37 @@ const char* pps_multi_last_error(const pps_multi* m) { return m ? m->err.c_str()
 
 static int multi_optimize(pps_multi* m, int* iterations, int* status);
 
+// The class lists of K2's throughput form (pps_device.h: k2t), once per upload of a graph that enters a large batch.
+static int ensure_k2t_lists(pps_graph* g) {
+  if (g->k2t_version == g->upload_version && g->dev.k2t) return PPS_OK;
+  const Analysis& A = g->an;
+  std::vector<int> big, small;
+  for (int sg : A.nd_segs) {
+    const int* r = &A.srec[8 * (size_t)sg];
+    const int rows = r[0], cols = r[1], size = r[2], c0 = r[3], cnt = r[4];
+    int cls = 0;
+    bool three = true, three_six = true, six = true, same = true;
+    for (int k = c0; k < c0 + cnt; k++) {
+      const int* c = &A.contrib[4 * (size_t)k];
+      const bool prod = c[3] >= kProductFlag;
+      const int mm = prod ? c[3] - kProductFlag : c[3];
+      three = three && mm == 3; six = six && mm == 6; three_six = three_six && (mm == 3 || mm == 6);
+      same = same && (prod || c[0] == c[1]);                    // row slice = column slice (a diagonal block)
+    }
+    if (cnt >= 1 && cnt <= 64 && rows == 3 && cols == 3 && size == 12 && three && same) { small.push_back(sg); continue; }
+    if (cnt >= 1 && cnt <= 64 && rows == 6 && cols == 6 && size == 42 && three_six && same) cls = 1;
+    else if (cnt >= 1 && cnt <= 64 && rows == 6 && cols == 6 && size == 36 && six) cls = 2;
+    big.push_back(sg | (cls << 28));
+  }
+  g->dev.n_k2t_big = (int)big.size(); g->dev.n_k2t_small = (int)small.size();
+  big.insert(big.end(), small.begin(), small.end());
+  if (big.empty()) big.push_back(0);
+  int rc = dev_alloc(g, &g->dev.k2t, big.size()); if (rc != PPS_OK) return rc;
+  if (hipMemcpy(g->dev.k2t, big.data(), sizeof(int) * big.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(g, PPS_EHIP, "upload of the K2 class lists failed");
+  g->k2t_version = g->upload_version;
+  return PPS_OK;
+}
+
 int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
   if (!m) return PPS_EINVAL;
   const int rc = multi_optimize(m, iterations, status);
@@ -98,6 +129,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     if (g->n_live_factors == 0) return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + " has no factors");
     if (g->props.jacobian_mode != mode) return mfail(m, PPS_EINVAL, "all graphs of a batch share one jacobian_mode");
     if (g->an.n_stages > 32) return mfail(m, PPS_ESTATE, "graph " + std::to_string(i) + ": elimination tree too deep for the batched schedule");
+    rc = ensure_k2t_lists(g);
+    if (rc != PPS_OK) return mfail(m, rc, "graph " + std::to_string(i) + ": " + g->err);
     MHIP(m, hipStreamSynchronize(g->stream));
     g->status_clean = false;
     max_stages = std::max(max_stages, g->an.n_stages);
@@ -156,6 +189,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.repop_blocks = std::max(q.repop_blocks, (d.n_obs - d.n_obs_fixed + 63) / 64);
       q.hblocks = std::max(q.hblocks, (d.n_nd_segs + 3) / 4);                     // (the segments K1 does not write itself)
       q.hblocks_nd = std::max(q.hblocks_nd, (d.n_nd_segs + 15) / 16);
+      q.k2t_blocks = std::max(q.k2t_blocks, (d.n_k2t_big + 15) / 16 + (d.n_k2t_small + 15) / 16);
       q.hreduce = std::max(q.hreduce, d.n_mseg);
       q.k2_blocks = std::max(q.k2_blocks, (d.n_k2_single + 15) / 16 + d.n_k2_multi);
       q.k2_finish = std::max(q.k2_finish, d.n_k2_finish);
@@ -248,6 +282,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
   }
   // ---- dual-lambda form: every graph walks lm_solve_dual's scheme, in lockstep rounds of one linearisation each ----
+  const double t_setup = now_s() - t0;
+  double t_wait = 0, t_launch = 0;
   {
     std::vector<BatchAlt> ha(G);
     for (int i = 0; i < G; i++) {
@@ -274,7 +310,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       }
       return a;
     };
-    auto wait_round = [&]() -> int {
+    auto wait_round_ = [&]() -> int {
       const double tw = now_s();
       unsigned spins = 0;
       for (int i = 0; i < G; i++) {
@@ -293,6 +329,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       return PPS_OK;
     };
+    auto wait_round = [&]() -> int { const double tw = now_s(); const int rc = wait_round_(); t_wait += now_s() - tw; return rc; };
     m->ev_used = 0; m->n_relin = 0; m->n_solves = 0;
     for (double& t : m->t_phase) t = 0;
     auto mark = [&]() {
@@ -408,6 +445,10 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
     int first_bad = PPS_OK;
     m->t_total = now_s() - t0;
+    if (getenv("PPS_MULTI_TIMING"))
+      fprintf(stderr, "pps_multi: G %d total %.3f ms = setup %.3f + waiting for results %.3f + host between (launches, LM bookkeeping) %.3f; %d rounds\n", G,
+              1e3 * m->t_total, 1e3 * t_setup, 1e3 * t_wait, 1e3 * (m->t_total - t_setup - t_wait), m->rounds);
+    (void)t_launch;
     for (int i = 0; i < G; i++) {
       pps_graph* g = m->gs[i];
       const LMD& q = lm[i];

@@ -61,17 +61,19 @@ def multi(G, reps, mode=P.JAC_NUMERIC):
     its, st = mm.optimize()
     chis = [gk.chi2() for gk in gs[:8]]
     h = hashlib.sha1(np.asarray(chis).tobytes() + np.asarray(its[:8], dtype=np.int64).tobytes()).hexdigest()[:12]
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); t_restore = 0.0
     for _ in range(reps):
+        tr = time.perf_counter()
         for gk in gs:
             gk.restore_state()
+        t_restore += time.perf_counter() - tr
         mm.optimize()
     el = time.perf_counter() - t0
     mm.set_profiling(1)
     for gk in gs:
         gk.restore_state()
     mm.optimize(); ph = mm.phase_times(); mm.set_profiling(0)
-    out = {"graphs": G, "graphs_per_s": G * reps / el, "ms_per_batch": 1e3 * el / reps, "rounds": mm.rounds(), "hash8": h,
+    out = {"graphs": G, "graphs_per_s": G * reps / el, "ms_per_batch": 1e3 * el / reps, "rounds": mm.rounds(), "hash8": h, "restore_ms": 1e3 * t_restore / reps,
            "phase_ms": {k: 1e3 * ph[k] for k in ("linearize", "assemble", "factor", "backsolve", "trial")}}
     mm.close()
     for gk in gs:
