@@ -152,15 +152,13 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         torch.cuda.synchronize()
         t1 = time.perf_counter(); iters = 0
         for _ in range(reps):
-            for gk in gs:
-                gk.restore_state()
+            mm.restore_state()
             its, st = mm.optimize()
             iters += int(its.sum())
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
         mm.set_profiling(1)
-        for gk in gs:
-            gk.restore_state()
+        mm.restore_state()
         mm.optimize()
         ph = mm.phase_times(); mm.set_profiling(0)
         ent = {"graphs": G, "graphs_per_sec": G * reps / el, "value": iters / el, "unit": "LM iters/s", "rounds": mm.rounds(),

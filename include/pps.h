@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define PPS_VERSION 301   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301) */
+#define PPS_VERSION 302   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301;
+                              pps_multi_save_state / pps_multi_restore_state: 302) */
 
 typedef struct pps_graph pps_graph;
 
@@ -136,6 +137,10 @@ int pps_multi_destroy(pps_multi* m);
 const char* pps_multi_last_error(const pps_multi* m);
 int pps_multi_optimize(pps_multi* m, int* iterations, int* status);
 int pps_multi_rounds(const pps_multi* m, int* rounds);    /* lockstep rounds of the last call = the longest LM run + 1 */
+/* pps_save_state / pps_restore_state of every graph of the batch; the restore is ONE launch and complete on return (a benchmark
+ * that solves the same graphs again from their initial estimates pays 30 us for it instead of a copy per handle) */
+int pps_multi_save_state(pps_multi* m);
+int pps_multi_restore_state(pps_multi* m);
 /* level 1: HIP events at the phase boundaries of every round (no host syncs); after the next pps_multi_optimize
  * sec[5] = device seconds in K1 (Jacobian sweep) | K2 (H blocks) | K3 factor | K3 back-substitution | trial step + chi2,
  * counts[2] = graphs re-linearised | factorised, summed over the rounds (counts may be NULL) */

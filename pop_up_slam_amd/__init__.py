@@ -25,7 +25,7 @@ _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 
 
-PPS_VERSION = 301      # include/pps.h: the struct layouts mirrored below
+PPS_VERSION = 302      # include/pps.h: the struct layouts mirrored below
 
 
 class PpsProps(C.Structure):
@@ -108,7 +108,7 @@ SYMBOLS = [
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
     "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
-    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_set_profiling", "pps_multi_phase_times", "pps_popup_polygons_simple", "pps_analysis_reuse", "pps_analysis_kept",
+    "pps_multi_create", "pps_multi_destroy", "pps_multi_last_error", "pps_multi_optimize", "pps_multi_rounds", "pps_multi_save_state", "pps_multi_restore_state", "pps_multi_set_profiling", "pps_multi_phase_times", "pps_popup_polygons_simple", "pps_analysis_reuse", "pps_analysis_kept",
 ]
 
 
@@ -184,6 +184,7 @@ def lib():
         L.pps_multi_last_error.restype = C.c_char_p
         L.pps_multi_optimize.argtypes = [C.c_void_p, _ip, _ip]
         L.pps_multi_rounds.argtypes = [C.c_void_p, _ip]
+        L.pps_multi_save_state.argtypes = [C.c_void_p]; L.pps_multi_restore_state.argtypes = [C.c_void_p]
         L.pps_multi_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pps_multi_phase_times.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_longlong)]
         L.pps_popup_fill_depth.argtypes = [C.c_void_p]
@@ -661,6 +662,17 @@ class Multi:
 
     def rounds(self):
         r = C.c_int(); self.L.pps_multi_rounds(self.h, C.byref(r)); return r.value
+
+    def save_state(self):
+        rc = self.L.pps_multi_save_state(self.h)
+        if rc != 0:
+            raise PpsError(rc, (self.L.pps_multi_last_error(self.h) or b"").decode())
+
+    def restore_state(self):
+        """every graph back to its snapshot, one launch"""
+        rc = self.L.pps_multi_restore_state(self.h)
+        if rc != 0:
+            raise PpsError(rc, (self.L.pps_multi_last_error(self.h) or b"").decode())
 
     def set_profiling(self, level=1):
         self.L.pps_multi_set_profiling(self.h, level)

@@ -250,6 +250,8 @@ hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mo
 hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStream_t st, bool products);   // K2 of the BF_RELIN graphs (products: their K1 ran in the lane form)
 hipError_t launch_batch_chi2(const BatchArgs& a, const BatchGeom& g, int slot, hipStream_t st);        // chi2 at lin -> results[8 b + 4 slot]
 hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_t st, hipEvent_t after_factor = nullptr);   // K3, lambda per graph
+struct RestoreRec { double* dst; const double* src; long long n; };
+hipError_t launch_batch_restore(const RestoreRec* tab, int n, hipStream_t st);                 // dst[0 .. n) <- src[0 .. n) per record
 hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // not-PD flags of both factorisations cleared
 hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // state[..] <- x (+) delta_z, chi2 -> slots 1 / 2
 

@@ -393,6 +393,17 @@ __global__ __launch_bounds__(kChiBlock) void kb_chi2_dual(BatchArgs a) {
                          a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
 }
 
+// pps_multi_restore_state: the snapshots of n graphs back into their estimates, one launch (tab: n records in pinned host memory)
+__global__ __launch_bounds__(256) void kb_restore(const RestoreRec* __restrict__ tab) {
+  const RestoreRec r = tab[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < r.n; i += 256LL * gridDim.x) r.dst[i] = r.src[i];
+}
+
+hipError_t launch_batch_restore(const RestoreRec* tab, int n, hipStream_t st) {
+  PPS_LAUNCH(kb_restore, dim3(8, n), dim3(256), 0, st, tab);
+  return hipGetLastError();
+}
+
 hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
   (void)g;
   PPS_LAUNCH(kb_begin_dual, dim3(1, a.n), dim3(64), 0, st, a);

@@ -133,6 +133,35 @@ def test_throughput_forms_are_bit_identical(built, monkeypatch, mode):
     assert o.batch_optimize() == ref[2][0] and abs(o.chi2() - ref[2][2]) <= 1e-7 * ref[2][2]
 
 
+def test_batch_snapshot_and_restore(built):
+    """pps_multi_save_state / pps_multi_restore_state: every graph back at its snapshot in one launch -- the second solve repeats
+    the first one bit for bit, the per-handle restore sees the same snapshot, and a graph without a snapshot is refused"""
+    specs = [synth.small_world(20, 6, seed=2), synth.corridor(120, 26, seed=5), synth.small_world(50, 10, seed=3), synth.corridor(60, 14, seed=7)]
+    batch, nids = _build(specs)
+    m = P.Multi(batch)
+    with pytest.raises(P.PpsError):
+        m.restore_state()                                   # nothing saved yet
+    m.save_state()
+    x0 = [_state(g, sp, nid) for g, sp, nid in zip(batch, specs, nids)]
+    its, _ = m.optimize()
+    first = [(int(its[k]), g.trace(), g.chi2()) for k, g in enumerate(batch)]
+    x1 = [_state(g, sp, nid) for g, sp, nid in zip(batch, specs, nids)]
+    m.restore_state()
+    for k, (g, sp, nid) in enumerate(zip(batch, specs, nids)):
+        a, b = _state(g, sp, nid)
+        assert np.array_equal(a, x0[k][0]) and np.array_equal(b, x0[k][1]), k
+    its, _ = m.optimize()
+    assert [(int(its[k]), g.trace(), g.chi2()) for k, g in enumerate(batch)] == first
+    for k, (g, sp, nid) in enumerate(zip(batch, specs, nids)):
+        a, b = _state(g, sp, nid)
+        assert np.array_equal(a, x1[k][0]) and np.array_equal(b, x1[k][1]), k
+    batch[1].restore_state()                                # the per-handle call restores the same snapshot
+    a, b = _state(batch[1], specs[1], nids[1])
+    assert np.array_equal(a, x0[1][0]) and np.array_equal(b, x0[1][1])
+    assert batch[1].batch_optimize() == first[1][0] and batch[1].chi2() == first[1][2]
+    m.close()
+
+
 @pytest.mark.gpu
 def test_two_bench_ranks_on_one_gpu(built):
     """The N > 1 path of bench.py on hardware without a second GPU: two ranks under torch.distributed.run, both on device 0

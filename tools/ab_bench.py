@@ -64,14 +64,12 @@ def multi(G, reps, mode=P.JAC_NUMERIC):
     t0 = time.perf_counter(); t_restore = 0.0
     for _ in range(reps):
         tr = time.perf_counter()
-        for gk in gs:
-            gk.restore_state()
+        mm.restore_state()
         t_restore += time.perf_counter() - tr
         mm.optimize()
     el = time.perf_counter() - t0
     mm.set_profiling(1)
-    for gk in gs:
-        gk.restore_state()
+    mm.restore_state()
     mm.optimize(); ph = mm.phase_times(); mm.set_profiling(0)
     out = {"graphs": G, "graphs_per_s": G * reps / el, "ms_per_batch": 1e3 * el / reps, "rounds": mm.rounds(), "hash8": h, "restore_ms": 1e3 * t_restore / reps,
            "phase_ms": {k: 1e3 * ph[k] for k in ("linearize", "assemble", "factor", "backsolve", "trial")}}
