@@ -1296,6 +1296,74 @@ PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, PPS_LVL3_WAVES)
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor4, 4, 2)
 #undef PPS_LEVEL_FACTOR_KERNEL
 
+// The back-substitution of one front in the level-per-launch form (large batches: throughput, every launch issue-bound).  The same sums in
+// the same order as wave_front_solve<false> -- same bits -- without what a front on a latency path pays to hide its round trips: the
+// panel is copied in as many batches as it has (a leaf of 46 x 18: 13, a separator of 40 x 6: 4 -- not 16), through ONE address register
+// per side (the batches are immediate offsets; the last one reads up to 63 doubles past the panel -- readable: L is followed by U in the
+// arena -- and writes them into the wave's own LDS slack); the pivots >= 16 of a leaf are a loop over the pivots it has instead of a
+// sixteen-way unrolled chunk; no second index register (b <= 64).  Fronts outside p <= 32, b <= 64, panel <= 1024 entries take the
+// general body.  G = 128: 10.9 -> ... ms of back-substitution per batch solve.
+#ifndef PPS_LEVEL_SOLVE_LEAN
+#define PPS_LEVEL_SOLVE_LEAN 1
+#endif
+constexpr bool kLevelSolveLean = PPS_LEVEL_SOLVE_LEAN != 0;
+constexpr int kLevelSolveSlack = 64;       // doubles of LDS behind a wave's panel area (the last copy batch may overrun the panel)
+template <int SH>                          // 1 << SH lanes per column of L_B: 16 (p <= 16) or 32 (p <= 32)
+__device__ __forceinline__ void wave_front_solve_level(const DevGraph& d, int rec, double* __restrict__ Wk) {
+#ifndef PPS_NO_FMA
+#pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here (as in wave_front_solve)
+#endif
+  const int lane = threadIdx.x & 63;
+  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2), f = p + b;
+  const double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
+  const int* __restrict__ ix = b == 0 ? d.frec : d.bidx + __builtin_amdgcn_readlane(rec, 8);
+  double* __restrict__ xb = Wk;
+  double* __restrict__ PL = Wk + kBandMaxRows;
+  const int ix0 = ix[lane < b ? lane : 0];
+  const int pix = d.pidx[__builtin_amdgcn_readlane(rec, 7) + (lane < p ? lane : 0)];
+  const int n = (f + 1) * p;
+  const double* __restrict__ src = Lp + lane;
+  double* __restrict__ dst = PL + lane;
+  double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) if (64 * u < n) v[u] = src[64 * u];
+  const double g0 = d.delta[lane < b ? ix0 : 0];
+#pragma unroll
+  for (int u = 0; u < 16; u++) if (64 * u < n) dst[64 * u] = v[u];
+  xb[lane] = lane < b ? g0 : 0.0;                        // (zero beyond b: rows past the boundary add l * 0 below)
+  xb[lane + 64] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  const int lc = lane < p ? lane : 0;
+  const double dinv = 1.0 / PL[lc * p + lc];
+  // y - L_B^T x_b: column j by 64 >> SH lanes, rows part (mod np), four partial sums per lane (rows part + np (4 t + m) in a_m)
+  constexpr int np = 64 >> SH;
+  const int j = lane & ((1 << SH) - 1), part = lane >> SH;
+  const int jc = j < p ? j : 0;
+  double a0 = part == 0 ? PL[f * p + jc] : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const double* __restrict__ lb = PL + p * p + jc;
+  const double* __restrict__ xr = xb + part;
+  const int blast = b > 0 ? b - 1 : 0;
+  for (int i0 = 0; i0 < b; i0 += 4 * np) {               // (wave-uniform trip count)
+    const int i = i0 + part, i1 = i + np, i2 = i + 2 * np, i3 = i + 3 * np;
+    const double l0 = lb[(i < blast ? i : blast) * p], l1 = lb[(i1 < blast ? i1 : blast) * p], l2 = lb[(i2 < blast ? i2 : blast) * p], l3 = lb[(i3 < blast ? i3 : blast) * p];
+    const double x0 = xr[i0], x1 = xr[i0 + np], x2 = xr[i0 + 2 * np], x3 = xr[i0 + 3 * np];
+    a0 -= l0 * x0; a1 -= l1 * x1; a2 -= l2 * x2; a3 -= l3 * x3;
+  }
+  double tj = (a0 + a1) + (a2 + a3);
+  tj += __shfl_xor(tj, 32);
+  if (SH == 4) tj += __shfl_xor(tj, 16);
+  tj = lane < p ? tj : 0.0;
+  for (int k = p - 1; k >= 16; k--) {                    // (leaves only)
+    const double l = PL[k * p + lc];
+    tj -= ((lane < k ? l : 0.0) * readlane_d(dinv, k)) * readlane_d(tj, k);
+  }
+  double lk[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) { const double l = PL[(u < p ? u : p - 1) * p + lc]; lk[u] = lane < u ? l : 0.0; }
+  solve_pivot_chain(p, lk, dinv, tj);
+  if (lane < p) d.delta[pix] = tj;
+}
+
 __global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, int lds_doubles_per_wave) {
   extern __shared__ double lds[];
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
@@ -1305,14 +1373,17 @@ __global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, in
   if (k >= d.cls_off[3 * level + 3]) return;
   const int rec = d.frec[(size_t)d.cls_fronts[k] * 16 + (threadIdx.x & 15)];
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
+  DevGraph d2 = d;
   if (blockIdx.z) {
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
-    DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
-    wave_front_solve<false>(d2, rec, W, nullptr, 0);
+  }
+  const int fp = __builtin_amdgcn_readlane(rec, 1), fb = __builtin_amdgcn_readlane(rec, 2);
+  if (kLevelSolveLean && fp <= 32 && fb <= 64 && (fp + fb + 1) * fp <= 1024) {
+    if (fp <= 16) wave_front_solve_level<4>(d2, rec, W); else wave_front_solve_level<5>(d2, rec, W);
     return;
   }
-  wave_front_solve<false>(d, rec, W, nullptr, 0);
+  wave_front_solve<false>(d2, rec, W, nullptr, 0);
 }
 
 static int level_lds_doubles(int nt) { return (int)(band_lds_bytes(16 * nt, true) / sizeof(double)); }   // fronts of <= 16 nt rows (+ rhs)
@@ -1344,7 +1415,7 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     }
     if (after_factor) (void)hipEventRecord(after_factor, st);
     for (int l = g.n_levels - 1; l >= 0; l--)
-      if (g.lvl_blocks[l] > 0) PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)g.solve_per_wave_all * 4 * sizeof(double), st, a, l, g.solve_per_wave_all);
+      if (g.lvl_blocks[l] > 0) PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)(g.solve_per_wave_all + kLevelSolveSlack) * 4 * sizeof(double), st, a, l, g.solve_per_wave_all + kLevelSolveSlack);
     return hipGetLastError();
   }
   for (int stg = 0; stg < g.n_stages; stg++) {
