@@ -18,7 +18,8 @@ struct pps_multi {
   int device = 0;
   std::string err;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // chunks alternate between the two streams: one chunk's narrow tree levels run under the other's wide ones
+  hipStream_t stream3 = nullptr, stream4 = nullptr;
+  hipStream_t stream2 = nullptr;   // chunk c runs on stream c mod (number of chunks a batch is split into): one chunk's narrow tree levels run under the others' wide ones
   DevGraph* d_gs = nullptr; size_t cap_gs = 0;
   BatchStage* d_stage = nullptr; size_t cap_stage = 0;
   BatchAlt* d_alt = nullptr; size_t cap_alt = 0;          // dual-lambda form: second factorisation + the three state copies per graph
@@ -54,6 +55,8 @@ int pps_multi_create(int n, pps_graph* const* graphs, pps_multi** out) {
 int pps_multi_destroy(pps_multi* m) {
   if (!m) return PPS_EINVAL;
   if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); m->stream2 = nullptr; }
+  if (m->stream3) { (void)hipStreamSynchronize(m->stream3); (void)hipStreamDestroy(m->stream3); m->stream3 = nullptr; }
+  if (m->stream4) { (void)hipStreamSynchronize(m->stream4); (void)hipStreamDestroy(m->stream4); m->stream4 = nullptr; }
   if (m->stream) {
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
@@ -188,6 +191,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   const bool dual = true;
   if (!m->stream) MHIP(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   if (!m->stream2) MHIP(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+  if (!m->stream3) MHIP(m, hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
+  if (!m->stream4) MHIP(m, hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
   if (m->cap_results < (size_t)G) {
     if (m->results) (void)hipHostFree(m->results);
     m->results = nullptr; m->cap_results = 0;
@@ -211,11 +216,16 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   // ---- launch geometry per chunk of kBatchMax graphs ----
   int n_cu = 256;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
-  // More than 64 graphs are split into (at least) two chunks of equal size, launched on two streams: the launches of a chunk's upper
-  // tree levels hold a few hundred wavefronts each and leave most of the device to the other chunk's kernels.  (Event-timed
-  // profiling keeps one stream and whole chunks: the phases must not overlap.)
-  const bool two_streams = G > 64 && !m->profiling;
-  const int CH = two_streams ? std::min(kBatchMax, (G + 1) / 2) : kBatchMax;
+  // Large batches are split into two or three chunks of equal size that advance on their own streams: the launches of a chunk's upper tree
+  // levels hold a few hundred wavefronts each and leave most of the device to the other chunks' kernels.  A chunk keeps at least 250 000
+  // factors -- below 200 000 its kernels would be the latency forms (G = 96 as 3 x 32: 57.4 ms per batch solve against 48.5 as 2 x 48;
+  // G = 64 as 2 x 32: 39.7 against 37.5 in one chunk; G = 128 as 3 x 43: 60.4 against 61.6 as 2 x 64).  (Event-timed profiling
+  // keeps one stream and whole chunks: the phases must not overlap.)
+  long long total_factors = 0;
+  for (int i = 0; i < G; i++) total_factors += m->gs[i]->n_live_factors;
+  const int n_split = getenv("PPS_MULTI_CHUNKS") ? std::min(4, std::max(1, atoi(getenv("PPS_MULTI_CHUNKS")))) : (int)std::min<long long>(3, std::max<long long>(1, total_factors / 250000));      // (A/B)
+  const bool two_streams = n_split > 1 && !m->profiling;
+  const int CH = two_streams ? std::min(kBatchMax, (G + n_split - 1) / n_split) : kBatchMax;
   const int n_chunks = (G + CH - 1) / CH;
   std::vector<BatchGeom> geom(n_chunks), geom_tail(n_chunks);
   std::vector<int> tail_graphs(n_chunks, 0);                    // a chunk with at most this many active graphs runs the round on geom_tail
@@ -344,7 +354,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   // ---- dual-lambda form: every graph walks lm_solve_dual's scheme, in lockstep rounds of one linearisation each ----
   const double t_setup = now_s() - t0;
   const bool timing_rounds = getenv("PPS_MULTI_TIMING") && atoi(getenv("PPS_MULTI_TIMING")) > 1;
-  double t_wait = 0, t_launch = 0;
+
   {
     std::vector<BatchAlt> ha(G);
     for (int i = 0; i < G; i++) {
@@ -357,10 +367,10 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     struct LMD { double lambda, error, dnorm; int num_iter, cur, xsel; bool done, have_next, relin, active, last_notpd, trial_taken; int n_notpd; };
     std::vector<LMD> lm(G);
     for (int i = 0; i < G; i++) lm[i] = LMD{m->gs[i]->props.lm_lambda0, 0.0, 0.0, 0, 0, 0, false, true, true, true, false, false, 0};
-    auto make_args = [&](int c) {
+    auto make_args = [&](int c, double seq) {
       BatchArgs a{};
       a.gs = m->d_gs; a.stage_tab = m->d_stage; a.results = m->results; a.n_total = G; a.b0 = c * CH;
-      a.n = std::min(G, (c + 1) * CH) - a.b0; a.seq = m->seq;
+      a.n = std::min(G, (c + 1) * CH) - a.b0; a.seq = seq;
       a.alt = m->d_alt; a.rstride = 12;
       a.no_products = geom[c].lin_thread_form ? 1 : 0;
       for (int k = 0; k < a.n; k++) {
@@ -371,26 +381,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       }
       return a;
     };
-    auto wait_round_ = [&]() -> int {
-      const double tw = now_s();
-      unsigned spins = 0;
-      for (int i = 0; i < G; i++) {
-        if (!lm[i].active) continue;
-        for (int slot = 1; slot <= 2; slot++) {
-          volatile double* r = m->results + 12 * (size_t)i + 4 * slot;
-          while (r[3] != m->seq) {
-            if ((++spins & 0x3ff) == 0 && now_s() - tw > 2.0) {
-              MHIP(m, hipStreamSynchronize(m->stream));
-              MHIP(m, hipStreamSynchronize(m->stream2));
-              if (r[3] != m->seq) return mfail(m, PPS_EHIP, "result record of graph " + std::to_string(i) + " did not arrive");
-            }
-          }
-        }
-      }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      return PPS_OK;
-    };
-    auto wait_round = [&]() -> int { const double tw = now_s(); const int rc = wait_round_(); t_wait += now_s() - tw; return rc; };
     m->ev_used = 0; m->n_relin = 0; m->n_solves = 0;
     for (double& t : m->t_phase) t = 0;
     auto mark = [&]() {
@@ -457,49 +447,82 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         return;
       }
     };
-    m->seq += 1.0; m->rounds = 0;
+    // The chunks advance on their own: a chunk's next round is launched as soon as ITS graphs have delivered their records, while the
+    // other chunk's kernels keep the device busy -- no barrier over the whole batch between rounds (the device would idle for the
+    // host's bookkeeping 42 times per solve), and the chunks drift apart, so that one's narrow tree levels meet the other's wide ones.
+    struct ChunkRun { double seq = 0.0; bool in_flight = false, first = true; int rounds = 0; };
+    std::vector<ChunkRun> cr(n_chunks);
+    hipStream_t const streams[4] = {m->stream, m->stream2, m->stream3, m->stream4};
+    auto stream_of = [&](int c) { return n_chunks > 1 && !m->profiling ? streams[c % n_split] : m->stream; };
+    auto chunk_done = [&](int c) -> bool {                     // (non-blocking) both records of every active graph of the chunk are this round's
+      for (int i = c * CH; i < std::min(G, (c + 1) * CH); i++) {
+        if (!lm[i].active) continue;
+        const volatile double* r = m->results + 12 * (size_t)i;
+        if (r[4 + 3] != cr[c].seq || r[8 + 3] != cr[c].seq) return false;
+      }
+      return true;
+    };
+    m->rounds = 0;
     for (int c = 0; c < n_chunks; c++) {
-      const BatchArgs a = make_args(c);
-      int rc = run_round(a, geom[c], true, true, (c & 1) && n_chunks > 1 && !m->profiling ? m->stream2 : m->stream); if (rc != PPS_OK) return rc;
+      m->seq += 1.0; cr[c].seq = m->seq; cr[c].in_flight = true;
+      const BatchArgs a = make_args(c, cr[c].seq);
+      int rc = run_round(a, geom[c], true, true, stream_of(c)); if (rc != PPS_OK) return rc;
     }
     m->n_relin += G; m->n_solves += 2 * (long long)G;
-    { int rc = wait_round(); if (rc != PPS_OK) return rc; }
-    m->rounds++;
-    for (int i = 0; i < G; i++) {
-      pps_graph* g = m->gs[i];
-      const double* r0 = m->results + 12 * (size_t)i;
-      lm[i].error = r0[0]; g->stats.chi2_initial = r0[0];
-      lm[i].dnorm = std::sqrt(r0[5]); lm[i].last_notpd = r0[6] != 0.0; lm[i].n_notpd = lm[i].last_notpd ? 1 : 0;
-      g->stats.n_linearize = 1; g->stats.n_factorize = 2;
-    }
-    for (;;) {
-      int n_active = 0;
-      for (int i = 0; i < G; i++) { if (!lm[i].done) advance(i); else { lm[i].active = false; lm[i].relin = false; } n_active += lm[i].active ? 1 : 0; }
-      if (n_active == 0) break;
-      const double t_round = now_s();
-      m->seq += 1.0;
+    int n_flight = n_chunks;
+    double t_progress = now_s();
+    static const bool lockstep = getenv("PPS_MULTI_LOCKSTEP") != nullptr;     // (A/B: a barrier over all chunks between rounds, as up to round 4)
+    while (n_flight > 0) {
+      bool progressed = false;
+      if (lockstep) { bool all = true; for (int c = 0; c < n_chunks; c++) all = all && (!cr[c].in_flight || chunk_done(c)); if (!all) continue; }
       for (int c = 0; c < n_chunks; c++) {
-        const BatchArgs a = make_args(c);
-        bool any = false, any_relin = false;
-        for (int k = 0; k < a.n; k++) { any = any || (a.flags[k] & BF_ACTIVE); any_relin = any_relin || (a.flags[k] & BF_RELIN); }
-        if (!any) continue;
-        int act = 0;
-        for (int k = 0; k < a.n; k++) { act += (a.flags[k] & BF_ACTIVE) ? 1 : 0; m->n_solves += (a.flags[k] & BF_ACTIVE) ? 2 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
-        int rc = run_round(a, act <= tail_graphs[c] ? geom_tail[c] : geom[c], false, any_relin, (c & 1) && n_chunks > 1 && !m->profiling ? m->stream2 : m->stream); if (rc != PPS_OK) return rc;
+        if (!cr[c].in_flight || !chunk_done(c)) continue;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        progressed = true;
+        cr[c].rounds++;
+        const int i0 = c * CH, i1 = std::min(G, (c + 1) * CH);
+        int n_active = 0;
+        for (int i = i0; i < i1; i++) {
+          pps_graph* g = m->gs[i];
+          if (cr[c].first) {
+            const double* r0 = m->results + 12 * (size_t)i;
+            lm[i].error = r0[0]; g->stats.chi2_initial = r0[0];
+            lm[i].dnorm = std::sqrt(r0[5]); lm[i].last_notpd = r0[6] != 0.0; lm[i].n_notpd = lm[i].last_notpd ? 1 : 0;
+            g->stats.n_linearize = 1; g->stats.n_factorize = 2;
+          } else if (lm[i].active) {
+            const double* r1 = m->results + 12 * (size_t)i + 4;
+            lm[i].dnorm = std::sqrt(r1[1]);
+            lm[i].last_notpd = r1[2] != 0.0;
+            lm[i].n_notpd += lm[i].last_notpd ? 1 : 0;
+          }
+          if (!lm[i].done) advance(i); else { lm[i].active = false; lm[i].relin = false; }
+          n_active += lm[i].active ? 1 : 0;
+        }
+        if (timing_rounds) fprintf(stderr, "  chunk %d round %d at %.3f ms: %d active next\n", c, cr[c].rounds, 1e3 * (now_s() - t0), n_active);
+        cr[c].first = false;
+        if (n_active == 0) { cr[c].in_flight = false; n_flight--; continue; }
+        m->seq += 1.0; cr[c].seq = m->seq;
+        const BatchArgs a = make_args(c, cr[c].seq);
+        bool any_relin = false;
+        for (int k = 0; k < a.n; k++) { any_relin = any_relin || (a.flags[k] & BF_RELIN); m->n_solves += (a.flags[k] & BF_ACTIVE) ? 2 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
+        int rc = run_round(a, n_active <= tail_graphs[c] ? geom_tail[c] : geom[c], false, any_relin, stream_of(c)); if (rc != PPS_OK) return rc;
       }
-      { int rc = wait_round(); if (rc != PPS_OK) return rc; }
-      m->rounds++;
-      if (timing_rounds) fprintf(stderr, "  round %d: %d active, %.3f ms\n", m->rounds, n_active, 1e3 * (now_s() - t_round));
-      for (int i = 0; i < G; i++) {
-        if (!lm[i].active) continue;
-        const double* r1 = m->results + 12 * (size_t)i + 4;
-        lm[i].dnorm = std::sqrt(r1[1]);
-        lm[i].last_notpd = r1[2] != 0.0;
-        lm[i].n_notpd += lm[i].last_notpd ? 1 : 0;
+      if (progressed) { t_progress = now_s(); continue; }
+      if (now_s() - t_progress > 2.0) {                        // (nothing for two seconds: let the streams drain, look once more)
+        MHIP(m, hipStreamSynchronize(m->stream));
+        MHIP(m, hipStreamSynchronize(m->stream2));
+        MHIP(m, hipStreamSynchronize(m->stream3));
+        MHIP(m, hipStreamSynchronize(m->stream4));
+        bool any_done = false;
+        for (int c = 0; c < n_chunks; c++) any_done = any_done || (cr[c].in_flight && chunk_done(c));
+        if (!any_done) return mfail(m, PPS_EHIP, "result records of a round did not arrive");
       }
     }
+    for (int c = 0; c < n_chunks; c++) m->rounds = std::max(m->rounds, cr[c].rounds);
     MHIP(m, hipStreamSynchronize(m->stream));
     MHIP(m, hipStreamSynchronize(m->stream2));
+    MHIP(m, hipStreamSynchronize(m->stream3));
+    MHIP(m, hipStreamSynchronize(m->stream4));
     for (size_t k = 0; k + 6 <= m->ev_used; k += 6) {
       const hipEvent_t* e = &m->evs[k];
       for (int ph = 0; ph < 5; ph++) {
@@ -510,9 +533,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     int first_bad = PPS_OK;
     m->t_total = now_s() - t0;
     if (getenv("PPS_MULTI_TIMING"))
-      fprintf(stderr, "pps_multi: G %d total %.3f ms = setup %.3f (per-graph checks + stream syncs %.3f, tables %.3f, geometry %.3f) + waiting for results %.3f + host between (launches, LM bookkeeping) %.3f; %d rounds\n", G,
-              1e3 * m->t_total, 1e3 * t_setup, 1e3 * t_s1, 1e3 * (t_s2 - t_s1), 1e3 * (t_setup - t_s2), 1e3 * t_wait, 1e3 * (m->t_total - t_setup - t_wait), m->rounds);
-    (void)t_launch;
+      fprintf(stderr, "pps_multi: G %d total %.3f ms, of which setup %.3f (per-graph checks %.3f, tables %.3f, geometry %.3f); %d rounds\n", G,
+              1e3 * m->t_total, 1e3 * t_setup, 1e3 * t_s1, 1e3 * (t_s2 - t_s1), 1e3 * (t_setup - t_s2), m->rounds);
     for (int i = 0; i < G; i++) {
       pps_graph* g = m->gs[i];
       const LMD& q = lm[i];
