@@ -243,6 +243,7 @@ struct BatchGeom {
   int n_levels = 0;
   int lvl_cls_blocks[64][3] = {{0}};    // workgroups (4 fronts each) per level and class: maximum over the chunk's graphs
   int lvl_blocks[64] = {0};             // ... per level, all classes (back-substitution)
+  int lvl_max_panel[64] = {0};          // largest factor panel ((p + b + 1) p doubles) of a level: the LDS a wave of its back-substitution needs
   int solve_per_wave_all = 0;           // LDS doubles per wave of the level solve (largest panel of the chunk)
   int stage_max_front[32] = {0};    // largest front (scalars, without the rhs row) of the stage over the chunk's graphs
 };

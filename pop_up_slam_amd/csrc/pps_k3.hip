@@ -1415,7 +1415,11 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     }
     if (after_factor) (void)hipEventRecord(after_factor, st);
     for (int l = g.n_levels - 1; l >= 0; l--)
-      if (g.lvl_blocks[l] > 0) PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)(g.solve_per_wave_all + kLevelSolveSlack) * 4 * sizeof(double), st, a, l, g.solve_per_wave_all + kLevelSolveSlack);
+      if (g.lvl_blocks[l] > 0) {
+        // (LDS by the level's own largest panel: the separators above the leaves hold a third of a leaf's panel -- five waves per SIMD instead of three)
+        const int pw = std::min(g.solve_per_wave_all, (int)(band_solve_lds_bytes(g.lvl_max_panel[l]) / sizeof(double))) + kLevelSolveSlack;
+        PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)pw * 4 * sizeof(double), st, a, l, pw);
+      }
     return hipGetLastError();
   }
   for (int stg = 0; stg < g.n_stages; stg++) {

@@ -255,6 +255,10 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.n_factors_total += (long long)d.n_obs + d.n_odo + d.n_pp + d.n_lp;
       q.n_levels = std::max(q.n_levels, A.n_levels);
       if (A.n_levels > 64 || A.max_front + 1 > band_reg_rows() || g->dev.trace) level_ok = false;
+      for (int s2 = 0; s2 < A.n_fronts; s2++) {
+        const int l = A.f_level[s2];
+        if (l >= 0 && l < 64) q.lvl_max_panel[l] = std::max(q.lvl_max_panel[l], (A.f_p[s2] + A.f_b[s2] + 1) * A.f_p[s2]);
+      }
       for (int l = 0; l < A.n_levels && l < 64; l++) {
         for (int c2 = 0; c2 < 3; c2++) q.lvl_cls_blocks[l][c2] = std::max(q.lvl_cls_blocks[l][c2], (A.cls_off[3 * l + c2 + 1] - A.cls_off[3 * l + c2] + 3) / 4);
         q.lvl_blocks[l] = std::max(q.lvl_blocks[l], (A.cls_off[3 * l + 3] - A.cls_off[3 * l] + 3) / 4);
