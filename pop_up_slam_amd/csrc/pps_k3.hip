@@ -1282,14 +1282,14 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
     double* F = lds + (size_t)wave * lds_doubles_per_wave;                                                           \
     double* const Pn = F;                     /* (panel buffer = head of the dead triangle: band_lds_bytes) */          \
     const int tr = lds_doubles_per_wave - 1;                                                                         \
+    DevGraph d2 = d;                            /* (one copy of the front's code for both damping values) */               \
+    double lam = a.lambda[b];                                                                                        \
     if (blockIdx.z) {                                                                                                \
       const BatchAlt al = load_alt(a.alt + a.b0 + b);                                                                \
-      DevGraph d2 = d;                                                                                               \
       d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;                                  \
-      wave_front_factor_reg<NT, false, false, PPS_PANEL_W_LEVEL>(d2, rec, a.lambda2[b], F, Pn, tr);                                             \
-      return;                                                                                                        \
+      lam = a.lambda2[b];                                                                                            \
     }                                                                                                                \
-    wave_front_factor_reg<NT, false, false, PPS_PANEL_W_LEVEL>(d, rec, a.lambda[b], F, Pn, tr);                                              \
+    wave_front_factor_reg<NT, false, false, PPS_PANEL_W_LEVEL>(d2, rec, lam, F, Pn, tr);                             \
   }
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor2, 2, 5)
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, PPS_LVL3_WAVES)
