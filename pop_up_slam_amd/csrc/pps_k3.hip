@@ -1207,14 +1207,14 @@ __global__ __launch_bounds__(512) void kb_band_factor(BatchArgs a, int stage, in
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
   if ((int)blockIdx.x >= sg.grp_count) return;
+  DevGraph d2 = d;                                               // (one copy of the body for both damping values)
+  double lam = a.lambda[b];
   if (blockIdx.z) {
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
-    DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
-    body_band_factor<REG_ONLY>(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, lds);
-    return;
+    lam = a.lambda2[b];
   }
-  body_band_factor<REG_ONLY>(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, lds);
+  body_band_factor<REG_ONLY>(d2, sg.grp_begin + blockIdx.x, lam, lds_doubles_per_wave, lds);
 }
 
 __global__ __launch_bounds__(512) void kb_band_factor_pre(BatchArgs a, int stage, int lds_doubles_per_wave) {
@@ -1222,14 +1222,14 @@ __global__ __launch_bounds__(512) void kb_band_factor_pre(BatchArgs a, int stage
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
   if ((int)blockIdx.x >= sg.grp_count) return;
+  DevGraph d2 = d;                                               // (one copy of the body for both damping values)
+  double lam = a.lambda[b];
   if (blockIdx.z) {
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
-    DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
-    body_band_factor_pre(d2, sg.grp_begin + blockIdx.x, a.lambda2[b], lds_doubles_per_wave, lds);
-    return;
+    lam = a.lambda2[b];
   }
-  body_band_factor_pre(d, sg.grp_begin + blockIdx.x, a.lambda[b], lds_doubles_per_wave, lds);
+  body_band_factor_pre(d2, sg.grp_begin + blockIdx.x, lam, lds_doubles_per_wave, lds);
 }
 
 __global__ __launch_bounds__(768) void kb_band_solve_flow(BatchArgs a, int stage, int lds_doubles_per_wave, int mg) {
@@ -1237,14 +1237,12 @@ __global__ __launch_bounds__(768) void kb_band_solve_flow(BatchArgs a, int stage
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
   if ((int)blockIdx.x >= sg.grp_count) return;
+  DevGraph d2 = d;
   if (blockIdx.z) {
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
-    DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
-    body_band_solve_flow(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
-    return;
   }
-  body_band_solve_flow(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
+  body_band_solve_flow(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
 }
 
 __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int lds_doubles_per_wave) {
@@ -1252,14 +1250,12 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   const BatchStage sg = a.stage_tab[(size_t)stage * a.n_total + a.b0 + b];
   if ((int)blockIdx.x >= sg.grp_count) return;
+  DevGraph d2 = d;
   if (blockIdx.z) {
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
-    DevGraph d2 = d;
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
-    body_band_solve(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
-    return;
   }
-  body_band_solve(d, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
+  body_band_solve(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds);
 }
 
 // ---- level-per-launch form of a batch (BatchGeom::level_form) ----
