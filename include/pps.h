@@ -124,8 +124,8 @@ int pps_chi2(pps_graph* g, double* chi2);
 
 /* ---- many graphs side by side (BASELINE config 4 on one device; north_star reports graphs/sec) ----------------
  * One C2-size LM solve is a dependency chain that occupies a few dozen of the 256 CUs.  pps_multi runs
- * Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) on n independent graphs in lockstep: every kernel of an LM
- * trial is launched once for all graphs, lambda / accept / reject stay per graph (host side, one 32-byte record per
+ * Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) on n independent graphs in rounds: every kernel of an LM
+ * trial is launched once for a chunk of up to 128 graphs, lambda / accept / reject stay per graph (host side, one 32-byte record per
  * graph and round).  Arithmetic, lambda schedule, iteration count and trace of every graph are exactly those of its own
  * pps_batch_optimize.  The graphs keep belonging to the caller (same device; they must outlive the pps_multi and must
  * not be used from another thread during the call); topology edits between calls are picked up.  Graphs with
@@ -136,7 +136,7 @@ int pps_multi_create(int n, pps_graph* const* graphs, pps_multi** out);
 int pps_multi_destroy(pps_multi* m);
 const char* pps_multi_last_error(const pps_multi* m);
 int pps_multi_optimize(pps_multi* m, int* iterations, int* status);
-int pps_multi_rounds(const pps_multi* m, int* rounds);    /* lockstep rounds of the last call = the longest LM run + 1 */
+int pps_multi_rounds(const pps_multi* m, int* rounds);    /* rounds of the last call (of the chunk of graphs that took most) = its longest LM run + 1 */
 /* pps_save_state / pps_restore_state of every graph of the batch; the restore is ONE launch and complete on return (a benchmark
  * that solves the same graphs again from their initial estimates pays 30 us for it instead of a copy per handle) */
 int pps_multi_save_state(pps_multi* m);

@@ -18,7 +18,7 @@ struct pps_multi {
   int device = 0;
   std::string err;
   hipStream_t stream = nullptr;
-  hipStream_t stream3 = nullptr, stream4 = nullptr;
+  hipStream_t stream3 = nullptr;
   hipStream_t stream2 = nullptr;   // chunk c runs on stream c mod (number of chunks a batch is split into): one chunk's narrow tree levels run under the others' wide ones
   DevGraph* d_gs = nullptr; size_t cap_gs = 0;
   BatchStage* d_stage = nullptr; size_t cap_stage = 0;
@@ -56,7 +56,6 @@ int pps_multi_destroy(pps_multi* m) {
   if (!m) return PPS_EINVAL;
   if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); m->stream2 = nullptr; }
   if (m->stream3) { (void)hipStreamSynchronize(m->stream3); (void)hipStreamDestroy(m->stream3); m->stream3 = nullptr; }
-  if (m->stream4) { (void)hipStreamSynchronize(m->stream4); (void)hipStreamDestroy(m->stream4); m->stream4 = nullptr; }
   if (m->stream) {
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
@@ -192,7 +191,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   if (!m->stream) MHIP(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   if (!m->stream2) MHIP(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
   if (!m->stream3) MHIP(m, hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
-  if (!m->stream4) MHIP(m, hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
   if (m->cap_results < (size_t)G) {
     if (m->results) (void)hipHostFree(m->results);
     m->results = nullptr; m->cap_results = 0;
@@ -223,7 +221,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   // keeps one stream and whole chunks: the phases must not overlap.)
   long long total_factors = 0;
   for (int i = 0; i < G; i++) total_factors += m->gs[i]->n_live_factors;
-  const int n_split = getenv("PPS_MULTI_CHUNKS") ? std::min(4, std::max(1, atoi(getenv("PPS_MULTI_CHUNKS")))) : (int)std::min<long long>(3, std::max<long long>(1, total_factors / 250000));      // (A/B)
+  const int n_split = (int)std::min<long long>(3, std::max<long long>(1, total_factors / 250000));
   const bool two_streams = n_split > 1 && !m->profiling;
   const int CH = two_streams ? std::min(kBatchMax, (G + n_split - 1) / n_split) : kBatchMax;
   const int n_chunks = (G + CH - 1) / CH;
@@ -309,8 +307,11 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       }
       total_groups = (total_groups * assumed + n_chunk - 1) / n_chunk;
       if (total_groups > 0) {
-        const long long slots_f = (long long)n_cu * std::max<size_t>(1, lds_budget / fw);
-        const long long slots_s = (long long)n_cu * std::max<size_t>(1, (lds_budget - std::min(lds_budget / 2, xbytes)) / sw);
+        // (wave-slots of a CU: what its LDS holds, and no more than the registers allow -- 2 waves per SIMD for the factor kernels, 3 for the
+        // back-substitution: G = 8 is 512 groups of stage 0, and with eight waves each only 256 of them were resident at a time)
+        // (counted by the LDS alone, up to round 4: G = 8 786 graphs/s against 865, G = 16 1 138 against 1 176, G = 24 1 222 against 1 259)
+        const long long slots_f = (long long)n_cu * std::min<size_t>(8, std::max<size_t>(1, lds_budget / fw));
+        const long long slots_s = (long long)n_cu * std::min<size_t>(12, std::max<size_t>(1, (lds_budget - std::min(lds_budget / 2, xbytes)) / sw));
         q.stage_nw_factor[stg] = (int)std::max<long long>(1, std::min<long long>(q.stage_nw_factor[stg], (slots_f + total_groups - 1) / total_groups));
         q.stage_nw_solve[stg] = (int)std::max<long long>(1, std::min<long long>(q.stage_nw_solve[stg], (slots_s + total_groups - 1) / total_groups));
       }
@@ -456,7 +457,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     // host's bookkeeping 42 times per solve), and the chunks drift apart, so that one's narrow tree levels meet the other's wide ones.
     struct ChunkRun { double seq = 0.0; bool in_flight = false, first = true; int rounds = 0; };
     std::vector<ChunkRun> cr(n_chunks);
-    hipStream_t const streams[4] = {m->stream, m->stream2, m->stream3, m->stream4};
+    hipStream_t const streams[3] = {m->stream, m->stream2, m->stream3};
     auto stream_of = [&](int c) { return n_chunks > 1 && !m->profiling ? streams[c % n_split] : m->stream; };
     auto chunk_done = [&](int c) -> bool {                     // (non-blocking) both records of every active graph of the chunk are this round's
       for (int i = c * CH; i < std::min(G, (c + 1) * CH); i++) {
@@ -516,7 +517,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         MHIP(m, hipStreamSynchronize(m->stream));
         MHIP(m, hipStreamSynchronize(m->stream2));
         MHIP(m, hipStreamSynchronize(m->stream3));
-        MHIP(m, hipStreamSynchronize(m->stream4));
         bool any_done = false;
         for (int c = 0; c < n_chunks; c++) any_done = any_done || (cr[c].in_flight && chunk_done(c));
         if (!any_done) return mfail(m, PPS_EHIP, "result records of a round did not arrive");
@@ -526,7 +526,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     MHIP(m, hipStreamSynchronize(m->stream));
     MHIP(m, hipStreamSynchronize(m->stream2));
     MHIP(m, hipStreamSynchronize(m->stream3));
-    MHIP(m, hipStreamSynchronize(m->stream4));
     for (size_t k = 0; k + 6 <= m->ev_used; k += 6) {
       const hipEvent_t* e = &m->evs[k];
       for (int ph = 0; ph < 5; ph++) {
