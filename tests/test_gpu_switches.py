@@ -27,6 +27,12 @@ if "single" in parts:                       # one handle, one LM solve (band ker
         it = g.batch_optimize()
         out["single_" + name] = [int(it), thash(g), g.chi2()]
         g.close()
+if "large" in parts:                        # 5 000 poses (> 2 048 fronts): the adaptive speculation of the LM loop
+    spec = synth.corridor(5000, 1000, seed=7)
+    g = P.Graph(); spec.replay(g)
+    it = g.batch_optimize()
+    out["large"] = [int(it), thash(g), g.chi2(), g.stats()["n_fronts"]]
+    g.close()
 if "frames" in parts:                       # a graph that grows: update() every ten nodes (difference uploads, list expansion)
     spec = synth.corridor(200, 40, seed=9)
     g = P.Graph(); nid = {}; nf = 0; chis = []
@@ -59,7 +65,7 @@ print("RESULT " + json.dumps(out))
 
 def _run(parts, **env):
     e = dict(os.environ)
-    for k in ("PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE", "PPS_SPLIT_EXPAND", "PPS_NO_UPLOAD_HINTS", "PPS_K2T_GENERIC",
+    for k in ("PPS_ALWAYS_DUAL", "PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE", "PPS_SPLIT_EXPAND", "PPS_NO_UPLOAD_HINTS", "PPS_K2T_GENERIC",
               "PPS_MULTI_NO_TAIL", "PPS_MULTI_LOCKSTEP"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
@@ -71,7 +77,7 @@ def _run(parts, **env):
 
 @pytest.fixture(scope="module")
 def default_run(built):
-    return _run("single,frames,multi")
+    return _run("single,frames,multi,large")
 
 
 @pytest.mark.parametrize("switch", ["PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE"])
@@ -81,6 +87,14 @@ def test_band_schedules(default_run, switch):
     for k in ("single_corridor", "single_world", "frames"):
         assert got[k] == default_run[k], (switch, k)
     assert default_run["single_corridor"][0] >= 10
+
+
+def test_adaptive_speculation(default_run):
+    """graphs of >= 2 048 fronts factor the second damping value only after a rejected trial; PPS_ALWAYS_DUAL=1 keeps
+    both in every launch: same trials, same chi2"""
+    got = _run("large", PPS_ALWAYS_DUAL=1)
+    assert default_run["large"][3] >= 2048
+    assert got["large"] == default_run["large"]
 
 
 def test_upload_forms(default_run):
