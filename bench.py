@@ -162,6 +162,7 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         mm.optimize()
         ph = mm.phase_times(); mm.set_profiling(0)
         ent = {"graphs": G, "graphs_per_sec": G * reps / el, "value": iters / el, "unit": "LM iters/s", "rounds": mm.rounds(),
+               "timed_region": "pps_multi_restore_state (every graph back at its initial estimate, one launch) + pps_multi_optimize, %d repetitions" % reps,
                "ms_per_batch_solve": 1e3 * el / reps, "bit_identical_to_single_handle": bool(same), "same_iteration_counts": bool(same_iters),
                "max_rel_chi2_diff_vs_single_handle": max_rel,
                "device_seconds_per_phase": {k: ph[k] for k in ("linearize", "assemble", "factor", "backsolve", "trial")},
@@ -180,7 +181,8 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
                                                   "update matrices + targets 12 B per entry read and 8 B written, factor panels 8 B per entry written"}
         if ph["linearize"] > 0:
             gb = k1_bytes * ph["n_relinearized"] / ph["linearize"] / 1e9
-            ent["roofline_k1"] = {"bound": "hbm", "kernel": "kb_linearize_lanes" if mode == P.JAC_NUMERIC else "kb_linearize<1,*>",
+            k1_name = ("kb_linearize<0,0,true> + kb_linearize<0,1,false> (thread per factor)" if G >= 34 else "kb_linearize_lanes") if mode == P.JAC_NUMERIC else "kb_linearize<1,*>"
+            ent["roofline_k1"] = {"bound": "hbm", "kernel": k1_name,
                                   "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None,
                                   "us_per_graph_amortised": 1e6 * ph["linearize"] / max(1, ph["n_relinearized"])}
         res[str(G)] = ent

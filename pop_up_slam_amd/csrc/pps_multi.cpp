@@ -225,8 +225,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   const bool two_streams = n_split > 1 && !m->profiling;
   const int CH = two_streams ? std::min(kBatchMax, (G + n_split - 1) / n_split) : kBatchMax;
   const int n_chunks = (G + CH - 1) / CH;
-  std::vector<BatchGeom> geom(n_chunks), geom_tail(n_chunks);
-  std::vector<int> tail_graphs(n_chunks, 0);                    // a chunk with at most this many active graphs runs the round on geom_tail
+  std::vector<BatchGeom> geom(n_chunks);
   const size_t lds_budget = 150 * 1024;
   for (int c = 0; c < n_chunks; c++) {
     BatchGeom& q = geom[c];
@@ -278,16 +277,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
     q.level_form = level_ok && ((q.n_factors_total > 200000 && !getenv("PPS_MULTI_NO_LEVELS")) || getenv("PPS_MULTI_LEVELS"));      // (PPS_MULTI_NO_*: A/B)
     { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
-    // The last rounds of a large batch have a few graphs left (C4: 16 of 128 in the last four of 42 rounds) and a launch per tree
-    // level costs them its latency thirty times per round: a chunk whose ACTIVE graphs are below the size that chose the level form
-    // runs that round on the band kernels, sized for that many graphs (same bits: the forms differ in schedule only).
-    geom_tail[c] = q;
-    geom_tail[c].level_form = false;
-    tail_graphs[c] = q.level_form && q.n_factors_total > 200000 && !getenv("PPS_MULTI_LEVELS") && !getenv("PPS_MULTI_NO_TAIL") ? (int)(200000 / std::max<long long>(1, q.n_factors_total / std::max(1, std::min(G, (c + 1) * CH) - c * CH))) : 0;
-    for (int pass = 0; pass < 2; pass++) {
-    BatchGeom& q = pass == 0 ? geom[c] : geom_tail[c];
-    const int n_chunk = std::min(G, (c + 1) * CH) - c * CH;
-    const int assumed = pass == 0 ? n_chunk : std::max(1, std::min(n_chunk, tail_graphs[c]));
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));
       q.stage_per_wave_solve[stg] = (int)(band_solve_lds_bytes(max_panel[stg]) / sizeof(double));
@@ -305,7 +294,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         const Analysis& A = m->gs[i]->an;
         if (stg < A.n_stages) total_groups += (dual ? 2 : 1) * (A.stage_grp_off[stg + 1] - A.stage_grp_off[stg]);
       }
-      total_groups = (total_groups * assumed + n_chunk - 1) / n_chunk;
       if (total_groups > 0) {
         // (wave-slots of a CU: what its LDS holds, and no more than the registers allow -- 2 waves per SIMD for the factor kernels, 3 for the
         // back-substitution: G = 8 is 512 groups of stage 0, and with eight waves each only 256 of them were resident at a time)
@@ -316,12 +304,10 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         q.stage_nw_solve[stg] = (int)std::max<long long>(1, std::min<long long>(q.stage_nw_solve[stg], (slots_s + total_groups - 1) / total_groups));
       }
     }
-    }
   }
   // the pre-assembling walk (k_band_factor_pre) and the data-flow back-substitution (k_band_solve_flow) of the band kernels, per chunk
-  for (int c2 = 0; c2 < 2 * n_chunks; c2++) {
-    const int c = c2 >> 1;
-    BatchGeom& q = (c2 & 1) ? geom_tail[c] : geom[c];
+  for (int c = 0; c < n_chunks; c++) {
+    BatchGeom& q = geom[c];
     for (int stg = 0; stg < q.n_stages && stg < 32; stg++) {
       bool pre = q.stage_reg_only[stg] && !getenv("PPS_NO_PREASSEMBLE");
       const int nw = q.stage_nw_factor[stg];
@@ -510,7 +496,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         const BatchArgs a = make_args(c, cr[c].seq);
         bool any_relin = false;
         for (int k = 0; k < a.n; k++) { any_relin = any_relin || (a.flags[k] & BF_RELIN); m->n_solves += (a.flags[k] & BF_ACTIVE) ? 2 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
-        int rc = run_round(a, n_active <= tail_graphs[c] ? geom_tail[c] : geom[c], false, any_relin, stream_of(c)); if (rc != PPS_OK) return rc;
+        int rc = run_round(a, geom[c], false, any_relin, stream_of(c)); if (rc != PPS_OK) return rc;
       }
       if (progressed) { t_progress = now_s(); continue; }
       if (now_s() - t_progress > 2.0) {                        // (nothing for two seconds: let the streams drain, look once more)

@@ -48,7 +48,7 @@ if "frames" in parts:                       # a graph that grows: update() every
     it = g.batch_optimize()
     out["frames"] = [int(it), thash(g), g.chi2(), hashlib.sha1(np.asarray(chis).tobytes()).hexdigest()]
     g.close()
-if "multi" in parts:                        # 32 C2-size graphs: the throughput forms chosen by size, last rounds included
+if "multi" in parts:                        # 32 C2-size graphs: the throughput forms chosen by size
     seeds = [42, 135, 110, 143, 225, 154, 169, 185]
     specs = {sd: synth.corridor(seed=sd) for sd in seeds}
     gs = []
@@ -66,7 +66,7 @@ print("RESULT " + json.dumps(out))
 def _run(parts, **env):
     e = dict(os.environ)
     for k in ("PPS_ALWAYS_DUAL", "PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE", "PPS_SPLIT_EXPAND", "PPS_NO_UPLOAD_HINTS", "PPS_K2T_GENERIC",
-              "PPS_MULTI_NO_TAIL", "PPS_MULTI_LOCKSTEP"):
+              "PPS_MULTI_LOCKSTEP"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", CHILD, parts], env=e, capture_output=True, text=True, timeout=600)
@@ -103,9 +103,9 @@ def test_upload_forms(default_run):
     assert got["frames"] == default_run["frames"]
 
 
-@pytest.mark.parametrize("switch", ["PPS_K2T_GENERIC", "PPS_MULTI_NO_TAIL", "PPS_MULTI_LOCKSTEP"])
+@pytest.mark.parametrize("switch", ["PPS_K2T_GENERIC", "PPS_MULTI_LOCKSTEP"])
 def test_large_batch_schedules(default_run, switch):
-    """K2's one-body throughput form / the last rounds on the level kernels / a barrier over all chunks between rounds"""
+    """K2's one-body throughput form / a barrier over all chunks between rounds"""
     got = _run("multi", **{switch: 1})
     assert got["multi"] == default_run["multi"], switch
     assert all(s == 0 for s in default_run["multi"][1]) and min(default_run["multi"][0]) >= 10
