@@ -148,7 +148,7 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
         same = all((int(its[k]), gs[k].chi2()) == single[rank_seed(k)] for k in range(G))
         same_iters = all(int(its[k]) == single[rank_seed(k)][0] for k in range(G))
         max_rel = max(abs(gs[k].chi2() - single[rank_seed(k)][1]) / single[rank_seed(k)][1] for k in range(G))
-        reps = max(2, args.steps // (10 if G >= 64 else 4))
+        reps = max(2, args.steps // (5 if G >= 64 else 4))
         torch.cuda.synchronize()
         t1 = time.perf_counter(); iters = 0
         for _ in range(reps):
