@@ -346,7 +346,7 @@ __device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
 // ------------------------------------------------------------------------------------------
 constexpr int kT66Slots = 8;
 constexpr int kT66Stride = 72;       // doubles per slot: [slice, k-major <= 36 | r[k] at 36 + 6 k]  /  [row slice 36 | column slice 36]
-constexpr int kT33U = 4;             // contributions in flight per 16-lane group
+constexpr int kT33U = 8;             // contributions in flight per 16-lane group
 constexpr int kTcWaveDoubles = kH2WaveDoubles;          // (the generic body's area: the largest)
 static_assert(kTcWaveDoubles >= kT33U * 4 * 16 && kTcWaveDoubles >= kT66Slots * kT66Stride, "one LDS area per wave serves all bodies");
 
