@@ -37,8 +37,8 @@
 extern "C" {
 #endif
 
-#define PPS_VERSION 302   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301;
-                              pps_multi_save_state / pps_multi_restore_state: 302) */
+#define PPS_VERSION 303   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301;
+                              pps_multi_save_state / pps_multi_restore_state: 302; pps_debug_exmap: 303) */
 
 typedef struct pps_graph pps_graph;
 
@@ -227,6 +227,12 @@ int pps_bench_sweep(pps_graph* g, int mode, int replicas, int iters, double sec_
  * picks for a front of this size; strip != 0: rows 64 .. 79 as a strip of the LDS triangle under four tile rows (fronts of 65 .. 80
  * rows only).  not_pd: 1.0 when a pivot was not positive.  p <= 64, p + b + 1 <= 80.  Runs on the current device. */
 int pps_debug_front_factor(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd);
+
+/* ---- K4 diagnostic: the retraction of n nodes outside any graph ---- */
+/* kind 0: Pose3d::exmap (Pose3d.h:131-136: t += d[0:3], q <- q * Exp(d[3:6])); x n x 7 (tx ty tz qx qy qz qw), delta n x 6, out n x 7.
+ * kind 1: Plane3d::exmap_3dof (isam_plane3d.h:101-127: Exp(d) * q, then normalised); x n x 4, delta n x 3, out n x 4.  The device
+ * functions every retraction and every numerical-difference step of the solver goes through.  Runs on the current device. */
+int pps_debug_exmap(int kind, int n, const double* x, const double* delta, double* out);
 
 /* ---- pop-up (fp32), /root/reference/pop_up_wall --------------------------------------- */
 /* popup_plane::update_plane_equation_from_seg (libs/popup_plane.cpp:654-705).

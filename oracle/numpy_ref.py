@@ -291,5 +291,127 @@ def main():
         json.dump(special_cases(), f)
 
 
+# ---- edge-case graphs (round 5): what the synthetic worlds never produce ---------------------------------------------
+def _ut_pack(U):
+    m = U.shape[0]
+    return np.array([U[r, c] for r in range(m) for c in range(r, m)])
+
+
+def dense_sqrtinf_spec():
+    """A small world whose factors carry NON-DIAGONAL upper-triangular square-root information matrices (Noise.h:36-62 accepts any
+    sqrtinf; Covariance() produces one from a full covariance): the diagonal of the application's weights times (I + strictly upper
+    random part)."""
+    from pop_up_slam_amd import synth
+    spec = synth.small_world(12, 4, seed=21, obs_per_pose=3, odo_scale=25.0, meas_sigma=0.03, name="dense_sqrtinf_12p_4l")
+    rng = np.random.default_rng(77)
+    sq = spec.f_sqrtinf.copy()
+    for k, t in enumerate(spec.f_type):
+        m = 6 if t in (F_POSE_PRIOR, F_ODOMETRY) else 3
+        U = unpack_ut(sq[k, :m * (m + 1) // 2], m)
+        S = np.triu(rng.uniform(-0.6, 0.6, (m, m)), 1)
+        U = np.diag(np.diag(U)) @ (np.eye(m) + S)
+        sq[k, :] = 0.0
+        sq[k, :m * (m + 1) // 2] = _ut_pack(U)
+    spec.f_sqrtinf = sq
+    return spec
+
+
+def pi_wrap_spec():
+    """Poses whose yaw -- absolute (pose prior) and relative (odometry) -- sits within 1e-6 of +-pi with the measurement on the OTHER
+    side of the wrap (slam3d.h:82-88,174-191 + standardRad, util.h:101-108), and plane observations whose measured 4-vector is the
+    negated (double-cover) representative, so that dq.w < 0 inside a solve (isam_plane3d.h:286-294)."""
+    from pop_up_slam_amd import synth
+    from scipy.optimize import brentq
+    rng = np.random.default_rng(123)
+    n = 8
+
+    def quat(y, pt, r):
+        return Rot.from_euler("ZYX", [y, pt, r]).as_quat()
+
+    def rel_yaw(q1, q2):
+        return (Rot.from_quat(q1).inv() * Rot.from_quat(q2)).as_euler("ZYX")[0]
+
+    # pose 0: absolute yaw pi - 3e-7.  Edges 0->1 and 4->5 are U-turns whose relative yaw is +pi - 5e-7 / -pi + 4e-7.
+    pr = rng.normal(0.0, 0.02, (n, 2))
+    yaws = [np.pi - 3e-7]
+    targets = {0: np.pi - 5e-7, 4: -np.pi + 4e-7}
+    q = [quat(yaws[0], *pr[0])]
+    for k in range(n - 1):
+        if k in targets:
+            tgt = targets[k]
+            f = lambda dy: wrap(rel_yaw(q[k], quat(yaws[k] + dy, *pr[k + 1])) - tgt)      # noqa: E731
+            dy = brentq(f, tgt - 0.2, tgt + 0.2, xtol=1e-15, rtol=1e-15)
+        else:
+            dy = rng.normal(0.4, 0.2)
+        yaws.append(yaws[k] + dy)
+        q.append(quat(yaws[-1], *pr[k + 1]))
+    t = np.cumsum(rng.normal(0.0, 0.3, (n, 3)), axis=0)
+    truth_pose = [np.concatenate([t[k], q[k]]) for k in range(n)]
+    planes = [np.array([0.0, 0.0, -1.0, 0.0])]
+    for _ in range(2):
+        v = rng.normal(size=3); v /= np.linalg.norm(v)
+        pl = np.append(v, rng.uniform(1.0, 4.0)); planes.append(pl / np.linalg.norm(pl))
+    nt, ni, ft, fn, fm, fs, after = [], [], [], [], [], [], []
+
+    def node(tp, init):
+        nt.append(tp); v = np.zeros(7); v[:len(init)] = init; ni.append(v); return len(nt) - 1
+
+    def factor(tp, a, b, meas, sq):
+        ft.append(tp); fn.append((a, b)); m = np.zeros(6); m[:len(meas)] = meas; fm.append(m)
+        s = np.zeros(21); s[:len(sq)] = sq; fs.append(s); after.append(len(nt) - 1)
+
+    pose_sq = _ut_pack(np.diag(1.0 / np.array([0.01, 0.01, 0.01, 3e-3, 3e-3, 3e-3])))    # physical weights: chi2 ~ dof
+    exact = {0, 1, 4, 5}                      # estimates that start exactly on the wrap
+    pnode, lnode = [], {}
+    for k in range(n):
+        est = truth_pose[k] if k in exact else pose_exmap(truth_pose[k], rng.normal(0.0, 0.05, 6))
+        pn = node(0, est); pnode.append(pn)
+        if k == 0:
+            m6 = pose_vec(truth_pose[0]); m6[3] = -np.pi + 4e-7            # the other side of the wrap: e_yaw = -7e-7
+            factor(F_POSE_PRIOR, pn, -1, m6, pose_sq)
+        else:
+            R1 = Rot.from_quat(truth_pose[k - 1][3:]); R2 = Rot.from_quat(truth_pose[k][3:])
+            m6 = np.concatenate([R1.inv().apply(truth_pose[k][:3] - truth_pose[k - 1][:3]), (R1.inv() * R2).as_euler("ZYX")])
+            m6 += rng.normal(0.0, 1.0, 6) * np.array([0.01, 0.01, 0.01, 3e-3, 3e-3, 3e-3])
+            if k - 1 == 0:
+                m6[3] = -np.pi + 3e-7          # true relative yaw +pi - 5e-7
+            if k - 1 == 4:
+                m6[3] = np.pi - 2e-7           # true relative yaw -pi + 4e-7
+            factor(F_ODOMETRY, pnode[k - 1], pn, m6, pose_sq)
+        seen = [0, 1 + (k % 2)] + ([2 - (k % 2)] if k % 3 == 0 else [])
+        meas = {}
+        for j in seen:
+            meas[j] = plane_exmap(res_plane_local(truth_pose[k], planes[j]), rng.normal(0.0, 0.03, 3))
+            if (k + j) % 2:
+                meas[j] = -meas[j]             # double cover: the same plane, dq.w < 0
+        for j in seen:
+            if j not in lnode:
+                lnode[j] = node(1, plane_exmap(planes[j], rng.normal(0.0, 0.05, 3)))
+                if j == 0:
+                    factor(F_PLANE_PRIOR, lnode[j], -1, planes[0], _ut_pack(np.eye(3) * 20.0))
+        for j in seen:
+            factor(F_PLANE_OBS, pn, lnode[j], meas[j], _ut_pack(np.eye(3) / 0.03))
+    return synth.GraphSpec(name="pi_wrap_8p_3l", node_type=np.array(nt, dtype=np.int32), node_init=np.array(ni),
+                           f_type=np.array(ft, dtype=np.int32), f_nodes=np.array(fn, dtype=np.int32), f_meas=np.array(fm),
+                           f_sqrtinf=np.array(fs), meta={"factor_after_node": np.array(after, dtype=np.int64)})
+
+
+def res_plane_local(pose, plane):
+    R = Rot.from_quat(pose[3:]).as_matrix()
+    u = np.concatenate([R.T @ plane[:3], [plane[:3] @ pose[:3] + plane[3]]])
+    return u / np.linalg.norm(u)
+
+
+def edge_main():
+    """python oracle/numpy_ref.py edge  -- writes the round-5 edge-case fixtures only (the files main() writes stay untouched)"""
+    out = os.path.join(ROOT, "tests", "golden")
+    for spec in (dense_sqrtinf_spec(), pi_wrap_spec()):
+        fx = fixture_for(spec)
+        with open(os.path.join(out, f"{spec.name}.json"), "w") as f:
+            json.dump(fx, f)
+        print(spec.name, "chi2", fx["chi2_initial"], "->", fx["chi2_final"], "iters", fx["lm_iterations"],
+              "rejected", sum(1 for _, _, a in fx["lm_trace"] if not a))
+
+
 if __name__ == "__main__":
-    main()
+    edge_main() if sys.argv[1:] == ["edge"] else main()

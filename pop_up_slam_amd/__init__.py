@@ -25,7 +25,7 @@ _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 
 
-PPS_VERSION = 302      # include/pps.h: the struct layouts mirrored below
+PPS_VERSION = 303      # include/pps.h: the struct layouts mirrored below
 
 
 class PpsProps(C.Structure):
@@ -104,7 +104,7 @@ SYMBOLS = [
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
     "pps_find_closest_planes", "pps_graph_save", "pps_graph_load", "pps_add_plane_obs2", "pps_edge_ray",
-    "pps_time_linearize", "pps_debug_front_factor", "pps_reproject_points", "pps_popup_set_outputs",
+    "pps_time_linearize", "pps_debug_front_factor", "pps_debug_exmap", "pps_reproject_points", "pps_popup_set_outputs",
     "pps_edge_default_params", "pps_edges_create", "pps_edges_destroy", "pps_edges_last_error", "pps_edges_select",
     "pps_edges_download_label", "pps_edges_contour", "pps_edges_last_kernel_time", "pps_edges_host_contour",
     "pps_edges_host_select", "pps_popup_fill_depth", "pps_popup_plane_info", "pps_popup_mask_host",
@@ -213,6 +213,7 @@ def lib():
         L.pps_edge_ray.argtypes = [_fp, _fp, _dp]
         L.pps_time_linearize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.pps_debug_front_factor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(C.c_double)]
+        L.pps_debug_exmap.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
         L.pps_reproject_points.argtypes = [C.c_void_p, C.c_int, _ip, _fp, _fp]
         L.pps_graph_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.pps_graph_load.argtypes = [C.c_char_p, C.POINTER(PpsProps), C.POINTER(C.c_void_p)]
@@ -833,3 +834,16 @@ def debug_front_factor(A_tri, p, b, tiles=0, strip=False):
     if rc != 0:
         raise PpsError(rc, "pps_debug_front_factor(tiles=%d, strip=%d, p=%d, b=%d)" % (tiles, strip, p, b))
     return Lp, U[:(b + 1) * (b + 2) // 2], bad.value
+
+
+def debug_exmap(kind, x, delta):
+    """pps_debug_exmap: the device's pose_exmap (kind 0; x n x 7, delta n x 6) / plane_exmap (kind 1; x n x 4, delta n x 3)."""
+    L_ = lib()
+    x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float64)))
+    d = np.ascontiguousarray(np.atleast_2d(np.asarray(delta, dtype=np.float64)))
+    assert x.shape == (len(d), 7 if kind == 0 else 4) and d.shape[1] == (6 if kind == 0 else 3)
+    out = np.empty_like(x)
+    rc = L_.pps_debug_exmap(int(kind), len(x), x.ctypes.data_as(_dp), d.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+    if rc != PPS_OK:
+        raise PpsError(rc, "pps_debug_exmap(kind=%d, n=%d)" % (kind, len(x)))
+    return out

@@ -400,6 +400,12 @@ int pps_debug_front_factor(int tiles, int strip, int p, int b, const double* A, 
   return rc == 0 ? PPS_OK : (rc < 0 ? PPS_EINVAL : PPS_EHIP);
 }
 
+int pps_debug_exmap(int kind, int n, const double* x, const double* delta, double* out) {
+  if (!x || !delta || !out) return PPS_EINVAL;
+  const int rc = pps::debug_exmap(kind, n, x, delta, out);
+  return rc == 0 ? PPS_OK : (rc < 0 ? PPS_EINVAL : PPS_EHIP);
+}
+
 int pps_time_linearize(pps_graph* g, int mode, int iters, double* sec_per_launch) {
   if (!g || iters < 1 || !sec_per_launch) return PPS_EINVAL;
   int rc = prepare_solve(g);

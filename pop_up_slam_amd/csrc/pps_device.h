@@ -167,6 +167,7 @@ int band_max_rows();
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
 int debug_front_factor(int tiles, int strip, int p, int b, const double* A_host, double* L_host, double* U_host, double* not_pd);   // pps_debug_front_factor
+int debug_exmap(int kind, int n, const double* x_host, const double* delta_host, double* out_host);   // pps_debug_exmap (pps_k4.hip)
 int band_reg_rows();                            // fronts up to this many rows (incl. rhs) take the register-resident path
 size_t band_lds_bytes(int max_front, bool reg_only_kernel = false);   // LDS bytes one wave needs for the factor kernel
 // est <- lin ; lin <- lin (+) delta          (LM trial: Optimizer.cpp:414-416)

@@ -443,4 +443,44 @@ hipError_t launch_clear_status(const DevGraph& d, hipStream_t st) {
   return hipMemsetAsync(d.result_dev, 0, 4 * sizeof(double), st);
 }
 
+// ---- diagnostic: the retraction of ONE node outside any graph (pps_debug_exmap) ----
+// n nodes of one kind through the functions k_retract / k_trial_dual call: pose_exmap (Pose3d::exmap, Pose3d.h:131-136) or
+// plane_exmap (Plane3d::exmap_3dof, isam_plane3d.h:101-127)
+__global__ void k_debug_exmap(int kind, int n, const double* __restrict__ x, const double* __restrict__ dl, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (kind == 0) {
+    double p[7], d[6], o[7];
+    for (int k = 0; k < 7; k++) p[k] = x[i * 7 + k];
+    for (int k = 0; k < 6; k++) d[k] = dl[i * 6 + k];
+    pose_exmap(p, d, o);
+    for (int k = 0; k < 7; k++) out[i * 7 + k] = o[k];
+  } else {
+    double p[4], d[3], o[4];
+    for (int k = 0; k < 4; k++) p[k] = x[i * 4 + k];
+    for (int k = 0; k < 3; k++) d[k] = dl[i * 3 + k];
+    plane_exmap(p, d, o);
+    for (int k = 0; k < 4; k++) out[i * 4 + k] = o[k];
+  }
+}
+
+// returns a hipError_t (0 = ok), -1 for bad arguments
+int debug_exmap(int kind, int n, const double* x_host, const double* delta_host, double* out_host) {
+  if ((kind != 0 && kind != 1) || n < 1) return -1;
+  const size_t nx = (size_t)n * (kind == 0 ? 7 : 4), nd = (size_t)n * (kind == 0 ? 6 : 3);
+  double *x = nullptr, *dl = nullptr, *o = nullptr;
+  hipError_t e = hipMalloc(&x, nx * 8);
+  if (e == hipSuccess) e = hipMalloc(&dl, nd * 8);
+  if (e == hipSuccess) e = hipMalloc(&o, nx * 8);
+  if (e == hipSuccess) e = hipMemcpy(x, x_host, nx * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dl, delta_host, nd * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_debug_exmap, dim3(cdiv(n, 64)), dim3(64), 0, 0, kind, n, x, dl, o);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out_host, o, nx * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(x); (void)hipFree(dl); (void)hipFree(o);
+  return (int)e;
+}
 }  // namespace pps

@@ -8,6 +8,10 @@ from pop_up_slam_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GRAPH_FIXTURES = ["small_5p_3l", "small_20p_6l", "small_50p_10l", "hard_30p_8l", "hard_40p_6l"]
+# round 5 (oracle/numpy_ref.py edge): non-diagonal sqrtinf on every factor; yaw within 1e-6 of +-pi with the measurement on the other
+# side of the wrap + double-cover (negated) plane measurements
+EDGE_FIXTURES = ["dense_sqrtinf_12p_4l", "pi_wrap_8p_3l"]
+ALL_FIXTURES = GRAPH_FIXTURES + EDGE_FIXTURES
 
 
 def load_fixture(name):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, GRAPH_FIXTURES, load_fixture, node_starts
+from helpers import ALL_FIXTURES as GRAPH_FIXTURES, GOLDEN, load_fixture, node_starts
 from oracle import oracle_py as O
 from pop_up_slam_amd import synth
 
