@@ -255,6 +255,41 @@ def cpu_dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside any launcher: start the N ranks -- one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1 -- exactly what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` would start; rank 0's stdout (the JSON line) is
+    this process' stdout.  Returns the first non-zero exit code of a rank."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs across processes on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for pr in procs:
+            c = pr.wait()
+            rc = rc or c
+            if c != 0:                      # a rank died: the others would wait at a barrier for ever
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    if rc:
+        raise SystemExit(rc)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,10 +308,20 @@ def main():
                     help="CI only: gloo backend, no GPU work -- exercises the rank/seed/aggregation plumbing of the N>1 path")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
     import torch
+    if not args.cpu_dry_run and os.environ.get("PPS_BENCH_SHARED_GPU") != "1" and args.gpus > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {torch.cuda.device_count()} device(s) visible "
+                         f"(PPS_BENCH_SHARED_GPU=1 puts every rank on device 0: validation on a one-GPU box only)")
     dist = None
     if args.cpu_dry_run:
         return cpu_dry_run(args, rank, world)

@@ -32,6 +32,28 @@ def test_bench_two_ranks_gloo(built):
     assert abs(js["value"] - 150.0) < 1e-9
 
 
+def test_bench_starts_its_own_ranks(built):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself (one process per GPU, 127.0.0.1
+    rendezvous) and rank 0 prints the one line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-dry-run"], capture_output=True,
+                         text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["total_iters"] == 30.0 and abs(js["value"] - 150.0) < 1e-9
+
+
+def test_gpus_flag_must_match_the_launcher(built):
+    """--gpus 2 inside a one-rank environment is refused instead of silently running the single-GPU bench"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-dry-run"], capture_output=True,
+                         text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
 def test_single_rank_dry_run(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-dry-run"], capture_output=True, text=True,
                          timeout=600, cwd=ROOT)
