@@ -169,7 +169,7 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
                "relinearisations": ph["n_relinearized"], "factorisations": ph["n_solves"]}
         if ph["factor"] > 0:
             tf = flops_per_factorisation * ph["n_solves"] / ph["factor"] / 1e12
-            ent["roofline_k3"] = {"bound": "mfma", "kernel": "kb_level_factor2/3/4" if G >= 34 else "kb_band_factor", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+            ent["roofline_k3"] = {"bound": "mfma", "kernel": "kb_level_factor2/3/4" if ph["level_form"] else "kb_band_factor", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
                                   "us_per_factorisation_amortised": 1e6 * ph["factor"] / max(1, ph["n_solves"])}
             if k3_bytes:
                 # a batch streams every graph's H entries, index lists, update matrices and factor panels through HBM once per
@@ -181,7 +181,7 @@ def multi_graph_bench(P, synth, device, mode, args, spec0, flops_per_factorisati
                                                   "update matrices + targets 12 B per entry read and 8 B written, factor panels 8 B per entry written"}
         if ph["linearize"] > 0:
             gb = k1_bytes * ph["n_relinearized"] / ph["linearize"] / 1e9
-            k1_name = ("kb_linearize<0,0,true> + kb_linearize<0,1,false> (thread per factor)" if G >= 34 else "kb_linearize_lanes") if mode == P.JAC_NUMERIC else "kb_linearize<1,*>"
+            k1_name = ("kb_linearize<0,0,true> + kb_linearize<0,1,false> (thread per factor)" if ph["thread_form"] else "kb_linearize_lanes") if mode == P.JAC_NUMERIC else "kb_linearize<1,*>"
             ent["roofline_k1"] = {"bound": "hbm", "kernel": k1_name,
                                   "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None,
                                   "us_per_graph_amortised": 1e6 * ph["linearize"] / max(1, ph["n_relinearized"])}

@@ -126,8 +126,12 @@ int pps_chi2(pps_graph* g, double* chi2);
  * One C2-size LM solve is a dependency chain that occupies a few dozen of the 256 CUs.  pps_multi runs
  * Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) on n independent graphs in rounds: every kernel of an LM
  * trial is launched once for a chunk of up to 128 graphs, lambda / accept / reject stay per graph (host side, one 32-byte record per
- * graph and round).  Arithmetic, lambda schedule, iteration count and trace of every graph are exactly those of its own
- * pps_batch_optimize.  The graphs keep belonging to the caller (same device; they must outlive the pps_multi and must
+ * graph and round).  While a chunk holds at most 200 000 factors, arithmetic, lambda schedule, iteration count and trace of every
+ * graph are exactly -- bit for bit -- those of its own pps_batch_optimize.  A larger chunk takes the throughput forms (K1 as one
+ * thread per factor without product records, K2 multiplying the Jacobian slices): the same sums in another rounding order, H and
+ * chi2 equal to about 1e-12 relative, LM verdicts and iteration counts the same on every graph measured; which chunk a graph
+ * lands in depends on the factor count of the whole batch, so below that level a graph's low-order bits can depend on what else
+ * is in its batch (pps_multi_phase_times reports the forms taken).  The graphs keep belonging to the caller (same device; they must outlive the pps_multi and must
  * not be used from another thread during the call); topology edits between calls are picked up.  Graphs with
  * loop-closure fronts (dense-front kernels) are refused with PPS_ESTATE.
  *   iterations[n], status[n] (either may be NULL): LM iterations and PPS_OK / PPS_ENOTPD per graph. */
@@ -143,9 +147,11 @@ int pps_multi_save_state(pps_multi* m);
 int pps_multi_restore_state(pps_multi* m);
 /* level 1: HIP events at the phase boundaries of every round (no host syncs); after the next pps_multi_optimize
  * sec[5] = device seconds in K1 (Jacobian sweep) | K2 (H blocks) | K3 factor | K3 back-substitution | trial step + chi2,
- * counts[2] = graphs re-linearised | factorised, summed over the rounds (counts may be NULL) */
+ * counts[4] (may be NULL) = graphs re-linearised | factorised, summed over the rounds | chunks the batch of the last call was cut
+ * into | forms its chunks took: bit 0 = thread-per-factor K1 + class-body K2 (throughput), bit 1 = one launch per tree level (K3);
+ * the last two are valid without profiling */
 int pps_multi_set_profiling(pps_multi* m, int level);
-int pps_multi_phase_times(const pps_multi* m, double sec[5], long long counts[2]);
+int pps_multi_phase_times(const pps_multi* m, double sec[5], long long counts[4]);
 
 /* ---- state access (NodeT::value(), Node.h:130) ---------------------------------------- */
 int pps_num_nodes(const pps_graph* g, int* n);

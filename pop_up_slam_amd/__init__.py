@@ -680,10 +680,11 @@ class Multi:
 
     def phase_times(self):
         """device seconds of the last optimize (profiling on): dict of K1 / K2 / factor / backsolve / trial + relinearisations, solves"""
-        t = np.zeros(5); c = (C.c_longlong * 2)()
+        t = np.zeros(5); c = (C.c_longlong * 4)()
         self.L.pps_multi_phase_times(self.h, t.ctypes.data_as(_dp), c)
         return {"linearize": t[0], "assemble": t[1], "factor": t[2], "backsolve": t[3], "trial": t[4],
-                "n_relinearized": int(c[0]), "n_solves": int(c[1])}
+                "n_relinearized": int(c[0]), "n_solves": int(c[1]), "n_chunks": int(c[2]),
+                "thread_form": bool(c[3] & 1), "level_form": bool(c[3] & 2)}        # the forms the last solve's chunks took
 
 
 def _flatten_polys(polys):

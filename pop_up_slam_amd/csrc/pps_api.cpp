@@ -6,6 +6,44 @@
 using namespace pps;
 using namespace pps_impl;
 
+namespace pps {
+// The library's only reader of the environment: once per handle (see Switches, pps_device.h).
+Switches read_switches() {
+  auto on = [](const char* k) { return getenv(k) != nullptr; };
+  auto num = [](const char* k, long long dflt) { const char* e = getenv(k); return e && *e ? atoll(e) : dflt; };
+  Switches s;
+  s.k1_thread_form = on("PPS_K1_THREAD_FORM");
+  s.no_preassemble = on("PPS_NO_PREASSEMBLE");
+  s.no_solve_flow = on("PPS_NO_SOLVE_FLOW");
+  s.no_root_fuse = on("PPS_NO_ROOT_FUSE");
+  s.always_dual = on("PPS_ALWAYS_DUAL");
+  s.no_spec_lin = on("PPS_NO_SPEC_LIN");
+  s.no_dual = on("PPS_NO_DUAL");
+  s.no_strip = on("PPS_NO_STRIP");
+  s.split_expand = on("PPS_SPLIT_EXPAND");
+  s.no_incremental = on("PPS_NO_INCREMENTAL");
+  s.no_incr_compact = on("PPS_NO_INCR_COMPACT");
+  s.no_upload_hints = on("PPS_NO_UPLOAD_HINTS");
+  s.verify_upload = on("PPS_DEBUG_VERIFY_UPLOAD");
+  s.upload_timing = on("PPS_UPLOAD_TIMING");
+  s.analysis_timing = on("PPS_ANALYSIS_TIMING");
+  s.k2t_generic = on("PPS_K2T_GENERIC");
+  s.multi_levels = on("PPS_MULTI_LEVELS");
+  s.multi_no_levels = on("PPS_MULTI_NO_LEVELS");
+  s.multi_thread_form = on("PPS_MULTI_THREAD_FORM");
+  s.multi_no_thread_form = on("PPS_MULTI_NO_THREAD_FORM");
+  s.multi_lockstep = on("PPS_MULTI_LOCKSTEP");
+  s.debug_drop_flag = on("PPS_DEBUG_DROP_FLAG");
+  s.trace = (int)num("PPS_TRACE", 0);
+  s.multi_timing = (int)num("PPS_MULTI_TIMING", 0);
+  s.multi_split = (int)num("PPS_MULTI_SPLIT", 0);
+  s.multi_thread_factors = num("PPS_MULTI_THREAD_FACTORS", 200000);
+  if (on("PPS_TRACE") && s.trace < 1) s.trace = 1;
+  if (on("PPS_MULTI_TIMING") && s.multi_timing < 1) s.multi_timing = 1;
+  return s;
+}
+}  // namespace pps
+
 extern "C" {
 
 void pps_default_props(pps_props* p) {
@@ -30,6 +68,8 @@ int pps_graph_create(const pps_props* props, pps_graph** out) {
   pps_graph* g = new (std::nothrow) pps_graph();
   if (!g) return PPS_ENOMEM;
   if (props) g->props = *props; else pps_default_props(&g->props);
+  g->sw = read_switches();
+  g->aprm.timing = g->sw.analysis_timing ? 1 : 0;
   *out = g;
   return PPS_OK;
 }

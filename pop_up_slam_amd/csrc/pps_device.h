@@ -91,12 +91,50 @@ struct DevGraph {
   long long* trace = nullptr;        // PPS_TRACE=1: 8 timestamps (s_memtime) per front of the last factorisation
   int trace_solve = 0;               // PPS_TRACE=2: the trace slots take the phases of the back-substitution instead of the factorisation's
   int no_strip = 0;                  // PPS_NO_STRIP=1: fronts of 65 .. 80 rows take the LDS-tile path (A/B, parity tests)
+  unsigned sw = 0;                   // SW_* bits of the owning handle's Switches that the launchers consult (set by upload_all)
   // step quaternions of the numerical Jacobian's rotation / plane columns: (a, 0, 0, c) = rot_exp((eps, 0, 0)) and plane_exp((eps, 0, 0)),
   // evaluated ONCE per device by the device's own functions (step_constants) -- the same bits as evaluating them per step
   double step_ac[4] = {0, 0, 0, 0};
   double* gwork = nullptr;           // global-memory front workspace for fronts that exceed LDS
   int64_t gwork_stride = 0;
 };
+
+// ---- run-time switches ----------------------------------------------------------------------------------------------------
+// Every PPS_* environment variable the library understands.  They are read ONCE per handle -- pps_graph_create / pps_graph_load /
+// pps_multi_create / pps_popup_create ... call read_switches() -- and never on a launch path: a handle keeps the schedule it was
+// created with whatever the environment does later (A/B tools and the parity tests set the variable before they create the handle).
+constexpr double kStatusInternal = 64.0;   // result_dev[2] at or above this: an internal time-out inside a kernel (PPS_EHIP), not a not-PD pivot
+enum : unsigned { SW_K1_THREAD_FORM = 1u, SW_NO_SOLVE_FLOW = 2u, SW_NO_ROOT_FUSE = 4u, SW_DEBUG_DROP_FLAG = 8u };
+struct Switches {
+  bool k1_thread_form = false;      // PPS_K1_THREAD_FORM: thread-per-factor K1 (no product records) on graphs of any size
+  bool no_preassemble = false;      // PPS_NO_PREASSEMBLE: plain walk of a band group instead of k_band_factor_pre
+  bool no_solve_flow = false;       // PPS_NO_SOLVE_FLOW: barrier form of the band back-substitution
+  bool no_root_fuse = false;        // PPS_NO_ROOT_FUSE: root stage as two launches
+  bool always_dual = false;         // PPS_ALWAYS_DUAL: no adaptive speculation on graphs of >= 2 048 fronts
+  bool no_spec_lin = false;         // PPS_NO_SPEC_LIN: no linearisation queued behind the trials
+  bool no_dual = false;             // PPS_NO_DUAL: the one-step-at-a-time LM loop
+  bool no_strip = false;            // PPS_NO_STRIP
+  bool split_expand = false;        // PPS_SPLIT_EXPAND: list expansion as two launches + a fill
+  bool no_incremental = false;      // PPS_NO_INCREMENTAL: every analysis from scratch
+  bool no_incr_compact = false;     // PPS_NO_INCR_COMPACT: compacted tables rebuilt per analysis
+  bool no_upload_hints = false;     // PPS_NO_UPLOAD_HINTS
+  bool verify_upload = false;       // PPS_DEBUG_VERIFY_UPLOAD: read the arena back after every flush
+  bool upload_timing = false;       // PPS_UPLOAD_TIMING
+  bool analysis_timing = false;     // PPS_ANALYSIS_TIMING
+  bool k2t_generic = false;         // PPS_K2T_GENERIC: one-body throughput form of K2
+  bool multi_levels = false, multi_no_levels = false, multi_thread_form = false, multi_no_thread_form = false;   // PPS_MULTI_*
+  bool multi_lockstep = false;      // PPS_MULTI_LOCKSTEP: a barrier over all chunks between rounds
+  bool debug_drop_flag = false;     // PPS_DEBUG_DROP_FLAG: the data-flow back-substitution withholds one hand-over flag (tests the time-out path)
+  int trace = 0;                    // PPS_TRACE: 1 = phase timestamps of the factorisation, 2 = of the back-substitution
+  int multi_timing = 0;             // PPS_MULTI_TIMING
+  int multi_split = 0;              // PPS_MULTI_SPLIT: chunks a batch is cut into (0 = by size)
+  long long multi_thread_factors = 200000;   // PPS_MULTI_THREAD_FACTORS: factors per chunk above which a batch takes the throughput forms
+  unsigned dev_bits() const {
+    return (k1_thread_form ? SW_K1_THREAD_FORM : 0u) | (no_solve_flow ? SW_NO_SOLVE_FLOW : 0u) | (no_root_fuse ? SW_NO_ROOT_FUSE : 0u) |
+           (debug_drop_flag ? SW_DEBUG_DROP_FLAG : 0u);
+  }
+};
+Switches read_switches();           // pps_api.cpp: the only place of the library that calls getenv
 
 // Accept-branch speculation of the dual LM loop: K1 / K2 are queued right behind the two trials, before the host has seen
 // their chi2.  The kernels repeat the host's accept test (Optimizer.cpp:425-428: error - error_new > 0, trial 0 first) on the
@@ -232,6 +270,7 @@ struct BatchGeom {
   int k2_blocks = 0, k2_finish = 0;   // workgroups of the K2 launch: maximum over the chunk's graphs of ceil(single / 16) + multi; blocks of its second pass
   long long n_factors_total = 0;
   bool lin_thread_form = false;   // numeric K1 as one thread per factor (many graphs) instead of 32 lanes per factor
+  bool k2t_generic = false;       // Switches::k2t_generic of the batch handle
   int n_stages = 0;
   int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
   int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};

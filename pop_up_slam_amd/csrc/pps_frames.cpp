@@ -57,7 +57,7 @@ int pps_refresh_measurements(pps_graph* g) {
     if (g->up_inflight) { HIP_TRY(g, hipStreamSynchronize(g->stream)); g->up_inflight = false; }
     // The first table upload after an upload_all goes to the slots the previous layout's first table upload went to (same number of
     // uploads in front of it: same cursor), which nothing has written since: the entries it sent are in the mirror.
-    g->verify_hints = getenv("PPS_DEBUG_VERIFY_UPLOAD") != nullptr;
+    g->verify_hints = g->sw.verify_upload;
     const size_t c0 = g->up_cursor;
     const bool first = g->fr_hint_version != g->upload_version;
     const bool hint = inc && first && !g->up_unknown && g->fr_hint_version + 1 == g->upload_version && g->fr_hint_cursor == c0 &&

@@ -76,6 +76,7 @@ struct pps_graph {
   bool grown_only_upload = false;  // ... since the last upload (false until there has been one)
   pps::Analysis an;
   pps::AnalysisParams aprm;
+  pps::Switches sw;                // the PPS_* environment switches as they were when the handle was created
   pps::AnalysisCache* acache = nullptr;   // what the last analysis left for the next one (frame loops)
   std::vector<int> pose_ids, plane_ids;   // slot -> node id
   std::vector<int> fslot_ids[4];          // per type: slot -> factor id

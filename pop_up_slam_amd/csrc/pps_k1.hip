@@ -96,11 +96,11 @@ __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double
 
 // PPS_K1_THREAD_FORM=1 forces the thread-per-factor kernels on small graphs (parity tests of that form)
 bool k1_lane_form(const DevGraph& d, int mode) {
-  return mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !getenv("PPS_K1_THREAD_FORM");
+  return mode == 0 && d.n_obs + d.n_odo + d.n_pp + d.n_lp <= kLaneParallelMaxFactors && !(d.sw & SW_K1_THREAD_FORM);
 }
 
 // does K1 write the plane observations' product records (and K2 sum them)?  Every form does, except under the test switch above
-bool k1_products(const DevGraph& d, int mode) { (void)d; (void)mode; return !getenv("PPS_K1_THREAD_FORM"); }
+bool k1_products(const DevGraph& d, int mode) { (void)mode; return !(d.sw & SW_K1_THREAD_FORM); }
 
 // ev0 / ev1 (profiling level 1): the launch is made with hipExtLaunchKernelGGL, whose start / stop events take the DISPATCH's own
 // begin / end timestamps -- what rocprofv3 reports as the kernel's duration -- instead of two event records around the launch,

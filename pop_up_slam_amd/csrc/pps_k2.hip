@@ -594,7 +594,7 @@ hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStrea
   if (g.lin_thread_form) {                                      // many graphs: throughput form over the Jacobians + the second pass
     // (the wave-per-segment kernel in its Jacobian-only mode, measured on the same G = 128 batch: 23.9 ms of K2 per batch solve
     // against 13.7 ms -- at this size the LDS-staged form's four segments per wave and prefetched headers win)
-    static const bool by_class = !getenv("PPS_K2T_GENERIC");          // (A/B: the one-body form)
+    const bool by_class = !g.k2t_generic;                             // (A/B: the one-body form)
     if (by_class) { if (g.k2t_blocks > 0) PPS_LAUNCH(kb_hblocks_tc, dim3(g.k2t_blocks, a.n), dim3(256), 0, st, a); }
     else if (g.hblocks_nd > 0) PPS_LAUNCH(kb_hblocks_t, dim3(g.hblocks_nd, a.n), dim3(256), 0, st, a);
     if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);

@@ -595,10 +595,26 @@ template <int K> __device__ __forceinline__ double row_bcast_d(double v) {
 #ifndef PPS_FLOW_SLEEP
 #define PPS_FLOW_SLEEP 1
 #endif
-__device__ __forceinline__ void flow_wait(int* flow, int q) {
-  // (a parent never waits for a child, so this cannot lock up; the bound turns a logic error into wrong numbers instead of a hung GPU)
+// Hand-over of a front's local solution inside a band group (body_band_solve_flow): the producer's writes to X, then a release fence
+// over the LDS, then the flag; the consumer polls the flag and passes an acquire fence before it reads X.  The fences are workgroup
+// scope and LOCAL address space only -- a plain workgroup release would also wait for the acknowledgement of the wave's stores to delta, a
+// memory round trip per level of the chain.
+// A parent never waits for a child, so the wait cannot lock up; the spin is bounded all the same, and a wait that runs out raises
+// kFlowTimeout in the graph's status word: the host then returns PPS_EHIP instead of numbers (read_status, pps_solve.cpp).
+constexpr double kFlowTimeout = kStatusInternal; // result_dev[2]: 0 ok | 1 not positive definite | >= 64 a hand-over flag never arrived
+__device__ __forceinline__ void flow_wait(const DevGraph& d, int* flow, int q) {
   int spin = 0;
-  while (*(volatile int*)(flow + q) == 0 && ++spin < (1 << 22)) __builtin_amdgcn_s_sleep(PPS_FLOW_SLEEP);
+  while (__hip_atomic_load(flow + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+    if (++spin >= (1 << 22)) { if ((threadIdx.x & 63) == 0) d.result_dev[2] = kFlowTimeout; break; }
+    __builtin_amdgcn_s_sleep(PPS_FLOW_SLEEP);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void flow_post(const DevGraph& d, int* flow, int slot, bool top) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  // (SW_DEBUG_DROP_FLAG, tests only: the top front of a group never raises its flag -- its children run into the time-out)
+  if ((threadIdx.x & 63) == 0 && !((d.sw & SW_DEBUG_DROP_FLAG) && top))
+    __hip_atomic_store(flow + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 #ifndef PPS_SOLVE_DIRECT
@@ -690,7 +706,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }
     if (flow) { dinv = 1.0 / dg; solve_pivot_scale(lk, dinv); }       // (all that can be done without the parent, before waiting for it)
     if (pslot >= 0) {
-      if (flow) flow_wait(flow, pslot);
+      if (flow) flow_wait(d, flow, pslot);
       const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows; g0 = Xp[ix0]; g1 = Xp[ix1];
     }
     if (TR) PPS_TR(1);
@@ -722,7 +738,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     if (lane < p) Xs[lane] = tj;
     if (lane < b) Xs[p + lane] = g0;
     if (lane + 64 < b) Xs[p + lane + 64] = g1;
-    if (flow && lane == 0) *(volatile int*)(flow + slot) = 1;            // (behind the solution: one wave's LDS operations complete in order)
+    if (flow) flow_post(d, flow, slot, pslot < 0);                       // (behind the solution)
     return;
   }
   // first batch of the panel (all of it for n <= 1024) issued right behind the index loads: the gather from delta below then waits
@@ -772,7 +788,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     }
   }
   if (pslot >= 0) {
-    if (flow) flow_wait(flow, pslot);
+    if (flow) flow_wait(d, flow, pslot);
     const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows;
     g0 = Xp[ix0]; g1 = Xp[ix1];
   }
@@ -843,7 +859,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane < p) Xs[lane] = tj;
   if (lane < b) Xs[p + lane] = g0;
   if (lane + 64 < b) Xs[p + lane + 64] = g1;
-  if (flow && lane == 0) *(volatile int*)(flow + slot) = 1;
+  if (flow) flow_post(d, flow, slot, pslot < 0);
 }
 
 // The back-substitution of a band group as a data flow: the group's fronts, top level first, are dealt to the waves round-robin and
@@ -911,7 +927,7 @@ __global__ __launch_bounds__(512) void k_band_solve(DevGraph d, DualAlt alt, int
 }
 __global__ __launch_bounds__(768) void k_band_solve_flow(DevGraph d, DualAlt alt, int grp_begin, int lds_doubles_per_wave, int mg) {
   extern __shared__ double lds[];
-  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; }
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; }
   body_band_solve_flow(d, grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
 }
 __global__ __launch_bounds__(768) void k_band_solve_flow_trace(DevGraph d, int grp_begin, int lds_doubles_per_wave, int mg) {     // PPS_TRACE=2
@@ -1135,7 +1151,7 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
   const int per_wave = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
   const size_t bytes = ((size_t)per_wave * nwaves + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
-  static const bool no_flow = getenv("PPS_NO_SOLVE_FLOW") != nullptr;
+  const bool no_flow = (d.sw & SW_NO_SOLVE_FLOW) != 0;
   if (!no_flow && !(d.trace != nullptr && d.trace_solve && alt) && max_group_fronts > 1) {
     // data-flow form: up to twelve waves (three per SIMD), as many as the group has fronts and the LDS holds
     const size_t fixed = ((size_t)max_group_fronts * kBandMaxRows + (size_t)(max_group_fronts + 1) / 2) * sizeof(double);
@@ -1157,7 +1173,7 @@ hipError_t launch_band_solve(const DevGraph& d, int grp_begin, int grp_count, in
 
 // the root stage as one launch (k_band_root): one group, every front register-resident, no trace
 bool band_root_fusable(const DevGraph& d, int grp_count, int max_front) {
-  static const bool off = getenv("PPS_NO_ROOT_FUSE") != nullptr;
+  const bool off = (d.sw & SW_NO_ROOT_FUSE) != 0;
   return !off && grp_count == 1 && max_front + 1 <= kRegRows && d.trace == nullptr;
 }
 hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,
@@ -1240,7 +1256,7 @@ __global__ __launch_bounds__(768) void kb_band_solve_flow(BatchArgs a, int stage
   DevGraph d2 = d;
   if (blockIdx.z) {
     const BatchAlt al = load_alt(a.alt + a.b0 + b);
-    d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
+    d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;
   }
   body_band_solve_flow(d2, sg.grp_begin + blockIdx.x, lds_doubles_per_wave, lds, mg);
 }

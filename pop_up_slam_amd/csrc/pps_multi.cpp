@@ -15,6 +15,8 @@ extern "C" {
 
 struct pps_multi {
   std::vector<pps_graph*> gs;
+  Switches sw;                     // the PPS_* environment switches as they were at pps_multi_create
+  int n_chunks_last = 0, forms_last = 0;   // of the last solve: chunks the batch was cut into; bit 0 thread-per-factor K1 + class-body K2, bit 1 level-per-launch K3 (any chunk)
   int device = 0;
   std::string err;
   hipStream_t stream = nullptr;
@@ -48,6 +50,7 @@ int pps_multi_create(int n, pps_graph* const* graphs, pps_multi** out) {
   if (!m) return PPS_ENOMEM;
   m->gs.assign(graphs, graphs + n);
   m->device = graphs[0]->props.device;
+  m->sw = read_switches();
   *out = m;
   return PPS_OK;
 }
@@ -152,8 +155,9 @@ int pps_multi_optimize(pps_multi* m, int* iterations, int* status) {
   if (!m) return PPS_EINVAL;
   const int rc = multi_optimize(m, iterations, status);
   if (rc != PPS_OK && rc != PPS_ENOTPD && rc != PPS_EINVAL && rc != PPS_ESTATE) {       // a HIP failure in the middle of the rounds: as a failed single solve
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->stream2) (void)hipStreamSynchronize(m->stream2);
+    // every stream a chunk may still be running on is drained BEFORE the handles are marked abandoned: the next upload_all frees or
+    // re-uploads their arenas, and a kernel of this solve still in flight would write into them
+    for (hipStream_t st : {m->stream, m->stream2, m->stream3}) if (st) (void)hipStreamSynchronize(st);
     for (pps_graph* g : m->gs) abandon_device_copy(g);
   }
   return rc;
@@ -221,7 +225,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   // keeps one stream and whole chunks: the phases must not overlap.)
   long long total_factors = 0;
   for (int i = 0; i < G; i++) total_factors += m->gs[i]->n_live_factors;
-  const int n_split = (int)std::min<long long>(3, std::max<long long>(1, total_factors / 250000));
+  const int n_split = m->sw.multi_split > 0 ? std::min(3, m->sw.multi_split)      // (PPS_MULTI_SPLIT: the multi-chunk scheduler on a small batch -- tests)
+                                            : (int)std::min<long long>(3, std::max<long long>(1, total_factors / 250000));
   const bool two_streams = n_split > 1 && !m->profiling;
   const int CH = two_streams ? std::min(kBatchMax, (G + n_split - 1) / n_split) : kBatchMax;
   const int n_chunks = (G + CH - 1) / CH;
@@ -273,9 +278,11 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
-    q.lin_thread_form = (q.n_factors_total > 200000 && !getenv("PPS_MULTI_NO_THREAD_FORM")) || getenv("PPS_MULTI_THREAD_FORM");      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
+    const long long thr = m->sw.multi_thread_factors;          // 200 000 (PPS_MULTI_THREAD_FACTORS lowers it for the tests)
+    q.k2t_generic = m->sw.k2t_generic;
+    q.lin_thread_form = (q.n_factors_total > thr && !m->sw.multi_no_thread_form) || m->sw.multi_thread_form;      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
-    q.level_form = level_ok && ((q.n_factors_total > 200000 && !getenv("PPS_MULTI_NO_LEVELS")) || getenv("PPS_MULTI_LEVELS"));      // (PPS_MULTI_NO_*: A/B)
+    q.level_form = level_ok && ((q.n_factors_total > thr && !m->sw.multi_no_levels) || m->sw.multi_levels);      // (PPS_MULTI_NO_*: A/B)
     { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));
@@ -309,7 +316,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   for (int c = 0; c < n_chunks; c++) {
     BatchGeom& q = geom[c];
     for (int stg = 0; stg < q.n_stages && stg < 32; stg++) {
-      bool pre = q.stage_reg_only[stg] && !getenv("PPS_NO_PREASSEMBLE");
+      bool pre = q.stage_reg_only[stg] && !m->sw.no_preassemble;
       const int nw = q.stage_nw_factor[stg];
       for (int i = c * CH; pre && i < std::min(G, (c + 1) * CH); i++) {
         const Analysis& A = m->gs[i]->an;
@@ -330,7 +337,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       // narrowed to fill the device with groups (throughput: G = 32 and up) keeps the barrier form -- waves that spin on a flag hold
       // wave slots other groups could use (G = 32: 3.9 against 3.7 ms of back-substitution per batch solve)
       q.stage_nw_flow[stg] = 0;
-      if (!getenv("PPS_NO_SOLVE_FLOW") && q.stage_grp_fronts[stg] > 1 && q.stage_nw_solve[stg] >= std::min(8, q.stage_grp_fronts[stg])) {
+      if (!m->sw.no_solve_flow && q.stage_grp_fronts[stg] > 1 && q.stage_nw_solve[stg] >= std::min(8, q.stage_grp_fronts[stg])) {
         const size_t per_wave = (size_t)q.stage_per_wave_solve[stg] * sizeof(double);
         const size_t fixed = ((size_t)q.stage_grp_fronts[stg] * band_max_rows() + (size_t)(q.stage_grp_fronts[stg] + 1) / 2) * sizeof(double);
         const size_t lds_budget = 150 * 1024;
@@ -344,7 +351,9 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   }
   // ---- dual-lambda form: every graph walks lm_solve_dual's scheme, in lockstep rounds of one linearisation each ----
   const double t_setup = now_s() - t0;
-  const bool timing_rounds = getenv("PPS_MULTI_TIMING") && atoi(getenv("PPS_MULTI_TIMING")) > 1;
+  const bool timing_rounds = m->sw.multi_timing > 1;
+  m->n_chunks_last = n_chunks; m->forms_last = 0;
+  for (int c = 0; c < n_chunks; c++) m->forms_last |= (geom[c].lin_thread_form ? 1 : 0) | (geom[c].level_form ? 2 : 0);
 
   {
     std::vector<BatchAlt> ha(G);
@@ -462,11 +471,13 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     m->n_relin += G; m->n_solves += 2 * (long long)G;
     int n_flight = n_chunks;
     double t_progress = now_s();
-    static const bool lockstep = getenv("PPS_MULTI_LOCKSTEP") != nullptr;     // (A/B: a barrier over all chunks between rounds, as up to round 4)
+    const bool lockstep = m->sw.multi_lockstep;     // (A/B: a barrier over all chunks between rounds, as up to round 4)
+    // a HIP failure inside the loop: whatever the other chunks still have in flight is drained before the caller sees the error
+    auto drain = [&]() { for (hipStream_t s3 : streams) if (s3) (void)hipStreamSynchronize(s3); };
     while (n_flight > 0) {
-      bool progressed = false;
-      if (lockstep) { bool all = true; for (int c = 0; c < n_chunks; c++) all = all && (!cr[c].in_flight || chunk_done(c)); if (!all) continue; }
-      for (int c = 0; c < n_chunks; c++) {
+      bool progressed = false, hold = false;
+      if (lockstep) { bool all = true; for (int c = 0; c < n_chunks; c++) all = all && (!cr[c].in_flight || chunk_done(c)); hold = !all; }   // (falls through to the time-out below)
+      for (int c = 0; c < n_chunks && !hold; c++) {
         if (!cr[c].in_flight || !chunk_done(c)) continue;
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         progressed = true;
@@ -486,6 +497,13 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
             lm[i].last_notpd = r1[2] != 0.0;
             lm[i].n_notpd += lm[i].last_notpd ? 1 : 0;
           }
+          if (lm[i].active || cr[c].first) {                      // status words of this round's records (see wait_result, pps_solve.cpp)
+            const double* rr = m->results + 12 * (size_t)i;
+            if (rr[4 + 2] >= kStatusInternal || rr[8 + 2] >= kStatusInternal) {
+              drain();
+              return mfail(m, PPS_EHIP, "graph " + std::to_string(i) + ": internal error: a hand-over flag of the data-flow back-substitution never arrived");
+            }
+          }
           if (!lm[i].done) advance(i); else { lm[i].active = false; lm[i].relin = false; }
           n_active += lm[i].active ? 1 : 0;
         }
@@ -496,7 +514,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         const BatchArgs a = make_args(c, cr[c].seq);
         bool any_relin = false;
         for (int k = 0; k < a.n; k++) { any_relin = any_relin || (a.flags[k] & BF_RELIN); m->n_solves += (a.flags[k] & BF_ACTIVE) ? 2 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
-        int rc = run_round(a, geom[c], false, any_relin, stream_of(c)); if (rc != PPS_OK) return rc;
+        int rc = run_round(a, geom[c], false, any_relin, stream_of(c)); if (rc != PPS_OK) { drain(); return rc; }
       }
       if (progressed) { t_progress = now_s(); continue; }
       if (now_s() - t_progress > 2.0) {                        // (nothing for two seconds: let the streams drain, look once more)
@@ -505,7 +523,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         MHIP(m, hipStreamSynchronize(m->stream3));
         bool any_done = false;
         for (int c = 0; c < n_chunks; c++) any_done = any_done || (cr[c].in_flight && chunk_done(c));
-        if (!any_done) return mfail(m, PPS_EHIP, "result records of a round did not arrive");
+        if (!any_done) return mfail(m, PPS_EHIP, "result records of a round did not arrive");     // (all three streams are idle here)
       }
     }
     for (int c = 0; c < n_chunks; c++) m->rounds = std::max(m->rounds, cr[c].rounds);
@@ -521,7 +539,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     }
     int first_bad = PPS_OK;
     m->t_total = now_s() - t0;
-    if (getenv("PPS_MULTI_TIMING"))
+    if (m->sw.multi_timing)
       fprintf(stderr, "pps_multi: G %d total %.3f ms, of which setup %.3f (per-graph checks %.3f, tables %.3f, geometry %.3f); %d rounds\n", G,
               1e3 * m->t_total, 1e3 * t_setup, 1e3 * t_s1, 1e3 * (t_s2 - t_s1), 1e3 * (t_setup - t_s2), m->rounds);
     for (int i = 0; i < G; i++) {
@@ -550,10 +568,10 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
 
 int pps_multi_set_profiling(pps_multi* m, int level) { if (!m) return PPS_EINVAL; m->profiling = level > 0 ? 1 : 0; return PPS_OK; }
 
-int pps_multi_phase_times(const pps_multi* m, double sec[5], long long counts[2]) {
+int pps_multi_phase_times(const pps_multi* m, double sec[5], long long counts[4]) {
   if (!m || !sec) return PPS_EINVAL;
   for (int k = 0; k < 5; k++) sec[k] = m->t_phase[k];
-  if (counts) { counts[0] = m->n_relin; counts[1] = m->n_solves; }
+  if (counts) { counts[0] = m->n_relin; counts[1] = m->n_solves; counts[2] = m->n_chunks_last; counts[3] = m->forms_last; }
   return PPS_OK;
 }
 

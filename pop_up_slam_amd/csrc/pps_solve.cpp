@@ -142,6 +142,9 @@ int wait_result(pps_graph* g, volatile double* slot, double seq, hipStream_t pro
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // status word of the solve that produced the record: 0 ok | 1 not positive definite | >= 64 an internal hand-over of the
+  // back-substitution timed out (flow_wait, pps_k3.hip) -- the numbers of this record are not a solution
+  if (slot[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag of the data-flow back-substitution never arrived (the step was discarded)");
   return PPS_OK;
 }
 
@@ -180,6 +183,7 @@ int read_result(pps_graph* g, bool at_estimate, double* chi2, double* dnorm, boo
   *chi2 = g->host_result[0];
   if (dnorm) *dnorm = std::sqrt(g->host_result[1]);
   if (notpd) *notpd = g->host_result[2] != 0.0;
+  if (g->host_result[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag of the data-flow back-substitution never arrived (the step was discarded)");
   return PPS_OK;
 }
 
@@ -313,7 +317,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   // Speculation costs what it computes: on a graph whose lower tree levels fill the GPU by themselves (C3: 5 359 fronts) the second
   // factorisation + back-substitution of a launch set are extra time, not idle lanes -- and LM accepts most steps there.  Such a
   // graph factors the second damping value only while LM zig-zags (after a rejection); the trace is the same either way.
-  const bool adaptive = A.n_fronts >= 2048 && !getenv("PPS_ALWAYS_DUAL");
+  const bool adaptive = A.n_fronts >= 2048 && !g->sw.always_dual;
   bool use_alt = !adaptive;
   bool have_next = true;                 // trial 1 of the last launch is the step for the next lambda after a rejection
   auto enqueue_dual = [&](double lam) -> int {
@@ -346,7 +350,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   // Accept-branch speculation: the relinearisation that follows an accepted step is queued behind the trials before their
   // verdict is known; its kernels apply the accept test themselves (LinGuard) and pick the accepted copy, so the device does
   // not idle for the host round trip between chi2 and K1.
-  const bool spec_lin = !getenv("PPS_NO_SPEC_LIN");
+  const bool spec_lin = !g->sw.no_spec_lin;
   int spec_pair = -1;                    // K1 event pair of the queued speculative linearisation
   auto enqueue_spec_lin = [&](double err) -> int {
     if (!spec_lin) return PPS_OK;
@@ -433,7 +437,7 @@ static int lm_solve(pps_graph* g, int* iterations) {
   g->tr_lambda.clear(); g->tr_chi2.clear(); g->tr_acc.clear();
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
-  if (g->use_band && g->profiling < 2 && !g->dev.trace && !getenv("PPS_NO_DUAL")) return lm_solve_dual(g, iterations, t0);      // (PPS_NO_DUAL: the loop-forms parity test)
+  if (g->use_band && g->profiling < 2 && !g->dev.trace && !g->sw.no_dual) return lm_solve_dual(g, iterations, t0);      // (PPS_NO_DUAL: the loop-forms parity test)
   const pps_props& prop = g->props;
   if (!g->status_clean) HIP_TRY(g, launch_clear_status(g->dev, g->stream));
   g->status_clean = false;

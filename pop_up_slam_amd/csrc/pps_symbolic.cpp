@@ -478,7 +478,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
                  Analysis& A, const char** msg, bool general_ordering, AnalysisCache* C, bool reuse) {
   static const char* kOk = "";
   *msg = kOk;
-  const bool timing = getenv("PPS_ANALYSIS_TIMING") != nullptr;
+  const bool timing = prm.timing != 0;
   auto t_prev = std::chrono::steady_clock::now();
   const int N = (int)nodes.size();
   if (N == 0) { reset_keep_capacity(A); *msg = "empty graph"; return 0; }

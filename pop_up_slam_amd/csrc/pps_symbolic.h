@@ -46,6 +46,7 @@ struct AnalysisParams {
   int band_rows = 127;     // largest front of the wave-per-front kernels: graphs beyond it skip the packed extend-add lists
   int dense_min = 64;      // a node is "dense" if degree > max(dense_min, dense_mult*sqrt(N))
   double dense_mult = 8.0;
+  int timing = 0;          // per-phase host times to stderr (Switches::analysis_timing of the handle)
 };
 
 struct Analysis {

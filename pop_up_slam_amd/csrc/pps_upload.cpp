@@ -133,7 +133,7 @@ int flush_uploads(pps_graph* g) {
 // loop under it.
 int verify_uploads(pps_graph* g, const char* where) {
   if (g->hint_violation) { g->hint_violation = false; return fail(g, PPS_ESTATE, std::string("upload verification (") + where + "): an array differs from the mirror inside the part the analysis reported as kept"); }
-  if (!getenv("PPS_DEBUG_VERIFY_UPLOAD") || g->up_high == 0 || g->up.spill) return PPS_OK;
+  if (!g->sw.verify_upload || g->up_high == 0 || g->up.spill) return PPS_OK;
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   std::vector<char> dev(g->up_high);
   HIP_TRY(g, hipMemcpy(dev.data(), g->up.base, g->up_high, hipMemcpyDeviceToHost));
@@ -199,7 +199,7 @@ static int run_analysis_impl(pps_graph* g) {
   // A graph that only grew since the last analysis (the frame loop) appends to the compacted tables instead of walking
   // every node and factor again; re-popping edges are ordered behind the fixed ones, which moves slots: they take the full path.
   bool append = g->cmp_valid && g->grown_only && g->n_analyses > 0 && !g->cmp_has_repop && g->cmp_nodes <= g->nodes.size() &&
-                g->cmp_factors <= g->factors.size() && !getenv("PPS_NO_INCR_COMPACT");
+                g->cmp_factors <= g->factors.size() && !g->sw.no_incr_compact;
   for (size_t i = g->cmp_factors; append && i < g->factors.size(); i++)
     append = !g->factors[i].deleted && !(g->factors[i].type == F_PLANE_OBS && g->factors[i].repop);
   for (size_t i = g->cmp_nodes; append && i < g->nodes.size(); i++) append = !g->nodes[i].deleted;
@@ -300,16 +300,16 @@ static int run_analysis_impl(pps_graph* g) {
   g->aprm.band_rows = band_front_limit();
   const char* msg = "";
   try {
-  if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "compaction (api)", 1e3 * (now_s() - t0));
+  if (g->sw.analysis_timing) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "compaction (api)", 1e3 * (now_s() - t0));
   if (!g->acache) g->acache = analysis_cache_new();
-  if (!analyze(sn, sf, g->aprm, g->an, &msg, getenv("PPS_NO_INCREMENTAL") ? nullptr : g->acache))
+  if (!analyze(sn, sf, g->aprm, g->an, &msg, g->sw.no_incremental ? nullptr : g->acache))
     return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
   // fronts beyond the wave-per-front kernels (loop-closure separators) run in the dense-front form, whose cost is
   // per tree level: split their supernodes into 64-pivot chunks instead of 48 (a quarter fewer levels)
   if (g->an.max_front > band_front_limit() && g->aprm.max_pivots < dense_front_max_pivots()) {
     AnalysisParams wide = g->aprm;
     wide.max_pivots = dense_front_max_pivots();
-    if (!analyze(sn, sf, wide, g->an, &msg, getenv("PPS_NO_INCREMENTAL") ? nullptr : g->acache))
+    if (!analyze(sn, sf, wide, g->an, &msg, g->sw.no_incremental ? nullptr : g->acache))
       return fail(g, PPS_EINVAL, std::string("analysis failed: ") + msg);
   }
   } catch (const std::bad_alloc&) {
@@ -358,7 +358,7 @@ static int run_analysis_impl(pps_graph* g) {
     const int max_waves = 8;
     for (int st = 0; st < A.n_stages; st++) {
       const int want = std::max(1, std::min(max_waves, A.stage_max_width[st]));
-      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st], A.stage_max_front[st] + 1 <= band_reg_rows() && !getenv("PPS_TRACE"))));
+      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st], A.stage_max_front[st] + 1 <= band_reg_rows() && g->sw.trace == 0)));
       int mg = 1;
       for (int gi = A.stage_grp_off[st]; gi < A.stage_grp_off[st + 1]; gi++)
         mg = std::max(mg, A.glvl_front_off[A.grp_lvl_off[gi + 1]] - A.glvl_front_off[A.grp_lvl_off[gi]]);
@@ -373,7 +373,7 @@ static int run_analysis_impl(pps_graph* g) {
     // k_band_factor_pre: groups of three or four local levels, every level in one round of the stage's waves, and the fronts of local
     // levels 2 and up on waves that idle from level 1 on (8 + 4 + 2 + 1 on eight waves: 4 + 2 + 1 <= 8)
     g->stage_pre.assign(A.n_stages, 0);
-    if (!getenv("PPS_NO_PREASSEMBLE"))
+    if (!g->sw.no_preassemble)
       for (int st = 0; st < A.n_stages; st++) {
         bool ok = A.stage_grp_off[st + 1] > A.stage_grp_off[st] && A.stage_max_front[st] + 1 <= band_reg_rows();
         const int nw = g->stage_nw_factor[st];
@@ -394,7 +394,7 @@ static int run_analysis_impl(pps_graph* g) {
   if (!g->use_band && !g->use_dense && g->an.max_front > 4096)
     return fail(g, PPS_ENOMEM, "fronts too wide for this ordering (max front " + std::to_string(g->an.max_front) +
                                " scalars): the pose chain is not a good dissection backbone for this graph");
-  if (getenv("PPS_ANALYSIS_TIMING")) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "total incl. api", 1e3 * (now_s() - t0));
+  if (g->sw.analysis_timing) fprintf(stderr, "[analysis] %-22s %8.3f ms\n", "total incl. api", 1e3 * (now_s() - t0));
   g->analyzed = true; g->analysis_stale = false;
   g->n_analyses++; g->grown_only = true;
   g->an_base_seq = g->an_seq; g->an_seq++;                // (an.kept is relative to the analysis this one replaced)
@@ -521,8 +521,8 @@ int upload_measurements(pps_graph* g) {
 int upload_all(pps_graph* g) {
   const double t0 = now_s();
   const bool was_grown_only = g->grown_only_upload;
-  const bool tm = getenv("PPS_UPLOAD_TIMING") != nullptr;
-  g->verify_hints = getenv("PPS_DEBUG_VERIFY_UPLOAD") != nullptr;
+  const bool tm = g->sw.upload_timing;
+  g->verify_hints = g->sw.verify_upload;
   double tl = t0;
   auto lap = [&](const char* what) { if (!tm) return; const double t = now_s(); g->up_laps[what] += t - tl; tl = t; };
   int rc = ensure_device(g);
@@ -563,13 +563,14 @@ int upload_all(pps_graph* g) {
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
   // the mirror holds the arrays of the analysis this one was built upon: its kept parts are not compared again
-  const bool hints = was_grown_only && !g->up_unknown && g->up_an_seq >= 0 && g->an_base_seq == g->up_an_seq && !getenv("PPS_NO_UPLOAD_HINTS");
+  const bool hints = was_grown_only && !g->up_unknown && g->up_an_seq >= 0 && g->an_base_seq == g->up_an_seq && !g->sw.no_upload_hints;
   const Analysis::Kept K = hints ? A.kept : Analysis::Kept();
   const size_t kF = (size_t)K.fronts, kFl = (size_t)K.fronts_lists, kB = (size_t)K.blocks, kS = (size_t)K.segs;
   auto at = [](const auto& v, size_t i) -> size_t { return i < v.size() ? (size_t)v[i] : 0; };     // (0 = no claim)
   double* zero_block = nullptr; size_t zero_doubles = 0;
   d.n_pose = (int)g->pose_ids.size(); d.n_plane = (int)g->plane_ids.size();
-  d.no_strip = getenv("PPS_NO_STRIP") ? 1 : 0;
+  d.no_strip = g->sw.no_strip ? 1 : 0;
+  d.sw = g->sw.dev_bits();
   HIP_TRY(g, step_constants(d.step_ac));
   d.pose_ld = std::max(1, (d.n_pose + 63) / 64 * 64); d.plane_ld = std::max(1, (d.n_plane + 63) / 64 * 64);
 #define TRY(x) do { rc = (x); if (rc != PPS_OK) return rc; } while (0)
@@ -752,8 +753,8 @@ int upload_all(pps_graph* g) {
   TRY(dev_alloc(g, &g->spec_pose, state_doubles + 1)); g->spec_plane = g->spec_pose + (size_t)7 * d.pose_ld;
   TRY(dev_alloc(g, &g->spec_chi2_partials, (size_t)std::max(1, d.chi2_blocks)));
   TRY(dev_alloc(g, &g->spec_dn_partials, (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1));
-  if (const char* e = getenv("PPS_TRACE")) d.trace_solve = atoi(e) >= 2 ? 1 : 0;
-  if (getenv("PPS_TRACE")) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
+  d.trace_solve = g->sw.trace >= 2 ? 1 : 0;
+  if (g->sw.trace) { TRY(dev_alloc(g, &d.trace, (size_t)A.n_fronts * 8)); HIP_TRY(g, hipMemset(d.trace, 0, (size_t)A.n_fronts * 64)); }
   // fronts that exceed the LDS limit run from a global workspace (one slab per front of the widest level)
   if (!g->use_band && !g->use_dense && A.max_front > lds_front_limit()) {
     const int fa = A.max_front + 1;
@@ -771,7 +772,7 @@ int upload_all(pps_graph* g) {
   // one launch for both expansions when every H block is assembled by exactly one front (always, unless an analysis ever lists a block
   // twice or not at all: then the fill of blk_dst has to run first, in a launch of its own)
   const bool one_launch = A.ea_total > 0 && zero_doubles < (size_t)1 << 30 && (int)A.asm_blk.size() == A.n_blocks && A.n_fronts > 0 &&
-                          !getenv("PPS_SPLIT_EXPAND");
+                          !g->sw.split_expand;
   if (one_launch) HIP_TRY(g, launch_expand_lists(d, A.n_fronts, (int)A.asm_blk.size(), zero_block, zero_doubles, g->stream));
   else {
     const size_t n_dst = (size_t)std::max(1, A.blk_doff[A.n_blocks]);

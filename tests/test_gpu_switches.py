@@ -1,5 +1,7 @@
-"""GPU: the A/B switches of round 4 select between two schedules of the same arithmetic.  They are read once per process, so every
-side runs in a process of its own; each side must reproduce the default build's LM traces, chi2 and iteration counts bit for bit."""
+"""GPU: the A/B switches select between two schedules of the same arithmetic.  A handle reads them once, when it is created (round 5:
+Switches, csrc/pps_device.h); every side still runs in a process of its own, with the variable set for the whole process, as the
+A/B tools do.  Each side must reproduce the default schedule's LM traces, chi2 and iteration counts bit for bit.  Plus: the time-out
+path of the data-flow back-substitution (PPS_DEBUG_DROP_FLAG) must fail loudly, not return numbers."""
 import json
 import os
 import subprocess
@@ -48,7 +50,8 @@ if "frames" in parts:                       # a graph that grows: update() every
     it = g.batch_optimize()
     out["frames"] = [int(it), thash(g), g.chi2(), hashlib.sha1(np.asarray(chis).tobytes()).hexdigest()]
     g.close()
-if "multi" in parts:                        # 32 C2-size graphs: the throughput forms chosen by size
+if "multi" in parts:                        # 32 C2-size graphs cut into three chunks that advance on their own streams, every chunk in
+    import os                               # the throughput forms (PPS_MULTI_SPLIT / PPS_MULTI_THREAD_FACTORS: what a batch of > 750 000 factors takes)
     seeds = [42, 135, 110, 143, 225, 154, 169, 185]
     specs = {sd: synth.corridor(seed=sd) for sd in seeds}
     gs = []
@@ -56,9 +59,41 @@ if "multi" in parts:                        # 32 C2-size graphs: the throughput 
         g = P.Graph(); specs[seeds[k %% 8]].replay(g); gs.append(g)
     m = P.Multi(gs)
     its, st = m.optimize()
+    ph = m.phase_times()
     out["multi"] = [[int(x) for x in its], [int(x) for x in st], [g.chi2() for g in gs], [thash(g) for g in gs[:8]], m.rounds()]
+    out["multi_forms"] = [ph["n_chunks"], ph["thread_form"], ph["level_form"]]
     m.close()
     for g in gs: g.close()
+    # the same eight graphs through their own handles, in the K1 form the chunks took (a handle reads the switch when it is created)
+    os.environ["PPS_K1_THREAD_FORM"] = "1"
+    single = []
+    for sd in seeds:
+        g = P.Graph(); specs[sd].replay(g)
+        it = g.batch_optimize()
+        single.append([int(it), thash(g), g.chi2()]); g.close()
+    del os.environ["PPS_K1_THREAD_FORM"]
+    out["multi_single"] = single
+if "drop" in parts:                         # PPS_DEBUG_DROP_FLAG=1: the top front of every band group withholds its hand-over flag
+    res = {}
+    spec = synth.corridor(300, 60, seed=4)
+    g = P.Graph(); spec.replay(g)
+    try:
+        g.batch_optimize(); res["single"] = "returned"
+    except P.PpsError as e:
+        res["single"] = [e.code, str(e)]
+    try:
+        g.update(); res["update"] = "returned"
+    except P.PpsError as e:
+        res["update"] = [e.code, str(e)]
+    gs = []
+    for sd in (4, 5):
+        h = P.Graph(); synth.corridor(300, 60, seed=sd).replay(h); gs.append(h)
+    m = P.Multi(gs)
+    try:
+        m.optimize(); res["multi"] = "returned"
+    except P.PpsError as e:
+        res["multi"] = [e.code, str(e)]
+    out["drop"] = res
 print("RESULT " + json.dumps(out))
 """ % ROOT
 
@@ -66,7 +101,7 @@ print("RESULT " + json.dumps(out))
 def _run(parts, **env):
     e = dict(os.environ)
     for k in ("PPS_ALWAYS_DUAL", "PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE", "PPS_SPLIT_EXPAND", "PPS_NO_UPLOAD_HINTS", "PPS_K2T_GENERIC",
-              "PPS_MULTI_LOCKSTEP"):
+              "PPS_MULTI_LOCKSTEP", "PPS_MULTI_SPLIT", "PPS_MULTI_THREAD_FACTORS", "PPS_DEBUG_DROP_FLAG", "PPS_K1_THREAD_FORM"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", CHILD, parts], env=e, capture_output=True, text=True, timeout=600)
@@ -77,7 +112,30 @@ def _run(parts, **env):
 
 @pytest.fixture(scope="module")
 def default_run(built):
-    return _run("single,frames,multi,large")
+    return _run("single,frames,large")
+
+
+MULTI_ENV = dict(PPS_MULTI_SPLIT=3, PPS_MULTI_THREAD_FACTORS=50000)
+
+
+@pytest.fixture(scope="module")
+def multi_run(built):
+    return _run("multi", **MULTI_ENV)
+
+
+def test_multi_chunk_scheduler_against_single_handles(multi_run):
+    """three chunks of 11 / 11 / 10 graphs on three streams, each advancing as soon as ITS records are in, K1 / K2 / K3 in the
+    throughput forms: per graph the iteration count, the LM trace and chi2 of its own handle running the same K1 form"""
+    its, st, chi, hashes, rounds = multi_run["multi"]
+    assert multi_run["multi_forms"] == [3, True, True]
+    assert all(s == 0 for s in st) and min(its) >= 10
+    single = multi_run["multi_single"]
+    for k in range(32):
+        it1, h1, c1 = single[k % 8]
+        assert its[k] == it1 and chi[k] == c1, k
+        if k < 8:
+            assert hashes[k] == h1, k
+    assert 1 <= rounds <= max(its) + 1
 
 
 @pytest.mark.parametrize("switch", ["PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE"])
@@ -104,8 +162,19 @@ def test_upload_forms(default_run):
 
 
 @pytest.mark.parametrize("switch", ["PPS_K2T_GENERIC", "PPS_MULTI_LOCKSTEP"])
-def test_large_batch_schedules(default_run, switch):
-    """K2's one-body throughput form / a barrier over all chunks between rounds"""
-    got = _run("multi", **{switch: 1})
-    assert got["multi"] == default_run["multi"], switch
-    assert all(s == 0 for s in default_run["multi"][1]) and min(default_run["multi"][0]) >= 10
+def test_large_batch_schedules(multi_run, switch):
+    """K2's one-body throughput form / a barrier over all chunks between rounds -- on a batch that really runs the class-body K2 and
+    more than one chunk (multi_forms)"""
+    got = _run("multi", **dict(MULTI_ENV, **{switch: 1}))
+    assert got["multi_forms"] == multi_run["multi_forms"] == [3, True, True]
+    assert got["multi"] == multi_run["multi"], switch
+
+
+def test_flow_timeout_fails_loudly(built):
+    """a hand-over flag of the data-flow back-substitution that never arrives: the waiting wave gives up after its bounded spin, raises
+    the status word, and every solve entry returns PPS_EHIP with a message -- never a step computed from a stale solution"""
+    import pop_up_slam_amd as P
+    got = _run("drop", PPS_DEBUG_DROP_FLAG=1)["drop"]
+    for k in ("single", "update", "multi"):
+        assert got[k] != "returned", k
+        assert got[k][0] == P.PPS_EHIP and "hand-over flag" in got[k][1], (k, got[k])

@@ -13,6 +13,14 @@ I6 = synth._ut_diag([1.0] * 6)
 I3 = synth._ut_diag([1.0] * 3)
 
 
+
+def _scratch_graph(monkeypatch):
+    """a handle whose every analysis starts from scratch: the switches are read once, when the handle is created"""
+    monkeypatch.setenv("PPS_NO_INCREMENTAL", "1"); monkeypatch.setenv("PPS_NO_INCR_COMPACT", "1")
+    g = P.Graph()
+    monkeypatch.delenv("PPS_NO_INCREMENTAL"); monkeypatch.delenv("PPS_NO_INCR_COMPACT")
+    return g
+
 def _grow(g, st, fr):
     p = g.add_pose(fr.true_pose)
     if st["prev"] is None:
@@ -31,16 +39,14 @@ def _grow(g, st, fr):
 def test_incremental_analysis_equals_analysis_from_scratch(built, monkeypatch):
     n = 260
     frames = pipeline.popup_sequence(n, seed=5)
-    gi, gf = P.Graph(), P.Graph()
+    gi, gf = P.Graph(), _scratch_graph(monkeypatch)
     si, sf = {"prev": None, "lm": {}}, {"prev": None, "lm": {}}
     kept = []
     for k, fr in enumerate(frames):
         _grow(gi, si, fr); _grow(gf, sf, fr)
         gi.analyze()
         kept.append(gi.analysis_reuse())
-        monkeypatch.setenv("PPS_NO_INCREMENTAL", "1"); monkeypatch.setenv("PPS_NO_INCR_COMPACT", "1")   # tables rebuilt, analysis from scratch
-        gf.analyze()
-        monkeypatch.delenv("PPS_NO_INCREMENTAL"); monkeypatch.delenv("PPS_NO_INCR_COMPACT")
+        gf.analyze()                                                 # (tables rebuilt, analysis from scratch: _scratch_graph)
         assert gf.analysis_reuse()[0] == 0
         if k % 5 == 0 or k >= n - 3:
             a, b = gi.analysis_dump(), gf.analysis_dump()
@@ -60,7 +66,7 @@ def test_incremental_analysis_survives_removals_and_odd_sequences(built, monkeyp
     analysis from scratch of the same graph"""
     rng = np.random.default_rng(seed)
     frames = pipeline.popup_sequence(150, seed=20 + seed)
-    gi, gf = P.Graph(), P.Graph()
+    gi, gf = P.Graph(), _scratch_graph(monkeypatch)
     si, sf = {"prev": None, "lm": {}}, {"prev": None, "lm": {}}
     poses = []                                                     # ids are the same in both graphs (same call sequence)
     n_cmp = 0
@@ -83,9 +89,7 @@ def test_incremental_analysis_survives_removals_and_odd_sequences(built, monkeyp
         if rng.random() < 0.3: continue                            # several frames between two analyses
         reps = 2 if rng.random() < 0.1 else 1                      # ... or the same graph analysed twice
         for _ in range(reps): gi.analyze()
-        monkeypatch.setenv("PPS_NO_INCREMENTAL", "1"); monkeypatch.setenv("PPS_NO_INCR_COMPACT", "1")
         for _ in range(reps): gf.analyze()                         # (the same number of analyses: an unchanged graph analysed again takes the frame-loop parameters)
-        monkeypatch.delenv("PPS_NO_INCREMENTAL"); monkeypatch.delenv("PPS_NO_INCR_COMPACT")
         a, b = gi.analysis_dump(), gf.analysis_dump()
         for key in b:
             np.testing.assert_array_equal(np.atleast_1d(a[key]), np.atleast_1d(b[key]), err_msg=f"seed {seed} frame {k}: {key}")
