@@ -34,9 +34,11 @@ Switches read_switches() {
   s.multi_no_thread_form = on("PPS_MULTI_NO_THREAD_FORM");
   s.multi_lockstep = on("PPS_MULTI_LOCKSTEP");
   s.debug_drop_flag = on("PPS_DEBUG_DROP_FLAG");
+  s.no_duo = on("PPS_NO_DUO");
   s.trace = (int)num("PPS_TRACE", 0);
   s.multi_timing = (int)num("PPS_MULTI_TIMING", 0);
   s.multi_split = (int)num("PPS_MULTI_SPLIT", 0);
+  s.band_levels = (int)num("PPS_BAND_LEVELS", 0);
   s.multi_thread_factors = num("PPS_MULTI_THREAD_FACTORS", 200000);
   if (on("PPS_TRACE") && s.trace < 1) s.trace = 1;
   if (on("PPS_MULTI_TIMING") && s.multi_timing < 1) s.multi_timing = 1;

@@ -67,6 +67,11 @@ struct DevGraph {
   int *blk_doff = nullptr, *blk_dst = nullptr;
   double* Hf = nullptr;      // H in front gather order: front s reads Hf[f_el_off[s] .. f_el_off[s+1])
   int64_t* f_ea_off = nullptr; int* ea_tgt = nullptr;
+  // two waves per front (pps_front_duo.h): per child RECORD (crec index) the split of the child's packed update matrix between the
+  // parent's two waves -- entries [0, split) land in rows of the parent below r1, the row that halves the children's entries; filled
+  // on the device by the list expansion (expand_split, pps_k3.hip)
+  int* c_split = nullptr;
+  int* f_crec0 = nullptr;            // front id -> first child record
   int *grp_lvl_off = nullptr, *glvl_front_off = nullptr, *glvl_fronts = nullptr;
   int* grp_span = nullptr;          // per band group, 8 ints: first position in glvl order, fronts, local levels, first position of local levels 1 .. 4, 0
   int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
@@ -104,7 +109,7 @@ struct DevGraph {
 // pps_multi_create / pps_popup_create ... call read_switches() -- and never on a launch path: a handle keeps the schedule it was
 // created with whatever the environment does later (A/B tools and the parity tests set the variable before they create the handle).
 constexpr double kStatusInternal = 64.0;   // result_dev[2] at or above this: an internal time-out inside a kernel (PPS_EHIP), not a not-PD pivot
-enum : unsigned { SW_K1_THREAD_FORM = 1u, SW_NO_SOLVE_FLOW = 2u, SW_NO_ROOT_FUSE = 4u, SW_DEBUG_DROP_FLAG = 8u };
+enum : unsigned { SW_K1_THREAD_FORM = 1u, SW_NO_SOLVE_FLOW = 2u, SW_NO_ROOT_FUSE = 4u, SW_DEBUG_DROP_FLAG = 8u, SW_NO_DUO = 16u };
 struct Switches {
   bool k1_thread_form = false;      // PPS_K1_THREAD_FORM: thread-per-factor K1 (no product records) on graphs of any size
   bool no_preassemble = false;      // PPS_NO_PREASSEMBLE: plain walk of a band group instead of k_band_factor_pre
@@ -124,14 +129,16 @@ struct Switches {
   bool k2t_generic = false;         // PPS_K2T_GENERIC: one-body throughput form of K2
   bool multi_levels = false, multi_no_levels = false, multi_thread_form = false, multi_no_thread_form = false;   // PPS_MULTI_*
   bool multi_lockstep = false;      // PPS_MULTI_LOCKSTEP: a barrier over all chunks between rounds
+  bool no_duo = false;              // PPS_NO_DUO: one wave per front everywhere (no helper waves in the band factorisation)
   bool debug_drop_flag = false;     // PPS_DEBUG_DROP_FLAG: the data-flow back-substitution withholds one hand-over flag (tests the time-out path)
   int trace = 0;                    // PPS_TRACE: 1 = phase timestamps of the factorisation, 2 = of the back-substitution
   int multi_timing = 0;             // PPS_MULTI_TIMING
+  int band_levels = 0;              // PPS_BAND_LEVELS: tree levels per band launch (0 = by graph size)
   int multi_split = 0;              // PPS_MULTI_SPLIT: chunks a batch is cut into (0 = by size)
   long long multi_thread_factors = 200000;   // PPS_MULTI_THREAD_FACTORS: factors per chunk above which a batch takes the throughput forms
   unsigned dev_bits() const {
     return (k1_thread_form ? SW_K1_THREAD_FORM : 0u) | (no_solve_flow ? SW_NO_SOLVE_FLOW : 0u) | (no_root_fuse ? SW_NO_ROOT_FUSE : 0u) |
-           (debug_drop_flag ? SW_DEBUG_DROP_FLAG : 0u);
+           (debug_drop_flag ? SW_DEBUG_DROP_FLAG : 0u) | (no_duo ? SW_NO_DUO : 0u);
   }
 };
 Switches read_switches();           // pps_api.cpp: the only place of the library that calls getenv
@@ -190,7 +197,8 @@ hipError_t launch_band_factor_dual(const DevGraph& d, const DualAlt& alt, int gr
 // the last factor stage and the first back-substitution stage as one launch, where band_root_fusable says so
 bool band_root_fusable(const DevGraph& d, int grp_count, int max_front);
 hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,
-                            int max_group_fronts, double lambda, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);      // ev0 / ev1: the dispatch's start / stop (profiling level 1)
+                            int max_group_fronts, double lambda, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,      // ev0 / ev1: the dispatch's start / stop (profiling level 1)
+                            bool pre = false);                                                                                          // pre: the group fits the pre-assembling walk (stage_pre)
 // both trials of a dual solve: out_k <- base (+) delta_k, chi2 and |delta|^2 of each into its own result record
 hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,

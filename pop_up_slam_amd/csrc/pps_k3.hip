@@ -13,7 +13,7 @@
 
 #include "pps_kcommon.h"
 #include "pps_regtile.h"
-#include "pps_front_reg.h"
+#include "pps_front_duo.h"
 
 namespace pps {
 
@@ -150,13 +150,66 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
 // ------------------------------------------------------------------------------------------
 constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
 
+// The split of a front's children between its two waves (DevGraph::c_split), by the workgroup that expands front s' own list: the
+// parent row r1 below which half of all the children's entries land -- a child's rows map to increasing parent rows (cmap), so "target
+// row < r1" is a leading range of the child's packed triangle -- and per child the length of that range.  A map that is not increasing
+// leaves the whole child with the front's own wave.  64 threads; sh: 8 ints of LDS.
+__device__ __forceinline__ void expand_split(const DevGraph& d, int s, int* sh) {
+  if (!d.c_split) return;
+  const int nch = d.f_child_off[s + 1] - d.f_child_off[s];
+  if (nch <= 0) return;
+  // (the records sit in band-schedule order; the front's own position is found through its children's shared parent record: every
+  // record of a parent is consecutive, and record k of the parent belongs to child d.child[f_child_off[s] + k])
+  const int fa = d.f_p[s] + d.f_b[s] + 1;
+  const int tid = threadIdx.x;
+  if (tid == 0) { sh[0] = fa; sh[1] = 1; sh[2] = 0; }
+  __syncthreads();
+  long long wtot = 0;
+  for (int k = 0; k < nch; k++) {
+    const int c = d.child[d.f_child_off[s] + k];
+    const int* __restrict__ m = d.cmap + d.f_cmap_off[c];
+    const int len = d.f_cmap_off[c + 1] - d.f_cmap_off[c];
+    wtot += (long long)len * (len + 1) / 2;
+    for (int i = tid; i < len; i += 64) if (m[i] < 0 || m[i] >= fa || (i > 0 && m[i] <= m[i - 1])) sh[1] = 0;
+  }
+  __syncthreads();
+  const bool mono = sh[1] != 0;
+  // smallest r with 2 W(r) >= Wtot, W(r) = entries of all children in parent rows below r
+  for (int r = tid; mono && r <= fa; r += 64) {
+    long long w = 0;
+    for (int k = 0; k < nch; k++) {
+      const int c = d.child[d.f_child_off[s] + k];
+      const int* __restrict__ m = d.cmap + d.f_cmap_off[c];
+      const int len = d.f_cmap_off[c + 1] - d.f_cmap_off[c];
+      int cnt = 0;
+      for (int i = 0; i < len; i++) cnt += m[i] < r ? 1 : 0;
+      w += (long long)cnt * (cnt + 1) / 2;
+    }
+    if (2 * w >= wtot) atomicMin(&sh[0], r);
+  }
+  __syncthreads();
+  const int r1 = sh[0];
+  // the parent's first child record: frec position of s -> through d.f_crec0 (host: position-ordered records)
+  const int cr0 = d.f_crec0[s];
+  for (int k = tid; k < nch; k += 64) {
+    const int c = d.child[d.f_child_off[s] + k];
+    const int* __restrict__ m = d.cmap + d.f_cmap_off[c];
+    const int len = d.f_cmap_off[c + 1] - d.f_cmap_off[c];
+    int cnt = len;
+    if (mono) { cnt = 0; for (int i = 0; i < len; i++) cnt += m[i] < r1 ? 1 : 0; }
+    d.c_split[cr0 + k] = cnt * (cnt + 1) / 2;
+  }
+}
+
 // One workgroup per front: row i of its (b+1)-row packed update matrix goes to row cmap[i] of the parent.
 // The launch also clears what an upload needs cleared -- the zeroed block behind delta (tickets, result records, partial sums) and
 // blk_dst (0xff: "no element") for k_expand_el, which follows on the same stream -- instead of one fill kernel each.
 __global__ __launch_bounds__(64) void k_expand_ea(DevGraph d, double* __restrict__ zero, int n_zero, int* __restrict__ ones, int n_ones) {
+  __shared__ int sh[8];
   for (int i = blockIdx.x * 64 + threadIdx.x; i < n_zero; i += gridDim.x * 64) zero[i] = 0.0;
   for (int i = blockIdx.x * 64 + threadIdx.x; i < n_ones; i += gridDim.x * 64) ones[i] = -1;
   const int s = blockIdx.x;
+  expand_split(d, s, sh);
   const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
   const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
   int* __restrict__ out = d.ea_tgt + d.f_ea_off[s];
@@ -196,9 +249,11 @@ __global__ __launch_bounds__(256) void k_expand_el(DevGraph d, int n_asm) {
 // range itself (-1 for the upper triangle of a diagonal block, which no front gathers), so no fill has to run before it -- valid when
 // every H block is assembled by exactly one front (the caller checks).
 __global__ __launch_bounds__(64) void k_expand_lists(DevGraph d, double* __restrict__ zero, int n_zero, int n_fronts, int n_asm) {
+  __shared__ int sh[8];
   for (int i = blockIdx.x * 64 + threadIdx.x; i < n_zero; i += gridDim.x * 64) zero[i] = 0.0;
   if ((int)blockIdx.x < n_fronts) {
     const int s = blockIdx.x;
+    expand_split(d, s, sh);
     const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
     const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
     int* __restrict__ out = d.ea_tgt + d.f_ea_off[s];
@@ -255,9 +310,12 @@ int band_max_rows() { return kBandMaxRows; }
 // row, LDS-tile path): triangle | spare | panel buffer of 80 rows.
 size_t band_lds_bytes(int max_front, bool reg_only_kernel) {
   const size_t fa = (size_t)max_front + 1, ntri = fa * (fa + 1) / 2;
-  const size_t n = reg_only_kernel ? std::max<size_t>(ntri, (size_t)kRegRows * kP8Stride) + 1 : ntri + 1 + (size_t)kRegRowsMax * kP8Stride;
+  // (register-only band kernels: at least the four panel buffers of a front eliminated by two waves, pps_front_duo.h)
+  const size_t n = reg_only_kernel ? std::max<size_t>(ntri, (size_t)kDuoPanels * kDuoQ) + 1 : ntri + 1 + (size_t)kRegRowsMax * kP8Stride;
   return ((n + 1) & ~size_t(1)) * sizeof(double);      // (an even number of doubles: every wave's triangle starts 16-byte aligned)
 }
+// the hand-over flags of the two-wave fronts, behind the waves' triangles (k_band_factor_pre, kb_band_factor_pre)
+static size_t duo_flag_bytes(int nwaves) { return (size_t)nwaves * (kDuoFlags + kDuoMail) * sizeof(int); }
 
 // One row of 16x16 tiles (I, J = o, o+16, ..., I) of the trailing lower triangle gets its rank-nb
 // update C -= P_I P_J^T: all LDS reads are issued unconditionally from clamped (always valid)
@@ -495,7 +553,9 @@ __device__ __forceinline__ void front_pre_issue(const DevGraph& d, int rec, int 
   const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
   el_issue(d.el_tgt, d.Hf, e0, e1, lane, o.q);
-  o.crv = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;      // records of up to 8 children in one coalesced load
+  // records of up to 8 children in one load; slot 6 of a record comes from c_split (the child's split between the front's two waves)
+  const int* src = (lane & 7) == 6 ? d.c_split + cr0 + (lane >> 3) : d.crec + (size_t)cr0 * 8 + lane;
+  o.crv = (lane < 8 * nch) ? *src : 0;
 }
 __device__ __forceinline__ void front_clear(int rec, int lane, double* __restrict__ F) {
   const int ntri = tri(__builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1);
@@ -535,6 +595,67 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
       for (int e = 0; e < n; e += 64 * kEaDepth) { ElBatch<kEaDepth> q; el_issue(tgc, Uc, e, n, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<false>(q, 0.0, F, tr); }
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// The extend-add of a front with two waves (pps_front_duo.h): PART 0 = the entries of every child that land in parent rows below r1
+// ([0, split) of the child's packed triangle), PART 1 = the others.  r1 halves the TOTAL over the children, not each child, so a wave's
+// share of one child is anything between nothing and all of it: the shares of two children are walked as ONE list -- child A's entries,
+// then child B's -- seven items per lane in flight (448 entries: more than half of two separator fronts' update matrices, 14 loads per
+// lane), and a batch is applied in two sweeps, A's items first: every entry receives its contributions in the order child 0, child 1, ...
+template <int PART>
+__device__ __forceinline__ void front_extend_add_part(const DevGraph& d, int rec, int crv, int lane, double* __restrict__ F, int tr) {
+  const int nch = __builtin_amdgcn_readlane(rec, 6);           // (<= 8: checked by the caller)
+  constexpr int NB = 7;
+  auto child = [&](int cj, int& lo, int& hi, int& last, const double* __restrict__& Uc, const int* __restrict__& tgc) {
+    const int n = __builtin_amdgcn_readlane(crv, 8 * cj), sp = __builtin_amdgcn_readlane(crv, 8 * cj + 6);
+    const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
+    const long long eo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 4) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 3);
+    Uc = d.U + uo; tgc = d.ea_tgt + eo;
+    lo = PART ? sp : 0; hi = PART ? n : sp; last = n > 0 ? n - 1 : 0;
+  };
+  int cj = 0;
+  for (; cj + 1 < nch; cj += 2) {
+    int loa, hia, lasta, lob, hib, lastb; const double *Ua, *Ub; const int *ta, *tb;
+    child(cj, loa, hia, lasta, Ua, ta); child(cj + 1, lob, hib, lastb, Ub, tb);
+    const int lenA = hia - loa, T = lenA + hib - lob;
+    for (int e = 0; e < T; e += 64 * NB) {
+      int tg[NB]; double v[NB]; bool isa[NB], isb[NB];
+#pragma unroll
+      for (int u = 0; u < NB; u++) {
+        const int x = e + lane + 64 * u;
+        const bool ina = x < lenA;
+        isa[u] = ina; isb[u] = !ina && x < T;
+        int ia = loa + x, ib = lob + x - lenA;                   // (clamped to an entry that exists: nothing is predicated)
+        ia = ia < lasta ? ia : lasta; ib = ib < lastb ? ib : lastb; ib = ib > 0 ? ib : 0;
+        const int* pt = ina ? ta + ia : tb + ib;
+        const double* pv = ina ? Ua + ia : Ub + ib;
+        tg[u] = *pt; v[u] = *pv;
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        int t[NB]; double old[NB];
+#pragma unroll
+        for (int u = 0; u < NB; u++) { t[u] = isa[u] ? tg[u] : tr; old[u] = F[t[u]]; }
+#pragma unroll
+        for (int u = 0; u < NB; u++) F[t[u]] = old[u] + (isa[u] ? v[u] : 0.0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (e + 64 * NB > lenA) {                                  // (wave-uniform) the batch holds items of child B
+        int t[NB]; double old[NB];
+#pragma unroll
+        for (int u = 0; u < NB; u++) { t[u] = isb[u] ? tg[u] : tr; old[u] = F[t[u]]; }
+#pragma unroll
+        for (int u = 0; u < NB; u++) F[t[u]] = old[u] + (isb[u] ? v[u] : 0.0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (cj < nch) {
+    int lo, hi, last; const double* Uc; const int* tgc;
+    child(cj, lo, hi, last, Uc, tgc);
+    for (int e = lo; e < hi; e += 64 * kEaDepth) { ElBatch<kEaDepth> q; el_issue(tgc, Uc, e, hi, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<false>(q, 0.0, F, tr); }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -983,6 +1104,12 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
   }
 }
 
+// Two waves per front (pps_front_duo.h): bit 0 = the extend-add is split between a front's own wave and a helper, bit 1 = the
+// elimination.  BUILD-TIME, DEFAULT OFF: measured on C2 (round 5, tools/r5_ab_duo.sh, us per LM iteration, same box): one wave 65.0 /
+// elimination split 64.9 / both 66.0 / extend-add split alone 68.8 -- bit-identical LM traces in every variant; DESIGN.md section 8.
+#ifndef PPS_DUO_MODE
+#define PPS_DUO_MODE 0
+#endif
 #ifndef PPS_NPRE_BIG
 #define PPS_NPRE_BIG 8
 #endif
@@ -1014,37 +1141,105 @@ __device__ __forceinline__ int front_orig_entries_sized(const DevGraph& d, int r
 __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
   // (the host has checked the shape of every group of the stage: stage_pre in pps_upload.cpp.  Few values stay live across the levels:
   // this kernel's register allocation is at its limit, see body_band_factor)
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = uni(blockDim.x >> 6);
   const int4 ga = reinterpret_cast<const int4*>(d.grp_span)[2 * (size_t)g], gb = reinterpret_cast<const int4*>(d.grp_span)[2 * (size_t)g + 1];
-  const int g0 = uni(ga.x), nl = uni(ga.z), lo1 = uni(ga.w), lo2 = uni(gb.x);       // first positions of local levels 0, 1, 2
+  const int nl = uni(ga.z);
+  const int o0 = uni(ga.x), o1 = uni(ga.w), o2 = uni(gb.x), o3 = uni(gb.y), o4 = uni(gb.z);      // first positions of the local levels
+  const int n0 = o1 - o0, n1 = nl > 1 ? o2 - o1 : 0, n2 = nl > 2 ? o3 - o2 : 0, n3 = nl > 3 ? o4 - o3 : 0;
   double* F = lds + (size_t)wave * lds_doubles_per_wave;
   const int tr = lds_doubles_per_wave - 1;
-  // this wave's front on an upper level: its record and local level (0: none)
+  int* flags = reinterpret_cast<int*>(lds + (size_t)nw * lds_doubles_per_wave);                  // kDuoFlags ints per (owner) wave
+  int* mail = flags + nw * kDuoFlags;                                                            // kDuoMail ints per (owner) wave
+  // Which wave owns which front.  Shape B -- the whole group fits the waves (4 + 2 + 1 on eight): every upper front has a wave of its
+  // own, which assembles what needs no child while local level 0 is eliminated.  Shape A (8 + 4 + 2 + 1 on eight): level 1 on the waves
+  // that eliminated level 0, levels 2 and 3 on waves that idle from level 1 on and pre-assemble there.
+  const bool shape_b = n0 + n1 + n2 + n3 <= nw;
+  const int b1 = shape_b ? n0 : 0, b2 = shape_b ? n0 + n1 : n1, b3 = b2 + n2;                    // first owner wave of local levels 1, 2, 3
+  // this wave's front above level 0 that is assembled ahead of its level: its record and local level (0: none)
   int up_ll = 0, up_rec = 0;
   {
-    const int o1 = uni(ga.w), o2 = uni(gb.x), o3 = uni(gb.y), o4 = uni(gb.z);
-    const int c1 = o2 - o1, c2 = o3 - o2, c3 = o4 - o3;
     int up_i = 0;
-    if (wave >= c1 && wave < c1 + c2) { up_ll = 2; up_i = o2 + wave - c1; }
-    else if (wave >= c1 + c2 && wave < c1 + c2 + c3) { up_ll = 3; up_i = o3 + wave - c1 - c2; }
+    if (shape_b && wave >= b1 && wave < b1 + n1) { up_ll = 1; up_i = o1 + wave - b1; }
+    else if (wave >= b2 && wave < b2 + n2 && (shape_b || wave >= n1)) { up_ll = 2; up_i = o2 + wave - b2; }
+    else if (wave >= b3 && wave < b3 + n3) { up_ll = 3; up_i = o3 + wave - b3; }
     if (up_ll) up_rec = d.frec[(size_t)up_i * 16 + (threadIdx.x & 15)];
   }
+  if (PPS_DUO_MODE != 0) {
+    if (threadIdx.x < nw * kDuoFlags) flags[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  const int pre_at = shape_b ? 0 : 1;                           // the level during which the upper fronts are pre-assembled
   int crv = 0;
   for (int ll = 0; ll < nl; ll++) {
-    const int i0 = ll == 0 ? g0 : lo1, cnt = ll == 0 ? lo1 - g0 : lo2 - lo1;              // (used on local levels 0 and 1 only)
-    const bool mine_low = ll <= 1 && wave < cnt;
-    const bool mine_up = ll >= 2 && up_ll == ll;
-    if (mine_low || mine_up) {                                  // (wave-uniform)
-      const int rec = mine_up ? up_rec : d.frec[(size_t)(i0 + wave) * 16 + (threadIdx.x & 15)];
-      const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
+    const int lb = ll == 0 ? 0 : ll == 1 ? b1 : ll == 2 ? b2 : b3;                               // owners of this level: waves [lb, lb + cnt)
+    const int cnt = ll == 0 ? n0 : ll == 1 ? n1 : ll == 2 ? n2 : n3;
+    const int i0 = ll == 0 ? o0 : ll == 1 ? o1 : ll == 2 ? o2 : o3;
+    const bool mine = wave >= lb && wave < lb + cnt;
+    const bool mine_up = mine && up_ll == ll && ll > pre_at;    // (assembled ahead: starts with the extend-add)
+    const int epoch = ll + 1;
+    // the helper of the j-th owner is the j-th wave that owns nothing on this level
+    const int hj = wave < lb ? wave : wave - cnt;
+    const bool helping = !mine && hj < cnt;
+    if (mine) {                                                 // (wave-uniform)
+      const int rec = (up_ll == ll && ll > 0) ? up_rec : d.frec[(size_t)(i0 + wave - lb) * 16 + (threadIdx.x & 15)];
+      const int p = __builtin_amdgcn_readlane(rec, 1);
+      const int fa = p + __builtin_amdgcn_readlane(rec, 2) + 1;
+      // two waves: pivots within one tile column, at most 8 children, and a wave to help (the j-th idle one)
+      const int hw = (wave - lb) < lb ? (wave - lb) : (wave - lb) + cnt;                         // the helper's wave
+      const bool duo = PPS_DUO_MODE != 0 && p <= 16 && __builtin_amdgcn_readlane(rec, 6) <= 8 && hw < nw && !(d.sw & SW_NO_DUO);
+      int* fl = flags + wave * kDuoFlags;
       if (!mine_up) crv = front_orig_entries_sized(d, rec, lane, 1.0 + lambda, F, tr);
-      front_extend_add(d, rec, crv, lane, F, tr);
-      if (fa <= 33) front_eliminate_out<2, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-      else if (fa <= 49) front_eliminate_out<3, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-      else front_eliminate_out<4, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-    } else if (ll == 1 && up_ll) {
-      // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
-      crv = front_orig_entries_sized(d, up_rec, lane, 1.0 + lambda, F, tr);
+      // the owner hands the front's record and child records over through its mailbox: the helper starts without the two dependent
+      // memory round trips they would cost it (flag A: the mailbox is written and the original entries are in the triangle; 0 = solo)
+      if (duo) { int* mb = mail + wave * kDuoMail; if (lane < 16) mb[lane] = rec; mb[16 + lane] = crv; }
+      if (PPS_DUO_MODE != 0 && hw < nw && !(d.sw & SW_NO_DUO)) duo_post(fl + DF_A, duo ? epoch : -epoch);
+      if (duo) {
+        if (PPS_DUO_MODE & 1) {
+          front_extend_add_part<0>(d, rec, crv, lane, F, tr);
+          duo_wait(d, fl + DF_B, epoch);
+        } else front_extend_add(d, rec, crv, lane, F, tr);
+        if (PPS_DUO_MODE & 2) {
+          duo_post(fl + DF_C, epoch);                  // the triangle is complete
+          if (fa <= 33) front_duo_owner<2>(d, rec, F, fl, epoch);
+          else if (fa <= 49) front_duo_owner<3>(d, rec, F, fl, epoch);
+          else front_duo_owner<4>(d, rec, F, fl, epoch);
+        } else {
+          if (fa <= 33) front_eliminate_out<2, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+          else if (fa <= 49) front_eliminate_out<3, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+          else front_eliminate_out<4, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+        }
+      } else {
+        front_extend_add(d, rec, crv, lane, F, tr);
+        if (fa <= 33) front_eliminate_out<2, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+        else if (fa <= 49) front_eliminate_out<3, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+        else front_eliminate_out<4, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
+      }
+    } else {
+      if (ll == pre_at && up_ll > pre_at) {
+        // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
+        crv = front_orig_entries_sized(d, up_rec, lane, 1.0 + lambda, F, tr);
+      }
+      if (PPS_DUO_MODE != 0 && helping && !(d.sw & SW_NO_DUO)) {
+        const int ow = lb + hj;                                 // the owner's wave
+        int* fl = flags + ow * kDuoFlags;
+        const bool hduo = duo_wait_either(d, fl + DF_A, epoch);  // (false: the owner eliminates this front alone)
+        if (hduo) {
+        const int* mb = mail + ow * kDuoMail;
+        const int hrec = mb[lane & 15], crh = mb[16 + lane];
+        const int fa = __builtin_amdgcn_readlane(hrec, 1) + __builtin_amdgcn_readlane(hrec, 2) + 1;
+        double* Fo = lds + (size_t)ow * lds_doubles_per_wave;
+        if (PPS_DUO_MODE & 1) {
+          front_extend_add_part<1>(d, hrec, crh, lane, Fo, tr);
+          duo_post(fl + DF_B, epoch);
+        }
+        if (PPS_DUO_MODE & 2) {
+          duo_wait(d, fl + DF_C, epoch);
+          if (fa <= 33) front_duo_helper<2>(d, hrec, Fo, fl, epoch);
+          else if (fa <= 49) front_duo_helper<3>(d, hrec, Fo, fl, epoch);
+          else front_duo_helper<4>(d, hrec, Fo, fl, epoch);
+        }
+        }
+      }
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
   }
@@ -1060,11 +1255,14 @@ __global__ __launch_bounds__(512) void k_band_factor(DevGraph d, DualAlt alt, in
 // The root stage of a tree whose top is ONE group of register-resident fronts (C2: the root front), factored and solved by one launch:
 // the workgroup that has eliminated the top fronts walks back down them.  L and the forward-solved rhs rows reach the back-substitution
 // through the CU's own cache behind the workgroup barrier that ends the last level of the factorisation.
-__global__ __launch_bounds__(512) void k_band_root(DevGraph d, DualAlt alt, int grp, double lambda, int per_wave_factor, int per_wave_solve) {
+// PRE: the group has the shape of the pre-assembling walk (stage_pre); FLOW: the walk back down as a data flow (a top group of several
+// fronts: 4 + 2 + 1 when the tree is banded three levels per launch), mg = fronts of the group.
+template <bool PRE, bool FLOW>
+__global__ __launch_bounds__(512) void k_band_root(DevGraph d, DualAlt alt, int grp, double lambda, int per_wave_factor, int per_wave_solve, int mg) {
   extern __shared__ double lds[];
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
-  body_band_factor<true>(d, grp, lambda, per_wave_factor, lds);
-  body_band_solve(d, grp, per_wave_solve, lds);
+  if (PRE) body_band_factor_pre(d, grp, lambda, per_wave_factor, lds); else body_band_factor<true>(d, grp, lambda, per_wave_factor, lds);
+  if (FLOW) body_band_solve_flow(d, grp, per_wave_solve, lds, mg); else body_band_solve(d, grp, per_wave_solve, lds);
 }
 
 __global__ __launch_bounds__(512) void k_band_factor_pre(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
@@ -1103,7 +1301,10 @@ static hipError_t ensure_band_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_flow_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_r5), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_lean_trace), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
   }
@@ -1121,7 +1322,7 @@ static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt,
   if (reg_only && d.trace != nullptr)      // phase trace of the register-only kernel
     PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (reg_only && pre)
-    PPS_LAUNCH_EV(ev0, ev1, k_band_factor_pre, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
+    PPS_LAUNCH_EV(ev0, ev1, k_band_factor_pre, dim3(grp_count, ny), dim3(64 * nwaves), bytes + duo_flag_bytes(nwaves), st, d, alt, grp_begin, lambda, per_wave);
   else if (reg_only)
     PPS_LAUNCH_EV(ev0, ev1, k_band_factor<true>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
@@ -1177,12 +1378,25 @@ bool band_root_fusable(const DevGraph& d, int grp_count, int max_front) {
   return !off && grp_count == 1 && max_front + 1 <= kRegRows && d.trace == nullptr;
 }
 hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,
-                            int max_group_fronts, double lambda, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                            int max_group_fronts, double lambda, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool pre) {
   { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
-  const int nw = nwaves_factor > nwaves_solve ? nwaves_factor : nwaves_solve;
   const int pwf = (int)(band_lds_bytes(max_front, true) / sizeof(double)), pws = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
-  const size_t bf = (size_t)pwf * nw * sizeof(double), bs = ((size_t)pws * nw + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
-  PPS_LAUNCH_EV(ev0, ev1, k_band_root, dim3(1, alt ? 2 : 1), dim3(64 * nw), bf > bs ? bf : bs, st, d, alt ? *alt : DualAlt{}, grp, lambda, pwf, pws);
+  // the walk back down: as a data flow when the group has more than one front and the LDS holds a wave per front (at most eight here)
+  const size_t flow_fixed = ((size_t)max_group_fronts * kBandMaxRows + (size_t)(max_group_fronts + 1) / 2) * sizeof(double);
+  int nw = nwaves_factor > nwaves_solve ? nwaves_factor : nwaves_solve;
+  bool flow = !(d.sw & SW_NO_SOLVE_FLOW) && max_group_fronts > 1;
+  if (flow) {
+    const int want = nwaves_factor > (max_group_fronts < 8 ? max_group_fronts : 8) ? nwaves_factor : (max_group_fronts < 8 ? max_group_fronts : 8);
+    if ((size_t)pws * want * sizeof(double) + flow_fixed <= (size_t)kLdsLimitBytes) nw = want; else flow = false;
+  }
+  const size_t bf = (size_t)pwf * nw * sizeof(double) + duo_flag_bytes(nw);
+  const size_t bs = flow ? (size_t)pws * nw * sizeof(double) + flow_fixed : ((size_t)pws * nw + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
+  const size_t bytes = bf > bs ? bf : bs;
+  const DualAlt a2 = alt ? *alt : DualAlt{};
+  if (pre && flow) PPS_LAUNCH_EV(ev0, ev1, (k_band_root<true, true>), dim3(1, alt ? 2 : 1), dim3(64 * nw), bytes, st, d, a2, grp, lambda, pwf, pws, max_group_fronts);
+  else if (pre) PPS_LAUNCH_EV(ev0, ev1, (k_band_root<true, false>), dim3(1, alt ? 2 : 1), dim3(64 * nw), bytes, st, d, a2, grp, lambda, pwf, pws, max_group_fronts);
+  else if (flow) PPS_LAUNCH_EV(ev0, ev1, (k_band_root<false, true>), dim3(1, alt ? 2 : 1), dim3(64 * nw), bytes, st, d, a2, grp, lambda, pwf, pws, max_group_fronts);
+  else PPS_LAUNCH_EV(ev0, ev1, (k_band_root<false, false>), dim3(1, alt ? 2 : 1), dim3(64 * nw), bytes, st, d, a2, grp, lambda, pwf, pws, max_group_fronts);
   return hipGetLastError();
 }
 
@@ -1398,7 +1612,11 @@ __global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, in
   wave_front_solve<false>(d2, rec, W, nullptr, 0);
 }
 
-static int level_lds_doubles(int nt) { return (int)(band_lds_bytes(16 * nt, true) / sizeof(double)); }   // fronts of <= 16 nt rows (+ rhs)
+// level-per-launch kernels: the packed triangle of a front of <= 16 nt rows (+ rhs), whose head doubles as the 8-column panel buffer, + the spare double
+static int level_lds_doubles(int nt) {
+  const size_t fa = (size_t)16 * nt + 1, n = std::max<size_t>(fa * (fa + 1) / 2, (size_t)kRegRows * kP8Stride) + 1;
+  return (int)((n + 1) & ~size_t(1));
+}
 
 static std::atomic<bool> g_batch_attr_set[64];
 
@@ -1439,7 +1657,7 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
     const size_t bytes = (size_t)per_wave * nw * sizeof(double);
     if (g.stage_reg_only[stg] && g.stage_pre[stg])
-      PPS_LAUNCH(kb_band_factor_pre, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
+      PPS_LAUNCH(kb_band_factor_pre, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes + duo_flag_bytes(nw), st, a, stg, per_wave);
     else if (g.stage_reg_only[stg])
       PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else

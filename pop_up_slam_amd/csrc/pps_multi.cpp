@@ -323,13 +323,13 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         if (stg >= A.n_stages) continue;
         for (int gi = A.stage_grp_off[stg]; pre && gi < A.stage_grp_off[stg + 1]; gi++) {
           const int l0 = A.grp_lvl_off[gi], nl = A.grp_lvl_off[gi + 1] - l0;
-          pre = nl >= 3 && nl <= 4;
-          int upper = 0;
+          pre = nl >= 1 && nl <= 4;
+          int upper = 0, c0 = 0;
           for (int k = 0; pre && k < nl; k++) {
             const int cnt = A.glvl_front_off[l0 + k + 1] - A.glvl_front_off[l0 + k];
-            if (k == 0) pre = cnt <= nw; else upper += cnt;
+            if (k == 0) c0 = cnt; else upper += cnt;
           }
-          pre = pre && upper <= nw;
+          pre = pre && (c0 + upper <= nw || (nl >= 3 && c0 <= nw && upper <= nw));      // (shape B | shape A of body_band_factor_pre)
         }
       }
       q.stage_pre[stg] = pre;

@@ -59,7 +59,7 @@ static int enqueue_factor_solve(pps_graph* g, const DevGraph& dv, const DualAlt*
     const bool pre = st < (int)g->stage_pre.size() && g->stage_pre[st] != 0;
     if (fuse && st == top)
       HIP_TRY(g, launch_band_root(dv, alt, g0, g->stage_nw_factor[st], g->stage_nw_solve[st], A.stage_max_front[st], g->stage_max_panel[st],
-                                  g->stage_max_grp_fronts[st], lambda, st_, e0, e1));
+                                  g->stage_max_grp_fronts[st], lambda, st_, e0, e1, pre));
     else if (alt) HIP_TRY(g, launch_band_factor_dual(dv, *alt, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1, pre));
     else HIP_TRY(g, launch_band_factor(dv, g0, ng, g->stage_nw_factor[st], A.stage_max_front[st], lambda, st_, e0, e1, pre));
   }

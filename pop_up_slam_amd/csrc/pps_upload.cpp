@@ -283,9 +283,13 @@ static int run_analysis_impl(pps_graph* g) {
   g->cmp_valid = !any_deleted && sn.size() == g->nodes.size();
   }
   g->cmp_nodes = g->nodes.size(); g->cmp_factors = g->factors.size();
-  // band depth: 4 levels per launch when the solve is latency bound (C2: 512 fronts; 113.3 vs 115.0 us per LM iteration
-  // with 3), 2 when the lower levels are throughput bound (C3: 5 360 fronts; 637 vs 710 us)
-  g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 4;
+  // band depth: 3 levels per launch when the solve is latency bound, 2 when the lower levels are throughput bound (C3: 5 360 fronts;
+  // 637 vs 710 us).  (Up to round 4: 4 levels, 113.3 vs 115.0 us per C2 LM iteration with 3.  Round 5: a group of 4 + 2 + 1 fronts on
+  // eight waves has a wave for every front, so every separator front is assembled ahead of its level while the leaves are eliminated,
+  // and the top group -- levels 6 .. 8 of C2's nine -- is factored and solved by one launch with the data-flow back-substitution:
+  // 60.9 against 63.7 us per C2 LM iteration with 4, same box, tools/r5_ab_duo.sh.)
+  g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 3;
+  if (g->sw.band_levels > 0) g->aprm.band_levels = g->sw.band_levels;      // (PPS_BAND_LEVELS: A/B)
   // H-block segments (contributions reduced by one wave of K2): short on small graphs, where the few long segments
   // (ground plane, 32 contributions = 16 dependent load rounds) are K2's critical path; long on large ones, where the
   // number of waves is (C2: 23.3 -> 18.7 us with 8; C3: 82 -> 102 us)
@@ -370,8 +374,9 @@ static int run_analysis_impl(pps_graph* g) {
       if (xbytes + per_wave > lds_budget) { g->use_band = false; g->stage_nw_solve[st] = 1; continue; }
       g->stage_nw_solve[st] = (int)std::max<size_t>(1, std::min<size_t>(want, (lds_budget - xbytes) / per_wave));
     }
-    // k_band_factor_pre: groups of three or four local levels, every level in one round of the stage's waves, and the fronts of local
-    // levels 2 and up on waves that idle from level 1 on (8 + 4 + 2 + 1 on eight waves: 4 + 2 + 1 <= 8)
+    // k_band_factor_pre: every level in one round of the stage's waves, and either the whole group on waves of its own (shape B: 4 + 2 + 1
+    // on eight waves) or three to four local levels with the fronts of local levels 2 and up on waves that idle from level 1 on (shape A:
+    // 8 + 4 + 2 + 1 on eight waves, 4 + 2 + 1 <= 8) -- body_band_factor_pre tells the two apart the same way
     g->stage_pre.assign(A.n_stages, 0);
     if (!g->sw.no_preassemble)
       for (int st = 0; st < A.n_stages; st++) {
@@ -379,13 +384,13 @@ static int run_analysis_impl(pps_graph* g) {
         const int nw = g->stage_nw_factor[st];
         for (int gi = A.stage_grp_off[st]; ok && gi < A.stage_grp_off[st + 1]; gi++) {
           const int l0 = A.grp_lvl_off[gi], nl = A.grp_lvl_off[gi + 1] - l0;
-          ok = nl >= 3 && nl <= 4;
-          int upper = 0;
+          ok = nl >= 1 && nl <= 4;
+          int upper = 0, c0 = 0;
           for (int k = 0; ok && k < nl; k++) {
             const int c = A.glvl_front_off[l0 + k + 1] - A.glvl_front_off[l0 + k];
-            if (k == 0) ok = c <= nw; else upper += c;
+            if (k == 0) c0 = c; else upper += c;
           }
-          ok = ok && upper <= nw;
+          ok = ok && (c0 + upper <= nw || (nl >= 3 && c0 <= nw && upper <= nw));
         }
         g->stage_pre[st] = ok ? 1 : 0;
       }
@@ -713,6 +718,7 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.f_el_off, A.f_el_off, kFl ? kFl + 1 : 0)); TRY(dev_alloc(g, &d.el_tgt, (size_t)std::max<int64_t>(1, A.el_total)));   // filled by k_expand_el below
   TRY(dev_upload(g, &d.asm_el0, A.asm_el0, kA)); TRY(dev_upload(g, &d.asm_fsz, A.asm_fsz, kA));
   TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off, kF ? kF + 1 : 0)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
+  TRY(dev_alloc(g, &d.c_split, std::max<size_t>(1, A.crec.size() / 8)));          // ... c_split likewise (expand_split)
   TRY(dev_upload(g, &d.blk_doff, A.blk_doff, kB ? kB + 1 : 0)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
   TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
@@ -729,6 +735,7 @@ int upload_all(pps_graph* g) {
     TRY(dev_upload(g, &d.grp_span, span));
   }
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
+  TRY(dev_upload(g, &d.f_crec0, A.f_crec0));
   TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec, 8 * kS));
   TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs, (size_t)K.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
   TRY(dev_upload(g, &d.cls_off, A.cls_off)); TRY(dev_upload(g, &d.cls_fronts, A.cls_fronts));
