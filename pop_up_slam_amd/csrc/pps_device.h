@@ -210,6 +210,7 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_
 hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st);
 hipError_t launch_expand_lists(const DevGraph& d, int n_fronts, int n_asm, double* zero, size_t n_zero, hipStream_t st);   // both + the zero fill, one launch
 int band_max_rows();
+int band_duo_mode();                            // PPS_DUO_MODE of the build (0: one wave per front, no c_split)
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
 int debug_front_factor(int tiles, int strip, int p, int b, const double* A_host, double* L_host, double* U_host, double* not_pd);   // pps_debug_front_factor

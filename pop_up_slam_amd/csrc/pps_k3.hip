@@ -15,6 +15,13 @@
 #include "pps_regtile.h"
 #include "pps_front_duo.h"
 
+// Two waves per front (pps_front_duo.h): bit 0 = the extend-add is split between a front's own wave and a helper, bit 1 = the
+// elimination.  BUILD-TIME, DEFAULT OFF: measured on C2 (round 5, tools/r5_ab_duo.sh, us per LM iteration, same box): one wave 65.0 /
+// elimination split 64.9 / both 66.0 / extend-add split alone 68.8 -- bit-identical LM traces in every variant; DESIGN.md section 8.
+#ifndef PPS_DUO_MODE
+#define PPS_DUO_MODE 0
+#endif
+
 namespace pps {
 
 
@@ -155,7 +162,7 @@ constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
 // row < r1" is a leading range of the child's packed triangle -- and per child the length of that range.  A map that is not increasing
 // leaves the whole child with the front's own wave.  64 threads; sh: 8 ints of LDS.
 __device__ __forceinline__ void expand_split(const DevGraph& d, int s, int* sh) {
-  if (!d.c_split) return;
+  if (PPS_DUO_MODE == 0 || !d.c_split) return;
   const int nch = d.f_child_off[s + 1] - d.f_child_off[s];
   if (nch <= 0) return;
   // (the records sit in band-schedule order; the front's own position is found through its children's shared parent record: every
@@ -302,6 +309,7 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_
 }
 
 int band_front_limit() { return kBandMaxRows - 1; }
+int band_duo_mode() { return PPS_DUO_MODE; }
 int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
 // LDS of one wave in the factor kernels.  Register-only kernels (every front of the stage <= 64 rows; the level kernels): the packed
@@ -553,9 +561,14 @@ __device__ __forceinline__ void front_pre_issue(const DevGraph& d, int rec, int 
   const int e0 = __builtin_amdgcn_readlane(rec, 3), e1 = __builtin_amdgcn_readlane(rec, 4);
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
   el_issue(d.el_tgt, d.Hf, e0, e1, lane, o.q);
-  // records of up to 8 children in one load; slot 6 of a record comes from c_split (the child's split between the front's two waves)
+  // records of up to 8 children in one coalesced load
+#if PPS_DUO_MODE
+  // (two waves per front: slot 6 of a record comes from c_split, the child's split between the front's two waves)
   const int* src = (lane & 7) == 6 ? d.c_split + cr0 + (lane >> 3) : d.crec + (size_t)cr0 * 8 + lane;
   o.crv = (lane < 8 * nch) ? *src : 0;
+#else
+  o.crv = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;
+#endif
 }
 __device__ __forceinline__ void front_clear(int rec, int lane, double* __restrict__ F) {
   const int ntri = tri(__builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1);
@@ -1104,12 +1117,6 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
   }
 }
 
-// Two waves per front (pps_front_duo.h): bit 0 = the extend-add is split between a front's own wave and a helper, bit 1 = the
-// elimination.  BUILD-TIME, DEFAULT OFF: measured on C2 (round 5, tools/r5_ab_duo.sh, us per LM iteration, same box): one wave 65.0 /
-// elimination split 64.9 / both 66.0 / extend-add split alone 68.8 -- bit-identical LM traces in every variant; DESIGN.md section 8.
-#ifndef PPS_DUO_MODE
-#define PPS_DUO_MODE 0
-#endif
 #ifndef PPS_NPRE_BIG
 #define PPS_NPRE_BIG 8
 #endif

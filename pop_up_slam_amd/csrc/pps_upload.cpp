@@ -361,12 +361,15 @@ static int run_analysis_impl(pps_graph* g) {
     const size_t lds_budget = 150 * 1024;
     const int max_waves = 8;
     for (int st = 0; st < A.n_stages; st++) {
-      const int want = std::max(1, std::min(max_waves, A.stage_max_width[st]));
-      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st], A.stage_max_front[st] + 1 <= band_reg_rows() && g->sw.trace == 0)));
       int mg = 1;
       for (int gi = A.stage_grp_off[st]; gi < A.stage_grp_off[st + 1]; gi++)
         mg = std::max(mg, A.glvl_front_off[A.grp_lvl_off[gi + 1]] - A.glvl_front_off[A.grp_lvl_off[gi]]);
       g->stage_max_grp_fronts[st] = mg;
+      // waves per group: one per front of its widest level -- or, when the whole group fits (4 + 2 + 1 on eight waves), one per front
+      // of the group: every upper front is then assembled ahead of its level by a wave of its own (body_band_factor_pre, shape B)
+      const bool reg_stage = A.stage_max_front[st] + 1 <= band_reg_rows() && g->sw.trace == 0;
+      const int want = std::max(1, std::min(max_waves, reg_stage && mg <= max_waves && !g->sw.no_preassemble ? mg : A.stage_max_width[st]));
+      g->stage_nw_factor[st] = (int)std::max<size_t>(1, std::min<size_t>(want, lds_budget / band_lds_bytes(A.stage_max_front[st], reg_stage)));
       // per workgroup: one local solution vector per front of a group + per wave xb and the factor panel.  A group that does
       // not fit (very wide elimination trees: hundreds of fronts in one band group) takes the graph off the band kernels.
       const size_t xbytes = (size_t)mg * band_max_rows() * sizeof(double);
@@ -718,7 +721,8 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.f_el_off, A.f_el_off, kFl ? kFl + 1 : 0)); TRY(dev_alloc(g, &d.el_tgt, (size_t)std::max<int64_t>(1, A.el_total)));   // filled by k_expand_el below
   TRY(dev_upload(g, &d.asm_el0, A.asm_el0, kA)); TRY(dev_upload(g, &d.asm_fsz, A.asm_fsz, kA));
   TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off, kF ? kF + 1 : 0)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
-  TRY(dev_alloc(g, &d.c_split, std::max<size_t>(1, A.crec.size() / 8)));          // ... c_split likewise (expand_split)
+  d.c_split = nullptr;
+  if (band_duo_mode()) TRY(dev_alloc(g, &d.c_split, std::max<size_t>(1, A.crec.size() / 8)));          // ... c_split likewise (expand_split; two-wave builds only)
   TRY(dev_upload(g, &d.blk_doff, A.blk_doff, kB ? kB + 1 : 0)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
   TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
@@ -735,7 +739,8 @@ int upload_all(pps_graph* g) {
     TRY(dev_upload(g, &d.grp_span, span));
   }
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
-  TRY(dev_upload(g, &d.f_crec0, A.f_crec0));
+  d.f_crec0 = nullptr;
+  if (band_duo_mode()) TRY(dev_upload(g, &d.f_crec0, A.f_crec0));
   TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec, 8 * kS));
   TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs, (size_t)K.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
   TRY(dev_upload(g, &d.cls_off, A.cls_off)); TRY(dev_upload(g, &d.cls_fronts, A.cls_fronts));

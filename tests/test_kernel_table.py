@@ -15,7 +15,7 @@ def test_design_register_table_matches_the_built_kernels(built):
         doc = K.parse_design_table(f.read())
     tab = K.built_table()
     # the hot-path kernels of the single C2 graph, the large batch and C3 / C5 must be listed
-    for must in ("k_linearize_lanes", "k_hblocks2", "k_band_factor_pre", "k_band_root", "k_band_solve_flow", "k_band_factor_r5",
+    for must in ("k_linearize_lanes", "k_hblocks2", "k_band_factor_pre", "k_band_root<true, true>", "k_band_solve_flow", "k_band_factor_r5",
                  "kb_level_factor3", "kb_level_solve", "kb_hblocks_tc", "k_trial_dual"):
         assert must in doc, must
     for name, (vgpr, agpr, waves, sspill, vspill, code) in doc.items():
