@@ -85,7 +85,8 @@ struct DevGraph {
   // throughput form of K2 (many-graph batches; built by pps_multi on first use): the non-direct segments by class -- entries
   // [0, n_k2t_big): segment | class << 28 (0 generic, 1 pose diagonal 6 x 6 + g with rows of 3 / 6, 2 pose-pose 6 x 6 with rows of 6),
   // then n_k2t_small plane diagonals (3 x 3 + g, rows of 3: four of them per wave)
-  int* k2t = nullptr; int n_k2t_big = 0, n_k2t_small = 0;
+  // (round 5: the entries with a class body come first, n_k2t_spec of them; the generic ones behind run in a kernel of their own)
+  int* k2t = nullptr; int n_k2t_big = 0, n_k2t_small = 0, n_k2t_spec = 0;
   int *cls_off = nullptr, *cls_fronts = nullptr;             // level-per-launch lists (pps_symbolic.h)
   // ---- reductions / status ----
   double* chi2_partials = nullptr;   // one per block of the residual sweep
@@ -275,7 +276,7 @@ struct BatchArgs {
 // grid extents (maxima over the graphs of the chunk) and LDS needs of one round
 struct BatchGeom {
   int lin_blocks = 0, lin_obs_blocks = 0, lin_rest_blocks = 0, repop_blocks = 0;
-  int hblocks = 0, hblocks_nd = 0, k2t_blocks = 0, hreduce = 0, retract = 0, chi2 = 0;
+  int hblocks = 0, hblocks_nd = 0, k2t_blocks = 0, k2tg_blocks = 0, hreduce = 0, retract = 0, chi2 = 0;      // k2tg: the generic entries of the class lists
   int k2_blocks = 0, k2_finish = 0;   // workgroups of the K2 launch: maximum over the chunk's graphs of ceil(single / 16) + multi; blocks of its second pass
   long long n_factors_total = 0;
   bool lin_thread_form = false;   // numeric K1 as one thread per factor (many graphs) instead of 32 lanes per factor

@@ -473,22 +473,28 @@ __device__ __forceinline__ void wave_hblock_33x4(const DevGraph& d, int first, d
   if (dst >= 0) d.Hf[dst] = acc;
 }
 
+// GENERIC = false: the entries with a class body ([0, n_k2t_spec): pose diagonals, pose-pose blocks) and the plane diagonals;
+// GENERIC = true: the entries behind them, one generic body -- a kernel of its own, so that its registers (it holds most of the 126
+// the common kernel needed) do not set the occupancy of the class bodies, which wait on memory most of the time.
+template <bool GENERIC>
 __device__ __forceinline__ void body_hblocks_tc(const DevGraph& d, int bx) {
   __shared__ double tc_lds[4 * kTcWaveDoubles];
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double* __restrict__ S = tc_lds + wave * kTcWaveDoubles;
-  const int nb_big = (d.n_k2t_big + 15) / 16;
+  const int e_begin = GENERIC ? d.n_k2t_spec : 0, e_end = GENERIC ? d.n_k2t_big : d.n_k2t_spec;
+  const int nb_big = (e_end - e_begin + 15) / 16;
   if (bx >= nb_big) {
+    if (GENERIC) return;
     const int first = uni(((bx - nb_big) * 4 + wave) * 4);
     if (first < d.n_k2t_small) wave_hblock_33x4(d, first, S);
     return;
   }
-  const int slot0 = uni((bx * 4 + wave) * 4);
-  if (slot0 >= d.n_k2t_big) return;
+  const int slot0 = uni(e_begin + (bx * 4 + wave) * 4);
+  if (slot0 >= e_end) return;
   SegHdr h[4];
   int cls[4];
   {
-    const int e = slot0 + (lane >> 3) < d.n_k2t_big && (lane >> 3) < 4 ? d.k2t[slot0 + (lane >> 3)] : -1;   // lanes 8q..8q+7: entry q
+    const int e = slot0 + (lane >> 3) < e_end && (lane >> 3) < 4 ? d.k2t[slot0 + (lane >> 3)] : -1;   // lanes 8q..8q+7: entry q
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int eq = __builtin_amdgcn_readlane(e, 8 * q);
@@ -500,9 +506,9 @@ __device__ __forceinline__ void body_hblocks_tc(const DevGraph& d, int bx) {
   for (int q = 0; q < 4; q++) seg_fetch_contrib(d, lane, h[q]);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    if (cls[q] == 1) wave_hblock_66_diag(d, h[q], S);
-    else if (cls[q] == 2) wave_hblock_66_off(d, h[q], S);
-    else wave_hblock_segment(d, h[q], S);
+    if (GENERIC) wave_hblock_segment(d, h[q], S);
+    else if (cls[q] == 1) wave_hblock_66_diag(d, h[q], S);
+    else wave_hblock_66_off(d, h[q], S);
   }
 }
 
@@ -580,8 +586,13 @@ __global__ __launch_bounds__(256) void kb_hblocks_t(BatchArgs a) {
 
 __global__ __launch_bounds__(256) void kb_hblocks_tc(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
-  if ((int)blockIdx.x >= (d.n_k2t_big + 15) / 16 + (d.n_k2t_small + 15) / 16) return;
-  body_hblocks_tc(d, blockIdx.x);
+  if ((int)blockIdx.x >= (d.n_k2t_spec + 15) / 16 + (d.n_k2t_small + 15) / 16) return;
+  body_hblocks_tc<false>(d, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void kb_hblocks_tg(BatchArgs a) {
+  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
+  if ((int)blockIdx.x >= (d.n_k2t_big - d.n_k2t_spec + 15) / 16) return;
+  body_hblocks_tc<true>(d, blockIdx.x);
 }
 
 __global__ __launch_bounds__(64) void kb_hreduce(BatchArgs a) {
@@ -595,7 +606,10 @@ hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStrea
     // (the wave-per-segment kernel in its Jacobian-only mode, measured on the same G = 128 batch: 23.9 ms of K2 per batch solve
     // against 13.7 ms -- at this size the LDS-staged form's four segments per wave and prefetched headers win)
     const bool by_class = !g.k2t_generic;                             // (A/B: the one-body form)
-    if (by_class) { if (g.k2t_blocks > 0) PPS_LAUNCH(kb_hblocks_tc, dim3(g.k2t_blocks, a.n), dim3(256), 0, st, a); }
+    if (by_class) {
+      if (g.k2t_blocks > 0) PPS_LAUNCH(kb_hblocks_tc, dim3(g.k2t_blocks, a.n), dim3(256), 0, st, a);
+      if (g.k2tg_blocks > 0) PPS_LAUNCH(kb_hblocks_tg, dim3(g.k2tg_blocks, a.n), dim3(256), 0, st, a);
+    }
     else if (g.hblocks_nd > 0) PPS_LAUNCH(kb_hblocks_t, dim3(g.hblocks_nd, a.n), dim3(256), 0, st, a);
     if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
     return hipGetLastError();

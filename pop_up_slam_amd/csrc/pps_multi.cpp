@@ -124,7 +124,7 @@ int pps_multi_restore_state(pps_multi* m) {
 static int ensure_k2t_lists(pps_graph* g) {
   if (g->k2t_version == g->upload_version && g->dev.k2t) return PPS_OK;
   const Analysis& A = g->an;
-  std::vector<int> big, small;
+  std::vector<int> big, small, generic;
   for (int sg : A.nd_segs) {
     const int* r = &A.srec[8 * (size_t)sg];
     const int rows = r[0], cols = r[1], size = r[2], c0 = r[3], cnt = r[4];
@@ -140,8 +140,11 @@ static int ensure_k2t_lists(pps_graph* g) {
     if (cnt >= 1 && cnt <= 64 && rows == 3 && cols == 3 && size == 12 && three && same) { small.push_back(sg); continue; }
     if (cnt >= 1 && cnt <= 64 && rows == 6 && cols == 6 && size == 42 && three_six && same) cls = 1;
     else if (cnt >= 1 && cnt <= 64 && rows == 6 && cols == 6 && size == 36 && six) cls = 2;
-    big.push_back(sg | (cls << 28));
+    (cls ? big : generic).push_back(sg | (cls << 28));
   }
+  // the entries with a class body first (kb_hblocks_tc: ~80 registers, six waves per SIMD), the generic ones behind them (kb_hblocks_tg)
+  g->dev.n_k2t_spec = (int)big.size();
+  big.insert(big.end(), generic.begin(), generic.end());
   g->dev.n_k2t_big = (int)big.size(); g->dev.n_k2t_small = (int)small.size();
   big.insert(big.end(), small.begin(), small.end());
   if (big.empty()) big.push_back(0);
@@ -248,7 +251,8 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.repop_blocks = std::max(q.repop_blocks, (d.n_obs - d.n_obs_fixed + 63) / 64);
       q.hblocks = std::max(q.hblocks, (d.n_nd_segs + 3) / 4);                     // (the segments K1 does not write itself)
       q.hblocks_nd = std::max(q.hblocks_nd, (d.n_nd_segs + 15) / 16);
-      q.k2t_blocks = std::max(q.k2t_blocks, (d.n_k2t_big + 15) / 16 + (d.n_k2t_small + 15) / 16);
+      q.k2t_blocks = std::max(q.k2t_blocks, (d.n_k2t_spec + 15) / 16 + (d.n_k2t_small + 15) / 16);
+      q.k2tg_blocks = std::max(q.k2tg_blocks, (d.n_k2t_big - d.n_k2t_spec + 15) / 16);
       q.hreduce = std::max(q.hreduce, d.n_mseg);
       q.k2_blocks = std::max(q.k2_blocks, (d.n_k2_single + 15) / 16 + d.n_k2_multi);
       q.k2_finish = std::max(q.k2_finish, d.n_k2_finish);
