@@ -211,6 +211,7 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_
 hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st);
 hipError_t launch_expand_lists(const DevGraph& d, int n_fronts, int n_asm, double* zero, size_t n_zero, hipStream_t st);   // both + the zero fill, one launch
 int band_max_rows();
+bool band_level_solve_direct_ok(int p, int b);   // a front whose level back-substitution may load L_B straight into registers (kb_level_solve)
 int band_duo_mode();                            // PPS_DUO_MODE of the build (0: one wave per front, no c_split)
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
@@ -293,6 +294,7 @@ struct BatchGeom {
   int n_levels = 0;
   int lvl_cls_blocks[64][3] = {{0}};    // workgroups (4 fronts each) per level and class: maximum over the chunk's graphs
   int lvl_blocks[64] = {0};             // ... per level, all classes (back-substitution)
+  int lvl_direct_pp[64] = {0};          // largest p x p of a level whose fronts ALL take the direct-load back-substitution (0: some do not)
   int lvl_max_panel[64] = {0};          // largest factor panel ((p + b + 1) p doubles) of a level: the LDS a wave of its back-substitution needs
   int solve_per_wave_all = 0;           // LDS doubles per wave of the level solve (largest panel of the chunk)
   int stage_max_front[32] = {0};    // largest front (scalars, without the rhs row) of the stage over the chunk's graphs

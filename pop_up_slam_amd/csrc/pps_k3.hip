@@ -310,6 +310,7 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_
 
 int band_front_limit() { return kBandMaxRows - 1; }
 int band_duo_mode() { return PPS_DUO_MODE; }
+bool band_level_solve_direct_ok(int p, int b);
 int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
 // LDS of one wave in the factor kernels.  Register-only kernels (every front of the stage <= 64 rows; the level kernels): the packed
@@ -1541,7 +1542,13 @@ PPS_LEVEL_FACTOR_KERNEL(kb_level_factor4, 4, 2)
 #endif
 constexpr bool kLevelSolveLean = PPS_LEVEL_SOLVE_LEAN != 0;
 constexpr int kLevelSolveSlack = 64;       // doubles of LDS behind a wave's panel area (the last copy batch may overrun the panel)
-template <int SH>                          // 1 << SH lanes per column of L_B: 16 (p <= 16) or 32 (p <= 32)
+// DIRECT (round 5): L_B never enters the LDS -- every lane loads exactly the entries of its column that it multiplies (rows part,
+// part + np, ...: at most sixteen loads, issued with the copy of L_A) and the products read registers; the LDS of a wave is x_b and the
+// p x p pivot block only (a 53 x 27 leaf: 7 KB instead of 12.7 KB, five waves per SIMD instead of three at the level where the waves
+// spend two thirds of their cycles waiting for memory).  The sums run in the order of the LDS form: same bits.
+// eligible: level_solve_direct_ok (shared with the host's LDS sizing)
+__host__ __device__ __forceinline__ constexpr bool level_solve_direct_ok(int p, int b) { return p >= 1 && p <= 32 && (p <= 16 ? b <= 64 : b <= 32); }
+template <int SH, bool DIRECT = false>     // 1 << SH lanes per column of L_B: 16 (p <= 16) or 32 (p <= 32)
 __device__ __forceinline__ void wave_front_solve_level(const DevGraph& d, int rec, double* __restrict__ Wk) {
 #ifndef PPS_NO_FMA
 #pragma clang fp contract(fast)     // dependent chains: a - b * c is one operation here (as in wave_front_solve)
@@ -1554,12 +1561,27 @@ __device__ __forceinline__ void wave_front_solve_level(const DevGraph& d, int re
   double* __restrict__ PL = Wk + kBandMaxRows;
   const int ix0 = ix[lane < b ? lane : 0];
   const int pix = d.pidx[__builtin_amdgcn_readlane(rec, 7) + (lane < p ? lane : 0)];
-  const int n = (f + 1) * p;
+  const int n = DIRECT ? p * p : (f + 1) * p;                  // (DIRECT: only L_A, the first p rows of the panel, is copied)
   const double* __restrict__ src = Lp + lane;
   double* __restrict__ dst = PL + lane;
+  constexpr int np = 64 >> SH;
+  const int j = lane & ((1 << SH) - 1), part = lane >> SH;
+  const int jc = j < p ? j : 0;
+  const int blast = b > 0 ? b - 1 : 0;
   double v[16];
 #pragma unroll
   for (int u = 0; u < 16; u++) if (64 * u < n) v[u] = src[64 * u];
+  double lbv[16], yr = 0.0;
+  if (DIRECT) {
+    const double* __restrict__ LB = Lp + p * p + jc;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (4 * q * np < b) {                                    // (wave-uniform) rows part + np (4 q + m), m = 0 .. 3
+#pragma unroll
+        for (int m = 0; m < 4; m++) { const int i = part + np * (4 * q + m); lbv[4 * q + m] = LB[(i < blast ? i : blast) * p]; }
+      }
+    yr = Lp[f * p + jc];
+  }
   const double g0 = d.delta[lane < b ? ix0 : 0];
 #pragma unroll
   for (int u = 0; u < 16; u++) if (64 * u < n) dst[64 * u] = v[u];
@@ -1569,18 +1591,24 @@ __device__ __forceinline__ void wave_front_solve_level(const DevGraph& d, int re
   const int lc = lane < p ? lane : 0;
   const double dinv = 1.0 / PL[lc * p + lc];
   // y - L_B^T x_b: column j by 64 >> SH lanes, rows part (mod np), four partial sums per lane (rows part + np (4 t + m) in a_m)
-  constexpr int np = 64 >> SH;
-  const int j = lane & ((1 << SH) - 1), part = lane >> SH;
-  const int jc = j < p ? j : 0;
-  double a0 = part == 0 ? PL[f * p + jc] : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  const double* __restrict__ lb = PL + p * p + jc;
+  double a0 = part == 0 ? (DIRECT ? yr : PL[f * p + jc]) : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const double* __restrict__ xr = xb + part;
-  const int blast = b > 0 ? b - 1 : 0;
-  for (int i0 = 0; i0 < b; i0 += 4 * np) {               // (wave-uniform trip count)
-    const int i = i0 + part, i1 = i + np, i2 = i + 2 * np, i3 = i + 3 * np;
-    const double l0 = lb[(i < blast ? i : blast) * p], l1 = lb[(i1 < blast ? i1 : blast) * p], l2 = lb[(i2 < blast ? i2 : blast) * p], l3 = lb[(i3 < blast ? i3 : blast) * p];
-    const double x0 = xr[i0], x1 = xr[i0 + np], x2 = xr[i0 + 2 * np], x3 = xr[i0 + 3 * np];
-    a0 -= l0 * x0; a1 -= l1 * x1; a2 -= l2 * x2; a3 -= l3 * x3;
+  if (DIRECT) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (4 * q * np < b) {
+        const int i0 = 4 * q * np;
+        const double x0 = xr[i0], x1 = xr[i0 + np], x2 = xr[i0 + 2 * np], x3 = xr[i0 + 3 * np];
+        a0 -= lbv[4 * q] * x0; a1 -= lbv[4 * q + 1] * x1; a2 -= lbv[4 * q + 2] * x2; a3 -= lbv[4 * q + 3] * x3;
+      }
+  } else {
+    const double* __restrict__ lb = PL + p * p + jc;
+    for (int i0 = 0; i0 < b; i0 += 4 * np) {               // (wave-uniform trip count)
+      const int i = i0 + part, i1 = i + np, i2 = i + 2 * np, i3 = i + 3 * np;
+      const double l0 = lb[(i < blast ? i : blast) * p], l1 = lb[(i1 < blast ? i1 : blast) * p], l2 = lb[(i2 < blast ? i2 : blast) * p], l3 = lb[(i3 < blast ? i3 : blast) * p];
+      const double x0 = xr[i0], x1 = xr[i0 + np], x2 = xr[i0 + 2 * np], x3 = xr[i0 + 3 * np];
+      a0 -= l0 * x0; a1 -= l1 * x1; a2 -= l2 * x2; a3 -= l3 * x3;
+    }
   }
   double tj = (a0 + a1) + (a2 + a3);
   tj += __shfl_xor(tj, 32);
@@ -1597,7 +1625,8 @@ __device__ __forceinline__ void wave_front_solve_level(const DevGraph& d, int re
   if (lane < p) d.delta[pix] = tj;
 }
 
-__global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, int lds_doubles_per_wave) {
+// direct: the host has checked that every front of the level is level_solve_direct_ok and sized the LDS for x_b + p x p
+__global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, int lds_doubles_per_wave, int direct) {
   extern __shared__ double lds[];
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
   if (level >= d.n_levels) return;
@@ -1612,6 +1641,10 @@ __global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, in
     d2.L = al.L; d2.U = al.U; d2.delta = al.delta;
   }
   const int fp = __builtin_amdgcn_readlane(rec, 1), fb = __builtin_amdgcn_readlane(rec, 2);
+  if (direct) {                                         // (kernel argument: uniform)
+    if (fp <= 16) wave_front_solve_level<4, true>(d2, rec, W); else wave_front_solve_level<5, true>(d2, rec, W);
+    return;
+  }
   if (kLevelSolveLean && fp <= 32 && fb <= 64 && (fp + fb + 1) * fp <= 1024) {
     if (fp <= 16) wave_front_solve_level<4>(d2, rec, W); else wave_front_solve_level<5>(d2, rec, W);
     return;
@@ -1620,6 +1653,7 @@ __global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, in
 }
 
 // level-per-launch kernels: the packed triangle of a front of <= 16 nt rows (+ rhs), whose head doubles as the 8-column panel buffer, + the spare double
+bool band_level_solve_direct_ok(int p, int b) { return level_solve_direct_ok(p, b); }
 static int level_lds_doubles(int nt) {
   const size_t fa = (size_t)16 * nt + 1, n = std::max<size_t>(fa * (fa + 1) / 2, (size_t)kRegRows * kP8Stride) + 1;
   return (int)((n + 1) & ~size_t(1));
@@ -1654,8 +1688,11 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     for (int l = g.n_levels - 1; l >= 0; l--)
       if (g.lvl_blocks[l] > 0) {
         // (LDS by the level's own largest panel: the separators above the leaves hold a third of a leaf's panel -- five waves per SIMD instead of three)
-        const int pw = std::min(g.solve_per_wave_all, (int)(band_solve_lds_bytes(g.lvl_max_panel[l]) / sizeof(double))) + kLevelSolveSlack;
-        PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)pw * 4 * sizeof(double), st, a, l, pw);
+        int pw = std::min(g.solve_per_wave_all, (int)(band_solve_lds_bytes(g.lvl_max_panel[l]) / sizeof(double))) + kLevelSolveSlack;
+        // ... and by x_b + the pivot block alone where every front of the level takes the direct-load form (lvl_direct_pp: its largest p x p)
+        const int direct = kLevelSolveLean && g.lvl_direct_pp[l] > 0 ? 1 : 0;
+        if (direct) pw = std::min(pw, kBandMaxRows + g.lvl_direct_pp[l] + kLevelSolveSlack);
+        PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)pw * 4 * sizeof(double), st, a, l, pw, direct);
       }
     return hipGetLastError();
   }

@@ -241,6 +241,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     int max_panel[32] = {0};
     for (int stg = 0; stg < 32; stg++) q.stage_reg_only[stg] = true;
     bool level_ok = true;
+    bool lvl_direct_bad[64] = {false};
     for (int i = c * CH; i < std::min(G, (c + 1) * CH); i++) {
       const pps_graph* g = m->gs[i];
       const DevGraph& d = g->dev;
@@ -263,7 +264,11 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       if (A.n_levels > 64 || A.max_front + 1 > band_reg_rows() || g->dev.trace) level_ok = false;
       for (int s2 = 0; s2 < A.n_fronts; s2++) {
         const int l = A.f_level[s2];
-        if (l >= 0 && l < 64) q.lvl_max_panel[l] = std::max(q.lvl_max_panel[l], (A.f_p[s2] + A.f_b[s2] + 1) * A.f_p[s2]);
+        if (l >= 0 && l < 64) {
+          q.lvl_max_panel[l] = std::max(q.lvl_max_panel[l], (A.f_p[s2] + A.f_b[s2] + 1) * A.f_p[s2]);
+          if (!band_level_solve_direct_ok(A.f_p[s2], A.f_b[s2])) lvl_direct_bad[l] = true;
+          q.lvl_direct_pp[l] = std::max(q.lvl_direct_pp[l], A.f_p[s2] * A.f_p[s2]);
+        }
       }
       for (int l = 0; l < A.n_levels && l < 64; l++) {
         for (int c2 = 0; c2 < 3; c2++) q.lvl_cls_blocks[l][c2] = std::max(q.lvl_cls_blocks[l][c2], (A.cls_off[3 * l + c2 + 1] - A.cls_off[3 * l + c2] + 3) / 4);
@@ -280,6 +285,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         if (A.stage_max_front[stg] + 1 > band_reg_rows() || g->dev.trace) q.stage_reg_only[stg] = false;
       }
     }
+    for (int l = 0; l < 64; l++) if (lvl_direct_bad[l]) q.lvl_direct_pp[l] = 0;
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
     const long long thr = m->sw.multi_thread_factors;          // 200 000 (PPS_MULTI_THREAD_FACTORS lowers it for the tests)
