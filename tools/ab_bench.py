@@ -72,7 +72,10 @@ def multi(G, reps, mode=P.JAC_NUMERIC):
     mm.restore_state()
     mm.optimize(); ph = mm.phase_times(); mm.set_profiling(0)
     out = {"graphs": G, "graphs_per_s": G * reps / el, "ms_per_batch": 1e3 * el / reps, "rounds": mm.rounds(), "hash8": h, "restore_ms": 1e3 * t_restore / reps,
-           "phase_ms": {k: 1e3 * ph[k] for k in ("linearize", "assemble", "factor", "backsolve", "trial")}}
+           "phase_ms": {k: 1e3 * ph[k] for k in ("linearize", "assemble", "factor", "backsolve", "trial")},
+           # what a kernel summary of this process holds: batch solves made, and per batch solve the factorisations / linearisations
+           "batch_solves_in_process": 2 + reps, "factorisations_per_batch_solve": ph["n_solves"], "relinearisations_per_batch_solve": ph["n_relinearized"],
+           "n_chunks_profiled": ph["n_chunks"], "thread_form": ph["thread_form"], "level_form": ph["level_form"]}
     mm.close()
     for gk in gs:
         gk.close()

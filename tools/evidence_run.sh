@@ -6,7 +6,7 @@
 # instruction mix / occupancy of the C2 and the pps_multi kernels; one front under the counters, this build and round 3's).
 # PMC passes run on their own, with --kernel-trace only.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ROOT=$(pwd); tag=${1:-r4}; out=$ROOT/gpurun_out/$tag; raw=/tmp/evidence_$tag; mkdir -p $out $raw   # (raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
+ROOT=$(pwd); tag=${1:-r5}; out=$ROOT/gpurun_out/$tag; raw=/tmp/evidence_$tag; mkdir -p $out $raw   # (raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
 export TMPDIR=/tmp
 cd /tmp
 summary() {   # summary NAME -- cmd...: rocprofv3 kernel trace of the command, summarised into $out/kernel_stats_NAME.txt
@@ -34,6 +34,29 @@ if d:
 PY
 summary c3 -- python $ROOT/tools/ab_bench.py c3 3                   # C3 (incl. one solve of the one-step profiling loop)
 summary multi128 -- python $ROOT/tools/ab_bench.py multi 128 1      # G = 128 through pps_multi (level-per-launch kernels)
+python - $out $raw <<'PY'
+# per-batch-solve footer of the G = 128 summary: launches and device time per kernel and batch solve, so that roofline_k3_hbm / roofline_k1
+# of the bench line can be recomputed from this file alone (algorithmic bytes x factorisations per batch solve / factor time per batch solve)
+import sqlite3, sys, glob, os, json
+out, raw = sys.argv[1], sys.argv[2]
+js = None
+for ln in open(os.path.join(out, "kt_multi128.log")):
+    if ln.startswith("AB "): js = json.loads(ln[3:])
+db = sqlite3.connect(sorted(glob.glob(os.path.join(raw, "kt_multi128", "**", "*.db"), recursive=True))[0])
+n = js["batch_solves_in_process"] if js else 3
+with open(os.path.join(out, "kernel_stats_multi128.txt"), "a") as f:
+    f.write("\n# per batch solve (%d batch solves in this process: warm-up, timed, event-timed): launches and device time per kernel\n" % n)
+    fac = 0.0
+    for name, c, tot in db.execute("select name, count(*), sum(end-start) from kernels group by name order by 3 desc"):
+        if "pps::" not in name: continue
+        f.write("%-64s %8.1f launches %10.3f ms\n" % (name.split("(")[0].replace("void ", "").replace("pps::", "")[:64], c / n, tot / 1e6 / n))
+        if "kb_level_factor" in name: fac += tot / 1e6 / n
+    if js:
+        nf, nr = js["factorisations_per_batch_solve"], js["relinearisations_per_batch_solve"]
+        f.write("# factorisations per batch solve %d, linearisations %d; kb_level_factor2/3/4 together %.3f ms per batch solve\n" % (nf, nr, fac))
+        f.write("# roofline_k3_hbm = 9 151 092 B x %d / %.3f ms = %.0f GB/s = %.3f of 8 TB/s (event-timed phase of the bench line: phase_ms.factor = %.3f ms)\n"
+                % (nf, fac, 9151092.0 * nf / (fac * 1e-3) / 1e9, 9151092.0 * nf / (fac * 1e-3) / 1e9 / 8000.0, js["phase_ms"]["factor"]))
+PY
 summary multi8 -- python $ROOT/tools/ab_bench.py multi 8 2          # G = 8 (band kernels, lane-form K1)
 summary sweep_numeric -- python $ROOT/tools/sweep_only.py 0 108     # roofline_batched: numeric thread form
 summary sweep_analytic -- python $ROOT/tools/sweep_only.py 1 108
@@ -95,6 +118,8 @@ with open(os.path.join(out, "pmc_multi_kernels.txt"), "w") as f:
     for (form, k), r in sorted(rows.items()):
         f.write("%-7s %-26s %6d %9.1f " % (form, k[:26], r.get("dispatches", 0), r.get("duration_us", 0)) + " ".join("%15.0f" % r.get(c, float("nan")) for c in cs) + "\n")
 PY
+# 5b. PMC: HBM bytes of the G = 128 kernels (FETCH_SIZE / WRITE_SIZE passes)
+( cd /tmp && timeout 600 python $ROOT/tools/pmc_multi_hbm.py $raw/pmc_multi_hbm 128 > $out/pmc_multi128_hbm.txt 2> $out/pmc_multi128_hbm.err )
 # 6. PMC: the single-graph kernels of a C2 LM solve (instruction mix per launch; two factorisations / trials per launch)
 for pass in "SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR"; do
   d=$raw/pmc_c2_$(echo $pass | tr ' ' '_')
