@@ -73,7 +73,7 @@ def short_name(mangled):
 DESIGN_KERNELS = [
     ("k_linearize_lanes", "K1, lane form"), ("k_linearize_obs_numeric", "K1, thread form: plane observations"),
     ("kb_linearize<0, 0, true>", ""), ("kb_linearize<0, 1, false>", "odometry / priors, numeric"),
-    ("k_hblocks2", "K2"), ("k_hfinish", ""), ("kb_hblocks_tc", "K2 of large batches, by segment class"),
+    ("k_hblocks2", "K2"), ("k_hfinish", ""), ("kb_hblocks_tc", "K2 of large batches: class bodies"), ("kb_hblocks_tg", "... the generic body"),
     ("k_band_factor_pre", "C2: pre-assembling walk, NT 2-4"), ("k_band_root<true, true>", "top group: pre-assembling walk + data-flow back-substitution in one launch"), ("k_band_root<false, false>", "top group, plain walk / barrier form"),
     ("k_band_solve_flow", "data-flow back-substitution"), ("k_band_solve", "barrier form"),
     ("k_band_factor<true>", "plain walk"), ("k_band_factor<false>", "general: traces"), ("k_band_factor_r5", "fronts of 65-80 rows"),
