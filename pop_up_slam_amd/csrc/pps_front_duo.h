@@ -23,7 +23,8 @@
 // helper may still be reading.
 // Arithmetic: the operations of front_reg_eliminate<NT, false, false, 4> on the same operands in the same order -- per entry the
 // original value, child 0, child 1, then one MFMA per panel; the pivot block is chol4 / trsm4 / rank4 -- so a front comes out
-// bit-identical whether one wave or two eliminate it (tests/test_gpu_fronts.py::test_two_waves_per_front, the loop-form tests).
+// bit-identical whether one wave or two eliminate it (tests/test_gpu_duo.py: the `make duo` build against the shipped one).
+// NOT SHIPPED: measured slower than one wave per front; compiled in only with -DPPS_DUO_MODE=1..3.
 #pragma once
 #include "pps_front_reg.h"
 
