@@ -680,7 +680,8 @@ __device__ __forceinline__ void front_extend_add_part(const DevGraph& d, int rec
 // triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
 // panel widths of the two families of kernels (build-time, A/B: -DPPS_PANEL_W_BAND=4 / -DPPS_PANEL_W_LEVEL=4)
 #ifndef PPS_PANEL_W_BAND
-#define PPS_PANEL_W_BAND 4      // (C2: 73.1 us per LM iteration against 74.1 with 8 -- a lone wave per SIMD is bound by the pivot chain)
+#define PPS_PANEL_W_BAND 4      // (C2: 73.1 us per LM iteration against 74.1 with 8 -- a lone wave per SIMD is bound by the pivot chain; round 5:
+                                // 16 = front_reg_eliminate16, a whole tile column in registers: 67.0 against 60.3 us, same bits -- DESIGN.md section 8)
 #endif
 #ifndef PPS_PANEL_W_LEVEL
 #define PPS_PANEL_W_LEVEL 8
@@ -708,9 +709,11 @@ __device__ __forceinline__ void front_assemble(const DevGraph& d, int rec, doubl
   if (TR) PPS_TR(3);
 }
 // Second half: elimination in registers, factor panel and update matrix out.
+// W = 16 (the register-only band kernels since round 5, PPS_PANEL_W_BAND): a tile column per LDS round trip, front_reg_eliminate16 -- same bits
 template <int NT, bool TR, bool STRIP = false, int W = PPS_PANEL_W_BAND>
 __device__ __forceinline__ void front_eliminate_out(const DevGraph& d, int rec, double* F, double* P) {
-  front_reg_eliminate<NT, TR, STRIP, W>(d, rec, F, P);
+  if constexpr (W == 16 && !TR && !STRIP && NT <= 4) front_reg_eliminate16<NT>(d, rec, F, P);
+  else front_reg_eliminate<NT, TR, STRIP, (W == 16 ? 4 : W)>(d, rec, F, P);
 }
 // One front from start to end (the level-per-launch kernels: one tile count per kernel)
 template <int NT, bool TR, bool STRIP = false, int W = PPS_PANEL_W_BAND>

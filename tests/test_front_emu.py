@@ -13,28 +13,48 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _dp = C.POINTER(C.c_double)
 
 
-@pytest.fixture(scope="module")
-def emu():
+def _emu_lib(fused):
+    """the emulation library; fused: built with -mfma -ffp-contract=fast, so that a - b * c is ONE operation on the host as it is in the GPU's
+    `#pragma clang fp contract(fast)` regions (g++ ignores the pragma) -- what a bit-for-bit comparison of two forms needs, since the emulated
+    MFMA accumulates with fused multiply-adds like the hardware"""
     src = os.path.join(ROOT, "tests", "cpp", "front_emu.cpp")
-    out = os.path.join(ROOT, "tests", "cpp", "libfront_emu.so")
+    out = os.path.join(ROOT, "tests", "cpp", "libfront_emu_fma.so" if fused else "libfront_emu.so")
     deps = [src, os.path.join(ROOT, "tests", "cpp", "wave_emu.h")] + [os.path.join(ROOT, "pop_up_slam_amd", "csrc", h) for h in ("pps_front_reg.h", "pps_regtile.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-psabi", "-Wno-unknown-pragmas", "-ffp-contract=off",
-                               "-I" + os.path.join(ROOT, "pop_up_slam_amd", "csrc"), src, "-o", out])
-    lib = C.CDLL(out)
+        fp = ["-mfma", "-ffp-contract=fast"] if fused else ["-ffp-contract=off"]
+        subprocess.check_call(["g++", "-O2" if fused else "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-psabi", "-Wno-unknown-pragmas"] + fp +
+                              ["-I" + os.path.join(ROOT, "pop_up_slam_amd", "csrc"), src, "-o", out])
+    return C.CDLL(out)
+
+
+def _runner(lib):
     lib.emu_front_factor.argtypes = [C.c_int] * 4 + [_dp, _dp, _dp, _dp, C.POINTER(C.c_longlong)]
     lib.emu_front_factor_w4.argtypes = lib.emu_front_factor.argtypes
+    lib.emu_front_factor_w16.argtypes = lib.emu_front_factor.argtypes
 
     def run(tri, p, b, tiles=0, strip=False, w=8):
         fa = p + b + 1
         a = np.ascontiguousarray(tri, dtype=np.float64)
         assert a.size == fa * (fa + 1) // 2
         L = np.zeros((fa, p)); U = np.zeros((b + 1) * (b + 2) // 2); bad = C.c_double(); cnt = (C.c_longlong * 3)()
-        rc = (lib.emu_front_factor if w == 8 else lib.emu_front_factor_w4)(tiles, int(strip), p, b, a.ctypes.data_as(_dp), L.ctypes.data_as(_dp), U.ctypes.data_as(_dp), C.byref(bad), cnt)
+        rc = {8: lib.emu_front_factor, 4: lib.emu_front_factor_w4, 16: lib.emu_front_factor_w16}[w](tiles, int(strip), p, b, a.ctypes.data_as(_dp), L.ctypes.data_as(_dp), U.ctypes.data_as(_dp), C.byref(bad), cnt)
         if rc != 0:
             raise ValueError(rc)
         return L, U, bad.value, list(cnt)
     return run
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return _runner(_emu_lib(False))
+
+
+@pytest.fixture(scope="module")
+def emu_fused():
+    with open("/proc/cpuinfo") as f:
+        if " fma " not in f.read():
+            pytest.skip("host CPU without FMA: the fused build of the emulation cannot run")
+    return _runner(_emu_lib(True))
 
 
 def _front(p, b, seed):
@@ -100,6 +120,33 @@ def test_four_column_panels(emu):
     for p, b in [(6, 70), (21, 50), (48, 31), (64, 15)]:
         _check(emu, p, b, 5, False, seed=p, w=4)
         _check(emu, p, b, 4, True, seed=p, w=4)
+
+
+def test_sixteen_column_panels(emu, emu_fused):
+    """front_reg_eliminate16 (a tile column per LDS round trip, rank-1 elimination in registers: the band kernels since round 5) against
+    numpy for every pivot count, and BIT FOR BIT against the 4-column form: per entry the same operations in the same order"""
+    rng = np.random.default_rng(9)
+    for p in range(1, 64):
+        for b in sorted({0, 1, int(rng.integers(0, 64 - p)), 63 - p}):
+            if p + b + 1 > 64:
+                continue
+            _check(emu, p, b, 0, False, seed=100 * p + b, w=16)
+            _, _, tri = _front(p, b, 100 * p + b)
+            L4, U4, bad4, _ = emu_fused(tri, p, b, 0, False, 4)
+            L16, U16, bad16, _ = emu_fused(tri, p, b, 0, False, 16)
+            ok = np.tril(np.ones((p + b + 1, p), dtype=bool))          # (above the diagonal of L_A: unspecified in both)
+            assert np.array_equal(L4[ok], L16[ok]) and np.array_equal(U4, U16) and bad4 == bad16, (p, b)
+    for p, b in [(4, 8), (6, 8), (9, 20), (15, 16), (15, 33), (18, 30), (27, 20)]:
+        for tiles in (2, 3, 4):
+            if p + b <= 16 * tiles:
+                _check(emu, p, b, tiles, False, seed=tiles, w=16)
+    _, _, tri = _front(14, 10, 1)
+    t = tri.copy(); t[13 * 14 // 2 + 13] = -1e6
+    assert emu(t, 14, 10, 0, False, 16)[2] == 1.0 and emu(tri, 14, 10, 0, False, 16)[2] == 0.0
+    # what it buys, counted by the emulation: a separator front of a C2 tree (p = 15, b = 33) is ONE round trip through the panel buffer
+    c16 = emu(_front(15, 33, 0)[2], 15, 33, 0, False, 16)[3]
+    c4 = emu(_front(15, 33, 0)[2], 15, 33, 0, False, 4)[3]
+    assert c16[2] < c4[2] and c16[1] <= c4[1]
 
 
 def test_cross_lane_operations_per_front(emu):
