@@ -103,11 +103,17 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
     load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
     load_soa<6>(d.obs_w, d.obs_ld, i, w);
     lin_plane_obs<MODE>(pz, pl, ms, w, out);
-    if (DIRECT && b * kLinBlock + (int)threadIdx.x < d.n_obs_fixed) {
-      const int hoff = d.obs_dir[3 * (size_t)i], el0 = d.obs_dir[3 * (size_t)i + 1], rows6 = d.obs_dir[3 * (size_t)i + 2];
+    if (DIRECT) {
+      // Round 5: the 18 entries of a direct block leave through the LDS like the Jacobian records.  Written straight from the lanes, every
+      // store instruction was 64 pieces of 8 bytes in 64 different lines -- the PMC counters showed 1.2 KB written per observation for 528
+      // bytes of records and blocks (profiles/r5_pmc_multi128_hbm.txt: 84 GB against 22 GB read).  Now lane l stages its block in row l of
+      // a 64 x 19 buffer and the wave writes the 1 152 entries in order: a store instruction covers three to four whole blocks.
+      const int lane = threadIdx.x & 63;
+      int hoff = -1, el0 = -1, rows6 = 0;
+      if (b * kLinBlock + (int)threadIdx.x < d.n_obs_fixed) { hoff = d.obs_dir[3 * (size_t)i]; el0 = d.obs_dir[3 * (size_t)i + 1]; rows6 = d.obs_dir[3 * (size_t)i + 2]; }
+      double* __restrict__ S = lds_wave;                                  // 64 x 19 doubles, then 2 x 64 ints (H offset, Hf offset per lane)
+      int* __restrict__ SI = reinterpret_cast<int*>(lds_wave + 64 * 19);
       if (hoff >= 0) {
-        double* __restrict__ h = d.H + hoff;
-        double* __restrict__ hf = d.Hf + el0;
         // block (v, u), rows = the node eliminated later: entry (i, j) = sum_k Jv[k][i] * Ju[k][j], k = 0, 1, 2
 #pragma unroll
         for (int e = 0; e < 18; e++) {
@@ -119,10 +125,19 @@ __device__ __forceinline__ void body_linearize(const DevGraph& d, const double* 
             const double bv = rows6 ? out[18 + k * 3 + cj] : out[k * 6 + cj];
             acc = PPS_MAC(acc, av, bv);
           }
-          h[e] = acc;
-          if (el0 >= 0) hf[e] = acc;
+          S[lane * 19 + e] = acc;
         }
       }
+      SI[lane] = hoff; SI[64 + lane] = el0;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 18; u++) {
+        const int it = lane + 64 * u, o = it / 18, e = it - 18 * o;
+        const int ho = SI[o], eo = SI[64 + o];
+        const double v = S[o * 19 + e];
+        if (ho >= 0) { d.H[ho + e] = v; if (eo >= 0) d.Hf[eo + e] = v; }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     if (i0 < d.n_obs_fixed) store_records_coalesced<30>(out, d.J + d.joff_obs + (size_t)i0 * 30, min(64, d.n_obs_fixed - i0), lds_wave);
     if (DIRECT && d.P && i0 < d.n_obs_fixed) {                  // the product record K2 sums (two staged halves of 27 doubles); P is null where K2 multiplies the Jacobians itself
