@@ -2,6 +2,7 @@
 only; corrections as tools/pmc_k1_sweep.py: FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact -- tools/calib_copy.hip).
 
   python tools/pmc_multi_hbm.py OUTDIR [G]     -> OUTDIR/pmc_multi_hbm.txt (per kernel: dispatches, total bytes, GB/s over its own time)
+  python tools/pmc_multi_hbm.py OUTDIR c3|c2|c5 [arg]   the same for another tools/ab_bench.py workload
 """
 import glob
 import os
@@ -12,9 +13,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_pass(outdir, counter, G):
+def run_pass(outdir, counter, what):
     d = os.path.join(outdir, f"pmc_{counter}")
-    subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable, os.path.join(ROOT, "tools", "ab_bench.py"), "multi", str(G), "1"],
+    subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable, os.path.join(ROOT, "tools", "ab_bench.py")] + what,
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     rows = []
     for path in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
@@ -25,11 +26,13 @@ def run_pass(outdir, counter, G):
 
 def main():
     outdir = sys.argv[1]
-    G = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    a = sys.argv[2:] or ["128"]
+    what = ["multi", a[0], "1"] if a[0].isdigit() else [a[0]] + (a[1:] or ["1"])
     os.makedirs(outdir, exist_ok=True)
-    f = run_pass(outdir, "FETCH_SIZE", G)
-    w = run_pass(outdir, "WRITE_SIZE", G)
-    lines = [f"# pps_multi G = {G} (tools/ab_bench.py multi {G} 1): HBM bytes per kernel, FETCH_SIZE x 2 (gfx950 correction) and WRITE_SIZE, KiB -> bytes",
+    f = run_pass(outdir, "FETCH_SIZE", what)
+    w = run_pass(outdir, "WRITE_SIZE", what)
+    G = " ".join(what)
+    lines = [f"# tools/ab_bench.py {G}: HBM bytes per kernel, FETCH_SIZE x 2 (gfx950 correction) and WRITE_SIZE, KiB -> bytes",
              "%-52s %8s %12s %12s %10s %10s" % ("kernel", "calls", "read MB", "written MB", "time ms", "GB/s")]
     for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0, 0))[2])):
         fr, n, dur = f.get(k, (0, 0, 0))
