@@ -525,6 +525,9 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // scatter-add items per lane in flight in the extend-add.  Measured on C2 (us per LM iteration): 8 -> 78.9, 10 -> 77.6,
 // 12 -> 78.5, 16 -> 92.4 -- more loads in flight than about two dozen per lane cost more than the round trips they save
 constexpr int kEaDepth = 10;
+#ifndef PPS_ORIG_PLAIN_STORE
+#define PPS_ORIG_PLAIN_STORE 1
+#endif
 template <int N> struct ElBatch { int tg[N]; double v[N]; };
 // loads are issued unconditionally from clamped (always valid) addresses and masked by selects afterwards: predicated loads
 // become one exec-masked basic block each and serialise
@@ -543,6 +546,16 @@ __device__ __forceinline__ void el_issue(const int* __restrict__ tgp, const doub
 // items past the end go to the spare double `tr` with a zero increment, so that nothing is predicated.
 template <bool ORIG, int N>     // ORIG: entries of H (bit 30 of the target = diagonal element, damped: Cholesky.cpp:94-97)
 __device__ __forceinline__ void el_apply(const ElBatch<N>& q, double damp, double* __restrict__ F, int tr) {
+  if constexpr (ORIG && PPS_ORIG_PLAIN_STORE) {
+    // Round 5: the original entries are the FIRST thing a cleared triangle receives and their targets are pairwise distinct, so old + inc is
+    // 0 + inc = inc (H entries are sums that start at +0: never -0): a plain store -- no LDS read, no add, one LDS round trip less per batch.
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+      const int t = q.tg[u] >= 0 ? (q.tg[u] & 0x3fffffff) : tr;
+      F[t] = (q.tg[u] & (1 << 30)) && q.tg[u] >= 0 ? q.v[u] * damp : q.v[u];        // (tg = -1: v = 0 into the spare double)
+    }
+    return;
+  }
   int t[N]; double old[N];
 #pragma unroll
   for (int u = 0; u < N; u++) { t[u] = q.tg[u] >= 0 ? (ORIG ? (q.tg[u] & 0x3fffffff) : q.tg[u]) : tr; old[u] = F[t[u]]; }
