@@ -54,6 +54,16 @@ def test_gpus_flag_must_match_the_launcher(built):
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
 
 
+def test_more_ranks_than_devices_is_refused(built):
+    """no GPU here: `python bench.py --gpus 2` starts its two ranks, and each refuses to run on devices that do not exist (instead of two
+    ranks sharing device 0 unasked: that needs PPS_BENCH_SHARED_GPU=1)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PPS_BENCH_SHARED_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "device(s) visible" in out.stderr, out.stderr[-1000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 def test_single_rank_dry_run(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-dry-run"], capture_output=True, text=True,
                          timeout=600, cwd=ROOT)
