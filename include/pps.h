@@ -38,7 +38,8 @@ extern "C" {
 #endif
 
 #define PPS_VERSION 303   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301;
-                              pps_multi_save_state / pps_multi_restore_state: 302; pps_debug_exmap: 303) */
+                              pps_multi_save_state / pps_multi_restore_state: 302; pps_debug_exmap AND pps_multi_phase_times' counts[] grown from 2 to 4
+                              entries -- a caller built against 302 that passes counts[2] must be rebuilt: 303) */
 
 typedef struct pps_graph pps_graph;
 

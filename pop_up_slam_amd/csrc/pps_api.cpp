@@ -13,35 +13,29 @@ Switches read_switches() {
   auto num = [](const char* k, long long dflt) { const char* e = getenv(k); return e && *e ? atoll(e) : dflt; };
   Switches s;
   s.k1_thread_form = on("PPS_K1_THREAD_FORM");
-  s.no_preassemble = on("PPS_NO_PREASSEMBLE");
-  s.no_solve_flow = on("PPS_NO_SOLVE_FLOW");
-  s.no_root_fuse = on("PPS_NO_ROOT_FUSE");
-  s.always_dual = on("PPS_ALWAYS_DUAL");
+  {
+    long long plain = num("PPS_PLAIN_SCHEDULE", 0);
+    if (on("PPS_PLAIN_SCHEDULE") && plain <= 0) plain = 15;
+    s.no_preassemble = (plain & 1) != 0; s.no_solve_flow = (plain & 2) != 0; s.no_root_fuse = (plain & 4) != 0; s.split_expand = (plain & 8) != 0;
+  }
   s.no_spec_lin = on("PPS_NO_SPEC_LIN");
   s.no_dual = on("PPS_NO_DUAL");
   s.no_strip = on("PPS_NO_STRIP");
-  s.split_expand = on("PPS_SPLIT_EXPAND");
   s.no_incremental = on("PPS_NO_INCREMENTAL");
   s.no_incr_compact = on("PPS_NO_INCR_COMPACT");
-  s.no_upload_hints = on("PPS_NO_UPLOAD_HINTS");
   s.verify_upload = on("PPS_DEBUG_VERIFY_UPLOAD");
-  s.upload_timing = on("PPS_UPLOAD_TIMING");
-  s.analysis_timing = on("PPS_ANALYSIS_TIMING");
-  s.k2t_generic = on("PPS_K2T_GENERIC");
   s.multi_levels = on("PPS_MULTI_LEVELS");
-  s.multi_no_levels = on("PPS_MULTI_NO_LEVELS");
   s.multi_thread_form = on("PPS_MULTI_THREAD_FORM");
-  s.multi_no_thread_form = on("PPS_MULTI_NO_THREAD_FORM");
-  s.multi_lockstep = on("PPS_MULTI_LOCKSTEP");
   s.debug_drop_flag = on("PPS_DEBUG_DROP_FLAG");
-  s.no_duo = on("PPS_NO_DUO");
   s.trace = (int)num("PPS_TRACE", 0);
-  s.multi_timing = (int)num("PPS_MULTI_TIMING", 0);
-  s.multi_split = (int)num("PPS_MULTI_SPLIT", 0);
-  s.band_levels = (int)num("PPS_BAND_LEVELS", 0);
-  s.multi_thread_factors = num("PPS_MULTI_THREAD_FACTORS", 200000);
   if (on("PPS_TRACE") && s.trace < 1) s.trace = 1;
-  if (on("PPS_MULTI_TIMING") && s.multi_timing < 1) s.multi_timing = 1;
+  {
+    long long tm = num("PPS_TIMING", 0);
+    if (on("PPS_TIMING") && tm <= 0) tm = 7;
+    s.analysis_timing = (tm & 1) != 0; s.upload_timing = (tm & 2) != 0; s.multi_timing = (tm & 8) ? 2 : ((tm & 4) ? 1 : 0);
+  }
+  s.multi_split = (int)num("PPS_MULTI_SPLIT", 0);
+  s.multi_thread_factors = num("PPS_MULTI_THREAD_FACTORS", 200000);
   return s;
 }
 }  // namespace pps

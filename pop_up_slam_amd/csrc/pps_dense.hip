@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_dense_panel(DevGraph d, int level_begin
       if (nb > 1) { const double t = d11 - l10 * l10; bad |= !(t > 0.0); i1 = t > 0.0 ? rsqrt_nr(t) : 0.0; l21 = (d21 - l20 * l10) * i1; l31 = (d31 - l30 * l10) * i1; }
       if (nb > 2) { const double t = d22 - l20 * l20 - l21 * l21; bad |= !(t > 0.0); i2 = t > 0.0 ? rsqrt_nr(t) : 0.0; l32 = (d32 - l30 * l20 - l31 * l21) * i2; }
       if (nb > 3) { const double t = d33 - l30 * l30 - l31 * l31 - l32 * l32; bad |= !(t > 0.0); i3 = t > 0.0 ? rsqrt_nr(t) : 0.0; }
-      if (bad && lane == 0 && slab == 0) d.result_dev[2] = 1.0;                // not positive definite
+      if (bad && lane == 0 && slab == 0) raise_status(&d.result_dev[2], 1.0);                // not positive definite
       const double x0 = r0 * i0;
       const double x1 = (r1 - x0 * l10) * i1;
       const double x2 = (r2 - x0 * l20 - x1 * l21) * i2;

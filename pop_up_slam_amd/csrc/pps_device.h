@@ -67,11 +67,6 @@ struct DevGraph {
   int *blk_doff = nullptr, *blk_dst = nullptr;
   double* Hf = nullptr;      // H in front gather order: front s reads Hf[f_el_off[s] .. f_el_off[s+1])
   int64_t* f_ea_off = nullptr; int* ea_tgt = nullptr;
-  // two waves per front (pps_front_duo.h): per child RECORD (crec index) the split of the child's packed update matrix between the
-  // parent's two waves -- entries [0, split) land in rows of the parent below r1, the row that halves the children's entries; filled
-  // on the device by the list expansion (expand_split, pps_k3.hip)
-  int* c_split = nullptr;
-  int* f_crec0 = nullptr;            // front id -> first child record
   int *grp_lvl_off = nullptr, *glvl_front_off = nullptr, *glvl_fronts = nullptr;
   int* grp_span = nullptr;          // per band group, 8 ints: first position in glvl order, fronts, local levels, first position of local levels 1 .. 4, 0
   int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
@@ -110,36 +105,33 @@ struct DevGraph {
 // pps_multi_create / pps_popup_create ... call read_switches() -- and never on a launch path: a handle keeps the schedule it was
 // created with whatever the environment does later (A/B tools and the parity tests set the variable before they create the handle).
 constexpr double kStatusInternal = 64.0;   // result_dev[2] at or above this: an internal time-out inside a kernel (PPS_EHIP), not a not-PD pivot
-enum : unsigned { SW_K1_THREAD_FORM = 1u, SW_NO_SOLVE_FLOW = 2u, SW_NO_ROOT_FUSE = 4u, SW_DEBUG_DROP_FLAG = 8u, SW_NO_DUO = 16u };
+enum : unsigned { SW_K1_THREAD_FORM = 1u, SW_NO_SOLVE_FLOW = 2u, SW_NO_ROOT_FUSE = 4u, SW_DEBUG_DROP_FLAG = 8u };
+// Fifteen variables (INTEGRATION.md lists them): each one selects a path that some graph shape takes anyway (so the parity tests can put every
+// graph through it) or a diagnostic.  A/B switches of experiments whose losing side was deleted do not exist.
 struct Switches {
   bool k1_thread_form = false;      // PPS_K1_THREAD_FORM: thread-per-factor K1 (no product records) on graphs of any size
-  bool no_preassemble = false;      // PPS_NO_PREASSEMBLE: plain walk of a band group instead of k_band_factor_pre
-  bool no_solve_flow = false;       // PPS_NO_SOLVE_FLOW: barrier form of the band back-substitution
-  bool no_root_fuse = false;        // PPS_NO_ROOT_FUSE: root stage as two launches
-  bool always_dual = false;         // PPS_ALWAYS_DUAL: no adaptive speculation on graphs of >= 2 048 fronts
-  bool no_spec_lin = false;         // PPS_NO_SPEC_LIN: no linearisation queued behind the trials
+  // PPS_PLAIN_SCHEDULE=<bits> (no value: all): the fall-back schedules that graphs of other shapes take, forced onto every graph --
+  bool no_preassemble = false;      //   1  plain walk of a band group instead of k_band_factor_pre
+  bool no_solve_flow = false;       //   2  barrier form of the band back-substitution
+  bool no_root_fuse = false;        //   4  root stage as two launches
+  bool split_expand = false;        //   8  list expansion as two launches + a fill
+  bool no_spec_lin = false;         // PPS_NO_SPEC_LIN: nothing of the next linearisation is computed before the trials' verdict is known
   bool no_dual = false;             // PPS_NO_DUAL: the one-step-at-a-time LM loop
-  bool no_strip = false;            // PPS_NO_STRIP
-  bool split_expand = false;        // PPS_SPLIT_EXPAND: list expansion as two launches + a fill
+  bool no_strip = false;            // PPS_NO_STRIP: fronts of 65 .. 80 rows through the LDS-tile path
   bool no_incremental = false;      // PPS_NO_INCREMENTAL: every analysis from scratch
   bool no_incr_compact = false;     // PPS_NO_INCR_COMPACT: compacted tables rebuilt per analysis
-  bool no_upload_hints = false;     // PPS_NO_UPLOAD_HINTS
-  bool verify_upload = false;       // PPS_DEBUG_VERIFY_UPLOAD: read the arena back after every flush
-  bool upload_timing = false;       // PPS_UPLOAD_TIMING
-  bool analysis_timing = false;     // PPS_ANALYSIS_TIMING
-  bool k2t_generic = false;         // PPS_K2T_GENERIC: one-body throughput form of K2
-  bool multi_levels = false, multi_no_levels = false, multi_thread_form = false, multi_no_thread_form = false;   // PPS_MULTI_*
-  bool multi_lockstep = false;      // PPS_MULTI_LOCKSTEP: a barrier over all chunks between rounds
-  bool no_duo = false;              // PPS_NO_DUO: one wave per front everywhere (no helper waves in the band factorisation)
+  bool verify_upload = false;       // PPS_DEBUG_VERIFY_UPLOAD: read the arena back after every flush, compare every skipped prefix
+  bool multi_levels = false, multi_thread_form = false;   // PPS_MULTI_LEVELS / PPS_MULTI_THREAD_FORM: the throughput forms on small batches
   bool debug_drop_flag = false;     // PPS_DEBUG_DROP_FLAG: the data-flow back-substitution withholds one hand-over flag (tests the time-out path)
   int trace = 0;                    // PPS_TRACE: 1 = phase timestamps of the factorisation, 2 = of the back-substitution
-  int multi_timing = 0;             // PPS_MULTI_TIMING
-  int band_levels = 0;              // PPS_BAND_LEVELS: tree levels per band launch (0 = by graph size)
+  // PPS_TIMING=<bits>: host-side timing printed to stderr -- 1 analysis phases, 2 upload phases, 4 pps_multi totals, 8 pps_multi rounds
+  bool analysis_timing = false, upload_timing = false;
+  int multi_timing = 0;             //   (0 off, 1 totals, 2 rounds)
   int multi_split = 0;              // PPS_MULTI_SPLIT: chunks a batch is cut into (0 = by size)
   long long multi_thread_factors = 200000;   // PPS_MULTI_THREAD_FACTORS: factors per chunk above which a batch takes the throughput forms
   unsigned dev_bits() const {
     return (k1_thread_form ? SW_K1_THREAD_FORM : 0u) | (no_solve_flow ? SW_NO_SOLVE_FLOW : 0u) | (no_root_fuse ? SW_NO_ROOT_FUSE : 0u) |
-           (debug_drop_flag ? SW_DEBUG_DROP_FLAG : 0u) | (no_duo ? SW_NO_DUO : 0u);
+           (debug_drop_flag ? SW_DEBUG_DROP_FLAG : 0u);
   }
 };
 Switches read_switches();           // pps_api.cpp: the only place of the library that calls getenv
@@ -212,7 +204,6 @@ hipError_t launch_expand_el(const DevGraph& d, int n_asm, hipStream_t st);
 hipError_t launch_expand_lists(const DevGraph& d, int n_fronts, int n_asm, double* zero, size_t n_zero, hipStream_t st);   // both + the zero fill, one launch
 int band_max_rows();
 bool band_level_solve_direct_ok(int p, int b);   // a front whose level back-substitution may load L_B straight into registers (kb_level_solve)
-int band_duo_mode();                            // PPS_DUO_MODE of the build (0: one wave per front, no c_split)
 size_t band_solve_lds_bytes(int max_panel);      // max_panel = largest (f+1)*p of the stage
 int band_front_limit();                         // largest front (scalars, without rhs row) of the band kernels
 int debug_front_factor(int tiles, int strip, int p, int b, const double* A_host, double* L_host, double* U_host, double* not_pd);   // pps_debug_front_factor
@@ -277,11 +268,10 @@ struct BatchArgs {
 // grid extents (maxima over the graphs of the chunk) and LDS needs of one round
 struct BatchGeom {
   int lin_blocks = 0, lin_obs_blocks = 0, lin_rest_blocks = 0, repop_blocks = 0;
-  int hblocks = 0, hblocks_nd = 0, k2t_blocks = 0, k2tg_blocks = 0, hreduce = 0, retract = 0, chi2 = 0;      // k2tg: the generic entries of the class lists
+  int hblocks = 0, k2t_blocks = 0, k2tg_blocks = 0, hreduce = 0, retract = 0, chi2 = 0;      // k2tg: the generic entries of the class lists
   int k2_blocks = 0, k2_finish = 0;   // workgroups of the K2 launch: maximum over the chunk's graphs of ceil(single / 16) + multi; blocks of its second pass
   long long n_factors_total = 0;
   bool lin_thread_form = false;   // numeric K1 as one thread per factor (many graphs) instead of 32 lanes per factor
-  bool k2t_generic = false;       // Switches::k2t_generic of the batch handle
   int n_stages = 0;
   int stage_groups[32] = {0}, stage_nw_factor[32] = {0}, stage_nw_solve[32] = {0};
   int stage_per_wave_factor[32] = {0}, stage_per_wave_solve[32] = {0}, stage_grp_fronts[32] = {0};

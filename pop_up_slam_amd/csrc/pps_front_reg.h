@@ -211,7 +211,7 @@ __device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double*
   } else {
     for (int K = 0; K < p; K += W) panel_step(K);
   }
-  if (bad && lane == 0) d.result_dev[2] = 1.0;             // not positive definite
+  if (bad && lane == 0) raise_status(&d.result_dev[2], 1.0);             // not positive definite
   if (TR) PPS_TR(4);
   if (TR && d.trace && lane == 0) { d.trace[(size_t)s * 8 + 6] = cyc_panel; d.trace[(size_t)s * 8 + 7] = cyc_trail; }
   // ---- update matrix: live part of the tiles -> packed global ----
@@ -244,169 +244,6 @@ __device__ __forceinline__ void front_reg_eliminate(const G& d, int rec, double*
   }
   if (!STRIP) Us[(lane >= p && lane <= f) ? (unsigned)(tri24(b) + lane - p) : trash_u] = lane < f ? y : 0.0;      // the rhs row of the update matrix
   if (TR) PPS_TR(5);
-}
-
-// ------------------------------------------------------------------------------------------
-// 16-column panels (round 5; NOT the default: -DPPS_PANEL_W_BAND=16 selects it for the register-only band kernels -- measured slower, see the
-// end of this comment): a whole TILE COLUMN per LDS round trip.  The tile column (up to 16 pivot columns, lane = row) is held in
-// sixteen registers per lane and eliminated right-looking, one pivot at a time: pivot k is broadcast from its lane, every row scales its
-// entry by 1 / sqrt(pivot) and subtracts l_ik * l_jk from its entries of the pivot columns j > k, l_jk broadcast from lane j.  Per entry
-// these are the operations of the blocked code above -- chol4 / trsm4 inside a 4 x 4 block, rank4 between the blocks of an 8-column panel,
-// one MFMA per earlier 4-column panel -- in the same order (contributions of the pivots k = 0, 1, 2, ... one fused multiply-add each, then the
-// scaling), so every entry of L, U and the rhs comes out bit-identical (tests/test_front_emu.py::test_sixteen_column_panels compares the
-// two forms bit for bit under the wave emulation; on the GPU the LM traces do not change).  What it removes from a lone wave's chain: three of
-// the four extract / read-back round trips of a 15-pivot separator front, their barriers, and the MFMAs that carried the earlier panels into
-// the later columns of the same tile column (9 of 21 for three tile rows).  The trailing update of the other tiles is four back-to-back MFMAs
-// per tile (k = 0..3, 4..7, 8..11, 12..15: the panels of the blocked code, in their order).
-// Fronts without a strip only (NT = 2 .. 4, rhs row as a vector); P: 64 rows of kP16Stride doubles, may be F.
-// Measured on C2 (same box): 67.0 us per LM iteration against 60.3 with the 4-column panels, same LM trace.  Why: the blocked code broadcasts
-// ten values per 4 x 4 pivot block and lets the MFMA carry a panel into the later columns of its tile column for free; eliminating in
-// registers needs a broadcast and a multiply-add per (pivot, later column) pair -- 120 pairs per tile column, 240 v_readlane + 120 FMAs on the
-// lone wave's in-order instruction stream -- which costs more than the three LDS round trips it saves.
-// ------------------------------------------------------------------------------------------
-constexpr int kP16Stride = 17;
-
-// the right-looking elimination of the NC (= ncols rounded up to four) leading columns of a tile column held as r[16] per lane (lane = row)
-template <int NC>
-__device__ __forceinline__ void col16_eliminate(double (&r)[16], int K0, int ncols, bool& bad) {
-#ifndef PPS_NO_FMA
-#pragma clang fp contract(fast)     // a - b * c is one operation, as in chol4 / trsm4 / rank4
-#endif
-#pragma unroll
-  for (int k = 0; k < NC; k++) {
-    if (k < NC - 4 || k < ncols) {                              // (only the last four columns of the class may be missing: wave-uniform)
-      const double dk = readlane_d(r[k], K0 + k);
-      const double q = rsqrt_nr(dk);                            // (NaN for a pivot that is not positive: selected away, as in chol4)
-      const bool pos = dk > 0.0;
-      bad |= !pos;
-      const double inv = pos ? q : 0.0;
-      r[k] = r[k] * inv;
-#pragma unroll
-      for (int j = k + 1; j < NC; j++) r[j] = r[j] - r[k] * readlane_d(r[k], K0 + j);     // (columns past ncols: junk, zeroed when their turn comes)
-    } else r[k] = 0.0;
-  }
-#pragma unroll
-  for (int k = NC; k < 16; k++) r[k] = 0.0;
-}
-
-template <int NT, class G>
-__device__ __forceinline__ void front_reg_eliminate16(const G& d, int rec, double* F, double* P) {      // (no __restrict__: P may be F)
-#ifndef PPS_NO_FMA
-#pragma clang fp contract(fast)
-#endif
-  const int lane = threadIdx.x & 63;
-  const int p = __builtin_amdgcn_readlane(rec, 1), b = __builtin_amdgcn_readlane(rec, 2);
-  const int l16 = lane & 15, lq = lane >> 4;
-  const int f = p + b, fa = f + 1;
-  double4_t c[NT * (NT + 1) / 2];
-#pragma unroll
-  for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = 16 * ti + lq + 4 * r;
-      const double* Fr = F + (tri24(row < f ? row : 0) + l16);
-#pragma unroll
-      for (int tj = 0; tj <= ti; tj++) c[tile_id(ti, tj)][r] = Fr[16 * tj];
-    }
-  double y;
-  { const double t = F[lane <= f ? tri24(f) + lane : 0]; y = lane < f ? t : 0.0; }
-  __builtin_amdgcn_wave_barrier();
-  double* __restrict__ Lp = d.L + (((long long)__builtin_amdgcn_readlane(rec, 10) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 9));
-  bool bad = false;
-  for (int TJ = 0; 16 * TJ < p; TJ++) {                         // (wave-uniform; at most NT trips)
-    const int K0 = 16 * TJ;
-    const int ncols = p - K0 < 16 ? p - K0 : 16;
-    // ---- tile column TJ -> P[row][16] ----
-    auto extract = [&](auto tjc) __attribute__((always_inline)) {
-      constexpr int tj = decltype(tjc)::value;
-#pragma unroll
-      for (int ti = tj; ti < NT; ti++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) P[(16 * ti + lq + 4 * r) * kP16Stride + l16] = c[tile_id(ti, tj)][r];
-    };
-    switch (TJ) {
-      case 0: extract(std::integral_constant<int, 0>{}); break;
-      case 1: extract(std::integral_constant<int, 1>{}); break;
-      case 2: if (NT > 2) extract(std::integral_constant<int, (NT > 2 ? 2 : 1)>{}); break;
-      default: if (NT > 3) extract(std::integral_constant<int, (NT > 3 ? 3 : NT - 1)>{}); break;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- lane = row: the sixteen columns in registers; the rhs row takes the idle lane f ----
-    double r[16];
-#pragma unroll
-    for (int m = 0; m < 16; m++) r[m] = P[lane * kP16Stride + m];
-#pragma unroll
-    for (int m = 0; m < 16; m++) { const double q = readlane_d(y, K0 + m); r[m] = lane == f ? q : r[m]; }
-    switch ((ncols + 3) >> 2) {                                 // (wave-uniform) one copy of the chain per column-count class
-      case 1: col16_eliminate<4>(r, K0, ncols, bad); break;
-      case 2: col16_eliminate<8>(r, K0, ncols, bad); break;
-      case 3: col16_eliminate<12>(r, K0, ncols, bad); break;
-      default: col16_eliminate<16>(r, K0, ncols, bad); break;
-    }
-#pragma unroll
-    for (int m = 0; m < 16; m++) P[lane * kP16Stride + m] = r[m];
-    // rank-ncols update of the rhs row: y_j -= sum_m L[f][K0+m] L[j][K0+m], m ascending (the order of the rank4 calls of the blocked code)
-#pragma unroll
-    for (int m = 0; m < 16; m++) y = y - r[m] * readlane_d(r[m], f);       // (columns past ncols are zero in every lane: y - 0 * 0)
-    if (lane < fa) {
-      double* __restrict__ lrow = Lp + (unsigned)(__mul24(lane, p) + K0);
-#pragma unroll
-      for (int m = 0; m < 16; m++)
-        if (m < ncols) lrow[m] = r[m];
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- trailing update: per tile one MFMA per four pivot columns, in their order ----
-    const bool short_of_end = ncols < 16;                       // boundary columns inside this tile column: its tiles stay live
-    auto trailing = [&](auto tjc) __attribute__((always_inline)) {
-      constexpr int tj0 = decltype(tjc)::value;
-#pragma unroll
-      for (int ch = 0; ch < 4; ch++) {
-        if (4 * ch >= ncols) continue;                          // (wave-uniform)
-        const bool kv = 4 * ch + lq < ncols;
-        double a[NT];
-#pragma unroll
-        for (int t = tj0; t < NT; t++) { const double v = P[(16 * t + l16) * kP16Stride + 4 * ch + lq]; a[t] = kv ? v : 0.0; }
-        if (short_of_end) {
-#pragma unroll
-          for (int ti = tj0; ti < NT; ti++) c[tile_id(ti, tj0)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[ti], a[tj0], c[tile_id(ti, tj0)], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ti = tj0 + 1; ti < NT; ti++)
-#pragma unroll
-          for (int tj = tj0 + 1; tj <= ti; tj++) c[tile_id(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[ti], a[tj], c[tile_id(ti, tj)], 0, 0, 0);
-      }
-    };
-    switch (TJ) {
-      case 0: trailing(std::integral_constant<int, 0>{}); break;
-      case 1: trailing(std::integral_constant<int, 1>{}); break;
-      case 2: if (NT > 2) trailing(std::integral_constant<int, (NT > 2 ? 2 : 1)>{}); break;
-      default: if (NT > 3) trailing(std::integral_constant<int, (NT > 3 ? 3 : NT - 1)>{}); break;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (bad && lane == 0) d.result_dev[2] = 1.0;             // not positive definite
-  // ---- update matrix (as front_reg_eliminate) ----
-  double* __restrict__ Us = d.U + (((long long)__builtin_amdgcn_readlane(rec, 12) << 32) | (unsigned int)__builtin_amdgcn_readlane(rec, 11));
-  const unsigned trash_u = (unsigned)(__mul24(b + 1, b + 1) - 1);
-#pragma unroll
-  for (int ti = 0; ti < NT; ti++) {
-    if (16 * ti >= f) continue;                              // (wave-uniform)
-    int rbase[4]; bool rok[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { const int row = 16 * ti + lq + 4 * q; rok[q] = row < f; rbase[q] = tri24(row - p) - p; }
-#pragma unroll
-    for (int tj = 0; tj <= ti; tj++) {
-      if (16 * tj + 15 < p) continue;                        // (wave-uniform)
-      const int col = 16 * tj + l16;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int row = 16 * ti + lq + 4 * q;
-        const bool ok = rok[q] && col <= row && col >= p;
-        Us[ok ? (unsigned)(rbase[q] + col) : trash_u] = c[tile_id(ti, tj)][q];
-      }
-    }
-  }
-  Us[(lane >= p && lane <= f) ? (unsigned)(tri24(b) + lane - p) : trash_u] = lane < f ? y : 0.0;      // the rhs row of the update matrix
 }
 
 }  // namespace pps

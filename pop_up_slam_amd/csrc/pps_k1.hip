@@ -10,21 +10,10 @@
 
 namespace pps {
 
-// PPS_ODO_WAVES (build-time, A/B): waves per SIMD the numeric odometry / prior launch (MODE 0, PART 1) is compiled for; 0 = the compiler's choice
-#ifndef PPS_ODO_WAVES
-#define PPS_ODO_WAVES 0
-#endif
-#if PPS_ODO_WAVES
-#define PPS_ODO_ATTR(M, P) __attribute__((amdgpu_waves_per_eu(((M) == 0 && (P) == 1) ? PPS_ODO_WAVES : 1, ((M) == 0 && (P) == 1) ? PPS_ODO_WAVES : 8)))
-#else
-#define PPS_ODO_ATTR(M, P)
-#endif
-#ifndef PPS_OBS_WAVES
-#define PPS_OBS_WAVES 2
-#endif
+constexpr int kObsNumericWaves = 2;      // waves per SIMD of the numeric plane-observation launch of the thread form (see k_linearize_obs_numeric)
 
 template <int MODE, int PART>
-__global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void k_linearize(DevGraph d, const double* __restrict__ pose,
+__global__ __launch_bounds__(kLinBlock) void k_linearize(DevGraph d, const double* __restrict__ pose,
                                                           const double* __restrict__ plane, int nb_obs, int nb_odo,
                                                           int nb_pp, LinGuard gd) {
   extern __shared__ double lin_lds[];
@@ -36,7 +25,7 @@ __global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void k_lineariz
 // registers + spill moves into the accumulator half (one wave per SIMD); held to two waves per SIMD (256 registers) it is a fifth
 // faster on the batched sweep (540 000 edges: 160 -> 126 us; three waves: 134, four: 153).  The odometry launch is fastest alone
 // on its SIMD (103 us; 154 with two waves) and keeps the default.
-__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(PPS_OBS_WAVES, PPS_OBS_WAVES)))
+__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(kObsNumericWaves, kObsNumericWaves)))
 void k_linearize_obs_numeric(DevGraph d, const double* __restrict__ pose, const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, LinGuard gd) {
   extern __shared__ double lin_lds[];
   if (!lin_guard(gd, pose, plane)) return;
@@ -200,10 +189,10 @@ __device__ __forceinline__ void body_sweep_bench(const DevGraph& d, double* __re
 }
 
 template <int MODE, int PART>
-__global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void k_sweep_bench(DevGraph d, double* __restrict__ Jbig, int nb_obs_per, int nb_odo_per, int replicas) {
+__global__ __launch_bounds__(kLinBlock) void k_sweep_bench(DevGraph d, double* __restrict__ Jbig, int nb_obs_per, int nb_odo_per, int replicas) {
   body_sweep_bench<MODE, PART>(d, Jbig, nb_obs_per, nb_odo_per, replicas);
 }
-__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(PPS_OBS_WAVES, PPS_OBS_WAVES)))      // (see k_linearize_obs_numeric)
+__global__ __launch_bounds__(kLinBlock) __attribute__((amdgpu_waves_per_eu(kObsNumericWaves, kObsNumericWaves)))      // (see k_linearize_obs_numeric)
 void k_sweep_bench_obs_numeric(DevGraph d, double* __restrict__ Jbig, int nb_obs_per, int nb_odo_per, int replicas) {
   body_sweep_bench<0, 0>(d, Jbig, nb_obs_per, nb_odo_per, replicas);
 }
@@ -257,7 +246,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void kb_linearize_lanes(BatchArgs a
 }
 
 template <int MODE, int PART, bool DIRECT>
-__global__ __launch_bounds__(kLinBlock) PPS_ODO_ATTR(MODE, PART) void kb_linearize(BatchArgs a) {
+__global__ __launch_bounds__(kLinBlock) void kb_linearize(BatchArgs a) {
   extern __shared__ double lin_lds[];
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
   const int nb_obs = dcdiv(d.n_obs_fixed, kLinBlock), nb_odo = dcdiv(d.n_odo, kLinBlock), nb_pp = dcdiv(d.n_pp, kLinBlock),

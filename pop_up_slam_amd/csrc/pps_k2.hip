@@ -19,10 +19,7 @@ namespace pps {
 // Sums are deterministic: Jacobian-based contributions first, in list order, as explicit multiply-adds; then the product records
 // in list order; partial sums of a block by wave index.  The same body serves one graph and the batches: same bits.
 // ------------------------------------------------------------------------------------------
-#ifndef PPS_K2_WAVES            // (build-time, A/B) waves per workgroup
-#define PPS_K2_WAVES 16
-#endif
-constexpr int kK2Waves = PPS_K2_WAVES;
+constexpr int kK2Waves = 16;    // waves per workgroup
 
 // plist: 64 ints of LDS of this wave (the offsets of the segment's product records, compacted)
 __device__ __forceinline__ double wave_segment_sum(const DevGraph& d, int rec, int4 mine, int lane, int* __restrict__ plist) {
@@ -309,26 +306,6 @@ __device__ __forceinline__ void wave_hblock_segment(const DevGraph& d, const Seg
   if (dst >= 0) d.Hf[dst] = acc;                          // final value (single-segment block): also where its front gathers it
 }
 
-// A wave takes S consecutive segments of the list of non-direct segments (the single-observation pose-plane blocks are written
-// by K1 itself in this mode).
-template <int S>
-__device__ __forceinline__ void body_hblocks_t(const DevGraph& d, int bx) {
-  __shared__ double h2_lds[4 * kH2WaveDoubles];
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int slot0 = uni((bx * 4 + wave) * S);        // position in the list of non-direct segments
-  if (slot0 >= d.n_nd_segs) return;
-  SegHdr h[S];
-  {
-    const int sidx = (lane >> 3) < S && slot0 + (lane >> 3) < d.n_nd_segs ? d.nd_segs[slot0 + (lane >> 3)] : -1;   // lanes 8q..8q+7: segment q
-#pragma unroll
-    for (int q = 0; q < S; q++) seg_fetch_record(d, __builtin_amdgcn_readlane(sidx, 8 * q), lane, h[q]);
-  }
-#pragma unroll
-  for (int q = 0; q < S; q++) seg_fetch_contrib(d, lane, h[q]);
-#pragma unroll
-  for (int q = 0; q < S; q++) wave_hblock_segment(d, h[q], h2_lds + wave * kH2WaveDoubles);
-}
-
 // ------------------------------------------------------------------------------------------
 // K2, throughput form by segment class.  The generic wave-per-segment body above spends ~55 wave instructions on every
 // contribution whatever the block holds (three clamped loads, three LDS writes, a dozen LDS reads with computed addresses, the lane
@@ -506,9 +483,11 @@ __device__ __forceinline__ void body_hblocks_tc(const DevGraph& d, int bx) {
   for (int q = 0; q < 4; q++) seg_fetch_contrib(d, lane, h[q]);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
+    // (a slot past the end of the list has class 0 and an empty record: the generic body returns on size 0, the class bodies are not
+    // entered -- wave_hblock_66_off has no guard of its own and would zero H[0 .. 35])
     if (GENERIC) wave_hblock_segment(d, h[q], S);
     else if (cls[q] == 1) wave_hblock_66_diag(d, h[q], S);
-    else wave_hblock_66_off(d, h[q], S);
+    else if (cls[q] == 2) wave_hblock_66_off(d, h[q], S);
   }
 }
 
@@ -577,13 +556,6 @@ __global__ __launch_bounds__(64) void kb_hfinish(BatchArgs a) {
   body_hfinish(d, blockIdx.x);
 }
 
-constexpr int kHblocksT = 4;      // segments per wave of the throughput form
-__global__ __launch_bounds__(256) void kb_hblocks_t(BatchArgs a) {
-  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
-  if ((int)blockIdx.x * 4 * kHblocksT >= d.n_nd_segs) return;
-  body_hblocks_t<kHblocksT>(d, blockIdx.x);
-}
-
 __global__ __launch_bounds__(256) void kb_hblocks_tc(BatchArgs a) {
   PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
   if ((int)blockIdx.x >= (d.n_k2t_spec + 15) / 16 + (d.n_k2t_small + 15) / 16) return;
@@ -605,12 +577,8 @@ hipError_t launch_batch_hblocks(const BatchArgs& a, const BatchGeom& g, hipStrea
   if (g.lin_thread_form) {                                      // many graphs: throughput form over the Jacobians + the second pass
     // (the wave-per-segment kernel in its Jacobian-only mode, measured on the same G = 128 batch: 23.9 ms of K2 per batch solve
     // against 13.7 ms -- at this size the LDS-staged form's four segments per wave and prefetched headers win)
-    const bool by_class = !g.k2t_generic;                             // (A/B: the one-body form)
-    if (by_class) {
-      if (g.k2t_blocks > 0) PPS_LAUNCH(kb_hblocks_tc, dim3(g.k2t_blocks, a.n), dim3(256), 0, st, a);
-      if (g.k2tg_blocks > 0) PPS_LAUNCH(kb_hblocks_tg, dim3(g.k2tg_blocks, a.n), dim3(256), 0, st, a);
-    }
-    else if (g.hblocks_nd > 0) PPS_LAUNCH(kb_hblocks_t, dim3(g.hblocks_nd, a.n), dim3(256), 0, st, a);
+    if (g.k2t_blocks > 0) PPS_LAUNCH(kb_hblocks_tc, dim3(g.k2t_blocks, a.n), dim3(256), 0, st, a);
+    if (g.k2tg_blocks > 0) PPS_LAUNCH(kb_hblocks_tg, dim3(g.k2tg_blocks, a.n), dim3(256), 0, st, a);
     if (g.hreduce > 0) PPS_LAUNCH(kb_hreduce, dim3(g.hreduce, a.n), dim3(64), 0, st, a);
     return hipGetLastError();
   }

@@ -13,14 +13,7 @@
 
 #include "pps_kcommon.h"
 #include "pps_regtile.h"
-#include "pps_front_duo.h"
-
-// Two waves per front (pps_front_duo.h): bit 0 = the extend-add is split between a front's own wave and a helper, bit 1 = the
-// elimination.  BUILD-TIME, DEFAULT OFF: measured on C2 (round 5, tools/r5_ab_duo.sh, us per LM iteration, same box): one wave 65.0 /
-// elimination split 64.9 / both 66.0 / extend-add split alone 68.8 -- bit-identical LM traces in every variant; DESIGN.md section 8.
-#ifndef PPS_DUO_MODE
-#define PPS_DUO_MODE 0
-#endif
+#include "pps_front_reg.h"
 
 namespace pps {
 
@@ -93,7 +86,7 @@ __global__ __launch_bounds__(256) void k_front_factor(DevGraph d, int level_begi
     const double dkk = F[k * ld + k];
     double dinv;
     if (!(dkk > 0.0)) {
-      if (tid == 0) d.result_dev[2] = 1.0;   // not positive definite
+      if (tid == 0) raise_status(&d.result_dev[2], 1.0);   // not positive definite
       dinv = 0.0;
     } else {
       dinv = 1.0 / sqrt(dkk);
@@ -157,66 +150,13 @@ hipError_t launch_factor_level(const DevGraph& d, int level_begin, int level_cou
 // ------------------------------------------------------------------------------------------
 constexpr int kBandMaxRows = 128;   // rows per front including the rhs row
 
-// The split of a front's children between its two waves (DevGraph::c_split), by the workgroup that expands front s' own list: the
-// parent row r1 below which half of all the children's entries land -- a child's rows map to increasing parent rows (cmap), so "target
-// row < r1" is a leading range of the child's packed triangle -- and per child the length of that range.  A map that is not increasing
-// leaves the whole child with the front's own wave.  64 threads; sh: 8 ints of LDS.
-__device__ __forceinline__ void expand_split(const DevGraph& d, int s, int* sh) {
-  if (PPS_DUO_MODE == 0 || !d.c_split) return;
-  const int nch = d.f_child_off[s + 1] - d.f_child_off[s];
-  if (nch <= 0) return;
-  // (the records sit in band-schedule order; the front's own position is found through its children's shared parent record: every
-  // record of a parent is consecutive, and record k of the parent belongs to child d.child[f_child_off[s] + k])
-  const int fa = d.f_p[s] + d.f_b[s] + 1;
-  const int tid = threadIdx.x;
-  if (tid == 0) { sh[0] = fa; sh[1] = 1; sh[2] = 0; }
-  __syncthreads();
-  long long wtot = 0;
-  for (int k = 0; k < nch; k++) {
-    const int c = d.child[d.f_child_off[s] + k];
-    const int* __restrict__ m = d.cmap + d.f_cmap_off[c];
-    const int len = d.f_cmap_off[c + 1] - d.f_cmap_off[c];
-    wtot += (long long)len * (len + 1) / 2;
-    for (int i = tid; i < len; i += 64) if (m[i] < 0 || m[i] >= fa || (i > 0 && m[i] <= m[i - 1])) sh[1] = 0;
-  }
-  __syncthreads();
-  const bool mono = sh[1] != 0;
-  // smallest r with 2 W(r) >= Wtot, W(r) = entries of all children in parent rows below r
-  for (int r = tid; mono && r <= fa; r += 64) {
-    long long w = 0;
-    for (int k = 0; k < nch; k++) {
-      const int c = d.child[d.f_child_off[s] + k];
-      const int* __restrict__ m = d.cmap + d.f_cmap_off[c];
-      const int len = d.f_cmap_off[c + 1] - d.f_cmap_off[c];
-      int cnt = 0;
-      for (int i = 0; i < len; i++) cnt += m[i] < r ? 1 : 0;
-      w += (long long)cnt * (cnt + 1) / 2;
-    }
-    if (2 * w >= wtot) atomicMin(&sh[0], r);
-  }
-  __syncthreads();
-  const int r1 = sh[0];
-  // the parent's first child record: frec position of s -> through d.f_crec0 (host: position-ordered records)
-  const int cr0 = d.f_crec0[s];
-  for (int k = tid; k < nch; k += 64) {
-    const int c = d.child[d.f_child_off[s] + k];
-    const int* __restrict__ m = d.cmap + d.f_cmap_off[c];
-    const int len = d.f_cmap_off[c + 1] - d.f_cmap_off[c];
-    int cnt = len;
-    if (mono) { cnt = 0; for (int i = 0; i < len; i++) cnt += m[i] < r1 ? 1 : 0; }
-    d.c_split[cr0 + k] = cnt * (cnt + 1) / 2;
-  }
-}
-
 // One workgroup per front: row i of its (b+1)-row packed update matrix goes to row cmap[i] of the parent.
 // The launch also clears what an upload needs cleared -- the zeroed block behind delta (tickets, result records, partial sums) and
 // blk_dst (0xff: "no element") for k_expand_el, which follows on the same stream -- instead of one fill kernel each.
 __global__ __launch_bounds__(64) void k_expand_ea(DevGraph d, double* __restrict__ zero, int n_zero, int* __restrict__ ones, int n_ones) {
-  __shared__ int sh[8];
   for (int i = blockIdx.x * 64 + threadIdx.x; i < n_zero; i += gridDim.x * 64) zero[i] = 0.0;
   for (int i = blockIdx.x * 64 + threadIdx.x; i < n_ones; i += gridDim.x * 64) ones[i] = -1;
   const int s = blockIdx.x;
-  expand_split(d, s, sh);
   const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
   const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
   int* __restrict__ out = d.ea_tgt + d.f_ea_off[s];
@@ -256,11 +196,9 @@ __global__ __launch_bounds__(256) void k_expand_el(DevGraph d, int n_asm) {
 // range itself (-1 for the upper triangle of a diagonal block, which no front gathers), so no fill has to run before it -- valid when
 // every H block is assembled by exactly one front (the caller checks).
 __global__ __launch_bounds__(64) void k_expand_lists(DevGraph d, double* __restrict__ zero, int n_zero, int n_fronts, int n_asm) {
-  __shared__ int sh[8];
   for (int i = blockIdx.x * 64 + threadIdx.x; i < n_zero; i += gridDim.x * 64) zero[i] = 0.0;
   if ((int)blockIdx.x < n_fronts) {
     const int s = blockIdx.x;
-    expand_split(d, s, sh);
     const int* __restrict__ m = d.cmap + d.f_cmap_off[s];
     const int len = d.f_cmap_off[s + 1] - d.f_cmap_off[s];
     int* __restrict__ out = d.ea_tgt + d.f_ea_off[s];
@@ -309,7 +247,6 @@ hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_
 }
 
 int band_front_limit() { return kBandMaxRows - 1; }
-int band_duo_mode() { return PPS_DUO_MODE; }
 bool band_level_solve_direct_ok(int p, int b);
 int band_reg_rows() { return kRegRows; }
 int band_max_rows() { return kBandMaxRows; }
@@ -319,13 +256,9 @@ int band_max_rows() { return kBandMaxRows; }
 // row, LDS-tile path): triangle | spare | panel buffer of 80 rows.
 size_t band_lds_bytes(int max_front, bool reg_only_kernel) {
   const size_t fa = (size_t)max_front + 1, ntri = fa * (fa + 1) / 2;
-  // (register-only band kernels: at least the four panel buffers of a front eliminated by two waves, pps_front_duo.h)
-  const size_t n = reg_only_kernel ? std::max<size_t>(ntri, (size_t)kDuoPanels * kDuoQ) + 1 : ntri + 1 + (size_t)kRegRowsMax * kP8Stride;
+  const size_t n = reg_only_kernel ? std::max<size_t>(ntri, (size_t)kRegRows * kP8Stride) + 1 : ntri + 1 + (size_t)kRegRowsMax * kP8Stride;
   return ((n + 1) & ~size_t(1)) * sizeof(double);      // (an even number of doubles: every wave's triangle starts 16-byte aligned)
 }
-// the hand-over flags of the two-wave fronts, behind the waves' triangles (k_band_factor_pre, kb_band_factor_pre)
-static size_t duo_flag_bytes(int nwaves) { return (size_t)nwaves * (kDuoFlags + kDuoMail) * sizeof(int); }
-
 // One row of 16x16 tiles (I, J = o, o+16, ..., I) of the trailing lower triangle gets its rank-nb
 // update C -= P_I P_J^T: all LDS reads are issued unconditionally from clamped (always valid)
 // addresses and masked by selects afterwards, so the NT tiles' loads overlap; then NT back-to-back
@@ -442,7 +375,7 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
         const double dmm = (c < 64) ? readlane_d(a0[m], c) : readlane_d(a1[m], c - 64);
         double dinv = 0.0;
         if (dmm > 0.0) dinv = rsqrt_nr(dmm);
-        else if (lane == 0) d.result_dev[2] = 1.0;         // not positive definite
+        else if (lane == 0) raise_status(&d.result_dev[2], 1.0);         // not positive definite
         if (r0 >= c) a0[m] *= dinv;                        // the diagonal becomes sqrt(dmm)
         if (r1 >= c) a1[m] *= dinv;
 #pragma unroll
@@ -525,9 +458,6 @@ __device__ __forceinline__ void wave_front_factor(const DevGraph& d, int s_in, d
 // scatter-add items per lane in flight in the extend-add.  Measured on C2 (us per LM iteration): 8 -> 78.9, 10 -> 77.6,
 // 12 -> 78.5, 16 -> 92.4 -- more loads in flight than about two dozen per lane cost more than the round trips they save
 constexpr int kEaDepth = 10;
-#ifndef PPS_ORIG_PLAIN_STORE
-#define PPS_ORIG_PLAIN_STORE 1
-#endif
 template <int N> struct ElBatch { int tg[N]; double v[N]; };
 // loads are issued unconditionally from clamped (always valid) addresses and masked by selects afterwards: predicated loads
 // become one exec-masked basic block each and serialise
@@ -546,8 +476,8 @@ __device__ __forceinline__ void el_issue(const int* __restrict__ tgp, const doub
 // items past the end go to the spare double `tr` with a zero increment, so that nothing is predicated.
 template <bool ORIG, int N>     // ORIG: entries of H (bit 30 of the target = diagonal element, damped: Cholesky.cpp:94-97)
 __device__ __forceinline__ void el_apply(const ElBatch<N>& q, double damp, double* __restrict__ F, int tr) {
-  if constexpr (ORIG && PPS_ORIG_PLAIN_STORE) {
-    // Round 5: the original entries are the FIRST thing a cleared triangle receives and their targets are pairwise distinct, so old + inc is
+  if constexpr (ORIG) {
+    // the original entries are the FIRST thing a cleared triangle receives and their targets are pairwise distinct, so old + inc is
     // 0 + inc = inc (H entries are sums that start at +0: never -0): a plain store -- no LDS read, no add, one LDS round trip less per batch.
 #pragma unroll
     for (int u = 0; u < N; u++) {
@@ -558,12 +488,9 @@ __device__ __forceinline__ void el_apply(const ElBatch<N>& q, double damp, doubl
   }
   int t[N]; double old[N];
 #pragma unroll
-  for (int u = 0; u < N; u++) { t[u] = q.tg[u] >= 0 ? (ORIG ? (q.tg[u] & 0x3fffffff) : q.tg[u]) : tr; old[u] = F[t[u]]; }
+  for (int u = 0; u < N; u++) { t[u] = q.tg[u] >= 0 ? q.tg[u] : tr; old[u] = F[t[u]]; }
 #pragma unroll
-  for (int u = 0; u < N; u++) {
-    const double inc = (ORIG && (q.tg[u] & (1 << 30))) ? q.v[u] * damp : q.v[u];      // (tg = -1: v = 0)
-    F[t[u]] = old[u] + inc;
-  }
+  for (int u = 0; u < N; u++) F[t[u]] = old[u] + q.v[u];      // (tg = -1: v = 0)
 }
 // what a front needs before its children are complete: first batch of its original entries and its child records (requested),
 // the cleared triangle, the original entries added.  issue -> [anything] -> finish.  NPRE items per lane are requested ahead:
@@ -576,13 +503,7 @@ __device__ __forceinline__ void front_pre_issue(const DevGraph& d, int rec, int 
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
   el_issue(d.el_tgt, d.Hf, e0, e1, lane, o.q);
   // records of up to 8 children in one coalesced load
-#if PPS_DUO_MODE
-  // (two waves per front: slot 6 of a record comes from c_split, the child's split between the front's two waves)
-  const int* src = (lane & 7) == 6 ? d.c_split + cr0 + (lane >> 3) : d.crec + (size_t)cr0 * 8 + lane;
-  o.crv = (lane < 8 * nch) ? *src : 0;
-#else
   o.crv = (lane < 8 * nch) ? d.crec[(size_t)cr0 * 8 + lane] : 0;
-#endif
 }
 __device__ __forceinline__ void front_clear(int rec, int lane, double* __restrict__ F) {
   const int ntri = tri(__builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1);
@@ -625,83 +546,16 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
   }
 }
 
-// The extend-add of a front with two waves (pps_front_duo.h): PART 0 = the entries of every child that land in parent rows below r1
-// ([0, split) of the child's packed triangle), PART 1 = the others.  r1 halves the TOTAL over the children, not each child, so a wave's
-// share of one child is anything between nothing and all of it: the shares of two children are walked as ONE list -- child A's entries,
-// then child B's -- seven items per lane in flight (448 entries: more than half of two separator fronts' update matrices, 14 loads per
-// lane), and a batch is applied in two sweeps, A's items first: every entry receives its contributions in the order child 0, child 1, ...
-template <int PART>
-__device__ __forceinline__ void front_extend_add_part(const DevGraph& d, int rec, int crv, int lane, double* __restrict__ F, int tr) {
-  const int nch = __builtin_amdgcn_readlane(rec, 6);           // (<= 8: checked by the caller)
-  constexpr int NB = 7;
-  auto child = [&](int cj, int& lo, int& hi, int& last, const double* __restrict__& Uc, const int* __restrict__& tgc) {
-    const int n = __builtin_amdgcn_readlane(crv, 8 * cj), sp = __builtin_amdgcn_readlane(crv, 8 * cj + 6);
-    const long long uo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 2) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 1);
-    const long long eo = ((long long)__builtin_amdgcn_readlane(crv, 8 * cj + 4) << 32) | (unsigned int)__builtin_amdgcn_readlane(crv, 8 * cj + 3);
-    Uc = d.U + uo; tgc = d.ea_tgt + eo;
-    lo = PART ? sp : 0; hi = PART ? n : sp; last = n > 0 ? n - 1 : 0;
-  };
-  int cj = 0;
-  for (; cj + 1 < nch; cj += 2) {
-    int loa, hia, lasta, lob, hib, lastb; const double *Ua, *Ub; const int *ta, *tb;
-    child(cj, loa, hia, lasta, Ua, ta); child(cj + 1, lob, hib, lastb, Ub, tb);
-    const int lenA = hia - loa, T = lenA + hib - lob;
-    for (int e = 0; e < T; e += 64 * NB) {
-      int tg[NB]; double v[NB]; bool isa[NB], isb[NB];
-#pragma unroll
-      for (int u = 0; u < NB; u++) {
-        const int x = e + lane + 64 * u;
-        const bool ina = x < lenA;
-        isa[u] = ina; isb[u] = !ina && x < T;
-        int ia = loa + x, ib = lob + x - lenA;                   // (clamped to an entry that exists: nothing is predicated)
-        ia = ia < lasta ? ia : lasta; ib = ib < lastb ? ib : lastb; ib = ib > 0 ? ib : 0;
-        const int* pt = ina ? ta + ia : tb + ib;
-        const double* pv = ina ? Ua + ia : Ub + ib;
-        tg[u] = *pt; v[u] = *pv;
-      }
-      __builtin_amdgcn_wave_barrier();
-      {
-        int t[NB]; double old[NB];
-#pragma unroll
-        for (int u = 0; u < NB; u++) { t[u] = isa[u] ? tg[u] : tr; old[u] = F[t[u]]; }
-#pragma unroll
-        for (int u = 0; u < NB; u++) F[t[u]] = old[u] + (isa[u] ? v[u] : 0.0);
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (e + 64 * NB > lenA) {                                  // (wave-uniform) the batch holds items of child B
-        int t[NB]; double old[NB];
-#pragma unroll
-        for (int u = 0; u < NB; u++) { t[u] = isb[u] ? tg[u] : tr; old[u] = F[t[u]]; }
-#pragma unroll
-        for (int u = 0; u < NB; u++) F[t[u]] = old[u] + (isb[u] ? v[u] : 0.0);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  if (cj < nch) {
-    int lo, hi, last; const double* Uc; const int* tgc;
-    child(cj, lo, hi, last, Uc, tgc);
-    for (int e = lo; e < hi; e += 64 * kEaDepth) { ElBatch<kEaDepth> q; el_issue(tgc, Uc, e, hi, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<false>(q, 0.0, F, tr); }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
 // One front from start to end.
 // TR: in-kernel phase trace (PPS_TRACE=1) compiled in
 // Fronts of 65 .. 80 rows (STRIP): rows 0 .. 63 live in the register tiles as usual; rows 64 .. fa-1 -- boundary rows, the pivots
 // are among the first 48 -- stay where the assembly put them, in the packed LDS triangle, and are carried along panel by panel:
 // triangular solve by lanes 0 .. 15, rank-4 update with lane = column.
-// panel widths of the two families of kernels (build-time, A/B: -DPPS_PANEL_W_BAND=4 / -DPPS_PANEL_W_LEVEL=4)
-#ifndef PPS_PANEL_W_BAND
-#define PPS_PANEL_W_BAND 4      // (C2: 73.1 us per LM iteration against 74.1 with 8 -- a lone wave per SIMD is bound by the pivot chain; round 5:
-                                // 16 = front_reg_eliminate16, a whole tile column in registers: 67.0 against 60.3 us, same bits -- DESIGN.md section 8)
-#endif
-#ifndef PPS_PANEL_W_LEVEL
-#define PPS_PANEL_W_LEVEL 8
-#endif
-#ifndef PPS_PANEL_W_R5                 // the kernels that also hold fronts of 65 .. 80 rows (fifth tile row / LDS strip) and the general one
-#define PPS_PANEL_W_R5 8
-#endif
+// panel widths (pivot columns per LDS round trip) of the kernel families
+constexpr int kPanelWBand = 4;    // register-only band kernels (C2: 73.1 us per LM iteration against 74.1 with 8 -- a lone wave per SIMD is bound by the
+                                  // pivot chain; a whole tile column in registers, 16, measured 67.0 against 60.3 us: docs/HISTORY.md, round 5)
+constexpr int kPanelWLevel = 8;   // level-per-launch kernels (several waves per SIMD)
+constexpr int kPanelWWide = 8;    // the kernels that also hold fronts of 65 .. 80 rows (fifth tile row / LDS strip) and the general one
 // First half of a register-resident front, the same for every tile count: the packed triangle assembled in LDS.
 template <bool TR>
 __device__ __forceinline__ void front_assemble(const DevGraph& d, int rec, double lambda, double* F, int tr) {
@@ -722,14 +576,12 @@ __device__ __forceinline__ void front_assemble(const DevGraph& d, int rec, doubl
   if (TR) PPS_TR(3);
 }
 // Second half: elimination in registers, factor panel and update matrix out.
-// W = 16 (the register-only band kernels since round 5, PPS_PANEL_W_BAND): a tile column per LDS round trip, front_reg_eliminate16 -- same bits
-template <int NT, bool TR, bool STRIP = false, int W = PPS_PANEL_W_BAND>
+template <int NT, bool TR, bool STRIP = false, int W = kPanelWBand>
 __device__ __forceinline__ void front_eliminate_out(const DevGraph& d, int rec, double* F, double* P) {
-  if constexpr (W == 16 && !TR && !STRIP && NT <= 4) front_reg_eliminate16<NT>(d, rec, F, P);
-  else front_reg_eliminate<NT, TR, STRIP, (W == 16 ? 4 : W)>(d, rec, F, P);
+  front_reg_eliminate<NT, TR, STRIP, W>(d, rec, F, P);
 }
 // One front from start to end (the level-per-launch kernels: one tile count per kernel)
-template <int NT, bool TR, bool STRIP = false, int W = PPS_PANEL_W_BAND>
+template <int NT, bool TR, bool STRIP = false, int W = kPanelWBand>
 __device__ __forceinline__ void wave_front_factor_reg(const DevGraph& d, int rec, double lambda, double* F, double* P, int tr) {   // (P may be F)
   front_assemble<TR>(d, rec, lambda, F, tr);
   front_eliminate_out<NT, TR, STRIP, W>(d, rec, F, P);
@@ -743,9 +595,6 @@ template <int K> __device__ __forceinline__ double row_bcast_d(double v) {
   return __hiloint2double(hi, lo);
 }
 
-#ifndef PPS_FLOW_SLEEP
-#define PPS_FLOW_SLEEP 1
-#endif
 // Hand-over of a front's local solution inside a band group (body_band_solve_flow): the producer's writes to X, then a release fence
 // over the LDS, then the flag; the consumer polls the flag and passes an acquire fence before it reads X.  The fences are workgroup
 // scope and LOCAL address space only -- a plain workgroup release would also wait for the acknowledgement of the wave's stores to delta, a
@@ -756,8 +605,8 @@ constexpr double kFlowTimeout = kStatusInternal; // result_dev[2]: 0 ok | 1 not 
 __device__ __forceinline__ void flow_wait(const DevGraph& d, int* flow, int q) {
   int spin = 0;
   while (__hip_atomic_load(flow + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
-    if (++spin >= (1 << 22)) { if ((threadIdx.x & 63) == 0) d.result_dev[2] = kFlowTimeout; break; }
-    __builtin_amdgcn_s_sleep(PPS_FLOW_SLEEP);
+    if (++spin >= (1 << 22)) { if ((threadIdx.x & 63) == 0) raise_status(&d.result_dev[2], kFlowTimeout); break; }
+    __builtin_amdgcn_s_sleep(1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
@@ -768,10 +617,6 @@ __device__ __forceinline__ void flow_post(const DevGraph& d, int* flow, int slot
     __hip_atomic_store(flow + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-#ifndef PPS_SOLVE_DIRECT
-#define PPS_SOLVE_DIRECT 1
-#endif
-constexpr bool kSolveDirect = PPS_SOLVE_DIRECT != 0;
 
 // The last sixteen pivots of a back-substitution (all of them for p <= 16), chain in registers: the scaling of the multipliers (does
 // not depend on the right-hand side) and the chain itself.
@@ -833,7 +678,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   const int n = (f + 1) * p;
   double tj = 0.0, dinv = 0.0;
   double lk[16];
-  if (kSolveDirect && GROUP && p <= 16) {                       // (wave-uniform) every separator front of a corridor tree; band form only:
+  if (GROUP && p <= 16) {                       // (wave-uniform) every separator front of a corridor tree; band form only:
     // the level-per-launch form of a large batch is issue-bound and 3 % slower with the extra address arithmetic (G = 128: 11.4 against 11.0 ms)
     // DIRECT form: no LDS copy of the panel.  Every lane requests exactly the entries it will multiply -- rows part, part + 4, ... of
     // L_B in column j (lane = 16 part + j), the sixteen rows of L_A^T in its column, the diagonal, the rhs row -- 30 independent loads
@@ -1116,7 +961,7 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
       constexpr bool ALIAS = REG_ONLY && !REG_STRIP;
       double* const Pn = ALIAS ? F : F + lds_doubles_per_wave - kRegRowsMax * kP8Stride;
       const int tr = ALIAS ? lds_doubles_per_wave - 1 : lds_doubles_per_wave - kRegRowsMax * kP8Stride - 1;
-      constexpr int WB = PPS_PANEL_W_BAND, WR = PPS_PANEL_W_R5;
+      constexpr int WB = kPanelWBand, WR = kPanelWWide;
       // the assembly is the same code for every tile count (one copy in the kernel); the elimination is per tile count
       if (REG_ONLY || fa <= kRegRowsMax) {
         if (REG_ONLY) front_assemble<TR>(d, rec, lambda, F, tr);
@@ -1134,13 +979,10 @@ __device__ __forceinline__ void body_band_factor(const DevGraph& d, int g, doubl
   }
 }
 
-#ifndef PPS_NPRE_BIG
-#define PPS_NPRE_BIG 8
-#endif
 // clear + original entries of a front, the first batch of NPRE x 64 entries requested before the clearing (front_pre_issue).  A
 // separator front of a corridor tree has 120 - 180 original entries, a leaf up to 650: three loads per lane cover the former -- eight
 // were five wasted load / read-modify-write pairs per lane (C2, same box, five runs each: 63.59 -> 63.33 us per LM iteration); eleven
-// for the leaves (one round trip instead of two for the largest) measured the same as eight: PPS_NPRE_BIG.
+// for the leaves (one round trip instead of two for the largest) measured the same as eight.
 template <int NPRE>
 __device__ __forceinline__ int front_orig_entries(const DevGraph& d, int rec, int lane, double damp, double* F, int tr) {
   FrontPre<NPRE> pre;
@@ -1152,7 +994,7 @@ __device__ __forceinline__ int front_orig_entries(const DevGraph& d, int rec, in
 __device__ __forceinline__ int front_orig_entries_sized(const DevGraph& d, int rec, int lane, double damp, double* F, int tr) {
   const int n_el = __builtin_amdgcn_readlane(rec, 4) - __builtin_amdgcn_readlane(rec, 3);
   if (n_el <= 192) return front_orig_entries<3>(d, rec, lane, damp, F, tr);        // (wave-uniform)
-  return front_orig_entries<PPS_NPRE_BIG>(d, rec, lane, damp, F, tr);
+  return front_orig_entries<8>(d, rec, lane, damp, F, tr);
 }
 
 // The register-only walk with the fronts of the upper local levels on waves of their own.  A band group of a dissection tree is a
@@ -1172,8 +1014,6 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
   const int n0 = o1 - o0, n1 = nl > 1 ? o2 - o1 : 0, n2 = nl > 2 ? o3 - o2 : 0, n3 = nl > 3 ? o4 - o3 : 0;
   double* F = lds + (size_t)wave * lds_doubles_per_wave;
   const int tr = lds_doubles_per_wave - 1;
-  int* flags = reinterpret_cast<int*>(lds + (size_t)nw * lds_doubles_per_wave);                  // kDuoFlags ints per (owner) wave
-  int* mail = flags + nw * kDuoFlags;                                                            // kDuoMail ints per (owner) wave
   // Which wave owns which front.  Shape B -- the whole group fits the waves (4 + 2 + 1 on eight): every upper front has a wave of its
   // own, which assembles what needs no child while local level 0 is eliminated.  Shape A (8 + 4 + 2 + 1 on eight): level 1 on the waves
   // that eliminated level 0, levels 2 and 3 on waves that idle from level 1 on and pre-assemble there.
@@ -1188,10 +1028,6 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
     else if (wave >= b3 && wave < b3 + n3) { up_ll = 3; up_i = o3 + wave - b3; }
     if (up_ll) up_rec = d.frec[(size_t)up_i * 16 + (threadIdx.x & 15)];
   }
-  if (PPS_DUO_MODE != 0) {
-    if (threadIdx.x < nw * kDuoFlags) flags[threadIdx.x] = 0;
-    __syncthreads();
-  }
   const int pre_at = shape_b ? 0 : 1;                           // the level during which the upper fronts are pre-assembled
   int crv = 0;
   for (int ll = 0; ll < nl; ll++) {
@@ -1200,70 +1036,17 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
     const int i0 = ll == 0 ? o0 : ll == 1 ? o1 : ll == 2 ? o2 : o3;
     const bool mine = wave >= lb && wave < lb + cnt;
     const bool mine_up = mine && up_ll == ll && ll > pre_at;    // (assembled ahead: starts with the extend-add)
-    const int epoch = ll + 1;
-    // the helper of the j-th owner is the j-th wave that owns nothing on this level
-    const int hj = wave < lb ? wave : wave - cnt;
-    const bool helping = !mine && hj < cnt;
     if (mine) {                                                 // (wave-uniform)
       const int rec = (up_ll == ll && ll > 0) ? up_rec : d.frec[(size_t)(i0 + wave - lb) * 16 + (threadIdx.x & 15)];
-      const int p = __builtin_amdgcn_readlane(rec, 1);
-      const int fa = p + __builtin_amdgcn_readlane(rec, 2) + 1;
-      // two waves: pivots within one tile column, at most 8 children, and a wave to help (the j-th idle one)
-      const int hw = (wave - lb) < lb ? (wave - lb) : (wave - lb) + cnt;                         // the helper's wave
-      const bool duo = PPS_DUO_MODE != 0 && p <= 16 && __builtin_amdgcn_readlane(rec, 6) <= 8 && hw < nw && !(d.sw & SW_NO_DUO);
-      int* fl = flags + wave * kDuoFlags;
+      const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
       if (!mine_up) crv = front_orig_entries_sized(d, rec, lane, 1.0 + lambda, F, tr);
-      // the owner hands the front's record and child records over through its mailbox: the helper starts without the two dependent
-      // memory round trips they would cost it (flag A: the mailbox is written and the original entries are in the triangle; 0 = solo)
-      if (duo) { int* mb = mail + wave * kDuoMail; if (lane < 16) mb[lane] = rec; mb[16 + lane] = crv; }
-      if (PPS_DUO_MODE != 0 && hw < nw && !(d.sw & SW_NO_DUO)) duo_post(fl + DF_A, duo ? epoch : -epoch);
-      if (duo) {
-        if (PPS_DUO_MODE & 1) {
-          front_extend_add_part<0>(d, rec, crv, lane, F, tr);
-          duo_wait(d, fl + DF_B, epoch);
-        } else front_extend_add(d, rec, crv, lane, F, tr);
-        if (PPS_DUO_MODE & 2) {
-          duo_post(fl + DF_C, epoch);                  // the triangle is complete
-          if (fa <= 33) front_duo_owner<2>(d, rec, F, fl, epoch);
-          else if (fa <= 49) front_duo_owner<3>(d, rec, F, fl, epoch);
-          else front_duo_owner<4>(d, rec, F, fl, epoch);
-        } else {
-          if (fa <= 33) front_eliminate_out<2, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-          else if (fa <= 49) front_eliminate_out<3, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-          else front_eliminate_out<4, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-        }
-      } else {
-        front_extend_add(d, rec, crv, lane, F, tr);
-        if (fa <= 33) front_eliminate_out<2, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-        else if (fa <= 49) front_eliminate_out<3, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-        else front_eliminate_out<4, false, false, PPS_PANEL_W_BAND>(d, rec, F, F);
-      }
-    } else {
-      if (ll == pre_at && up_ll > pre_at) {
-        // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
-        crv = front_orig_entries_sized(d, up_rec, lane, 1.0 + lambda, F, tr);
-      }
-      if (PPS_DUO_MODE != 0 && helping && !(d.sw & SW_NO_DUO)) {
-        const int ow = lb + hj;                                 // the owner's wave
-        int* fl = flags + ow * kDuoFlags;
-        const bool hduo = duo_wait_either(d, fl + DF_A, epoch);  // (false: the owner eliminates this front alone)
-        if (hduo) {
-        const int* mb = mail + ow * kDuoMail;
-        const int hrec = mb[lane & 15], crh = mb[16 + lane];
-        const int fa = __builtin_amdgcn_readlane(hrec, 1) + __builtin_amdgcn_readlane(hrec, 2) + 1;
-        double* Fo = lds + (size_t)ow * lds_doubles_per_wave;
-        if (PPS_DUO_MODE & 1) {
-          front_extend_add_part<1>(d, hrec, crh, lane, Fo, tr);
-          duo_post(fl + DF_B, epoch);
-        }
-        if (PPS_DUO_MODE & 2) {
-          duo_wait(d, fl + DF_C, epoch);
-          if (fa <= 33) front_duo_helper<2>(d, hrec, Fo, fl, epoch);
-          else if (fa <= 49) front_duo_helper<3>(d, hrec, Fo, fl, epoch);
-          else front_duo_helper<4>(d, hrec, Fo, fl, epoch);
-        }
-        }
-      }
+      front_extend_add(d, rec, crv, lane, F, tr);
+      if (fa <= 33) front_eliminate_out<2, false, false, kPanelWBand>(d, rec, F, F);
+      else if (fa <= 49) front_eliminate_out<3, false, false, kPanelWBand>(d, rec, F, F);
+      else front_eliminate_out<4, false, false, kPanelWBand>(d, rec, F, F);
+    } else if (ll == pre_at && up_ll > pre_at) {
+      // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
+      crv = front_orig_entries_sized(d, up_rec, lane, 1.0 + lambda, F, tr);
     }
     __syncthreads();   // children of the next local level are complete and visible (same CU)
   }
@@ -1346,7 +1129,7 @@ static hipError_t launch_band_factor_impl(const DevGraph& d, const DualAlt& alt,
   if (reg_only && d.trace != nullptr)      // phase trace of the register-only kernel
     PPS_LAUNCH(k_band_factor_lean_trace, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (reg_only && pre)
-    PPS_LAUNCH_EV(ev0, ev1, k_band_factor_pre, dim3(grp_count, ny), dim3(64 * nwaves), bytes + duo_flag_bytes(nwaves), st, d, alt, grp_begin, lambda, per_wave);
+    PPS_LAUNCH_EV(ev0, ev1, k_band_factor_pre, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (reg_only)
     PPS_LAUNCH_EV(ev0, ev1, k_band_factor<true>, dim3(grp_count, ny), dim3(64 * nwaves), bytes, st, d, alt, grp_begin, lambda, per_wave);
   else if (max_front + 1 <= kRegRowsMax && d.trace == nullptr && !d.no_strip) {
@@ -1413,7 +1196,7 @@ hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int 
     const int want = nwaves_factor > (max_group_fronts < 8 ? max_group_fronts : 8) ? nwaves_factor : (max_group_fronts < 8 ? max_group_fronts : 8);
     if ((size_t)pws * want * sizeof(double) + flow_fixed <= (size_t)kLdsLimitBytes) nw = want; else flow = false;
   }
-  const size_t bf = (size_t)pwf * nw * sizeof(double) + duo_flag_bytes(nw);
+  const size_t bf = (size_t)pwf * nw * sizeof(double);
   const size_t bs = flow ? (size_t)pws * nw * sizeof(double) + flow_fixed : ((size_t)pws * nw + (size_t)max_group_fronts * kBandMaxRows) * sizeof(double);
   const size_t bytes = bf > bs ? bf : bs;
   const DualAlt a2 = alt ? *alt : DualAlt{};
@@ -1516,9 +1299,6 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
 // One launch per tree level and size class; a workgroup is four independent fronts (no group, no barrier), the kernel of a
 // class holds exactly its tile rows: 86 / 118 VGPRs for fronts of <= 32 / <= 48 rows against the 256 of the band kernel that
 // carries all three, so 5 / 3 waves share a SIMD instead of 2 (the 12 KB triangle of a 48-row front is what stops at 3).
-#ifndef PPS_LVL3_WAVES
-#define PPS_LVL3_WAVES 3
-#endif
 #define PPS_LEVEL_FACTOR_KERNEL(NAME, NT, WAVES)                                                                      \
   __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(BatchArgs a, int level,   \
                                                                                                 int lds_doubles_per_wave) { \
@@ -1539,10 +1319,10 @@ __global__ __launch_bounds__(512) void kb_band_solve(BatchArgs a, int stage, int
       d2.L = al.L; d2.U = al.U; d2.delta = al.delta; d2.result_dev = al.result_dev;                                  \
       lam = a.lambda2[b];                                                                                            \
     }                                                                                                                \
-    wave_front_factor_reg<NT, false, false, PPS_PANEL_W_LEVEL>(d2, rec, lam, F, Pn, tr);                             \
+    wave_front_factor_reg<NT, false, false, kPanelWLevel>(d2, rec, lam, F, Pn, tr);                             \
   }
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor2, 2, 5)
-PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, PPS_LVL3_WAVES)
+PPS_LEVEL_FACTOR_KERNEL(kb_level_factor3, 3, 3)
 PPS_LEVEL_FACTOR_KERNEL(kb_level_factor4, 4, 2)
 #undef PPS_LEVEL_FACTOR_KERNEL
 
@@ -1553,10 +1333,6 @@ PPS_LEVEL_FACTOR_KERNEL(kb_level_factor4, 4, 2)
 // arena -- and writes them into the wave's own LDS slack); the pivots >= 16 of a leaf are a loop over the pivots it has instead of a
 // sixteen-way unrolled chunk; no second index register (b <= 64).  Fronts outside p <= 32, b <= 64, panel <= 1024 entries take the
 // general body.  G = 128: 10.9 -> ... ms of back-substitution per batch solve.
-#ifndef PPS_LEVEL_SOLVE_LEAN
-#define PPS_LEVEL_SOLVE_LEAN 1
-#endif
-constexpr bool kLevelSolveLean = PPS_LEVEL_SOLVE_LEAN != 0;
 constexpr int kLevelSolveSlack = 64;       // doubles of LDS behind a wave's panel area (the last copy batch may overrun the panel)
 // DIRECT (round 5): L_B never enters the LDS -- every lane loads exactly the entries of its column that it multiplies (rows part,
 // part + np, ...: at most sixteen loads, issued with the copy of L_A) and the products read registers; the LDS of a wave is x_b and the
@@ -1661,7 +1437,7 @@ __global__ __launch_bounds__(256) void kb_level_solve(BatchArgs a, int level, in
     if (fp <= 16) wave_front_solve_level<4, true>(d2, rec, W); else wave_front_solve_level<5, true>(d2, rec, W);
     return;
   }
-  if (kLevelSolveLean && fp <= 32 && fb <= 64 && (fp + fb + 1) * fp <= 1024) {
+  if (fp <= 32 && fb <= 64 && (fp + fb + 1) * fp <= 1024) {
     if (fp <= 16) wave_front_solve_level<4>(d2, rec, W); else wave_front_solve_level<5>(d2, rec, W);
     return;
   }
@@ -1706,7 +1482,7 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
         // (LDS by the level's own largest panel: the separators above the leaves hold a third of a leaf's panel -- five waves per SIMD instead of three)
         int pw = std::min(g.solve_per_wave_all, (int)(band_solve_lds_bytes(g.lvl_max_panel[l]) / sizeof(double))) + kLevelSolveSlack;
         // ... and by x_b + the pivot block alone where every front of the level takes the direct-load form (lvl_direct_pp: its largest p x p)
-        const int direct = kLevelSolveLean && g.lvl_direct_pp[l] > 0 ? 1 : 0;
+        const int direct = g.lvl_direct_pp[l] > 0 ? 1 : 0;
         if (direct) pw = std::min(pw, kBandMaxRows + g.lvl_direct_pp[l] + kLevelSolveSlack);
         PPS_LAUNCH(kb_level_solve, dim3(g.lvl_blocks[l], a.n, nz), dim3(256), (size_t)pw * 4 * sizeof(double), st, a, l, pw, direct);
       }
@@ -1717,7 +1493,7 @@ hipError_t launch_batch_solve(const BatchArgs& a, const BatchGeom& g, hipStream_
     const int per_wave = g.stage_per_wave_factor[stg], nw = g.stage_nw_factor[stg];
     const size_t bytes = (size_t)per_wave * nw * sizeof(double);
     if (g.stage_reg_only[stg] && g.stage_pre[stg])
-      PPS_LAUNCH(kb_band_factor_pre, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes + duo_flag_bytes(nw), st, a, stg, per_wave);
+      PPS_LAUNCH(kb_band_factor_pre, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else if (g.stage_reg_only[stg])
       PPS_LAUNCH(kb_band_factor<true>, dim3(g.stage_groups[stg], a.n, a.alt ? 2 : 1), dim3(64 * nw), bytes, st, a, stg, per_wave);
     else

@@ -251,7 +251,6 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
       q.lin_rest_blocks = std::max(q.lin_rest_blocks, (d.n_odo + 127) / 128 + (d.n_pp + 127) / 128 + (d.n_lp + 127) / 128);
       q.repop_blocks = std::max(q.repop_blocks, (d.n_obs - d.n_obs_fixed + 63) / 64);
       q.hblocks = std::max(q.hblocks, (d.n_nd_segs + 3) / 4);                     // (the segments K1 does not write itself)
-      q.hblocks_nd = std::max(q.hblocks_nd, (d.n_nd_segs + 15) / 16);
       q.k2t_blocks = std::max(q.k2t_blocks, (d.n_k2t_spec + 15) / 16 + (d.n_k2t_small + 15) / 16);
       q.k2tg_blocks = std::max(q.k2tg_blocks, (d.n_k2t_big - d.n_k2t_spec + 15) / 16);
       q.hreduce = std::max(q.hreduce, d.n_mseg);
@@ -289,10 +288,9 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
     const long long thr = m->sw.multi_thread_factors;          // 200 000 (PPS_MULTI_THREAD_FACTORS lowers it for the tests)
-    q.k2t_generic = m->sw.k2t_generic;
-    q.lin_thread_form = (q.n_factors_total > thr && !m->sw.multi_no_thread_form) || m->sw.multi_thread_form;      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
+    q.lin_thread_form = q.n_factors_total > thr || m->sw.multi_thread_form;      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
-    q.level_form = level_ok && ((q.n_factors_total > thr && !m->sw.multi_no_levels) || m->sw.multi_levels);      // (PPS_MULTI_NO_*: A/B)
+    q.level_form = level_ok && (q.n_factors_total > thr || m->sw.multi_levels);
     { int mp = 1; for (int stg = 0; stg < max_stages; stg++) mp = std::max(mp, max_panel[stg]); q.solve_per_wave_all = (int)(band_solve_lds_bytes(mp) / sizeof(double)); }
     for (int stg = 0; stg < max_stages; stg++) {
       q.stage_per_wave_factor[stg] = (int)(band_lds_bytes(q.stage_per_wave_factor[stg], q.stage_reg_only[stg]) / sizeof(double));
@@ -481,13 +479,11 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     m->n_relin += G; m->n_solves += 2 * (long long)G;
     int n_flight = n_chunks;
     double t_progress = now_s();
-    const bool lockstep = m->sw.multi_lockstep;     // (A/B: a barrier over all chunks between rounds, as up to round 4)
     // a HIP failure inside the loop: whatever the other chunks still have in flight is drained before the caller sees the error
     auto drain = [&]() { for (hipStream_t s3 : streams) if (s3) (void)hipStreamSynchronize(s3); };
     while (n_flight > 0) {
-      bool progressed = false, hold = false;
-      if (lockstep) { bool all = true; for (int c = 0; c < n_chunks; c++) all = all && (!cr[c].in_flight || chunk_done(c)); hold = !all; }   // (falls through to the time-out below)
-      for (int c = 0; c < n_chunks && !hold; c++) {
+      bool progressed = false;
+      for (int c = 0; c < n_chunks; c++) {
         if (!cr[c].in_flight || !chunk_done(c)) continue;
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         progressed = true;

@@ -30,6 +30,17 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
+// The status word of a solve (result_dev[2]: 0 ok | 1 not positive definite | >= 64 an internal time-out) is RAISED, never overwritten: a not-PD
+// front that reports after a hand-over time-out must not turn the internal error into an ordinary rejected step.  Non-negative doubles order
+// like their bit patterns, so the maximum is one integer atomic without a return value.
+#ifndef PPS_WAVE_EMU
+__device__ __forceinline__ void raise_status(double* w, double v) {
+  atomicMax(reinterpret_cast<unsigned long long*>(w), (unsigned long long)__double_as_longlong(v));
+}
+#else
+inline void raise_status(double* w, double v) { if (v > *w) *w = v; }
+#endif
+
 // broadcast lane `l` (wave-uniform) of a double through two v_readlane_b32
 #ifndef PPS_WAVE_EMU
 __device__ __forceinline__ double readlane_d(double x, int l) {

@@ -317,7 +317,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   // Speculation costs what it computes: on a graph whose lower tree levels fill the GPU by themselves (C3: 5 359 fronts) the second
   // factorisation + back-substitution of a launch set are extra time, not idle lanes -- and LM accepts most steps there.  Such a
   // graph factors the second damping value only while LM zig-zags (after a rejection); the trace is the same either way.
-  const bool adaptive = A.n_fronts >= 2048 && !g->sw.always_dual;
+  const bool adaptive = A.n_fronts >= 2048;
   bool use_alt = !adaptive;
   bool have_next = true;                 // trial 1 of the last launch is the step for the next lambda after a rejection
   auto enqueue_dual = [&](double lam) -> int {

@@ -420,7 +420,6 @@ void reset_keep_capacity(Analysis& A) {
   A.ea_tgt.clear();
   A.frec.clear();
   A.crec.clear();
-  A.f_crec0.clear();
   A.srec.clear();
   A.blk_rows.clear();
   A.blk_cols.clear();
@@ -1094,7 +1093,6 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   {
     A.frec.assign((size_t)F * 16, 0);
     A.crec.clear();
-    A.f_crec0.assign((size_t)F, 0);
     std::vector<int> pos_of(F, -1);
     for (int i = 0; i < F; i++) pos_of[A.glvl_fronts[i]] = i;
     std::vector<int> grp_first(F, 0);                    // position -> first position of its group
@@ -1107,7 +1105,6 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       int* r = &A.frec[(size_t)i * 16];
       r[0] = s2; r[1] = A.f_p[s2]; r[2] = A.f_b[s2]; r[3] = A.f_el_off[s2]; r[4] = A.f_el_off[s2 + 1];
       r[5] = (int)(A.crec.size() / 8); r[6] = A.f_child_off[s2 + 1] - A.f_child_off[s2];
-      A.f_crec0[s2] = r[5];
       r[7] = A.f_poff[s2]; r[8] = A.f_bidx_off[s2];
       r[9] = (int)(A.f_Loff[s2] & 0xffffffffLL); r[10] = (int)(A.f_Loff[s2] >> 32);
       r[11] = (int)(A.f_Uoff[s2] & 0xffffffffLL); r[12] = (int)(A.f_Uoff[s2] >> 32);

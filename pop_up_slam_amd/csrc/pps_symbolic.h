@@ -116,7 +116,6 @@ struct Analysis {
   // crec: 8 ints per child edge: 0 packed entries of the child's update matrix, 1/2 its Uoff lo/hi, 3/4 its ea_off lo/hi
   // srec: 8 ints per H segment: 0 rows, 1 cols, 2 size, 3 c0, 4 cnt, 5 hoff (segment slot), 6 blk_doff, 7 nseg of the block
   std::vector<int> frec, crec, srec;
-  std::vector<int> f_crec0;              // front id -> index of its first child record in crec (what frec slot 5 holds per position)
 
   // ---- level-per-launch form (many-graph batches): positions in frec of the fronts of tree level l with size class c --
   // 0: p + b <= 32, 1: <= 48, 2: larger -- at cls_fronts[cls_off[3 l + c] .. cls_off[3 l + c + 1]) ----

@@ -287,9 +287,8 @@ static int run_analysis_impl(pps_graph* g) {
   // 637 vs 710 us).  (Up to round 4: 4 levels, 113.3 vs 115.0 us per C2 LM iteration with 3.  Round 5: a group of 4 + 2 + 1 fronts on
   // eight waves has a wave for every front, so every separator front is assembled ahead of its level while the leaves are eliminated,
   // and the top group -- levels 6 .. 8 of C2's nine -- is factored and solved by one launch with the data-flow back-substitution:
-  // 60.9 against 63.7 us per C2 LM iteration with 4, same box, tools/r5_ab_duo.sh.)
+  // 60.9 against 63.7 us per C2 LM iteration with 4, same box.)
   g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 3;
-  if (g->sw.band_levels > 0) g->aprm.band_levels = g->sw.band_levels;      // (PPS_BAND_LEVELS: A/B)
   // H-block segments (contributions reduced by one wave of K2): short on small graphs, where the few long segments
   // (ground plane, 32 contributions = 16 dependent load rounds) are K2's critical path; long on large ones, where the
   // number of waves is (C2: 23.3 -> 18.7 us with 8; C3: 82 -> 102 us)
@@ -571,7 +570,7 @@ int upload_all(pps_graph* g) {
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
   // the mirror holds the arrays of the analysis this one was built upon: its kept parts are not compared again
-  const bool hints = was_grown_only && !g->up_unknown && g->up_an_seq >= 0 && g->an_base_seq == g->up_an_seq && !g->sw.no_upload_hints;
+  const bool hints = was_grown_only && !g->up_unknown && g->up_an_seq >= 0 && g->an_base_seq == g->up_an_seq;
   const Analysis::Kept K = hints ? A.kept : Analysis::Kept();
   const size_t kF = (size_t)K.fronts, kFl = (size_t)K.fronts_lists, kB = (size_t)K.blocks, kS = (size_t)K.segs;
   auto at = [](const auto& v, size_t i) -> size_t { return i < v.size() ? (size_t)v[i] : 0; };     // (0 = no claim)
@@ -721,8 +720,6 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.f_el_off, A.f_el_off, kFl ? kFl + 1 : 0)); TRY(dev_alloc(g, &d.el_tgt, (size_t)std::max<int64_t>(1, A.el_total)));   // filled by k_expand_el below
   TRY(dev_upload(g, &d.asm_el0, A.asm_el0, kA)); TRY(dev_upload(g, &d.asm_fsz, A.asm_fsz, kA));
   TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off, kF ? kF + 1 : 0)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
-  d.c_split = nullptr;
-  if (band_duo_mode()) TRY(dev_alloc(g, &d.c_split, std::max<size_t>(1, A.crec.size() / 8)));          // ... c_split likewise (expand_split; two-wave builds only)
   TRY(dev_upload(g, &d.blk_doff, A.blk_doff, kB ? kB + 1 : 0)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
   TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
@@ -739,8 +736,6 @@ int upload_all(pps_graph* g) {
     TRY(dev_upload(g, &d.grp_span, span));
   }
   TRY(dev_upload(g, &d.glvl_fronts, A.glvl_fronts));
-  d.f_crec0 = nullptr;
-  if (band_duo_mode()) TRY(dev_upload(g, &d.f_crec0, A.f_crec0));
   TRY(dev_upload(g, &d.frec, A.frec)); TRY(dev_upload(g, &d.crec, A.crec)); TRY(dev_upload(g, &d.srec, A.srec, 8 * kS));
   TRY(dev_upload(g, &d.obs_dir, A.obs_dir)); TRY(dev_upload(g, &d.nd_segs, A.nd_segs, (size_t)K.nd_segs)); d.n_nd_segs = (int)A.nd_segs.size();
   TRY(dev_upload(g, &d.cls_off, A.cls_off)); TRY(dev_upload(g, &d.cls_fronts, A.cls_fronts));

@@ -30,23 +30,6 @@ void run_front(int p, int b, const double* A, double* L, double* U, double* res,
     front_reg_eliminate<NT, false, STRIP, W>(d, rec, F, P);
   });
 }
-template <int NT>
-void run_front16(int p, int b, const double* A, double* L, double* U, double* res) {
-  using namespace pps;
-  const int fa = p + b + 1;
-  const int ntri = fa * (fa + 1) / 2;
-  std::vector<double> lds(std::max(ntri, kRegRows * kP16Stride) + 2 + 64, std::nan(""));
-  double* F = lds.data();
-  for (int i = 0; i < ntri; i++) F[i] = A[i];
-  EmuGraph d{L, U, res, nullptr};
-  pps_emu::run_wave([&] {
-    const int lane = threadIdx.x;
-    int rec = 0;
-    if (lane == 1) rec = p;
-    if (lane == 2) rec = b;
-    front_reg_eliminate16<NT>(d, rec, F, F);          // (the panel buffer is the head of the dead triangle, as in the band kernels)
-  });
-}
 }  // namespace
 
 template <int W>
@@ -61,13 +44,7 @@ static int front_factor_w(int tiles, int strip, int p, int b, const double* A, d
   double res[4] = {0, 0, 0, 0};
   pps_emu::Wave& w = pps_emu::W();
   w.n_yields = w.n_readlane = w.n_mfma = w.n_barrier = 0;
-  if (W == 16) {
-    if (wide || strip) return -1;
-    if (tiles == 4) run_front16<4>(p, b, A, Lb.data(), Ub.data(), res);
-    else if (tiles == 3) run_front16<3>(p, b, A, Lb.data(), Ub.data(), res);
-    else run_front16<2>(p, b, A, Lb.data(), Ub.data(), res);
-  }
-  else if (tiles == 5) run_front<5, true, W>(p, b, A, Lb.data(), Ub.data(), res, false);
+  if (tiles == 5) run_front<5, true, W>(p, b, A, Lb.data(), Ub.data(), res, false);
   else if (tiles == 4 && wide) run_front<4, true, W>(p, b, A, Lb.data(), Ub.data(), res, false);
   else if (tiles == 4) run_front<4, false, W>(p, b, A, Lb.data(), Ub.data(), res, true);
   else if (tiles == 3) run_front<3, false, W>(p, b, A, Lb.data(), Ub.data(), res, true);
@@ -82,10 +59,6 @@ static int front_factor_w(int tiles, int strip, int p, int b, const double* A, d
 // W = 8: what the r5 / general / level kernels run; W = 4: the register-only band kernels (one pivot block per panel step)
 extern "C" int emu_front_factor(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd, long long* counts) {
   return front_factor_w<8>(tiles, strip, p, b, A, L, U, not_pd, counts);
-}
-// W = 16: a whole tile column per LDS round trip, rank-1 elimination in registers (front_reg_eliminate16: the band kernels since round 5)
-extern "C" int emu_front_factor_w16(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd, long long* counts) {
-  return front_factor_w<16>(tiles, strip, p, b, A, L, U, not_pd, counts);
 }
 extern "C" int emu_front_factor_w4(int tiles, int strip, int p, int b, const double* A, double* L, double* U, double* not_pd, long long* counts) {
   return front_factor_w<4>(tiles, strip, p, b, A, L, U, not_pd, counts);

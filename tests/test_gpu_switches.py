@@ -1,4 +1,4 @@
-"""GPU: the A/B switches select between two schedules of the same arithmetic.  A handle reads them once, when it is created (round 5:
+"""GPU: the schedule switches select between two schedules of the same arithmetic.  A handle reads them once, when it is created (round 5:
 Switches, csrc/pps_device.h); every side still runs in a process of its own, with the variable set for the whole process, as the
 A/B tools do.  Each side must reproduce the default schedule's LM traces, chi2 and iteration counts bit for bit.  Plus: the time-out
 path of the data-flow back-substitution (PPS_DEBUG_DROP_FLAG) must fail loudly, not return numbers."""
@@ -100,8 +100,7 @@ print("RESULT " + json.dumps(out))
 
 def _run(parts, **env):
     e = dict(os.environ)
-    for k in ("PPS_ALWAYS_DUAL", "PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE", "PPS_SPLIT_EXPAND", "PPS_NO_UPLOAD_HINTS", "PPS_K2T_GENERIC",
-              "PPS_MULTI_LOCKSTEP", "PPS_MULTI_SPLIT", "PPS_MULTI_THREAD_FACTORS", "PPS_DEBUG_DROP_FLAG", "PPS_K1_THREAD_FORM"):
+    for k in ("PPS_PLAIN_SCHEDULE", "PPS_NO_DUAL", "PPS_MULTI_SPLIT", "PPS_MULTI_THREAD_FACTORS", "PPS_DEBUG_DROP_FLAG", "PPS_K1_THREAD_FORM"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", CHILD, parts], env=e, capture_output=True, text=True, timeout=600)
@@ -138,36 +137,28 @@ def test_multi_chunk_scheduler_against_single_handles(multi_run):
     assert 1 <= rounds <= max(its) + 1
 
 
-@pytest.mark.parametrize("switch", ["PPS_NO_SOLVE_FLOW", "PPS_NO_PREASSEMBLE", "PPS_NO_ROOT_FUSE"])
-def test_band_schedules(default_run, switch):
-    """barrier form of the back-substitution / plain walk of a band group / root stage as two launches, against the shipped schedule"""
-    got = _run("single,frames", **{switch: 1})
+@pytest.mark.parametrize("bits", [1, 2, 4, 15])
+def test_band_schedules(default_run, bits):
+    """PPS_PLAIN_SCHEDULE: plain walk of a band group (1) / barrier form of the back-substitution (2) / root stage as two launches (4) / all
+    fall-backs at once (15), against the shipped schedule"""
+    got = _run("single,frames", PPS_PLAIN_SCHEDULE=bits)
     for k in ("single_corridor", "single_world", "frames"):
-        assert got[k] == default_run[k], (switch, k)
+        assert got[k] == default_run[k], (bits, k)
     assert default_run["single_corridor"][0] >= 10
 
 
 def test_adaptive_speculation(default_run):
-    """graphs of >= 2 048 fronts factor the second damping value only after a rejected trial; PPS_ALWAYS_DUAL=1 keeps
-    both in every launch: same trials, same chi2"""
-    got = _run("large", PPS_ALWAYS_DUAL=1)
+    """graphs of >= 2 048 fronts factor the second damping value only after a rejected trial: same trials, same chi2 as the
+    one-step-at-a-time loop (PPS_NO_DUAL), which never speculates"""
+    got = _run("large", PPS_NO_DUAL=1)
     assert default_run["large"][3] >= 2048
     assert got["large"] == default_run["large"]
 
 
 def test_upload_forms(default_run):
-    """list expansion as two launches + a fill; every array compared in full against the mirror (no kept-prefix hints)"""
-    got = _run("frames", PPS_SPLIT_EXPAND=1, PPS_NO_UPLOAD_HINTS=1)
+    """list expansion as two launches + a fill"""
+    got = _run("frames", PPS_PLAIN_SCHEDULE=8)
     assert got["frames"] == default_run["frames"]
-
-
-@pytest.mark.parametrize("switch", ["PPS_K2T_GENERIC", "PPS_MULTI_LOCKSTEP"])
-def test_large_batch_schedules(multi_run, switch):
-    """K2's one-body throughput form / a barrier over all chunks between rounds -- on a batch that really runs the class-body K2 and
-    more than one chunk (multi_forms)"""
-    got = _run("multi", **dict(MULTI_ENV, **{switch: 1}))
-    assert got["multi_forms"] == multi_run["multi_forms"] == [3, True, True]
-    assert got["multi"] == multi_run["multi"], switch
 
 
 def test_flow_timeout_fails_loudly(built):

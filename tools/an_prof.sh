@@ -3,7 +3,7 @@
 cd /root/repo
 ( cd pop_up_slam_amd/csrc && make -j8 2>&1 | grep -E "error|warning" | head )
 timeout 900 python -m pytest tests/test_host_incremental.py tests/test_host_analysis.py -x -q 2>&1 | tail -n 3
-PPS_ANALYSIS_TIMING=1 taskset -c 5 python tools/analysis_bench.py ${1:-1000} 2> /tmp/an_timing.txt | tail -n 1
+PPS_TIMING=1 taskset -c 5 python tools/analysis_bench.py ${1:-1000} 2> /tmp/an_timing.txt | tail -n 1
 python - <<'PY'
 import re, collections
 lines=[l for l in open('/tmp/an_timing.txt') if l.startswith('[analysis]')]
