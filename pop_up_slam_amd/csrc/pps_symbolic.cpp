@@ -44,6 +44,10 @@ struct Builder {
   std::vector<TNode> tree;
   std::vector<int> lidx;           // scratch: node -> local pose index in the current call
   std::vector<char> dense;
+  int chain_first = -1, chain_last = -1;   // first / last pose of the whole chain (node ids)
+  int border_dim = 0;              // scalars of the dense border: rows of every front (the ground plane is seen from every pose)
+  std::vector<int> own_stamp;      // scratch of ext_adjacent
+  int own_stamp_id = 0;
 
   Builder(const std::vector<SymNode>& n, const std::vector<SymFactor>& f, const AnalysisParams& p)
       : nodes(n), factors(f), prm(p), N((int)n.size()) {}
@@ -213,8 +217,31 @@ struct Builder {
     return top;
   }
 
-  // poses: node ids sorted by rank; planes: node ids.  Returns tnode id.
-  int dissect(std::vector<int> poses, std::vector<int> planes) {
+  // The nodes of `cand` (separator nodes of the ancestors) that have a neighbour among `poses` / `planes`: what the fronts of this
+  // sub-chain's sub-tree carry as boundary rows besides the border.  A function of the sub-chain and the adjacency alone (its external
+  // neighbours are exactly these), so a memoised sub-tree needs no record of it.
+  std::vector<int> ext_adjacent(const std::vector<int>& cand, const std::vector<int>& poses, const std::vector<int>& planes, int* dim) {
+    std::vector<int> out;
+    *dim = 0;
+    if (cand.empty() || poses.empty()) return out;
+    if ((int)own_stamp.size() < N) own_stamp.assign(N, 0);
+    const int id = ++own_stamp_id;
+    int lo = poses[0], hi = poses[0];
+    for (int u : poses) { own_stamp[u] = id; lo = std::min(lo, u); hi = std::max(hi, u); }
+    for (int u : planes) { own_stamp[u] = id; lo = std::min(lo, u); hi = std::max(hi, u); }
+    for (int v : cand) {
+      const int* a0 = adj.data() + adj_off[v];
+      const int* a1 = adj.data() + adj_off[v + 1];
+      bool hit = false;
+      for (const int* q = std::lower_bound(a0, a1, lo); q < a1 && *q <= hi && !hit; q++) hit = own_stamp[*q] == id;      // (rows are sorted)
+      if (hit) { out.push_back(v); *dim += nodes[v].dim; }
+    }
+    return out;
+  }
+
+  // poses: node ids sorted by rank; planes: node ids; ext: separator nodes of the ancestors (candidates for this sub-chain's external
+  // boundary).  Returns tnode id.
+  int dissect(std::vector<int> poses, std::vector<int> planes, const std::vector<int>& ext = std::vector<int>()) {
     const int n = (int)poses.size();
     if (old_memo && n > 0 && poses[0] < (int)old_memo_of_first->size()) {
       for (int mi = (*old_memo_of_first)[poses[0]]; mi >= 0; mi = (*old_memo_next)[mi]) {
@@ -250,7 +277,17 @@ struct Builder {
     const int t = new_tnode();
     const size_t my_memo = memo.size();
     memo.push_back(DissectMemo{n > 0 ? poses[0] : -1, n > 0 ? poses[n - 1] : -1, n, t, -1, planes});
-    if (n <= prm.leaf_poses) {
+    // rows the first front of this sub-chain's top would hold besides its own pivots
+    int ext_dim = 0;
+    std::vector<int> ext_here;
+    const bool limit = prm.front_rows > 0;
+    if (limit) ext_here = ext_adjacent(ext, poses, planes, &ext_dim);
+    const int fixed_rows = ext_dim + border_dim;
+    int own_dim = 0;
+    for (int po : poses) own_dim += nodes[po].dim;
+    for (int pl : planes) own_dim += nodes[pl].dim;
+    // (a would-be leaf of more than front_rows rows is dissected further: its poses leave it one separator at a time)
+    if (n <= prm.leaf_poses && (!limit || n <= 1 || own_dim + fixed_rows <= prm.front_rows)) {
       for (int pl : planes) tree[t].piv.push_back(pl);
       for (int po : poses) tree[t].piv.push_back(po);
       memo[my_memo].t1 = (int)tree.size();
@@ -260,6 +297,7 @@ struct Builder {
     // observer span of every plane inside this sub-chain
     std::vector<int> pmin(planes.size(), n), pmax(planes.size(), -1);
     std::vector<int> diff(n + 1, 0);
+    std::vector<int> only(limit ? n : 0, 0);               // scalars of the planes seen from pose m alone (they join a cut at m)
     // A landmark's observers are sorted by node id, which grows with the pose rank: inside this sub-chain they are one run of
     // the row, and its two ends are the span (two binary searches instead of a walk over every observer -- the ground-level
     // chains of a frame loop are walked once per frame).  Anything unexpected falls back to the walk.
@@ -283,6 +321,7 @@ struct Builder {
           pmax[k] = std::max(pmax[k], li);
         }
       if (pmax[k] - pmin[k] >= 2) { diff[pmin[k] + 1] += 3; diff[pmax[k]] -= 3; }  // spans m for pmin < m < pmax
+      if (limit && pmax[k] == pmin[k] && pmin[k] >= 0 && pmin[k] < n) only[pmin[k]] += nodes[pl].dim;
     }
     // pose-pose edges that are not between chain neighbours
     std::vector<std::pair<int, int>> cross;
@@ -307,13 +346,37 @@ struct Builder {
       // inside this sub-chain.  A chain that grows at its end (a SLAM front
       // end adds one pose per frame) then keeps every sub-tree left of its newest poses -- ordering, fronts and all index
       // arrays of that part stay what they were, frame after frame (a quantile cut moves with n).
-      const int r_lo = nodes[poses[0]].rank, r_hi = nodes[poses[n - 1]].rank;
+      // (round 6: cuts may leave their aligned rank by a few poses -- below -- so the ends of a sub-chain are no longer aligned themselves, and
+      // the multiple of the largest power of two inside it can sit next to one of them.  The rank is therefore looked for in the MIDDLE QUARTER
+      // of the sub-chain -- still an absolute position, a function of the sub-chain's two end ranks alone -- measured from the ends that are
+      // cuts: the chain's own first pose bounds nothing, and the newest poses of a growing chain must not push the cut of the right spine back)
+      int r_lo = nodes[poses[0]].rank, r_hi = nodes[poses[n - 1]].rank;
+      if (limit && prm.cut_shift > 0) {
+        const int margin = 3 * (r_hi - r_lo) / 8;
+        if (poses[0] != chain_first) r_lo += margin;
+        if (poses[n - 1] != chain_last) r_hi -= margin;
+      }
       int c_rank = r_hi;
       for (int k = 30; k >= 0; k--) { const int c = (r_hi >> k) << k; if (c > r_lo) { c_rank = c; break; } }
       int centre = (int)(std::lower_bound(poses.begin(), poses.end(), c_rank, [&](int u, int r) { return nodes[u].rank < r; }) - poses.begin());
       // (no search window here: a cut that leaves its aligned rank makes the child ranges straddle their own aligned cuts
       // and the tree degenerates -- 12 levels instead of 9 on a 512-pose chain)
-      cuts.push_back(std::min(std::max(centre, 1), n - 2));
+      centre = std::min(std::max(centre, 1), n - 2);
+      // (round 6) ... except by a few poses: within cut_shift of the aligned rank the cheapest position is taken (ties: the nearest).  The
+      // planes of a cut are boundary rows of every front below it on that side, so a sub-chain between two cuts of five walls each whose own
+      // cut holds five more is a front of 66 rows; a pose that sees four walls is rarely far.  The aligned rank itself keeps away from the
+      // ends of the sub-chain (above), so the children never find their parent's rank inside their own window.
+      if (limit && prm.cut_shift > 0 && cross.empty()) {
+        int best = centre;
+        for (int dlt = 1; dlt <= std::min(prm.cut_shift, n / 8); dlt++)
+          for (int sg = -1; sg <= 1; sg += 2) {
+            const int m2 = centre + sg * dlt;
+            if (m2 < 1 || m2 > n - 2) continue;
+            if (cost[m2] + only[m2] < cost[best] + only[best]) best = m2;
+          }
+        centre = best;
+      }
+      cuts.push_back(centre);
     }
     for (int c = 1; c < K && !aligned; c++) {
       const int centre = (int)((long long)n * c / K);
@@ -327,6 +390,24 @@ struct Builder {
       cuts.push_back(best);
     }
     if (cuts.empty()) cuts.push_back(std::min(std::max(1, n / 2), n - 1));
+    if (limit && cuts.size() == 1 && cross.empty() && n >= 3) {
+      // The separator front of a cut at m holds the cut pose, the planes that span m or are seen from m alone, and the sub-chain's external
+      // boundary.  Beyond front_rows the cut moves to the NEAREST position that fits, at most a quarter of the sub-chain away (the parts stay
+      // balanced; an aligned cut has already taken the cheapest position within cut_shift poses of its rank, so this is its last resort); where
+      // nothing in reach fits it stays.
+      auto rows_at = [&](int m2) { return nodes[poses[m2]].dim + cost[m2] + only[m2] + fixed_rows; };
+      const int m0 = cuts[0];
+      if (rows_at(m0) > prm.front_rows) {
+        const int reach = std::max(1, n / 4);
+        bool fits = false;
+        for (int dlt = 1; dlt <= reach && !fits; dlt++)
+          for (int sg = -1; sg <= 1 && !fits; sg += 2) {
+            const int m2 = m0 + sg * dlt;
+            if (m2 < 1 || m2 > n - 2) continue;
+            if (rows_at(m2) <= prm.front_rows) { cuts[0] = m2; fits = true; }
+          }
+      }
+    }
     const int nparts = (int)cuts.size() + 1;
     // part index of every pose (-1 = separator)
     std::vector<int> part(n, 0);
@@ -368,8 +449,10 @@ struct Builder {
     for (int i = 0; i < n; i++) lidx[poses[i]] = -1;
     for (int pl : sep_planes) tree[t].piv.push_back(pl);
     for (int po : sep_poses) tree[t].piv.push_back(po);
+    std::vector<int> ext_kids;
+    if (limit) { ext_kids = ext_here; ext_kids.insert(ext_kids.end(), sep_planes.begin(), sep_planes.end()); ext_kids.insert(ext_kids.end(), sep_poses.begin(), sep_poses.end()); }
     for (int q = 0; q < nparts; q++)
-      if (!pposes[q].empty()) { const int c = dissect(std::move(pposes[q]), std::move(pplanes[q])); tree[t].kids.push_back(c); }
+      if (!pposes[q].empty()) { const int c = dissect(std::move(pposes[q]), std::move(pplanes[q]), ext_kids); tree[t].kids.push_back(c); }
     memo[my_memo].t1 = (int)tree.size();
     return t;
   }
@@ -497,7 +580,8 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     bool ok = C->valid && !general_ordering && prm.aligned_cuts && std::max(2, prm.arity) == 2 && N0 <= nodes.size() && M0 <= factors.size() &&
               C->prm.leaf_poses == prm.leaf_poses && C->prm.max_pivots == prm.max_pivots && C->prm.seg_len == prm.seg_len &&
               C->prm.band_levels == prm.band_levels && C->prm.band_rows == prm.band_rows && C->prm.aligned_cuts == prm.aligned_cuts &&
-              C->prm.dense_min == prm.dense_min && C->prm.dense_mult == prm.dense_mult && (int)A.f_b.size() == C->fronts_total;
+              C->prm.dense_min == prm.dense_min && C->prm.dense_mult == prm.dense_mult && C->prm.front_rows == prm.front_rows &&
+              C->prm.cut_shift == prm.cut_shift && (int)A.f_b.size() == C->fronts_total;
     // (SymNode / SymFactor are plain ints without padding: the old parts are compared as bytes)
     static_assert(sizeof(SymNode) == 3 * sizeof(int) && sizeof(SymFactor) == 6 * sizeof(int), "byte-wise comparison of the cached graph");
     ok = ok && (N0 == 0 || memcmp(nodes.data(), C->nodes.data(), N0 * sizeof(SymNode)) == 0);
@@ -536,6 +620,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     else if (nodes[u].type == NODE_POSE) poses.push_back(u);
     else planes.push_back(u);
   }
+  for (int u : dense_nodes) B.border_dim += nodes[u].dim;
   if (reuse) {                                            // the border block must be the one it was
     for (size_t u = 0; u < C->dense.size(); u++) if (C->dense[u] != B.dense[u]) return from_scratch(2);
     for (size_t u = C->dense.size(); u < (size_t)N; u++) if (B.dense[u]) return from_scratch(3);
@@ -581,6 +666,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
             if (factors[i].b >= 0 && factors[i].b < n_old) touched[factors[i].b] = 1;
           }
           B.touched = &touched; }
+        if (!poses.empty()) { B.chain_first = poses.front(); B.chain_last = poses.back(); }
         top = B.dissect(poses, planes);
       }
     }

@@ -44,6 +44,11 @@ struct AnalysisParams {
   int ordering = 0;        // 0 = pose-chain dissection, minimum degree as well when its fronts exceed band_rows (cheaper wins);
                            // 1 = minimum degree only; 2 = chain dissection only
   int band_rows = 127;     // largest front of the wave-per-front kernels: graphs beyond it skip the packed extend-add lists
+  int front_rows = 63;     // rows (without the rhs row) a front should not exceed where the dissection can arrange it: every front then lives in
+                           // the register tiles of ONE wave at two waves per SIMD (kRegRows, pps_regtile.h).  A would-be leaf beyond it is dissected
+                           // further; a cut whose separator front would exceed it moves to the nearest position that fits -- anywhere in the
+                           // sub-chain for cost-driven cuts, at most cut_shift poses from its aligned rank for aligned cuts.  0 = off.
+  int cut_shift = 8;
   int dense_min = 64;      // a node is "dense" if degree > max(dense_min, dense_mult*sqrt(N))
   double dense_mult = 8.0;
   int timing = 0;          // per-phase host times to stderr (Switches::analysis_timing of the handle)

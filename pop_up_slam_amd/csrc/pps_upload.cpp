@@ -297,8 +297,8 @@ static int run_analysis_impl(pps_graph* g) {
   g->aprm.seg_len = 64;
   // a graph that is re-analysed after pure appends is a frame loop: absolute cut positions keep the left part of its tree
   g->aprm.aligned_cuts = (g->n_analyses > 0 && g->grown_only) ? 1 : 0;
-  // ... and its aligned cuts leave a few fronts of 65 .. 80 rows, whose 25 KB triangles let 5 waves share a CU's LDS, not 8:
-  // groups of 4 leaves (3 levels per launch) keep every front of a level on its own wave (C5: 1 580 vs 1 500 frames/s)
+  // ... whose groups of 4 leaves (3 levels per launch) keep every front of a level on its own wave (C5: 1 580 vs 1 500 frames/s; up to round 5
+  // its aligned cuts also left fronts of 65 .. 80 rows: AnalysisParams::front_rows / cut_shift now keep every front of the loop within 63)
   if (g->aprm.aligned_cuts && g->pose_ids.size() < 4000) g->aprm.band_levels = 3;
   g->aprm.band_rows = band_front_limit();
   const char* msg = "";

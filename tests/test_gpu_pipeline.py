@@ -58,8 +58,10 @@ def test_config5_at_size_1000_frames(built, tmp_path):
     t0 = time.perf_counter()
     t_oracle = 0.0
     lm_calls = 0
+    largest_front = 0
     for k, fr in enumerate(frames):
         it = pl.process(fr)
+        largest_front = max(largest_front, g.stats()["max_front"])
         if it >= 0:
             lm_calls += 1
             tr = g.trace()
@@ -82,6 +84,9 @@ def test_config5_at_size_1000_frames(built, tmp_path):
     wall = time.perf_counter() - t0 - t_oracle
     st = g.stats()
     assert st["n_poses"] == n and lm_calls == n // 5
+    # round 6: the dissection keeps every front of every frame's tree within the 64 rows (63 + the rhs row) of the register-tile kernels at two
+    # waves per SIMD -- no launch of the loop takes k_band_factor_r5
+    assert largest_front <= 63, largest_front
     est = np.array([g.get_pose(p)[:3] for p in pl.pose_nodes])
     true = np.array([fr.true_pose[:3] for fr in frames])
     rms = float(np.sqrt(np.mean(np.sum((est - true) ** 2, axis=1))))
