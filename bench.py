@@ -420,17 +420,21 @@ def main():
         achieved = bytes_per_launch / k1_in_solve / 1e9 if k1_in_solve > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "k_linearize_lanes" if mode == P.JAC_NUMERIC else "k_linearize<1,0>+<1,1>",
+                    "kernel": "k_trial_lin (both trials' retraction + chi2 and the K1 sweep at the trial point LM is predicted to accept, ONE launch); "
+                              "k_linearize_lanes for the first linearisation and after a wrong prediction" if mode == P.JAC_NUMERIC else "k_linearize<1,0>+<1,1>",
                     "launches": k1_launches, "avg_launch_us": k1_in_solve * 1e6,
                     "replay_avg_launch_us": k1_replay * 1e6, "replay_launches": 400,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "note": "K1 of the C2 graph inside an LM solve, on the solver's stream: mean dispatch duration (start / stop "
-                            "events of hipExtLaunchKernelGGL = the kernel's own begin / end timestamps) over every sweep of one "
-                            "solve; the same kernel in profiles/r5_kernel_stats_c2.txt (rocprofv3 of tools/timeline_c2.py, C2 "
-                            "only).  replay_avg_launch_us: 400 back-to-back launches between two events (hot caches, the more "
-                            "flattering figure; not used for frac).  One C2 graph is 2.8 MB per sweep: cache-resident and "
-                            "latency bound, so HBM traffic is not meaningful here (traffic: null); see roofline_batched for "
-                            "the same kernel family over > 256 MB"}
+                            "events of hipExtLaunchKernelGGL = the kernel's own begin / end timestamps) over every launch of one "
+                            "solve whose sweep became a linearisation LM used.  Since round 6 that launch is k_trial_lin: the sweep "
+                            "runs BESIDE the two trials' retraction + chi2 blocks, so its duration covers both (12.9 us against "
+                            "9.1 + 9.3 for the two launches it replaces); only the sweep's 392 / 840 B per edge are counted as "
+                            "algorithmic bytes, not the trials' 176 B per edge.  profiles/r6_kernel_stats_c2.txt has the same "
+                            "launches (rocprofv3 of tools/timeline_c2.py, C2 only).  replay_avg_launch_us: 400 back-to-back "
+                            "launches of the plain sweep between two events (hot caches, the more flattering figure; not used for "
+                            "frac).  One C2 graph is 2.8 MB per sweep: cache-resident and latency bound, so HBM traffic is not "
+                            "meaningful here (traffic: null); see roofline_batched for the same kernel family over > 256 MB"}
         # the same solve: dispatch durations of its factor launches; a launch set holds two factorisations (lambda and lambda * 10)
         # -- or one, where the loop dropped the speculation (graphs that fill the GPU: pps_solve.cpp)
         fact_us = 1e6 * st["t_factor"] / max(1, st["n_factorize"])               # device time per factorisation, amortised

@@ -145,6 +145,19 @@ struct LinGuard {
   const double* plane[2];
   double error;              // chi2 at the linearisation point the trials started from
   int on, single;            // single: only trial 0 was computed (the second record is stale: never consulted)
+  int want = -1;             // 0 / 1: run only if THAT trial is the accepted one (K2 of a speculative linearisation, SpecLin); -1: if either is
+};
+
+// Round 6 -- the next linearisation off the LM loop's dependency chain.  The launch that applies the two trial steps and reduces their chi2
+// (k_trial_lin) also sweeps K1 at ONE of the two trial points, x (+) delta_which -- evaluated on the spot, no launch boundary behind the
+// retraction -- into a spare set of J / P / H / Hf, and a K2 launch assembles that H.  `which` is the host's prediction of the trial LM will
+// accept (the one it accepted last time: LM zig-zags between "rejected at lambda, accepted at 10 lambda" and runs of first-trial accepts).
+// When the host has seen the verdict and the prediction held, the spare set trades places with the current one by pointer; otherwise the
+// linearisation is launched the plain way.  (Both trial points in one launch were built first and measured: 4 600 waves do not fit the
+// 3 072 - 4 096 wave slots of the chip at this kernel's register count, the launch took as long as the two it replaced -- DESIGN.md section 8.)
+struct SpecLin {
+  double *J, *P, *H, *Hf;
+  int which;                 // trial whose point is linearised (0 / 1)
 };
 
 // kernel launches issued by the calling host thread (pps_stats::n_launches is the difference over a solve call)
@@ -196,6 +209,15 @@ hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int 
 hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
                              double seq1, hipStream_t st);
+// the same + K1 (lane form) at trial point sl.which into sl's buffers, one launch (k_trial_lin); ev0 / ev1: the dispatch's start / stop
+hipError_t launch_trial_lin(const DevGraph& d, const DualAlt& alt, const SpecLin& sl, const double* base_pose, const double* base_plane, double* out_pose0,
+                            double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
+                            double seq1, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+int trial_lin_waves(const DevGraph& d);               // waves of that launch
+bool trial_lin_ok(const DevGraph& d, int mode);      // the graph's K1 is the lane form over plain plane observations: k_trial_lin applies
+// K2 of the speculative linearisation: J / P of the spare set -> its H / Hf; guard (want = sl.which): the launch leaves early where the
+// trials' records say that another trial -- or none -- was accepted
+hipError_t launch_hblocks_spec(const DevGraph& d, const SpecLin& sl, hipStream_t st, const LinGuard* guard = nullptr);
 // ea_tgt (packed update matrix of a front -> packed index in its parent) expanded from cmap / f_cmap_off / f_ea_off
 hipError_t launch_expand_ea(const DevGraph& d, int n_fronts, double* zero, size_t n_zero, int* ones, size_t n_ones, hipStream_t st);   // + the upload's two fills
 // el_tgt / blk_dst (H block element <-> front-ordered H <-> packed front index) expanded from the per-block records;
@@ -261,7 +283,7 @@ struct BatchArgs {
   // dual form (alt != nullptr): grid z = 0 / 1 of the solve and trial kernels = lambda / lambda2, 12 result doubles per graph
   // ([0..3] chi2 at x, [4..7] trial for lambda, [8..11] trial for lambda2)
   const BatchAlt* alt;
-  int rstride, pad2;
+  int rstride, lin_apply;      // lin_apply: 0 (the lane-form sweep's run-time flag, see k_linearize_lanes)
   double lambda2[kBatchMax];
   unsigned char xsel[kBatchMax];
 };

@@ -145,6 +145,9 @@ struct pps_graph {
   double seq2 = 0.0;
   double *spec_L = nullptr, *spec_U = nullptr, *spec_delta = nullptr;
   double* spec_result = nullptr;   // result_dev of the speculative set: its own not-PD flag
+  // the spare set of J / P / H / Hf that the fused trial + linearisation launch writes (SpecLin, pps_device.h); when LM accepts the trial it was
+  // made for, the set trades places with dev.J / P / H / Hf by pointer.  Null where the dual LM loop does not apply (no band schedule).
+  double *spec_J = nullptr, *spec_P = nullptr, *spec_H = nullptr, *spec_Hf = nullptr;
   double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
   int snap_version = -1, upload_version = 0;
   int k2t_version = -1;              // upload_version the class lists of K2's throughput form (dev.k2t) were built for

@@ -69,11 +69,15 @@ static thread_local unsigned long long t_launches = 0;
 unsigned long long launch_count() { return t_launches; }
 void count_launch() { ++t_launches; }
 
+// apply: always 0 here, and a kernel ARGUMENT on purpose -- see body_linearize_lanes: the compiler must not know it, so that this kernel, the
+// batched one and the fused trial + linearisation launch (k_trial_lin, pps_k4.hip: apply = 1) all compile the same sweep
 __global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, const double* __restrict__ pose,
                                                                     const double* __restrict__ plane, int nb_obs, int nb_odo,
-                                                                    int nb_pp, LinGuard gd) {
+                                                                    int nb_pp, LinGuard gd, int apply) {
   if (!lin_guard(gd, pose, plane)) return;
-  body_linearize_lanes(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x);
+  // (one block of work per workgroup: a loop over several -- fewer, longer-lived workgroups -- was measured in round 6: the compiler hoists the
+  // sweep's invariants out of it, 291 registers and one wave per SIMD instead of 124 and four)
+  body_linearize_lanes(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x, apply != 0);
 }
 
 __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double* __restrict__ pose,
@@ -112,11 +116,11 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
     if (ev0 && ev1) {
       count_launch();
       hipExtLaunchKernelGGL(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, ev0, ev1, 0, d, pose, plane,
-                            lb_obs, lb_odo, lb_pp, gd);
+                            lb_obs, lb_odo, lb_pp, gd, 0);
       return hipGetLastError();
     }
     PPS_LAUNCH(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
-                       lb_obs, lb_odo, lb_pp, gd);
+                       lb_obs, lb_odo, lb_pp, gd, 0);
     return hipGetLastError();
   }
   if (ev0) { const hipError_t e = hipEventRecord(ev0, st); if (e != hipSuccess) return e; }      // (two launches: the pair goes around both)
@@ -200,7 +204,7 @@ void k_sweep_bench_obs_numeric(DevGraph d, double* __restrict__ Jbig, int nb_obs
 // the lane-parallel numeric form over the replicated edges (mode 2 of the sweep benchmark): PART 0 plane observations (19 lanes
 // each), PART 1 odometry edges (32 lanes each)
 template <int PART>
-__global__ __launch_bounds__(kLanesPerBlock) void k_sweep_bench_lanes(DevGraph d, double* __restrict__ Jbig, int lb_obs_per, int lb_odo_per) {
+__global__ __launch_bounds__(kLanesPerBlock) void k_sweep_bench_lanes(DevGraph d, double* __restrict__ Jbig, int lb_obs_per, int lb_odo_per, int apply) {
   const int per = PART == 0 ? lb_obs_per : lb_odo_per;
   const int rep = blockIdx.x / per;
   const int b = blockIdx.x % per + (PART == 0 ? 0 : lb_obs_per);
@@ -213,14 +217,14 @@ __global__ __launch_bounds__(kLanesPerBlock) void k_sweep_bench_lanes(DevGraph d
   r.odo_a = d.odo_a + (size_t)rep * d.n_odo; r.odo_b = d.odo_b + (size_t)rep * d.n_odo;
   r.n_obs_fixed = d.n_obs;
   r.obs_dir = nullptr; r.P = nullptr;
-  body_linearize_lanes(r, d.pose_lin, d.plane_lin, lb_obs_per, lb_odo_per, 0, b);
+  body_linearize_lanes(r, d.pose_lin, d.plane_lin, lb_obs_per, lb_odo_per, 0, b, apply != 0);
 }
 
 hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, int part, hipStream_t st) {
   if (mode == 2) {
     const int lb_obs = cdiv(d.n_obs, kObsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock);
-    if (lb_obs && part != 1) PPS_LAUNCH(k_sweep_bench_lanes<0>, dim3(lb_obs * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo);
-    if (lb_odo && part != 0) PPS_LAUNCH(k_sweep_bench_lanes<1>, dim3(lb_odo * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo);
+    if (lb_obs && part != 1) PPS_LAUNCH(k_sweep_bench_lanes<0>, dim3(lb_obs * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo, 0);
+    if (lb_odo && part != 0) PPS_LAUNCH(k_sweep_bench_lanes<1>, dim3(lb_odo * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo, 0);
     return hipGetLastError();
   }
   const int nb_obs = cdiv(d.n_obs, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock);
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(kLanesPerBlock) void kb_linearize_lanes(BatchArgs a
   const int nb_obs = dcdiv(d.n_obs_fixed, kObsPerBlock), nb_odo = dcdiv(d.n_odo, kFactorsPerBlock),
             nb_pp = dcdiv(d.n_pp, kFactorsPerBlock), nb_lp = dcdiv(d.n_lp, kFactorsPerBlock);
   if ((int)blockIdx.x >= nb_obs + nb_odo + nb_pp + nb_lp) return;
-  body_linearize_lanes(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x);
+  body_linearize_lanes(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, a.lin_apply != 0);      // (always 0: see k_linearize_lanes)
 }
 
 template <int MODE, int PART, bool DIRECT>

@@ -236,8 +236,37 @@ constexpr int kObsLanes = 19;                                         // evaluat
 constexpr int kObsPerWave = 64 / kObsLanes;                           // 3
 constexpr int kObsPerBlock = (kLanesPerBlock / 64) * kObsPerWave;     // 12
 
+// apply (round 6, the fused trial + linearisation launch; wave-uniform): the point of linearisation is pose / plane (+) d.delta, evaluated per
+// lane on the spot by the functions the retraction kernel uses (pose_exmap / plane_exmap: compiled without contraction, the same bits as the
+// copy that kernel stores) -- the sweep then needs no launch boundary behind the retraction.  A RUN-TIME flag, not a template parameter: every
+// kernel that sweeps in the lane form inlines the same source, so that the compiler contracts the same multiply-adds in all of them and a
+// factor's Jacobian has the same bits whichever launch produced it (a second instantiation was measured to differ in the 13th digit).
+__device__ __forceinline__ void state_pose(const DevGraph& d, const double* __restrict__ pose, int idx, bool apply, double o[7]) {
+  load_pose(pose, d.pose_ld, idx, o);
+  if (apply) {
+    double p[7], dl[6];
+#pragma unroll
+    for (int k = 0; k < 7; k++) p[k] = o[k];
+    const int off = d.pose_voff[idx];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dl[k] = d.delta[off + k];
+    pose_exmap(p, dl, o);
+  }
+}
+__device__ __forceinline__ void state_plane(const DevGraph& d, const double* __restrict__ plane, int idx, bool apply, double o[4]) {
+  load_plane(plane, d.plane_ld, idx, o);
+  if (apply) {
+    double p[4], dl[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = o[k];
+    const int off = d.plane_voff[idx];
+#pragma unroll
+    for (int k = 0; k < 3; k++) dl[k] = d.delta[off + k];
+    plane_exmap(p, dl, o);
+  }
+}
 __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const double* __restrict__ pose,
-                                                     const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx) {
+                                                     const double* __restrict__ plane, int nb_obs, int nb_odo, int nb_pp, int bx, bool apply = false) {
   const int grp = threadIdx.x / kLaneGroup, gl = threadIdx.x % kLaneGroup;
   const int q = gl >> 1;                       // perturbed column
   const double sgn = (gl & 1) ? -1.0 : 1.0;
@@ -250,8 +279,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     const int q3 = l3 > 0 ? (l3 - 1) >> 1 : 9;                    // perturbed column (9: none, the nominal residual)
     const double s3 = (l3 & 1) ? 1.0 : -1.0;                      // odd lane: + eps, the even lane after it: - eps
     double pz[7], pl[4], ms[4], w[6], e[3], y[3];
-    load_pose(pose, d.pose_ld, d.obs_pose[i], pz);
-    load_plane(plane, d.plane_ld, d.obs_plane[i], pl);
+    state_pose(d, pose, d.obs_pose[i], apply, pz);
+    state_plane(d, plane, d.obs_plane[i], apply, pl);
     load_soa<4>(d.obs_meas, d.obs_ld, i, ms);
     load_soa<6>(d.obs_w, d.obs_ld, i, w);
     {
@@ -329,8 +358,8 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     const int i = b * kFactorsPerBlock + grp;
     if (i >= d.n_odo) return;
     double p1[7], p2[7], ms[6], w[21], e[6], y[6];
-    load_pose(pose, d.pose_ld, d.odo_a[i], p1);
-    load_pose(pose, d.pose_ld, d.odo_b[i], p2);
+    state_pose(d, pose, d.odo_a[i], apply, p1);
+    state_pose(d, pose, d.odo_b[i], apply, p2);
     load_soa<6>(d.odo_meas, d.odo_ld, i, ms);
     load_soa<21>(d.odo_w, d.odo_ld, i, w);
     {
@@ -358,7 +387,7 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     const int i = b * kFactorsPerBlock + grp;
     if (i >= d.n_pp) return;
     double pz[7], ms[6], w[21], e[6], y[6];
-    load_pose(pose, d.pose_ld, d.pp_pose[i], pz);
+    state_pose(d, pose, d.pp_pose[i], apply, pz);
     load_soa<6>(d.pp_meas, d.pp_ld, i, ms);
     load_soa<21>(d.pp_w, d.pp_ld, i, w);
     { double pp[7]; perturb6(pz, q, sgn, d.step_ac, pp); res_pose_prior(pp, ms, e); }
@@ -380,7 +409,7 @@ __device__ __forceinline__ void body_linearize_lanes(const DevGraph& d, const do
     const int i = b * kFactorsPerBlock + grp;
     if (i >= d.n_lp) return;
     double pl[4], ms[4], w[6], e[3], y[3];
-    load_plane(plane, d.plane_ld, d.lp_plane[i], pl);
+    state_plane(d, plane, d.lp_plane[i], apply, pl);
     load_soa<4>(d.lp_meas, d.lp_ld, i, ms);
     load_soa<6>(d.lp_w, d.lp_ld, i, w);
     {

@@ -193,6 +193,13 @@ __global__ __launch_bounds__(64) void k_hfinish(DevGraph d, LinGuard gd) { if (!
 
 __global__ __launch_bounds__(64 * kK2Waves) void k_hblocks2(DevGraph d, LinGuard gd) { if (!lin_guard(gd)) return; body_hblocks2(d, blockIdx.x); }
 
+// K2 of the speculative linearisation (SpecLin): the launch above on the spare set's buffers
+hipError_t launch_hblocks_spec(const DevGraph& d_in, const SpecLin& sl, hipStream_t st, const LinGuard* guard) {
+  DevGraph d = d_in;
+  d.J = sl.J; d.P = sl.P; d.H = sl.H; d.Hf = sl.Hf;
+  return launch_hblocks(d, st, guard, true);
+}
+
 hipError_t launch_hblocks(const DevGraph& d_in, hipStream_t st, const LinGuard* guard, bool products) {
   const int nb = (d_in.n_k2_single + kK2Waves - 1) / kK2Waves + d_in.n_k2_multi;
   if (nb == 0) return hipSuccess;

@@ -3,8 +3,11 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "pps_geom.h"
 #include "pps_kcommon.h"
+#include "pps_k1_body.h"
 
 namespace pps {
 
@@ -95,30 +98,6 @@ __device__ __forceinline__ void chi2_finish(const DevGraph& d, int nb, int n_dn,
     // the sequence number goes last, with system-scope release: the host polls it instead of paying a stream sync
     __hip_atomic_store(&out[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-}
-
-// The state a residual is evaluated at: the stored copy, or (APPLY) base (+) delta computed on the spot -- the fused trial kernel
-// evaluates chi2 at x (+) delta without waiting for the retraction to be written (pose_exmap / plane_exmap are compiled without
-// contraction, pps_geom.h: the same bits as the stored copy).
-template <bool APPLY>
-__device__ __forceinline__ void fetch_pose(const DevGraph& d, const double* __restrict__ pose, int idx, double o[7]) {
-  if (!APPLY) { load_pose(pose, d.pose_ld, idx, o); return; }
-  double p[7], dl[6];
-  load_pose(pose, d.pose_ld, idx, p);
-  const int off = d.pose_voff[idx];
-#pragma unroll
-  for (int k = 0; k < 6; k++) dl[k] = d.delta[off + k];
-  pose_exmap(p, dl, o);
-}
-template <bool APPLY>
-__device__ __forceinline__ void fetch_plane(const DevGraph& d, const double* __restrict__ plane, int idx, double o[4]) {
-  if (!APPLY) { load_plane(plane, d.plane_ld, idx, o); return; }
-  double p[4], dl[3];
-  load_plane(plane, d.plane_ld, idx, p);
-  const int off = d.plane_voff[idx];
-#pragma unroll
-  for (int k = 0; k < 3; k++) dl[k] = d.delta[off + k];
-  plane_exmap(p, dl, o);
 }
 
 // bx: block within the graph, nb: blocks of the graph (TICKET: the one that draws the last ticket reduces)
@@ -294,6 +273,76 @@ hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double
   const int nb_ret = cdiv(n, 256);
   PPS_LAUNCH(k_trial_dual, dim3(nb_ret + nb, 2), dim3(kChiBlock), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1, nb_ret,
              nb_obs, nb_odo, nb_pp, nb, host_result0, seq0, host_result1, seq1);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the trials AND the next linearisation in one launch.  Grid y = trial (damping value); blocks [0, nb_ret + nb_chi) of a row are
+// k_trial_dual's -- retraction into the trial's copy of the state, chi2 at x (+) delta on the fly, ticket, result record --; row sl.which
+// has more blocks behind them: K1 in its lane form at that trial's point x (+) delta, also evaluated on the fly, writing Jacobians, product
+// records and direct H blocks into the spare set (SpecLin).  Nothing in the launch waits for anything else in it: the sweep that used to
+// start after the trial kernel had ended -- and after its verdict had been tested by a guard -- runs beside it.  Whether that linearisation
+// is the one LM wants the host decides from the records as before (Optimizer.cpp:425-458).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kChiBlock) void k_trial_lin(DevGraph d, DualAlt alt, SpecLin sl, const double* __restrict__ base_pose, const double* __restrict__ base_plane,
+                                                         double* __restrict__ out_pose, double* __restrict__ out_plane, double* __restrict__ out_pose1,
+                                                         double* __restrict__ out_plane1, int nb_ret, int nb_obs, int nb_odo, int nb_pp, int nb_chi,
+                                                         double* __restrict__ out, double seq, double* __restrict__ out1, double seq1, int lb_obs, int lb_odo, int lb_pp, int apply) {
+  static_assert(kChiBlock == kLanesPerBlock, "one block size for the trial blocks and the lane-form sweep");
+  // blocks [0, total) trial 0 | [total, 2 total) trial 1 | the rest: the sweep at trial sl.which's point
+  const int total = nb_ret + nb_chi;
+  const bool sweep = (int)blockIdx.x >= 2 * total;
+  const int y = sweep ? sl.which : ((int)blockIdx.x >= total ? 1 : 0);
+  const int bx0 = sweep ? (int)blockIdx.x - 2 * total : (int)blockIdx.x - y * total;
+  if (y) {
+    d.delta = alt.delta; d.chi2_partials = alt.chi2_partials; d.dn_partials = alt.dn_partials; d.ticket = alt.ticket; d.result_dev = alt.result_dev;
+    out_pose = out_pose1; out_plane = out_plane1; out = out1; seq = seq1;
+  }
+  if (sweep) {
+    d.J = sl.J; d.P = sl.P; d.H = sl.H; d.Hf = sl.Hf;
+    body_linearize_lanes(d, base_pose, base_plane, lb_obs, lb_odo, lb_pp, bx0, apply != 0);      // (1: see k_linearize_lanes)
+    return;
+  }
+  if (bx0 >= nb_ret) {
+    body_chi2<true, true>(d, base_pose, base_plane, nb_obs, nb_odo, nb_pp, nb_ret, out, seq, bx0 - nb_ret, nb_chi, total);
+    return;
+  }
+  __shared__ double red[4];
+  body_retract_to(d, base_pose, base_plane, out_pose, out_plane, bx0, red);
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicAdd(d.ticket, 1u) == (unsigned int)(total - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  chi2_finish(d, nb_chi, nb_ret, out, seq);
+  if (threadIdx.x == 0) *d.ticket = 0u;
+}
+
+int trial_lin_waves(const DevGraph& d) {
+  const int nb = cdiv(d.n_obs, kChiBlock) + cdiv(d.n_odo, kChiBlock) + cdiv(d.n_pp, kChiBlock) + cdiv(d.n_lp, kChiBlock) + cdiv(d.n_pose + d.n_plane, 256);
+  const int lb = cdiv(d.n_obs_fixed, kObsPerBlock) + cdiv(d.n_odo, kFactorsPerBlock) + cdiv(d.n_pp, kFactorsPerBlock) + cdiv(d.n_lp, kFactorsPerBlock);
+  return (2 * nb + lb) * (kChiBlock / 64);
+}
+bool trial_lin_ok(const DevGraph& d, int mode) { return k1_lane_form(d, mode) && d.n_obs == d.n_obs_fixed && d.P != nullptr; }
+
+hipError_t launch_trial_lin(const DevGraph& d, const DualAlt& alt, const SpecLin& sl, const double* base_pose, const double* base_plane, double* out_pose0,
+                            double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
+                            double seq1, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  const int n = d.n_pose + d.n_plane;
+  const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock), nb_lp = cdiv(d.n_lp, kChiBlock);
+  const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
+  if (nb == 0 || n == 0) return hipErrorInvalidValue;
+  const int nb_ret = cdiv(n, 256);
+  const int lb_obs = cdiv(d.n_obs_fixed, kObsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock), lb_pp = cdiv(d.n_pp, kFactorsPerBlock),
+            lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
+  const int lb_all = lb_obs + lb_odo + lb_pp + lb_lp;
+  PPS_LAUNCH_EV(ev0, ev1, k_trial_lin, dim3(2 * (nb_ret + nb) + lb_all), dim3(kChiBlock), 0, st, d, alt, sl, base_pose, base_plane, out_pose0,
+                out_plane0, out_pose1, out_plane1, nb_ret, nb_obs, nb_odo, nb_pp, nb, host_result0, seq0, host_result1, seq1, lb_obs, lb_odo, lb_pp, 1);
   return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pps_device.h"
+#include "pps_geom.h"
 
 namespace pps {
 
@@ -42,6 +43,30 @@ __device__ __forceinline__ void load_soa(const double* __restrict__ base, int ld
   for (int k = 0; k < K; k++) o[k] = base[(size_t)k * ld + i];
 }
 
+// The state a residual is evaluated at: the stored copy, or (APPLY) base (+) delta computed on the spot -- the fused trial kernel
+// evaluates chi2 at x (+) delta without waiting for the retraction to be written (pose_exmap / plane_exmap are compiled without
+// contraction, pps_geom.h: the same bits as the stored copy).
+template <bool APPLY>
+__device__ __forceinline__ void fetch_pose(const DevGraph& d, const double* __restrict__ pose, int idx, double o[7]) {
+  if (!APPLY) { load_pose(pose, d.pose_ld, idx, o); return; }
+  double p[7], dl[6];
+  load_pose(pose, d.pose_ld, idx, p);
+  const int off = d.pose_voff[idx];
+#pragma unroll
+  for (int k = 0; k < 6; k++) dl[k] = d.delta[off + k];
+  pose_exmap(p, dl, o);
+}
+template <bool APPLY>
+__device__ __forceinline__ void fetch_plane(const DevGraph& d, const double* __restrict__ plane, int idx, double o[4]) {
+  if (!APPLY) { load_plane(plane, d.plane_ld, idx, o); return; }
+  double p[4], dl[3];
+  load_plane(plane, d.plane_ld, idx, p);
+  const int off = d.plane_voff[idx];
+#pragma unroll
+  for (int k = 0; k < 3; k++) dl[k] = d.delta[off + k];
+  plane_exmap(p, dl, o);
+}
+
 // LinGuard (pps_device.h): which state does a speculatively queued K1 linearise at?  false = neither trial was accepted
 __device__ __forceinline__ bool lin_guard(const LinGuard& gd, const double* __restrict__& pose, const double* __restrict__& plane) {
   if (!gd.on) return true;
@@ -52,7 +77,8 @@ __device__ __forceinline__ bool lin_guard(const LinGuard& gd, const double* __re
 }
 __device__ __forceinline__ bool lin_guard(const LinGuard& gd) {
   if (!gd.on) return true;
-  return gd.error - *gd.chi[0] > 0. || (!gd.single && gd.error - *gd.chi[1] > 0.);
+  const bool a0 = gd.error - *gd.chi[0] > 0., a1 = !a0 && !gd.single && gd.error - *gd.chi[1] > 0.;
+  return gd.want < 0 ? (a0 || a1) : (gd.want == 0 ? a0 : a1);
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -320,6 +320,36 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   const bool adaptive = A.n_fronts >= 2048;
   bool use_alt = !adaptive;
   bool have_next = true;                 // trial 1 of the last launch is the step for the next lambda after a rejection
+  // Round 6: the linearisation at the trial point LM is expected to accept rides in the trial launch, and K2 follows at once (SpecLin,
+  // pps_device.h): when the host has seen the verdict and the prediction held, that point's J / H exist and become the current ones by
+  // pointer; a wrong prediction launches the linearisation the plain way.  Graphs whose K1 is not the lane form over plain plane
+  // observations keep the linearisation queued behind a device-side guard (LinGuard).
+  // ... as do graphs whose sweep does not fit the chip's wave slots beside the trial blocks (k_trial_lin holds three waves per SIMD: 3 072
+  // slots; C2 needs 2 700): a second round of waves costs more than the launch boundary saved (C3, same box: 384 against 365 us per iteration).
+  const bool fuse_lin = !g->sw.no_spec_lin && g->spec_J != nullptr && trial_lin_ok(d, prop.jacobian_mode) && trial_lin_waves(d) <= 3072;
+  int fused_pair = -1;                   // K1 event pair of the last fused launch (profiling level 1)
+  int pred = 0, pred_launched = 0;       // the trial predicted to be accepted: the one that was accepted last | the one the last launch linearised
+  // trials + the predicted linearisation + its H blocks: what ends every launch set in this mode
+  bool error_known = false;              // `error` holds chi2 at the linearisation point (not yet while the first launch set is queued)
+  double error = 0.0;
+  auto enqueue_trial_lin = [&](const DualAlt& alt, double s0, double s1) -> int {
+    pred_launched = use_alt ? pred : 0;
+    const SpecLin sl{g->spec_J, g->spec_P, g->spec_H, g->spec_Hf, pred_launched};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    fused_pair = -1;
+    if (g->profiling == 1) {
+      if (g->k1_used + 2 > (int)g->k1_events.size()) for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->k1_events.push_back(e); }
+      g->k1_skip.resize(g->k1_events.size() / 2, 0);
+      fused_pair = g->k1_used / 2;
+      g->k1_skip[fused_pair] = 1;          // (counted once the predicted trial is accepted: its sweep was a linearisation the solve asked for)
+      e0 = g->k1_events[g->k1_used]; e1 = g->k1_events[g->k1_used + 1]; g->k1_used += 2;
+    }
+    HIP_TRY(g, launch_trial_lin(d, alt, sl, d.pose_lin, d.plane_lin, t_pose[0], t_plane[0], t_pose[1], t_plane[1], slot[0], s0, slot[1], s1, g->stream, e0, e1));
+    // (K2 of that linearisation leaves at once where the records say the prediction failed: 2 us instead of 7 in front of the plain sweep)
+    const LinGuard gd{{d.result_dev, g->spec_result}, {nullptr, nullptr}, {nullptr, nullptr}, error, error_known ? 1 : 0, use_alt ? 0 : 1, pred_launched};
+    HIP_TRY(g, launch_hblocks_spec(d, sl, g->stream, &gd));
+    return PPS_OK;
+  };
   auto enqueue_dual = [&](double lam) -> int {
     DualAlt alt{g->spec_L, g->spec_U, g->spec_delta, g->spec_result, g->spec_chi2_partials, g->spec_dn_partials, g->spec_ticket,
                 lam * prop.lm_lambda_factor};
@@ -331,6 +361,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
       g->stats.n_factorize += 1;
       g->seq += 1.0; seqs[0] = g->seq;
       g->seq2 += 1.0; seqs[1] = g->seq2;
+      if (fuse_lin) return enqueue_trial_lin(alt, seqs[0], seqs[1]);
       HIP_TRY(g, launch_trial_dual(d, alt, d.pose_lin, d.plane_lin, t_pose[0], t_plane[0], t_pose[1], t_plane[1], slot[0], seqs[0], slot[1], seqs[1],
                                    g->stream));
       return PPS_OK;
@@ -339,6 +370,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
     g->stats.n_factorize += 2;
     g->seq += 1.0; seqs[0] = g->seq;
     g->seq2 += 1.0; seqs[1] = g->seq2;
+    if (fuse_lin) return enqueue_trial_lin(alt, seqs[0], seqs[1]);
     HIP_TRY(g, launch_trial_dual(d, alt, d.pose_lin, d.plane_lin, t_pose[0], t_plane[0], t_pose[1], t_plane[1], slot[0], seqs[0], slot[1], seqs[1],
                                  g->stream));
     return PPS_OK;
@@ -350,7 +382,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   // Accept-branch speculation: the relinearisation that follows an accepted step is queued behind the trials before their
   // verdict is known; its kernels apply the accept test themselves (LinGuard) and pick the accepted copy, so the device does
   // not idle for the host round trip between chi2 and K1.
-  const bool spec_lin = !g->sw.no_spec_lin;
+  const bool spec_lin = !g->sw.no_spec_lin && !fuse_lin;
   int spec_pair = -1;                    // K1 event pair of the queued speculative linearisation
   auto enqueue_spec_lin = [&](double err) -> int {
     if (!spec_lin) return PPS_OK;
@@ -361,7 +393,7 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   auto drop_spec_lin = [&]() { if (spec_pair >= 0 && (size_t)spec_pair < g->k1_skip.size()) g->k1_skip[spec_pair] = 1; spec_pair = -1; };
   rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;
   rc = wait_result(g, slot0, seq0); if (rc != PPS_OK) return rc;
-  double error = slot0[0];
+  error = slot0[0]; error_known = true;
   g->stats.chi2_initial = error;
   rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;
   rc = wait_result(g, slot[0], seqs[0]); if (rc != PPS_OK) return rc;
@@ -383,9 +415,16 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
       lambda /= prop.lm_lambda_factor;
       error = error_new;
       if (adaptive) use_alt = cur != 0;                           // (accepted at once: no speculation next time; after a rejection: keep it)
+      pred = cur;
       // the accepted copy becomes the linearisation point; the old one is the spare now
       std::swap(d.pose_lin, t_pose[cur]); std::swap(d.plane_lin, t_plane[cur]);
-      if (spec_lin) { g->stats.n_linearize++; spec_pair = -1; }    // relinearise (:444): queued already, at this very copy
+      if (fuse_lin && cur == pred_launched) {                      // relinearise (:444): done beside the trials, at this very point
+        std::swap(d.J, g->spec_J); std::swap(d.P, g->spec_P); std::swap(d.H, g->spec_H); std::swap(d.Hf, g->spec_Hf);
+        g->stats.n_linearize++;
+        if (fused_pair >= 0 && (size_t)fused_pair < g->k1_skip.size()) g->k1_skip[fused_pair] = 0;
+      }
+      else if (fuse_lin) { rc = do_linearize(g); if (rc != PPS_OK) return rc; }      // (the other trial was accepted: the plain way)
+      else if (spec_lin) { g->stats.n_linearize++; spec_pair = -1; }    // ... queued already, at this very copy
       else { rc = do_linearize(g); if (rc != PPS_OK) return rc; }
       rc = enqueue_dual(lambda); if (rc != PPS_OK) return rc;      // (:458)
       rc = enqueue_spec_lin(error); if (rc != PPS_OK) return rc;

@@ -561,6 +561,7 @@ int upload_all(pps_graph* g) {
   free_device(g);
   g->spec_L = g->spec_U = g->spec_delta = nullptr; g->spec_result = nullptr;
   g->spec_pose = g->spec_plane = g->spec_chi2_partials = g->spec_dn_partials = nullptr; g->spec_ticket = nullptr;
+  g->spec_J = g->spec_P = g->spec_H = g->spec_Hf = nullptr;
   g->d_item_frame = g->d_item_plane = g->d_item_slot = g->d_frame_pose_slot = g->d_frame_seg_off = nullptr; g->d_fr_seg = nullptr;
   g->frames_dirty = true;
   g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
@@ -722,6 +723,10 @@ int upload_all(pps_graph* g) {
   TRY(dev_upload(g, &d.f_ea_off, A.f_ea_off, kF ? kF + 1 : 0)); TRY(dev_alloc(g, &d.ea_tgt, (size_t)std::max<int64_t>(1, A.ea_total)));   // filled by k_expand_ea below
   TRY(dev_upload(g, &d.blk_doff, A.blk_doff, kB ? kB + 1 : 0)); TRY(dev_alloc(g, &d.blk_dst, (size_t)std::max(1, A.blk_doff[A.n_blocks])));
   TRY(dev_alloc(g, &d.Hf, (size_t)A.el_total));
+  if (g->use_band && !g->sw.no_spec_lin) {                        // the spare set of the fused trial + linearisation launch (lm_solve_dual)
+    TRY(dev_alloc(g, &g->spec_J, (size_t)A.J_size)); TRY(dev_alloc(g, &g->spec_P, (size_t)std::max<int64_t>(1, A.P_size)));
+    TRY(dev_alloc(g, &g->spec_H, (size_t)A.H_size)); TRY(dev_alloc(g, &g->spec_Hf, (size_t)A.el_total));
+  }
   TRY(dev_upload(g, &d.grp_lvl_off, A.grp_lvl_off)); TRY(dev_upload(g, &d.glvl_front_off, A.glvl_front_off));
   {
     // per group, one 32-byte record: first position, fronts, local levels, first position of local levels 1 .. 4 (the last one
