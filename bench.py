@@ -34,7 +34,7 @@ B_ODO_EDGE = 840     # 216 B read + 624 B written per odometry edge
 HBM_PEAK_GBS = 8000.0
 
 
-K1_SOURCES = ("pps_k1.hip", "pps_k1_body.h", "pps_lin.h", "pps_geom.h")
+K1_SOURCES = ("pps_k1.hip", "pps_k1_lanes.hip", "pps_k1_body.h", "pps_lin.h", "pps_geom.h")
 
 
 def k1_source_hash():

@@ -10,6 +10,11 @@
 
 namespace pps {
 
+// the lane form lives in pps_k1_lanes.hip (compiled WITHOUT multiply-add contraction: see there)
+hipError_t launch_linearize_lanes(const DevGraph& d, const double* pose, const double* plane, const LinGuard& gd, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+hipError_t launch_sweep_bench_lanes(const DevGraph& d, int replicas, double* Jbig, int part, hipStream_t st);
+hipError_t launch_batch_linearize_lanes(const BatchArgs& a, const BatchGeom& g, hipStream_t st);
+
 constexpr int kObsNumericWaves = 2;      // waves per SIMD of the numeric plane-observation launch of the thread form (see k_linearize_obs_numeric)
 
 template <int MODE, int PART>
@@ -69,17 +74,6 @@ static thread_local unsigned long long t_launches = 0;
 unsigned long long launch_count() { return t_launches; }
 void count_launch() { ++t_launches; }
 
-// apply: always 0 here, and a kernel ARGUMENT on purpose -- see body_linearize_lanes: the compiler must not know it, so that this kernel, the
-// batched one and the fused trial + linearisation launch (k_trial_lin, pps_k4.hip: apply = 1) all compile the same sweep
-__global__ __launch_bounds__(kLanesPerBlock) void k_linearize_lanes(DevGraph d, const double* __restrict__ pose,
-                                                                    const double* __restrict__ plane, int nb_obs, int nb_odo,
-                                                                    int nb_pp, LinGuard gd, int apply) {
-  if (!lin_guard(gd, pose, plane)) return;
-  // (one block of work per workgroup: a loop over several -- fewer, longer-lived workgroups -- was measured in round 6: the compiler hoists the
-  // sweep's invariants out of it, 291 registers and one wave per SIMD instead of 124 and four)
-  body_linearize_lanes(d, pose, plane, nb_obs, nb_odo, nb_pp, blockIdx.x, apply != 0);
-}
-
 __global__ __launch_bounds__(64) void k_linearize_repop(DevGraph d, const double* __restrict__ pose,
                                                         const double* __restrict__ plane, LinGuard gd) {
   __shared__ double repop_lds[64 * 31];
@@ -110,19 +104,7 @@ hipError_t launch_linearize(const DevGraph& d, int mode, bool at_estimate, hipSt
   if (nb == 0) return hipSuccess;
   const double* pose = at_estimate ? d.pose_est : d.pose_lin;
   const double* plane = at_estimate ? d.plane_est : d.plane_lin;
-  if (k1_lane_form(d, mode)) {
-    const int lb_obs = cdiv(d.n_obs_fixed, kObsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock),
-              lb_pp = cdiv(d.n_pp, kFactorsPerBlock), lb_lp = cdiv(d.n_lp, kFactorsPerBlock);
-    if (ev0 && ev1) {
-      count_launch();
-      hipExtLaunchKernelGGL(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, ev0, ev1, 0, d, pose, plane,
-                            lb_obs, lb_odo, lb_pp, gd, 0);
-      return hipGetLastError();
-    }
-    PPS_LAUNCH(k_linearize_lanes, dim3(lb_obs + lb_odo + lb_pp + lb_lp), dim3(kLanesPerBlock), 0, st, d, pose, plane,
-                       lb_obs, lb_odo, lb_pp, gd, 0);
-    return hipGetLastError();
-  }
+  if (k1_lane_form(d, mode)) return launch_linearize_lanes(d, pose, plane, gd, st, ev0, ev1);
   if (ev0) { const hipError_t e = hipEventRecord(ev0, st); if (e != hipSuccess) return e; }      // (two launches: the pair goes around both)
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   const int nb_rest = nb - nb_obs;
@@ -201,32 +183,8 @@ void k_sweep_bench_obs_numeric(DevGraph d, double* __restrict__ Jbig, int nb_obs
   body_sweep_bench<0, 0>(d, Jbig, nb_obs_per, nb_odo_per, replicas);
 }
 
-// the lane-parallel numeric form over the replicated edges (mode 2 of the sweep benchmark): PART 0 plane observations (19 lanes
-// each), PART 1 odometry edges (32 lanes each)
-template <int PART>
-__global__ __launch_bounds__(kLanesPerBlock) void k_sweep_bench_lanes(DevGraph d, double* __restrict__ Jbig, int lb_obs_per, int lb_odo_per, int apply) {
-  const int per = PART == 0 ? lb_obs_per : lb_odo_per;
-  const int rep = blockIdx.x / per;
-  const int b = blockIdx.x % per + (PART == 0 ? 0 : lb_obs_per);
-  const size_t slab = (size_t)d.n_obs * 30 + (size_t)d.n_odo * 78;
-  DevGraph r = d;                       // replica `rep` reads shifted copies of the edge arrays and writes its own J slab
-  r.J = Jbig + (size_t)rep * slab; r.joff_obs = 0; r.joff_odo = (int64_t)d.n_obs * 30;
-  r.obs_meas = d.obs_meas + (size_t)rep * 4 * d.obs_ld; r.obs_w = d.obs_w + (size_t)rep * 6 * d.obs_ld;
-  r.obs_pose = d.obs_pose + (size_t)rep * d.n_obs; r.obs_plane = d.obs_plane + (size_t)rep * d.n_obs;
-  r.odo_meas = d.odo_meas + (size_t)rep * 6 * d.odo_ld; r.odo_w = d.odo_w + (size_t)rep * 21 * d.odo_ld;
-  r.odo_a = d.odo_a + (size_t)rep * d.n_odo; r.odo_b = d.odo_b + (size_t)rep * d.n_odo;
-  r.n_obs_fixed = d.n_obs;
-  r.obs_dir = nullptr; r.P = nullptr;
-  body_linearize_lanes(r, d.pose_lin, d.plane_lin, lb_obs_per, lb_odo_per, 0, b, apply != 0);
-}
-
 hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double* Jbig, int part, hipStream_t st) {
-  if (mode == 2) {
-    const int lb_obs = cdiv(d.n_obs, kObsPerBlock), lb_odo = cdiv(d.n_odo, kFactorsPerBlock);
-    if (lb_obs && part != 1) PPS_LAUNCH(k_sweep_bench_lanes<0>, dim3(lb_obs * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo, 0);
-    if (lb_odo && part != 0) PPS_LAUNCH(k_sweep_bench_lanes<1>, dim3(lb_odo * replicas), dim3(kLanesPerBlock), 0, st, d, Jbig, lb_obs, lb_odo, 0);
-    return hipGetLastError();
-  }
+  if (mode == 2) return launch_sweep_bench_lanes(d, replicas, Jbig, part, st);
   const int nb_obs = cdiv(d.n_obs, kLinBlock), nb_odo = cdiv(d.n_odo, kLinBlock);
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   if (nb_obs + nb_odo == 0) return hipSuccess;
@@ -241,14 +199,6 @@ hipError_t launch_sweep_bench(const DevGraph& d, int mode, int replicas, double*
 }
 
 // ---- batched forms ----
-__global__ __launch_bounds__(kLanesPerBlock) void kb_linearize_lanes(BatchArgs a) {
-  PPS_BATCH_PROLOGUE(BF_ACTIVE | BF_RELIN)
-  const int nb_obs = dcdiv(d.n_obs_fixed, kObsPerBlock), nb_odo = dcdiv(d.n_odo, kFactorsPerBlock),
-            nb_pp = dcdiv(d.n_pp, kFactorsPerBlock), nb_lp = dcdiv(d.n_lp, kFactorsPerBlock);
-  if ((int)blockIdx.x >= nb_obs + nb_odo + nb_pp + nb_lp) return;
-  body_linearize_lanes(d, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, blockIdx.x, a.lin_apply != 0);      // (always 0: see k_linearize_lanes)
-}
-
 template <int MODE, int PART, bool DIRECT>
 __global__ __launch_bounds__(kLinBlock) void kb_linearize(BatchArgs a) {
   extern __shared__ double lin_lds[];
@@ -272,7 +222,7 @@ hipError_t launch_batch_linearize(const BatchArgs& a, const BatchGeom& g, int mo
   if (g.repop_blocks > 0) PPS_LAUNCH(kb_linearize_repop, dim3(g.repop_blocks, a.n), dim3(64), 0, st, a);
   const size_t lds0 = (size_t)(kLinBlock / 64) * 64 * 31 * sizeof(double), lds1 = (size_t)(kLinBlock / 64) * 64 * 79 * sizeof(double);
   if (mode == 0) {
-    if (g.lin_blocks > 0) PPS_LAUNCH(kb_linearize_lanes, dim3(g.lin_blocks, a.n), dim3(kLanesPerBlock), 0, st, a);
+    if (g.lin_blocks > 0) { const hipError_t e = launch_batch_linearize_lanes(a, g, st); if (e != hipSuccess) return e; }
   } else if (mode == 2) {          // numeric, one thread per factor
     if (g.lin_obs_blocks > 0) {
       PPS_LAUNCH((kb_linearize<0, 0, true>), dim3(g.lin_obs_blocks, a.n), dim3(kLinBlock), lds0, st, a);

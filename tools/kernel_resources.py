@@ -19,7 +19,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pop_up_slam_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-SOLVER = {"pps_k1.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip", "pps_dense.hip"}
+SOLVER = {"pps_k1.hip", "pps_k2.hip", "pps_k3.hip", "pps_dense.hip"}      # (built with contraction; pps_k1_lanes.hip / pps_k4.hip without)
 
 
 def resources(src, extra, built=False):
@@ -86,7 +86,7 @@ TABLE_BEGIN, TABLE_END = "<!-- kernel-table:begin (tools/kernel_resources.py --u
 def built_table():
     """{name: dict} of every kernel of the solver objects the Makefile built"""
     out = {}
-    for f in ("pps_k1.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip"):
+    for f in ("pps_k1.hip", "pps_k1_lanes.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip"):
         for r in resources(os.path.join(CSRC, f), [], built=True):
             v = int(r["vgpr_count"])
             out[short_name(r["name"])] = {"vgpr": v, "agpr": int(r["agpr_count"]), "waves": min(8, 512 // max(8, (v + 7) // 8 * 8)),
@@ -126,7 +126,7 @@ def update_design():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("files", nargs="*", default=["pps_k1.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip"])
+    ap.add_argument("files", nargs="*", default=["pps_k1.hip", "pps_k1_lanes.hip", "pps_k2.hip", "pps_k3.hip", "pps_k4.hip"])
     ap.add_argument("--filter", default="")
     ap.add_argument("--flags", default="")
     ap.add_argument("--built", action="store_true", help="read the objects under csrc/build instead of compiling")
