@@ -71,6 +71,7 @@ struct DevGraph {
   int* grp_span = nullptr;          // per band group, 8 ints: first position in glvl order, fronts, local levels, first position of local levels 1 .. 4, 0
   int *frec = nullptr, *crec = nullptr, *srec = nullptr;   // packed metadata records (pps_symbolic.h)
   int* obs_dir = nullptr;                                   // direct (pose, plane) blocks: 3 ints per plane-observation slot (pps_symbolic.h)
+  int* k3_flag = nullptr;                                   // hand-over flags between workgroups of the whole-tree launches (XGroup, pps_k3.hip): 4 x n_fronts ints
   int* nd_segs = nullptr; int n_nd_segs = 0;                // H segments that are not direct
   // K2 work lists (round 4): the non-direct segments of single-segment blocks (one wave each) and, per block of several
   // segments, its first segment (one workgroup each: the partial sums meet in LDS)
@@ -193,6 +194,11 @@ struct DualAlt {
   unsigned int* ticket;
   double lambda;
 };
+// the whole tree in one factor launch + one back-substitution launch (k_band_factor_all / k_band_solve_all: hand-over between workgroups through
+// DevGraph::k3_flag); epoch: the number of this launch pair (> 0, growing)
+hipError_t launch_band_all(const DevGraph& d, const DualAlt* alt, int n_groups, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,
+                           int max_group_fronts, double lambda, int epoch, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+int band_all_solve_waves(int max_panel, int max_group_fronts);
 // pre: every group of the stage has the shape the pre-assembling walk needs (k_band_factor_pre)
 hipError_t launch_band_factor(const DevGraph& d, int grp_begin, int grp_count, int nwaves, int max_front, double lambda, hipStream_t st,
                               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool pre = false);

@@ -148,6 +148,10 @@ struct pps_graph {
   // the spare set of J / P / H / Hf that the fused trial + linearisation launch writes (SpecLin, pps_device.h); when LM accepts the trial it was
   // made for, the set trades places with dev.J / P / H / Hf by pointer.  Null where the dual LM loop does not apply (no band schedule).
   double *spec_J = nullptr, *spec_P = nullptr, *spec_H = nullptr, *spec_Hf = nullptr;
+  // the whole tree in one factor launch + one back-substitution launch (run_analysis decides; launch_band_all): maxima over the stages, and the
+  // number of the last launch pair (its hand-over flags carry it: DevGraph::k3_flag)
+  bool k3_all = false;
+  int k3_nw_factor = 0, k3_nw_solve = 0, k3_max_front = 0, k3_max_panel = 0, k3_max_grp = 0, k3_epoch = 0;
   double *snap_pose = nullptr, *snap_plane = nullptr;   // pps_save_state
   int snap_version = -1, upload_version = 0;
   int k2t_version = -1;              // upload_version the class lists of K2's throughput form (dev.k2t) were built for

@@ -524,7 +524,29 @@ __device__ __forceinline__ void front_pre_finish(const DevGraph& d, int rec, int
 }
 // extend-add of the children's packed update matrices, child by child, one batch of 512 entries in flight (more loads in
 // flight -- both children at once, two batches per child -- measured SLOWER on MI355X: DESIGN.md section 8)
-__device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int crv0, int lane, double* __restrict__ F, int tr) {
+// Hand-over between WORKGROUPS of one launch (round 6: the whole tree in one factor launch and one back-substitution launch, XG = true
+// below).  A flag per front in global memory carries the number of the launch pair (the epoch: never reset).  Producer: the wave's stores,
+// an agent-scope release (on this chip: the wave's stores acknowledged + the XCD's L2 written back), the flag.  Consumer: polls the flag,
+// agent-scope acquire, then reads.  A workgroup only ever waits for workgroups with a LOWER block index -- children in the factor launch,
+// parents in the back-substitution launch, whose groups are numbered the other way round -- and the hardware starts workgroups in index
+// order: whatever a waiting workgroup waits for has been started and waits, if at all, for still lower indices.  No cycle, no dependence on
+// how many workgroups are resident, or on what else shares the device.  The spin is bounded like flow_wait's.
+struct XGroup { int* flag; int epoch; };          // flag: one int per front (of this damping value); epoch 0 / flag null: off
+__device__ __forceinline__ void xg_post(const XGroup& x, int s) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(x.flag + s, x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xg_wait(const DevGraph& d, const XGroup& x, int s) {
+  int spin = 0;
+  while (__hip_atomic_load(x.flag + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != x.epoch) {
+    if (++spin >= (1 << 21)) { if ((threadIdx.x & 63) == 0) raise_status(&d.result_dev[2], kStatusInternal); break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// XG: a child that another workgroup of this launch factors (child record slot 6) is waited for first (xg_wait)
+template <bool XG = false>
+__device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int crv0, int lane, double* __restrict__ F, int tr, const XGroup* xg = nullptr) {
   const int cr0 = __builtin_amdgcn_readlane(rec, 5), nch = __builtin_amdgcn_readlane(rec, 6);
   for (int cb = 0; cb < nch; cb += 8) {
     const int crv = cb == 0 ? crv0 : ((lane < 8 * (nch - cb)) ? d.crec[(size_t)(cr0 + cb) * 8 + lane] : 0);      // (more than 8 children: rare)
@@ -538,6 +560,7 @@ __device__ __forceinline__ void front_extend_add(const DevGraph& d, int rec, int
     for (; cj < 8 && cb + cj < nch; cj++) {
       int n; const double* Uc; const int* tgc;
       child(cj, n, Uc, tgc);
+      if (XG) { if (__builtin_amdgcn_readlane(crv, 8 * cj + 6)) xg_wait(d, *xg, __builtin_amdgcn_readlane(crv, 8 * cj + 5)); }
       // batches of kEaDepth x 64 = 640 entries: the update matrix of a separator front of a corridor tree (34 rows + rhs: 595
       // entries) is one memory round trip, not a full batch of 512 followed by a nearly empty one
       for (int e = 0; e < n; e += 64 * kEaDepth) { ElBatch<kEaDepth> q; el_issue(tgc, Uc, e, n, lane, q); __builtin_amdgcn_wave_barrier(); el_apply<false>(q, 0.0, F, tr); }
@@ -657,8 +680,10 @@ __device__ __forceinline__ void solve_pivot_chain(int p, double (&lk)[16], doubl
 // flow (band groups, body_band_solve_flow): every front of the group has been started at once; flow[q] != 0 <=> the local solution of the
 // group's front q is in X.  The front does everything that does not need its parent's solution, waits for the parent's flag right where
 // the boundary values are read, and raises its own flag behind its solution.
-template <bool GROUP = true, bool TR = false>
-__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot, int* flow = nullptr) {
+// XG (with flow): the launch holds every band group (k_band_solve_all) -- a group's top front waits for its parent's flag before it gathers its
+// boundary values from delta, and every front with children raises its own flag behind its solution
+template <bool GROUP = true, bool TR = false, bool XG = false>
+__device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, double* __restrict__ W, double* __restrict__ X, int slot, int* flow = nullptr, const XGroup* xg = nullptr) {
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readlane(rec, 0);
   (void)s;
@@ -699,11 +724,15 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     const double dg = Lp[lc * p + lc], yr = Lp[f * p + jc];
     const int ix0 = lane < b ? ix0r : 0, ix1 = lane + 64 < b ? ix1r : 0;
     double g0 = 0.0, g1 = 0.0;
-    if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }
+    const int xpar = XG ? __builtin_amdgcn_readlane(rec, 13) : -1;         // the parent's front when another workgroup of this launch solves it
+    if (pslot < 0 && xpar < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }
     if (flow) { dinv = 1.0 / dg; solve_pivot_scale(lk, dinv); }       // (all that can be done without the parent, before waiting for it)
     if (pslot >= 0) {
       if (flow) flow_wait(d, flow, pslot);
       const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows; g0 = Xp[ix0]; g1 = Xp[ix1];
+    } else if (XG && xpar >= 0) {
+      xg_wait(d, *xg, xpar);
+      g0 = d.delta[ix0]; g1 = d.delta[ix1];
     }
     if (TR) PPS_TR(1);
     if (lane < b) xb[lane] = g0;
@@ -735,6 +764,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     if (lane < b) Xs[p + lane] = g0;
     if (lane + 64 < b) Xs[p + lane + 64] = g1;
     if (flow) flow_post(d, flow, slot, pslot < 0);                       // (behind the solution)
+    if (XG) { if (__builtin_amdgcn_readlane(rec, 6) > 0) xg_post(*xg, s); }
     return;
   }
   // first batch of the panel (all of it for n <= 1024) issued right behind the index loads: the gather from delta below then waits
@@ -744,7 +774,8 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; v[u] = Lp[e < n ? e : n - 1]; }
   const int ix0 = lane < b ? ix0r : 0, ix1 = lane + 64 < b ? ix1r : 0;
   double g0 = 0.0, g1 = 0.0;
-  if (pslot < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }          // clamped index 0 when out of range: harmless
+  const int xpar = XG ? __builtin_amdgcn_readlane(rec, 13) : -1;
+  if (pslot < 0 && xpar < 0) { g0 = d.delta[ix0]; g1 = d.delta[ix1]; }          // clamped index 0 when out of range: harmless
   // (entries past the end of the panel land in xb[127], which no front uses: b <= 126 -- unpredicated LDS writes)
 #pragma unroll
   for (int u = 0; u < 16; u++) { const int e = 64 * u + lane; PL[e < n ? e : -1] = v[u]; }
@@ -787,6 +818,9 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
     if (flow) flow_wait(d, flow, pslot);
     const double* __restrict__ Xp = X + (size_t)pslot * kBandMaxRows;
     g0 = Xp[ix0]; g1 = Xp[ix1];
+  } else if (XG && xpar >= 0) {
+    xg_wait(d, *xg, xpar);
+    g0 = d.delta[ix0]; g1 = d.delta[ix1];
   }
   if (lane < b) xb[lane] = g0;
   if (lane + 64 < b) xb[lane + 64] = g1;
@@ -856,6 +890,7 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
   if (lane < b) Xs[p + lane] = g0;
   if (lane + 64 < b) Xs[p + lane + 64] = g1;
   if (flow) flow_post(d, flow, slot, pslot < 0);
+  if (XG) { if (__builtin_amdgcn_readlane(rec, 6) > 0) xg_post(*xg, s); }
 }
 
 // The back-substitution of a band group as a data flow: the group's fronts, top level first, are dealt to the waves round-robin and
@@ -864,8 +899,8 @@ __device__ __forceinline__ void wave_front_solve(const DevGraph& d, int rec, dou
 // the gather of the boundary values, y - L_B^T x_b and the pivot chain; a level no longer costs the memory round trips of its panels,
 // and no workgroup barrier holds the fast fronts of a level back.  Same arithmetic as body_band_solve, same bits.
 // mg: solution slots behind the waves' scratch (fronts of the largest group of the stage); the flags sit behind them.
-template <bool TR = false>
-__device__ __forceinline__ void body_band_solve_flow(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds, int mg) {
+template <bool TR = false, bool XG = false>
+__device__ __forceinline__ void body_band_solve_flow(const DevGraph& d, int g, int lds_doubles_per_wave, double* __restrict__ lds, int mg, const XGroup* xg = nullptr) {
   const int wave = uni(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* W = lds + (size_t)wave * lds_doubles_per_wave;
   double* X = lds + (size_t)nw * lds_doubles_per_wave;
@@ -880,7 +915,7 @@ __device__ __forceinline__ void body_band_solve_flow(const DevGraph& d, int g, i
   for (int q = threadIdx.x; q < gn; q += blockDim.x) flow[q] = 0;
   __syncthreads();
   for (int i = i_first; i >= g0; i -= nw) {
-    wave_front_solve<true, TR>(d, rec, W, X, i - g0, flow);
+    wave_front_solve<true, TR, XG>(d, rec, W, X, i - g0, flow, xg);
     if (i - nw >= g0) rec = d.frec[(size_t)(i - nw) * 16 + (threadIdx.x & 15)];
   }
 }
@@ -1004,7 +1039,10 @@ __device__ __forceinline__ int front_orig_entries_sized(const DevGraph& d, int r
 // that does not depend on the children --, so that its level starts with the extend-add.  Same order of the sums (original entries,
 // then the children in order): same bits.  Groups of another shape (more fronts on a level than waves, fewer than three levels, upper
 // levels that do not fit the idle waves) take the plain walk.
-__device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds) {
+// XG: the launch holds every band group of the tree (k_band_factor_all): children factored by other workgroups are waited for, and a
+// group's top front raises its flag behind its update matrix
+template <bool XG = false>
+__device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, double lambda, int lds_doubles_per_wave, double* __restrict__ lds, const XGroup* xg = nullptr) {
   // (the host has checked the shape of every group of the stage: stage_pre in pps_upload.cpp.  Few values stay live across the levels:
   // this kernel's register allocation is at its limit, see body_band_factor)
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = uni(blockDim.x >> 6);
@@ -1040,10 +1078,11 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
       const int rec = (up_ll == ll && ll > 0) ? up_rec : d.frec[(size_t)(i0 + wave - lb) * 16 + (threadIdx.x & 15)];
       const int fa = __builtin_amdgcn_readlane(rec, 1) + __builtin_amdgcn_readlane(rec, 2) + 1;
       if (!mine_up) crv = front_orig_entries_sized(d, rec, lane, 1.0 + lambda, F, tr);
-      front_extend_add(d, rec, crv, lane, F, tr);
+      front_extend_add<XG>(d, rec, crv, lane, F, tr, xg);
       if (fa <= 33) front_eliminate_out<2, false, false, kPanelWBand>(d, rec, F, F);
       else if (fa <= 49) front_eliminate_out<3, false, false, kPanelWBand>(d, rec, F, F);
       else front_eliminate_out<4, false, false, kPanelWBand>(d, rec, F, F);
+      if (XG) { if (__builtin_amdgcn_readlane(rec, 13) >= 0) xg_post(*xg, __builtin_amdgcn_readlane(rec, 0)); }      // (slot 13: the parent's front when another group holds it)
     } else if (ll == pre_at && up_ll > pre_at) {
       // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
       crv = front_orig_entries_sized(d, up_rec, lane, 1.0 + lambda, F, tr);
@@ -1070,6 +1109,24 @@ __global__ __launch_bounds__(512) void k_band_root(DevGraph d, DualAlt alt, int 
   if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; }
   if (PRE) body_band_factor_pre(d, grp, lambda, per_wave_factor, lds); else body_band_factor<true>(d, grp, lambda, per_wave_factor, lds);
   if (FLOW) body_band_solve_flow(d, grp, per_wave_solve, lds, mg); else body_band_solve(d, grp, per_wave_solve, lds);
+}
+
+// The WHOLE tree in one launch (round 6; graphs whose every stage has the shape of the pre-assembling walk and whose groups fit the chip a
+// few times over): workgroup b = band group b, leaves first -- the groups are numbered stage by stage --, hand-over of a group's top front to
+// its parent's workgroup through XGroup flags.  A stage boundary no longer costs a launch boundary, and the fronts of the next stage are
+// cleared and receive their original entries while their children are still being eliminated.
+__global__ __launch_bounds__(512) void k_band_factor_all(DevGraph d, DualAlt alt, double lambda, int lds_doubles_per_wave, int epoch) {
+  extern __shared__ double lds[];
+  XGroup xg{d.k3_flag, epoch};
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; lambda = alt.lambda; xg.flag += d.n_fronts; }
+  body_band_factor_pre<true>(d, blockIdx.x, lambda, lds_doubles_per_wave, lds, &xg);
+}
+// ... and the whole back-substitution in one: workgroup b = group n_groups - 1 - b, the top group first
+__global__ __launch_bounds__(768) void k_band_solve_all(DevGraph d, DualAlt alt, int n_groups, int lds_doubles_per_wave, int mg, int epoch) {
+  extern __shared__ double lds[];
+  XGroup xg{d.k3_flag + 2 * d.n_fronts, epoch};
+  if (blockIdx.y) { d.L = alt.L; d.U = alt.U; d.delta = alt.delta; d.result_dev = alt.result_dev; xg.flag += d.n_fronts; }
+  body_band_solve_flow<false, true>(d, n_groups - 1 - (int)blockIdx.x, lds_doubles_per_wave, lds, mg, &xg);
 }
 
 __global__ __launch_bounds__(512) void k_band_factor_pre(DevGraph d, DualAlt alt, int grp_begin, double lambda, int lds_doubles_per_wave) {
@@ -1112,6 +1169,8 @@ static hipError_t ensure_band_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_root<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_all), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_solve_all), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimitBytes);
     if (e != hipSuccess) return e;
     g_band_attr_set[dev & 63] = true;
   }
@@ -1205,6 +1264,26 @@ hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int 
   else if (flow) PPS_LAUNCH_EV(ev0, ev1, (k_band_root<false, true>), dim3(1, alt ? 2 : 1), dim3(64 * nw), bytes, st, d, a2, grp, lambda, pwf, pws, max_group_fronts);
   else PPS_LAUNCH_EV(ev0, ev1, (k_band_root<false, false>), dim3(1, alt ? 2 : 1), dim3(64 * nw), bytes, st, d, a2, grp, lambda, pwf, pws, max_group_fronts);
   return hipGetLastError();
+}
+
+// the whole tree: one factor launch + one back-substitution launch (k_band_factor_all / k_band_solve_all)
+// nwaves_factor / max_front / max_panel / max_group_fronts: maxima over the stages; epoch: number of this launch pair (> 0, never repeated)
+hipError_t launch_band_all(const DevGraph& d, const DualAlt* alt, int n_groups, int nwaves_factor, int nwaves_solve, int max_front, int max_panel,
+                           int max_group_fronts, double lambda, int epoch, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  { const hipError_t e = ensure_band_attrs(); if (e != hipSuccess) return e; }
+  const int pwf = (int)(band_lds_bytes(max_front, true) / sizeof(double)), pws = (int)(band_solve_lds_bytes(max_panel) / sizeof(double));
+  const DualAlt a2 = alt ? *alt : DualAlt{};
+  PPS_LAUNCH_EV(ev0, ev1, k_band_factor_all, dim3(n_groups, alt ? 2 : 1), dim3(64 * nwaves_factor), (size_t)pwf * nwaves_factor * sizeof(double), st, d, a2, lambda, pwf, epoch);
+  const size_t fixed = ((size_t)max_group_fronts * kBandMaxRows + (size_t)(max_group_fronts + 1) / 2) * sizeof(double);
+  PPS_LAUNCH(k_band_solve_all, dim3(n_groups, alt ? 2 : 1), dim3(64 * nwaves_solve), (size_t)pws * nwaves_solve * sizeof(double) + fixed, st, d, a2, n_groups, pws, max_group_fronts, epoch);
+  return hipGetLastError();
+}
+// waves of the data-flow back-substitution of such a launch (0: the LDS does not hold a group): as launch_band_solve picks them per stage
+int band_all_solve_waves(int max_panel, int max_group_fronts) {
+  const size_t per_wave = band_solve_lds_bytes(max_panel);
+  const size_t fixed = ((size_t)max_group_fronts * kBandMaxRows + (size_t)(max_group_fronts + 1) / 2) * sizeof(double);
+  const size_t room = (size_t)kLdsLimitBytes > fixed ? ((size_t)kLdsLimitBytes - fixed) / per_wave : 0;
+  return (int)std::min<size_t>(std::min<size_t>(12, (size_t)max_group_fronts), room);
 }
 
 // Back-substitution for one level (parents already solved): x_p = L_A^-T (y - L_B^T x_b).

@@ -47,6 +47,16 @@ int do_linearize(pps_graph* g, const LinGuard* guard = nullptr) {
 // stop events (profiling level 1; the fused root launch's pair spans its back-substitution as well).
 static int enqueue_factor_solve(pps_graph* g, const DevGraph& dv, const DualAlt* alt, double lambda, hipStream_t st_, bool events) {
   const Analysis& A = g->an;
+  if (g->k3_all) {                                                 // the whole tree: two launches (pps_k3.hip, XGroup)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (events) {
+      if (g->fk_used + 2 > (int)g->fk_events.size()) for (int k = 0; k < 2; k++) { hipEvent_t e; HIP_TRY(g, hipEventCreate(&e)); g->fk_events.push_back(e); }
+      e0 = g->fk_events[g->fk_used]; e1 = g->fk_events[g->fk_used + 1]; g->fk_used += 2;
+    }
+    g->k3_epoch = g->k3_epoch >= (1 << 30) ? 1 : g->k3_epoch + 1;
+    HIP_TRY(g, launch_band_all(dv, alt, A.n_groups, g->k3_nw_factor, g->k3_nw_solve, g->k3_max_front, g->k3_max_panel, g->k3_max_grp, lambda, g->k3_epoch, st_, e0, e1));
+    return PPS_OK;
+  }
   const int top = A.n_stages - 1;
   const bool fuse = top >= 0 && band_root_fusable(dv, A.stage_grp_off[top + 1] - A.stage_grp_off[top], A.stage_max_front[top]);
   for (int st = 0; st < A.n_stages; st++) {

@@ -1194,7 +1194,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       r[7] = A.f_poff[s2]; r[8] = A.f_bidx_off[s2];
       r[9] = (int)(A.f_Loff[s2] & 0xffffffffLL); r[10] = (int)(A.f_Loff[s2] >> 32);
       r[11] = (int)(A.f_Uoff[s2] & 0xffffffffLL); r[12] = (int)(A.f_Uoff[s2] >> 32);
-      r[13] = (A.f_b[s2] + 1) * (A.f_b[s2] + 2) / 2;
+      r[13] = -1;                                             // the parent's front when another band group holds it (hand-over between workgroups: XGroup, pps_k3.hip)
       // solve hand-down: a front whose parent sits in the same group reads its boundary values from the parent's
       // local solution vector (LDS) through cmap instead of gathering them from delta
       r[14] = -1;
@@ -1205,12 +1205,14 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
         // slot = position inside the group (groups are contiguous in glvl_fronts: grp_first = first position of the group's
         // first local level)
         if (par >= 0 && A.f_level[par] / Bn2 == A.f_level[s2] / Bn2) r[14] = pos_of[par] - grp_first[pos_of[par]];
+        else if (par >= 0) r[13] = par;
       }
       for (int ci = A.f_child_off[s2]; ci < A.f_child_off[s2 + 1]; ci++) {
         const int c = A.child[ci];
         const int bc1 = A.f_b[c] + 1;
         int cr[8] = {bc1 * (bc1 + 1) / 2, (int)(A.f_Uoff[c] & 0xffffffffLL), (int)(A.f_Uoff[c] >> 32),
-                     (int)(A.f_ea_off[c] & 0xffffffffLL), (int)(A.f_ea_off[c] >> 32), c, 0, 0};
+                     (int)(A.f_ea_off[c] & 0xffffffffLL), (int)(A.f_ea_off[c] >> 32), c,
+                     A.f_level[c] / std::max(1, prm.band_levels) != A.f_level[s2] / std::max(1, prm.band_levels) ? 1 : 0, 0};      // slot 6: the child belongs to another band group
         A.crec.insert(A.crec.end(), cr, cr + 8);
       }
     }

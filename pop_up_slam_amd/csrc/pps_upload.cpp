@@ -396,6 +396,23 @@ static int run_analysis_impl(pps_graph* g) {
         }
         g->stage_pre[st] = ok ? 1 : 0;
       }
+    // The whole tree in one factor launch + one back-substitution launch (k_band_factor_all / k_band_solve_all, round 6): every stage takes the
+    // pre-assembling walk on register-resident fronts, the data-flow back-substitution holds a group of any stage, and the groups fit the chip
+    // a few times over -- a graph of thousands of groups (C3) keeps a launch per stage: its upper workgroups would sit on wave slots its leaves
+    // need.
+    g->k3_all = false;
+    if (g->use_band && A.n_stages >= 2 && g->sw.trace == 0 && !g->sw.no_preassemble && !g->sw.no_solve_flow && !g->sw.no_root_fuse && A.n_groups <= 512) {
+      bool ok = true;
+      int nwf = 1, mf = 0, mp = 1, mg = 1;
+      for (int st = 0; st < A.n_stages; st++) {
+        ok = ok && g->stage_pre[st] != 0 && A.stage_max_front[st] + 1 <= band_reg_rows();
+        nwf = std::max(nwf, g->stage_nw_factor[st]); mf = std::max(mf, A.stage_max_front[st]);
+        mp = std::max(mp, g->stage_max_panel[st]); mg = std::max(mg, g->stage_max_grp_fronts[st]);
+      }
+      const int nws = ok ? band_all_solve_waves(mp, mg) : 0;
+      ok = ok && mg > 1 && nws >= std::min(8, mg) && band_lds_bytes(mf, true) * (size_t)nwf <= lds_budget;
+      if (ok) { g->k3_all = true; g->k3_nw_factor = nwf; g->k3_nw_solve = nws; g->k3_max_front = mf; g->k3_max_panel = mp; g->k3_max_grp = mg; }
+    }
     // (such a graph then runs on the level-per-launch kernels: its fronts are <= 127 rows by the use_band test above)
   }
   if (!g->use_band && !g->use_dense && g->an.max_front > 4096)
@@ -750,11 +767,14 @@ int upload_all(pps_graph* g) {
 
   {
     // one zeroed block: [dn_partials | ticket | spec ticket | result record | the second factorisation's result record |
-    // delta | the second delta]
+    // delta | the second delta | the hand-over flags of the whole-tree launches: 4 ints per front]
     const size_t n_dn = (size_t)(d.n_pose + d.n_plane + 255) / 256 + 1;
+    const size_t flag_doubles = 2 * (size_t)std::max(1, A.n_fronts) + 1;
     double* zb = nullptr;
-    TRY(dev_alloc(g, &zb, n_dn + 2 + 8 + 2 * delta_doubles));
-    zero_block = zb; zero_doubles = n_dn + 2 + 8 + 2 * delta_doubles;     // (cleared by k_expand_ea below, or by a memset when that launch has nothing to expand)
+    TRY(dev_alloc(g, &zb, n_dn + 2 + 8 + 2 * delta_doubles + flag_doubles));
+    zero_block = zb; zero_doubles = n_dn + 2 + 8 + 2 * delta_doubles + flag_doubles;     // (cleared by k_expand_ea below, or by a memset when that launch has nothing to expand)
+    d.k3_flag = reinterpret_cast<int*>(zb + n_dn + 2 + 8 + 2 * delta_doubles);
+    g->k3_epoch = 0;
     d.delta = zb + n_dn + 10; g->spec_delta = d.delta + delta_doubles;
     d.dn_partials = zb;
     d.ticket = reinterpret_cast<unsigned int*>(zb + n_dn);
