@@ -37,9 +37,9 @@
 extern "C" {
 #endif
 
-#define PPS_VERSION 303   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301;
+#define PPS_VERSION 304   /* round.minor: bump whenever a struct of this header changes layout or an entry point is added (pps_stats grew in 200; pps_debug_front_factor: 301;
                               pps_multi_save_state / pps_multi_restore_state: 302; pps_debug_exmap AND pps_multi_phase_times' counts[] grown from 2 to 4
-                              entries -- a caller built against 302 that passes counts[2] must be rebuilt: 303) */
+                              entries -- a caller built against 302 that passes counts[2] must be rebuilt: 303; pps_popup_run_async / _planes_wait / _wait: 304) */
 
 typedef struct pps_graph pps_graph;
 
@@ -275,6 +275,15 @@ int pps_popup_set_image(pps_popup* p, const unsigned char* bgr);
  * ceiling_thre.  Depth: z_s, with the ceiling plane substituted above ceiling_thre (:903-916). */
 int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys,
                   const int* poly_off, int nplanes, int step, float depth_thre, float ceiling_thre, int* n_valid);
+/* The same run without waiting for it (the frame loop, Mapping.cpp:401-586 / main_3d.cpp:423-503: the graph construction needs the plane
+ * equations, the pixels are nobody's input before the frame is drawn).  pps_popup_planes_wait returns the (n+1) x 4 plane equations as soon as
+ * the kernel's first workgroup has written them -- a few microseconds after the launch --, pps_popup_wait the end of the run (n_valid may be
+ * NULL).  Every entry point that reads results of a run (download, plane_info, fill_depth, download_segments3d, the next run) waits for a
+ * run in flight by itself. */
+int pps_popup_run_async(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys,
+                        const int* poly_off, int nplanes, int step, float depth_thre, float ceiling_thre);
+int pps_popup_planes_wait(pps_popup* p, float* planes);
+int pps_popup_wait(pps_popup* p, int* n_valid);
 /* any output may be NULL: planes (n+1)x4 sensor-frame, cloud width*height pps_point, depth width*height,
  * plane_id width*height (-1 = none) */
 int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* depth, int32_t* plane_id);

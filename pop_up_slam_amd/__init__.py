@@ -25,7 +25,7 @@ _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 
 
-PPS_VERSION = 303      # include/pps.h: the struct layouts mirrored below
+PPS_VERSION = 304      # include/pps.h: the struct layouts mirrored below
 
 
 class PpsProps(C.Structure):
@@ -100,7 +100,7 @@ SYMBOLS = [
     "pps_set_profiling", "pps_factor_shape", "pps_eval_factor", "pps_analyze", "pps_analysis_dump",
     "pps_bench_sweep", "pps_save_state", "pps_restore_state",
     "pps_popup_planes", "pps_popup_create", "pps_popup_destroy", "pps_popup_last_error", "pps_popup_set_image",
-    "pps_popup_run", "pps_popup_download", "pps_popup_last_kernel_time",
+    "pps_popup_run", "pps_popup_run_async", "pps_popup_planes_wait", "pps_popup_wait", "pps_popup_download", "pps_popup_last_kernel_time",
     "pps_frames_set_calibration", "pps_frames_add", "pps_refresh_measurements", "pps_get_measurement",
     "pps_popup_download_segments3d", "pps_assoc_default_params", "pps_landmark_update", "pps_landmark_set_merged",
     "pps_find_closest_planes", "pps_graph_save", "pps_graph_load", "pps_add_plane_obs2", "pps_edge_ray",
@@ -174,6 +174,9 @@ def lib():
         L.pps_popup_last_error.restype = C.c_char_p
         L.pps_popup_set_image.argtypes = [C.c_void_p, _u8]
         L.pps_popup_run.argtypes = [C.c_void_p, _fp, C.c_int, _fp, _fp, _ip, C.c_int, C.c_int, C.c_float, C.c_float, _ip]
+        L.pps_popup_run_async.argtypes = L.pps_popup_run.argtypes[:-1]
+        L.pps_popup_planes_wait.argtypes = [C.c_void_p, _fp]
+        L.pps_popup_wait.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.pps_popup_download.argtypes = [C.c_void_p, _fp, C.c_void_p, _fp, C.POINTER(C.c_int32)]
         L.pps_popup_last_kernel_time.argtypes = [C.c_void_p, _dp]
         L.pps_popup_mask_host.argtypes = [_fp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
@@ -588,7 +591,21 @@ class Popup:
         assert a.size == self.w * self.h_ * 3
         self._ck(self.L.pps_popup_set_image(self.h, a.ctypes.data_as(C.POINTER(C.c_ubyte))))
 
-    def run(self, seg2d, T_wc, polys, step=1, depth_thre=10.0, ceiling_thre=2.5):
+    def run_async(self, seg2d, T_wc, polys, step=1, depth_thre=10.0, ceiling_thre=2.5):
+        """pps_popup_run_async: the run is enqueued and not waited for; planes_wait() / wait() collect its results"""
+        return self.run(seg2d, T_wc, polys, step, depth_thre, ceiling_thre, _async=True)
+
+    def planes_wait(self):
+        """the (n + 1) x 4 plane equations of the run in flight, as soon as the kernel has published them"""
+        planes = np.zeros((self.n + 1, 4), dtype=np.float32)
+        self._ck(self.L.pps_popup_planes_wait(self.h, planes.ctypes.data_as(_fp)))
+        return planes
+
+    def wait(self):
+        """the end of the run in flight: points of its cloud"""
+        nv = C.c_int(); self._ck(self.L.pps_popup_wait(self.h, C.byref(nv))); return nv.value
+
+    def run(self, seg2d, T_wc, polys, step=1, depth_thre=10.0, ceiling_thre=2.5, _async=False):
         """polys: list of (k_i x 2) vertex arrays, one per plane (plane 0 = ground); may be empty arrays."""
         seg = np.ascontiguousarray(seg2d, dtype=np.float32).reshape(-1, 4)
         t = np.ascontiguousarray(T_wc, dtype=np.float32).reshape(16)
@@ -599,6 +616,11 @@ class Popup:
         for i, p in enumerate(polys):
             if len(p):
                 flat[off[i]:off[i + 1]] = np.asarray(p, dtype=np.float32).reshape(-1, 2)
+        if _async:
+            self._ck(self.L.pps_popup_run_async(self.h, seg.ctypes.data_as(_fp), len(seg), t.ctypes.data_as(_fp),
+                                                flat.ctypes.data_as(_fp), off.ctypes.data_as(_ip), len(polys), step, depth_thre, ceiling_thre))
+            self.n = len(seg)
+            return None
         nv = C.c_int()
         self._ck(self.L.pps_popup_run(self.h, seg.ctypes.data_as(_fp), len(seg), t.ctypes.data_as(_fp),
                                       flat.ctypes.data_as(_fp), off.ctypes.data_as(_ip), len(polys), step,

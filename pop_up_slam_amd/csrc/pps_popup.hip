@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,7 +28,8 @@
 namespace pps {
 
 constexpr int kMaxPlanes = 64;
-constexpr int kPlaneBlock = 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * kMaxPlanes;   // floats: plane equations | ground segments | plane info
+constexpr int kPlaneData = 4 * (kMaxPlanes + 1) + 6 * kMaxPlanes + 2 * kMaxPlanes;    // floats: plane equations | ground segments | plane info
+constexpr int kPlaneBlock = kPlaneData + 2;       // ... | the number of the run that wrote them (pps_popup_planes_wait polls it) | pad
 constexpr int kMaxVerts = 512;
 constexpr size_t kInSegOff = 512, kInPolyOff = kInSegOff + sizeof(float) * 4 * kMaxPlanes, kInBytes = kInPolyOff + sizeof(float) * 2 * kMaxVerts;
 static_assert(sizeof(int) * (kMaxPlanes + 2) <= kInSegOff, "poly_off does not fit its part of the input block");
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
                                                      const int4* __restrict__ boxes, const unsigned char* __restrict__ bgr,
                                                      float* __restrict__ planes_out, pps_point* __restrict__ cloud,
                                                      float* __restrict__ depth, int* __restrict__ plane_id,
-                                                     unsigned int* __restrict__ n_valid) {
+                                                     unsigned int* __restrict__ n_valid, unsigned int run_seq) {
   __shared__ float s_planes[kMaxPlanes + 1][4];
   __shared__ int s_off[kMaxPlanes + 2];
   __shared__ int4 s_box[kMaxPlanes];              // boundingRect of the truncated polygon: x, y, width, height
@@ -277,6 +279,11 @@ __global__ __launch_bounds__(256) void k_popup_frame(PopupParams prm, const floa
     s_cnt = 0;
   }
   __syncthreads();
+  // (the plane equations are what the caller's graph construction waits for: block (0, 0) has just written them into the pinned host block --
+  // the run's number goes behind them with system-scope release, so that pps_popup_planes_wait sees them microseconds after the launch
+  // started, long before the pixels are done)
+  if (publish && planes_out && tid == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(planes_out + kPlaneData), run_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   int E;                                                        // entries per row of the interval lists
   if (FUSED) {
     __shared__ PolySetup L;
@@ -486,6 +493,9 @@ struct pps_popup {
   int4* d_boxes = nullptr;            // kMaxPlanes
   unsigned int* d_count = nullptr;   // kept points per workgroup of the last run
   size_t count_cap = 0;
+  unsigned int run_seq = 0;          // number of the last run (the frame kernel publishes it behind the plane equations)
+  bool in_flight = false;            // pps_popup_run_async was not waited for yet
+  size_t n_wg_last = 0;              // workgroups of the last run (their point counts sit in h_count)
   unsigned int* h_count = nullptr;   // pinned (behind h_planes)
   float* h_planes = nullptr;         // pinned mirror of d_planes as the last run left it: [plane equations | ground segments | plane info]
   int last_n = 0;
@@ -584,8 +594,15 @@ int pps_popup_set_image(pps_popup* p, const unsigned char* bgr) {
   return PPS_OK;
 }
 
-int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys, const int* poly_off,
-                  int nplanes, int step, float depth_thre, float ceiling_thre, int* n_valid) {
+// a run enqueued by pps_popup_run_async is over before anything reads its results
+static int popup_settle(pps_popup* p) {
+  if (p && p->in_flight) { PHIP(p, hipSetDevice(p->device)); PHIP(p, hipStreamSynchronize(p->stream)); p->in_flight = false; }
+  return PPS_OK;
+}
+
+// one run enqueued on the handle's stream; timed: with the event pair around the kernel (the synchronous entry point)
+static int popup_enqueue(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys, const int* poly_off, int nplanes, int step,
+                         float depth_thre, float ceiling_thre, bool timed) {
   if (!p || !T_wc || !poly_off || n < 0 || nplanes < 0) return PPS_EINVAL;
   if (n > kMaxPlanes - 1 || nplanes > kMaxPlanes) return pfail(p, PPS_EINVAL, "too many planes for one frame (max 64)");
   if (nplanes > n + 1) return pfail(p, PPS_EINVAL, "more polygons than planes");
@@ -593,6 +610,7 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   if (step != 1 && step != 2) return pfail(p, PPS_EINVAL, "step must be 1 or 2");
   PHIP(p, hipSetDevice(p->device));
   if ((n > 0 && !seg2d) || (poly_off[nplanes] > 0 && !polys)) return PPS_EINVAL;
+  if (p->in_flight) { PHIP(p, hipStreamSynchronize(p->stream)); p->in_flight = false; }      // (the pinned input block is reused)
   PopupParams prm{};
   memcpy(prm.invK, p->invK, sizeof prm.invK);
   memcpy(prm.T, T_wc, sizeof prm.T);
@@ -603,9 +621,10 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   if (n > 0) memcpy(p->h_in + kInSegOff, seg2d, sizeof(float) * 4 * (size_t)n);
   const size_t poly_bytes = sizeof(float) * 2 * (size_t)poly_off[nplanes];
   if (poly_bytes > 0) memcpy(p->h_in + kInPolyOff, polys, poly_bytes);
-  PHIP(p, hipMemcpyAsync(p->d_in, p->h_in, kInPolyOff + poly_bytes, hipMemcpyHostToDevice, p->stream));
   const int npx = p->width * p->height;
-  PHIP(p, hipEventRecord(p->ev[0], p->stream));
+  PHIP(p, hipMemcpyAsync(p->d_in, p->h_in, kInPolyOff + poly_bytes, hipMemcpyHostToDevice, p->stream));
+  if (timed) PHIP(p, hipEventRecord(p->ev[0], p->stream));
+  p->run_seq++;
   // column strips of 256 x PX pixels: 2 rows per thread on small frames (640x480: 720 workgroups), 8 from ~1 Mpixel up;
   // frames up to 640 x 480 derive their row intervals inside the frame kernel (one launch), larger ones in a launch of their own
   const int pxt = npx >= (1 << 20) ? 8 : 2;
@@ -621,24 +640,68 @@ int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16],
   }
   if (fused)
     hipLaunchKernelGGL((k_popup_frame<2, true>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count);
+                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count, p->run_seq);
   else if (pxt == 8)
     hipLaunchKernelGGL((k_popup_frame<8, false>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count);
+                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count, p->run_seq);
   else
     hipLaunchKernelGGL((k_popup_frame<2, false>), grid, dim3(256), 0, p->stream, prm, p->d_seg, n, p->d_polys, p->d_off, nplanes, p->d_row_iv, p->d_row_cnt,
-                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count);
+                       p->d_boxes, img, p->h_planes, p->d_cloud, dep, pidp, p->h_count, p->run_seq);
   PHIP(p, hipGetLastError());
-  PHIP(p, hipEventRecord(p->ev[1], p->stream));
-  const size_t n_wg = (size_t)grid.x * grid.y;
+  if (timed) PHIP(p, hipEventRecord(p->ev[1], p->stream));
+  p->n_wg_last = (size_t)grid.x * grid.y;
+  p->last_n = n; p->last_step = step;
+  memcpy(p->last_T, T_wc, sizeof p->last_T);
+  p->in_flight = true;
+  return PPS_OK;
+}
+
+int pps_popup_run(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys, const int* poly_off,
+                  int nplanes, int step, float depth_thre, float ceiling_thre, int* n_valid) {
+  const int rc = popup_enqueue(p, seg2d, n, T_wc, polys, poly_off, nplanes, step, depth_thre, ceiling_thre, true);
+  if (rc != PPS_OK) return rc;
   // (plane block and point counts were written into pinned host memory by the kernel itself)
   PHIP(p, hipStreamSynchronize(p->stream));
+  p->in_flight = false;
   float ms = 0;
   (void)hipEventElapsedTime(&ms, p->ev[0], p->ev[1]);
   p->last_kernel_s = 1e-3 * ms;
-  p->last_n = n; p->last_step = step;
-  memcpy(p->last_T, T_wc, sizeof p->last_T);
-  if (n_valid) { unsigned int tot = 0; for (size_t i = 0; i < n_wg; i++) tot += p->h_count[i]; *n_valid = (int)tot; }
+  if (n_valid) { unsigned int tot = 0; for (size_t i = 0; i < p->n_wg_last; i++) tot += p->h_count[i]; *n_valid = (int)tot; }
+  return PPS_OK;
+}
+
+// The same run without waiting for it (round 6: the frame loop's graph construction needs the plane equations, which the kernel's first
+// workgroup publishes at once; the pixels -- cloud, depth, plane ids -- are nobody's input before the frame is drawn).
+int pps_popup_run_async(pps_popup* p, const float* seg2d, int n, const float T_wc[16], const float* polys, const int* poly_off,
+                        int nplanes, int step, float depth_thre, float ceiling_thre) {
+  return popup_enqueue(p, seg2d, n, T_wc, polys, poly_off, nplanes, step, depth_thre, ceiling_thre, false);
+}
+// the plane equations of the run in flight ((n + 1) x 4), as soon as its first workgroup has written them
+int pps_popup_planes_wait(pps_popup* p, float* planes) {
+  if (!p || !planes) return PPS_EINVAL;
+  if (p->run_seq == 0) return pfail(p, PPS_ESTATE, "no pop-up run");
+  const volatile unsigned int* seq = reinterpret_cast<const volatile unsigned int*>(p->h_planes + kPlaneData);
+  if (p->in_flight) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*seq != p->run_seq) {
+      if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.5) {
+        PHIP(p, hipStreamSynchronize(p->stream));
+        p->in_flight = false;
+        if (*seq != p->run_seq) return pfail(p, PPS_EHIP, "the pop-up kernel did not publish its plane equations");
+        break;
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  memcpy(planes, p->h_planes, sizeof(float) * 4 * (size_t)(p->last_n + 1));
+  return PPS_OK;
+}
+// the end of the run in flight: its pixels are on the device (pps_popup_download), n_valid = points of its cloud
+int pps_popup_wait(pps_popup* p, int* n_valid) {
+  if (!p) return PPS_EINVAL;
+  if (p->in_flight) { PHIP(p, hipSetDevice(p->device)); PHIP(p, hipStreamSynchronize(p->stream)); p->in_flight = false; }
+  if (n_valid) { unsigned int tot = 0; for (size_t i = 0; i < p->n_wg_last; i++) tot += p->h_count[i]; *n_valid = (int)tot; }
   return PPS_OK;
 }
 
@@ -666,6 +729,7 @@ __global__ __launch_bounds__(256) void k_depth_fill(const float* __restrict__ sp
 }
 
 int pps_popup_fill_depth(pps_popup* p) {
+  { const int rc0 = popup_settle(p); if (rc0 != PPS_OK) return rc0; }
   if (!p) return PPS_EINVAL;
   if (!p->want_depth) return pfail(p, PPS_ESTATE, "depth output is switched off (pps_popup_set_outputs)");
   if (p->last_step != 2) return pfail(p, PPS_ESTATE, "pps_popup_fill_depth follows a pps_popup_run with step = 2");
@@ -682,6 +746,7 @@ int pps_popup_fill_depth(pps_popup* p) {
 }
 
 int pps_popup_download(pps_popup* p, float* planes, pps_point* cloud, float* depth, int32_t* plane_id) {
+  { const int rc0 = popup_settle(p); if (rc0 != PPS_OK) return rc0; }
   if (!p) return PPS_EINVAL;
   PHIP(p, hipSetDevice(p->device));
   const size_t npx = (size_t)p->width * p->height;
@@ -702,6 +767,7 @@ int pps_popup_set_outputs(pps_popup* p, int want_depth, int want_plane_id) {
 
 int pps_popup_plane_info(pps_popup* p, float plane_cam_dist_thre, const int* actual_plane_indices, int n_actual, float* dist_to_cam,
                          int32_t* good) {
+  { const int rc0 = popup_settle(p); if (rc0 != PPS_OK) return rc0; }
   if (!p || (!dist_to_cam && !good) || n_actual < 0 || (n_actual > 0 && !actual_plane_indices)) return PPS_EINVAL;
   PHIP(p, hipSetDevice(p->device));
   const int n = p->last_n;
@@ -723,6 +789,7 @@ int pps_popup_plane_info(pps_popup* p, float plane_cam_dist_thre, const int* act
 }
 
 int pps_popup_download_segments3d(pps_popup* p, float* seg3d_world) {
+  { const int rc0 = popup_settle(p); if (rc0 != PPS_OK) return rc0; }
   if (!p || !seg3d_world) return PPS_EINVAL;
   PHIP(p, hipSetDevice(p->device));
   if (p->last_n > 0)

@@ -241,8 +241,14 @@ class PopupSlamPipeline:
         return it
 
 
+def gpu_pipeline_finish(pp, stats):
+    """collects the pop-up run that is still in flight at the end of a frame loop driven with async_popup"""
+    if stats.get("in_flight"):
+        stats["points"] += pp.wait(); stats["in_flight"] = False
+
+
 def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, with_image=True, seed=0, associate=False,
-                 assoc_params=None, repop=False):
+                 assoc_params=None, repop=False, async_popup=False):
     """Product pipeline: Graph + Popup on the GPU; pop-up results stay on the device."""
     import pop_up_slam_amd as P
     invK = np.linalg.inv(K).astype(np.float32)
@@ -256,6 +262,14 @@ def gpu_pipeline(width=640, height=480, K=synth.K_TUM, jacobian_mode=0, step=2, 
     stats = {"popup_kernel_s": 0.0, "points": 0}
 
     def popup_fn(seg, T32, polys):
+        if async_popup and not associate:
+            # round 6: the graph construction waits for the plane equations only (published by the kernel's first workgroup); the pixels of
+            # frame k are counted when frame k + 1 is launched (gpu_pipeline_finish collects the last frame's)
+            if stats.get("in_flight"):
+                stats["points"] += pp.wait()
+            pp.run_async(seg, T32, polys, step=step, depth_thre=10.0, ceiling_thre=2.5)
+            stats["in_flight"] = True
+            return pp.planes_wait()
         stats["points"] += pp.run(seg, T32, polys, step=step, depth_thre=10.0, ceiling_thre=2.5)
         stats["popup_kernel_s"] += pp.last_kernel_time()
         planes = np.zeros((len(seg) + 1, 4), dtype=np.float32)

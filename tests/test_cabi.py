@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/pps.h but not exported by libpps.so"
     assert set(names) == set(P.SYMBOLS), set(names) ^ set(P.SYMBOLS)
-    assert P.lib().pps_version() == P.PPS_VERSION == 303
+    assert P.lib().pps_version() == P.PPS_VERSION == 304
 
 
 def test_no_oracle_in_the_product(built):

@@ -75,6 +75,30 @@ def test_fused_frame_matches_oracle(built, step):
             pp.fill_depth()            # the map is dense now: a second fill has nothing to work on
 
 
+def test_run_that_is_not_waited_for(built):
+    """pps_popup_run_async: the plane equations are handed out as soon as the kernel's first workgroup has published them, the pixels when
+    the run is waited for -- frame after frame, the same bits as the synchronous run; a reader (download) settles a run in flight itself"""
+    rng = np.random.default_rng(2)
+    bgr = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    pa, ps = P.Popup(W, H, INVK), P.Popup(W, H, INVK)
+    pa.set_image(bgr); ps.set_image(bgr)
+    for k in range(6):
+        tq = _pose(); tq[1] += 0.3 * k
+        seg, polys, T = synth.corridor_frame(tq)
+        nv = ps.run(seg, T, polys, step=2, depth_thre=10.0, ceiling_thre=2.5)
+        want = ps.download()
+        assert pa.run_async(seg, T, polys, step=2, depth_thre=10.0, ceiling_thre=2.5) is None
+        planes = pa.planes_wait()
+        np.testing.assert_array_equal(planes, want[0])
+        np.testing.assert_array_equal(planes, O.popup_planes(seg, INVK, T))
+        if k % 2 == 0:
+            assert pa.wait() == nv
+        got = pa.download()                      # (odd frames: the download waits for the run itself)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+        assert pa.wait() == nv                   # (idempotent once the run is over)
+
+
 def test_wall_points_lie_on_the_wall(built):
     """size-independent property: popped-up wall pixels are at the wall's world position."""
     tq = _pose(yaw=0.0, pitch=0.0, x=0.0, y=0.0)

@@ -85,10 +85,11 @@ def multi(G, reps, mode=P.JAC_NUMERIC):
 def c5(n):
     from pop_up_slam_amd import pipeline
     frames = pipeline.popup_sequence(n)
-    pl, g, pp, st5 = pipeline.gpu_pipeline(step=2)
+    pl, g, pp, st5 = pipeline.gpu_pipeline(step=2, async_popup=not os.environ.get("AB_SYNC_POPUP"))
     t1 = time.perf_counter(); lm = 0
     for fr in frames:
         lm += max(pl.process(fr), 0)
+    pipeline.gpu_pipeline_finish(pp, st5)
     e = time.perf_counter() - t1
     out = {"frames": n, "frames_per_s": n / e, "lm_iterations": lm, "chi2": g.chi2(), "popup_us": 1e6 * st5["popup_kernel_s"] / n}
     g.close(); pp.close()

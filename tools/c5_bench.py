@@ -8,7 +8,7 @@ from pop_up_slam_amd import pipeline
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 step = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 frames = pipeline.popup_sequence(n)
-pl, g, pp, stats = pipeline.gpu_pipeline(step=step)
+pl, g, pp, stats = pipeline.gpu_pipeline(step=step, async_popup=True)
 t_solve = t_an = t_up = 0.0
 lm_iters = lm_calls = 0
 t0 = time.perf_counter()
@@ -21,6 +21,7 @@ for k, fr in enumerate(frames):
     t_solve += st["t_total"]; t_an += st["t_analysis"]; t_up += st["t_upload"]
     if (k + 1) % 250 == 0:
         marks.append((k + 1, time.perf_counter() - t0))
+pipeline.gpu_pipeline_finish(pp, stats)
 wall = time.perf_counter() - t0
 st = g.stats()
 print(json.dumps({"frames": n, "frames_per_sec": n / wall, "wall_s": wall, "pixel_step": step,

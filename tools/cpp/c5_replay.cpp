@@ -82,11 +82,13 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 16; i++) T32[i] = (float)T[i];
       int n_valid = 0;
       lap(0);
-      CK(pps_popup_run(pp, fr.seg.data(), n, T32, fr.polys.data(), fr.poly_off.data(), n + 1, step, 10.0f, 2.5f, &n_valid));
-      points += n_valid;
+      // (round 6) the run is not waited for: the graph construction needs the plane equations only, which the kernel's first workgroup publishes
+      // at once; the previous frame's pixels are counted here, when their run has long finished
+      if (k > 0) { CK(pps_popup_wait(pp, &n_valid)); points += n_valid; }
+      CK(pps_popup_run_async(pp, fr.seg.data(), n, T32, fr.polys.data(), fr.poly_off.data(), n + 1, step, 10.0f, 2.5f));
       lap(1);
       planes.resize(4 * (size_t)(n + 1));
-      CK(pps_popup_download(pp, planes.data(), nullptr, nullptr, nullptr));
+      CK(pps_popup_planes_wait(pp, planes.data()));
       lap(2);
       Pose3d_Node* poseNode = new Pose3d_Node();
       slam.add_node(poseNode);                                                   // Mapping.cpp:464-465
@@ -120,6 +122,7 @@ int main(int argc, char** argv) {
       CK(pps_refresh_measurements(g));                                           // main_3d.cpp:504 -> Mapping.cpp:590-607
       lap(6);
     }
+    { int n_valid = 0; CK(pps_popup_wait(pp, &n_valid)); points += n_valid; }
     const double chi2 = slam.chi2();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("{\"frames\": %d, \"frames_per_sec\": %.3f, \"wall_s\": %.6f, \"pixel_step\": %d, \"final_chi2\": %.17g, \"lm_calls\": %ld, "
