@@ -34,6 +34,7 @@ B_ODO_EDGE = 840     # 216 B read + 624 B written per odometry edge
 HBM_PEAK_GBS = 8000.0
 
 
+N_SIMD, CLOCK_HZ = 1024, 2.4e9          # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock (/opt/skills/guides/MI355X_MICROARCH.md)
 K1_SOURCES = ("pps_k1.hip", "pps_k1_lanes.hip", "pps_k1_body.h", "pps_lin.h", "pps_geom.h")
 
 
@@ -460,6 +461,14 @@ def main():
                 ent[part] = {"bound": "hbm", "achieved": nbytes / sec_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": nbytes / sec_k / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                              "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec_k * 1e6}
+                # the numeric sweeps' own roof is vector-instruction ISSUE, not HBM: wave instructions of the launch (PMC SQ_INSTS_VALU, same
+                # source hash) x 4 cycles (one fp64 wave instruction occupies its SIMD for four) / (1 024 SIMDs x clock) / measured time
+                if rec and reps == pmc_js.get("replicas") and rec.get("valu_wave_insts_per_launch"):
+                    issue_s = rec["valu_wave_insts_per_launch"] * 4.0 / (N_SIMD * CLOCK_HZ)
+                    ent[part]["valu_frac"] = issue_s / sec_k
+                    ent[part]["valu_insts_per_edge"] = rec.get("valu_insts_per_edge_lane")
+                    ent[part]["valu_note"] = ("issue-bound time %.1f us = %.0f wave instructions x 4 cycles / (%d SIMDs x %.1f GHz)"
+                                              % (issue_s * 1e6, rec["valu_wave_insts_per_launch"], N_SIMD, CLOCK_HZ / 1e9))
             ent["both_launches_us"] = sec_all * 1e6
             ent["replicas"], ent["n_plane_edges"], ent["n_odometry_edges"] = reps, npl, nod
             ent["traffic_source"] = pmc_src

@@ -59,7 +59,7 @@ def main():
         out["git_head"] = None                # (no .git on the GPU box: the source hash is what binds the file to a build)
     acc = {}
     for mode, mname in ((1, "analytic"), (0, "numeric"), (2, "numeric_lanes")):
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):      # (SQ_INSTS_VALU: wave instructions, for the issue roof of the numeric sweeps)
             for name, c, v, n, dur in run_pass(outdir, counter, f"sweep_{mname}", [sys.executable, "tools/sweep_only.py", str(mode), str(REPLICAS)]):
                 if mode == 2:
                     m = re.search(r"k_sweep_bench_lanes<(\d)>", name)
@@ -78,7 +78,7 @@ def main():
                         part = "plane_edges" if m.group(2) == "0" else "odometry"
                 key = f"{mname}_{part}"
                 acc.setdefault(key, {"kernel": name.split("(")[0]})
-                acc[key]["fetch_kib_raw" if c == "FETCH_SIZE" else "write_kib"] = v
+                acc[key]["fetch_kib_raw" if c == "FETCH_SIZE" else ("write_kib" if c == "WRITE_SIZE" else "insts_valu")] = v
                 acc[key]["duration_us"] = dur / 1e3
                 acc[key]["dispatches"] = n
     n_pl, n_od = 5000 * REPLICAS, 999 * REPLICAS
@@ -86,6 +86,12 @@ def main():
         rec["algorithmic_bytes"] = n_pl * 392 if key.endswith("plane_edges") else n_od * 840
         if "fetch_kib_raw" in rec and "write_kib" in rec:
             rec["hbm_bytes_corrected"] = 1024.0 * (rec["fetch_kib_raw"] * fcorr + rec["write_kib"] * wcorr)
+        if "insts_valu" in rec:
+            # vector instructions one EDGE costs: wave instructions x 64 lanes / lanes per edge -- 1 in the thread forms, 19 (plane edge) / 32
+            # (odometry edge) in the lane form -- / edges
+            edges = n_pl if key.endswith("plane_edges") else n_od
+            rec["valu_wave_insts_per_launch"] = rec["insts_valu"]
+            rec["valu_insts_per_edge_lane"] = rec["insts_valu"] * 64.0 / edges / (1 if not key.startswith("numeric_lanes") else (19 if key.endswith("plane_edges") else 32))
     out["kernels"] = acc
     path = os.path.join(outdir, "pmc_k1_sweep.json")
     json.dump(out, open(path, "w"), indent=1)
