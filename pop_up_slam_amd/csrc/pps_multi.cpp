@@ -481,11 +481,14 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     double t_progress = now_s();
     // a HIP failure inside the loop: whatever the other chunks still have in flight is drained before the caller sees the error
     auto drain = [&]() { for (hipStream_t s3 : streams) if (s3) (void)hipStreamSynchronize(s3); };
+    double t_launch = 0.0, t_book = 0.0;                       // host seconds inside run_round / between a chunk's records and its next launch
+    int n_launch_rounds = 0;
     while (n_flight > 0) {
       bool progressed = false;
       for (int c = 0; c < n_chunks; c++) {
         if (!cr[c].in_flight || !chunk_done(c)) continue;
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const double tb0 = m->sw.multi_timing ? now_s() : 0.0;
         progressed = true;
         cr[c].rounds++;
         const int i0 = c * CH, i1 = std::min(G, (c + 1) * CH);
@@ -520,7 +523,9 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
         const BatchArgs a = make_args(c, cr[c].seq);
         bool any_relin = false;
         for (int k = 0; k < a.n; k++) { any_relin = any_relin || (a.flags[k] & BF_RELIN); m->n_solves += (a.flags[k] & BF_ACTIVE) ? 2 : 0; m->n_relin += (a.flags[k] & BF_RELIN) ? 1 : 0; }
+        const double tb1 = m->sw.multi_timing ? now_s() : 0.0;
         int rc = run_round(a, geom[c], false, any_relin, stream_of(c)); if (rc != PPS_OK) { drain(); return rc; }
+        if (m->sw.multi_timing) { t_book += tb1 - tb0; t_launch += now_s() - tb1; n_launch_rounds++; }
       }
       if (progressed) { t_progress = now_s(); continue; }
       if (now_s() - t_progress > 2.0) {                        // (nothing for two seconds: let the streams drain, look once more)
@@ -548,6 +553,9 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     if (m->sw.multi_timing)
       fprintf(stderr, "pps_multi: G %d total %.3f ms, of which setup %.3f (per-graph checks %.3f, tables %.3f, geometry %.3f); %d rounds\n", G,
               1e3 * m->t_total, 1e3 * t_setup, 1e3 * t_s1, 1e3 * (t_s2 - t_s1), 1e3 * (t_setup - t_s2), m->rounds);
+    if (m->sw.multi_timing && n_launch_rounds > 0)
+      fprintf(stderr, "pps_multi: host side of %d chunk rounds: launches %.3f ms (%.1f us per round), verdicts + arguments %.3f ms (%.1f us per round)\n",
+              n_launch_rounds, 1e3 * t_launch, 1e6 * t_launch / n_launch_rounds, 1e3 * t_book, 1e6 * t_book / n_launch_rounds);
     for (int i = 0; i < G; i++) {
       pps_graph* g = m->gs[i];
       const LMD& q = lm[i];
