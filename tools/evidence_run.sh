@@ -3,10 +3,10 @@
 # Collects everything profiles/ holds for a round into gpurun_out/TAG/: the bench line; ONE rocprofv3 kernel summary PER WORKLOAD (C2,
 # C3, the frame loop, pps_multi at G = 128, the batched K1 sweeps) so that every roofline figure of the bench line can be recomputed
 # as bytes / mean duration of the named kernel in the matching summary; the C2 timeline; the PMC passes (K1 sweep traffic;
-# instruction mix / occupancy of the C2 and the pps_multi kernels; one front under the counters, this build and round 3's).
+# instruction mix / occupancy of the C2 and the pps_multi kernels; one front under the counters).
 # PMC passes run on their own, with --kernel-trace only.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-ROOT=$(pwd); tag=${1:-r5}; out=$ROOT/gpurun_out/$tag; raw=/tmp/evidence_$tag; mkdir -p $out $raw   # (raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
+ROOT=$(pwd); tag=${1:-r6}; out=$ROOT/gpurun_out/$tag; raw=/tmp/evidence_$tag; mkdir -p $out $raw   # (raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
 export TMPDIR=/tmp
 cd /tmp
 summary() {   # summary NAME -- cmd...: rocprofv3 kernel trace of the command, summarised into $out/kernel_stats_NAME.txt
@@ -20,17 +20,22 @@ summary() {   # summary NAME -- cmd...: rocprofv3 kernel trace of the command, s
 # 2. one kernel summary per workload
 summary c2 -- python $ROOT/tools/timeline_c2.py run                 # two LM solves of the C2 graph: nothing else
 python - $out $raw <<'PY'
-# K1 launches that left at their guard (a relinearisation queued behind two trials that were both rejected, or behind the last
-# trial of a solve) are dispatches too: the bench line's in-solve figure counts the sweeps that ran, so the summary gets that split
+# The K1 sweep of an LM iteration runs inside k_trial_lin (beside the two trials' retraction + chi2 blocks) at the trial point LM is predicted to
+# accept; k_linearize_lanes is the first linearisation of a solve and the one after a wrong prediction (a launch that left at its guard is a
+# dispatch too).  bench.py's roofline.avg_launch_us is the mean over the launches whose sweep LM used: the footer gives both kernels' figures.
 import sqlite3, sys, glob, os
 out, raw = sys.argv[1], sys.argv[2]
 db = sqlite3.connect(sorted(glob.glob(os.path.join(raw, "kt_c2", "**", "*.db"), recursive=True))[0])
-d = [r[0] / 1e3 for r in db.execute("select end - start from kernels where name like '%k_linearize_lanes%'")]
-if d:
-    cut = 0.7 * max(d); ran = [x for x in d if x >= cut]; left = [x for x in d if x < cut]
-    with open(os.path.join(out, "kernel_stats_c2.txt"), "a") as f:
-        f.write("\n# k_linearize_lanes: %d dispatches swept the graph, mean %.2f us (what bench.py's roofline.avg_launch_us measures); %d left at their guard, mean %.2f us\n"
+with open(os.path.join(out, "kernel_stats_c2.txt"), "a") as f:
+    t = [r[0] / 1e3 for r in db.execute("select end - start from kernels where name like '%k_trial_lin%'")]
+    if t: f.write("\n# k_trial_lin: %d dispatches, mean %.2f us (two trials + the predicted sweep in one launch)\n" % (len(t), sum(t) / len(t)))
+    d = [r[0] / 1e3 for r in db.execute("select end - start from kernels where name like '%k_linearize_lanes%'")]
+    if d:
+        cut = 0.7 * max(d); ran = [x for x in d if x >= cut]; left = [x for x in d if x < cut]
+        f.write("# k_linearize_lanes: %d dispatches swept the graph, mean %.2f us; %d left at their guard, mean %.2f us\n"
                 % (len(ran), sum(ran) / len(ran), len(left), sum(left) / max(1, len(left))))
+    n = db.execute("select count(*), sum(end - start) from kernels where name like '%pps::%'").fetchone()
+    f.write("# all pps kernels: %d dispatches, %.1f us\n" % (n[0], n[1] / 1e3))
 PY
 summary c3 -- python $ROOT/tools/ab_bench.py c3 3                   # C3 (incl. one solve of the one-step profiling loop)
 summary multi128 -- python $ROOT/tools/ab_bench.py multi 128 1      # G = 128 through pps_multi (level-per-launch kernels)
