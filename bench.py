@@ -414,7 +414,7 @@ def main():
         n_obs, n_odo = counts[synth.F_PLANE_OBS], counts[synth.F_ODOMETRY]
         bytes_per_launch = n_obs * B_PLANE_EDGE + n_odo * B_ODO_EDGE
         # K1 INSIDE a solve: every launch of one extra solve is made with hipExtLaunchKernelGGL, whose start / stop events carry
-        # the dispatch's own begin / end timestamps (what rocprofv3 reports for the kernel: profiles/r5_kernel_stats_c2.txt)
+        # the dispatch's own begin / end timestamps (what rocprofv3 reports for the kernel: profiles/r6_kernel_stats_c2.txt)
         k1_in_solve = k1_time / max(1, k1_launches)
         g.restore_state()
         k1_replay = g.time_linearize(mode, 400)             # 400 back-to-back launches between two events: hot caches
@@ -537,7 +537,11 @@ def main():
             fl, k3_bytes_c2 = factorisation_work(A)
             g.restore_state(); g.set_profiling(2); g.batch_optimize(); st2 = g.stats(); g.set_profiling(0)
             t_fac = st2["t_factor"] / max(1, st2["n_factorize"])
-            out["roofline_k3"] = {"bound": "mfma", "kernel": "k_band_factor_pre x %d + k_band_root<true, true> (top group of 4 + 2 + 1 fronts: factorisation and data-flow back-substitution in one launch)" % (int(A["n_stages"]) - 1),
+            whole_tree = int(A["n_groups"]) <= 512 and int(A["n_stages"]) >= 2       # (the rule of run_analysis, pps_upload.cpp: k_band_factor_all)
+            k3_kernel = ("k_band_factor_all (every band group of the tree is a workgroup of ONE launch; groups hand their update matrices over through "
+                         "per-front flags in global memory)" if whole_tree else
+                         "k_band_factor_pre x %d + k_band_root<true, true>" % (int(A["n_stages"]) - 1))
+            out["roofline_k3"] = {"bound": "mfma", "kernel": k3_kernel,
                                   "achieved": 2 * fl / (dual_factor_us * 1e-6) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                   "frac": 2 * fl / (dual_factor_us * 1e-6) / 1e12 / 78.6,
                                   "flops_per_factorisation": fl, "us_per_pair_of_factorisations": dual_factor_us,
@@ -545,14 +549,12 @@ def main():
                                                     "us_per_backsolve": 1e6 * st2["t_backsolve"] / max(1, st2["n_factorize"])},
                                   "hbm": {"bound": "hbm", "achieved": 2 * k3_bytes_c2 / (dual_factor_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": 2 * k3_bytes_c2 / (dual_factor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_factorisation": k3_bytes_c2},
-                                  "note": "the shipped dual-lambda loop factors H for lambda and lambda * 10 in the same launches: "
+                                  "note": "the shipped dual-lambda loop factors H for lambda and lambda * 10 in the same launch (blockIdx.y): "
                                           "us_per_pair_of_factorisations = sum of the dispatch durations of the factor launches of one "
-                                          "solve / number of launch sets (profiles/r5_kernel_stats_c2.txt: k_band_factor_pre, %d "
-                                          "launches per set, + k_band_root<true, true>, whose duration includes the top group's "
-                                          "back-substitution -- three tree levels, ~7 us: the figure is pessimistic by that much); one_step_loop = the profiling loop with one factorisation at a time "
-                                          "(unfused launches).  " 
-                                          "Latency bound by construction (511 fronts of <= 51 rows, 9 levels in three launches of three levels); peak = fp64 matrix "
-                                          "rate of MI355X (public spec; the CDNA4 guide lists none)" % (int(A["n_stages"]) - 1)}
+                                          "solve / number of launch sets (profiles/r6_kernel_stats_c2.txt: k_band_factor_all, one launch per set); "
+                                          "one_step_loop = the profiling loop with one factorisation at a time.  Latency bound by construction "
+                                          "(511 fronts of <= 51 rows, 9 tree levels: a chain of nine single-wave front latencies); peak = fp64 matrix "
+                                          "rate of MI355X (public spec; the CDNA4 guide lists none)"}
             # headroom on one GPU: one C2 solve keeps a few dozen of the 256 CUs busy, so independent graphs (one handle
             # + one host thread each, no shared state) overlap.  Reported next to the headline, which stays the
             # one-graph-per-GPU configuration BASELINE.json names.
@@ -619,13 +621,13 @@ def main():
                                          "achieved": bytes3 / k1_3_solve / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes3 / k1_3_solve / 1e9 / HBM_PEAK_GBS,
                                          "algorithmic_bytes_per_launch": bytes3, "avg_launch_us": 1e6 * k1_3_solve, "launches": s3d["n_linearize"],
                                          "replay_avg_launch_us": 1e6 * k1_3, "traffic": None,
-                                         "note": "inside the solve (dispatch timestamps); profiles/r5_kernel_stats_c3.txt"},
+                                         "note": "inside the solve (dispatch timestamps); profiles/r6_kernel_stats_c3.txt"},
                          "roofline_k3_hbm": {"bound": "hbm", "kernel": "k_band_factor_pre / k_band_factor<true> + k_band_factor_r5",
                                              "achieved": 2 * k3_bytes3 / pair3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": 2 * k3_bytes3 / pair3 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_factorisation": k3_bytes3,
                                              "us_per_factorisation_amortised": 1e6 * pair3 / 2, "factorisations": s3d["n_factorize"], "traffic": None,
                                              "note": "sum of the dispatch durations of the factor launches of one solve / factorisations done (adaptive "
-                                                     "speculation: most launch sets of C3 hold ONE factorisation); profiles/r5_kernel_stats_c3.txt"},
+                                                     "speculation: most launch sets of C3 hold ONE factorisation); profiles/r6_kernel_stats_c3.txt"},
                          "roofline_k3": {"bound": "mfma", "achieved": 2 * fl3 / pair3 / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": 2 * fl3 / pair3 / 1e12 / 78.6,
                                          "flops_per_factorisation": fl3}}
             g3.close()

@@ -71,10 +71,12 @@ def short_name(mangled):
 
 # the kernels of DESIGN.md section 5's register table, in its order: (name as the tool prints it, what the row says in addition)
 DESIGN_KERNELS = [
-    ("k_linearize_lanes", "K1, lane form"), ("k_linearize_obs_numeric", "K1, thread form: plane observations"),
+    ("k_trial_lin", "K4 + K1: both trials and the predicted lane-form sweep, C2's launch per LM pair"), ("k_linearize_lanes", "K1, lane form on its own"),
+    ("k_linearize_obs_numeric", "K1, thread form: plane observations"),
     ("kb_linearize<0, 0, true>", ""), ("kb_linearize<0, 1, false>", "odometry / priors, numeric"),
     ("k_hblocks2", "K2"), ("k_hfinish", ""), ("kb_hblocks_tc", "K2 of large batches: class bodies"), ("kb_hblocks_tg", "... the generic body"),
-    ("k_band_factor_pre", "C2: pre-assembling walk, NT 2-4"), ("k_band_root<true, true>", "top group: pre-assembling walk + data-flow back-substitution in one launch"), ("k_band_root<false, false>", "top group, plain walk / barrier form"),
+    ("k_band_factor_all", "the whole tree in one launch: C2, C5"), ("k_band_solve_all", "... and its back-substitution"),
+    ("k_band_factor_pre", "one band per launch, pre-assembling walk: C3"), ("k_band_root<true, true>", "top group: pre-assembling walk + data-flow back-substitution in one launch"), ("k_band_root<false, false>", "top group, plain walk / barrier form"),
     ("k_band_solve_flow", "data-flow back-substitution"), ("k_band_solve", "barrier form"),
     ("k_band_factor<true>", "plain walk"), ("k_band_factor<false>", "general: traces"), ("k_band_factor_r5", "fronts of 65-80 rows"),
     ("kb_band_factor<true>", ""), ("kb_band_factor_pre", ""), ("kb_level_factor2", ""), ("kb_level_factor3", ""), ("kb_level_factor4", ""),
