@@ -326,9 +326,9 @@ hipError_t launch_batch_restore(const RestoreRec* tab, int n, hipStream_t st);  
 hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // not-PD flags of both factorisations cleared
 hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st);   // state[..] <- x (+) delta_z, chi2 -> slots 1 / 2
 
-// patch upload: table of (dst offset, src offset, bytes, unit: 0 = multiple of 16 copied as int4, 1 = multiple of 8 copied word by
-// word) int64 quadruples at the head of `patch`
-hipError_t launch_scatter_patches(const char* patch, int n_patches, char* arena, hipStream_t st);
+// patch upload: `table` = (dst offset in the arena, src offset in src_base, bytes, unit: 0 = multiple of 16 copied as int4, 1 = multiple of 8 copied word by
+// word) int64 quadruples; table and src_base may be pinned host memory
+hipError_t launch_scatter_patches(const char* table, const char* src_base, int n_patches, char* arena, hipStream_t st);
 
 // Largest front (scalars incl. rhs row) the LDS path of the factor kernel accepts.
 int lds_front_limit();

@@ -133,8 +133,7 @@ struct pps_graph {
   std::unordered_map<std::string, double> up_laps;         // PPS_UPLOAD_TIMING=1: seconds per phase of upload_all, summed; printed at destroy
   struct UpPatch { size_t off, len; bool exact8 = false; };   // exact8: 8-byte granularity, nothing around the piece may be written
   std::vector<UpPatch> up_patches;
-  char* patch_host = nullptr; size_t patch_cap = 0;    // pinned: [table | data]
-  char* patch_dev = nullptr; size_t patch_dev_cap = 0;
+  char* patch_host = nullptr; size_t patch_cap = 0;    // pinned: the table of k_scatter_patches (the pieces are read from the pinned mirror)
   size_t up_bytes_sent = 0, up_bytes_total = 0;        // of the last flush (stats)
   double* host_result = nullptr;   // pinned, 12 doubles: chi2 at the linearisation point | trial | speculative trial
   double seq = 0.0;                // sequence number the chi2 kernel publishes last (host polls it)

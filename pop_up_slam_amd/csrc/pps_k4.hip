@@ -467,24 +467,25 @@ hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipSt
   return hipGetLastError();
 }
 
-// patch upload of a re-uploaded topology (pps_upload.cpp: flush_uploads): piece i of the patch buffer -> its place in the arena
-__global__ __launch_bounds__(256) void k_scatter_patches(const char* __restrict__ patch, char* __restrict__ arena) {
-  const long long* tab = reinterpret_cast<const long long*>(patch) + 4 * (size_t)blockIdx.x;
+// patch upload of a re-uploaded topology (pps_upload.cpp: flush_uploads): piece i of `src` (the pinned mirror of the arena, read over the bus)
+// -> its place in the arena; the table is in pinned host memory as well
+__global__ __launch_bounds__(256) void k_scatter_patches(const char* __restrict__ table, const char* __restrict__ src_base, char* __restrict__ arena) {
+  const long long* tab = reinterpret_cast<const long long*>(table) + 4 * (size_t)blockIdx.x;
   const long long dst = tab[0], src = tab[1], len = tab[2];
   if (tab[3]) {                  // an exact piece: 8-byte units (refreshed measurements sit right next to it)
-    const long long* s8 = reinterpret_cast<const long long*>(patch + src);
+    const long long* s8 = reinterpret_cast<const long long*>(src_base + src);
     long long* d8 = reinterpret_cast<long long*>(arena + dst);
     for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len / 8; i += (long long)gridDim.y * 256) d8[i] = s8[i];
     return;
   }
-  const int4* s4 = reinterpret_cast<const int4*>(patch + src);
+  const int4* s4 = reinterpret_cast<const int4*>(src_base + src);
   int4* d4 = reinterpret_cast<int4*>(arena + dst);
   for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < len / 16; i += (long long)gridDim.y * 256) d4[i] = s4[i];
 }
 
-hipError_t launch_scatter_patches(const char* patch, int n_patches, char* arena, hipStream_t st) {
+hipError_t launch_scatter_patches(const char* table, const char* src_base, int n_patches, char* arena, hipStream_t st) {
   if (n_patches <= 0) return hipSuccess;
-  PPS_LAUNCH(k_scatter_patches, dim3(n_patches, 8), dim3(256), 0, st, patch, arena);
+  PPS_LAUNCH(k_scatter_patches, dim3(n_patches, 8), dim3(256), 0, st, table, src_base, arena);
   return hipGetLastError();
 }
 

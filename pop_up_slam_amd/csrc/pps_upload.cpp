@@ -40,8 +40,7 @@ void release_arenas(pps_graph* g) {
   if (g->patch_host) (void)hipHostFree(g->patch_host);
   if (g->state_pin) (void)hipHostFree(g->state_pin);
   g->state_pin = nullptr; g->state_pin_cap = 0; g->pin_holds_est = false;
-  if (g->patch_dev) (void)hipFree(g->patch_dev);
-  g->patch_host = g->patch_dev = nullptr; g->patch_cap = g->patch_dev_cap = 0;
+  g->patch_host = nullptr; g->patch_cap = 0;
   g->up_slots.clear(); g->up_high = 0; g->up_unknown = true;
 }
 
@@ -88,39 +87,28 @@ int flush_uploads(pps_graph* g) {
     hi = std::max(hi, g->up_high); hi = std::min(hi, g->stage_cap);
     HIP_TRY(g, hipMemcpyAsync(g->up.base + lo, g->stage + lo, hi - lo, hipMemcpyHostToDevice, g->stream));
     g->up_bytes_sent = hi - lo;
-  } else if (g->up_patches.size() <= 3) {
-    for (const auto& pt : g->up_patches)        // a few pieces: straight from the pinned mirror
-      HIP_TRY(g, hipMemcpyAsync(g->up.base + pt.off, g->stage + pt.off, pt.len, hipMemcpyHostToDevice, g->stream));
   } else {
-    // [table: 4 x int64 per patch | data, 16-byte aligned pieces] -> one copy -> scatter kernel
+    // A table of (destination, source, bytes, unit) records in pinned host memory; k_scatter_patches reads the table AND the pieces -- straight
+    // from the pinned mirror, whose offsets are the arena's -- over the bus (round 6: no patch buffer, no host copy of the pieces into it, no
+    // copy launch in front of the kernel: 1.7 copies of 63 KB per frame of the frame loop).  Piece lengths are rounded up to 16 bytes except
+    // where the bytes behind a piece may be newer on the device than in the mirror (exact8).
     const size_t np = g->up_patches.size();
-    size_t need = np * 32;
-    std::vector<size_t> src_off(np);
-    auto plen = [&](size_t i) { const auto& pt = g->up_patches[i]; return pt.exact8 ? pt.len : ((pt.len + 15) & ~size_t(15)); };   // (exact pieces are multiples of 8)
-    for (size_t i = 0; i < np; i++) { need = (need + 15) & ~size_t(15); src_off[i] = need; need += plen(i); }
+    const size_t need = np * 32;
     if (need > g->patch_cap) {
       if (g->patch_host) (void)hipHostFree(g->patch_host);
       g->patch_host = nullptr; g->patch_cap = 0;
-      const size_t cap = std::max<size_t>(1 << 16, 2 * need);
+      const size_t cap = std::max<size_t>(1 << 12, 2 * need);
       HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->patch_host), cap, hipHostMallocDefault));
       g->patch_cap = cap;
-    }
-    if (need > g->patch_dev_cap) {
-      if (g->patch_dev) (void)hipFree(g->patch_dev);
-      g->patch_dev = nullptr; g->patch_dev_cap = 0;
-      const size_t cap = std::max<size_t>(1 << 16, 2 * need);
-      HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->patch_dev), cap));
-      g->patch_dev_cap = cap;
     }
     long long* tab = reinterpret_cast<long long*>(g->patch_host);
     for (size_t i = 0; i < np; i++) {
       const auto& pt = g->up_patches[i];
-      tab[4 * i + 0] = (long long)pt.off; tab[4 * i + 1] = (long long)src_off[i]; tab[4 * i + 2] = (long long)plen(i); tab[4 * i + 3] = pt.exact8 ? 1 : 0;
-      memcpy(g->patch_host + src_off[i], g->stage + pt.off, plen(i));    // the mirror already holds the new bytes
+      const size_t len = pt.exact8 ? pt.len : ((pt.len + 15) & ~size_t(15));      // (exact pieces are multiples of 8; the arena's capacity is a multiple of 16)
+      tab[4 * i + 0] = (long long)pt.off; tab[4 * i + 1] = (long long)pt.off; tab[4 * i + 2] = (long long)len; tab[4 * i + 3] = pt.exact8 ? 1 : 0;
     }
-    HIP_TRY(g, hipMemcpyAsync(g->patch_dev, g->patch_host, need, hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(g, launch_scatter_patches(g->patch_dev, (int)np, g->up.base, g->stream));
-    // (the mirror and the patch buffer are written again by the next upload_all, which begins and ends with a stream sync)
+    HIP_TRY(g, launch_scatter_patches(g->patch_host, g->stage, (int)np, g->up.base, g->stream));
+    // (table and mirror are written again by the next upload_all / refresh, which wait for the stream first: up_inflight)
   }
   g->up_unknown = false;
   g->up_patches.clear();
