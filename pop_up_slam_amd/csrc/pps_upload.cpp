@@ -560,6 +560,10 @@ int upload_all(pps_graph* g) {
     }
   }
   lap("1b measurements");
+  // the analysis is host work on host tables: it runs while the device finishes what the last frame left on the stream (the measurement
+  // refresh of a frame loop: the opening sync below waited 10 us per frame for it)
+  if (!g->analyzed || g->analysis_stale) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
+  lap("3 analysis");
   HIP_TRY(g, hipStreamSynchronize(g->stream));
   g->up_inflight = false;
   lap("1c opening stream sync");
@@ -571,8 +575,6 @@ int upload_all(pps_graph* g) {
   g->frames_dirty = true;
   g->snap_pose = g->snap_plane = nullptr; g->upload_version++;
   lap("2 free_device");
-  if (!g->analyzed || g->analysis_stale) { rc = run_analysis(g); if (rc != PPS_OK) return rc; }
-  lap("3 analysis");
   const Analysis& A = g->an;
   DevGraph& d = g->dev;
   // the mirror holds the arrays of the analysis this one was built upon: its kept parts are not compared again
