@@ -214,7 +214,8 @@ hipError_t launch_band_root(const DevGraph& d, const DualAlt* alt, int grp, int 
 // both trials of a dual solve: out_k <- base (+) delta_k, chi2 and |delta|^2 of each into its own result record
 hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
-                             double seq1, hipStream_t st);
+                             double seq1, hipStream_t st, int n_trials = 2);
+// (n_trials = 1: the first trial only -- the step of pps_update, retraction + chi2 in one launch; alt and the second set of arguments are not read)
 // the same + K1 (lane form) at trial point sl.which into sl's buffers, one launch (k_trial_lin); ev0 / ev1: the dispatch's start / stop
 hipError_t launch_trial_lin(const DevGraph& d, const DualAlt& alt, const SpecLin& sl, const double* base_pose, const double* base_plane, double* out_pose0,
                             double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,

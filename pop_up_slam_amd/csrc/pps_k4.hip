@@ -265,13 +265,13 @@ __global__ __launch_bounds__(kChiBlock) void k_trial_dual(DevGraph d, DualAlt al
 
 hipError_t launch_trial_dual(const DevGraph& d, const DualAlt& alt, const double* base_pose, const double* base_plane, double* out_pose0,
                              double* out_plane0, double* out_pose1, double* out_plane1, double* host_result0, double seq0, double* host_result1,
-                             double seq1, hipStream_t st) {
+                             double seq1, hipStream_t st, int n_trials) {
   const int n = d.n_pose + d.n_plane;
   const int nb_obs = cdiv(d.n_obs, kChiBlock), nb_odo = cdiv(d.n_odo, kChiBlock), nb_pp = cdiv(d.n_pp, kChiBlock), nb_lp = cdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
   if (nb == 0 || n == 0) return hipErrorInvalidValue;
   const int nb_ret = cdiv(n, 256);
-  PPS_LAUNCH(k_trial_dual, dim3(nb_ret + nb, 2), dim3(kChiBlock), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1, nb_ret,
+  PPS_LAUNCH(k_trial_dual, dim3(nb_ret + nb, n_trials), dim3(kChiBlock), 0, st, d, alt, base_pose, base_plane, out_pose0, out_plane0, out_pose1, out_plane1, nb_ret,
              nb_obs, nb_odo, nb_pp, nb, host_result0, seq0, host_result1, seq1);
   return hipGetLastError();
 }

@@ -265,10 +265,22 @@ static int update_impl(pps_graph* g) {
   rc = copy_state(g, true); if (rc != PPS_OK) return rc;          // estimate_to_linpoint (Optimizer.cpp:116)
   rc = do_linearize(g); if (rc != PPS_OK) return rc;              // jacobian() (:119)
   rc = do_solve(g, 0.0); if (rc != PPS_OK) return rc;             // compute_gauss_newton_step, lambda = 0 (:122)
-  { PhaseTimer t(g, &g->stats.t_retract_chi2); HIP_TRY(g, launch_retract_apply(g->dev, g->stream)); }   // apply_exmap (:183)
-  rc = enqueue_state_download(g); if (rc != PPS_OK) return rc;   // (arrives with read_result's synchronisation)
-  double chi2, dn; bool notpd;
-  rc = read_result(g, true, &chi2, &dn, &notpd); if (rc != PPS_OK) return rc;
+  // apply_exmap (:183) and chi2 at the new estimate in ONE launch (round 6: the trial kernel of the LM loop with one trial -- the retraction
+  // blocks write est <- lin (+) delta, the chi2 blocks evaluate at lin (+) delta on the fly, same bits; it was k_retract + k_chi2)
+  double chi2 = 0.0, dn = 0.0; bool notpd = false;
+  if (g->n_live_factors > 0 && g->dev.n_pose + g->dev.n_plane > 0) {
+    const DevGraph& d = g->dev;
+    { PhaseTimer t(g, &g->stats.t_retract_chi2);
+      HIP_TRY(g, launch_trial_dual(d, DualAlt{}, d.pose_lin, d.plane_lin, d.pose_est, d.plane_est, nullptr, nullptr, g->host_result, 0.0, nullptr, 0.0, g->stream, 1)); }
+    rc = enqueue_state_download(g); if (rc != PPS_OK) return rc;   // (arrives with the synchronisation below)
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    chi2 = g->host_result[0]; dn = std::sqrt(g->host_result[1]); notpd = g->host_result[2] != 0.0;
+    if (g->host_result[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag of the data-flow back-substitution never arrived (the step was discarded)");
+  } else {
+    { PhaseTimer t(g, &g->stats.t_retract_chi2); HIP_TRY(g, launch_retract_apply(g->dev, g->stream)); }
+    rc = enqueue_state_download(g); if (rc != PPS_OK) return rc;
+    rc = read_result(g, true, &chi2, &dn, &notpd); if (rc != PPS_OK) return rc;
+  }
   resolve_k1_events(g);
   if (notpd) {
     // the step is garbage: put the estimate back (lin still holds it) instead of handing NaNs to the caller
