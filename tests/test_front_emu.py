@@ -112,7 +112,7 @@ def test_fronts_of_65_to_80_rows_both_ways(emu):
 
 
 def test_four_column_panels(emu):
-    """the register-only band kernels run the same code with one pivot block per panel step (PPS_PANEL_W_BAND = 4: a lone wave per
+    """the register-only band kernels run the same code with one pivot block per panel step (kPanelWBand = 4, pps_k3.hip: a lone wave per
     SIMD is bound by the pivot chain, and two 4-column steps are shorter than one 8-column step there)"""
     for p, b in [(1, 2), (4, 8), (6, 8), (13, 0), (15, 33), (18, 30), (27, 36), (33, 30), (48, 15), (63, 0)]:
         _check(emu, p, b, 0, False, seed=p, w=4)
