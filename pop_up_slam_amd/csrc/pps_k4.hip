@@ -413,33 +413,29 @@ __global__ __launch_bounds__(64) void kb_begin_dual(BatchArgs a) {
   if (threadIdx.x < 4) { d.result_dev[threadIdx.x] = 0.0; al.result_dev[threadIdx.x] = 0.0; }
 }
 
-__global__ __launch_bounds__(256) void kb_retract_dual(BatchArgs a) {
+// both trials of every graph of the chunk in one launch (grid z = trial): blocks [0, nb_ret) of a graph's row write the trial's copy of the
+// state, x (+) delta_z, and their |delta|^2 partials; the rest reduce chi2 at x (+) delta_z computed on the spot, like k_trial_dual (the stored
+// copy is for the next K1).  kb_chi2_finish sums the partials a kernel boundary later.  (Two launches up to round 5: kb_retract_dual, kb_chi2_dual.)
+__global__ __launch_bounds__(kChiBlock) void kb_trial_dual(BatchArgs a, int nb_ret) {
   __shared__ double red[4];
   PPS_BATCH_PROLOGUE(BF_ACTIVE)
-  if ((int)blockIdx.x * 256 >= d.n_pose + d.n_plane) return;
   const BatchAlt al = load_alt(a.alt + a.b0 + b);
   const int xs = a.xsel[b], z = blockIdx.z;
   const int ts = (xs + 1 + z) % 3;
   DevGraph d2 = d;
-  if (z) { d2.delta = al.delta; d2.dn_partials = al.dn_partials; }
-  body_retract_to(d2, pose_lin, plane_lin, sel3(al.pose, ts), sel3(al.plane, ts), blockIdx.x, red);
-}
-
-__global__ __launch_bounds__(kChiBlock) void kb_chi2_dual(BatchArgs a) {
-  PPS_BATCH_PROLOGUE(BF_ACTIVE)
+  if (z) { d2.delta = al.delta; d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.ticket = al.ticket; d2.result_dev = al.result_dev; }
+  if ((int)blockIdx.x < nb_ret) {
+    if ((int)blockIdx.x * 256 >= d.n_pose + d.n_plane) return;
+    body_retract_to(d2, pose_lin, plane_lin, sel3(al.pose, ts), sel3(al.plane, ts), blockIdx.x, red);
+    return;
+  }
   const int nb_obs = dcdiv(d.n_obs, kChiBlock), nb_odo = dcdiv(d.n_odo, kChiBlock), nb_pp = dcdiv(d.n_pp, kChiBlock),
             nb_lp = dcdiv(d.n_lp, kChiBlock);
   const int nb = nb_obs + nb_odo + nb_pp + nb_lp;
-  if ((int)blockIdx.x >= nb) return;
-  const BatchAlt al = load_alt(a.alt + a.b0 + b);
-  const int xs = a.xsel[b], z = blockIdx.z;
-  const int ts = (xs + 1 + z) % 3;
-  (void)ts;
-  DevGraph d2 = d;
-  if (z) { d2.delta = al.delta; d2.chi2_partials = al.chi2_partials; d2.dn_partials = al.dn_partials; d2.ticket = al.ticket; d2.result_dev = al.result_dev; }
-  // chi2 at x (+) delta_z computed on the spot, like k_trial_dual (the stored copy kb_retract_dual writes is for the next K1)
+  const int bx = (int)blockIdx.x - nb_ret;
+  if (bx >= nb) return;
   body_chi2<false, true>(d2, pose_lin, plane_lin, nb_obs, nb_odo, nb_pp, dcdiv(d.n_pose + d.n_plane, 256),
-                         a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, blockIdx.x, nb);
+                         a.results + 12 * (size_t)(a.b0 + b) + 4 * (1 + z), a.seq, bx, nb);
 }
 
 // pps_multi_restore_state: the snapshots of n graphs back into their estimates, one launch (tab: n records in pinned host memory)
@@ -461,8 +457,8 @@ hipError_t launch_batch_begin_dual(const BatchArgs& a, const BatchGeom& g, hipSt
 
 hipError_t launch_batch_trial_dual(const BatchArgs& a, const BatchGeom& g, hipStream_t st) {
   if (g.chi2 <= 0) return hipErrorInvalidValue;
-  if (g.retract > 0) PPS_LAUNCH(kb_retract_dual, dim3(g.retract, a.n, 2), dim3(256), 0, st, a);
-  PPS_LAUNCH(kb_chi2_dual, dim3(g.chi2, a.n, 2), dim3(kChiBlock), 0, st, a);
+  static_assert(kChiBlock == 256, "the retraction blocks of kb_trial_dual are 256 nodes wide");
+  PPS_LAUNCH(kb_trial_dual, dim3(g.retract + g.chi2, a.n, 2), dim3(kChiBlock), 0, st, a, g.retract);
   PPS_LAUNCH(kb_chi2_finish, dim3(1, a.n, 2), dim3(kChiBlock), 0, st, a, 0, 1);
   return hipGetLastError();
 }

@@ -1219,7 +1219,24 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
     {
       A.cls_off.assign((size_t)A.n_levels * 3 + 1, 0);
       A.cls_fronts.assign(F, 0);
-      auto cls_of = [&](int s2) { const int f = A.f_p[s2] + A.f_b[s2]; return f <= 32 ? 0 : (f <= 48 ? 1 : 2); };
+      // size class of a front = tile rows of the level kernel that takes it (kb_level_factor2 / 3 / 4).  A class that holds a handful of a
+      // level's fronts next to sixteen times as many of the next class is merged into that class: a launch of its own costs its latency
+      // (10 us for four fronts of a C2 tree's leaf level), the larger kernel runs a smaller front at the price of its empty tiles.
+      std::vector<int> raw((size_t)A.n_levels * 3, 0);
+      auto rows_cls = [&](int s2) { const int f = A.f_p[s2] + A.f_b[s2]; return f <= 32 ? 0 : (f <= 48 ? 1 : 2); };
+      for (int s2 = 0; s2 < F; s2++) raw[(size_t)A.f_level[s2] * 3 + rows_cls(s2)]++;
+      std::vector<signed char> up((size_t)A.n_levels * 3, 0);          // class c of level l runs as class up[3 l + c]
+      for (int l = 0; l < A.n_levels; l++) {
+        int* r = &raw[(size_t)l * 3];
+        signed char* u = &up[(size_t)l * 3];
+        u[0] = 0; u[1] = 1; u[2] = 2;
+        if (r[1] > 0 && r[1] * 16 <= r[2]) { u[1] = 2; r[2] += r[1]; r[1] = 0; }
+        if (r[0] > 0) {
+          if (r[1] > 0 && r[0] * 16 <= r[1]) u[0] = 1;
+          else if (r[1] == 0 && r[2] > 0 && r[0] * 16 <= r[2]) u[0] = 2;
+        }
+      }
+      auto cls_of = [&](int s2) { return (int)up[(size_t)A.f_level[s2] * 3 + rows_cls(s2)]; };
       for (int i = 0; i < F; i++) { const int s2 = A.glvl_fronts[i]; A.cls_off[(size_t)A.f_level[s2] * 3 + cls_of(s2) + 1]++; }
       for (size_t k = 0; k + 1 < A.cls_off.size(); k++) A.cls_off[k + 1] += A.cls_off[k];
       std::vector<int> w(A.cls_off.begin(), A.cls_off.end() - 1);
