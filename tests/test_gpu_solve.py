@@ -251,14 +251,16 @@ def test_fronts_of_65_to_80_rows(built, mk, monkeypatch):
     h.close()
 
 
-def test_lm_loop_forms_are_bit_identical(built, monkeypatch):
-    """The LM loop as shipped -- both damping values of a linearisation in the same launches, the next linearisation queued
-    behind the trials with the accept test repeated on the device -- against the same loop without the queued linearisation
-    (PPS_NO_SPEC_LIN=1) and the one-step-at-a-time loop with its speculation stream (PPS_NO_DUAL=1): same trials, same chi2,
-    same state, bit for bit; and it needs about half the launches."""
+@pytest.mark.parametrize("which", ["300p", "c2"])
+def test_lm_loop_forms_are_bit_identical(built, monkeypatch, which):
+    """The LM loop as shipped -- both damping values of a linearisation in the same launches, the next linearisation computed INSIDE the
+    trial launch at the trial point LM is predicted to accept (k_trial_lin; its H blocks behind it with the accept test repeated on the
+    device) -- against the same loop without anything computed ahead of the verdict (PPS_NO_SPEC_LIN=1) and the one-step-at-a-time loop
+    (PPS_NO_DUAL=1): same trials, same chi2, same state, bit for bit; and it needs about half the launches.  c2: the headline graph, where
+    the prediction fails five times in 32 and the plain sweep takes over."""
     import os
     suite_wide = os.environ.get("PPS_NO_DUAL") or os.environ.get("PPS_NO_SPEC_LIN")   # (the whole suite is also run with a switch set)
-    spec = synth.corridor(300, 60, seed=4)
+    spec = synth.corridor(300, 60, seed=4) if which == "300p" else synth.corridor()
     runs = []
     for env in (None, "PPS_NO_SPEC_LIN", "PPS_NO_DUAL"):
         if env:
