@@ -88,6 +88,25 @@ def test_analysis_invariants_c2(built):
     assert st["n_fronts"] == A["n_fronts"] and st["n_levels"] == A["n_levels"]
 
 
+def test_fronts_fit_the_register_tiles_of_one_wave(built):
+    """AnalysisParams::front_rows = 63 (round 6): the dissection keeps every front within the 63 rows (+ rhs) one wave holds in register tiles
+    where a cut position exists that allows it -- C2 outright, C3 but for two fronts that sit between two 24-row ancestor separators
+    (DESIGN section 8), and EVERY frame of the C5 loop (one incremental analysis per frame, aligned cuts): the fifteen-tile kernel of the
+    65 .. 80-row fronts never runs there.  No GPU: the topology of the frame loop replayed into a handle (tools/c5_fronts_cpu.py)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import c5_fronts_cpu
+    g = P.Graph(); synth.corridor().replay(g); g.analyze()
+    A = g.analysis_dump()
+    assert (A["f_p"] + A["f_b"]).max() <= 51 and A["n_levels"] == 9
+    g = P.Graph(); synth.manhattan_rooms().replay(g); g.analyze()
+    A = g.analysis_dump()
+    rows = A["f_p"] + A["f_b"]
+    assert (rows > 63).sum() <= 2 and rows.max() <= 69 and A["n_levels"] <= 13
+    worst, over, A = c5_fronts_cpu.replay(400)
+    assert worst <= 63 and not any(over)
+
+
 def test_reanalysis_after_topology_change(built):
     spec = synth.small_world(12, 4, seed=2)
     g = P.Graph(); nid, fid = spec.replay(g); g.analyze()
