@@ -26,7 +26,8 @@ Switches read_switches() {
   s.verify_upload = on("PPS_DEBUG_VERIFY_UPLOAD");
   s.multi_levels = on("PPS_MULTI_LEVELS");
   s.multi_thread_form = on("PPS_MULTI_THREAD_FORM");
-  s.debug_drop_flag = on("PPS_DEBUG_DROP_FLAG");
+  s.debug_drop_flag = (int)num("PPS_DEBUG_DROP_FLAG", 0);
+  if (on("PPS_DEBUG_DROP_FLAG") && s.debug_drop_flag < 1) s.debug_drop_flag = 1;
   s.trace = (int)num("PPS_TRACE", 0);
   if (on("PPS_TRACE") && s.trace < 1) s.trace = 1;
   {

@@ -106,7 +106,7 @@ struct DevGraph {
 // pps_multi_create / pps_popup_create ... call read_switches() -- and never on a launch path: a handle keeps the schedule it was
 // created with whatever the environment does later (A/B tools and the parity tests set the variable before they create the handle).
 constexpr double kStatusInternal = 64.0;   // result_dev[2] at or above this: an internal time-out inside a kernel (PPS_EHIP), not a not-PD pivot
-enum : unsigned { SW_K1_THREAD_FORM = 1u, SW_NO_SOLVE_FLOW = 2u, SW_NO_ROOT_FUSE = 4u, SW_DEBUG_DROP_FLAG = 8u };
+enum : unsigned { SW_K1_THREAD_FORM = 1u, SW_NO_SOLVE_FLOW = 2u, SW_NO_ROOT_FUSE = 4u, SW_DEBUG_DROP_FLAG = 8u, SW_DEBUG_DROP_XFLAG = 16u };
 // Fifteen variables (INTEGRATION.md lists them): each one selects a path that some graph shape takes anyway (so the parity tests can put every
 // graph through it) or a diagnostic.  A/B switches of experiments whose losing side was deleted do not exist.
 struct Switches {
@@ -123,7 +123,8 @@ struct Switches {
   bool no_incr_compact = false;     // PPS_NO_INCR_COMPACT: compacted tables rebuilt per analysis
   bool verify_upload = false;       // PPS_DEBUG_VERIFY_UPLOAD: read the arena back after every flush, compare every skipped prefix
   bool multi_levels = false, multi_thread_form = false;   // PPS_MULTI_LEVELS / PPS_MULTI_THREAD_FORM: the throughput forms on small batches
-  bool debug_drop_flag = false;     // PPS_DEBUG_DROP_FLAG: the data-flow back-substitution withholds one hand-over flag (tests the time-out path)
+  int debug_drop_flag = 0;          // PPS_DEBUG_DROP_FLAG (tests of the time-out path): 1 = the data-flow back-substitution withholds the hand-over flag of every
+                                    // group's top front (LDS), 2 = the whole-tree factor launch withholds the flag a group's top front raises for its parent's workgroup
   int trace = 0;                    // PPS_TRACE: 1 = phase timestamps of the factorisation, 2 = of the back-substitution
   // PPS_TIMING=<bits>: host-side timing printed to stderr -- 1 analysis phases, 2 upload phases, 4 pps_multi totals, 8 pps_multi rounds
   bool analysis_timing = false, upload_timing = false;
@@ -132,7 +133,7 @@ struct Switches {
   long long multi_thread_factors = 200000;   // PPS_MULTI_THREAD_FACTORS: factors per chunk above which a batch takes the throughput forms
   unsigned dev_bits() const {
     return (k1_thread_form ? SW_K1_THREAD_FORM : 0u) | (no_solve_flow ? SW_NO_SOLVE_FLOW : 0u) | (no_root_fuse ? SW_NO_ROOT_FUSE : 0u) |
-           (debug_drop_flag ? SW_DEBUG_DROP_FLAG : 0u);
+           (debug_drop_flag == 1 ? SW_DEBUG_DROP_FLAG : 0u) | (debug_drop_flag == 2 ? SW_DEBUG_DROP_XFLAG : 0u);
   }
 };
 Switches read_switches();           // pps_api.cpp: the only place of the library that calls getenv

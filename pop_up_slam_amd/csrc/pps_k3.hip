@@ -1082,7 +1082,8 @@ __device__ __forceinline__ void body_band_factor_pre(const DevGraph& d, int g, d
       if (fa <= 33) front_eliminate_out<2, false, false, kPanelWBand>(d, rec, F, F);
       else if (fa <= 49) front_eliminate_out<3, false, false, kPanelWBand>(d, rec, F, F);
       else front_eliminate_out<4, false, false, kPanelWBand>(d, rec, F, F);
-      if (XG) { if (__builtin_amdgcn_readlane(rec, 13) >= 0) xg_post(*xg, __builtin_amdgcn_readlane(rec, 0)); }      // (slot 13: the parent's front when another group holds it)
+      // (slot 13: the parent's front when another group holds it; SW_DEBUG_DROP_XFLAG, tests only: the flag is withheld and the parent's workgroup runs into its time-out)
+      if (XG) { if (__builtin_amdgcn_readlane(rec, 13) >= 0 && !(d.sw & SW_DEBUG_DROP_XFLAG)) xg_post(*xg, __builtin_amdgcn_readlane(rec, 0)); }
     } else if (ll == pre_at && up_ll > pre_at) {
       // nothing to eliminate on this level: the part of the upper front's assembly that needs no child
       crv = front_orig_entries_sized(d, up_rec, lane, 1.0 + lambda, F, tr);

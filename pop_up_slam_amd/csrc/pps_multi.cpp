@@ -510,7 +510,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
             const double* rr = m->results + 12 * (size_t)i;
             if (rr[4 + 2] >= kStatusInternal || rr[8 + 2] >= kStatusInternal) {
               drain();
-              return mfail(m, PPS_EHIP, "graph " + std::to_string(i) + ": internal error: a hand-over flag of the data-flow back-substitution never arrived");
+              return mfail(m, PPS_EHIP, "graph " + std::to_string(i) + ": internal error: a hand-over flag between the waves or workgroups of a K3 launch never arrived");
             }
           }
           if (!lm[i].done) advance(i); else { lm[i].active = false; lm[i].relin = false; }

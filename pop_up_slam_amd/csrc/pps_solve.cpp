@@ -154,7 +154,7 @@ int wait_result(pps_graph* g, volatile double* slot, double seq, hipStream_t pro
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   // status word of the solve that produced the record: 0 ok | 1 not positive definite | >= 64 an internal hand-over of the
   // back-substitution timed out (flow_wait, pps_k3.hip) -- the numbers of this record are not a solution
-  if (slot[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag of the data-flow back-substitution never arrived (the step was discarded)");
+  if (slot[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag between the waves or workgroups of a K3 launch never arrived (the step was discarded)");
   return PPS_OK;
 }
 
@@ -193,7 +193,7 @@ int read_result(pps_graph* g, bool at_estimate, double* chi2, double* dnorm, boo
   *chi2 = g->host_result[0];
   if (dnorm) *dnorm = std::sqrt(g->host_result[1]);
   if (notpd) *notpd = g->host_result[2] != 0.0;
-  if (g->host_result[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag of the data-flow back-substitution never arrived (the step was discarded)");
+  if (g->host_result[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag between the waves or workgroups of a K3 launch never arrived (the step was discarded)");
   return PPS_OK;
 }
 
@@ -275,7 +275,7 @@ static int update_impl(pps_graph* g) {
     rc = enqueue_state_download(g); if (rc != PPS_OK) return rc;   // (arrives with the synchronisation below)
     HIP_TRY(g, hipStreamSynchronize(g->stream));
     chi2 = g->host_result[0]; dn = std::sqrt(g->host_result[1]); notpd = g->host_result[2] != 0.0;
-    if (g->host_result[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag of the data-flow back-substitution never arrived (the step was discarded)");
+    if (g->host_result[2] >= kStatusInternal) return fail(g, PPS_EHIP, "internal error: a hand-over flag between the waves or workgroups of a K3 launch never arrived (the step was discarded)");
   } else {
     { PhaseTimer t(g, &g->stats.t_retract_chi2); HIP_TRY(g, launch_retract_apply(g->dev, g->stream)); }
     rc = enqueue_state_download(g); if (rc != PPS_OK) return rc;

@@ -161,6 +161,16 @@ def test_upload_forms(default_run):
     assert got["frames"] == default_run["frames"]
 
 
+def test_tree_flag_timeout_fails_loudly(built):
+    """the whole tree in one factor launch: a band group's top front that never raises the flag its parent's workgroup waits for (global memory,
+    PPS_DEBUG_DROP_FLAG=2) -- the bounded spin runs out, the status word is raised, PPS_EHIP comes back from the LM solve and from the update"""
+    import pop_up_slam_amd as P
+    got = _run("drop", PPS_DEBUG_DROP_FLAG=2)["drop"]
+    for k in ("single", "update"):
+        assert got[k] != "returned", k
+        assert got[k][0] == P.PPS_EHIP and "hand-over flag" in got[k][1], (k, got[k])
+
+
 def test_flow_timeout_fails_loudly(built):
     """a hand-over flag of the data-flow back-substitution that never arrives: the waiting wave gives up after its bounded spin, raises
     the status word, and every solve entry returns PPS_EHIP with a message -- never a step computed from a stale solution"""
