@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 
 B_PLANE_EDGE = 392   # 152 B read + 240 B written per pose-plane edge linearisation
 B_ODO_EDGE = 840     # 216 B read + 624 B written per odometry edge
+B_TRIAL_EDGE = 176   # K4: one edge's residual at a trial point
 HBM_PEAK_GBS = 8000.0
 
 
@@ -426,6 +427,10 @@ def main():
                     "launches": k1_launches, "avg_launch_us": k1_in_solve * 1e6,
                     "replay_avg_launch_us": k1_replay * 1e6, "replay_launches": 400,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                    # the same launches with the trials' own work counted as well: k_trial_lin also evaluates every edge at both trial points
+                    # (K4: 176 B per edge and trial) -- given for transparency, `frac` above counts the sweep alone
+                    "frac_incl_trial_bytes": ((bytes_per_launch + 2 * B_TRIAL_EDGE * (n_obs + n_odo)) / k1_in_solve / 1e9 / HBM_PEAK_GBS
+                                              if (mode == P.JAC_NUMERIC and k1_in_solve > 0) else None),
                     "note": "K1 of the C2 graph inside an LM solve, on the solver's stream: mean dispatch duration (start / stop "
                             "events of hipExtLaunchKernelGGL = the kernel's own begin / end timestamps) over every launch of one "
                             "solve whose sweep became a linearisation LM used.  Since round 6 that launch is k_trial_lin: the sweep "
