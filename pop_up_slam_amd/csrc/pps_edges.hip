@@ -214,10 +214,20 @@ constexpr int kEmitRowsPerGroup = kRowThreads / 64;
 // segments, a shuffle scan places the runs, and the lane classifies its cells a second time to write them in order.
 __global__ __launch_bounds__(kRowThreads) void k_cells_emit(const unsigned char* __restrict__ img, int w, int h,
                                                             const int* __restrict__ row_count, int* __restrict__ next_row_count, int n_counters,
-                                                            pps_edges_host::CellSeg* __restrict__ segs) {
+                                                            pps_edges_host::CellSeg* __restrict__ segs, pps_edges_host::CellSeg* __restrict__ host_segs,
+                                                            int host_cap, int* __restrict__ host_total) {
   // the counters of the next call (k_label_close accumulates into zeros); all of them: the next map may be larger
   for (int r = blockIdx.x * kRowThreads + threadIdx.x; r < n_counters; r += gridDim.x * kRowThreads) next_row_count[r] = 0;
   const int lane = threadIdx.x & 63;
+  // (round 6) the segments also go straight into pinned host memory -- the first host_cap of them, which is all of them for any real
+  // contour -- and the first wave leaves their number there: the caller synchronises once and reads, no copy of the row counters and
+  // no second copy sized by them
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    int tot = 0;
+    for (int r = lane; r + 1 < h; r += 64) tot += row_count[r];
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) host_total[0] = tot;
+  }
   const int r0 = blockIdx.x * kEmitRowsPerGroup + (threadIdx.x >> 6);
   if (r0 + 1 >= h || row_count[r0] == 0) return;   // most rows hold no boundary
   int above = 0;
@@ -234,8 +244,8 @@ __global__ __launch_bounds__(kRowThreads) void k_cells_emit(const unsigned char*
   if (n == 0) return;
   for (int c = c_begin; c < c_end; c++) {
     const int k = cell_segments(img, w, r0, c, tmp);
-    if (k > 0) segs[at] = tmp[0];
-    if (k > 1) segs[at + 1] = tmp[1];
+    if (k > 0) { segs[at] = tmp[0]; if (at < host_cap) host_segs[at] = tmp[0]; }
+    if (k > 1) { segs[at + 1] = tmp[1]; if (at + 1 < host_cap) host_segs[at + 1] = tmp[1]; }
     at += k;
   }
 }
@@ -252,8 +262,10 @@ struct pps_edges {
   int* d_row_count[2] = {nullptr, nullptr};   // height each; alternate between calls (the idle one is zeroed by k_cells_emit)
   int flip = 0;
   pps_edges_host::CellSeg* d_segs = nullptr;   // 2 (width - 1)(height - 1)
+  pps_edges_host::CellSeg* h_segs = nullptr;   // pinned: the first h_cap segments as k_cells_emit writes them
+  int h_cap = 0;
+  int* h_total = nullptr;                      // pinned: number of segments of the last call
   int pre_w = 0, pre_h = 0;
-  std::vector<int> row_count;
   std::vector<pps_edges_host::CellSeg> segs;
   pps_edges_host::Contour contour;
   double last_kernel_s = 0;
@@ -295,6 +307,9 @@ int pps_edges_create(int device, int width, int height, pps_edges** out) {
     if (st == hipSuccess) st = hipMemset(e->d_row_count[k], 0, sizeof(int) * (size_t)height);
   }
   if (st == hipSuccess) st = hipMalloc(reinterpret_cast<void**>(&e->d_segs), sizeof(pps_edges_host::CellSeg) * 2 * px);
+  e->h_cap = (int)std::min<size_t>(2 * px, (size_t)1 << 18);        // 2 MB of pinned memory at most; more segments than that take the copy
+  if (st == hipSuccess) st = hipHostMalloc(reinterpret_cast<void**>(&e->h_segs), sizeof(pps_edges_host::CellSeg) * (size_t)e->h_cap, hipHostMallocDefault);
+  if (st == hipSuccess) st = hipHostMalloc(reinterpret_cast<void**>(&e->h_total), 2 * sizeof(int), hipHostMallocDefault);
   if (st != hipSuccess) { pps_edges_destroy(e); return PPS_EHIP; }
   *out = e;
   return PPS_OK;
@@ -305,6 +320,8 @@ int pps_edges_destroy(pps_edges* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   (void)hipFree(e->d_label); (void)hipFree(e->d_pre); (void)hipFree(e->d_row_count[0]); (void)hipFree(e->d_row_count[1]); (void)hipFree(e->d_segs);
+  if (e->h_segs) (void)hipHostFree(e->h_segs);
+  if (e->h_total) (void)hipHostFree(e->h_total);
   if (e->ev[0]) (void)hipEventDestroy(e->ev[0]);
   if (e->ev[1]) (void)hipEventDestroy(e->ev[1]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -346,23 +363,21 @@ int pps_edges_select(pps_edges* e, const unsigned char* label_map, int label_on_
   if (kd == 11 && ke == 11) hipLaunchKernelGGL((k_label_close<11, 11>), grid, dim3(kCloseThreads), lds_bytes, e->stream, ca);
   else if (kd == 8 && ke == 8) hipLaunchKernelGGL((k_label_close<8, 8>), grid, dim3(kCloseThreads), lds_bytes, e->stream, ca);
   else hipLaunchKernelGGL((k_label_close<0, 0>), grid, dim3(kCloseThreads), lds_bytes, e->stream, ca);
-  hipLaunchKernelGGL(k_cells_emit, dim3((h - 1 + kEmitRowsPerGroup - 1) / kEmitRowsPerGroup), dim3(kRowThreads), 0, e->stream, e->d_pre, w, h, rc, rc_next, e->height, e->d_segs);
+  hipLaunchKernelGGL(k_cells_emit, dim3((h - 1 + kEmitRowsPerGroup - 1) / kEmitRowsPerGroup), dim3(kRowThreads), 0, e->stream, e->d_pre, w, h, rc, rc_next, e->height, e->d_segs, e->h_segs, e->h_cap, e->h_total);
   EHIP(e, hipGetLastError());
   EHIP(e, hipEventRecord(e->ev[1], e->stream));
   try {
-    e->row_count.resize((size_t)h - 1);
-    EHIP(e, hipMemcpyAsync(e->row_count.data(), rc, sizeof(int) * (size_t)(h - 1), hipMemcpyDeviceToHost, e->stream));
-    EHIP(e, hipStreamSynchronize(e->stream));
-    size_t nseg = 0;
-    for (int c : e->row_count) nseg += (size_t)c;
-    e->segs.resize(nseg);
-    if (nseg) {
-      EHIP(e, hipMemcpyAsync(e->segs.data(), e->d_segs, sizeof(pps_edges_host::CellSeg) * nseg, hipMemcpyDeviceToHost, e->stream));
-      EHIP(e, hipStreamSynchronize(e->stream));
+    EHIP(e, hipStreamSynchronize(e->stream));                    // the one synchronisation of the call: count and segments are in pinned memory
+    const size_t nseg = (size_t)std::max(0, e->h_total[0]);
+    const pps_edges_host::CellSeg* segs = e->h_segs;
+    if (nseg > (size_t)e->h_cap) {                                // (more boundary cells than the pinned block holds: the copy, sized by the count)
+      e->segs.resize(nseg);
+      EHIP(e, hipMemcpy(e->segs.data(), e->d_segs, sizeof(pps_edges_host::CellSeg) * nseg, hipMemcpyDeviceToHost));
+      segs = e->segs.data();
     }
     float ms = 0;
     if (hipEventElapsedTime(&ms, e->ev[0], e->ev[1]) == hipSuccess) e->last_kernel_s = 1e-3 * ms;
-    e->contour = pps_edges_host::ground_contour(e->segs.data(), (int)nseg, prm.downsample_contour ? 2.0f : 1.0f);
+    e->contour = pps_edges_host::ground_contour(segs, (int)nseg, prm.downsample_contour ? 2.0f : 1.0f);
     if (e->contour.xy.empty()) return PPS_OK;
     const pps_edges_host::Selection sel = pps_edges_host::select(e->contour.xy, e->width, e->height, lsd_lines, n_lines, prm);
     *n_open = (int)sel.open_segs.size() / 4;
