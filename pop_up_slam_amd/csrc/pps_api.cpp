@@ -93,6 +93,7 @@ int pps_graph_destroy(pps_graph* g) {
     if (g->d_queries) (void)hipFree(g->d_queries);
     if (g->d_results) (void)hipFree(g->d_results);
     if (g->d_lm_planes) (void)hipFree(g->d_lm_planes);
+    if (g->rp_pin) (void)hipHostFree(g->rp_pin);
     (void)hipStreamDestroy(g->stream);
   }
   delete g;

@@ -230,18 +230,26 @@ int pps_reproject_points(pps_graph* g, int n, const int* plane_ids, const float*
   if (n == 0) return PPS_OK;
   int rc = prepare_solve(g);
   if (rc != PPS_OK) return rc;
-  std::vector<int> slot(n);
+  // one pinned block [slots | points in | points out] that the kernel reads and writes over the bus (every element once): no allocation, no
+  // copy and one synchronisation per call (up to round 5: three hipMalloc / hipFree pairs and three copies per call)
+  const size_t off_in = ((size_t)n * sizeof(int) + 15) & ~size_t(15), off_out = off_in + (((size_t)3 * n * sizeof(float) + 15) & ~size_t(15));
+  const size_t need = off_out + (size_t)3 * n * sizeof(float);
+  if (need > g->rp_cap) {
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (g->rp_pin) (void)hipHostFree(g->rp_pin);
+    g->rp_pin = nullptr; g->rp_cap = 0;
+    const size_t cap = std::max<size_t>(1 << 14, 2 * need);
+    HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->rp_pin), cap, hipHostMallocDefault));
+    g->rp_cap = cap;
+  }
+  int* slot = reinterpret_cast<int*>(g->rp_pin);
+  float* p_in = reinterpret_cast<float*>(g->rp_pin + off_in);
+  float* p_out = reinterpret_cast<float*>(g->rp_pin + off_out);
   for (int i = 0; i < n; i++) slot[i] = live_node(g, plane_ids[i], NODE_PLANE) ? g->nodes[plane_ids[i]].slot : -1;
-  int* d_slot = nullptr; float *d_in = nullptr, *d_out = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_slot), (size_t)n * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)3 * n * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)3 * n * sizeof(float));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_slot, slot.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, g->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_in, pts_xyz, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, g->stream);
-  if (e == hipSuccess) e = launch_reproject(n, d_slot, d_in, g->dev.plane_est, g->dev.plane_ld, d_out, g->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(out_xyz, d_out, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost, g->stream);
+  std::memcpy(p_in, pts_xyz, (size_t)3 * n * sizeof(float));
+  hipError_t e = launch_reproject(n, slot, p_in, g->dev.plane_est, g->dev.plane_ld, p_out, g->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-  (void)hipFree(d_slot); (void)hipFree(d_in); (void)hipFree(d_out);
+  if (e == hipSuccess) std::memcpy(out_xyz, p_out, (size_t)3 * n * sizeof(float));
   if (e != hipSuccess) return hip_fail(g, e, "pps_reproject_points");
   return PPS_OK;
 }

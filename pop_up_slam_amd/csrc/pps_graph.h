@@ -188,6 +188,7 @@ struct pps_graph {
   pps::AssocLandmark* d_lms = nullptr; size_t d_lms_cap = 0;
   pps::AssocQuery* d_queries = nullptr; pps::AssocResult* d_results = nullptr; size_t d_q_cap = 0;
   double* d_lm_planes = nullptr; size_t d_lm_planes_cap = 0;   // [4][n] landmark planes when the solver state is not current
+  char* rp_pin = nullptr; size_t rp_cap = 0;                  // pinned block of pps_reproject_points: [slots | points in | points out], read and written by the kernel
   // stats / trace
   pps_stats stats{};
   std::vector<double> tr_lambda, tr_chi2;
