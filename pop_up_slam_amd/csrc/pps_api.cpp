@@ -90,8 +90,9 @@ int pps_graph_destroy(pps_graph* g) {
     for (hipEvent_t e : g->k1_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->fk_events) (void)hipEventDestroy(e);
     if (g->d_lms) (void)hipFree(g->d_lms);
-    if (g->d_queries) (void)hipFree(g->d_queries);
-    if (g->d_results) (void)hipFree(g->d_results);
+    if (g->h_lms) (void)hipHostFree(g->h_lms);
+    if (g->d_queries) (void)hipHostFree(g->d_queries);
+    if (g->d_results) (void)hipHostFree(g->d_results);
     if (g->d_lm_planes) (void)hipFree(g->d_lm_planes);
     if (g->rp_pin) (void)hipHostFree(g->rp_pin);
     (void)hipStreamDestroy(g->stream);

@@ -169,11 +169,15 @@ int pps_find_closest_planes(pps_graph* g, const double est_pose[7], int frame_se
   }
   if (g->lms_dirty || g->lms_upload_version != (state_current ? g->upload_version : -2)) {
     if ((size_t)nl > g->d_lms_cap) {
+      HIP_TRY(g, hipStreamSynchronize(g->stream));
       if (g->d_lms) (void)hipFree(g->d_lms);
+      if (g->h_lms) (void)hipHostFree(g->h_lms);
+      g->d_lms = nullptr; g->h_lms = nullptr;
       g->d_lms_cap = std::max<size_t>(256, 2 * (size_t)nl);
       HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->d_lms), g->d_lms_cap * sizeof(AssocLandmark)));
+      HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->h_lms), g->d_lms_cap * sizeof(AssocLandmark), hipHostMallocDefault));
     }
-    std::vector<AssocLandmark> rec(nl);
+    AssocLandmark* rec = g->h_lms;       // (pinned; the copy below has ended when this call returns: the call ends with a stream synchronisation)
     for (int i = 0; i < nl; i++) {
       const pps_graph::Landmark& L = g->lms[i];
       const HostNode& nd = g->nodes[L.plane_id];
@@ -181,34 +185,35 @@ int pps_find_closest_planes(pps_graph* g, const double est_pose[7], int frame_se
       rec[i].frame_plane_indice = L.fpi; rec[i].frame_seq_id = L.seq; rec[i].deleted = L.deleted;
       memcpy(rec[i].seg2d, L.seg2d, sizeof L.seg2d); memcpy(rec[i].seg3d, L.seg3d, sizeof L.seg3d);
     }
-    HIP_TRY(g, hipMemcpyAsync(g->d_lms, rec.data(), rec.size() * sizeof(AssocLandmark), hipMemcpyHostToDevice, g->stream));
-    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    HIP_TRY(g, hipMemcpyAsync(g->d_lms, rec, (size_t)nl * sizeof(AssocLandmark), hipMemcpyHostToDevice, g->stream));
     g->lms_dirty = false;
     g->lms_upload_version = state_current ? g->upload_version : -2;
   }
   if ((size_t)n > g->d_q_cap) {
-    if (g->d_queries) (void)hipFree(g->d_queries);
-    if (g->d_results) (void)hipFree(g->d_results);
+    HIP_TRY(g, hipStreamSynchronize(g->stream));
+    if (g->d_queries) (void)hipHostFree(g->d_queries);
+    if (g->d_results) (void)hipHostFree(g->d_results);
+    g->d_queries = nullptr; g->d_results = nullptr;
     g->d_q_cap = std::max<size_t>(64, 2 * (size_t)n);
-    HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->d_queries), g->d_q_cap * sizeof(AssocQuery)));
-    HIP_TRY(g, hipMalloc(reinterpret_cast<void**>(&g->d_results), g->d_q_cap * sizeof(AssocResult)));
+    HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->d_queries), g->d_q_cap * sizeof(AssocQuery), hipHostMallocDefault));
+    HIP_TRY(g, hipHostMalloc(reinterpret_cast<void**>(&g->d_results), g->d_q_cap * sizeof(AssocResult), hipHostMallocDefault));
   }
-  std::vector<AssocQuery> q(n);
+  // the queries of a frame (a few hundred bytes) and their results live in pinned host memory: the kernel reads and writes them over the bus,
+  // the call synchronises once (round 6; it was a pageable copy each way)
+  AssocQuery* q = g->d_queries;
   for (int i = 0; i < n; i++) {
     memcpy(q[i].plane_local, planes_local + 4 * i, 4 * sizeof(double));
     memcpy(q[i].seg2d, seg2d + 4 * i, 4 * sizeof(float)); memcpy(q[i].seg3d, seg3d_xy + 4 * i, 4 * sizeof(float));
     q[i].frame_plane_indice = frame_plane_indice[i]; q[i].frame_seq_id = frame_seq_id;
     memset(q[i].pad, 0, sizeof q[i].pad);
   }
-  HIP_TRY(g, hipMemcpyAsync(g->d_queries, q.data(), q.size() * sizeof(AssocQuery), hipMemcpyHostToDevice, g->stream));
   a.n_queries = n; a.n_landmarks = nl; a.queries = g->d_queries; a.landmarks = g->d_lms; a.results = g->d_results;
   memcpy(a.pose, est_pose, sizeof a.pose);
   a.edge_asso_2ddist = P.edge_asso_2ddist; a.edge_asso_planedist = P.edge_asso_planedist;
   a.edge_asso_proj = P.edge_asso_proj; a.edge_asso_angle = P.edge_asso_angle; a.assoc_near_frames = P.assoc_near_frames;
   HIP_TRY(g, launch_assoc(a, g->stream));
-  std::vector<AssocResult> r(n);
-  HIP_TRY(g, hipMemcpyAsync(r.data(), g->d_results, r.size() * sizeof(AssocResult), hipMemcpyDeviceToHost, g->stream));
   HIP_TRY(g, hipStreamSynchronize(g->stream));
+  const AssocResult* r = g->d_results;
   for (int i = 0; i < n; i++) {
     best_plane_id[i] = r[i].best >= 0 ? g->lms[r[i].best].plane_id : -1;
     best_err[i] = r[i].err;

@@ -186,7 +186,8 @@ struct pps_graph {
   bool lms_dirty = true;
   int lms_upload_version = -1;       // upload_version the slots of d_lms were resolved against
   pps::AssocLandmark* d_lms = nullptr; size_t d_lms_cap = 0;
-  pps::AssocQuery* d_queries = nullptr; pps::AssocResult* d_results = nullptr; size_t d_q_cap = 0;
+  pps::AssocLandmark* h_lms = nullptr;                        // pinned staging of d_lms (same capacity): the copy is not waited for on its own
+  pps::AssocQuery* d_queries = nullptr; pps::AssocResult* d_results = nullptr; size_t d_q_cap = 0;   // PINNED host memory: k_assoc reads the queries and writes the results over the bus
   double* d_lm_planes = nullptr; size_t d_lm_planes_cap = 0;   // [4][n] landmark planes when the solver state is not current
   char* rp_pin = nullptr; size_t rp_cap = 0;                  // pinned block of pps_reproject_points: [slots | points in | points out], read and written by the kernel
   // stats / trace
