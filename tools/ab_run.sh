@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/ab_run.sh OUTDIR [quick]  -- parity suite + the standard A/B lines (one GPU call)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-out=gpurun_out/${1:-r3x}; mkdir -p $out
+out=gpurun_out/${1:-ab}; mkdir -p $out
 export TMPDIR=/tmp
 if [ "$2" = "quick" ]; then
   timeout 300 python -m pytest tests/test_gpu_solve.py tests/test_gpu_multi.py tests/test_gpu_edge_cases.py -m gpu -x -q > $out/pytest.log 2>&1
