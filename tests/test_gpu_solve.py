@@ -66,6 +66,9 @@ def test_gauss_newton_update_matches_oracle(built, mk):
     o.update()
     c, co = g.chi2(), o.chi2()
     assert abs(c - co) <= 1e-8 * abs(co), (c, co)
+    # the chi2 the update reports was reduced at lin (+) delta on the fly, inside the launch that wrote the new estimate (round 6); the chi2
+    # kernel reads that estimate back: the same residuals, the same bits
+    assert g.stats()["chi2_final"] == c
     for a, b in zip(nid, onid):
         if spec.node_type[list(nid).index(a)] == synth.NODE_POSE:
             np.testing.assert_allclose(g.get_pose(int(a)), o.get_pose(int(b)), atol=1e-8)
