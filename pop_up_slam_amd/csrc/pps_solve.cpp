@@ -377,15 +377,16 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
                 lam * prop.lm_lambda_factor};
     have_next = use_alt;
     if (!use_alt) {
-      // one damping value: the single-lambda launches; the trial kernel still walks both copies (the second one's step is a stale
-      // delta: finite, never read -- have_next is false)
+      // one damping value: the single-lambda launches, and the trial kernel with ONE trial (round 6: it used to walk both copies, the second
+      // one with a stale delta that nothing read -- twice the retraction and chi2 work of a launch that C3 pays 22 us for; have_next is false,
+      // the second record is never waited for)
       { const int rc2 = enqueue_factor_solve(g, d, nullptr, lam, g->stream, g->profiling == 1); if (rc2 != PPS_OK) return rc2; }
       g->stats.n_factorize += 1;
       g->seq += 1.0; seqs[0] = g->seq;
       g->seq2 += 1.0; seqs[1] = g->seq2;
       if (fuse_lin) return enqueue_trial_lin(alt, seqs[0], seqs[1]);
       HIP_TRY(g, launch_trial_dual(d, alt, d.pose_lin, d.plane_lin, t_pose[0], t_plane[0], t_pose[1], t_plane[1], slot[0], seqs[0], slot[1], seqs[1],
-                                   g->stream));
+                                   g->stream, 1));
       return PPS_OK;
     }
     { const int rc2 = enqueue_factor_solve(g, d, &alt, lam, g->stream, g->profiling == 1); if (rc2 != PPS_OK) return rc2; }
@@ -404,7 +405,9 @@ static int lm_solve_dual(pps_graph* g, int* iterations, double t0) {
   // Accept-branch speculation: the relinearisation that follows an accepted step is queued behind the trials before their
   // verdict is known; its kernels apply the accept test themselves (LinGuard) and pick the accepted copy, so the device does
   // not idle for the host round trip between chi2 and K1.
-  const bool spec_lin = !g->sw.no_spec_lin && !fuse_lin;
+  // (not on a graph that fills the GPU by itself -- `adaptive` --: there the queued launches cost more than the host round trip they hide; C3, same
+  // box, three runs each: 358-361 us per LM iteration with them, 352-354 without)
+  const bool spec_lin = !g->sw.no_spec_lin && !fuse_lin && !adaptive;
   int spec_pair = -1;                    // K1 event pair of the queued speculative linearisation
   auto enqueue_spec_lin = [&](double err) -> int {
     if (!spec_lin) return PPS_OK;
