@@ -452,7 +452,7 @@ def main():
         pmc = pmc_js.get("kernels", {})
         roofline_batched = {}
         # numeric_lanes: the lane-parallel central differences (3 plane observations per wavefront) -- the form a graph below
-        # 200 000 factors runs; numeric: one thread per factor (large batches); analytic: closed-form Jacobians
+        # 200 000 factors (a batch chunk below 120 000) runs; numeric: one thread per factor (large batches); analytic: closed-form Jacobians
         for mname, mcode in (("analytic", P.JAC_ANALYTIC), ("numeric_lanes", 2), ("numeric", P.JAC_NUMERIC)):
             (sec_all, sec_pl, sec_od), npl, nod = g.bench_sweep(mcode, reps, 10)
             ent = {}

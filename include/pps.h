@@ -127,7 +127,7 @@ int pps_chi2(pps_graph* g, double* chi2);
  * One C2-size LM solve is a dependency chain that occupies a few dozen of the 256 CUs.  pps_multi runs
  * Optimizer::levenberg_marquardt (Optimizer.cpp:371-467) on n independent graphs in rounds: every kernel of an LM
  * trial is launched once for a chunk of up to 128 graphs, lambda / accept / reject stay per graph (host side, one 32-byte record per
- * graph and round).  While a chunk holds at most 200 000 factors, arithmetic, lambda schedule, iteration count and trace of every
+ * graph and round).  While a chunk holds at most 120 000 factors, arithmetic, lambda schedule, iteration count and trace of every
  * graph are exactly -- bit for bit -- those of its own pps_batch_optimize.  A larger chunk takes the throughput forms (K1 as one
  * thread per factor without product records, K2 multiplying the Jacobian slices): the same sums in another rounding order, H and
  * chi2 equal to about 1e-12 relative, LM verdicts and iteration counts the same on every graph measured; which chunk a graph

@@ -36,7 +36,7 @@ Switches read_switches() {
     s.analysis_timing = (tm & 1) != 0; s.upload_timing = (tm & 2) != 0; s.multi_timing = (tm & 8) ? 2 : ((tm & 4) ? 1 : 0);
   }
   s.multi_split = (int)num("PPS_MULTI_SPLIT", 0);
-  s.multi_thread_factors = num("PPS_MULTI_THREAD_FACTORS", 200000);
+  s.multi_thread_factors = num("PPS_MULTI_THREAD_FACTORS", 120000);
   return s;
 }
 }  // namespace pps

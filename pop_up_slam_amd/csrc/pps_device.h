@@ -130,7 +130,9 @@ struct Switches {
   bool analysis_timing = false, upload_timing = false;
   int multi_timing = 0;             //   (0 off, 1 totals, 2 rounds)
   int multi_split = 0;              // PPS_MULTI_SPLIT: chunks a batch is cut into (0 = by size)
-  long long multi_thread_factors = 200000;   // PPS_MULTI_THREAD_FACTORS: factors per chunk above which a batch takes the throughput forms
+  long long multi_thread_factors = 120000;   // PPS_MULTI_THREAD_FACTORS: factors per chunk above which a batch takes the throughput forms (round 6: 120 000,
+                                             // measured on C2-size graphs -- G = 16 (96 k factors) 1 198 graphs/s in the latency forms against 1 136, G = 24 (144 k)
+                                             // 1 229 against 1 401, G = 32 1 384 against 1 581; it was 200 000)
   unsigned dev_bits() const {
     return (k1_thread_form ? SW_K1_THREAD_FORM : 0u) | (no_solve_flow ? SW_NO_SOLVE_FLOW : 0u) | (no_root_fuse ? SW_NO_ROOT_FUSE : 0u) |
            (debug_drop_flag == 1 ? SW_DEBUG_DROP_FLAG : 0u) | (debug_drop_flag == 2 ? SW_DEBUG_DROP_XFLAG : 0u);

@@ -222,14 +222,15 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
   int n_cu = 256;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
   // Large batches are split into two or three chunks of equal size that advance on their own streams: the launches of a chunk's upper tree
-  // levels hold a few hundred wavefronts each and leave most of the device to the other chunks' kernels.  A chunk keeps at least 250 000
-  // factors -- below 200 000 its kernels would be the latency forms (G = 96 as 3 x 32: 57.4 ms per batch solve against 48.5 as 2 x 48;
-  // G = 64 as 2 x 32: 39.7 against 37.5 in one chunk; G = 128 as 3 x 43: 60.4 against 61.6 as 2 x 64).  (Event-timed profiling
-  // keeps one stream and whole chunks: the phases must not overlap.)
+  // levels hold a few hundred wavefronts each and leave most of the device to the other chunks' kernels.  A chunk keeps at least 120 000
+  // factors -- below that its kernels would be the latency forms.  Round 6 (with the throughput forms from 120 000 factors per chunk on, same
+  // box, graphs/s): G = 40 as 1 chunk 1 724, as 2 x 20 1 809; G = 48 1 845 / 1 935; G = 64 1 950 / 2 091; G = 72 as 2 / 3 chunks 2 163 / 2 155;
+  // G = 80 2 220 / 2 199; G = 96 2 234 / 2 269; G = 128 2 314 / 2 346 -- two chunks from 240 000 factors, three from 560 000.  (Event-timed
+  // profiling keeps one stream and whole chunks: the phases must not overlap.)
   long long total_factors = 0;
   for (int i = 0; i < G; i++) total_factors += m->gs[i]->n_live_factors;
   const int n_split = m->sw.multi_split > 0 ? std::min(3, m->sw.multi_split)      // (PPS_MULTI_SPLIT: the multi-chunk scheduler on a small batch -- tests)
-                                            : (int)std::min<long long>(3, std::max<long long>(1, total_factors / 250000));
+                                            : (total_factors >= 560000 ? 3 : (total_factors >= 240000 ? 2 : 1));
   const bool two_streams = n_split > 1 && !m->profiling;
   const int CH = two_streams ? std::min(kBatchMax, (G + n_split - 1) / n_split) : kBatchMax;
   const int n_chunks = (G + CH - 1) / CH;
@@ -287,7 +288,7 @@ static int multi_optimize(pps_multi* m, int* iterations, int* status) {
     for (int l = 0; l < 64; l++) if (lvl_direct_bad[l]) q.lvl_direct_pp[l] = 0;
     // the lane-parallel central differences (32 lanes per factor, 13 of them idle) are the low-latency form; from a few
     // hundred thousand factors per launch the thread-per-factor form has the higher throughput
-    const long long thr = m->sw.multi_thread_factors;          // 200 000 (PPS_MULTI_THREAD_FACTORS lowers it for the tests)
+    const long long thr = m->sw.multi_thread_factors;          // 120 000 (PPS_MULTI_THREAD_FACTORS lowers it for the tests)
     q.lin_thread_form = q.n_factors_total > thr || m->sw.multi_thread_form;      // (PPS_MULTI_THREAD_FORM / PPS_MULTI_LEVELS: forced onto small batches by the parity test)
     // throughput over latency from the same size on: a launch per tree level and size class instead of a launch per band
     q.level_form = level_ok && (q.n_factors_total > thr || m->sw.multi_levels);

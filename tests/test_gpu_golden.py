@@ -126,7 +126,7 @@ def test_fixtures_through_pps_multi(built):
 
 
 def test_fixtures_through_the_level_forms_of_pps_multi(built, monkeypatch):
-    """the throughput forms a batch of > 200 000 factors takes (thread-form K1, class-body K2, one launch per tree level), forced
+    """the throughput forms a batch of > 120 000 factors takes (thread-form K1, class-body K2, one launch per tree level), forced
     onto the fixture batch"""
     monkeypatch.setenv("PPS_MULTI_LEVELS", "1")
     monkeypatch.setenv("PPS_K1_THREAD_FORM", "1")
