@@ -387,9 +387,12 @@ static int run_analysis_impl(pps_graph* g) {
     // The whole tree in one factor launch + one back-substitution launch (k_band_factor_all / k_band_solve_all, round 6): every stage takes the
     // pre-assembling walk on register-resident fronts, the data-flow back-substitution holds a group of any stage, and the groups fit the chip
     // a few times over -- a graph of thousands of groups (C3) keeps a launch per stage: its upper workgroups would sit on wave slots its leaves
-    // need.
+    // need.  Measured over corridor graphs of 500 .. 3 500 poses (tools/size_probe.py, same box, us per LM iteration, whole tree | a launch per
+    // band): 75 groups and fewer (up to 1 250 poses; C2 and every frame of C5: 73) 52.2 | 55.9, 56.5 | 57.3, 82.0 | 88.3; 127 groups and
+    // more 87.7 | 77.0, 81.4 | 71.0, 85.5 | 74.9, 140.8 | 110.2 (every group's top front releases at agent scope, every waiting group acquires:
+    // hundreds of L2 write-backs and invalidations inside one launch instead of one per band): at most 100 groups (it was 512).
     g->k3_all = false;
-    if (g->use_band && A.n_stages >= 2 && g->sw.trace == 0 && !g->sw.no_preassemble && !g->sw.no_solve_flow && !g->sw.no_root_fuse && A.n_groups <= 512) {
+    if (g->use_band && A.n_stages >= 2 && g->sw.trace == 0 && !g->sw.no_preassemble && !g->sw.no_solve_flow && !g->sw.no_root_fuse && A.n_groups <= 100) {
       bool ok = true;
       int nwf = 1, mf = 0, mp = 1, mg = 1;
       for (int st = 0; st < A.n_stages; st++) {
