@@ -881,7 +881,23 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   lap("boundaries");
   // ---- band schedule ----
   {
-    const int Bn = std::max(1, prm.band_levels);
+    // levels per band.  Given, or (0) chosen here from what the tree turned out to be -- measured on one MI355X, us per LM iteration, corridor
+    // graphs (tools/size_probe.py; builds with a fixed depth): up to 2 250 poses three levels per band (1 000 poses 57.8 against 62.7 with four,
+    // 2 000 poses 75.2 / 78.1, 2 250 poses 84.2 / 88.8); from there on FOUR (2 500 poses 108.7 -> 95.9, 3 000 101.7 -> 87.8, 3 900 99.9 -> 87.3, and
+    // against the two levels of rounds 3 - 5: 4 000 poses 107.5 -> 91.4, 6 000 142.9 -> 128.4, 8 000 140.3 -> 124.4, 12 000 184.8 -> 172.1) --
+    // unless a front needs the fifteen-tile kernel, which a band of four levels would put under more fronts (C3: 357 us with two, 369 with four).
+    int Bn = std::max(0, prm.band_levels);
+    if (Bn == 0) {
+      int n_poses = 0, widest = 0;
+      for (int u = 0; u < N; u++) n_poses += nodes[u].type == NODE_POSE ? 1 : 0;
+      for (int s = 0; s < F; s++) {
+        int rows = A.f_p[s];
+        for (int v : bnd[s]) rows += nodes[v].dim;
+        widest = std::max(widest, rows);
+      }
+      Bn = n_poses < 2400 ? 3 : (prm.front_rows > 0 && widest > prm.front_rows ? 2 : 4);
+    }
+    A.band_levels = Bn;
     A.n_stages = (A.n_levels + Bn - 1) / Bn;
     std::vector<int> grp(F, -1), ll(F, 0);
     std::vector<int> grp_stage;
@@ -946,7 +962,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
   A.max_front = 0;
   for (int s = 0; s < F; s++) {
     A.max_front = std::max(A.max_front, A.f_p[s] + A.f_b[s]);
-    const int st = A.f_level[s] / std::max(1, prm.band_levels);
+    const int st = A.f_level[s] / std::max(1, A.band_levels);
     A.stage_max_front[st] = std::max(A.stage_max_front[st], A.f_p[s] + A.f_b[s]);
   }
   // child -> parent scatter maps: a kept front whose parent is kept as well keeps its map; the children of redone fronts
@@ -1201,7 +1217,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
       r[15] = A.f_cmap_off[s2];
       {
         const int par = A.f_parent[s2];
-        const int Bn2 = std::max(1, prm.band_levels);
+        const int Bn2 = std::max(1, A.band_levels);
         // slot = position inside the group (groups are contiguous in glvl_fronts: grp_first = first position of the group's
         // first local level)
         if (par >= 0 && A.f_level[par] / Bn2 == A.f_level[s2] / Bn2) r[14] = pos_of[par] - grp_first[pos_of[par]];
@@ -1212,7 +1228,7 @@ int analyze_with(const std::vector<SymNode>& nodes, const std::vector<SymFactor>
         const int bc1 = A.f_b[c] + 1;
         int cr[8] = {bc1 * (bc1 + 1) / 2, (int)(A.f_Uoff[c] & 0xffffffffLL), (int)(A.f_Uoff[c] >> 32),
                      (int)(A.f_ea_off[c] & 0xffffffffLL), (int)(A.f_ea_off[c] >> 32), c,
-                     A.f_level[c] / std::max(1, prm.band_levels) != A.f_level[s2] / std::max(1, prm.band_levels) ? 1 : 0, 0};      // slot 6: the child belongs to another band group
+                     A.f_level[c] / std::max(1, A.band_levels) != A.f_level[s2] / std::max(1, A.band_levels) ? 1 : 0, 0};      // slot 6: the child belongs to another band group
         A.crec.insert(A.crec.end(), cr, cr + 8);
       }
     }

@@ -40,7 +40,7 @@ struct AnalysisParams {
                            // balanced, cost-driven cuts give the smaller fronts on a graph that is analysed once
   int max_pivots = 48;     // split supernodes with more pivot scalars into a chain
   int seg_len = 32;        // contributions reduced per wave in the H-block kernel
-  int band_levels = 3;     // tree levels walked by one workgroup inside one launch ("band")
+  int band_levels = 3;     // tree levels walked by one workgroup inside one launch ("band"); 0 = chosen by the analysis from the tree (Analysis::band_levels)
   int ordering = 0;        // 0 = pose-chain dissection, minimum degree as well when its fronts exceed band_rows (cheaper wins);
                            // 1 = minimum degree only; 2 = chain dissection only
   int band_rows = 127;     // largest front of the wave-per-front kernels: graphs beyond it skip the packed extend-add lists
@@ -93,6 +93,7 @@ struct Analysis {
 
   // ---- band schedule: levels [B*s, B*s+B) form stage s; inside a stage the connected sub-trees are
   // "groups", each walked by ONE workgroup (one wave per front, workgroup barrier between local levels) ----
+  int band_levels = 3;     // levels per band of this analysis (AnalysisParams::band_levels, or the automatic choice)
   int n_stages = 0, n_groups = 0, n_glevels = 0;
   std::vector<int> stage_grp_off;    // [n_stages+1] -> groups
   std::vector<int> grp_lvl_off;      // [n_groups+1] -> local levels

@@ -276,7 +276,7 @@ static int run_analysis_impl(pps_graph* g) {
   // eight waves has a wave for every front, so every separator front is assembled ahead of its level while the leaves are eliminated,
   // and the top group -- levels 6 .. 8 of C2's nine -- is factored and solved by one launch with the data-flow back-substitution:
   // 60.9 against 63.7 us per C2 LM iteration with 4, same box.)
-  g->aprm.band_levels = g->pose_ids.size() >= 4000 ? 2 : 3;
+  g->aprm.band_levels = 0;        // chosen by the analysis from the tree: three levels per band below 2 400 poses, four above -- two where a front needs the fifteen-tile kernel (pps_symbolic.cpp)
   // H-block segments (contributions reduced by one wave of K2): short on small graphs, where the few long segments
   // (ground plane, 32 contributions = 16 dependent load rounds) are K2's critical path; long on large ones, where the
   // number of waves is (C2: 23.3 -> 18.7 us with 8; C3: 82 -> 102 us)
@@ -314,7 +314,7 @@ static int run_analysis_impl(pps_graph* g) {
   }
   {
     const Analysis& A = g->an;
-    const int Bn = std::max(1, g->aprm.band_levels);
+    const int Bn = std::max(1, A.band_levels);
     g->stage_max_piv.assign(A.n_stages, 1);
     for (int s = 0; s < A.n_fronts; s++) { int& m = g->stage_max_piv[A.f_level[s] / Bn]; m = std::max(m, A.f_p[s]); }
     int max_piv = 0;
